@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING the reference (never copying it).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+Two stub modules (gymnasium, fsrl.utils) are injected so ``osrl.algorithms``
+imports.  Inputs come from tests/cases.py (numpy RandomState, so
+tests regenerate them bit-identically).  Gaussian noise is injected by patching
+the samplers the reference calls (torch.randn / randn_like / Normal.rsample /
+Normal.sample) to pop pre-drawn numpy tensors, in the reference's own draw order;
+shapes are asserted, so a wrong order fails loudly.
+
+Each fixture holds: per-step stats, final parameters after ``steps`` steps
+(full tensors for small cases, a strided sample + per-tensor sums for wide ones),
+scalar state (log_alpha / PID), optimizer moments of one tensor per optimizer,
+and ``act()`` outputs on the batch observations.  torch/numpy versions are
+recorded in the file.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from cases import CASES, hyper, make_batch, make_noise, make_params, noise_shapes  # noqa: E402
+
+REF = os.environ.get("OSRL_REFERENCE", "/root/reference")
+
+
+def _install_stubs():
+    g = types.ModuleType("gymnasium")
+    g.Env = object
+    sys.modules["gymnasium"] = g
+    f = types.ModuleType("fsrl")
+    fu = types.ModuleType("fsrl.utils")
+
+    class DummyLogger:
+        def __init__(self, *a, **k):
+            self.rows = []
+            self.cur = {}
+
+        def store(self, tab=None, **kw):
+            self.cur.update(kw)
+
+        def flush(self):
+            self.rows.append(dict(self.cur))
+            self.cur = {}
+
+    fu.DummyLogger = DummyLogger
+    fu.WandbLogger = DummyLogger
+    f.utils = fu
+    sys.modules["fsrl"] = f
+    sys.modules["fsrl.utils"] = fu
+    return DummyLogger
+
+
+class NoiseQueue:
+    """Replaces the reference's Gaussian samplers with a FIFO of numpy draws."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.q = []
+
+    def push_step(self, case, step):
+        nz = make_noise(case, step)
+        for k, shape in noise_shapes(case):
+            self.q.append((k, nz[k]))
+
+    def pop(self, shape):
+        k, v = self.q.pop(0)
+        assert tuple(v.shape) == tuple(shape), (k, v.shape, tuple(shape))
+        return self.torch.from_numpy(v.copy())
+
+    def install(self):
+        torch, q = self.torch, self
+        import torch.distributions.normal as tdn
+
+        torch.randn_like = lambda t, **kw: q.pop(t.shape)
+
+        def randn(*size, **kw):
+            if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+                size = tuple(size[0])
+            return q.pop(size)
+
+        torch.randn = randn
+        tdn._standard_normal = lambda shape, dtype, device: q.pop(shape)
+        # Normal.sample(): torch.normal(loc.expand(shape), scale.expand(shape))
+        torch.normal = lambda mean, std, **kw: mean + std * q.pop(mean.shape)
+
+
+def build(case, torch, algos, Logger):
+    hp = hyper(case)
+    lg = Logger()
+    if case.algo == "bc":
+        m = algos.BC(case.od, case.ad, case.max_action, case.hidden, case.episode_len)
+        tr = algos.BCTrainer(m, None, lg, actor_lr=hp["actor_lr"])
+    elif case.algo == "cpq":
+        m = algos.CPQ(case.od, case.ad, case.max_action, case.hidden, case.hidden, case.vae_hidden,
+                      case.N, hp["gamma"], hp["tau"], hp["beta"], case.num_q, case.num_qc,
+                      hp["qc_scalar"], case.cost_limit, case.episode_len)
+        tr = algos.CPQTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["alpha_lr"], hp["vae_lr"])
+    else:
+        m = algos.BCQL(case.od, case.ad, case.max_action, case.hidden, case.hidden, case.vae_hidden,
+                       case.N, hp["gamma"], hp["tau"], hp["phi"], hp["lmbda"], hp["beta"],
+                       list(hp["PID"]), case.num_q, case.num_qc, case.cost_limit, case.episode_len)
+        tr = algos.BCQLTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["vae_lr"])
+    sd = {k: torch.from_numpy(v.copy()) for k, v in make_params(case).items()}
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m, tr, lg
+
+
+def main():
+    Logger = _install_stubs()
+    sys.path.insert(0, REF)
+    import torch
+    import osrl.algorithms as algos
+
+    torch.set_num_threads(4)
+    nq = NoiseQueue(torch)
+    nq.install()
+    for case in CASES.values():
+        m, tr, lg = build(case, torch, algos, Logger)
+        b = {k: torch.from_numpy(v) for k, v in make_batch(case).items()}
+        out = {}
+        snap_steps = sorted({1, 3, case.steps} & set(range(1, case.steps + 1)))
+        for s in range(case.steps):
+            nq.push_step(case, s)
+            if case.algo == "bc":
+                tr.train_one_step(b["observations"], b["actions"])
+            else:
+                tr.train_one_step(b["observations"], b["next_observations"], b["actions"],
+                                  b["rewards"], b["costs"], b["done"])
+            assert not nq.q, f"{case.name}: {len(nq.q)} noise tensors left unconsumed"
+            lg.flush()
+            if s + 1 in snap_steps:
+                wide = case.name.endswith("_wide") or case.name == "bc_c1"
+                for k, v in m.state_dict().items():
+                    a = v.detach().numpy()
+                    if wide:
+                        out[f"p{s + 1}/sum/{k}"] = np.float64(a.astype(np.float64).sum())
+                        out[f"p{s + 1}/abs/{k}"] = np.float64(np.abs(a.astype(np.float64)).sum())
+                        out[f"p{s + 1}/smp/{k}"] = a.reshape(-1)[::97].copy()
+                    else:
+                        out[f"p{s + 1}/{k}"] = a.copy()
+                if case.algo == "cpq":
+                    out[f"s{s + 1}/log_alpha"] = np.float64(m.log_alpha.item())
+                if case.algo == "bcql":
+                    out[f"s{s + 1}/pid_error_old"] = np.float64(float(m.controller.error_old))
+                    out[f"s{s + 1}/pid_error_integral"] = np.float64(float(m.controller.error_integral))
+        keys = sorted(lg.rows[0].keys())
+        out["stat_keys"] = np.array(keys)
+        out["stats"] = np.array([[r[k] for k in keys] for r in lg.rows], dtype=np.float64)
+        # one Adam moment pair per optimizer (first parameter of each)
+        for oname in ("actor_optim", "critic_optim", "cost_critic_optim", "vae_optim"):
+            opt = getattr(m, oname, None)
+            if opt is None:
+                continue
+            p0 = opt.param_groups[0]["params"][0]
+            st = opt.state[p0]
+            out[f"adam/{oname}/exp_avg"] = st["exp_avg"].numpy().copy()
+            out[f"adam/{oname}/exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+            out[f"adam/{oname}/step"] = np.float64(float(st["step"]))
+        # act() on the batch observations after training
+        with torch.no_grad():
+            if case.algo == "bc":
+                out["act"] = m.actor(b["observations"]).numpy()
+            elif case.algo == "cpq":
+                a, _ = m._actor_forward(b["observations"], True, True)
+                out["act"] = a.numpy()
+            else:
+                z = np.random.RandomState(4000 + case.seed).randn(case.B, 2 * case.ad).astype(np.float32)
+                dec = m.vae.decode(b["observations"], torch.from_numpy(z).clamp(-0.5, 0.5))
+                out["act_z"] = z
+                out["act"] = m.actor(b["observations"], dec).numpy()
+        out["meta"] = np.array([f"torch={torch.__version__}", f"numpy={np.__version__}",
+                                f"case={case}"])
+        path = os.path.join(HERE, case.name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{case.name}: {os.path.getsize(path) / 1024:.1f} KB  stats[0]={dict(zip(keys, out['stats'][0]))}")
+
+
+if __name__ == "__main__":
+    main()

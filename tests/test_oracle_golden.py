@@ -1,0 +1,55 @@
+"""Pin the oracle (oracle/osrl_oracle.py) against vectors captured from the
+reference itself (tests/golden/*.npz, made by tests/golden/make_golden.py).
+
+Gates (SURVEY.md 8c tolerance model): step-1 stats <= 1e-5, <=10-step stats and
+parameters <= 1e-4 (observed ~1e-6)."""
+import numpy as np
+import pytest
+
+from cases import CASES, make_batch
+from oracle_util import build_oracle, load_golden, oracle_step
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_oracle_matches_reference(name, dtype):
+    c = CASES[name]
+    g = load_golden(name)
+    keys = [str(k) for k in g["stat_keys"]]
+    o = build_oracle(c, dtype)
+    for s in range(c.steps):
+        st = oracle_step(o, c, s)
+        ref = dict(zip(keys, g["stats"][s]))
+        tol = 1e-5 if s == 0 else 1e-4
+        for k in keys:
+            assert abs(st[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (name, s, k, st[k], ref[k])
+        if f"s{s + 1}/log_alpha" in g:
+            assert abs(o.log_alpha - float(g[f"s{s + 1}/log_alpha"])) < 1e-6
+        if f"s{s + 1}/pid_error_old" in g:
+            assert abs(o.controller.error_old - float(g[f"s{s + 1}/pid_error_old"])) < 1e-5
+            assert abs(o.controller.error_integral - float(g[f"s{s + 1}/pid_error_integral"])) < 1e-5
+        for k, v in o.p.items():
+            if f"p{s + 1}/{k}" in g:
+                np.testing.assert_allclose(v, g[f"p{s + 1}/{k}"], rtol=0, atol=1e-4, err_msg=f"{name} {k}")
+            elif f"p{s + 1}/smp/{k}" in g:
+                np.testing.assert_allclose(v.reshape(-1)[::97], g[f"p{s + 1}/smp/{k}"], rtol=0, atol=1e-4)
+                assert abs(float(v.astype(np.float64).sum()) - float(g[f"p{s + 1}/sum/{k}"])) < 1e-3
+    # Adam moments of the first tensor of each optimizer
+    for oname, opt in (("actor_optim", getattr(o, "opt_actor", getattr(o, "opt", None))),
+                       ("critic_optim", getattr(o, "opt_critic", None)),
+                       ("cost_critic_optim", getattr(o, "opt_cost", None)),
+                       ("vae_optim", getattr(o, "opt_vae", None))):
+        if opt is None or f"adam/{oname}/exp_avg" not in g:
+            continue
+        m_ref = g[f"adam/{oname}/exp_avg"]
+        k0 = [k for k in opt.keys if opt.m[k].shape == m_ref.shape][0]
+        assert opt.t == int(g[f"adam/{oname}/step"])
+        np.testing.assert_allclose(opt.m[k0], m_ref, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(opt.v[k0], g[f"adam/{oname}/exp_avg_sq"], rtol=0, atol=1e-6)
+    # act()
+    b = make_batch(c)
+    if c.algo == "bcql":
+        a = o.act(b["observations"], g["act_z"])
+    else:
+        a = o.act(b["observations"])
+    np.testing.assert_allclose(a, g["act"], rtol=0, atol=1e-4)
