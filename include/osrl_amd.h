@@ -1,0 +1,199 @@
+/*
+ * osrl_amd.h -- C ABI of libosrl_amd.so: the MI355X (gfx950) kernels behind the
+ * OSRL Trainer.train_one_step() hot path (BC / CPQ / BCQ-Lag).
+ *
+ * The reference (liuzuxin/OSRL) is pure Python on PyTorch aten and has NO FFI seam
+ * (SURVEY.md section 8b); the seam this library fills is "what aten did for the
+ * reference": each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (row-major) unless stated otherwise;
+ *    nn.Linear weights are [out,in] exactly as in the reference state_dict;
+ *  - caller allocates every output and workspace; nothing is allocated or freed here;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), makes no
+ *    host synchronisation and is hipGraph-capturable;
+ *  - return value: 0 on success, otherwise a hipError_t (or -1 for a bad argument);
+ *    nothing throws across the ABI; there is no global mutable state.
+ */
+#ifndef OSRL_AMD_H
+#define OSRL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSRL_MAX_LAYERS 4 /* Linear layers per MLP */
+#define OSRL_MAX_NETS 8   /* ensemble members sharing one input tile */
+#define OSRL_MAX_WIDTH 448 /* widest hidden layer supported by the fused kernels */
+
+enum { OSRL_ACT_ID = 0, OSRL_ACT_RELU = 1, OSRL_ACT_TANH = 2 };
+/* row r of the virtual input maps to source row: r | r % div | r / div
+ * (MOD = torch.tile(obs[None],(N,1,1)) cpq.py:170-174 ; DIV = repeat_interleave bcql.py:138) */
+enum { OSRL_MAP_ID = 0, OSRL_MAP_MOD = 1, OSRL_MAP_DIV = 2 };
+
+/* A stack of n_layers Linear(+activation) layers for n_nets ensemble members:
+ * osrl/common/net.py:12-30 `mlp()`; ensembles net.py:208-287. */
+typedef struct {
+  int32_t n_layers, n_nets;
+  int32_t dims[OSRL_MAX_LAYERS + 1]; /* in, h1, ..., out */
+  int32_t acts[OSRL_MAX_LAYERS];     /* activation after each layer */
+  float out_scale;                   /* net output = out_scale * act(z)  (act_limit of net.py:62,85,339) */
+  int32_t pad_;
+  const float* W[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1], dims[l]] */
+  const float* b[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1]] */
+} osrl_mlp_t;
+
+/* Virtual input matrix [rows, d0+d1] = cat(src0[map0(r)], src1[map1(r)]) -- replaces the
+ * torch.cat / tile / repeat_interleave copies of net.py:232,273,320,337 and cpq.py:170. */
+typedef struct {
+  int32_t rows;
+  int32_t d0, map0, div0;
+  int32_t d1, map1, div1;
+  const float* src0;
+  const float* src1; /* may be NULL when d1 == 0 */
+} osrl_rows_t;
+
+/* Activations written by forward / read by backward.  h[e][l] = post-activation output of
+ * layer l of net e, [rows, dims[l+1]].  h[e][n_layers-1] (the net output) is REQUIRED in
+ * forward; every other pointer may be NULL (= not saved). */
+typedef struct {
+  float* x; /* [rows, dims[0]] the concatenated input (needed by dW of layer 0) */
+  float* h[OSRL_MAX_NETS][OSRL_MAX_LAYERS];
+} osrl_mlp_acts_t;
+
+typedef struct {
+  const float* dy[OSRL_MAX_NETS]; /* [rows, dims[L]] grad wrt the net's (post-activation) output */
+  float* dz[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* out (NULL = skip): grad wrt pre-activation of layer l */
+  float* dx[OSRL_MAX_NETS]; /* out (NULL = skip): [rows, dx_cols] = dX[:, dx_col0 : dx_col0+dx_cols] */
+  int32_t dx_col0, dx_cols;
+} osrl_mlp_grads_t;
+
+/* One weight-gradient GEMM  dW[out,in] = dz^T a,  db[out] = sum_rows dz  (autograd of addmm). */
+typedef struct {
+  const float* dz; /* [rows, out] */
+  const float* a;  /* [rows, in]  */
+  int64_t w_off, b_off; /* float offsets of dW / db inside one gradient slab */
+  int32_t out, in;
+} osrl_dw_entry_t;
+
+/* Device-resident per-step scalars, advanced once per train step by osrl_step_tick(). */
+typedef struct {
+  int64_t step;     /* optimizer step count t (1-based after the first tick) */
+  float bc1;        /* 1 - beta1^t */
+  float bc2_sqrt;   /* sqrt(1 - beta2^t) */
+  float lr_scale;   /* LambdaLR factor min(t/warmup,1) (cdt.py:327-330); 1 when warmup == 0 */
+  float pad_;
+} osrl_step_state_t;
+
+/* ---- fused MLP (mlp.hip): replaces nn.Sequential(Linear,act,...) forward + its autograd ---- */
+/* lds_bytes / tile selection are internal; rows may be any value >= 1. */
+int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, void* stream);
+int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                         const osrl_mlp_grads_t* g, void* stream);
+/* entries/items live in DEVICE memory (static plan): items[i] = {entry, o_tile, i_tile, 0} with
+ * 64x64 tiles; slabs = [n_splits][slab_stride] partial gradients (deterministic split-K over rows). */
+int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
+                         int32_t rows, int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
+
+/* ---- optimizer (optim.hip): torch.optim.Adam/AdamW.step + _soft_update (cpq.py:107-113,232-238) ---- */
+/* Advance the device step state (t += 1, bias corrections, LR-warmup factor).  If stats_cur/ring are
+ * given, first commits the previous step's statistics into ring[((t-1) % ring_len)][n_stats] so that
+ * the host can read logged values lazily instead of .item()-syncing every step. */
+int osrl_step_tick(osrl_step_state_t* st, float beta1, float beta2, int32_t warmup, const float* stats_cur,
+                   float* ring, int32_t n_stats, int32_t ring_len, void* stream);
+/* g = sum_s slabs[s][i] (* *gscale if gscale != NULL); AdamW decay if weight_decay != 0;
+ * then tgt = tau*p + (1-tau)*tgt if tgt != NULL.  n and slab_stride must be multiples of 4. */
+int osrl_adam_step(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,
+                   int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
+                   void* stream);
+/* flat[i] = sum_s slabs[s][i]  (pre-reduction before an RCCL all-reduce in the data-parallel path) */
+int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
+                      void* stream);
+
+/* ---- RNG + replay (rng.hip): torch.randn / TransitionDataset sampling (dataset.py:832-847) ---- */
+/* out[i] ~ N(0,1): Philox4x32-10 keyed by seed, counter = (i/4, st->step, stream_id), Box-Muller. */
+int osrl_randn_fill(float* out, int64_t n, uint64_t seed, uint32_t stream_id, const osrl_step_state_t* st,
+                    void* stream);
+/* idx[b] ~ U{0..n_rows-1} (with replacement) and gather of `n_fields` (<= 8) row-major fp32 tables:
+ * dst[f][b, :width[f]] = src[f][idx[b], :width[f]] * scale[f].  src/dst/width/scale are HOST arrays
+ * of device pointers / ints / floats (copied into the launch). idx_out (device int32[batch]) optional. */
+int osrl_replay_gather(int32_t n_fields, const float* const* src, float* const* dst, const int32_t* width,
+                       const float* scale, int64_t n_rows, int32_t batch, int32_t* idx_out, uint64_t seed,
+                       uint32_t stream_id, const osrl_step_state_t* st, void* stream);
+
+/* ---- glue (glue.hip): the elementwise / reduction tails of the loss functions ----
+ * `rows_global` (0 = rows) is the data-parallel global batch used in every 1/B normalisation.
+ * `stat` pointers are device floats (logged statistics), may be NULL. */
+/* SquashedGaussianMLPActor tail net.py:176-201: head=[rows,2*ad]=(mu|log_std_raw);
+ * u = mu + exp(clamp(ls,-20,2))*eps (eps NULL => deterministic), a = max_action*tanh(u).
+ * Outputs (each may be NULL): a[rows,ad], tanh_u[rows,ad], logp[rows]. */
+int osrl_gauss_head(const float* head, const float* eps, int32_t rows, int32_t ad, float max_action,
+                    float* a, float* tanh_u, float* logp, void* stream);
+/* d head from d a (autograd of the tail above); da_nets = [n_nets][rows,ad] is summed over nets. */
+int osrl_gauss_head_bwd(const float* head, const float* eps, const float* tanh_u, const float* da_nets,
+                        int32_t n_nets, int32_t rows, int32_t ad, float max_action, float* dhead,
+                        void* stream);
+/* pi_dist.sample([N]) cpq.py:166-169: out[j*rows+b,:] = mu[b] + std[b]*eps[j,b,:]  (pre-tanh) */
+int osrl_gauss_ood_sample(const float* head, const float* eps, int32_t n_samples, int32_t rows, int32_t ad,
+                          float* out, void* stream);
+/* VAE latent net.py:323-327: head=[rows,2L]=(mean|log_std_raw) -> z = mean + exp(clamp(ls,-4,15))*eps */
+int osrl_vae_latent(const float* head, const float* eps, int32_t rows, int32_t L, float* z, void* stream);
+/* vae_loss cpq.py:125-129 == bcql.py:122-126: stat = mse(u, act) + beta*KL(head); du = d loss / d u. */
+int osrl_vae_loss(const float* u, const float* act, const float* head, int32_t rows, int32_t ad, int32_t L,
+                  float beta, int32_t rows_global, float* du, float* stat, void* stream);
+/* d head of the VAE latent given dz = d loss / d z from the decoder backward (+ the KL term). */
+int osrl_vae_latent_bwd(const float* head, const float* eps, const float* dz, int32_t rows, int32_t L,
+                        float beta, int32_t rows_global, float* dhead, void* stream);
+/* per-row mean over the latent of the KL term (cpq.py:181-182): kl[r] */
+int osrl_vae_kl_rows(const float* head, int32_t rows, int32_t L, float* kl, void* stream);
+/* torch.quantile(x, q) (linear interpolation) by an exact 4-pass radix select; out[0] = quantile. */
+int osrl_quantile(const float* x, int64_t n, float q, float* out, void* stream);
+
+/* CPQ critic target + loss gradient (cpq.py:145-148, net.py:240-242).
+ * q_old/qc_old/q are [n][rows] net-major outputs. dq[e][rows] = 2(q_e-backup)/B; stat = sum_e mse. */
+int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_old, int32_t n_qc_old,
+                         const float* q, int32_t n_q, const float* rew, const float* done, int32_t rows,
+                         float gamma, float q_thres, int32_t rows_global, float* dq, float* stat, void* stream);
+/* CPQ cost-critic loss (cpq.py:161,181-199): backup = c + gamma*min qc_old; qc_ood from kl >= quantile;
+ * log_alpha (device scalar) updated in place; stat[0] = loss, stat[1] = exp(log_alpha) after update. */
+int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* qc, int32_t n_qc,
+                       const float* qc_sampled, const float* kl, const float* quantile, int32_t n_samples,
+                       const float* cost, int32_t rows, float gamma, float qc_thres, float alpha_lr,
+                       int32_t rows_global, float* log_alpha, float* dq, float* stat, void* stream);
+/* CPQ actor loss (cpq.py:210-212): loss = -mean(1[min qc <= thres] * min q); dq routed to arg-min net. */
+int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_qc, int32_t rows,
+                        float q_thres, int32_t rows_global, float* dq, float* stat, void* stream);
+/* F.mse_loss (bc.py:46-47): stat = mean((u-target)^2) over n elements; du = 2(u-target)/n_global */
+int osrl_mse_loss(const float* u, const float* target, int64_t n, int64_t n_global, float* du, float* stat,
+                  void* stream);
+
+/* in-place clamp: the `.clamp(-0.5, 0.5)` of VAE.decode's latent draw (net.py:334-335) */
+int osrl_clamp(float* x, int64_t n, float lo, float hi, void* stream);
+/* BCQ-Lag perturbation tail net.py:61-62: a = clamp(dec + phi*max_a*t, +-max_a) */
+int osrl_bcq_perturb(const float* dec, const float* t, int32_t rows, int32_t ad, float phi, float max_action,
+                     float* a, void* stream);
+/* d t of the perturbation actor from d a (da_nets [n_nets][rows,ad] summed), through the clamp */
+int osrl_bcq_perturb_bwd(const float* dec, const float* t, const float* da_nets, int32_t n_nets, int32_t rows,
+                         int32_t ad, float phi, float max_action, float* dt, void* stream);
+/* BCQ-Lag target (bcql.py:144-150): q_t[e][rows*N] (first n1 = q1 nets, then n2 = q2 nets), row b*N+j ->
+ * backup[b] = base[b] + gamma*(1-done[b])*max_j(lmbda*min(q1,q2)+(1-lmbda)*max(q1,q2)); then
+ * dq[e][b] = 2*(q_on[e][b]-backup[b])/B, stat = sum_e mse.  done may be NULL (cost critic, bcql.py:172). */
+int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_samples, const float* q_on,
+                         int32_t n_on, const float* base, const float* done, int32_t rows, float gamma,
+                         float lmbda, int32_t rows_global, float* dq, float* stat, void* stream);
+/* BCQ-Lag actor loss (bcql.py:190-198 + PID net.py:376-387).  q/qc = [n1+n2][rows] (q1 nets then q2 nets).
+ * pid = device {error_old, error_integral}; stat: [0]=loss [1]=qc_penalty [2]=multiplier. */
+int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
+                        int32_t rows, float qc_thres, float KP, float KI, float KD, int32_t rows_global,
+                        float* pid, float* dq, float* dqc, float* stat, void* stream);
+
+/* library identity */
+const char* osrl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSRL_AMD_H */

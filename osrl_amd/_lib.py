@@ -1,0 +1,126 @@
+"""ctypes binding of libosrl_amd.so (the C ABI declared in include/osrl_amd.h).
+
+The library is the product path: if it is missing (and cannot be built because
+hipcc is absent) every op raises -- there is no CPU / PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+MAX_LAYERS = 4
+MAX_NETS = 8
+MAX_WIDTH = 448
+MAX_FIELDS = 8
+
+ACT_ID, ACT_RELU, ACT_TANH = 0, 1, 2
+MAP_ID, MAP_MOD, MAP_DIV = 0, 1, 2
+ACT_CODES = {"id": ACT_ID, "identity": ACT_ID, "relu": ACT_RELU, "tanh": ACT_TANH}
+
+_fp = C.c_void_p  # device float*
+
+
+class MlpT(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_nets", C.c_int32),
+                ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
+                ("out_scale", C.c_float), ("pad_", C.c_int32),
+                ("W", (_fp * MAX_LAYERS) * MAX_NETS), ("b", (_fp * MAX_LAYERS) * MAX_NETS)]
+
+
+class RowsT(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("d0", C.c_int32), ("map0", C.c_int32), ("div0", C.c_int32),
+                ("d1", C.c_int32), ("map1", C.c_int32), ("div1", C.c_int32),
+                ("src0", _fp), ("src1", _fp)]
+
+
+class ActsT(C.Structure):
+    _fields_ = [("x", _fp), ("h", (_fp * MAX_LAYERS) * MAX_NETS)]
+
+
+class GradsT(C.Structure):
+    _fields_ = [("dy", _fp * MAX_NETS), ("dz", (_fp * MAX_LAYERS) * MAX_NETS), ("dx", _fp * MAX_NETS),
+                ("dx_col0", C.c_int32), ("dx_cols", C.c_int32)]
+
+
+class DwEntryT(C.Structure):
+    _fields_ = [("dz", _fp), ("a", _fp), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("out", C.c_int32), ("in_", C.c_int32)]
+
+
+class StepStateT(C.Structure):
+    _fields_ = [("step", C.c_int64), ("bc1", C.c_float), ("bc2_sqrt", C.c_float),
+                ("lr_scale", C.c_float), ("pad_", C.c_float)]
+
+
+_i32, _i64, _f32, _u32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_void_p
+_P = C.POINTER
+
+# name -> argtypes  (all return int except osrl_version); must match include/osrl_amd.h
+PROTOTYPES = {
+    "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
+    "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
+    "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
+    "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
+    "osrl_adam_step": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,
+                       _vp, _vp],
+    "osrl_reduce_slabs": [_fp, _fp, _i32, _i64, _i64, _vp],
+    "osrl_randn_fill": [_fp, _i64, _u64, _u32, _vp, _vp],
+    "osrl_replay_gather": [_i32, _P(_fp), _P(_fp), _P(_i32), _P(_f32), _i64, _i32, _vp, _u64, _u32, _vp, _vp],
+    "osrl_gauss_head": [_fp, _fp, _i32, _i32, _f32, _fp, _fp, _fp, _vp],
+    "osrl_gauss_head_bwd": [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _f32, _fp, _vp],
+    "osrl_gauss_ood_sample": [_fp, _fp, _i32, _i32, _i32, _fp, _vp],
+    "osrl_vae_latent": [_fp, _fp, _i32, _i32, _fp, _vp],
+    "osrl_vae_loss": [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _i32, _fp, _fp, _vp],
+    "osrl_vae_latent_bwd": [_fp, _fp, _fp, _i32, _i32, _f32, _i32, _fp, _vp],
+    "osrl_vae_kl_rows": [_fp, _i32, _i32, _fp, _vp],
+    "osrl_quantile": [_fp, _i64, _f32, _fp, _vp],
+    "osrl_cpq_critic_loss": [_fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
+    "osrl_cpq_cost_loss": [_fp, _i32, _fp, _i32, _fp, _fp, _fp, _i32, _fp, _i32, _f32, _f32, _f32, _i32, _fp,
+                           _fp, _fp, _vp],
+    "osrl_cpq_actor_loss": [_fp, _i32, _fp, _i32, _i32, _f32, _i32, _fp, _fp, _vp],
+    "osrl_mse_loss": [_fp, _fp, _i64, _i64, _fp, _fp, _vp],
+    "osrl_clamp": [_fp, _i64, _f32, _f32, _vp],
+    "osrl_bcq_perturb": [_fp, _fp, _i32, _i32, _f32, _f32, _fp, _vp],
+    "osrl_bcq_perturb_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _fp, _vp],
+    "osrl_bcq_critic_loss": [_fp, _i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
+    "osrl_bcq_actor_loss": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _fp, _fp, _fp,
+                            _fp, _vp],
+}
+
+_LIB: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libosrl_amd.so")
+
+
+def load() -> C.CDLL:
+    """Load (building first if the sources are newer and hipcc exists).  Raises if unavailable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    try:
+        from . import build as _build
+        path = _build.build()
+    except Exception as e:  # no hipcc on this machine: use the prebuilt library if present
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"libosrl_amd.so is missing at {path} and could not be built ({e}); "
+                "osrl_amd has no CPU fallback -- build it with `python -m osrl_amd.build`") from e
+    lib = C.CDLL(path)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.osrl_version.restype = C.c_char_p
+    lib.osrl_version.argtypes = []
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc} "
+                           f"({'bad argument' if rc == -1 else 'hipError_t'})")

@@ -1,0 +1,100 @@
+"""Behaviour cloning on MI355X behind the reference's API (osrl/algorithms/bc.py)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..common.logger import DummyLogger, store_stats
+from ..common.net import MLPActor, bind_group, plan_group
+from ..engine.core import FlatGroup, require_cuda
+
+
+class BC(nn.Module):
+    """bc.py:12-64."""
+
+    def __init__(self, state_dim: int, action_dim: int, max_action: float, a_hidden_sizes: list = [128, 128],
+                 episode_len: int = 300, device: str = "cuda"):
+        super().__init__()
+        self.state_dim, self.action_dim, self.max_action = state_dim, action_dim, max_action
+        self.a_hidden_sizes = list(a_hidden_sizes)
+        self.episode_len = episode_len
+        self.device = str(device)
+        dev = require_cuda(device)
+        self.actor = MLPActor(state_dim, action_dim, self.a_hidden_sizes, nn.ReLU, max_action)
+        g = FlatGroup("actor", dev)
+        plan_group(g, "actor", self.actor)
+        g.finalize()
+        bind_group(g, "actor", self.actor)
+        self.groups: Dict[str, FlatGroup] = {"actor": g}
+        self._engine = None
+        self._lrs: Optional[dict] = None
+
+    def _apply(self, fn, *a, **k):
+        raise RuntimeError("osrl_amd models are bound to their HIP device at construction (pass device=)")
+
+    def setup_optimizers(self, actor_lr):
+        self._lrs = dict(actor=actor_lr)
+
+    def engine(self, batch_size: int, **kw):
+        from ..engine.bc import BCEngine
+        if self._engine is None or self._engine.B != batch_size or kw:
+            if self._lrs is None:
+                raise RuntimeError("call setup_optimizers() (or build a BCTrainer) before training")
+            self._engine = BCEngine(self, batch_size, **kw)
+        return self._engine
+
+    @torch.no_grad()
+    def act(self, obs):
+        """bc.py:57-64."""
+        o = torch.as_tensor(np.asarray(obs)[None, ...], dtype=torch.float32, device=self.device)
+        return np.squeeze(self.actor(o).cpu().numpy(), axis=0)
+
+
+class BCTrainer:
+    """bc.py:67-145."""
+
+    def __init__(self, model: BC, env=None, logger=DummyLogger(), actor_lr: float = 1e-4, bc_mode: str = "all",
+                 cost_limit: int = 10, device="cuda", stats_mode: str = "lazy", use_graph: bool = True):
+        self.model, self.logger, self.env, self.device = model, logger, env, device
+        self.bc_mode, self.cost_limit = bc_mode, cost_limit
+        self.stats_mode, self.use_graph = stats_mode, use_graph
+        self.model.setup_optimizers(actor_lr)
+
+    def set_target_cost(self, target_cost):
+        self.cost_limit = target_cost
+
+    def train_one_step(self, observations, actions):
+        eng = self.model.engine(observations.shape[0])
+        eng.step(observations, actions, use_graph=self.use_graph)
+        store_stats(self.logger, eng.st, self.stats_mode)
+
+    def evaluate(self, eval_episodes):
+        self.model.eval()
+        rets, costs, lens = [], [], []
+        for _ in range(eval_episodes):
+            r, l, c = self.rollout()
+            rets.append(r); lens.append(l); costs.append(c)
+        self.model.train()
+        return np.mean(rets), np.mean(costs), np.mean(lens)  # bc.py:123 does not rescale
+
+    @torch.no_grad()
+    def rollout(self):
+        ep_ret, ep_cost, ep_len = 0.0, 0.0, 0
+        obs, info = self.env.reset()
+        if self.bc_mode == "multi-task":
+            obs = np.append(obs, self.cost_limit)
+        for _ in range(self.model.episode_len):
+            act = self.model.act(obs)
+            obs_next, reward, terminated, truncated, info = self.env.step(act)
+            if self.bc_mode == "multi-task":
+                obs_next = np.append(obs_next, self.cost_limit)
+            obs = obs_next
+            ep_ret += reward
+            ep_len += 1
+            ep_cost += info["cost"]
+            if terminated or truncated:
+                break
+        return ep_ret, ep_len, ep_cost

@@ -1,0 +1,257 @@
+"""Network containers with the reference's names and ``state_dict`` layout
+(osrl/common/net.py of liuzuxin/OSRL), re-hosted for MI355X.
+
+These modules hold parameters only -- as VIEWS into flat HBM optimizer groups
+(engine/core.py FlatGroup) -- plus thin ``forward`` methods that call the fused HIP
+MLP through ``osrl_amd.ops`` (a ``torch.autograd.Function`` over libosrl_amd.so).
+There is no aten arithmetic here and no CPU path.
+
+Construction mirrors the reference's module/parameter creation ORDER (nn.Linear default
+init draws from the global torch RNG), so ``torch.manual_seed(s)`` followed by building a
+model yields the same initial weights as the reference under the same seed.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..engine.core import FlatGroup, NetDesc
+
+_ACT_NAME = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Identity: "id"}
+
+
+def mlp(sizes: Sequence[int], activation, output_activation=nn.Identity) -> nn.Sequential:
+    """Linear/activation stack with the reference's Sequential indexing (net.py:12-30):
+    Linear layers sit at even indices, so keys are ``{0,2,4,...}.{weight,bias}``."""
+    mods: List[nn.Module] = []
+    n = len(sizes) - 1
+    for j in range(n):
+        mods.append(nn.Linear(int(sizes[j]), int(sizes[j + 1])))
+        mods.append((activation if j < n - 1 else output_activation)())
+    return nn.Sequential(*mods)
+
+
+def seq_linears(seq: nn.Sequential) -> List[nn.Linear]:
+    return [m for m in seq if isinstance(m, nn.Linear)]
+
+
+def seq_acts(seq: nn.Sequential) -> List[str]:
+    return [_ACT_NAME[type(m)] for m in seq if not isinstance(m, nn.Linear)]
+
+
+class MLPActor(nn.Module):
+    """net.py:65-85: ``act_limit * tanh(mlp(obs))``."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes, activation, act_limit=1):
+        super().__init__()
+        self.pi = mlp([obs_dim] + list(hidden_sizes) + [act_dim], activation, nn.Tanh)
+        self.act_limit = act_limit
+
+    def forward(self, obs):
+        from .. import ops
+        return ops.mlp_apply(net_desc_seq([self.pi], self.act_limit), obs)[0]
+
+
+class MLPGaussianPerturbationActor(nn.Module):
+    """net.py:33-62: ``clamp(act + phi*act_limit*tanh(mlp([obs,act])), +-act_limit)``."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes, activation, phi=0.05, act_limit=1):
+        super().__init__()
+        self.pi = mlp([obs_dim + act_dim] + list(hidden_sizes) + [act_dim], activation, nn.Tanh)
+        self.act_limit = act_limit
+        self.phi = phi
+
+    def forward(self, obs, act):
+        from .. import ops
+        t = ops.mlp_apply(net_desc_seq([self.pi], 1.0), obs, act)[0]
+        return ops.bcq_perturb(act, t, self.phi, self.act_limit)
+
+
+class SquashedGaussianMLPActor(nn.Module):
+    """net.py:152-205: ReLU trunk + mu / log_std heads, tanh-squashed Gaussian."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes, activation):
+        super().__init__()
+        self.net = mlp([obs_dim] + list(hidden_sizes), activation, activation)
+        self.mu_layer = nn.Linear(hidden_sizes[-1], act_dim)
+        self.log_std_layer = nn.Linear(hidden_sizes[-1], act_dim)
+
+    def forward(self, obs, deterministic=False, with_logprob=True, eps=None):
+        """Returns (tanh(u), logp).  ``eps`` = explicit standard-normal noise [rows, act_dim]
+        (drawn on device when omitted and not deterministic)."""
+        from .. import ops
+        head = ops.mlp_apply(actor_head_desc(self), obs)[0]
+        return ops.gauss_head(head, eps, deterministic, with_logprob)
+
+
+class EnsembleQCritic(nn.Module):
+    """net.py:208-242."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes, activation, num_q=2):
+        super().__init__()
+        assert num_q >= 1, "num_q param should be greater than 1"
+        self.q_nets = nn.ModuleList(
+            [mlp([obs_dim + act_dim] + list(hidden_sizes) + [1], nn.ReLU) for _ in range(num_q)])
+
+    def forward(self, obs, act=None):
+        from .. import ops
+        y = ops.mlp_apply(net_desc_seq(list(self.q_nets), 1.0), obs, act)
+        return [y[e, :, 0] for e in range(len(self.q_nets))]
+
+    def predict(self, obs, act):
+        q_list = self.forward(obs, act)
+        return torch.min(torch.vstack(q_list), dim=0).values, q_list
+
+
+class EnsembleDoubleQCritic(nn.Module):
+    """net.py:245-287."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes, activation, num_q=2):
+        super().__init__()
+        assert num_q >= 1, "num_q param should be greater than 1"
+        mk = lambda: mlp([obs_dim + act_dim] + list(hidden_sizes) + [1], nn.ReLU)  # noqa: E731
+        self.q1_nets = nn.ModuleList([mk() for _ in range(num_q)])
+        self.q2_nets = nn.ModuleList([mk() for _ in range(num_q)])
+
+    def all_nets(self) -> List[nn.Sequential]:
+        return list(self.q1_nets) + list(self.q2_nets)
+
+    def forward(self, obs, act):
+        from .. import ops
+        y = ops.mlp_apply(net_desc_seq(self.all_nets(), 1.0), obs, act)
+        n = len(self.q1_nets)
+        return [y[e, :, 0] for e in range(n)], [y[n + e, :, 0] for e in range(n)]
+
+    def predict(self, obs, act):
+        q1, q2 = self.forward(obs, act)
+        return torch.min(torch.vstack(q1), 0).values, torch.min(torch.vstack(q2), 0).values, q1, q2
+
+
+class VAE(nn.Module):
+    """net.py:290-339 (decode_multiple is BEARL-only and out of scope)."""
+
+    def __init__(self, obs_dim, act_dim, hidden_size, latent_dim, act_lim, device="cuda"):
+        super().__init__()
+        self.e1 = nn.Linear(obs_dim + act_dim, hidden_size)
+        self.e2 = nn.Linear(hidden_size, hidden_size)
+        self.mean = nn.Linear(hidden_size, latent_dim)
+        self.log_std = nn.Linear(hidden_size, latent_dim)
+        self.d1 = nn.Linear(obs_dim + latent_dim, hidden_size)
+        self.d2 = nn.Linear(hidden_size, hidden_size)
+        self.d3 = nn.Linear(hidden_size, act_dim)
+        self.act_lim = act_lim
+        self.latent_dim = latent_dim
+        self.device = device
+
+    def decode(self, obs, z=None):
+        from .. import ops
+        if z is None:
+            z = ops.randn((obs.shape[0], self.latent_dim), obs.device).clamp_(-0.5, 0.5)
+        return ops.mlp_apply(vae_dec_desc(self), obs, z)[0]
+
+
+# --------------------------------------------------------------------------- #
+# NetDesc builders (pointers into the modules' CURRENT parameter storage)
+# --------------------------------------------------------------------------- #
+def _wb(lin: nn.Linear) -> Tuple[torch.Tensor, torch.Tensor]:
+    return lin.weight.data, lin.bias.data
+
+
+def net_desc_seq(seqs: Sequence[nn.Sequential], out_scale: float, prefixes: Optional[Sequence[str]] = None
+                 ) -> NetDesc:
+    nets = [[_wb(l) for l in seq_linears(s)] for s in seqs]
+    keys = None
+    if prefixes is not None:
+        keys = [[(f"{p}.{2 * i}.weight", f"{p}.{2 * i}.bias") for i in range(len(n))]
+                for p, n in zip(prefixes, nets)]
+    return NetDesc(nets, seq_acts(seqs[0]), out_scale, keys)
+
+
+def _packed(first: nn.Linear, second: nn.Linear) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[2k, H] weight / [2k] bias spanning two ADJACENT Linear layers (materialize() guarantees it)."""
+    k, H = first.weight.shape
+    w0, w1, b0, b1 = first.weight.data, second.weight.data, first.bias.data, second.bias.data
+    if w1.data_ptr() != w0.data_ptr() + 4 * k * H or b1.data_ptr() != b0.data_ptr() + 4 * k:
+        raise RuntimeError("packed head layers are not adjacent in HBM -- model was not materialize()d")
+    W = torch.as_strided(w0, (2 * k, H), (H, 1))
+    b = torch.as_strided(b0, (2 * k,), (1,))
+    return W, b
+
+
+def actor_head_desc(actor: SquashedGaussianMLPActor, prefix: Optional[str] = None) -> NetDesc:
+    lins = seq_linears(actor.net)
+    nets = [[_wb(l) for l in lins] + [_packed(actor.mu_layer, actor.log_std_layer)]]
+    keys = None
+    if prefix is not None:
+        keys = [[(f"{prefix}.net.{2 * i}.weight", f"{prefix}.net.{2 * i}.bias") for i in range(len(lins))] +
+                [(f"{prefix}.head.weight", f"{prefix}.head.bias")]]
+    return NetDesc(nets, ["relu"] * len(lins) + ["id"], 1.0, keys)
+
+
+def vae_enc_desc(vae: VAE, prefix: Optional[str] = None) -> NetDesc:
+    nets = [[_wb(vae.e1), _wb(vae.e2), _packed(vae.mean, vae.log_std)]]
+    keys = None
+    if prefix is not None:
+        keys = [[(f"{prefix}.e1.weight", f"{prefix}.e1.bias"), (f"{prefix}.e2.weight", f"{prefix}.e2.bias"),
+                 (f"{prefix}.head.weight", f"{prefix}.head.bias")]]
+    return NetDesc(nets, ["relu", "relu", "id"], 1.0, keys)
+
+
+def vae_dec_desc(vae: VAE, prefix: Optional[str] = None) -> NetDesc:
+    nets = [[_wb(vae.d1), _wb(vae.d2), _wb(vae.d3)]]
+    keys = None
+    if prefix is not None:
+        keys = [[(f"{prefix}.{n}.weight", f"{prefix}.{n}.bias") for n in ("d1", "d2", "d3")]]
+    return NetDesc(nets, ["relu", "relu", "tanh"], float(vae.act_lim), keys)
+
+
+# --------------------------------------------------------------------------- #
+# materialisation: move a module's parameters into a FlatGroup (views)
+# --------------------------------------------------------------------------- #
+PACKED_PAIRS = (("mu_layer", "log_std_layer"), ("mean", "log_std"))
+
+
+def plan_group(group: FlatGroup, prefix: str, module: nn.Module) -> None:
+    """Register every parameter of ``module`` (keys ``prefix.<name>``) in ``group``; the
+    (mu|log_std) head pairs are laid out adjacently and aliased as ``<scope>.head.{weight,bias}``."""
+    named: Dict[str, torch.Tensor] = dict(module.named_parameters())
+    done = set()
+    for name, p in named.items():
+        if name in done:
+            continue
+        scope, _, leaf = name.rpartition(".")
+        owner, _, mod = scope.rpartition(".")
+        pair = next((pr for pr in PACKED_PAIRS if mod == pr[0]), None)
+        second = None if pair is None else ((owner + "." if owner else "") + pair[1])
+        if pair is not None and second + ".weight" in named:
+            pfx = prefix + "." + (owner + "." if owner else "")
+            first = (owner + "." if owner else "") + pair[0]
+            w0, w1 = named[first + ".weight"], named[second + ".weight"]
+            group.add(prefix + "." + first + ".weight", w0.shape)
+            group.add(prefix + "." + second + ".weight", w1.shape, align=False)
+            group.add(prefix + "." + first + ".bias", named[first + ".bias"].shape)
+            group.add(prefix + "." + second + ".bias", named[second + ".bias"].shape, align=False)
+            group.alias(pfx + "head.weight", prefix + "." + first + ".weight", (2 * w0.shape[0], w0.shape[1]))
+            group.alias(pfx + "head.bias", prefix + "." + first + ".bias", (2 * w0.shape[0],))
+            done.update({first + ".weight", first + ".bias", second + ".weight", second + ".bias"})
+        else:
+            group.add(prefix + "." + name, p.shape)
+            done.add(name)
+
+
+def bind_group(group: FlatGroup, prefix: str, module: nn.Module, target: Optional[nn.Module] = None) -> None:
+    """Copy ``module``'s (CPU-initialised) parameters into the group and re-point ``.data`` at the
+    flat views; ``target`` (a deepcopy) is bound to the Polyak target buffer the same way."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            v = group.view(prefix + "." + name)
+            v.copy_(p.data)
+            p.data = v
+        if target is not None:
+            for name, p in target.named_parameters():
+                v = group.tgt_view(prefix + "." + name)
+                v.copy_(p.data)
+                p.data = v
+                p.requires_grad_(False)

@@ -1,0 +1,580 @@
+// glue.hip -- the elementwise / reduction tails of the OSRL loss functions for gfx950.
+//
+// Everything between two fused-MLP launches of a train step: distribution heads, Bellman backups,
+// loss values and the loss gradients d(loss)/d(net output) that seed the MLP backward kernels,
+// the CPQ OOD quantile, the log_alpha ascent and the PID-Lagrangian controller.  All scalar state
+// (log_alpha, PID integrators, logged statistics) stays device-resident: no .item() host sync
+// (the reference syncs 5-6 times per step: cpq.py:134,152,198,199,216; bcql.py:131,154,178,205-207).
+//
+// These are latency-bound kernels on [rows, <=16] arrays (rows = batch or N*batch); the
+// batch-global reductions run in ONE 1024-thread workgroup with wavefront shuffles + a 16-entry
+// LDS stage, in a fixed order (deterministic).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/osrl_amd.h"
+
+namespace {
+
+constexpr float kLogStdMin = -20.0f, kLogStdMax = 2.0f;  // net.py:148-149
+constexpr float kVaeLsMin = -4.0f, kVaeLsMax = 15.0f;    // net.py:325
+constexpr int kRed = 1024;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over a 1024-thread block; result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* sm /*>=17 floats*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+    sm[16] = t;
+  }
+  __syncthreads();
+  return sm[16];
+}
+__device__ __forceinline__ float softplus(float x) {  // log(1+exp(x)), F.softplus
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+
+#define GRID_1D(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+// ---------------- squashed Gaussian head ----------------
+__global__ void gauss_head_kernel(const float* __restrict__ head, const float* __restrict__ eps, int rows, int ad,
+                                  float max_a, float* __restrict__ a, float* __restrict__ tanh_u,
+                                  float* __restrict__ logp) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float lp = 0.f;
+  for (int j = 0; j < ad; ++j) {
+    const float mu = head[(size_t)r * 2 * ad + j];
+    const float ls = fminf(fmaxf(head[(size_t)r * 2 * ad + ad + j], kLogStdMin), kLogStdMax);
+    const float sd = expf(ls);
+    const float e = eps ? eps[(size_t)r * ad + j] : 0.f;
+    const float u = mu + sd * e;
+    const float t = tanhf(u);
+    if (a) a[(size_t)r * ad + j] = max_a * t;
+    if (tanh_u) tanh_u[(size_t)r * ad + j] = t;
+    // Normal(mu,sd).log_prob(u) - 2*(log2 - u - softplus(-2u))   (net.py:191-193)
+    lp += -0.5f * e * e - ls - 0.9189385332046727f;
+    lp -= 2.0f * (0.6931471805599453f - u - softplus(-2.0f * u));
+  }
+  if (logp) logp[r] = lp;
+}
+
+__global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
+                                      const float* __restrict__ tanh_u, const float* __restrict__ da_nets,
+                                      int n_nets, int rows, int ad, float max_a, float* __restrict__ dhead) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ad) return;
+  const int r = i / ad, j = i - r * ad;
+  float da = 0.f;
+  for (int e = 0; e < n_nets; ++e) da += da_nets[(size_t)e * rows * ad + i];
+  const float t = tanh_u[i];
+  const float du = da * max_a * (1.0f - t * t);
+  const float lsr = head[(size_t)r * 2 * ad + ad + j];
+  const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
+  const bool inside = lsr >= kLogStdMin && lsr <= kLogStdMax;
+  dhead[(size_t)r * 2 * ad + j] = du;
+  dhead[(size_t)r * 2 * ad + ad + j] = inside ? du * eps[i] * expf(ls) : 0.f;
+}
+
+__global__ void gauss_ood_kernel(const float* __restrict__ head, const float* __restrict__ eps, int n_samples,
+                                 int rows, int ad, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n_samples * rows * ad;
+  if (i >= total) return;
+  const int k = (int)(i % ad);
+  const int b = (int)((i / ad) % rows);
+  const float mu = head[(size_t)b * 2 * ad + k];
+  const float ls = fminf(fmaxf(head[(size_t)b * 2 * ad + ad + k], kLogStdMin), kLogStdMax);
+  out[i] = mu + expf(ls) * eps[i];
+}
+
+// ---------------- VAE tails ----------------
+__global__ void vae_latent_kernel(const float* __restrict__ head, const float* __restrict__ eps, int rows, int L,
+                                  float* __restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * L) return;
+  const int r = i / L, k = i - r * L;
+  const float mean = head[(size_t)r * 2 * L + k];
+  const float ls = fminf(fmaxf(head[(size_t)r * 2 * L + L + k], kVaeLsMin), kVaeLsMax);
+  z[i] = mean + expf(ls) * eps[i];
+}
+
+__device__ __forceinline__ float kl_elem(float mean, float ls_raw) {
+  const float sd = expf(fminf(fmaxf(ls_raw, kVaeLsMin), kVaeLsMax));
+  return -0.5f * (1.0f + logf(sd * sd) - mean * mean - sd * sd);
+}
+
+__global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict__ u, const float* __restrict__ act,
+                                                        const float* __restrict__ head, int rows, int ad, int L,
+                                                        float beta, float inv_rows, float* __restrict__ du,
+                                                        float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float rec = 0.f, kl = 0.f;
+  const float ia = inv_rows / (float)ad, il = inv_rows / (float)L;
+  for (int i = threadIdx.x; i < rows * ad; i += kRed) {
+    const float d = u[i] - act[i];
+    rec += d * d;
+    du[i] = 2.0f * d * ia;
+  }
+  for (int i = threadIdx.x; i < rows * L; i += kRed) {
+    const int r = i / L, k = i - r * L;
+    kl += kl_elem(head[(size_t)r * 2 * L + k], head[(size_t)r * 2 * L + L + k]);
+  }
+  rec = block_sum(rec, sm);
+  kl = block_sum(kl, sm);
+  if (threadIdx.x == 0 && stat) stat[0] = rec * ia + beta * (kl * il);
+}
+
+__global__ void vae_latent_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
+                                      const float* __restrict__ dz, int rows, int L, float beta, float inv_rows,
+                                      float* __restrict__ dhead) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * L) return;
+  const int r = i / L, k = i - r * L;
+  const float mean = head[(size_t)r * 2 * L + k];
+  const float lsr = head[(size_t)r * 2 * L + L + k];
+  const float sd = expf(fminf(fmaxf(lsr, kVaeLsMin), kVaeLsMax));
+  const float c = beta * inv_rows / (float)L;
+  const float g = dz[i];
+  dhead[(size_t)r * 2 * L + k] = g + c * mean;
+  const bool inside = lsr >= kVaeLsMin && lsr <= kVaeLsMax;
+  dhead[(size_t)r * 2 * L + L + k] = inside ? (g * eps[i] + c * (sd - 1.0f / sd)) * sd : 0.f;
+}
+
+__global__ void vae_kl_rows_kernel(const float* __restrict__ head, int rows, int L, float* __restrict__ kl) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int k = 0; k < L; ++k) s += kl_elem(head[(size_t)r * 2 * L + k], head[(size_t)r * 2 * L + L + k]);
+  kl[r] = s / (float)L;
+}
+
+// ---------------- exact quantile: 4-pass 8-bit radix select in one workgroup ----------------
+__device__ __forceinline__ uint32_t f2key(float f) {  // order-preserving float -> uint
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// k-th smallest (0-based) key among x[0..n); every thread returns it.  hist: 256 uints in LDS.
+__device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t k, uint32_t* hist,
+                                 uint32_t* bc /*2 uints*/) {
+  uint32_t prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t key = f2key(x[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t kk = k;
+      uint32_t d = 0;
+      for (; d < 256; ++d) {
+        const uint32_t c = hist[d];
+        if (kk < (int64_t)c) break;
+        kk -= c;
+      }
+      bc[0] = d;
+      bc[1] = (uint32_t)kk;
+    }
+    __syncthreads();
+    prefix |= bc[0] << shift;
+    mask |= 255u << shift;
+    k = bc[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict__ x, int64_t n, float q,
+                                                        float* __restrict__ out) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t bc[2];
+  // torch.quantile 'linear': pos = q*(n-1); lo=floor(pos); result = x_lo + (x_hi-x_lo)*(pos-lo)
+  const double pos = (double)q * (double)(n - 1);
+  const int64_t lo = (int64_t)floor(pos);
+  const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
+  const float w = (float)(pos - (double)lo);
+  const float vlo = key2f(radix_select(x, n, lo, hist, bc));
+  const float vhi = hi == lo ? vlo : key2f(radix_select(x, n, hi, hist, bc));
+  if (threadIdx.x == 0) out[0] = vlo + (vhi - vlo) * w;
+}
+
+// ---------------- CPQ ----------------
+__device__ __forceinline__ float min_over(const float* __restrict__ q, int n, int stride, int i) {
+  float v = q[i];
+  for (int e = 1; e < n; ++e) v = fminf(v, q[(size_t)e * stride + i]);
+  return v;
+}
+
+__global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __restrict__ q_old, int n_q_old,
+                                                               const float* __restrict__ qc_old, int n_qc_old,
+                                                               const float* __restrict__ q, int n_q,
+                                                               const float* __restrict__ rew,
+                                                               const float* __restrict__ done, int rows,
+                                                               float gamma, float q_thres, float inv_rows,
+                                                               float* __restrict__ dq, float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float loss = 0.f;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    const float qt = min_over(q_old, n_q_old, rows, b);
+    const float qct = min_over(qc_old, n_qc_old, rows, b);
+    // backup = r + gamma*(1-done)*(qc_targ<=q_thres)*q_targ      cpq.py:145-146
+    const float backup = rew[b] + gamma * (1.0f - done[b]) * (qct <= q_thres ? 1.0f : 0.0f) * qt;
+    for (int e = 0; e < n_q; ++e) {
+      const float d = q[(size_t)e * rows + b] - backup;
+      loss += d * d;
+      dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+    }
+  }
+  loss = block_sum(loss, sm);
+  if (threadIdx.x == 0 && stat) stat[0] = loss * inv_rows;
+}
+
+__global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
+    const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
+    const float* __restrict__ qc_sampled, const float* __restrict__ kl, const float* __restrict__ quantile,
+    int n_samples, const float* __restrict__ cost, int rows, float gamma, float qc_thres, float alpha_lr,
+    float inv_rows, float* __restrict__ log_alpha, float* __restrict__ dq, float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float loss = 0.f, ood = 0.f;
+  const float quant = quantile[0];
+  const int nr = n_samples * rows;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    const float backup = cost[b] + gamma * min_over(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
+    for (int e = 0; e < n_qc; ++e) {
+      const float d = qc[(size_t)e * rows + b] - backup;
+      loss += d * d;
+      dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+    }
+    float s = 0.f;  // qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184
+    for (int j = 0; j < n_samples; ++j) {
+      const int i = j * rows + b;
+      if (kl[i] >= quant) s += min_over(qc_sampled, n_qc_old, nr, i);
+    }
+    ood += s / (float)n_samples;
+  }
+  loss = block_sum(loss, sm);
+  ood = block_sum(ood, sm);
+  if (threadIdx.x == 0) {
+    const float ood_mean = ood * inv_rows;
+    float la = log_alpha[0];
+    const float ea = expf(la);
+    if (stat) stat[0] = loss * inv_rows - ea * (ood_mean - qc_thres);  // cpq.py:186-187
+    la += alpha_lr * ea * (qc_thres - ood_mean);                      // cpq.py:193-194
+    la = fminf(fmaxf(la, -5.0f), 5.0f);
+    log_alpha[0] = la;
+    if (stat) stat[1] = expf(la);
+  }
+}
+
+__global__ __launch_bounds__(kRed) void cpq_actor_loss_kernel(const float* __restrict__ q, int n_q,
+                                                              const float* __restrict__ qc, int n_qc, int rows,
+                                                              float q_thres, float inv_rows,
+                                                              float* __restrict__ dq, float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float loss = 0.f;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    int am = 0;
+    float qm = q[b];
+    for (int e = 1; e < n_q; ++e) {
+      const float v = q[(size_t)e * rows + b];
+      if (v < qm) { qm = v; am = e; }
+    }
+    const float mask = min_over(qc, n_qc, rows, b) <= q_thres ? 1.0f : 0.0f;
+    loss -= mask * qm;
+    for (int e = 0; e < n_q; ++e) dq[(size_t)e * rows + b] = e == am ? -mask * inv_rows : 0.f;
+  }
+  loss = block_sum(loss, sm);
+  if (threadIdx.x == 0 && stat) stat[0] = loss * inv_rows;
+}
+
+__global__ __launch_bounds__(kRed) void mse_loss_kernel(const float* __restrict__ u, const float* __restrict__ act,
+                                                        int n, float inv_n, float* __restrict__ du,
+                                                        float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float loss = 0.f;
+  for (int i = threadIdx.x; i < n; i += kRed) {
+    const float d = u[i] - act[i];
+    loss += d * d;
+    du[i] = 2.0f * d * inv_n;
+  }
+  loss = block_sum(loss, sm);
+  if (threadIdx.x == 0 && stat) stat[0] = loss * inv_n;
+}
+
+// ---------------- BCQ-Lag ----------------
+__global__ void clamp_kernel(float* __restrict__ x, int64_t n, float lo, float hi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+__global__ void bcq_perturb_kernel(const float* __restrict__ dec, const float* __restrict__ t, int n, float phi,
+                                   float max_a, float* __restrict__ a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  a[i] = fminf(fmaxf(dec[i] + phi * max_a * t[i], -max_a), max_a);  // net.py:61-62
+}
+
+__global__ void bcq_perturb_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ t,
+                                       const float* __restrict__ da_nets, int n_nets, int n, float phi, float max_a,
+                                       float* __restrict__ dt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float da = 0.f;
+  for (int e = 0; e < n_nets; ++e) da += da_nets[(size_t)e * n + i];
+  const float pre = dec[i] + phi * max_a * t[i];
+  dt[i] = (pre >= -max_a && pre <= max_a) ? da * phi * max_a : 0.f;
+}
+
+__global__ __launch_bounds__(kRed) void bcq_critic_loss_kernel(const float* __restrict__ q_t, int n1, int n2,
+                                                               int n_samples, const float* __restrict__ q_on,
+                                                               int n_on, const float* __restrict__ base,
+                                                               const float* __restrict__ done, int rows,
+                                                               float gamma, float lmbda, float inv_rows,
+                                                               float* __restrict__ dq, float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float loss = 0.f;
+  const int nr = rows * n_samples;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    float best = -INFINITY;
+    for (int j = 0; j < n_samples; ++j) {
+      const int i = b * n_samples + j;  // repeat_interleave order, bcql.py:138,146
+      const float q1 = min_over(q_t, n1, nr, i);
+      const float q2 = min_over(q_t + (size_t)n1 * nr, n2, nr, i);
+      const float v = lmbda * fminf(q1, q2) + (1.0f - lmbda) * fmaxf(q1, q2);
+      best = fmaxf(best, v);
+    }
+    const float nd = done ? (1.0f - done[b]) : 1.0f;
+    const float backup = base[b] + gamma * nd * best;
+    for (int e = 0; e < n_on; ++e) {
+      const float d = q_on[(size_t)e * rows + b] - backup;
+      loss += d * d;
+      dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+    }
+  }
+  loss = block_sum(loss, sm);
+  if (threadIdx.x == 0 && stat) stat[0] = loss * inv_rows;
+}
+
+// min over the q1 group, min over the q2 group, then the binary min with torch's tie rule
+__device__ __forceinline__ float minmin(const float* __restrict__ q, int n1, int n2, int rows, int b, int* i1,
+                                        int* i2, float* w1) {
+  int a1 = 0, a2 = 0;
+  float m1 = q[b], m2 = q[(size_t)n1 * rows + b];
+  for (int e = 1; e < n1; ++e) {
+    const float v = q[(size_t)e * rows + b];
+    if (v < m1) { m1 = v; a1 = e; }
+  }
+  for (int e = 1; e < n2; ++e) {
+    const float v = q[(size_t)(n1 + e) * rows + b];
+    if (v < m2) { m2 = v; a2 = e; }
+  }
+  *i1 = a1;
+  *i2 = a2;
+  *w1 = m1 < m2 ? 1.0f : (m1 == m2 ? 0.5f : 0.0f);
+  return fminf(m1, m2);
+}
+
+__global__ __launch_bounds__(kRed) void bcq_actor_loss_kernel(const float* __restrict__ q, int nq1, int nq2,
+                                                              const float* __restrict__ qc, int nc1, int nc2,
+                                                              int rows, float qc_thres, float KP, float KI, float KD,
+                                                              float inv_rows, float* __restrict__ pid,
+                                                              float* __restrict__ dq, float* __restrict__ dqc,
+                                                              float* __restrict__ stat) {
+  __shared__ float sm[20];
+  __shared__ float s_mult;
+  float sq = 0.f, sqc = 0.f;
+  int i1, i2;
+  float w1;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    sq += minmin(q, nq1, nq2, rows, b, &i1, &i2, &w1);
+    sqc += minmin(qc, nc1, nc2, rows, b, &i1, &i2, &w1);
+  }
+  sq = block_sum(sq, sm);
+  sqc = block_sum(sqc, sm);
+  if (threadIdx.x == 0) {
+    // LagrangianPIDController.control  net.py:376-387
+    const float e_new = sqc * inv_rows - qc_thres;
+    const float e_old = pid[0], integ = pid[1];
+    const float diff = fmaxf(e_new - e_old, 0.f);
+    const float integ_new = fmaxf(integ + e_new, 0.f);
+    pid[0] = e_new;
+    pid[1] = integ_new;
+    const float mult = fmaxf(KP * fmaxf(e_new, 0.f) + KI * integ_new + KD * diff, 0.f);
+    s_mult = mult;
+    const float penalty = (sqc * inv_rows - qc_thres) * mult;  // mean((qc_pi - thres)*mult)
+    if (stat) {
+      stat[0] = -sq * inv_rows + penalty;
+      stat[1] = penalty;
+      stat[2] = mult;
+    }
+  }
+  __syncthreads();
+  const float mult = s_mult;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    minmin(q, nq1, nq2, rows, b, &i1, &i2, &w1);
+    for (int e = 0; e < nq1; ++e) dq[(size_t)e * rows + b] = e == i1 ? -w1 * inv_rows : 0.f;
+    for (int e = 0; e < nq2; ++e) dq[(size_t)(nq1 + e) * rows + b] = e == i2 ? -(1.0f - w1) * inv_rows : 0.f;
+    minmin(qc, nc1, nc2, rows, b, &i1, &i2, &w1);
+    for (int e = 0; e < nc1; ++e) dqc[(size_t)e * rows + b] = e == i1 ? w1 * mult * inv_rows : 0.f;
+    for (int e = 0; e < nc2; ++e) dqc[(size_t)(nc1 + e) * rows + b] = e == i2 ? (1.0f - w1) * mult * inv_rows : 0.f;
+  }
+}
+
+#define S ((hipStream_t)stream)
+#define LAUNCH_CHECK() return (int)hipGetLastError()
+
+}  // namespace
+
+extern "C" {
+
+int osrl_gauss_head(const float* head, const float* eps, int32_t rows, int32_t ad, float max_action, float* a,
+                    float* tanh_u, float* logp, void* stream) {
+  if (!head || rows < 1 || ad < 1) return -1;
+  hipLaunchKernelGGL(gauss_head_kernel, GRID_1D(rows), 0, S, head, eps, rows, ad, max_action, a, tanh_u, logp);
+  LAUNCH_CHECK();
+}
+
+int osrl_gauss_head_bwd(const float* head, const float* eps, const float* tanh_u, const float* da_nets,
+                        int32_t n_nets, int32_t rows, int32_t ad, float max_action, float* dhead, void* stream) {
+  if (!head || !eps || !tanh_u || !da_nets || !dhead || rows < 1 || ad < 1 || n_nets < 1) return -1;
+  hipLaunchKernelGGL(gauss_head_bwd_kernel, GRID_1D(rows * ad), 0, S, head, eps, tanh_u, da_nets, n_nets, rows, ad,
+                     max_action, dhead);
+  LAUNCH_CHECK();
+}
+
+int osrl_gauss_ood_sample(const float* head, const float* eps, int32_t n_samples, int32_t rows, int32_t ad,
+                          float* out, void* stream) {
+  if (!head || !eps || !out || n_samples < 1 || rows < 1 || ad < 1) return -1;
+  const int64_t n = (int64_t)n_samples * rows * ad;
+  hipLaunchKernelGGL(gauss_ood_kernel, GRID_1D(n), 0, S, head, eps, n_samples, rows, ad, out);
+  LAUNCH_CHECK();
+}
+
+int osrl_vae_latent(const float* head, const float* eps, int32_t rows, int32_t L, float* z, void* stream) {
+  if (!head || !eps || !z || rows < 1 || L < 1) return -1;
+  hipLaunchKernelGGL(vae_latent_kernel, GRID_1D(rows * L), 0, S, head, eps, rows, L, z);
+  LAUNCH_CHECK();
+}
+
+int osrl_vae_loss(const float* u, const float* act, const float* head, int32_t rows, int32_t ad, int32_t L,
+                  float beta, int32_t rows_global, float* du, float* stat, void* stream) {
+  if (!u || !act || !head || !du || rows < 1) return -1;
+  hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(kRed), 0, S, u, act, head, rows, ad, L, beta,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), du, stat);
+  LAUNCH_CHECK();
+}
+
+int osrl_vae_latent_bwd(const float* head, const float* eps, const float* dz, int32_t rows, int32_t L, float beta,
+                        int32_t rows_global, float* dhead, void* stream) {
+  if (!head || !eps || !dz || !dhead || rows < 1) return -1;
+  hipLaunchKernelGGL(vae_latent_bwd_kernel, GRID_1D(rows * L), 0, S, head, eps, dz, rows, L, beta,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), dhead);
+  LAUNCH_CHECK();
+}
+
+int osrl_vae_kl_rows(const float* head, int32_t rows, int32_t L, float* kl, void* stream) {
+  if (!head || !kl || rows < 1 || L < 1) return -1;
+  hipLaunchKernelGGL(vae_kl_rows_kernel, GRID_1D(rows), 0, S, head, rows, L, kl);
+  LAUNCH_CHECK();
+}
+
+int osrl_quantile(const float* x, int64_t n, float q, float* out, void* stream) {
+  if (!x || !out || n < 1 || q < 0.f || q > 1.f) return -1;
+  hipLaunchKernelGGL(quantile_kernel, dim3(1), dim3(kRed), 0, S, x, n, q, out);
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_old, int32_t n_qc_old,
+                         const float* q, int32_t n_q, const float* rew, const float* done, int32_t rows,
+                         float gamma, float q_thres, int32_t rows_global, float* dq, float* stat, void* stream) {
+  if (!q_old || !qc_old || !q || !rew || !done || !dq || rows < 1) return -1;
+  hipLaunchKernelGGL(cpq_critic_loss_kernel, dim3(1), dim3(kRed), 0, S, q_old, n_q_old, qc_old, n_qc_old, q, n_q,
+                     rew, done, rows, gamma, q_thres, 1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* qc, int32_t n_qc,
+                       const float* qc_sampled, const float* kl, const float* quantile, int32_t n_samples,
+                       const float* cost, int32_t rows, float gamma, float qc_thres, float alpha_lr,
+                       int32_t rows_global, float* log_alpha, float* dq, float* stat, void* stream) {
+  if (!qc_old_next || !qc || !qc_sampled || !kl || !quantile || !cost || !log_alpha || !dq || rows < 1) return -1;
+  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc, qc_sampled,
+                     kl, quantile, n_samples, cost, rows, gamma, qc_thres, alpha_lr,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), log_alpha, dq, stat);
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_qc, int32_t rows, float q_thres,
+                        int32_t rows_global, float* dq, float* stat, void* stream) {
+  if (!q || !qc || !dq || rows < 1) return -1;
+  hipLaunchKernelGGL(cpq_actor_loss_kernel, dim3(1), dim3(kRed), 0, S, q, n_q, qc, n_qc, rows, q_thres,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
+  LAUNCH_CHECK();
+}
+
+int osrl_mse_loss(const float* u, const float* target, int64_t n, int64_t n_global, float* du, float* stat,
+                  void* stream) {
+  if (!u || !target || !du || n < 1) return -1;
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(kRed), 0, S, u, target, (int)n,
+                     1.0f / (float)(n_global > 0 ? n_global : n), du, stat);
+  LAUNCH_CHECK();
+}
+
+int osrl_clamp(float* x, int64_t n, float lo, float hi, void* stream) {
+  if (!x || n < 1) return -1;
+  hipLaunchKernelGGL(clamp_kernel, GRID_1D(n), 0, S, x, n, lo, hi);
+  LAUNCH_CHECK();
+}
+
+int osrl_bcq_perturb(const float* dec, const float* t, int32_t rows, int32_t ad, float phi, float max_action,
+                     float* a, void* stream) {
+  if (!dec || !t || !a || rows < 1 || ad < 1) return -1;
+  hipLaunchKernelGGL(bcq_perturb_kernel, GRID_1D((int64_t)rows * ad), 0, S, dec, t, rows * ad, phi, max_action, a);
+  LAUNCH_CHECK();
+}
+
+int osrl_bcq_perturb_bwd(const float* dec, const float* t, const float* da_nets, int32_t n_nets, int32_t rows,
+                         int32_t ad, float phi, float max_action, float* dt, void* stream) {
+  if (!dec || !t || !da_nets || !dt || rows < 1 || ad < 1 || n_nets < 1) return -1;
+  hipLaunchKernelGGL(bcq_perturb_bwd_kernel, GRID_1D((int64_t)rows * ad), 0, S, dec, t, da_nets, n_nets, rows * ad,
+                     phi, max_action, dt);
+  LAUNCH_CHECK();
+}
+
+int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_samples, const float* q_on,
+                         int32_t n_on, const float* base, const float* done, int32_t rows, float gamma,
+                         float lmbda, int32_t rows_global, float* dq, float* stat, void* stream) {
+  if (!q_t || !q_on || !base || !dq || rows < 1 || n1 < 1 || n2 < 1 || n_samples < 1) return -1;
+  hipLaunchKernelGGL(bcq_critic_loss_kernel, dim3(1), dim3(kRed), 0, S, q_t, n1, n2, n_samples, q_on, n_on, base,
+                     done, rows, gamma, lmbda, 1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
+  LAUNCH_CHECK();
+}
+
+int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
+                        int32_t rows, float qc_thres, float KP, float KI, float KD, int32_t rows_global,
+                        float* pid, float* dq, float* dqc, float* stat, void* stream) {
+  if (!q || !qc || !pid || !dq || !dqc || rows < 1) return -1;
+  hipLaunchKernelGGL(bcq_actor_loss_kernel, dim3(1), dim3(kRed), 0, S, q, nq1, nq2, qc, nc1, nc2, rows, qc_thres,
+                     KP, KI, KD, 1.0f / (float)(rows_global > 0 ? rows_global : rows), pid, dq, dqc, stat);
+  LAUNCH_CHECK();
+}
+
+const char* osrl_version(void) { return "osrl_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,527 @@
+// mlp.hip -- fused multi-layer-perceptron forward / backward for gfx950 (MI355X, CDNA4).
+//
+// Replaces, for the OSRL hot path, every `nn.Sequential(Linear, act, ...)` forward and its
+// autograd (osrl/common/net.py:12-30 mlp(); users: MLPActor :65-85, SquashedGaussianMLPActor
+// :152-205 trunk+heads, EnsembleQCritic :208-242, EnsembleDoubleQCritic :245-287, VAE :290-339,
+// MLPGaussianPerturbationActor :33-62).
+//
+// Design (fp32 everywhere: the parity budget is 1e-4 -> only v_mfma_f32_16x16x4_f32, which is an
+// exact k-ordered fmaf chain, see /opt/skills/guides/cdna_hip_programming.md section 3):
+//   * one workgroup = 4 wave64 = one tile of BM = 16*NRB rows of ONE ensemble member;
+//   * the row tile's activations live in ONE LDS buffer [BM][lda] that every layer overwrites in
+//     place (k-loop reads it -> barrier -> epilogue writes the next layer's activations);
+//   * wave w owns a contiguous group of 16-wide output-column blocks and ALL NRB row blocks, so
+//     the A fragments (activations, ds_read_b128) are shared by the 4 waves through LDS while each
+//     weight element is fetched by exactly one wave, straight from L2 into its B fragment;
+//   * k-slot trick: MFMA 16x16x4 sums over 4 k-slots; slot kq of the t-th MFMA is mapped to
+//     k = k0 + 4*kq + t, so ONE 16-byte load per lane (A: ds_read_b128, B: global_load_dwordx4 of
+//     4 consecutive k of a weight row) feeds 4 MFMAs.  Per 16-deep k step a wave issues
+//     NRB + NCB wide loads for 4*NRB*NCB MFMAs (8 loads : 64 MFMAs at NRB=NCB=4);
+//   * lda = round16(max width) + 8 floats => (lda/4) mod 16 is 2 mod 4, which makes the
+//     ds_read_b128 A-fragment pattern (16 rows x 4 k-quads per wave) bank-conflict free for the
+//     four 16-lane service groups of ds_read_b128 (MI355X_MICROARCH.md LDS table).
+//   * backward-dz walks the same structure with the transposed weight access; backward-dw is a
+//     split-K (over rows) MFMA GEMM dW = dZ^T A writing per-split slabs that the Adam kernel sums
+//     in a fixed order (deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/osrl_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  if (act == OSRL_ACT_RELU) return fmaxf(x, 0.0f);
+  if (act == OSRL_ACT_TANH) return tanhf(x);
+  return x;
+}
+// derivative expressed with the activation OUTPUT y (relu: threshold_backward on the output)
+__device__ __forceinline__ float act_bwd(int act, float y) {
+  if (act == OSRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == OSRL_ACT_TANH) return 1.0f - y * y;
+  return 1.0f;
+}
+__device__ __forceinline__ int map_row(int r, int map, int div) {
+  if (map == OSRL_MAP_MOD) return r % div;
+  if (map == OSRL_MAP_DIV) return r / div;
+  return r;
+}
+__device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
+
+// B fragment for 4 consecutive k of output column n.
+//  BT == false : B[k][n] = W[n*ldw + k]   (forward:  W is [N,K] row-major)
+//  BT == true  : B[k][n] = W[k*ldw + n]   (backward: W is [K,N] row-major)
+template <bool BT>
+__device__ __forceinline__ f32x4 load_b4(const float* __restrict__ W, int K, int N, int ldw, int n, int k,
+                                         bool vec_ok) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    if (!BT) {
+      const float* p = W + (size_t)n * ldw + k;
+      if (vec_ok && k + 3 < K) {
+        v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+        if (k + 0 < K) v[0] = p[0];
+        if (k + 1 < K) v[1] = p[1];
+        if (k + 2 < K) v[2] = p[2];
+        if (k + 3 < K) v[3] = p[3];
+      }
+    } else {
+      const float* p = W + (size_t)k * ldw + n;
+      if (k + 0 < K) v[0] = p[0];
+      if (k + 1 < K) v[1] = p[(size_t)ldw];
+      if (k + 2 < K) v[2] = p[2 * (size_t)ldw];
+      if (k + 3 < K) v[3] = p[3 * (size_t)ldw];
+    }
+  }
+  return v;
+}
+
+// acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols (cb0+c)*16..)   over k in [0,Kp)
+template <int NRB, int NCB, bool BT>
+__device__ __forceinline__ void layer_mm(const float* lds, int lda, int Kp, const float* __restrict__ W, int K,
+                                         int N, int ldw, int cb0, int cnt, f32x4 (&acc)[NRB][NCB]) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* arow = lds + m * lda + 4 * kq;
+  const bool vec_ok = (!BT) && ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  f32x4 a[NRB], b[NCB];
+
+  for (int k0 = 0; k0 < Kp; k0 += 16) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0);
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+      if (c < cnt) b[c] = load_b4<BT>(W, K, N, ldw, (cb0 + c) * 16 + m, k0 + 4 * kq, vec_ok);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        if (c < cnt) {
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb)
+            acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][t], b[c][t], acc[rb][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int NRB, int NCB>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRB][NCB]) {
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// copy the LDS tile [BM][N] (stride lda) to global dst[(row0+r)*N + c]
+__device__ __forceinline__ void tile_to_global(const float* lds, int lda, int BM, int N, float* __restrict__ dst,
+                                               int row0, int rows) {
+  const int tid = threadIdx.x;
+  if ((N & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    const int n4 = N >> 2;
+    for (int idx = tid; idx < BM * n4; idx += 256) {
+      const int r = idx / n4, c4 = idx - r * n4;
+      if (row0 + r < rows)
+        *reinterpret_cast<f32x4*>(dst + (size_t)(row0 + r) * N + 4 * c4) =
+            *reinterpret_cast<const f32x4*>(lds + r * lda + 4 * c4);
+    }
+  } else {
+    for (int idx = tid; idx < BM * N; idx += 256) {
+      const int r = idx / N, c = idx - r * N;
+      if (row0 + r < rows) dst[(size_t)(row0 + r) * N + c] = lds[r * lda + c];
+    }
+  }
+}
+
+struct FwdArgs {
+  osrl_mlp_t net;
+  osrl_rows_t in;
+  osrl_mlp_acts_t out;
+  int32_t lda;
+};
+
+template <int NRB, int NCB>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 16 * NRB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e = blockIdx.y;
+  const int row0 = blockIdx.x * BM;
+  const int rows = a.in.rows, lda = a.lda;
+  const int L = a.net.n_layers;
+
+  {  // stage cat(src0[map0(r)], src1[map1(r)]) zero-padded to a multiple of 16 columns
+    const int K0 = a.net.dims[0], K0p = round16(K0);
+    const int d0 = a.in.d0, d1 = a.in.d1;
+    for (int idx = tid; idx < BM * K0p; idx += 256) {
+      const int r = idx / K0p, c = idx - r * K0p;
+      const int gr = row0 + r;
+      float v = 0.f;
+      if (gr < rows) {
+        if (c < d0)
+          v = a.in.src0[(size_t)map_row(gr, a.in.map0, a.in.div0) * d0 + c];
+        else if (c < d0 + d1)
+          v = a.in.src1[(size_t)map_row(gr, a.in.map1, a.in.div1) * d1 + (c - d0)];
+      }
+      lds[r * lda + c] = v;
+    }
+    __syncthreads();
+    if (e == 0 && a.out.x) tile_to_global(lds, lda, BM, K0, a.out.x, row0, rows);
+  }
+
+  for (int l = 0; l < L; ++l) {
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    const int nblk = (N + 15) >> 4, cpw = (nblk + 3) >> 2;
+    const int cb0 = wave * cpw;
+    int cnt = nblk - cb0;
+    cnt = cnt > cpw ? cpw : cnt;  // may be <= 0 for idle waves
+    f32x4 acc[NRB][NCB];
+    zero_acc<NRB, NCB>(acc);
+    if (cnt > 0) layer_mm<NRB, NCB, false>(lds, lda, round16(K), a.net.W[e][l], K, N, K, cb0, cnt, acc);
+    __syncthreads();  // every wave finished reading the previous activations
+    const float* __restrict__ bias = a.net.b[e][l];
+    const int act = a.net.acts[l];
+    const float oscale = (l == L - 1) ? a.net.out_scale : 1.0f;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      if (c < cnt) {
+        const int col = (cb0 + c) * 16 + (lane & 15);
+        const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = rb * 16 + (lane >> 4) * 4 + r;
+            float v = act_fwd(act, acc[rb][c][r] + bv) * oscale;
+            lds[row * lda + col] = col < N ? v : 0.f;  // zero the k-padding of the next layer
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* save = a.out.h[e][l];
+    if (save) tile_to_global(lds, lda, BM, N, save, row0, rows);
+  }
+}
+
+struct BwdArgs {
+  osrl_mlp_t net;
+  osrl_mlp_acts_t saved;
+  osrl_mlp_grads_t g;
+  int32_t rows, lda;
+};
+
+template <int NRB, int NCB>
+__global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 16 * NRB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e = blockIdx.y;
+  const int row0 = blockIdx.x * BM;
+  const int rows = a.rows, lda = a.lda;
+  const int L = a.net.n_layers;
+
+  {  // dZ_{L-1} = dY * out_scale * act'(Y / out_scale)
+    const float oscale = a.net.out_scale, inv_oscale = 1.0f / a.net.out_scale;
+    const int NL = a.net.dims[L], NLp = round16(NL);
+    const float* __restrict__ dy = a.g.dy[e];
+    const float* __restrict__ y = a.saved.h[e][L - 1];
+    const int act = a.net.acts[L - 1];
+    for (int idx = tid; idx < BM * NLp; idx += 256) {
+      const int r = idx / NLp, c = idx - r * NLp;
+      const int gr = row0 + r;
+      float v = 0.f;
+      if (gr < rows && c < NL) {
+        v = dy[(size_t)gr * NL + c] * oscale;
+        if (act != OSRL_ACT_ID) v *= act_bwd(act, y[(size_t)gr * NL + c] * inv_oscale);
+      }
+      lds[r * lda + c] = v;
+    }
+    __syncthreads();
+    if (a.g.dz[e][L - 1]) tile_to_global(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);
+  }
+
+  for (int l = L - 1; l >= 1; --l) {
+    // dH_{l-1}[r][i] = sum_o dZ_l[r][o] * W_l[o][i]   (K = dims[l+1] (o), N = dims[l] (i))
+    const int K = a.net.dims[l + 1], N = a.net.dims[l];
+    const int nblk = (N + 15) >> 4, cpw = (nblk + 3) >> 2;
+    const int cb0 = wave * cpw;
+    int cnt = nblk - cb0;
+    cnt = cnt > cpw ? cpw : cnt;
+    f32x4 acc[NRB][NCB];
+    zero_acc<NRB, NCB>(acc);
+    if (cnt > 0) layer_mm<NRB, NCB, true>(lds, lda, round16(K), a.net.W[e][l], K, N, N, cb0, cnt, acc);
+    __syncthreads();
+    const float* __restrict__ h = a.saved.h[e][l - 1];
+    const int act = a.net.acts[l - 1];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      if (c < cnt) {
+        const int col = (cb0 + c) * 16 + (lane & 15);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = rb * 16 + (lane >> 4) * 4 + r;
+            const int gr = row0 + row;
+            float v = 0.f;
+            if (col < N && gr < rows) v = acc[rb][c][r] * act_bwd(act, h[(size_t)gr * N + col]);
+            lds[row * lda + col] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (a.g.dz[e][l - 1]) tile_to_global(lds, lda, BM, N, a.g.dz[e][l - 1], row0, rows);
+  }
+
+  if (a.g.dx[e]) {
+    // dX[:, c0:c0+nc] = dZ_0 * W_0[:, c0:c0+nc]
+    const int K = a.net.dims[1], nc = a.g.dx_cols, ldw = a.net.dims[0];
+    const int nblk = (nc + 15) >> 4, cpw = (nblk + 3) >> 2;
+    const int cb0 = wave * cpw;
+    int cnt = nblk - cb0;
+    cnt = cnt > cpw ? cpw : cnt;
+    f32x4 acc[NRB][NCB];
+    zero_acc<NRB, NCB>(acc);
+    if (cnt > 0)
+      layer_mm<NRB, NCB, true>(lds, lda, round16(K), a.net.W[e][0] + a.g.dx_col0, K, nc, ldw, cb0, cnt, acc);
+    float* __restrict__ dx = a.g.dx[e];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      if (c < cnt) {
+        const int col = (cb0 + c) * 16 + (lane & 15);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gr = row0 + rb * 16 + (lane >> 4) * 4 + r;
+            if (col < nc && gr < rows) dx[(size_t)gr * nc + col] = acc[rb][c][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- dW = dZ^T A, db = colsum(dZ): split-K over rows, one 64x64 tile per wave ------------------
+__global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __restrict__ entries,
+                                                      const int32_t* __restrict__ items, int n_items, int rows,
+                                                      int rows_per_split, float* __restrict__ slabs,
+                                                      int64_t slab_stride) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_items) return;  // no barriers in this kernel
+  const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
+  const osrl_dw_entry_t E = entries[ei];
+  const int out = E.out, in = E.in;
+  const int o0 = ot * 64, i0 = it * 64;
+  const int s = blockIdx.y;
+  const int r_begin = s * rows_per_split;
+  int r_end = r_begin + rows_per_split;
+  r_end = r_end > rows ? rows : r_end;
+  const int m = lane & 15, kq = lane >> 4;
+  int nob = (out - o0 + 15) >> 4;
+  nob = nob > 4 ? 4 : nob;
+  int nib = (in - i0 + 15) >> 4;
+  nib = nib > 4 ? 4 : nib;
+
+  f32x4 acc[4][4];
+  zero_acc<4, 4>(acc);
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ dz = E.dz;
+  const float* __restrict__ av = E.a;
+  for (int r0 = r_begin; r0 < r_end; r0 += 16) {
+    f32x4 af[4], bf[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      af[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ob < nob) {
+        const int o = o0 + ob * 16 + m;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = r0 + 4 * kq + t;
+          if (o < out && r < r_end) af[ob][t] = dz[(size_t)r * out + o];
+        }
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      bf[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ib < nib) {
+        const int i = i0 + ib * 16 + m;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = r0 + 4 * kq + t;
+          if (i < in && r < r_end) bf[ib][t] = av[(size_t)r * in + i];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        if (ob < nob) {
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib)
+            if (ib < nib)
+              acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ob][t], bf[ib][t], acc[ob][ib], 0, 0, 0);
+        }
+      }
+    }
+    if (it == 0) {
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) dbacc[ob] += (af[ob][0] + af[ob][1]) + (af[ob][2] + af[ob][3]);
+    }
+  }
+  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) {
+    if (ob < nob) {
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        if (ib < nib) {
+          const int i = i0 + ib * 16 + m;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = o0 + ob * 16 + kq * 4 + r;
+            if (o < out && i < in) slab[E.w_off + (size_t)o * in + i] = acc[ob][ib][r];
+          }
+        }
+      }
+    }
+  }
+  if (it == 0) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      float v = dbacc[ob];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int o = o0 + ob * 16 + m;
+      if (ob < nob && kq == 0 && o < out) slab[E.b_off + o] = v;
+    }
+  }
+}
+
+inline int round16h(int x) { return (x + 15) & ~15; }
+
+struct TileChoice {
+  int nrb, ncb, lda;
+};
+
+// tile rows: keep >= ~2 workgroups per CU in flight when the row count allows it, otherwise shrink
+// the tile so that small batches still spread over the 256 CUs.
+inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) {
+  int maxw = extra_width;
+  for (int l = 0; l <= net->n_layers; ++l) maxw = net->dims[l] > maxw ? net->dims[l] : maxw;
+  const int nblk = (maxw + 15) / 16;
+  const int cpw = (nblk + 3) / 4;
+  TileChoice t;
+  t.ncb = cpw <= 1 ? 1 : cpw <= 2 ? 2 : cpw <= 4 ? 4 : 7;
+  t.lda = round16h(maxw) + 8;
+  const long wg64 = (long)((rows + 63) / 64) * net->n_nets;
+  const long wg32 = (long)((rows + 31) / 32) * net->n_nets;
+  if (t.ncb == 7) {
+    t.nrb = wg32 >= 256 ? 2 : 1;  // 7 column blocks/wave: cap the accumulators at 56 VGPRs
+  } else {
+    t.nrb = wg64 >= 512 ? 4 : wg32 >= 256 ? 2 : 1;
+  }
+  return t;
+}
+
+template <typename Args, typename K>
+int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int lda, hipStream_t stream) {
+  const int BM = 16 * nrb;
+  const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
+  dim3 grid((rows + BM - 1) / BM, nets, 1);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, stream, args);
+  return (int)hipGetLastError();
+}
+
+#define OSRL_DISPATCH_TILE(KERNEL, ARGS, ROWS, NETS, T, STREAM)                         \
+  do {                                                                                  \
+    if (T.ncb == 1) {                                                                   \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 1>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 1>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
+      return launch_tiles(KERNEL<1, 1>, ARGS, ROWS, NETS, 1, T.lda, STREAM);             \
+    }                                                                                   \
+    if (T.ncb == 2) {                                                                   \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 2>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 2>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
+      return launch_tiles(KERNEL<1, 2>, ARGS, ROWS, NETS, 1, T.lda, STREAM);             \
+    }                                                                                   \
+    if (T.ncb == 4) {                                                                   \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 4>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 4>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
+      return launch_tiles(KERNEL<1, 4>, ARGS, ROWS, NETS, 1, T.lda, STREAM);             \
+    }                                                                                   \
+    if (T.nrb == 2) return launch_tiles(KERNEL<2, 7>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
+    return launch_tiles(KERNEL<1, 7>, ARGS, ROWS, NETS, 1, T.lda, STREAM);               \
+  } while (0)
+
+bool valid_net(const osrl_mlp_t* n) {
+  if (!n || n->n_layers < 1 || n->n_layers > OSRL_MAX_LAYERS || n->n_nets < 1 || n->n_nets > OSRL_MAX_NETS)
+    return false;
+  for (int l = 0; l <= n->n_layers; ++l)
+    if (n->dims[l] < 1 || n->dims[l] > OSRL_MAX_WIDTH) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
+                                void* stream) {
+  if (!valid_net(net) || net->out_scale == 0.f || !in || !out || in->rows < 1 || in->d0 + in->d1 != net->dims[0]) return -1;
+  for (int e = 0; e < net->n_nets; ++e)
+    if (!out->h[e][net->n_layers - 1]) return -1;
+  FwdArgs a;
+  a.net = *net;
+  a.in = *in;
+  a.out = *out;
+  const TileChoice t = choose_tile(net, in->rows, 0);
+  a.lda = t.lda;
+  OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream);
+}
+
+extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                                    const osrl_mlp_grads_t* g, void* stream) {
+  if (!valid_net(net) || !saved || !g || rows < 1) return -1;
+  for (int e = 0; e < net->n_nets; ++e) {
+    if (!g->dy[e]) return -1;
+    for (int l = 0; l < net->n_layers; ++l)
+      if (!saved->h[e][l] && (l < net->n_layers - 1 || net->acts[l] != OSRL_ACT_ID)) return -1;
+    if (g->dx[e] && (g->dx_cols < 1 || g->dx_col0 < 0 || g->dx_col0 + g->dx_cols > net->dims[0])) return -1;
+  }
+  BwdArgs a;
+  a.net = *net;
+  a.saved = *saved;
+  a.g = *g;
+  a.rows = rows;
+  const TileChoice t = choose_tile(net, rows, g->dx_cols);
+  a.lda = t.lda;
+  OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream);
+}
+
+extern "C" int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
+                                    int32_t rows, int32_t n_splits, float* slabs, int64_t slab_stride,
+                                    void* stream) {
+  if (!d_entries || !d_items || n_items < 1 || rows < 1 || n_splits < 1 || !slabs) return -1;
+  int rps = (rows + n_splits - 1) / n_splits;
+  rps = (rps + 15) & ~15;
+  dim3 grid((n_items + 3) / 4, n_splits, 1);
+  hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_entries, d_items, n_items, rows,
+                     rps, slabs, slab_stride);
+  return (int)hipGetLastError();
+}

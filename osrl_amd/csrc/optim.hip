@@ -1,0 +1,116 @@
+// optim.hip -- device-resident optimizer step for gfx950.
+//
+// Replaces torch.optim.Adam.step / AdamW.step (osrl/algorithms/cpq.py:232-238, bcql.py:218-226,
+// bc.py:54-55, cdt.py:321-326) and the python-loop Polyak `_soft_update` (cpq.py:107-113,
+// bcql.py:114-120), fused into ONE pass over a flat fp32 parameter group:
+//     g  = sum_s slabs[s][i]                (fixed-order reduction of the split-K dW partials)
+//     m  = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2
+//     p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+//     tgt = tau p + (1-tau) tgt             (only for groups that own a target copy)
+// HBM-bound streaming kernel: float4 per lane, grid-stride, traffic = (S + 7 [+2]) * 4 B / param.
+// Fusing Polyak here is exact: in every algorithm the target of a group is not read again between
+// that group's optimizer step and the end of train_one_step (CPQ/BCQL phase order).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/osrl_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__global__ void step_tick_kernel(osrl_step_state_t* st, float beta1, float beta2, int warmup,
+                                 const float* __restrict__ stats_cur, float* __restrict__ ring, int n_stats,
+                                 int ring_len) {
+  const int64_t t_old = st->step;
+  if (stats_cur && ring && t_old >= 1) {
+    const int slot = (int)((t_old - 1) % ring_len);
+    for (int i = threadIdx.x; i < n_stats; i += blockDim.x) ring[(size_t)slot * n_stats + i] = stats_cur[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int64_t t = t_old + 1;
+    st->step = t;
+    st->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    // LambdaLR(min((s+1)/warmup, 1)) with s = number of scheduler steps taken = t-1 (cdt.py:327-330,409)
+    st->lr_scale = warmup > 0 ? (float)fmin((double)t / (double)warmup, 1.0) : 1.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ tgt,
+                                                   const float* __restrict__ slabs, int n_splits,
+                                                   int64_t slab_stride, int64_t n4, float lr, float b1, float b2,
+                                                   float eps, float wd, float tau, const float* __restrict__ gscale,
+                                                   const osrl_step_state_t* __restrict__ st) {
+  const float lr_t = lr * st->lr_scale;
+  const float step_size = lr_t / st->bc1;
+  const float bc2s = st->bc2_sqrt;
+  const float gs = gscale ? *gscale : 1.0f;
+  const float decay = 1.0f - lr_t * wd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 g = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int s = 1; s < n_splits; ++s) g += reinterpret_cast<const f32x4*>(slabs + (size_t)s * slab_stride)[i];
+    g *= gs;
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    if (wd != 0.0f) pv *= decay;
+    mv = b1 * mv + (1.0f - b1) * g;
+    vv = b2 * vv + (1.0f - b2) * g * g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) / bc2s + eps));
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (tgt) {
+      f32x4 tv = reinterpret_cast<f32x4*>(tgt)[i];
+      tv = tau * pv + (1.0f - tau) * tv;
+      reinterpret_cast<f32x4*>(tgt)[i] = tv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ flat, const float* __restrict__ slabs,
+                                                           int n_splits, int64_t slab_stride, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 g = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int s = 1; s < n_splits; ++s) g += reinterpret_cast<const f32x4*>(slabs + (size_t)s * slab_stride)[i];
+    reinterpret_cast<f32x4*>(flat)[i] = g;
+  }
+}
+
+inline int stream_grid(int64_t n4) {
+  int64_t b = (n4 + 255) / 256;
+  return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+
+}  // namespace
+
+extern "C" int osrl_step_tick(osrl_step_state_t* st, float beta1, float beta2, int32_t warmup,
+                              const float* stats_cur, float* ring, int32_t n_stats, int32_t ring_len,
+                              void* stream) {
+  if (!st) return -1;
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st, beta1, beta2, warmup,
+                     stats_cur, ring, n_stats, ring_len > 0 ? ring_len : 1);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_adam_step(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,
+                              int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
+                              void* stream) {
+  if (!p || !m || !v || !slabs || !st || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, tgt, slabs,
+                     n_splits, slab_stride, n / 4, lr, beta1, beta2, eps, weight_decay, tau, gscale, st);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
+                                 void* stream) {
+  if (!flat || !slabs || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, flat, slabs,
+                     n_splits, slab_stride, n / 4);
+  return (int)hipGetLastError();
+}

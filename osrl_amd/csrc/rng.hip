@@ -1,0 +1,134 @@
+// rng.hip -- on-device Gaussian noise and the on-device replay sampler for gfx950.
+//
+// * osrl_randn_fill replaces the host-side torch samplers of the reference's train step
+//   (randn_like net.py:327, Normal.rsample net.py:187, Normal.sample cpq.py:166, torch.randn
+//   net.py:334 -- the latter is even drawn on the CPU and copied to the device every call).
+//   Philox4x32-10 (counter = {element/4, step, stream_id, 0}, key = seed) + Box-Muller; the step
+//   comes from the device-resident osrl_step_state_t so a captured hipGraph draws fresh noise at
+//   every replay.  Parity tests inject explicit noise tensors instead.
+// * osrl_replay_gather replaces TransitionDataset.__iter__/__prepare_sample + DataLoader + H2D
+//   (osrl/common/dataset.py:832-847, examples/train/train_cpq.py:122-142): uniform-with-replacement
+//   row indices drawn on device, then a row gather of the resident transition tables.  HBM-bound:
+//   one wave reads one row of each table with coalesced dword loads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/osrl_amd.h"
+
+namespace {
+
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+    U4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+__device__ inline float u01(uint32_t x) {  // (0,1]
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
+                                                    uint32_t stream_id, const osrl_step_state_t* __restrict__ st) {
+  const uint32_t step = st ? (uint32_t)st->step : 0u;
+  const int64_t n4 = (n + 3) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const U4 r = philox4x32_10(U4{(uint32_t)i, (uint32_t)(i >> 32), step, stream_id}, k0, k1);
+    const float r0 = sqrtf(-2.0f * __logf(u01(r.x))), r1 = sqrtf(-2.0f * __logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+    __sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+    const float z[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+    const int64_t base = i * 4;
+    if (base + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+      *reinterpret_cast<float4*>(out + base) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (base + k < n) out[base + k] = z[k];
+    }
+  }
+}
+
+#define OSRL_MAX_FIELDS 8
+struct GatherArgs {
+  const float* src[OSRL_MAX_FIELDS];
+  float* dst[OSRL_MAX_FIELDS];
+  int32_t width[OSRL_MAX_FIELDS];
+  float scale[OSRL_MAX_FIELDS];
+  int32_t n_fields, batch;
+  int64_t n_rows;
+  int32_t* idx_out;
+  uint32_t k0, k1, stream_id;
+  const osrl_step_state_t* st;
+};
+
+// one wave per sampled row; lanes stride over the row's columns (coalesced both sides)
+__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.batch) return;
+  const uint32_t step = a.st ? (uint32_t)a.st->step : 0u;
+  const U4 r = philox4x32_10(U4{(uint32_t)b, 0x5eedu, step, a.stream_id}, a.k0, a.k1);
+  // 64-bit multiply-shift maps a 64-bit uniform onto [0, n_rows) (bias < 2^-40 for n_rows < 2^24)
+  const uint64_t u = ((uint64_t)r.x << 32) | r.y;
+  const int64_t idx = (int64_t)__umul64hi(u, (uint64_t)a.n_rows);
+  if (lane == 0 && a.idx_out) a.idx_out[b] = (int32_t)idx;
+  for (int f = 0; f < a.n_fields; ++f) {
+    const int w = a.width[f];
+    const float* __restrict__ s = a.src[f] + (size_t)idx * w;
+    float* __restrict__ d = a.dst[f] + (size_t)b * w;
+    const float sc = a.scale[f];
+    for (int c = lane; c < w; c += 64) d[c] = s[c] * sc;
+  }
+}
+
+}  // namespace
+
+extern "C" int osrl_randn_fill(float* out, int64_t n, uint64_t seed, uint32_t stream_id,
+                               const osrl_step_state_t* st, void* stream) {
+  if (!out || n < 1) return -1;
+  const int64_t n4 = (n + 3) / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(randn_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, n, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), stream_id, st);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_replay_gather(int32_t n_fields, const float* const* src, float* const* dst,
+                                  const int32_t* width, const float* scale, int64_t n_rows, int32_t batch,
+                                  int32_t* idx_out, uint64_t seed, uint32_t stream_id,
+                                  const osrl_step_state_t* st, void* stream) {
+  if (n_fields < 1 || n_fields > OSRL_MAX_FIELDS || !src || !dst || !width || n_rows < 1 || batch < 1) return -1;
+  GatherArgs a;
+  for (int f = 0; f < OSRL_MAX_FIELDS; ++f) {
+    a.src[f] = f < n_fields ? src[f] : nullptr;
+    a.dst[f] = f < n_fields ? dst[f] : nullptr;
+    a.width[f] = f < n_fields ? width[f] : 0;
+    a.scale[f] = (f < n_fields && scale) ? scale[f] : 1.0f;
+    if (f < n_fields && (!a.src[f] || !a.dst[f] || a.width[f] < 1)) return -1;
+  }
+  a.n_fields = n_fields;
+  a.batch = batch;
+  a.n_rows = n_rows;
+  a.idx_out = idx_out;
+  a.k0 = (uint32_t)seed;
+  a.k1 = (uint32_t)(seed >> 32);
+  a.stream_id = stream_id;
+  a.st = st;
+  hipLaunchKernelGGL(gather_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,212 @@
+"""The BCQ-Lag train step as a static launch plan on MI355X.
+
+Follows ``BCQLTrainer.train_one_step`` (osrl/algorithms/bcql.py:283-306): ``vae_loss`` :122-132 ->
+``critic_loss`` :134-155 -> ``cost_critic_loss`` :157-179 -> ``actor_loss`` :181-216 (+ PID controller
+net.py:376-387) -> ``sync_weight`` :228-234 (fused into each group's Adam kernel).
+The N*B-row target pipeline (repeat_interleave -> vae.decode -> actor_old -> twin ensembles) never
+materialises the repeated observations: the MLP kernels read ``next_obs[r / N]`` directly.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib as L
+from ..common.net import net_desc_seq, vae_dec_desc, vae_enc_desc
+from . import glue as G
+from .core import DwPlan, MlpRun, StepState, concat_nets, randn_fill
+
+STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/qc_penalty",
+             "loss/lagrangian"]
+NOISE_KEYS = ["eps_vae", "z_c", "z_cc", "z_actor"]
+
+
+class BCQLEngine:
+    def __init__(self, model, batch_size: int, rows_global: int = 0, seed: int = 0, dist=None):
+        m = self.model = model
+        B = self.B = int(batch_size)
+        self.rows_global, self.seed, self.dist = int(rows_global), seed, dist
+        dev = torch.device(m.device)
+        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
+        nq, nqc = m.num_q, m.num_qc
+        if 2 * nq + 2 * nqc > L.MAX_NETS:
+            raise ValueError(f"2*num_q + 2*num_qc = {2 * nq + 2 * nqc} > {L.MAX_NETS} nets per fused launch")
+        f = dict(dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
+        self.st = StepState(dev, STAT_KEYS)
+        self.obs, self.nobs, self.act = z(B, od), z(B, od), z(B, ad)
+        self.rew, self.cost, self.done = z(B), z(B), z(B)
+        shapes = {"eps_vae": (B, Lz), "z_c": (N * B, Lz), "z_cc": (N * B, Lz), "z_actor": (B, Lz)}
+        tot = sum(int(torch.Size(s).numel()) for s in shapes.values())
+        self.noise_flat = z((tot + 3) // 4 * 4)
+        self.noise: Dict[str, torch.Tensor] = {}
+        o = 0
+        for k in NOISE_KEYS:
+            n = int(torch.Size(shapes[k]).numel())
+            self.noise[k] = self.noise_flat[o:o + n].view(shapes[k])
+            o += n
+
+        def twin(mod, grp=None):
+            pre = None
+            if grp is not None:
+                pre = [f"{grp}.q1_nets.{i}" for i in range(len(mod.q1_nets))] + \
+                      [f"{grp}.q2_nets.{i}" for i in range(len(mod.q2_nets))]
+            return net_desc_seq(mod.all_nets(), 1.0, pre)
+
+        self.d_actor = net_desc_seq([m.actor.pi], 1.0, ["actor.pi"])
+        self.d_actor_old = net_desc_seq([m.actor_old.pi], 1.0)
+        self.d_critic, self.d_cost = twin(m.critic, "critic"), twin(m.cost_critic, "cost_critic")
+        self.d_critic_old, self.d_cost_old = twin(m.critic_old), twin(m.cost_critic_old)
+        self.d_enc, self.d_dec = vae_enc_desc(m.vae, "vae"), vae_dec_desc(m.vae, "vae")
+        g = m.groups
+
+        # vae phase
+        self.r_enc, self.r_dec = MlpRun(self.d_enc, B, True, dev), MlpRun(self.d_dec, B, True, dev)
+        self.z, self.du, self.dhead_enc = z(B, Lz), z(1, B, ad), z(1, B, 2 * Lz)
+        self.r_dec.setup_backward(self.du, dx_cols=(od, Lz))
+        self.r_enc.setup_backward(self.dhead_enc)
+        self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev)
+
+        # target pipeline buffers (shared by the critic and the cost-critic phases)
+        NB = N * B
+        self.r_dec_t = MlpRun(self.d_dec, NB, False, dev)
+        self.r_actor_old_t = MlpRun(self.d_actor_old, NB, False, dev)
+        self.a_t = z(NB, ad)
+        self.r_qold_t = MlpRun(self.d_critic_old, NB, False, dev)
+        self.r_qcold_t = MlpRun(self.d_cost_old, NB, False, dev)
+
+        self.r_critic = MlpRun(self.d_critic, B, True, dev)
+        self.dq = z(2 * nq, B, 1)
+        self.r_critic.setup_backward(self.dq)
+        self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev)
+        self.r_cost = MlpRun(self.d_cost, B, True, dev)
+        self.dqc = z(2 * nqc, B, 1)
+        self.r_cost.setup_backward(self.dqc)
+        self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev)
+
+        # actor phase
+        self.r_dec_b = MlpRun(self.d_dec, B, False, dev)
+        self.r_actor = MlpRun(self.d_actor, B, True, dev)
+        self.a_pi = z(B, ad)
+        self.r_pi_q = MlpRun(concat_nets(self.d_critic, self.d_cost), B, True, dev)
+        self.dq_pi = z(2 * nq + 2 * nqc, B, 1)
+        self.r_pi_q.setup_backward(self.dq_pi, need_dz=False, dx_cols=(od, ad))
+        self.dt = z(1, B, ad)
+        self.r_actor.setup_backward(self.dt)
+        self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
+        plan.launch()
+        grp = self.model.groups[name]
+        if self.dist is not None:
+            self.dist.allreduce_group(grp)
+        grp.adam_step(self.model._lrs[name], self.st.ptr, tau=tau)
+
+    def _targets(self, zkey: str, r_q: MlpRun) -> torch.Tensor:
+        """bcql.py:138-142: Q_old(obs', actor_old(obs', vae.decode(obs'))) on the N*B repeated rows."""
+        m, N, NB = self.model, self.model.sample_action_num, self.model.sample_action_num * self.B
+        dec = self.r_dec_t.forward(self.nobs, self.noise[zkey], map0=L.MAP_DIV, div0=N)[0]
+        t = self.r_actor_old_t.forward(self.nobs, dec, map0=L.MAP_DIV, div0=N)[0]
+        G.bcq_perturb(dec, t, NB, m.action_dim, m.phi, m.max_action, self.a_t)
+        return r_q.forward(self.nobs, self.a_t, map0=L.MAP_DIV, div0=N)
+
+    def body(self, device_noise: bool) -> None:
+        m, st, nz, B = self.model, self.st, self.noise, self.B
+        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
+        nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
+        st.tick()
+        if device_noise:
+            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+        for k in ("z_c", "z_cc", "z_actor"):  # net.py:334-335 clamps the latent draw
+            G.clamp_(nz[k], -0.5, 0.5)
+
+        head = self.r_enc.forward(self.obs, self.act)[0]
+        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        u = self.r_dec.forward(self.obs, self.z)[0]
+        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+        self.r_dec.backward_dz()
+        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        self.r_enc.backward_dz()
+        self._optim("vae", self.p_vae, 0.0)
+
+        q_t = self._targets("z_c", self.r_qold_t)
+        q = self.r_critic.forward(self.obs, self.act)
+        G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
+                          st.stat_ptr("loss/critic_loss"))
+        self.r_critic.backward_dz()
+        self._optim("critic", self.p_critic, m.tau)
+
+        qc_t = self._targets("z_cc", self.r_qcold_t)
+        qc = self.r_cost.forward(self.obs, self.act)
+        G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
+                          st.stat_ptr("loss/cost_critic_loss"))
+        self.r_cost.backward_dz()
+        self._optim("cost_critic", self.p_cost, m.tau)
+
+        dec = self.r_dec_b.forward(self.obs, nz["z_actor"])[0]
+        t = self.r_actor.forward(self.obs, dec)[0]
+        G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
+        y = self.r_pi_q.forward(self.obs, self.a_pi)
+        G.bcq_actor_loss(y[:2 * nq], nq, nq, y[2 * nq:], nqc, nqc, B, m.qc_thres, m.KP, m.KI, m.KD, rg, m.pid_state,
+                         self.dq_pi[:2 * nq], self.dq_pi[2 * nq:], st.stat_ptr("loss/actor_loss"))
+        self.r_pi_q.backward_dz()
+        G.bcq_perturb_bwd(dec, t, self.r_pi_q.dx, 2 * nq + 2 * nqc, B, ad, m.phi, m.max_action, self.dt)
+        self.r_actor.backward_dz()
+        self._optim("actor", self.p_actor, m.tau)
+
+    def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
+        for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
+                         (self.rew, rewards), (self.cost, costs), (self.done, done)):
+            if src is not dst:
+                dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+
+    def _snapshot(self):
+        m = self.model
+        snap = {"pid": m.pid_state.clone(), "state": self.st.state.clone(), "host": self.st.host_step,
+                "stats": self.st.stats.clone(), "ring": self.st.ring.clone()}
+        for n, g in m.groups.items():
+            snap[n] = (g.p.clone(), g.m.clone(), g.v.clone(), None if g.tgt is None else g.tgt.clone())
+        return snap
+
+    def _restore(self, snap) -> None:
+        m = self.model
+        m.pid_state.copy_(snap["pid"])
+        self.st.state.copy_(snap["state"]); self.st.stats.copy_(snap["stats"]); self.st.ring.copy_(snap["ring"])
+        self.st.host_step = snap["host"]
+        for n, g in m.groups.items():
+            p, mm, v, t = snap[n]
+            g.p.copy_(p); g.m.copy_(mm); g.v.copy_(v)
+            if t is not None:
+                g.tgt.copy_(t)
+
+    def capture(self) -> None:
+        snap = self._snapshot()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.body(True)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.body(True)
+        torch.cuda.synchronize()
+        self._restore(snap)
+        self.graph = g
+
+    def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
+             use_graph: bool = True) -> None:
+        self.load_batch(observations, next_observations, actions, rewards, costs, done)
+        if noise is not None:
+            for k in NOISE_KEYS:
+                self.noise[k].copy_(torch.as_tensor(noise[k]).reshape(self.noise[k].shape), non_blocking=True)
+            self.body(False)
+            return
+        if use_graph and self.dist is None:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body(True)

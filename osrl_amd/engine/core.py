@@ -1,0 +1,358 @@
+"""Host-side plumbing shared by the BC / CPQ / BCQ-Lag step engines.
+
+* ``FlatGroup``  -- one optimizer group as flat fp32 HBM buffers (param, Adam m, Adam v, optional
+  Polyak target, split-K gradient slabs).  ``nn.Parameter``s of the model are VIEWS into ``p`` /
+  ``tgt`` so the reference's ``state_dict`` layout is preserved while the optimizer + Polyak update
+  is ONE streaming kernel per group (csrc/optim.hip).
+* ``NetDesc``    -- pointers/dims of an ensemble of identical MLPs (``osrl_mlp_t``).
+* ``MlpRun``     -- activation / gradient buffers of one (NetDesc, rows) use + fwd / bwd launches.
+* ``DwPlan``     -- the static device-resident work list of the weight-gradient GEMM launch.
+
+PyTorch is used for device memory and streams only; all arithmetic is in libosrl_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def cur_stream() -> int:
+    if not torch.cuda.is_available():
+        raise RuntimeError("osrl_amd: kernels need a HIP device (no CPU fallback)")
+    return torch.cuda.current_stream().cuda_stream
+
+
+LAYOUT_ONLY_OK = False  # tests flip this to build parameter layouts on a GPU-less host (no launches possible)
+
+
+def require_cuda(device) -> torch.device:
+    dev = torch.device(device)
+    if LAYOUT_ONLY_OK and dev.type == "cpu":
+        return dev
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"osrl_amd runs on MI355X only (device={device!r}); there is no CPU fallback. "
+            "Use device='cuda' / 'cuda:N'.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("osrl_amd: no HIP device visible (torch.cuda.is_available() is False)")
+    return dev
+
+
+def _align4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+class FlatGroup:
+    """Flat storage of one optimizer group.  Usage: add()* -> finalize() -> view()/tgt_view()."""
+
+    def __init__(self, name: str, device, with_target: bool = False):
+        self.name = name
+        self.device = torch.device(device)
+        self.with_target = with_target
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self._n = 0
+        self.p = self.m = self.v = self.tgt = self.slabs = None
+        self.n_splits = 0
+
+    def add(self, key: str, shape: Sequence[int], align: bool = True) -> int:
+        assert self.p is None, "FlatGroup already finalized"
+        if align:
+            self._n = _align4(self._n)
+        off = self._n
+        n = 1
+        for s in shape:
+            n *= int(s)
+        self.layout[key] = (off, tuple(int(s) for s in shape))
+        self._n += n
+        return off
+
+    def finalize(self) -> None:
+        n = max(_align4(self._n), 4)
+        self.n = n
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)  # noqa: E731
+        self.p, self.m, self.v = z(), z(), z()
+        self.tgt = z() if self.with_target else None
+
+    def ensure_slabs(self, n_splits: int) -> None:
+        if self.slabs is None or self.n_splits < n_splits:
+            self.slabs = torch.zeros(n_splits, self.n, dtype=torch.float32, device=self.device)
+            self.n_splits = n_splits
+
+    def offset(self, key: str) -> int:
+        return self.layout[key][0]
+
+    def alias(self, key: str, first_key: str, shape: Sequence[int]) -> None:
+        """Name a contiguous range that spans several adjacent tensors (packed mu|log_std heads)."""
+        self.layout[key] = (self.layout[first_key][0], tuple(int(s) for s in shape))
+
+    def _view(self, buf: torch.Tensor, key: str) -> torch.Tensor:
+        off, shape = self.layout[key]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+    def view(self, key: str) -> torch.Tensor:
+        return self._view(self.p, key)
+
+    def tgt_view(self, key: str) -> torch.Tensor:
+        return self._view(self.tgt, key)
+
+    def grad_view(self, key: str, reduce: bool = True) -> torch.Tensor:
+        """Summed gradient of one tensor (debug / tests)."""
+        off, shape = self.layout[key]
+        n = 1
+        for s in shape:
+            n *= s
+        g = self.slabs[:self.cur_splits, off:off + n]
+        return g.sum(0).view(shape) if reduce else g
+
+    cur_splits = 1
+
+    def adam_step(self, lr: float, st_ptr: int, tau: float = 0.0, betas=(0.9, 0.999), eps=1e-8,
+                  weight_decay: float = 0.0, gscale: Optional[torch.Tensor] = None,
+                  polyak: bool = True) -> None:
+        lib = L.load()
+        L.check(lib.osrl_adam_step(self.p.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                   _ptr(self.tgt) if (polyak and self.tgt is not None) else None,
+                                   self.slabs.data_ptr(), self.cur_splits, self.n, self.n, lr, betas[0],
+                                   betas[1], eps, weight_decay, tau, _ptr(gscale), st_ptr, cur_stream()),
+                "osrl_adam_step")
+
+
+class NetDesc:
+    """An ensemble of identical MLPs: ``nets[e][l] = (W, b)`` tensors (views into a FlatGroup)."""
+
+    def __init__(self, nets: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], acts: Sequence[str],
+                 out_scale: float = 1.0, keys: Optional[Sequence[Sequence[Tuple[str, str]]]] = None):
+        E, nl = len(nets), len(nets[0])
+        if not (1 <= E <= L.MAX_NETS) or not (1 <= nl <= L.MAX_LAYERS):
+            raise ValueError(f"fused MLP supports <= {L.MAX_NETS} nets and <= {L.MAX_LAYERS} Linear layers "
+                             f"(got {E} nets, {nl} layers)")
+        self.E, self.nl = E, nl
+        dims = [nets[0][0][0].shape[1]] + [nets[0][l][0].shape[0] for l in range(nl)]
+        if max(dims) > L.MAX_WIDTH:
+            raise ValueError(f"layer width {max(dims)} > {L.MAX_WIDTH} unsupported by the fused MLP kernels")
+        self.dims = dims
+        self.acts = [L.ACT_CODES[a] for a in acts]
+        self.out_scale = float(out_scale)
+        self.nets = nets
+        self.keys = keys
+        d = L.MlpT()
+        d.n_layers, d.n_nets = nl, E
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        for i, a in enumerate(self.acts):
+            d.acts[i] = a
+        d.out_scale = self.out_scale
+        for e in range(E):
+            for l in range(nl):
+                W, b = nets[e][l]
+                assert W.is_contiguous() and b.is_contiguous() and W.dtype == torch.float32
+                assert tuple(W.shape) == (dims[l + 1], dims[l]) and tuple(b.shape) == (dims[l + 1],)
+                d.W[e][l] = W.data_ptr()
+                d.b[e][l] = b.data_ptr()
+        self.c = d
+
+    def subset(self, idx: Sequence[int]) -> "NetDesc":
+        return NetDesc([self.nets[i] for i in idx], [_ACT_NAMES[a] for a in self.acts], self.out_scale,
+                       None if self.keys is None else [self.keys[i] for i in idx])
+
+
+_ACT_NAMES = {L.ACT_ID: "id", L.ACT_RELU: "relu", L.ACT_TANH: "tanh"}
+
+
+def concat_nets(a: NetDesc, b: NetDesc) -> NetDesc:
+    """One launch over two ensembles of identical shape (e.g. critic_old + cost_critic_old)."""
+    assert a.dims == b.dims and a.acts == b.acts and a.out_scale == b.out_scale
+    keys = None if (a.keys is None or b.keys is None) else list(a.keys) + list(b.keys)
+    return NetDesc(list(a.nets) + list(b.nets), [_ACT_NAMES[x] for x in a.acts], a.out_scale, keys)
+
+
+class MlpRun:
+    """Buffers + launches for one use of a NetDesc on ``rows`` rows.
+
+    ``save=True`` keeps every layer's activations (+ the concatenated input) for the backward pass;
+    otherwise only the net outputs ``y`` [E, rows, out] are written.
+    """
+
+    def __init__(self, net: NetDesc, rows: int, save: bool, device, save_nets: Optional[Sequence[int]] = None):
+        self.net, self.rows, self.save = net, rows, save
+        f = dict(dtype=torch.float32, device=device)
+        E, nl, dims = net.E, net.nl, net.dims
+        self.y = torch.zeros(E, rows, dims[-1], **f)
+        self.acts_c = L.ActsT()
+        self.h: List[List[Optional[torch.Tensor]]] = [[None] * nl for _ in range(E)]
+        self.x = None
+        sn = set(range(E) if save_nets is None else save_nets) if save else set()
+        if save:
+            self.x = torch.zeros(rows, dims[0], **f)
+            self.acts_c.x = self.x.data_ptr()
+        for e in range(E):
+            for l in range(nl - 1):
+                if e in sn:
+                    self.h[e][l] = torch.zeros(rows, dims[l + 1], **f)
+                    self.acts_c.h[e][l] = self.h[e][l].data_ptr()
+            self.h[e][nl - 1] = self.y[e]
+            self.acts_c.h[e][nl - 1] = self.y[e].data_ptr()
+        self.saved_nets = sorted(sn)
+        self.dz: Optional[List[List[torch.Tensor]]] = None
+        self.dx = None
+        self.grads_c = None
+        self.bwd_net = None
+
+    # ---- forward ----
+    def forward(self, src0: torch.Tensor, src1: Optional[torch.Tensor] = None, map0=L.MAP_ID, div0=1,
+                map1=L.MAP_ID, div1=1) -> torch.Tensor:
+        r = L.RowsT()
+        r.rows = self.rows
+        r.d0, r.map0, r.div0 = src0.shape[-1], map0, div0
+        r.src0 = src0.data_ptr()
+        if src1 is not None:
+            r.d1, r.map1, r.div1 = src1.shape[-1], map1, div1
+            r.src1 = src1.data_ptr()
+        else:
+            r.d1, r.map1, r.div1 = 0, L.MAP_ID, 1
+        assert r.d0 + r.d1 == self.net.dims[0], (r.d0, r.d1, self.net.dims)
+        L.check(L.load().osrl_mlp_forward(C.byref(self.net.c), C.byref(r), C.byref(self.acts_c), cur_stream()),
+                "osrl_mlp_forward")
+        return self.y
+
+    # ---- backward ----
+    def setup_backward(self, dy: torch.Tensor, need_dz: bool = True, dx_cols: Optional[Tuple[int, int]] = None,
+                       dx_out: Optional[torch.Tensor] = None) -> None:
+        """dy: [len(saved_nets), rows, out] gradient wrt the outputs of the saved nets."""
+        assert self.save
+        idx = self.saved_nets
+        net = self.net if len(idx) == self.net.E else self.net.subset(idx)
+        self.bwd_net = net
+        f = dict(dtype=torch.float32, device=dy.device)
+        g = L.GradsT()
+        sv = L.ActsT()
+        sv.x = self.x.data_ptr()
+        self.dy = dy
+        self.dz = []
+        for j, e in enumerate(idx):
+            g.dy[j] = dy[j].data_ptr()
+            row = []
+            for l in range(net.nl):
+                sv.h[j][l] = self.h[e][l].data_ptr()
+                if need_dz:
+                    t = torch.zeros(self.rows, net.dims[l + 1], **f)
+                    g.dz[j][l] = t.data_ptr()
+                    row.append(t)
+            self.dz.append(row)
+        if dx_cols is not None:
+            c0, nc = dx_cols
+            self.dx = dx_out if dx_out is not None else torch.zeros(len(idx), self.rows, nc, **f)
+            assert tuple(self.dx.shape) == (len(idx), self.rows, nc) and self.dx.is_contiguous()
+            for j in range(len(idx)):
+                g.dx[j] = self.dx[j].data_ptr()
+            g.dx_col0, g.dx_cols = c0, nc
+        self.grads_c, self.saved_c = g, sv
+
+    def backward_dz(self) -> None:
+        L.check(L.load().osrl_mlp_backward_dz(C.byref(self.bwd_net.c), self.rows, C.byref(self.saved_c),
+                                              C.byref(self.grads_c), cur_stream()), "osrl_mlp_backward_dz")
+
+    def dw_entries(self) -> List[Tuple[torch.Tensor, torch.Tensor, str, str]]:
+        """(dz, input activation, weight key, bias key) for every layer of every saved net."""
+        out = []
+        net = self.bwd_net
+        for j, e in enumerate(self.saved_nets):
+            for l in range(net.nl):
+                a = self.x if l == 0 else self.h[e][l - 1]
+                wk, bk = net.keys[j][l]
+                out.append((self.dz[j][l], a, wk, bk))
+        return out
+
+
+class DwPlan:
+    """Static work list for osrl_mlp_backward_dw over one optimizer group."""
+
+    def __init__(self, group: FlatGroup, entries: Sequence[Tuple[torch.Tensor, torch.Tensor, str, str]],
+                 rows: int, device, n_splits: Optional[int] = None):
+        self.group, self.rows = group, rows
+        arr = (L.DwEntryT * len(entries))()
+        items: List[int] = []
+        for i, (dz, a, wk, bk) in enumerate(entries):
+            out_f, in_f = dz.shape[1], a.shape[1]
+            assert group.layout[wk][1] == (out_f, in_f), (wk, group.layout[wk], out_f, in_f)
+            arr[i].dz, arr[i].a = dz.data_ptr(), a.data_ptr()
+            arr[i].w_off, arr[i].b_off = group.offset(wk), group.offset(bk)
+            arr[i].out, arr[i].in_ = out_f, in_f
+            for ot in range((out_f + 63) // 64):
+                for it in range((in_f + 63) // 64):
+                    items += [i, ot, it, 0]
+        self.n_items = len(items) // 4
+        raw = bytes(arr)
+        self.d_entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.d_items = torch.tensor(items, dtype=torch.int32, device=device)
+        self._keep = [e[0] for e in entries] + [e[1] for e in entries]
+        if n_splits is None:
+            # fill ~2 waves of workgroups over 256 CUs, keep >= 64 rows per split
+            wgs = (self.n_items + 3) // 4
+            n_splits = max(1, min((512 + wgs - 1) // wgs, max(rows // 64, 1), 32))
+        self.n_splits = n_splits
+        group.ensure_slabs(n_splits)
+
+    def launch(self) -> None:
+        g = self.group
+        g.cur_splits = self.n_splits
+        L.check(L.load().osrl_mlp_backward_dw(self.d_entries.data_ptr(), self.d_items.data_ptr(), self.n_items,
+                                              self.rows, self.n_splits, g.slabs.data_ptr(), g.n, cur_stream()),
+                "osrl_mlp_backward_dw")
+
+
+class StepState:
+    """Device-resident step counter / bias corrections / statistics ring (csrc/optim.hip)."""
+
+    def __init__(self, device, stat_keys: Sequence[str], ring_len: int = 256, betas=(0.9, 0.999), warmup: int = 0):
+        self.keys = list(stat_keys)
+        self.index = {k: i for i, k in enumerate(self.keys)}
+        self.n_stats = max(len(self.keys), 1)
+        self.ring_len = ring_len
+        self.betas, self.warmup = betas, warmup
+        self.state = torch.zeros(24, dtype=torch.uint8, device=device)
+        self.stats = torch.zeros(self.n_stats, dtype=torch.float32, device=device)
+        self.ring = torch.zeros(ring_len, self.n_stats, dtype=torch.float32, device=device)
+        self.host_step = 0
+
+    @property
+    def ptr(self) -> int:
+        return self.state.data_ptr()
+
+    def stat_ptr(self, key: str) -> int:
+        return self.stats.data_ptr() + 4 * self.index[key]
+
+    def tick(self) -> None:
+        L.check(L.load().osrl_step_tick(self.ptr, self.betas[0], self.betas[1], self.warmup, self.stats.data_ptr(),
+                                        self.ring.data_ptr(), self.n_stats, self.ring_len, cur_stream()),
+                "osrl_step_tick")
+        self.host_step += 1
+
+    def device_step(self) -> int:
+        return int(self.state[:8].view(torch.int64).item())
+
+    def read_stats(self, step: Optional[int] = None) -> Dict[str, float]:
+        """Statistics of train step ``step`` (1-based; default = the latest).  Synchronises."""
+        if step is None or step == self.host_step:
+            v = self.stats.tolist()
+        else:
+            if self.host_step - step >= self.ring_len:
+                raise RuntimeError("statistics of that step were already overwritten in the ring")
+            v = self.ring[(step - 1) % self.ring_len].tolist()
+        return dict(zip(self.keys, v))
+
+
+def randn_fill(out: torch.Tensor, seed: int, stream_id: int, st_ptr: Optional[int]) -> None:
+    L.check(L.load().osrl_randn_fill(out.data_ptr(), out.numel(), seed, stream_id, st_ptr, cur_stream()),
+            "osrl_randn_fill")

@@ -1,0 +1,242 @@
+"""The CPQ train step as a static launch plan on MI355X.
+
+Follows ``CPQTrainer.train_one_step`` (osrl/algorithms/cpq.py:294-313) phase by phase:
+``vae_loss`` :125-135 -> ``critic_loss`` :137-153 -> ``cost_critic_loss`` :155-201 ->
+``actor_loss`` :203-222 -> ``sync_weight`` :224-230 (fused into each group's Adam kernel).
+
+Every buffer is allocated once; one step is a fixed sequence of ~40 kernel launches with no host
+synchronisation, so it is captured in a hipGraph (``torch.cuda.CUDAGraph``) and replayed.
+Common sub-expressions the reference recomputes are evaluated once (exact, not approximate):
+  * the actor trunk on ``next_observations`` (cpq.py:141 and :159 differ only by the noise draw);
+  * the actor trunk on ``observations`` (cpq.py:164 and :209: the actor is not updated in between).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib as L
+from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
+from . import glue as G
+from .core import DwPlan, MlpRun, StepState, concat_nets, randn_fill
+
+STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
+NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
+
+
+class CPQEngine:
+    def __init__(self, model, batch_size: int, rows_global: int = 0, seed: int = 0, dist=None):
+        m = self.model = model
+        B = self.B = int(batch_size)
+        self.rows_global = int(rows_global)
+        self.seed = seed
+        self.dist = dist
+        dev = torch.device(m.device)
+        self.dev = dev
+        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
+        f = dict(dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
+        self.st = StepState(dev, STAT_KEYS)
+        nq, nqc = m.num_q, m.num_qc
+
+        # static inputs (a replayed graph reads these addresses)
+        self.obs, self.nobs, self.act = z(B, od), z(B, od), z(B, ad)
+        self.rew, self.cost, self.done = z(B), z(B), z(B)
+        # one flat noise buffer -> one Philox launch per step
+        shapes = {"eps_vae": (B, Lz), "eps_next_c": (B, ad), "eps_next_cc": (B, ad), "eps_ood": (N, B, ad),
+                  "eps_actor": (B, ad)}
+        tot = sum(int(torch.Size(s).numel()) for s in shapes.values())
+        self.noise_flat = z((tot + 3) // 4 * 4)
+        self.noise: Dict[str, torch.Tensor] = {}
+        o = 0
+        for k in NOISE_KEYS:
+            n = int(torch.Size(shapes[k]).numel())
+            self.noise[k] = self.noise_flat[o:o + n].view(shapes[k])
+            o += n
+
+        # network descriptors (pointers into the flat groups)
+        qp = lambda grp, n: [f"{grp}.q_nets.{i}" for i in range(n)]  # noqa: E731
+        self.d_actor = actor_head_desc(m.actor, "actor")
+        self.d_critic = net_desc_seq(list(m.critic.q_nets), 1.0, qp("critic", nq))
+        self.d_cost = net_desc_seq(list(m.cost_critic.q_nets), 1.0, qp("cost_critic", nqc))
+        self.d_critic_old = net_desc_seq(list(m.critic_old.q_nets), 1.0)
+        self.d_cost_old = net_desc_seq(list(m.cost_critic_old.q_nets), 1.0)
+        self.d_enc = vae_enc_desc(m.vae, "vae")
+        self.d_dec = vae_dec_desc(m.vae, "vae")
+        g = m.groups
+
+        # ---- vae phase
+        self.r_enc = MlpRun(self.d_enc, B, True, dev)
+        self.r_dec = MlpRun(self.d_dec, B, True, dev)
+        self.z = z(B, Lz)
+        self.du = z(1, B, ad)
+        self.dhead_enc = z(1, B, 2 * Lz)
+        self.r_dec.setup_backward(self.du, dx_cols=(od, Lz))
+        self.r_enc.setup_backward(self.dhead_enc)
+        self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev)
+
+        # ---- critic phase
+        self.r_actor_next = MlpRun(self.d_actor, B, False, dev)
+        self.a_next = z(B, ad)
+        self.r_old_next = MlpRun(concat_nets(self.d_critic_old, self.d_cost_old), B, False, dev)
+        self.r_critic = MlpRun(self.d_critic, B, True, dev)
+        self.dq = z(nq, B, 1)
+        self.r_critic.setup_backward(self.dq)
+        self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev)
+
+        # ---- cost-critic phase
+        self.a_next2 = z(B, ad)
+        self.r_costold_next = MlpRun(self.d_cost_old, B, False, dev)
+        self.r_actor_obs = MlpRun(self.d_actor, B, True, dev)  # also the actor forward of the actor phase
+        self.sampled = z(N * B, ad)
+        self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev)
+        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev)
+        self.kl = z(N * B)
+        self.quant = z(4)
+        self.r_cost = MlpRun(self.d_cost, B, True, dev)
+        self.dqc = z(nqc, B, 1)
+        self.r_cost.setup_backward(self.dqc)
+        self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev)
+
+        # ---- actor phase
+        self.a_pi, self.tanh_u = z(B, ad), z(B, ad)
+        self.r_pi_q = MlpRun(concat_nets(self.d_critic, self.d_cost), B, True, dev, save_nets=list(range(nq)))
+        self.dq_pi = z(nq, B, 1)
+        self.r_pi_q.setup_backward(self.dq_pi, need_dz=False, dx_cols=(od, ad))
+        self.dhead_actor = z(1, B, 2 * ad)
+        self.r_actor_obs.setup_backward(self.dhead_actor)
+        self.p_actor = DwPlan(g["actor"], self.r_actor_obs.dw_entries(), B, dev)
+
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph_failed = False
+
+    # ------------------------------------------------------------------ #
+    def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
+        m = self.model
+        plan.launch()
+        grp = m.groups[name]
+        if self.dist is not None:
+            self.dist.allreduce_group(grp)
+        grp.adam_step(m._lrs[name], self.st.ptr, tau=tau)
+
+    def body(self, device_noise: bool) -> None:
+        m, st, nz, B = self.model, self.st, self.noise, self.B
+        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
+        nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
+        st.tick()
+        if device_noise:
+            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+
+        # ---- vae_loss  (cpq.py:125-135)
+        head = self.r_enc.forward(self.obs, self.act)[0]
+        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        u = self.r_dec.forward(self.obs, self.z)[0]
+        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+        self.r_dec.backward_dz()
+        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        self.r_enc.backward_dz()
+        self._optim("vae", self.p_vae, 0.0)
+
+        # ---- critic_loss  (cpq.py:137-153)
+        head_next = self.r_actor_next.forward(self.nobs)[0]
+        G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
+        y_old = self.r_old_next.forward(self.nobs, self.a_next)
+        q = self.r_critic.forward(self.obs, self.act)
+        G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres, rg,
+                          self.dq, st.stat_ptr("loss/critic_loss"))
+        self.r_critic.backward_dz()
+        self._optim("critic", self.p_critic, m.tau)
+
+        # ---- cost_critic_loss  (cpq.py:155-201)
+        G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+        qc_old_next = self.r_costold_next.forward(self.nobs, self.a_next2)
+        head_obs = self.r_actor_obs.forward(self.obs)[0]
+        G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
+        qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+        head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
+        G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
+        if self.dist is not None:
+            self.dist.quantile(self.kl, 0.75, self.quant)
+        else:
+            G.quantile(self.kl, N * B, 0.75, self.quant)
+        qc = self.r_cost.forward(self.obs, self.act)
+        G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, qc_s, self.kl, self.quant, N, self.cost, B, m.gamma, m.qc_thres,
+                        m.alpha_lr, rg, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+        self.r_cost.backward_dz()
+        self._optim("cost_critic", self.p_cost, m.tau)
+
+        # ---- actor_loss  (cpq.py:203-222)
+        G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
+        y = self.r_pi_q.forward(self.obs, self.a_pi)
+        G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
+        self.r_pi_q.backward_dz()
+        G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
+                         self.dhead_actor)
+        self.r_actor_obs.backward_dz()
+        self._optim("actor", self.p_actor, m.tau)
+
+    # ------------------------------------------------------------------ #
+    def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
+        for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
+                         (self.rew, rewards), (self.cost, costs), (self.done, done)):
+            if src is not dst:
+                dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+
+    def load_noise(self, noise: Dict[str, torch.Tensor]) -> None:
+        for k in NOISE_KEYS:
+            self.noise[k].copy_(torch.as_tensor(noise[k]).reshape(self.noise[k].shape), non_blocking=True)
+
+    def capture(self) -> None:
+        """Capture one step (device-drawn noise) into a hipGraph.  Warm-up launches run first on a
+        side stream as torch requires; the model state they advance is restored afterwards."""
+        snap = self._snapshot()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.body(True)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.body(True)
+        torch.cuda.synchronize()
+        self._restore(snap)
+        self.graph = g
+
+    def _snapshot(self):
+        m = self.model
+        snap = {"log_alpha": m.log_alpha.clone(), "state": self.st.state.clone(), "host": self.st.host_step,
+                "stats": self.st.stats.clone(), "ring": self.st.ring.clone()}
+        for n, g in m.groups.items():
+            snap[n] = (g.p.clone(), g.m.clone(), g.v.clone(), None if g.tgt is None else g.tgt.clone())
+        return snap
+
+    def _restore(self, snap) -> None:
+        m = self.model
+        m.log_alpha.copy_(snap["log_alpha"])
+        self.st.state.copy_(snap["state"])
+        self.st.stats.copy_(snap["stats"])
+        self.st.ring.copy_(snap["ring"])
+        self.st.host_step = snap["host"]
+        for n, g in m.groups.items():
+            p, mm, v, t = snap[n]
+            g.p.copy_(p)
+            g.m.copy_(mm)
+            g.v.copy_(v)
+            if t is not None:
+                g.tgt.copy_(t)
+
+    def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
+             use_graph: bool = True) -> None:
+        self.load_batch(observations, next_observations, actions, rewards, costs, done)
+        if noise is not None:
+            self.load_noise(noise)
+            self.body(False)
+            return
+        if use_graph and self.dist is None:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body(True)

@@ -1,0 +1,105 @@
+"""Thin typed wrappers over the glue kernels of libosrl_amd.so (csrc/glue.hip).
+
+Arguments are torch CUDA tensors (or raw device addresses for ``stat``); every call is an
+asynchronous launch on the current stream.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+from .core import _ptr, cur_stream
+
+
+def _p(t) -> Optional[int]:
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def gauss_head(head, eps, rows, ad, max_action, a=None, tanh_u=None, logp=None):
+    L.check(L.load().osrl_gauss_head(_p(head), _p(eps), rows, ad, max_action, _p(a), _p(tanh_u), _p(logp),
+                                     cur_stream()), "osrl_gauss_head")
+
+
+def gauss_head_bwd(head, eps, tanh_u, da_nets, n_nets, rows, ad, max_action, dhead):
+    L.check(L.load().osrl_gauss_head_bwd(_p(head), _p(eps), _p(tanh_u), _p(da_nets), n_nets, rows, ad, max_action,
+                                         _p(dhead), cur_stream()), "osrl_gauss_head_bwd")
+
+
+def gauss_ood_sample(head, eps, n_samples, rows, ad, out):
+    L.check(L.load().osrl_gauss_ood_sample(_p(head), _p(eps), n_samples, rows, ad, _p(out), cur_stream()),
+            "osrl_gauss_ood_sample")
+
+
+def vae_latent(head, eps, rows, Lz, z):
+    L.check(L.load().osrl_vae_latent(_p(head), _p(eps), rows, Lz, _p(z), cur_stream()), "osrl_vae_latent")
+
+
+def vae_loss(u, act, head, rows, ad, Lz, beta, rows_global, du, stat):
+    L.check(L.load().osrl_vae_loss(_p(u), _p(act), _p(head), rows, ad, Lz, beta, rows_global, _p(du), _p(stat),
+                                   cur_stream()), "osrl_vae_loss")
+
+
+def vae_latent_bwd(head, eps, dz, rows, Lz, beta, rows_global, dhead):
+    L.check(L.load().osrl_vae_latent_bwd(_p(head), _p(eps), _p(dz), rows, Lz, beta, rows_global, _p(dhead),
+                                         cur_stream()), "osrl_vae_latent_bwd")
+
+
+def vae_kl_rows(head, rows, Lz, kl):
+    L.check(L.load().osrl_vae_kl_rows(_p(head), rows, Lz, _p(kl), cur_stream()), "osrl_vae_kl_rows")
+
+
+def quantile(x, n, q, out):
+    L.check(L.load().osrl_quantile(_p(x), n, q, _p(out), cur_stream()), "osrl_quantile")
+
+
+def cpq_critic_loss(q_old, n_q_old, qc_old, n_qc_old, q, n_q, rew, done, rows, gamma, q_thres, rows_global, dq,
+                    stat):
+    L.check(L.load().osrl_cpq_critic_loss(_p(q_old), n_q_old, _p(qc_old), n_qc_old, _p(q), n_q, _p(rew), _p(done),
+                                          rows, gamma, q_thres, rows_global, _p(dq), _p(stat), cur_stream()),
+            "osrl_cpq_critic_loss")
+
+
+def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, qc_sampled, kl, quant, n_samples, cost, rows, gamma, qc_thres,
+                  alpha_lr, rows_global, log_alpha, dq, stat):
+    L.check(L.load().osrl_cpq_cost_loss(_p(qc_old_next), n_qc_old, _p(qc), n_qc, _p(qc_sampled), _p(kl), _p(quant),
+                                        n_samples, _p(cost), rows, gamma, qc_thres, alpha_lr, rows_global,
+                                        _p(log_alpha), _p(dq), _p(stat), cur_stream()), "osrl_cpq_cost_loss")
+
+
+def cpq_actor_loss(q, n_q, qc, n_qc, rows, q_thres, rows_global, dq, stat):
+    L.check(L.load().osrl_cpq_actor_loss(_p(q), n_q, _p(qc), n_qc, rows, q_thres, rows_global, _p(dq), _p(stat),
+                                         cur_stream()), "osrl_cpq_actor_loss")
+
+
+def mse_loss(u, target, n, n_global, du, stat):
+    L.check(L.load().osrl_mse_loss(_p(u), _p(target), n, n_global, _p(du), _p(stat), cur_stream()),
+            "osrl_mse_loss")
+
+
+def bcq_perturb(dec, t, rows, ad, phi, max_action, a):
+    L.check(L.load().osrl_bcq_perturb(_p(dec), _p(t), rows, ad, phi, max_action, _p(a), cur_stream()),
+            "osrl_bcq_perturb")
+
+
+def bcq_perturb_bwd(dec, t, da_nets, n_nets, rows, ad, phi, max_action, dt):
+    L.check(L.load().osrl_bcq_perturb_bwd(_p(dec), _p(t), _p(da_nets), n_nets, rows, ad, phi, max_action, _p(dt),
+                                          cur_stream()), "osrl_bcq_perturb_bwd")
+
+
+def bcq_critic_loss(q_t, n1, n2, n_samples, q_on, n_on, base, done, rows, gamma, lmbda, rows_global, dq, stat):
+    L.check(L.load().osrl_bcq_critic_loss(_p(q_t), n1, n2, n_samples, _p(q_on), n_on, _p(base), _p(done), rows,
+                                          gamma, lmbda, rows_global, _p(dq), _p(stat), cur_stream()),
+            "osrl_bcq_critic_loss")
+
+
+def bcq_actor_loss(q, nq1, nq2, qc, nc1, nc2, rows, qc_thres, KP, KI, KD, rows_global, pid, dq, dqc, stat):
+    L.check(L.load().osrl_bcq_actor_loss(_p(q), nq1, nq2, _p(qc), nc1, nc2, rows, qc_thres, KP, KI, KD, rows_global,
+                                         _p(pid), _p(dq), _p(dqc), _p(stat), cur_stream()), "osrl_bcq_actor_loss")
+
+
+def clamp_(x, lo, hi):
+    L.check(L.load().osrl_clamp(_p(x), x.numel(), lo, hi, cur_stream()), "osrl_clamp")

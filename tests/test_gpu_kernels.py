@@ -1,0 +1,230 @@
+"""GPU unit parity of the individual HIP kernels (through the C ABI via ctypes) against fp64
+numpy/torch-CPU references of the same op.  Tolerances: fp32 round-off (1e-5 relative-ish)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _mk_nets(rs, E, dims, dev):
+    nets = []
+    for _ in range(E):
+        layers = []
+        for l in range(len(dims) - 1):
+            k = 1 / math.sqrt(dims[l])
+            W = torch.tensor(rs.uniform(-k, k, (dims[l + 1], dims[l])), dtype=torch.float32, device=dev)
+            b = torch.tensor(rs.uniform(-k, k, (dims[l + 1],)), dtype=torch.float32, device=dev)
+            layers.append((W, b))
+        nets.append(layers)
+    return nets
+
+
+def _act64(name, x):
+    return {"relu": lambda v: np.maximum(v, 0), "tanh": np.tanh, "id": lambda v: v}[name](x)
+
+
+def _dact64(name, y):
+    return {"relu": lambda v: (v > 0).astype(np.float64), "tanh": lambda v: 1 - v * v,
+            "id": lambda v: np.ones_like(v)}[name](y)
+
+
+MLP_CASES = [
+    # E, dims, acts, out_scale, rows, (d0, map0, div0, map1, div1), dx_cols
+    (2, [78, 256, 256, 1], ["relu", "relu", "id"], 1.0, 100, (76, 0, 1, 0, 1), (76, 2)),
+    (1, [80, 400, 400, 2], ["relu", "relu", "tanh"], 1.5, 77, (76, 0, 1, 0, 1), (76, 4)),
+    (1, [78, 400, 400, 8], ["relu", "relu", "id"], 1.0, 2048, (76, 0, 1, 0, 1), None),
+    (3, [9, 32, 24, 3], ["tanh", "tanh", "tanh"], 1.0, 1, (6, 0, 1, 0, 1), (0, 9)),
+    (4, [41, 256, 256, 1], ["relu", "relu", "id"], 1.0, 333, (33, 2, 3, 0, 1), (33, 8)),     # DIV map
+    (2, [78, 256, 256, 1], ["relu", "relu", "id"], 1.0, 4096 + 40, (76, 1, 517, 0, 1), None),  # MOD map, NRB=4
+    (1, [76, 256, 256, 4], ["relu", "relu", "id"], 1.0, 2048, (76, 0, 1, 0, 1), None),       # no second source
+    (8, [12, 64, 64, 1], ["relu", "relu", "id"], 1.0, 50, (8, 0, 1, 0, 1), (8, 4)),
+    (1, [7, 48, 5], ["relu", "id"], 1.0, 19, (7, 0, 1, 0, 1), None),                          # 2 layers
+    (1, [20, 64, 48, 32, 6], ["relu", "tanh", "relu", "tanh"], 2.0, 130, (16, 0, 1, 0, 1), (3, 11)),  # 4 layers
+]
+
+
+@pytest.mark.parametrize("ci", range(len(MLP_CASES)))
+def test_mlp_fwd_bwd(ci):
+    from osrl_amd.engine.core import DwPlan, FlatGroup, MlpRun, NetDesc
+    E, dims, acts, oscale, rows, (d0, map0, div0, map1, div1), dxc = MLP_CASES[ci]
+    dev = _dev()
+    rs = np.random.RandomState(10 + ci)
+    # parameters in a FlatGroup so dW offsets are exercised
+    grp = FlatGroup("t", dev)
+    for e in range(E):
+        for l in range(len(dims) - 1):
+            grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.add(f"{e}.{l}.b", (dims[l + 1],))
+    grp.finalize()
+    nets, keys = [], []
+    for e in range(E):
+        layers, kk = [], []
+        for l in range(len(dims) - 1):
+            k = 1 / math.sqrt(dims[l])
+            W, b = grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")
+            W.copy_(torch.tensor(rs.uniform(-k, k, W.shape), dtype=torch.float32))
+            b.copy_(torch.tensor(rs.uniform(-k, k, b.shape), dtype=torch.float32))
+            layers.append((W, b))
+            kk.append((f"{e}.{l}.w", f"{e}.{l}.b"))
+        nets.append(layers)
+        keys.append(kk)
+    desc = NetDesc(nets, acts, oscale, keys)
+    d1 = dims[0] - d0
+    n0 = {0: rows, 1: div0, 2: (rows + div0 - 1) // div0}[map0]
+    src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
+    src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
+    run = MlpRun(desc, rows, True, dev)
+    y = run.forward(src0, src1, map0=map0, div0=div0, map1=map1, div1=div1)
+    torch.cuda.synchronize()
+
+    # fp64 reference
+    idx0 = {0: np.arange(rows), 1: np.arange(rows) % div0, 2: np.arange(rows) // div0}[map0]
+    X = src0.cpu().numpy().astype(np.float64)[idx0]
+    if d1:
+        X = np.concatenate([X, src1.cpu().numpy().astype(np.float64)], 1)
+    np.testing.assert_allclose(run.x.cpu().numpy(), X, atol=0, rtol=0, err_msg="saved input x")
+    caches = []
+    for e in range(E):
+        h, c = X, [X]
+        for l, a in enumerate(acts):
+            W, b = (t.cpu().numpy().astype(np.float64) for t in nets[e][l])
+            h = _act64(a, h @ W.T + b)
+            if l == len(acts) - 1:
+                h = h * oscale
+            c.append(h)
+            got = run.h[e][l].cpu().numpy()
+            err = np.abs(got - h).max()
+            assert err < 2e-5 * max(1.0, np.abs(h).max()), f"case {ci} fwd net {e} layer {l}: max err {err}"
+        caches.append(c)
+    assert np.isfinite(y.cpu().numpy()).all()
+
+    # backward
+    dy = torch.tensor(rs.randn(E, rows, dims[-1]), dtype=torch.float32, device=dev)
+    run.setup_backward(dy, need_dz=True, dx_cols=dxc)
+    run.backward_dz()
+    plan = DwPlan(grp, run.dw_entries(), rows, dev)
+    plan.launch()
+    torch.cuda.synchronize()
+    for e in range(E):
+        c = caches[e]
+        g = dy[e].cpu().numpy().astype(np.float64)
+        L_ = len(acts)
+        for l in range(L_ - 1, -1, -1):
+            yl = c[l + 1] / (oscale if l == L_ - 1 else 1.0)
+            dz = g * _dact64(acts[l], yl) * (oscale if l == L_ - 1 else 1.0)
+            got = run.dz[e][l].cpu().numpy()
+            sc = max(1.0, np.abs(dz).max())
+            assert np.abs(got - dz).max() < 3e-5 * sc, f"case {ci} dz net {e} layer {l}: {np.abs(got - dz).max()}"
+            W = nets[e][l][0].cpu().numpy().astype(np.float64)
+            dW, db = dz.T @ c[l], dz.sum(0)
+            gW = grp.grad_view(f"{e}.{l}.w").cpu().numpy()
+            gb = grp.grad_view(f"{e}.{l}.b").cpu().numpy()
+            scw = max(1.0, np.abs(dW).max())
+            assert np.abs(gW - dW).max() < 1e-4 * scw, f"case {ci} dW net {e} layer {l}: {np.abs(gW - dW).max()} / {scw}"
+            assert np.abs(gb - db).max() < 1e-4 * max(1.0, np.abs(db).max()), f"case {ci} db net {e} layer {l}"
+            g = dz @ W
+        if dxc is not None:
+            c0, nc = dxc
+            got = run.dx[e].cpu().numpy()
+            ref = g[:, c0:c0 + nc]
+            assert np.abs(got - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), f"case {ci} dx net {e}"
+
+
+def test_adam_polyak_matches_oracle():
+    from oracle.osrl_oracle import Adam
+    from osrl_amd.engine.core import FlatGroup, StepState
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    grp = FlatGroup("g", dev, with_target=True)
+    grp.add("w", (37, 5))
+    grp.add("b", (6,))
+    grp.finalize()
+    p0 = {"w": rs.randn(37, 5).astype(np.float32), "b": rs.randn(6).astype(np.float32)}
+    tgt = {k: v.copy() for k, v in p0.items()}
+    for k in p0:
+        grp.view(k).copy_(torch.tensor(p0[k]))
+        grp.tgt_view(k).copy_(torch.tensor(p0[k]))
+    grp.ensure_slabs(3)
+    grp.cur_splits = 3
+    st = StepState(dev, ["x"])
+    opt = Adam(["w", "b"], 1e-3)
+    p = {k: v.copy() for k, v in p0.items()}
+    tau = 0.005
+    for step in range(5):
+        gs = {k: rs.randn(3, *p0[k].shape).astype(np.float32) for k in p0}
+        for k in p0:
+            off, shape = grp.layout[k]
+            grp.slabs[:3, off:off + p0[k].size] = torch.tensor(gs[k].reshape(3, -1))
+        st.tick()
+        grp.adam_step(1e-3, st.ptr, tau=tau)
+        opt.step(p, {k: gs[k].sum(0) for k in p0})
+        for k in p0:
+            tgt[k] = (tau * p[k] + (1 - tau) * tgt[k]).astype(np.float32)
+    torch.cuda.synchronize()
+    assert st.device_step() == 5
+    for k in p0:
+        np.testing.assert_allclose(grp.view(k).cpu().numpy(), p[k], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(grp.tgt_view(k).cpu().numpy(), tgt[k], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 20480, 163840])
+def test_quantile_exact(n):
+    from osrl_amd.engine import glue as G
+    dev = _dev()
+    rs = np.random.RandomState(n)
+    x = rs.randn(n).astype(np.float32)
+    if n > 100:
+        x[::7] = x[3]  # duplicates
+        x[5] = -0.0
+        x[6] = 0.0
+    xt = torch.tensor(x, device=dev)
+    out = torch.zeros(4, device=dev)
+    for q in (0.75, 0.0, 1.0, 0.5):
+        G.quantile(xt, n, q, out)
+        ref = torch.quantile(torch.tensor(x), q).item()
+        assert abs(out[0].item() - ref) <= 1e-6 * max(1, abs(ref)), (n, q, out[0].item(), ref)
+
+
+def test_randn_and_gather():
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import StepState, cur_stream, randn_fill
+    import ctypes as C
+    dev = _dev()
+    st = StepState(dev, ["x"])
+    st.tick()
+    a = torch.zeros(1 << 20, device=dev)
+    randn_fill(a, 1234, 0, st.ptr)
+    b = a.clone()
+    randn_fill(a, 1234, 0, st.ptr)
+    assert torch.equal(a, b), "same (seed, step, stream) must reproduce"
+    st.tick()
+    randn_fill(a, 1234, 0, st.ptr)
+    assert not torch.equal(a, b), "a new step must draw fresh noise"
+    x = a.double().cpu().numpy()
+    assert abs(x.mean()) < 5e-3 and abs(x.std() - 1) < 5e-3
+    assert abs((x ** 4).mean() - 3) < 0.05 and abs(np.mean(x > 1.0) - 0.158655) < 2e-3
+    # replay gather
+    n_rows, B = 5000, 2048
+    tabs = [torch.arange(n_rows * w, device=dev, dtype=torch.float32).view(n_rows, w) for w in (76, 2, 1)]
+    outs = [torch.zeros(B, w, device=dev) for w in (76, 2, 1)]
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    src = (C.c_void_p * 3)(*[t.data_ptr() for t in tabs])
+    dst = (C.c_void_p * 3)(*[t.data_ptr() for t in outs])
+    width = (C.c_int32 * 3)(76, 2, 1)
+    scale = (C.c_float * 3)(1.0, 1.0, 0.5)
+    L.check(L.load().osrl_replay_gather(3, src, dst, width, scale, n_rows, B, idx.data_ptr(), 99, 1, st.ptr,
+                                        cur_stream()), "gather")
+    torch.cuda.synchronize()
+    ii = idx.long()
+    assert ii.min() >= 0 and ii.max() < n_rows and len(torch.unique(ii)) > B * 0.7
+    assert torch.equal(outs[0], tabs[0][ii]) and torch.equal(outs[1], tabs[1][ii])
+    assert torch.equal(outs[2], tabs[2][ii] * 0.5)
+    assert abs(ii.float().mean().item() / n_rows - 0.5) < 0.03
