@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- grad-steps/sec of the OSRL CPQ train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): CPQ, (obs_dim, act_dim) = (76, 2) [OfflinePointGoal1], batch 2048
+per GPU, hidden [256,256], VAE 400, N=10 sampled actions, num_q = num_qc = 2, fp32, train-config
+learning rates -- every phase of CPQTrainer.train_one_step (vae, critic, cost-critic incl. the
+N*B OOD scoring + quantile, actor, Adam x4, Polyak x3) plus the on-device minibatch draw from a
+HBM-resident synthetic transition store and the Gaussian noise generation are INSIDE the timed step.
+One "step" (unit) = one 2048-transition gradient step; with N GPUs the job is data parallel (global
+batch 2048*N, gradient all-reduce over RCCL) so value = N * global-steps/s  ("scaling": "weak").
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OD, AD, B, HID, VAE_H, NS = 76, 2, 2048, [256, 256], 400, 10
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def lin(sizes):
+    return sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+
+
+def cpq_flops_per_step(od, ad, Bsz, H, V, N, nq, nqc):
+    """Algorithmic FLOPs of one reference CPQ step (SURVEY.md 8d formula; 1 MAC = 2 FLOP)."""
+    actor = lin([od] + H) + 2 * H[-1] * ad
+    q = lin([od + ad] + H + [1])
+    vae = lin([od + ad, V, V]) + 2 * V * 2 * ad + lin([od + 2 * ad, V, V, ad])
+    step = 3 * vae + (3 * nq * q + actor + nq * q + nqc * q) + \
+        (3 * nqc * q + 2 * actor + nqc * q + N * nqc * q + N * vae) + (3 * actor + 2 * nq * q + nqc * q)
+    return 2.0 * step * Bsz
+
+
+def build(device, rank, world, seed=0, n_store=1 << 20):
+    from osrl_amd.algorithms import CPQ, CPQTrainer
+    from osrl_amd.common.replay import ReplayStore, synthetic_transitions
+    torch.manual_seed(seed)
+    model = CPQ(OD, AD, 1.0, HID, HID, VAE_H, NS, 0.99, 0.005, 0.5, 2, 2, 1.5, 10, 1000, device=str(device))
+    trainer = CPQTrainer(model, None, None, actor_lr=1e-4, critic_lr=1e-3, alpha_lr=1e-4, vae_lr=1e-3,
+                         reward_scale=0.1, cost_scale=1.0, device=str(device), stats_mode="none")
+    shard = n_store // world
+    store = ReplayStore(synthetic_transitions(shard, OD, AD, seed=1 + rank), device, reward_scale=0.1,
+                        cost_scale=1.0, seed=1, rank=rank, world=1)
+    return model, trainer, store
+
+
+def time_kernel(fn, iters=30):
+    """Average duration (s) of ``fn`` (one kernel launch on the current stream) by HIP events."""
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def mlp_fwd_flops(run):
+    d = run.net.dims
+    return 2.0 * run.rows * run.net.E * lin(d)
+
+
+def roofline(eng):
+    """Dominant kernels of the step: the two N*B-row forward launches (69% of the step's FLOPs)."""
+    from osrl_amd import _lib as L
+    cands = {
+        "mlp_fwd<vae-encoder, N*B rows>": (eng.r_enc_ood, lambda: eng.r_enc_ood.forward(
+            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B)),
+        "mlp_fwd<cost_critic_old x2, N*B rows>": (eng.r_costold_ood, lambda: eng.r_costold_ood.forward(
+            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B)),
+    }
+    res = {}
+    for name, (run, fn) in cands.items():
+        t = time_kernel(fn)
+        res[name] = dict(seconds=t, flops=mlp_fwd_flops(run))
+    dom = max(res, key=lambda k: res[k]["seconds"])
+    ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom)
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+            "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)}
+                        for k, v in res.items()}}
+
+
+def cpu_baseline(budget_s=20.0):
+    """The numpy oracle (a port of the reference's CPU path, oracle/osrl_oracle.py) timed on this host's
+    cores on the SAME workload (CPQ (76,2) B=2048), bounded to ~budget_s of CPU work."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import Case, make_batch, make_noise
+    from oracle_util import build_oracle
+    c = Case("bench_c2", "cpq", od=OD, ad=AD, B=B, hidden=HID, vae_hidden=VAE_H, N=NS, steps=1, episode_len=1000)
+    o = build_oracle(c)
+    b, nz = make_batch(c), make_noise(c, 0)
+    args = (b["observations"], b["next_observations"], b["actions"], b["rewards"], b["costs"], b["done"], nz)
+    o.train_one_step(*args)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        o.train_one_step(*args)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 200:
+            break
+    dt = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+        nt = [p.get("num_threads") for p in threadpool_info() if p.get("user_api") == "blas"]
+        cores = max(nt) if nt else cores
+    except Exception:
+        pass
+    return {"value": round(n / dt, 3), "unit": "grad-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} CPQ steps (76,2) B=2048 of the numpy oracle, OpenBLAS threads={cores}, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        from osrl_amd.engine.dist import DataParallel
+        dp = DataParallel()
+
+    model, trainer, store = build(device, rank, world)
+    eng = model.engine(B, rows_global=B * world, seed=1234 + rank, dist=dp) if world > 1 else model.engine(B)
+    eng.attach_replay(store)
+    if dp is not None:
+        dp.broadcast_model(model)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    use_graph = not args.eager
+    for _ in range(args.warmup):
+        eng.step_replay(use_graph)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step_replay(use_graph)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stats = eng.st.read_stats()
+    assert all(np.isfinite(v) for v in stats.values()), stats
+    assert eng.st.device_step() == args.warmup + args.steps
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "grad-steps/sec", "value": round(world * args.steps / dt, 2),
+            "unit": "grad-steps/s (one step = one 2048-transition CPQ gradient step)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "CPQ train_one_step, OfflinePointGoal1-shaped (obs 76, act 2), batch 2048/GPU, "
+                                   "hidden [256,256], VAE 400, N=10, num_q=num_qc=2; on-device replay sampling "
+                                   "from a 2^20-transition HBM store + Philox noise inside the step",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "graph": bool(use_graph and world == 1)},
+            "algorithmic_gflop_per_step": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / 1e9, 2),
+            "step_tflops": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / (dt / args.steps) / 1e12, 3),
+            "last_stats": {k: round(float(v), 5) for k, v in stats.items()},
+        }
+        if not args.no_roofline:
+            out["roofline"] = roofline(eng)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Device-resident transition store + on-device uniform sampler.
+
+Replaces the reference's minibatch source -- ``TransitionDataset`` (osrl/common/dataset.py:790-847:
+``done = terminals | timeouts`` as fp32 :815-816, ``rewards*reward_scale``, ``costs*cost_scale``,
+one uniform-with-replacement index per sample :846) + torch ``DataLoader`` + six ``.to(device)``
+copies per step (examples/train/train_cpq.py:122-142) -- with tables that stay in HBM and a gather
+kernel (csrc/rng.hip ``osrl_replay_gather``) that draws the indices on device inside the captured
+train step.  In the data-parallel setting every rank holds its own shard of the transitions
+(``shard(rank, world)``) and samples locally: with random partitions this is distributionally the
+same as global uniform sampling.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..engine.core import cur_stream
+
+FIELDS = ("observations", "next_observations", "actions", "rewards", "costs", "done")
+
+
+class ReplayStore:
+    def __init__(self, data: Dict[str, "np.ndarray | torch.Tensor"], device, reward_scale: float = 1.0,
+                 cost_scale: float = 1.0, seed: int = 0, rank: int = 0, world: int = 1):
+        """``data`` uses the DSRL dataset keys (observations, next_observations, actions, rewards, costs,
+        and either ``done`` or ``terminals``+``timeouts``)."""
+        d = dict(data)
+        if "done" not in d:
+            d["done"] = np.logical_or(np.asarray(d["terminals"]) == 1, np.asarray(d["timeouts"]) == 1)
+        n = len(d["observations"])
+        sl = slice(rank, n, world) if world > 1 else slice(None)
+        self.tables = []
+        for k in FIELDS:
+            t = torch.as_tensor(np.asarray(d[k])[sl] if not torch.is_tensor(d[k]) else d[k][sl])
+            t = t.to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous()
+            self.tables.append(t)
+        self.n_rows = self.tables[0].shape[0]
+        self.widths = [t.shape[1] for t in self.tables]
+        self.scales = [1.0, 1.0, 1.0, float(reward_scale), float(cost_scale), 1.0]
+        self.seed = int(seed) * 1000003 + rank
+        self.device = torch.device(device)
+        self._src = (C.c_void_p * 6)(*[t.data_ptr() for t in self.tables])
+        self._w = (C.c_int32 * 6)(*self.widths)
+        self._s = (C.c_float * 6)(*self.scales)
+        self.bytes_per_row = 4 * sum(self.widths)
+
+    def gather(self, dst: Sequence[torch.Tensor], st_ptr: Optional[int], idx_out: Optional[torch.Tensor] = None,
+               stream_id: int = 1) -> None:
+        """dst = (obs, next_obs, act, rew, cost, done) batch buffers; asynchronous on the current stream."""
+        B = dst[0].shape[0]
+        d = (C.c_void_p * 6)(*[t.data_ptr() for t in dst])
+        L.check(L.load().osrl_replay_gather(6, self._src, d, self._w, self._s, self.n_rows, B,
+                                            None if idx_out is None else idx_out.data_ptr(), self.seed, stream_id,
+                                            st_ptr, cur_stream()), "osrl_replay_gather")
+
+
+def synthetic_transitions(n: int, od: int, ad: int, seed: int = 1, max_action: float = 1.0) -> Dict[str, np.ndarray]:
+    """Synthetic DSRL-shaped data: obs~N(0,1), act~U(-1,1), rew~N(0,1), cost~Bern(.1),
+    terminals~Bern(.01)."""
+    rs = np.random.RandomState(seed)
+    f = np.float32
+    return dict(observations=rs.randn(n, od).astype(f), next_observations=rs.randn(n, od).astype(f),
+                actions=(rs.uniform(-1, 1, (n, ad)) * max_action).astype(f), rewards=rs.randn(n).astype(f),
+                costs=(rs.uniform(size=n) < 0.1).astype(f), terminals=(rs.uniform(size=n) < 0.01).astype(f),
+                timeouts=np.zeros(n, f))

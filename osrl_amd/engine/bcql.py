@@ -96,6 +96,7 @@ class BCQLEngine:
         self.r_actor.setup_backward(self.dt)
         self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.replay = None
 
     def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
         plan.launch()
@@ -117,6 +118,8 @@ class BCQLEngine:
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         st.tick()
+        if self.replay is not None:
+            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
         if device_noise:
             randn_fill(self.noise_flat, self.seed, 0, st.ptr)
         for k in ("z_c", "z_cc", "z_actor"):  # net.py:334-335 clamps the latent draw
@@ -195,8 +198,26 @@ class BCQLEngine:
         self._restore(snap)
         self.graph = g
 
+    def attach_replay(self, store) -> None:
+        """Sample minibatches on device from ``store`` (common/replay.py) inside the step itself."""
+        self.replay = store
+        self.graph = None
+
+    def step_replay(self, use_graph: bool = True) -> None:
+        """One train step on a minibatch drawn on device from the attached replay store."""
+        assert self.replay is not None
+        if use_graph and self.dist is None:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body(True)
+
     def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
              use_graph: bool = True) -> None:
+        if self.replay is not None:
+            raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done)
         if noise is not None:
             for k in NOISE_KEYS:

@@ -109,6 +109,7 @@ class CPQEngine:
         self.p_actor = DwPlan(g["actor"], self.r_actor_obs.dw_entries(), B, dev)
 
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.replay = None
         self._graph_failed = False
 
     # ------------------------------------------------------------------ #
@@ -125,6 +126,8 @@ class CPQEngine:
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         st.tick()
+        if self.replay is not None:
+            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
         if device_noise:
             randn_fill(self.noise_flat, self.seed, 0, st.ptr)
 
@@ -226,8 +229,26 @@ class CPQEngine:
             if t is not None:
                 g.tgt.copy_(t)
 
+    def attach_replay(self, store) -> None:
+        """Sample minibatches on device from ``store`` (common/replay.py) inside the step itself."""
+        self.replay = store
+        self.graph = None
+
+    def step_replay(self, use_graph: bool = True) -> None:
+        """One train step on a minibatch drawn on device from the attached replay store."""
+        assert self.replay is not None
+        if use_graph and self.dist is None:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body(True)
+
     def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
              use_graph: bool = True) -> None:
+        if self.replay is not None:
+            raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done)
         if noise is not None:
             self.load_noise(noise)
