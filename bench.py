@@ -119,23 +119,37 @@ def cpu_baseline(budget_s=20.0):
     b, nz = make_batch(c), make_noise(c, 0)
     args = (b["observations"], b["next_observations"], b["actions"], b["rewards"], b["costs"], b["done"], nz)
     o.train_one_step(*args)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        o.train_one_step(*args)
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 200:
-            break
-    dt = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        nt = [p.get("num_threads") for p in threadpool_info() if p.get("user_api") == "blas"]
-        cores = max(nt) if nt else cores
-    except Exception:
-        pass
-    return {"value": round(n / dt, 3), "unit": "grad-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} CPQ steps (76,2) B=2048 of the numpy oracle, OpenBLAS threads={cores}, {dt:.1f}s"}
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+
+    def run(nthreads, budget, max_steps=200):
+        ctx = threadpool_limits(limits=nthreads, user_api="blas") if threadpool_limits else None
+        try:
+            o.train_one_step(*args)
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                o.train_one_step(*args)
+                n += 1
+                if time.perf_counter() - t0 > budget or n >= max_steps:
+                    break
+            return n, time.perf_counter() - t0
+        finally:
+            if ctx is not None:
+                ctx.unregister() if hasattr(ctx, "unregister") else ctx.__exit__(None, None, None)
+
+    # OpenBLAS oversubscribes on big hosts: probe a few thread counts briefly, keep the fastest
+    cands = sorted({c for c in (4, 8, 16, 32, ncpu) if c <= ncpu}) if threadpool_limits else [ncpu]
+    probe = {c: run(c, budget_s / (2.0 * len(cands))) for c in cands}
+    best = max(probe, key=lambda c: probe[c][0] / probe[c][1])
+    n, dt = run(best, budget_s / 2.0)
+    return {"value": round(n / dt, 3), "unit": "grad-steps/s", "cores": int(best), "kind": "port",
+            "sample": f"{n} CPQ steps (76,2) B=2048 of the numpy oracle in {dt:.1f}s at {best} BLAS threads "
+                      f"(best of {cands} on a {ncpu}-cpu host; reference default is 4 threads: "
+                      f"{probe[min(cands)][0] / probe[min(cands)][1]:.2f} steps/s at {min(cands)})"}
 
 
 def main():

@@ -40,7 +40,7 @@ typedef struct {
   int32_t dims[OSRL_MAX_LAYERS + 1]; /* in, h1, ..., out */
   int32_t acts[OSRL_MAX_LAYERS];     /* activation after each layer */
   float out_scale;                   /* net output = out_scale * act(z)  (act_limit of net.py:62,85,339) */
-  int32_t pad_;
+  int32_t tile_rows;                 /* tuning hint: rows per workgroup tile (0 = auto, else 16 / 32 / 64) */
   const float* W[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1], dims[l]] */
   const float* b[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1]] */
 } osrl_mlp_t;
@@ -157,12 +157,18 @@ int osrl_quantile(const float* x, int64_t n, float q, float* out, void* stream);
 int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_old, int32_t n_qc_old,
                          const float* q, int32_t n_q, const float* rew, const float* done, int32_t rows,
                          float gamma, float q_thres, int32_t rows_global, float* dq, float* stat, void* stream);
-/* CPQ cost-critic loss (cpq.py:161,181-199): backup = c + gamma*min qc_old; qc_ood from kl >= quantile;
- * log_alpha (device scalar) updated in place; stat[0] = loss, stat[1] = exp(log_alpha) after update. */
+/* out[0] = mean over the (global) batch of qc_ood = ((KL >= quantile) * min_e qc_sampled).mean(0)
+ * (cpq.py:184,187); under data parallelism this rank's share, to be all-reduced(SUM). */
+int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl, const float* quantile,
+                      int32_t n_samples, int32_t rows, int32_t rows_global, float* out, void* stream);
+/* CPQ cost-critic loss (cpq.py:161,186-199): backup = c + gamma*min qc_old; dq = 2(qc-backup)/B;
+ * log_alpha (device scalar) ascends with the GLOBAL ood_mean (device scalar) and is clamped to +-5;
+ * stat[0] = loss, stat[1] = exp(log_alpha) after the update.  stat_share = 1/world_size scales the
+ * batch-global terms of the statistics so that an all-reduce(SUM) of per-rank stats is exact. */
 int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* qc, int32_t n_qc,
-                       const float* qc_sampled, const float* kl, const float* quantile, int32_t n_samples,
-                       const float* cost, int32_t rows, float gamma, float qc_thres, float alpha_lr,
-                       int32_t rows_global, float* log_alpha, float* dq, float* stat, void* stream);
+                       const float* ood_mean, const float* cost, int32_t rows, float gamma, float qc_thres,
+                       float alpha_lr, int32_t rows_global, float stat_share, float* log_alpha, float* dq,
+                       float* stat, void* stream);
 /* CPQ actor loss (cpq.py:210-212): loss = -mean(1[min qc <= thres] * min q); dq routed to arg-min net. */
 int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_qc, int32_t rows,
                         float q_thres, int32_t rows_global, float* dq, float* stat, void* stream);

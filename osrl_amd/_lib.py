@@ -9,6 +9,10 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch bundles its own libamdhip64 / libhsa-runtime64; it must be loaded BEFORE libosrl_amd.so so
+# that both share ONE HIP runtime (streams created by torch are then valid handles for our launches).
+import torch  # noqa: F401  (import order matters)
+
 MAX_LAYERS = 4
 MAX_NETS = 8
 MAX_WIDTH = 448
@@ -24,7 +28,7 @@ _fp = C.c_void_p  # device float*
 class MlpT(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("n_nets", C.c_int32),
                 ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
-                ("out_scale", C.c_float), ("pad_", C.c_int32),
+                ("out_scale", C.c_float), ("tile_rows", C.c_int32),
                 ("W", (_fp * MAX_LAYERS) * MAX_NETS), ("b", (_fp * MAX_LAYERS) * MAX_NETS)]
 
 
@@ -76,8 +80,8 @@ PROTOTYPES = {
     "osrl_vae_kl_rows": [_fp, _i32, _i32, _fp, _vp],
     "osrl_quantile": [_fp, _i64, _f32, _fp, _vp],
     "osrl_cpq_critic_loss": [_fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
-    "osrl_cpq_cost_loss": [_fp, _i32, _fp, _i32, _fp, _fp, _fp, _i32, _fp, _i32, _f32, _f32, _f32, _i32, _fp,
-                           _fp, _fp, _vp],
+    "osrl_cpq_ood_mean": [_fp, _i32, _fp, _fp, _i32, _i32, _i32, _fp, _vp],
+    "osrl_cpq_cost_loss": [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _f32, _i32, _f32, _fp, _fp, _fp, _vp],
     "osrl_cpq_actor_loss": [_fp, _i32, _fp, _i32, _i32, _f32, _i32, _fp, _fp, _vp],
     "osrl_mse_loss": [_fp, _fp, _i64, _i64, _fp, _fp, _vp],
     "osrl_clamp": [_fp, _i64, _f32, _f32, _vp],

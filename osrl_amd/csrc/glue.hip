@@ -168,33 +168,64 @@ __device__ __forceinline__ uint32_t f2key(float f) {  // order-preserving float 
 __device__ __forceinline__ float key2f(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+// Histogram add with wave-level pre-aggregation: the top bytes of real-valued keys are concentrated in
+// a few bins, where per-lane LDS atomics on one address serialise (the first version of this kernel
+// spent 94 us there).  Up to 4 rounds elect a leader bin and add its popcount once; lanes still
+// unserved after that (spread-out bins, no contention) fall back to plain LDS atomics.
+__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t bin, bool active) {
+  unsigned long long remaining = __ballot(active);
+#pragma unroll 1
+  for (int round = 0; round < 4 && remaining; ++round) {
+    const int lead = __ffsll((long long)remaining) - 1;
+    const uint32_t lb = __shfl(bin, lead);
+    const unsigned long long m = __ballot(active && bin == lb);
+    if ((int)(threadIdx.x & 63) == lead) atomicAdd(&hist[lb], (uint32_t)__popcll(m));
+    if (bin == lb) active = false;
+    remaining &= ~m;
+  }
+  if (active) atomicAdd(&hist[bin], 1u);
+}
+
 // k-th smallest (0-based) key among x[0..n); every thread returns it.  hist: 256 uints in LDS.
+// bc[2] returns the number of elements <= the selected key (for the interpolation partner).
 __device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t k, uint32_t* hist,
-                                 uint32_t* bc /*2 uints*/) {
+                                 uint32_t* bc /*4 uints*/) {
   uint32_t prefix = 0, mask = 0;
+  int64_t below = 0;  // elements strictly below the current prefix range
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint32_t key = f2key(x[i]);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    const int64_t nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
+    for (int64_t i = threadIdx.x; i < nround; i += blockDim.x) {
+      uint32_t key = 0;
+      bool act = false;
+      if (i < n) {
+        key = f2key(x[i]);
+        act = (key & mask) == prefix;
+      }
+      hist_add(hist, (key >> shift) & 255u, act);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       int64_t kk = k;
-      uint32_t d = 0;
+      uint32_t d = 0, acc = 0;
       for (; d < 256; ++d) {
         const uint32_t c = hist[d];
         if (kk < (int64_t)c) break;
         kk -= c;
+        acc += c;
       }
       bc[0] = d;
       bc[1] = (uint32_t)kk;
+      bc[2] = acc;          // elements in lower bins of this pass
+      bc[3] = hist[d];      // elements in the chosen bin
     }
     __syncthreads();
     prefix |= bc[0] << shift;
     mask |= 255u << shift;
     k = bc[1];
+    below += bc[2];
+    if (shift == 0) bc[2] = (uint32_t)(below + bc[3]);  // count of elements <= selected key
     __syncthreads();
   }
   return prefix;
@@ -203,15 +234,42 @@ __device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t
 __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict__ x, int64_t n, float q,
                                                         float* __restrict__ out) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t bc[2];
+  __shared__ uint32_t bc[4];
+  __shared__ uint32_t s_min[16];
   // torch.quantile 'linear': pos = q*(n-1); lo=floor(pos); result = x_lo + (x_hi-x_lo)*(pos-lo)
   const double pos = (double)q * (double)(n - 1);
   const int64_t lo = (int64_t)floor(pos);
   const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
   const float w = (float)(pos - (double)lo);
-  const float vlo = key2f(radix_select(x, n, lo, hist, bc));
-  const float vhi = hi == lo ? vlo : key2f(radix_select(x, n, hi, hist, bc));
-  if (threadIdx.x == 0) out[0] = vlo + (vhi - vlo) * w;
+  const uint32_t klo = radix_select(x, n, lo, hist, bc);
+  const int64_t n_le = bc[2];
+  uint32_t khi = klo;
+  if (hi != lo && n_le < hi + 1) {
+    // the (lo+1)-th order statistic is the smallest key strictly above klo: one min-reduction pass
+    uint32_t mn = 0xffffffffu;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t key = f2key(x[i]);
+      if (key > klo && key < mn) mn = key;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint32_t other = __shfl_xor(mn, o);
+      mn = other < mn ? other : mn;
+    }
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = s_min[0];
+      for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = s_min[i] < t ? s_min[i] : t;
+      s_min[0] = t;
+    }
+    __syncthreads();
+    khi = s_min[0];
+  }
+  if (threadIdx.x == 0) {
+    const float vlo = key2f(klo), vhi = key2f(khi);
+    out[0] = vlo + (vhi - vlo) * w;
+  }
 }
 
 // ---------------- CPQ ----------------
@@ -245,15 +303,34 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
   if (threadIdx.x == 0 && stat) stat[0] = loss * inv_rows;
 }
 
-__global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
-    const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
-    const float* __restrict__ qc_sampled, const float* __restrict__ kl, const float* __restrict__ quantile,
-    int n_samples, const float* __restrict__ cost, int rows, float gamma, float qc_thres, float alpha_lr,
-    float inv_rows, float* __restrict__ log_alpha, float* __restrict__ dq, float* __restrict__ stat) {
+// mean over the (global) batch of qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184,187
+__global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restrict__ qc_sampled, int n_qc_old,
+                                                            const float* __restrict__ kl,
+                                                            const float* __restrict__ quantile, int n_samples,
+                                                            int rows, float inv_rows, float* __restrict__ out) {
   __shared__ float sm[20];
-  float loss = 0.f, ood = 0.f;
+  float ood = 0.f;
   const float quant = quantile[0];
   const int nr = n_samples * rows;
+  for (int b = threadIdx.x; b < rows; b += kRed) {
+    float s = 0.f;
+    for (int j = 0; j < n_samples; ++j) {
+      const int i = j * rows + b;
+      if (kl[i] >= quant) s += min_over(qc_sampled, n_qc_old, nr, i);
+    }
+    ood += s / (float)n_samples;
+  }
+  ood = block_sum(ood, sm);
+  if (threadIdx.x == 0) out[0] = ood * inv_rows;
+}
+
+__global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
+    const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
+    const float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
+    float alpha_lr, float inv_rows, float stat_share, float* __restrict__ log_alpha, float* __restrict__ dq,
+    float* __restrict__ stat) {
+  __shared__ float sm[20];
+  float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
     const float backup = cost[b] + gamma * min_over(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
     for (int e = 0; e < n_qc; ++e) {
@@ -261,24 +338,19 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
       loss += d * d;
       dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
     }
-    float s = 0.f;  // qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184
-    for (int j = 0; j < n_samples; ++j) {
-      const int i = j * rows + b;
-      if (kl[i] >= quant) s += min_over(qc_sampled, n_qc_old, nr, i);
-    }
-    ood += s / (float)n_samples;
   }
   loss = block_sum(loss, sm);
-  ood = block_sum(ood, sm);
   if (threadIdx.x == 0) {
-    const float ood_mean = ood * inv_rows;
+    const float ood_mean = ood_mean_p[0];
     float la = log_alpha[0];
     const float ea = expf(la);
-    if (stat) stat[0] = loss * inv_rows - ea * (ood_mean - qc_thres);  // cpq.py:186-187
-    la += alpha_lr * ea * (qc_thres - ood_mean);                      // cpq.py:193-194
+    // cpq.py:186-187; under data parallelism the mse part is this rank's partial sum and the global
+    // terms are pre-divided by the world size (stat_share) so that an all-reduce(SUM) restores them
+    if (stat) stat[0] = loss * inv_rows - stat_share * ea * (ood_mean - qc_thres);
+    la += alpha_lr * ea * (qc_thres - ood_mean);  // cpq.py:193-194
     la = fminf(fmaxf(la, -5.0f), 5.0f);
     log_alpha[0] = la;
-    if (stat) stat[1] = expf(la);
+    if (stat) stat[1] = stat_share * expf(la);
   }
 }
 
@@ -446,6 +518,7 @@ extern "C" {
 int osrl_gauss_head(const float* head, const float* eps, int32_t rows, int32_t ad, float max_action, float* a,
                     float* tanh_u, float* logp, void* stream) {
   if (!head || rows < 1 || ad < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(gauss_head_kernel, GRID_1D(rows), 0, S, head, eps, rows, ad, max_action, a, tanh_u, logp);
   LAUNCH_CHECK();
 }
@@ -453,6 +526,7 @@ int osrl_gauss_head(const float* head, const float* eps, int32_t rows, int32_t a
 int osrl_gauss_head_bwd(const float* head, const float* eps, const float* tanh_u, const float* da_nets,
                         int32_t n_nets, int32_t rows, int32_t ad, float max_action, float* dhead, void* stream) {
   if (!head || !eps || !tanh_u || !da_nets || !dhead || rows < 1 || ad < 1 || n_nets < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(gauss_head_bwd_kernel, GRID_1D(rows * ad), 0, S, head, eps, tanh_u, da_nets, n_nets, rows, ad,
                      max_action, dhead);
   LAUNCH_CHECK();
@@ -462,12 +536,14 @@ int osrl_gauss_ood_sample(const float* head, const float* eps, int32_t n_samples
                           float* out, void* stream) {
   if (!head || !eps || !out || n_samples < 1 || rows < 1 || ad < 1) return -1;
   const int64_t n = (int64_t)n_samples * rows * ad;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(gauss_ood_kernel, GRID_1D(n), 0, S, head, eps, n_samples, rows, ad, out);
   LAUNCH_CHECK();
 }
 
 int osrl_vae_latent(const float* head, const float* eps, int32_t rows, int32_t L, float* z, void* stream) {
   if (!head || !eps || !z || rows < 1 || L < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(vae_latent_kernel, GRID_1D(rows * L), 0, S, head, eps, rows, L, z);
   LAUNCH_CHECK();
 }
@@ -475,6 +551,7 @@ int osrl_vae_latent(const float* head, const float* eps, int32_t rows, int32_t L
 int osrl_vae_loss(const float* u, const float* act, const float* head, int32_t rows, int32_t ad, int32_t L,
                   float beta, int32_t rows_global, float* du, float* stat, void* stream) {
   if (!u || !act || !head || !du || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(kRed), 0, S, u, act, head, rows, ad, L, beta,
                      1.0f / (float)(rows_global > 0 ? rows_global : rows), du, stat);
   LAUNCH_CHECK();
@@ -483,6 +560,7 @@ int osrl_vae_loss(const float* u, const float* act, const float* head, int32_t r
 int osrl_vae_latent_bwd(const float* head, const float* eps, const float* dz, int32_t rows, int32_t L, float beta,
                         int32_t rows_global, float* dhead, void* stream) {
   if (!head || !eps || !dz || !dhead || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(vae_latent_bwd_kernel, GRID_1D(rows * L), 0, S, head, eps, dz, rows, L, beta,
                      1.0f / (float)(rows_global > 0 ? rows_global : rows), dhead);
   LAUNCH_CHECK();
@@ -490,12 +568,14 @@ int osrl_vae_latent_bwd(const float* head, const float* eps, const float* dz, in
 
 int osrl_vae_kl_rows(const float* head, int32_t rows, int32_t L, float* kl, void* stream) {
   if (!head || !kl || rows < 1 || L < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(vae_kl_rows_kernel, GRID_1D(rows), 0, S, head, rows, L, kl);
   LAUNCH_CHECK();
 }
 
 int osrl_quantile(const float* x, int64_t n, float q, float* out, void* stream) {
   if (!x || !out || n < 1 || q < 0.f || q > 1.f) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(quantile_kernel, dim3(1), dim3(kRed), 0, S, x, n, q, out);
   LAUNCH_CHECK();
 }
@@ -504,25 +584,37 @@ int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_ol
                          const float* q, int32_t n_q, const float* rew, const float* done, int32_t rows,
                          float gamma, float q_thres, int32_t rows_global, float* dq, float* stat, void* stream) {
   if (!q_old || !qc_old || !q || !rew || !done || !dq || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cpq_critic_loss_kernel, dim3(1), dim3(kRed), 0, S, q_old, n_q_old, qc_old, n_qc_old, q, n_q,
                      rew, done, rows, gamma, q_thres, 1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
   LAUNCH_CHECK();
 }
 
+int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl, const float* quantile,
+                      int32_t n_samples, int32_t rows, int32_t rows_global, float* out, void* stream) {
+  if (!qc_sampled || !kl || !quantile || !out || rows < 1 || n_samples < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(cpq_ood_mean_kernel, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, quantile, n_samples,
+                     rows, 1.0f / (float)(rows_global > 0 ? rows_global : rows), out);
+  LAUNCH_CHECK();
+}
+
 int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* qc, int32_t n_qc,
-                       const float* qc_sampled, const float* kl, const float* quantile, int32_t n_samples,
-                       const float* cost, int32_t rows, float gamma, float qc_thres, float alpha_lr,
-                       int32_t rows_global, float* log_alpha, float* dq, float* stat, void* stream) {
-  if (!qc_old_next || !qc || !qc_sampled || !kl || !quantile || !cost || !log_alpha || !dq || rows < 1) return -1;
-  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc, qc_sampled,
-                     kl, quantile, n_samples, cost, rows, gamma, qc_thres, alpha_lr,
-                     1.0f / (float)(rows_global > 0 ? rows_global : rows), log_alpha, dq, stat);
+                       const float* ood_mean, const float* cost, int32_t rows, float gamma, float qc_thres,
+                       float alpha_lr, int32_t rows_global, float stat_share, float* log_alpha, float* dq,
+                       float* stat, void* stream) {
+  if (!qc_old_next || !qc || !ood_mean || !cost || !log_alpha || !dq || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc, ood_mean,
+                     cost, rows, gamma, qc_thres, alpha_lr, 1.0f / (float)(rows_global > 0 ? rows_global : rows),
+                     stat_share, log_alpha, dq, stat);
   LAUNCH_CHECK();
 }
 
 int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_qc, int32_t rows, float q_thres,
                         int32_t rows_global, float* dq, float* stat, void* stream) {
   if (!q || !qc || !dq || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cpq_actor_loss_kernel, dim3(1), dim3(kRed), 0, S, q, n_q, qc, n_qc, rows, q_thres,
                      1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
   LAUNCH_CHECK();
@@ -531,6 +623,7 @@ int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_
 int osrl_mse_loss(const float* u, const float* target, int64_t n, int64_t n_global, float* du, float* stat,
                   void* stream) {
   if (!u || !target || !du || n < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(kRed), 0, S, u, target, (int)n,
                      1.0f / (float)(n_global > 0 ? n_global : n), du, stat);
   LAUNCH_CHECK();
@@ -538,6 +631,7 @@ int osrl_mse_loss(const float* u, const float* target, int64_t n, int64_t n_glob
 
 int osrl_clamp(float* x, int64_t n, float lo, float hi, void* stream) {
   if (!x || n < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(clamp_kernel, GRID_1D(n), 0, S, x, n, lo, hi);
   LAUNCH_CHECK();
 }
@@ -545,6 +639,7 @@ int osrl_clamp(float* x, int64_t n, float lo, float hi, void* stream) {
 int osrl_bcq_perturb(const float* dec, const float* t, int32_t rows, int32_t ad, float phi, float max_action,
                      float* a, void* stream) {
   if (!dec || !t || !a || rows < 1 || ad < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(bcq_perturb_kernel, GRID_1D((int64_t)rows * ad), 0, S, dec, t, rows * ad, phi, max_action, a);
   LAUNCH_CHECK();
 }
@@ -552,6 +647,7 @@ int osrl_bcq_perturb(const float* dec, const float* t, int32_t rows, int32_t ad,
 int osrl_bcq_perturb_bwd(const float* dec, const float* t, const float* da_nets, int32_t n_nets, int32_t rows,
                          int32_t ad, float phi, float max_action, float* dt, void* stream) {
   if (!dec || !t || !da_nets || !dt || rows < 1 || ad < 1 || n_nets < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(bcq_perturb_bwd_kernel, GRID_1D((int64_t)rows * ad), 0, S, dec, t, da_nets, n_nets, rows * ad,
                      phi, max_action, dt);
   LAUNCH_CHECK();
@@ -561,6 +657,7 @@ int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_sam
                          int32_t n_on, const float* base, const float* done, int32_t rows, float gamma,
                          float lmbda, int32_t rows_global, float* dq, float* stat, void* stream) {
   if (!q_t || !q_on || !base || !dq || rows < 1 || n1 < 1 || n2 < 1 || n_samples < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(bcq_critic_loss_kernel, dim3(1), dim3(kRed), 0, S, q_t, n1, n2, n_samples, q_on, n_on, base,
                      done, rows, gamma, lmbda, 1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
   LAUNCH_CHECK();
@@ -570,6 +667,7 @@ int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* q
                         int32_t rows, float qc_thres, float KP, float KI, float KD, int32_t rows_global,
                         float* pid, float* dq, float* dqc, float* stat, void* stream) {
   if (!q || !qc || !pid || !dq || !dqc || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(bcq_actor_loss_kernel, dim3(1), dim3(kRed), 0, S, q, nq1, nq2, qc, nc1, nc2, rows, qc_thres,
                      KP, KI, KD, 1.0f / (float)(rows_global > 0 ? rows_global : rows), pid, dq, dqc, stat);
   LAUNCH_CHECK();

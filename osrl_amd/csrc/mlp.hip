@@ -50,61 +50,112 @@ __device__ __forceinline__ int map_row(int r, int map, int div) {
 }
 __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 
-// B fragment for 4 consecutive k of output column n.
+// B fragment for 4 consecutive k of output column n  (k-slot trick: the 4 values feed 4 MFMAs).
 //  BT == false : B[k][n] = W[n*ldw + k]   (forward:  W is [N,K] row-major)
 //  BT == true  : B[k][n] = W[k*ldw + n]   (backward: W is [K,N] row-major)
-template <bool BT>
-__device__ __forceinline__ f32x4 load_b4(const float* __restrict__ W, int K, int N, int ldw, int n, int k,
-                                         bool vec_ok) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (n < N) {
+// FAST: the whole fragment is in range and (forward) 16-byte aligned -> no predicates at all.
+// Generic: branch-free clamped addresses + selects, so the k-loop stays straight-line code.
+template <bool BT, bool FAST>
+__device__ __forceinline__ f32x4 load_b4(const float* __restrict__ W, int K, int N, int ldw, int n, int k) {
+  f32x4 v;
+  if (FAST) {
     if (!BT) {
-      const float* p = W + (size_t)n * ldw + k;
-      if (vec_ok && k + 3 < K) {
-        v = *reinterpret_cast<const f32x4*>(p);
-      } else {
-        if (k + 0 < K) v[0] = p[0];
-        if (k + 1 < K) v[1] = p[1];
-        if (k + 2 < K) v[2] = p[2];
-        if (k + 3 < K) v[3] = p[3];
-      }
+      v = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + k);
     } else {
       const float* p = W + (size_t)k * ldw + n;
-      if (k + 0 < K) v[0] = p[0];
-      if (k + 1 < K) v[1] = p[(size_t)ldw];
-      if (k + 2 < K) v[2] = p[2 * (size_t)ldw];
-      if (k + 3 < K) v[3] = p[3 * (size_t)ldw];
+      v[0] = p[0];
+      v[1] = p[(size_t)ldw];
+      v[2] = p[2 * (size_t)ldw];
+      v[3] = p[3 * (size_t)ldw];
+    }
+  } else {
+    const bool nok = n < N;
+    const int nc = nok ? n : N - 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kk = k + t;
+      const int kc = kk < K ? kk : K - 1;
+      const float x = BT ? W[(size_t)kc * ldw + nc] : W[(size_t)nc * ldw + kc];
+      v[t] = (nok && kk < K) ? x : 0.f;
     }
   }
   return v;
 }
 
-// acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols (cb0+c)*16..)   over k in [0,Kp)
-template <int NRB, int NCB, bool BT>
-__device__ __forceinline__ void layer_mm(const float* lds, int lda, int Kp, const float* __restrict__ W, int K,
-                                         int N, int ldw, int cb0, int cnt, f32x4 (&acc)[NRB][NCB]) {
+// acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols (cb0+c)*16..)   over k in [0,Kp), c < CNT.
+// Software pipeline: a ring of STAGES B-fragment sets keeps STAGES-1 k-steps of weight loads in
+// flight (global -> VGPR, straight from L2) while the MFMAs of the current step run; the A
+// fragments (ds_read_b128 from the LDS activation tile) are prefetched one step ahead.
+template <int NRB, int NCB, int CNT, bool BT, bool FAST, int STAGES>
+__device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int Kp, const float* __restrict__ W, int K,
+                                              int N, int ldw, int cb0, f32x4 (&acc)[NRB][NCB]) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
-  const bool vec_ok = (!BT) && ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-  f32x4 a[NRB], b[NCB];
-
-  for (int k0 = 0; k0 < Kp; k0 += 16) {
+  const int nk = Kp >> 4;
+  const int n0 = cb0 * 16 + m;
+  f32x4 b[STAGES][CNT];
+  f32x4 a[2][NRB];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0);
+  for (int s = 0; s < STAGES - 1; ++s) {
+    const int kc = s < nk ? s : nk - 1;
 #pragma unroll
-    for (int c = 0; c < NCB; ++c)
-      if (c < cnt) b[c] = load_b4<BT>(W, K, N, ldw, (cb0 + c) * 16 + m, k0 + 4 * kq, vec_ok);
+    for (int c = 0; c < CNT; ++c) b[s][c] = load_b4<BT, FAST>(W, K, N, ldw, n0 + c * 16, kc * 16 + 4 * kq);
+  }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+  for (int rb = 0; rb < NRB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda);
+  for (int kb = 0; kb < nk; kb += 2 * STAGES) {
 #pragma unroll
-      for (int c = 0; c < NCB; ++c) {
-        if (c < cnt) {
+    for (int s = 0; s < 2 * STAGES; ++s) {
+      const int kc = kb + s;
+      if (kc < nk) {
+        {  // issue the loads of k-step kc + STAGES - 1 into the ring slot freed by step kc - 1
+          int kl = kc + STAGES - 1;
+          kl = kl < nk ? kl : nk - 1;
+#pragma unroll
+          for (int c = 0; c < CNT; ++c)
+            b[(s + STAGES - 1) % STAGES][c] = load_b4<BT, FAST>(W, K, N, ldw, n0 + c * 16, kl * 16 + 4 * kq);
+          int ka = kc + 1 < nk ? kc + 1 : kc;
 #pragma unroll
           for (int rb = 0; rb < NRB; ++rb)
-            acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][t], b[c][t], acc[rb][c], 0, 0, 0);
+            a[(s + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ka * 16);
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < CNT; ++c)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+              acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][rb][t], b[s % STAGES][c][t], acc[rb][c], 0, 0, 0);
       }
+    }
+  }
+}
+
+template <int NRB, int NCB, bool BT>
+__device__ __forceinline__ void layer_mm(const float* lds, int lda, int Kp, const float* __restrict__ W, int K,
+                                         int N, int ldw, int cb0, int cnt, f32x4 (&acc)[NRB][NCB]) {
+  constexpr int STAGES = (NRB * NCB >= 16) ? 2 : 3;  // short k-steps need a deeper load ring
+  const bool full = cnt == NCB && (cb0 + NCB) * 16 <= N;
+  const bool fast = full && (K & 15) == 0 &&
+                    (BT || (((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)));
+  if (fast) {
+    layer_mm_core<NRB, NCB, NCB, BT, true, STAGES>(lds, lda, Kp, W, K, N, ldw, cb0, acc);
+  } else if (cnt == NCB) {
+    layer_mm_core<NRB, NCB, NCB, BT, false, STAGES>(lds, lda, Kp, W, K, N, ldw, cb0, acc);
+  } else {
+    // ragged wave (fewer column blocks): one block at a time keeps the code small
+    for (int c = 0; c < cnt; ++c) {
+      f32x4 t[NRB][1];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      layer_mm_core<NRB, 1, 1, BT, false, 3>(lds, lda, Kp, W, K, N, ldw, cb0 + c, t);
+#pragma unroll
+      for (int cc = 0; cc < NCB; ++cc)
+        if (cc == c) {
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) acc[rb][cc] = t[rb][0];
+        }
     }
   }
 }
@@ -433,6 +484,8 @@ inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) 
   } else {
     t.nrb = wg64 >= 512 ? 4 : wg32 >= 256 ? 2 : 1;
   }
+  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7))
+    t.nrb = net->tile_rows / 16;
   return t;
 }
 
@@ -446,6 +499,7 @@ int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int ld
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
   }
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, stream, args);
   return (int)hipGetLastError();
 }
@@ -521,6 +575,7 @@ extern "C" int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int3
   int rps = (rows + n_splits - 1) / n_splits;
   rps = (rps + 15) & ~15;
   dim3 grid((n_items + 3) / 4, n_splits, 1);
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_entries, d_items, n_items, rows,
                      rps, slabs, slab_stride);
   return (int)hipGetLastError();

@@ -92,6 +92,7 @@ extern "C" int osrl_step_tick(osrl_step_state_t* st, float beta1, float beta2, i
                               const float* stats_cur, float* ring, int32_t n_stats, int32_t ring_len,
                               void* stream) {
   if (!st) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st, beta1, beta2, warmup,
                      stats_cur, ring, n_stats, ring_len > 0 ? ring_len : 1);
   return (int)hipGetLastError();
@@ -102,6 +103,7 @@ extern "C" int osrl_adam_step(float* p, float* m, float* v, float* tgt, const fl
                               float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
                               void* stream) {
   if (!p || !m || !v || !slabs || !st || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, tgt, slabs,
                      n_splits, slab_stride, n / 4, lr, beta1, beta2, eps, weight_decay, tau, gscale, st);
   return (int)hipGetLastError();
@@ -110,6 +112,7 @@ extern "C" int osrl_adam_step(float* p, float* m, float* v, float* tgt, const fl
 extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
                                  void* stream) {
   if (!flat || !slabs || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, flat, slabs,
                      n_splits, slab_stride, n / 4);
   return (int)hipGetLastError();

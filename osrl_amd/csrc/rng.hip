@@ -103,6 +103,7 @@ extern "C" int osrl_randn_fill(float* out, int64_t n, uint64_t seed, uint32_t st
   const int64_t n4 = (n + 3) / 4;
   int64_t blocks = (n4 + 255) / 256;
   blocks = blocks > 4096 ? 4096 : blocks;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(randn_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, n, (uint32_t)seed,
                      (uint32_t)(seed >> 32), stream_id, st);
   return (int)hipGetLastError();
@@ -129,6 +130,7 @@ extern "C" int osrl_replay_gather(int32_t n_fields, const float* const* src, flo
   a.k1 = (uint32_t)(seed >> 32);
   a.stream_id = stream_id;
   a.st = st;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(gather_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -94,6 +94,7 @@ class CPQEngine:
         self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev)
         self.kl = z(N * B)
         self.quant = z(4)
+        self.ood_mean = z(4)
         self.r_cost = MlpRun(self.d_cost, B, True, dev)
         self.dqc = z(nqc, B, 1)
         self.r_cost.setup_backward(self.dqc)
@@ -163,9 +164,14 @@ class CPQEngine:
             self.dist.quantile(self.kl, 0.75, self.quant)
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
+        G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+        share = 1.0
+        if self.dist is not None:
+            self.dist.all_reduce_(self.ood_mean)
+            share = 1.0 / self.dist.world
         qc = self.r_cost.forward(self.obs, self.act)
-        G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, qc_s, self.kl, self.quant, N, self.cost, B, m.gamma, m.qc_thres,
-                        m.alpha_lr, rg, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+        G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg,
+                        share, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
         self._optim("cost_critic", self.p_cost, m.tau)
 
@@ -178,6 +184,8 @@ class CPQEngine:
                          self.dhead_actor)
         self.r_actor_obs.backward_dz()
         self._optim("actor", self.p_actor, m.tau)
+        if self.dist is not None:  # per-rank partial statistics -> global values
+            self.dist.all_reduce_(st.stats)
 
     # ------------------------------------------------------------------ #
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:

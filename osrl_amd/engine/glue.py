@@ -63,11 +63,16 @@ def cpq_critic_loss(q_old, n_q_old, qc_old, n_qc_old, q, n_q, rew, done, rows, g
             "osrl_cpq_critic_loss")
 
 
-def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, qc_sampled, kl, quant, n_samples, cost, rows, gamma, qc_thres,
-                  alpha_lr, rows_global, log_alpha, dq, stat):
-    L.check(L.load().osrl_cpq_cost_loss(_p(qc_old_next), n_qc_old, _p(qc), n_qc, _p(qc_sampled), _p(kl), _p(quant),
-                                        n_samples, _p(cost), rows, gamma, qc_thres, alpha_lr, rows_global,
-                                        _p(log_alpha), _p(dq), _p(stat), cur_stream()), "osrl_cpq_cost_loss")
+def cpq_ood_mean(qc_sampled, n_qc_old, kl, quant, n_samples, rows, rows_global, out):
+    L.check(L.load().osrl_cpq_ood_mean(_p(qc_sampled), n_qc_old, _p(kl), _p(quant), n_samples, rows, rows_global,
+                                       _p(out), cur_stream()), "osrl_cpq_ood_mean")
+
+
+def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows, gamma, qc_thres, alpha_lr, rows_global,
+                  stat_share, log_alpha, dq, stat):
+    L.check(L.load().osrl_cpq_cost_loss(_p(qc_old_next), n_qc_old, _p(qc), n_qc, _p(ood_mean), _p(cost), rows, gamma,
+                                        qc_thres, alpha_lr, rows_global, stat_share, _p(log_alpha), _p(dq), _p(stat),
+                                        cur_stream()), "osrl_cpq_cost_loss")
 
 
 def cpq_actor_loss(q, n_q, qc, n_qc, rows, q_thres, rows_global, dq, stat):

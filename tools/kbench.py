@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks (HIP events) for tuning tile shapes / split counts on the GPU box.
+Usage: python tools/kbench.py [--quick]   -> prints one line per (kernel, config)."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from osrl_amd import _lib as L  # noqa: E402
+from osrl_amd.engine import glue as G  # noqa: E402
+from osrl_amd.engine.core import DwPlan, FlatGroup, MlpRun, NetDesc, StepState  # noqa: E402
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters  # us
+
+
+def mk(E, dims, acts, dev, tile_rows=0):
+    grp = FlatGroup("t", dev)
+    for e in range(E):
+        for l in range(len(dims) - 1):
+            grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.add(f"{e}.{l}.b", (dims[l + 1],))
+    grp.finalize()
+    grp.p.uniform_(-0.05, 0.05)
+    nets = [[(grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")) for l in range(len(dims) - 1)] for e in range(E)]
+    keys = [[(f"{e}.{l}.w", f"{e}.{l}.b") for l in range(len(dims) - 1)] for e in range(E)]
+    d = NetDesc(nets, acts, 1.0, keys)
+    d.c.tile_rows = tile_rows
+    return grp, d
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lin = lambda d: sum(a * b for a, b in zip(d[:-1], d[1:]))  # noqa: E731
+    cfgs = [("q x2", 2, [78, 256, 256, 1], ["relu", "relu", "id"], 76),
+            ("q x4", 4, [78, 256, 256, 1], ["relu", "relu", "id"], 76),
+            ("actor", 1, [76, 256, 256, 4], ["relu", "relu", "id"], 76),
+            ("enc", 1, [78, 400, 400, 8], ["relu", "relu", "id"], 76),
+            ("dec", 1, [80, 400, 400, 2], ["relu", "relu", "tanh"], 76)]
+    for name, E, dims, acts, d0 in cfgs:
+        for rows in (2048, 20480):
+            for tr in (16, 32, 64):
+                if tr == 64 and max(dims) > 256:
+                    continue
+                grp, d = mk(E, dims, acts, dev, tr)
+                x0 = torch.randn(rows, d0, device=dev)
+                x1 = torch.randn(rows, dims[0] - d0, device=dev) if dims[0] > d0 else None
+                run = MlpRun(d, rows, rows == 2048, dev)
+                t_f = timeit(lambda: run.forward(x0, x1))
+                fl = 2.0 * rows * E * lin(dims)
+                line = f"fwd {name:6s} rows={rows:6d} tile={tr:2d}: {t_f:8.2f} us  {fl / t_f / 1e6:7.2f} TF/s"
+                if rows == 2048:
+                    dy = torch.randn(E, rows, dims[-1], device=dev)
+                    run.setup_backward(dy, need_dz=True, dx_cols=(d0, dims[0] - d0) if x1 is not None else None)
+                    t_b = timeit(run.backward_dz)
+                    line += f" | bwd_dz {t_b:8.2f} us {2.0 * rows * E * (lin(dims) - dims[0] * dims[1]) / t_b / 1e6:7.2f} TF/s"
+                    if tr == 16:
+                        for ns in (1, 2, 4, 8, 16, 32):
+                            plan = DwPlan(grp, run.dw_entries(), rows, dev, n_splits=ns)
+                            t_w = timeit(plan.launch)
+                            line += f" | dw[S={ns}] {t_w:6.1f}"
+                print(line, flush=True)
+    # quantile / adam
+    x = torch.randn(20480, device=dev).abs()
+    out = torch.zeros(4, device=dev)
+    print(f"quantile n=20480: {timeit(lambda: G.quantile(x, 20480, 0.75, out)):.2f} us")
+    x = torch.randn(163840, device=dev).abs()
+    print(f"quantile n=163840: {timeit(lambda: G.quantile(x, 163840, 0.75, out)):.2f} us")
+    st = StepState(dev, ["x"])
+    st.tick()
+    for n, S in ((388812, 15), (388812, 4), (172552, 8), (86532, 1)):
+        g = FlatGroup("a", dev, True)
+        g.add("w", (n,))
+        g.finalize()
+        g.ensure_slabs(S)
+        g.cur_splits = S
+        print(f"adam n={n} S={S}: {timeit(lambda: g.adam_step(1e-3, st.ptr, tau=0.005)):.2f} us")
+
+
+if __name__ == "__main__":
+    main()
