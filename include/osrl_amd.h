@@ -41,9 +41,20 @@ typedef struct {
   int32_t acts[OSRL_MAX_LAYERS];     /* activation after each layer */
   float out_scale;                   /* net output = out_scale * act(z)  (act_limit of net.py:62,85,339) */
   int32_t tile_rows;                 /* tuning hint: rows per workgroup tile (0 = auto, else 16 / 32 / 64) */
-  const float* W[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1], dims[l]] */
-  const float* b[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1]] */
+  /* PACKED weights (osrl_pack_weights): Wf feeds forward, Wb (packed W^T) feeds backward-dz.
+   * Wf[e][l]: PF[k/4][n][k%4], n < round16(out), k < round16(in), zero padded.
+   * Wb[e][l]: PB[o/4][i][o%4], i < round16(in)+16, o < round16(out), zero padded (NULL if unused). */
+  const float* Wf[OSRL_MAX_NETS][OSRL_MAX_LAYERS];
+  const float* Wb[OSRL_MAX_NETS][OSRL_MAX_LAYERS];
+  const float* b[OSRL_MAX_NETS][OSRL_MAX_LAYERS]; /* [dims[l+1]] canonical bias */
 } osrl_mlp_t;
+
+/* One canonical nn.Linear weight [out,in] (row-major, at src_flat + src_off) and where its packed
+ * copies go (float offsets into pf / pb; negative = skip). */
+typedef struct {
+  int64_t src_off, f_off, b_off;
+  int32_t out, in;
+} osrl_pack_entry_t;
 
 /* Virtual input matrix [rows, d0+d1] = cat(src0[map0(r)], src1[map1(r)]) -- replaces the
  * torch.cat / tile / repeat_interleave copies of net.py:232,273,320,337 and cpq.py:170. */
@@ -92,6 +103,11 @@ typedef struct {
 int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, void* stream);
 int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                          const osrl_mlp_grads_t* g, void* stream);
+/* Refresh the packed copies of `n_entries` weights (entries in DEVICE memory).  Sizes in floats:
+ * forward round16(in)*round16(out), backward round16(out)*(round16(in)+16).  max_elems = the largest
+ * packed size among the entries (grid sizing).  Must run after every change of the canonical weights. */
+int osrl_pack_weights(const float* src_flat, float* pf, float* pb, const osrl_pack_entry_t* d_entries,
+                      int32_t n_entries, int32_t max_elems, void* stream);
 /* entries/items live in DEVICE memory (static plan): items[i] = {entry, o_tile, i_tile, 0} with
  * 64x64 tiles; slabs = [n_splits][slab_stride] partial gradients (deterministic split-K over rows). */
 int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,

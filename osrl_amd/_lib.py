@@ -29,7 +29,8 @@ class MlpT(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("n_nets", C.c_int32),
                 ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
                 ("out_scale", C.c_float), ("tile_rows", C.c_int32),
-                ("W", (_fp * MAX_LAYERS) * MAX_NETS), ("b", (_fp * MAX_LAYERS) * MAX_NETS)]
+                ("Wf", (_fp * MAX_LAYERS) * MAX_NETS), ("Wb", (_fp * MAX_LAYERS) * MAX_NETS),
+                ("b", (_fp * MAX_LAYERS) * MAX_NETS)]
 
 
 class RowsT(C.Structure):
@@ -52,6 +53,11 @@ class DwEntryT(C.Structure):
                 ("out", C.c_int32), ("in_", C.c_int32)]
 
 
+class PackEntryT(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("f_off", C.c_int64), ("b_off", C.c_int64),
+                ("out", C.c_int32), ("in_", C.c_int32)]
+
+
 class StepStateT(C.Structure):
     _fields_ = [("step", C.c_int64), ("bc1", C.c_float), ("bc2_sqrt", C.c_float),
                 ("lr_scale", C.c_float), ("pad_", C.c_float)]
@@ -64,6 +70,7 @@ _P = C.POINTER
 PROTOTYPES = {
     "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
+    "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
     "osrl_adam_step": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,

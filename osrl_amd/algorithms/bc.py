@@ -32,6 +32,20 @@ class BC(nn.Module):
         self._engine = None
         self._lrs: Optional[dict] = None
 
+    def repack(self) -> None:
+        """Refresh the fragment-ordered weight copies the kernels read; call after modifying parameters
+        in place from outside the trainer (load_state_dict does it automatically)."""
+        for g in self.groups.values():
+            if g.device.type == "cuda":
+                g.repack()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        if assign:
+            raise RuntimeError("assign=True would detach parameters from their flat HBM groups")
+        res = super().load_state_dict(state_dict, strict=strict)
+        self.repack()
+        return res
+
     def _apply(self, fn, *a, **k):
         raise RuntimeError("osrl_amd models are bound to their HIP device at construction (pass device=)")
 

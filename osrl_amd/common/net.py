@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
-from ..engine.core import FlatGroup, NetDesc
+from ..engine.core import FlatGroup, LayerRef, NetDesc
 
 _ACT_NAME = {nn.ReLU: "relu", nn.Tanh: "tanh", nn.Identity: "id"}
 
@@ -153,58 +153,41 @@ class VAE(nn.Module):
 
 
 # --------------------------------------------------------------------------- #
-# NetDesc builders (pointers into the modules' CURRENT parameter storage)
+# NetDesc builders (pointers into the modules' flat-group storage; set up by bind_group)
 # --------------------------------------------------------------------------- #
-def _wb(lin: nn.Linear) -> Tuple[torch.Tensor, torch.Tensor]:
-    return lin.weight.data, lin.bias.data
+def _ref(lin: nn.Linear) -> LayerRef:
+    if not hasattr(lin, "_osrl"):
+        raise RuntimeError("module parameters are not bound to a FlatGroup (model not materialised)")
+    grp, wkey, bkey, tgt = lin._osrl
+    return LayerRef(lin.weight.data, lin.bias.data, grp, wkey, bkey, tgt)
 
 
-def net_desc_seq(seqs: Sequence[nn.Sequential], out_scale: float, prefixes: Optional[Sequence[str]] = None
-                 ) -> NetDesc:
-    nets = [[_wb(l) for l in seq_linears(s)] for s in seqs]
-    keys = None
-    if prefixes is not None:
-        keys = [[(f"{p}.{2 * i}.weight", f"{p}.{2 * i}.bias") for i in range(len(n))]
-                for p, n in zip(prefixes, nets)]
-    return NetDesc(nets, seq_acts(seqs[0]), out_scale, keys)
+def net_desc_seq(seqs: Sequence[nn.Sequential], out_scale: float) -> NetDesc:
+    return NetDesc([[_ref(l) for l in seq_linears(s)] for s in seqs], seq_acts(seqs[0]), out_scale)
 
 
-def _packed(first: nn.Linear, second: nn.Linear) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[2k, H] weight / [2k] bias spanning two ADJACENT Linear layers (materialize() guarantees it)."""
+def _packed(first: nn.Linear, second: nn.Linear) -> LayerRef:
+    """[2k, H] weight / [2k] bias spanning two ADJACENT Linear layers (plan_group lays them out so)."""
     k, H = first.weight.shape
     w0, w1, b0, b1 = first.weight.data, second.weight.data, first.bias.data, second.bias.data
     if w1.data_ptr() != w0.data_ptr() + 4 * k * H or b1.data_ptr() != b0.data_ptr() + 4 * k:
-        raise RuntimeError("packed head layers are not adjacent in HBM -- model was not materialize()d")
-    W = torch.as_strided(w0, (2 * k, H), (H, 1))
-    b = torch.as_strided(b0, (2 * k,), (1,))
-    return W, b
+        raise RuntimeError("packed head layers are not adjacent in HBM -- model was not materialised")
+    grp, hw, hb, tgt = first._osrl_head
+    return LayerRef(torch.as_strided(w0, (2 * k, H), (H, 1)), torch.as_strided(b0, (2 * k,), (1,)), grp, hw, hb, tgt)
 
 
-def actor_head_desc(actor: SquashedGaussianMLPActor, prefix: Optional[str] = None) -> NetDesc:
+def actor_head_desc(actor: SquashedGaussianMLPActor) -> NetDesc:
     lins = seq_linears(actor.net)
-    nets = [[_wb(l) for l in lins] + [_packed(actor.mu_layer, actor.log_std_layer)]]
-    keys = None
-    if prefix is not None:
-        keys = [[(f"{prefix}.net.{2 * i}.weight", f"{prefix}.net.{2 * i}.bias") for i in range(len(lins))] +
-                [(f"{prefix}.head.weight", f"{prefix}.head.bias")]]
-    return NetDesc(nets, ["relu"] * len(lins) + ["id"], 1.0, keys)
+    return NetDesc([[_ref(l) for l in lins] + [_packed(actor.mu_layer, actor.log_std_layer)]],
+                   ["relu"] * len(lins) + ["id"], 1.0)
 
 
-def vae_enc_desc(vae: VAE, prefix: Optional[str] = None) -> NetDesc:
-    nets = [[_wb(vae.e1), _wb(vae.e2), _packed(vae.mean, vae.log_std)]]
-    keys = None
-    if prefix is not None:
-        keys = [[(f"{prefix}.e1.weight", f"{prefix}.e1.bias"), (f"{prefix}.e2.weight", f"{prefix}.e2.bias"),
-                 (f"{prefix}.head.weight", f"{prefix}.head.bias")]]
-    return NetDesc(nets, ["relu", "relu", "id"], 1.0, keys)
+def vae_enc_desc(vae: VAE) -> NetDesc:
+    return NetDesc([[_ref(vae.e1), _ref(vae.e2), _packed(vae.mean, vae.log_std)]], ["relu", "relu", "id"], 1.0)
 
 
-def vae_dec_desc(vae: VAE, prefix: Optional[str] = None) -> NetDesc:
-    nets = [[_wb(vae.d1), _wb(vae.d2), _wb(vae.d3)]]
-    keys = None
-    if prefix is not None:
-        keys = [[(f"{prefix}.{n}.weight", f"{prefix}.{n}.bias") for n in ("d1", "d2", "d3")]]
-    return NetDesc(nets, ["relu", "relu", "tanh"], float(vae.act_lim), keys)
+def vae_dec_desc(vae: VAE) -> NetDesc:
+    return NetDesc([[_ref(vae.d1), _ref(vae.d2), _ref(vae.d3)]], ["relu", "relu", "tanh"], float(vae.act_lim))
 
 
 # --------------------------------------------------------------------------- #
@@ -215,7 +198,8 @@ PACKED_PAIRS = (("mu_layer", "log_std_layer"), ("mean", "log_std"))
 
 def plan_group(group: FlatGroup, prefix: str, module: nn.Module) -> None:
     """Register every parameter of ``module`` (keys ``prefix.<name>``) in ``group``; the
-    (mu|log_std) head pairs are laid out adjacently and aliased as ``<scope>.head.{weight,bias}``."""
+    (mu|log_std) head pairs are laid out adjacently and aliased as ``<scope>.head.{weight,bias}``.
+    Every Linear weight (or head alias) is marked for packing."""
     named: Dict[str, torch.Tensor] = dict(module.named_parameters())
     done = set()
     for name, p in named.items():
@@ -223,35 +207,50 @@ def plan_group(group: FlatGroup, prefix: str, module: nn.Module) -> None:
             continue
         scope, _, leaf = name.rpartition(".")
         owner, _, mod = scope.rpartition(".")
+        own = owner + "." if owner else ""
         pair = next((pr for pr in PACKED_PAIRS if mod == pr[0]), None)
-        second = None if pair is None else ((owner + "." if owner else "") + pair[1])
-        if pair is not None and second + ".weight" in named:
-            pfx = prefix + "." + (owner + "." if owner else "")
-            first = (owner + "." if owner else "") + pair[0]
+        if pair is not None and own + pair[1] + ".weight" in named:
+            first, second = own + pair[0], own + pair[1]
             w0, w1 = named[first + ".weight"], named[second + ".weight"]
             group.add(prefix + "." + first + ".weight", w0.shape)
             group.add(prefix + "." + second + ".weight", w1.shape, align=False)
             group.add(prefix + "." + first + ".bias", named[first + ".bias"].shape)
             group.add(prefix + "." + second + ".bias", named[second + ".bias"].shape, align=False)
-            group.alias(pfx + "head.weight", prefix + "." + first + ".weight", (2 * w0.shape[0], w0.shape[1]))
-            group.alias(pfx + "head.bias", prefix + "." + first + ".bias", (2 * w0.shape[0],))
+            hk = prefix + "." + own + "head"
+            group.alias(hk + ".weight", prefix + "." + first + ".weight", (2 * w0.shape[0], w0.shape[1]))
+            group.alias(hk + ".bias", prefix + "." + first + ".bias", (2 * w0.shape[0],))
+            group.mark_weight(hk + ".weight")
             done.update({first + ".weight", first + ".bias", second + ".weight", second + ".bias"})
         else:
             group.add(prefix + "." + name, p.shape)
+            if leaf == "weight" and p.dim() == 2:
+                group.mark_weight(prefix + "." + name)
             done.add(name)
 
 
 def bind_group(group: FlatGroup, prefix: str, module: nn.Module, target: Optional[nn.Module] = None) -> None:
     """Copy ``module``'s (CPU-initialised) parameters into the group and re-point ``.data`` at the
-    flat views; ``target`` (a deepcopy) is bound to the Polyak target buffer the same way."""
-    with torch.no_grad():
-        for name, p in module.named_parameters():
-            v = group.view(prefix + "." + name)
-            v.copy_(p.data)
-            p.data = v
-        if target is not None:
-            for name, p in target.named_parameters():
-                v = group.tgt_view(prefix + "." + name)
+    flat views; ``target`` (a deepcopy) is bound to the Polyak target buffer the same way.  Every
+    nn.Linear is tagged with its (group, weight key, bias key, is_target) for the NetDesc builders."""
+    def bind(mod: nn.Module, is_tgt: bool):
+        view = group.tgt_view if is_tgt else group.view
+        with torch.no_grad():
+            for name, p in mod.named_parameters():
+                v = view(prefix + "." + name)
                 v.copy_(p.data)
                 p.data = v
-                p.requires_grad_(False)
+                if is_tgt:
+                    p.requires_grad_(False)
+        for mname, sub in mod.named_modules():
+            if isinstance(sub, nn.Linear):
+                full = prefix + ("." + mname if mname else "")
+                sub._osrl = (group, full + ".weight", full + ".bias", is_tgt)
+                scope, _, leaf = mname.rpartition(".")
+                if any(leaf == pr[0] for pr in PACKED_PAIRS):
+                    hk = prefix + "." + (scope + "." if scope else "") + "head"
+                    if hk + ".weight" in group.layout:
+                        sub._osrl_head = (group, hk + ".weight", hk + ".bias", is_tgt)
+
+    bind(module, False)
+    if target is not None:
+        bind(target, True)

@@ -17,6 +17,14 @@
 //     k = k0 + 4*kq + t, so ONE 16-byte load per lane (A: ds_read_b128, B: global_load_dwordx4 of
 //     4 consecutive k of a weight row) feeds 4 MFMAs.  Per 16-deep k step a wave issues
 //     NRB + NCB wide loads for 4*NRB*NCB MFMAs (8 loads : 64 MFMAs at NRB=NCB=4);
+//   * weights are read from a PACKED, fragment-ordered copy  P[k/16][(k%16)/4][n][k%4]  (zero
+//     padded to 16 in both dims, refreshed by osrl_pack_weights after every optimizer step):
+//     lanes m=0..15 of a fragment load then read 16 consecutive 16-byte words, i.e. every
+//     global_load_dwordx4 is 4 x 256 B contiguous and guard-free.  (Loading fragments from the
+//     canonical [out,in] layout puts consecutive lanes 1 KB apart -> 64 L1 requests per
+//     instruction; measured: the TA/L1 pipe time per k-step then equals the MFMA time and the
+//     kernel sits at ~30% of the fp32 MFMA roof.)  The backward pass uses the analogous packing
+//     of W^T.
 //   * lda = round16(max width) + 8 floats => (lda/4) mod 16 is 2 mod 4, which makes the
 //     ds_read_b128 A-fragment pattern (16 rows x 4 k-quads per wave) bank-conflict free for the
 //     four 16-lane service groups of ds_read_b128 (MI355X_MICROARCH.md LDS table).
@@ -49,61 +57,46 @@ __device__ __forceinline__ int map_row(int r, int map, int div) {
   return r;
 }
 __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
-
-// B fragment for 4 consecutive k of output column n  (k-slot trick: the 4 values feed 4 MFMAs).
-//  BT == false : B[k][n] = W[n*ldw + k]   (forward:  W is [N,K] row-major)
-//  BT == true  : B[k][n] = W[k*ldw + n]   (backward: W is [K,N] row-major)
-// FAST: the whole fragment is in range and (forward) 16-byte aligned -> no predicates at all.
-// Generic: branch-free clamped addresses + selects, so the k-loop stays straight-line code.
-template <bool BT, bool FAST>
-__device__ __forceinline__ f32x4 load_b4(const float* __restrict__ W, int K, int N, int ldw, int n, int k) {
-  f32x4 v;
-  if (FAST) {
-    if (!BT) {
-      v = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + k);
-    } else {
-      const float* p = W + (size_t)k * ldw + n;
-      v[0] = p[0];
-      v[1] = p[(size_t)ldw];
-      v[2] = p[2 * (size_t)ldw];
-      v[3] = p[3 * (size_t)ldw];
-    }
-  } else {
-    const bool nok = n < N;
-    const int nc = nok ? n : N - 1;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kk = k + t;
-      const int kc = kk < K ? kk : K - 1;
-      const float x = BT ? W[(size_t)kc * ldw + nc] : W[(size_t)nc * ldw + kc];
-      v[t] = (nok && kk < K) ? x : 0.f;
-    }
-  }
-  return v;
+// balanced split of nblk column blocks over the 4 waves: first (nblk%4) waves take one extra block
+__device__ __forceinline__ void wave_blocks(int nblk, int wave, int* cb0, int* cnt) {
+  const int base = nblk >> 2, rem = nblk & 3;
+  *cnt = base + (wave < rem ? 1 : 0);
+  *cb0 = wave * base + (wave < rem ? wave : rem);
 }
 
-// acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols (cb0+c)*16..)   over k in [0,Kp), c < CNT.
+// B fragment (4 consecutive k of column n) from the packed layout P[q = k/4][n][4], Np columns.
+__device__ __forceinline__ f32x4 load_bp(const float* __restrict__ P, int Np, int q, int n) {
+  return *reinterpret_cast<const f32x4*>(P + ((size_t)q * Np + n) * 4);
+}
+
+// acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols n0 + c*16..)   over nk 16-deep k steps.
 // Software pipeline: a ring of STAGES B-fragment sets keeps STAGES-1 k-steps of weight loads in
 // flight (global -> VGPR, straight from L2) while the MFMAs of the current step run; the A
 // fragments (ds_read_b128 from the LDS activation tile) are prefetched one step ahead.
-template <int NRB, int NCB, int CNT, bool BT, bool FAST, int STAGES>
-__device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int Kp, const float* __restrict__ W, int K,
-                                              int N, int ldw, int cb0, f32x4 (&acc)[NRB][NCB]) {
+template <int NRB, int CNT, int STAGES>
+__device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
+                                              int col0, f32x4 (&acc)[NRB][CNT]) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
-  const int nk = Kp >> 4;
-  const int n0 = cb0 * 16 + m;
+  const int n0 = col0 + m;
+  // Every workgroup needs the SAME weight lines; each starts its k-walk at a different step so the
+  // request streams are decorrelated (fp32 sum order changes per workgroup; fixed per (grid, tile)).
+  const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u + (threadIdx.x >> 6)) % (unsigned)nk);
+  auto kstep = [&](int kc) {
+    int k = kc + rot;
+    return k >= nk ? k - nk : k;
+  };
   f32x4 b[STAGES][CNT];
   f32x4 a[2][NRB];
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) {
-    const int kc = s < nk ? s : nk - 1;
+    const int kc = kstep(s < nk ? s : nk - 1);
 #pragma unroll
-    for (int c = 0; c < CNT; ++c) b[s][c] = load_b4<BT, FAST>(W, K, N, ldw, n0 + c * 16, kc * 16 + 4 * kq);
+    for (int c = 0; c < CNT; ++c) b[s][c] = load_bp(P, Np, kc * 4 + kq, n0 + c * 16);
   }
 #pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda);
+  for (int rb = 0; rb < NRB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kstep(0) * 16);
   for (int kb = 0; kb < nk; kb += 2 * STAGES) {
 #pragma unroll
     for (int s = 0; s < 2 * STAGES; ++s) {
@@ -111,11 +104,10 @@ __device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int Kp,
       if (kc < nk) {
         {  // issue the loads of k-step kc + STAGES - 1 into the ring slot freed by step kc - 1
           int kl = kc + STAGES - 1;
-          kl = kl < nk ? kl : nk - 1;
+          kl = kstep(kl < nk ? kl : nk - 1);
 #pragma unroll
-          for (int c = 0; c < CNT; ++c)
-            b[(s + STAGES - 1) % STAGES][c] = load_b4<BT, FAST>(W, K, N, ldw, n0 + c * 16, kl * 16 + 4 * kq);
-          int ka = kc + 1 < nk ? kc + 1 : kc;
+          for (int c = 0; c < CNT; ++c) b[(s + STAGES - 1) % STAGES][c] = load_bp(P, Np, kl * 4 + kq, n0 + c * 16);
+          const int ka = kstep(kc + 1 < nk ? kc + 1 : kc);
 #pragma unroll
           for (int rb = 0; rb < NRB; ++rb)
             a[(s + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ka * 16);
@@ -132,24 +124,33 @@ __device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int Kp,
   }
 }
 
-template <int NRB, int NCB, bool BT>
-__device__ __forceinline__ void layer_mm(const float* lds, int lda, int Kp, const float* __restrict__ W, int K,
-                                         int N, int ldw, int cb0, int cnt, f32x4 (&acc)[NRB][NCB]) {
+// cnt (<= NCB) column blocks starting at column col0 (= first block * 16 [+ dx_col0])
+template <int NRB, int NCB>
+__device__ __forceinline__ void layer_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
+                                         int col0, int cnt, f32x4 (&acc)[NRB][NCB]) {
   constexpr int STAGES = (NRB * NCB >= 16) ? 2 : 3;  // short k-steps need a deeper load ring
-  const bool full = cnt == NCB && (cb0 + NCB) * 16 <= N;
-  const bool fast = full && (K & 15) == 0 &&
-                    (BT || (((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)));
-  if (fast) {
-    layer_mm_core<NRB, NCB, NCB, BT, true, STAGES>(lds, lda, Kp, W, K, N, ldw, cb0, acc);
-  } else if (cnt == NCB) {
-    layer_mm_core<NRB, NCB, NCB, BT, false, STAGES>(lds, lda, Kp, W, K, N, ldw, cb0, acc);
+  if (cnt == NCB) {
+    layer_mm_core<NRB, NCB, STAGES>(lds, lda, nk, P, Np, col0, acc);
+  } else if (NCB > 2 && cnt == NCB - 1) {
+    // balanced split of e.g. 25 column blocks as 7/6/6/6: the 6-block waves keep a dense k-loop
+    constexpr int C1 = NCB > 2 ? NCB - 1 : 1;
+    f32x4 t[NRB][C1];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int c = 0; c < C1; ++c) t[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    layer_mm_core<NRB, C1, STAGES>(lds, lda, nk, P, Np, col0, t);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int c = 0; c < C1; ++c) acc[rb][c] = t[rb][c];
   } else {
-    // ragged wave (fewer column blocks): one block at a time keeps the code small
+    // ragged wave (few column blocks, e.g. the 1-wide Q head): one block at a time
     for (int c = 0; c < cnt; ++c) {
       f32x4 t[NRB][1];
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      layer_mm_core<NRB, 1, 1, BT, false, 3>(lds, lda, Kp, W, K, N, ldw, cb0 + c, t);
+      layer_mm_core<NRB, 1, 3>(lds, lda, nk, P, Np, col0 + c * 16, t);
 #pragma unroll
       for (int cc = 0; cc < NCB; ++cc)
         if (cc == c) {
@@ -227,13 +228,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
 
   for (int l = 0; l < L; ++l) {
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
-    const int nblk = (N + 15) >> 4, cpw = (nblk + 3) >> 2;
-    const int cb0 = wave * cpw;
-    int cnt = nblk - cb0;
-    cnt = cnt > cpw ? cpw : cnt;  // may be <= 0 for idle waves
+    const int nblk = (N + 15) >> 4;
+    int cb0, cnt;
+    wave_blocks(nblk, wave, &cb0, &cnt);  // cnt may be 0 for idle waves
     f32x4 acc[NRB][NCB];
     zero_acc<NRB, NCB>(acc);
-    if (cnt > 0) layer_mm<NRB, NCB, false>(lds, lda, round16(K), a.net.W[e][l], K, N, K, cb0, cnt, acc);
+    if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wf[e][l], round16(N), cb0 * 16, cnt, acc);
     __syncthreads();  // every wave finished reading the previous activations
     const float* __restrict__ bias = a.net.b[e][l];
     const int act = a.net.acts[l];
@@ -301,13 +301,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
   for (int l = L - 1; l >= 1; --l) {
     // dH_{l-1}[r][i] = sum_o dZ_l[r][o] * W_l[o][i]   (K = dims[l+1] (o), N = dims[l] (i))
     const int K = a.net.dims[l + 1], N = a.net.dims[l];
-    const int nblk = (N + 15) >> 4, cpw = (nblk + 3) >> 2;
-    const int cb0 = wave * cpw;
-    int cnt = nblk - cb0;
-    cnt = cnt > cpw ? cpw : cnt;
+    const int nblk = (N + 15) >> 4;
+    int cb0, cnt;
+    wave_blocks(nblk, wave, &cb0, &cnt);
     f32x4 acc[NRB][NCB];
     zero_acc<NRB, NCB>(acc);
-    if (cnt > 0) layer_mm<NRB, NCB, true>(lds, lda, round16(K), a.net.W[e][l], K, N, N, cb0, cnt, acc);
+    // packed W^T: contraction over the layer's outputs (K), columns = the layer's inputs (N) (+16 pad)
+    if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt, acc);
     __syncthreads();
     const float* __restrict__ h = a.saved.h[e][l - 1];
     const int act = a.net.acts[l - 1];
@@ -334,15 +334,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
 
   if (a.g.dx[e]) {
     // dX[:, c0:c0+nc] = dZ_0 * W_0[:, c0:c0+nc]
-    const int K = a.net.dims[1], nc = a.g.dx_cols, ldw = a.net.dims[0];
-    const int nblk = (nc + 15) >> 4, cpw = (nblk + 3) >> 2;
-    const int cb0 = wave * cpw;
-    int cnt = nblk - cb0;
-    cnt = cnt > cpw ? cpw : cnt;
+    const int K = a.net.dims[1], nc = a.g.dx_cols;
+    const int nblk = (nc + 15) >> 4;
+    int cb0, cnt;
+    wave_blocks(nblk, wave, &cb0, &cnt);
     f32x4 acc[NRB][NCB];
     zero_acc<NRB, NCB>(acc);
     if (cnt > 0)
-      layer_mm<NRB, NCB, true>(lds, lda, round16(K), a.net.W[e][0] + a.g.dx_col0, K, nc, ldw, cb0, cnt, acc);
+      layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][0], round16(a.net.dims[0]) + 16,
+                         a.g.dx_col0 + cb0 * 16, cnt, acc);
     float* __restrict__ dx = a.g.dx[e];
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
@@ -461,6 +461,37 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
   }
 }
 
+
+// ---- weight packing ------------------------------------------------------------------------------
+// forward pack  PF[q = k/4][n][k%4],  n < round16(N), q < round16(K)/4        (y = x W^T, W [N,K])
+// backward pack PB[q = o/4][i][o%4],  i < round16(K)+16, q < round16(N)/4     (dx = dz W)
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src_flat, float* __restrict__ pf,
+                                                    float* __restrict__ pb, const osrl_pack_entry_t* __restrict__ ents) {
+  const osrl_pack_entry_t E = ents[blockIdx.y];
+  const float* __restrict__ W = src_flat + E.src_off;
+  const int N = E.out, K = E.in;
+  const int Np = round16(N), Kp = round16(K);
+  if (pf && E.f_off >= 0) {
+    float* __restrict__ d = pf + E.f_off;
+    const int total = Kp * Np;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+      const int t = j & 3, n = (j >> 2) % Np, q = (j >> 2) / Np;
+      const int k = q * 4 + t;
+      d[j] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+    }
+  }
+  if (pb && E.b_off >= 0) {
+    float* __restrict__ d = pb + E.b_off;
+    const int Kb = Kp + 16;
+    const int total = Np * Kb;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+      const int t = j & 3, i = (j >> 2) % Kb, q = (j >> 2) / Kb;
+      const int o = q * 4 + t;
+      d[j] = (o < N && i < K) ? W[(size_t)o * K + i] : 0.f;
+    }
+  }
+}
+
 inline int round16h(int x) { return (x + 15) & ~15; }
 
 struct TileChoice {
@@ -538,8 +569,11 @@ bool valid_net(const osrl_mlp_t* n) {
 extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
                                 void* stream) {
   if (!valid_net(net) || net->out_scale == 0.f || !in || !out || in->rows < 1 || in->d0 + in->d1 != net->dims[0]) return -1;
-  for (int e = 0; e < net->n_nets; ++e)
+  for (int e = 0; e < net->n_nets; ++e) {
     if (!out->h[e][net->n_layers - 1]) return -1;
+    for (int l = 0; l < net->n_layers; ++l)
+      if (!net->Wf[e][l] || !net->b[e][l]) return -1;
+  }
   FwdArgs a;
   a.net = *net;
   a.in = *in;
@@ -554,6 +588,8 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
   if (!valid_net(net) || !saved || !g || rows < 1) return -1;
   for (int e = 0; e < net->n_nets; ++e) {
     if (!g->dy[e]) return -1;
+    for (int l = g->dx[e] ? 0 : 1; l < net->n_layers; ++l)
+      if (!net->Wb[e][l]) return -1;
     for (int l = 0; l < net->n_layers; ++l)
       if (!saved->h[e][l] && (l < net->n_layers - 1 || net->acts[l] != OSRL_ACT_ID)) return -1;
     if (g->dx[e] && (g->dx_cols < 1 || g->dx_col0 < 0 || g->dx_col0 + g->dx_cols > net->dims[0])) return -1;
@@ -566,6 +602,16 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
   const TileChoice t = choose_tile(net, rows, g->dx_cols);
   a.lda = t.lda;
   OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream);
+}
+
+extern "C" int osrl_pack_weights(const float* src_flat, float* pf, float* pb, const osrl_pack_entry_t* d_entries,
+                                 int32_t n_entries, int32_t max_elems, void* stream) {
+  if (!src_flat || !d_entries || n_entries < 1 || (!pf && !pb)) return -1;
+  int bx = (max_elems + 255) / 256;
+  bx = bx < 1 ? 1 : bx > 64 ? 64 : bx;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(pack_kernel, dim3(bx, n_entries), dim3(256), 0, (hipStream_t)stream, src_flat, pf, pb, d_entries);
+  return (int)hipGetLastError();
 }
 
 extern "C" int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,

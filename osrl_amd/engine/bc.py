@@ -22,7 +22,8 @@ class BCEngine:
         self.st = StepState(dev, STAT_KEYS)
         self.obs = torch.zeros(B, m.actor.pi[0].in_features, **f)
         self.act = torch.zeros(B, m.action_dim, **f)
-        self.d_pi = net_desc_seq([m.actor.pi], float(m.max_action), ["actor.pi"])
+        self.d_pi = net_desc_seq([m.actor.pi], float(m.max_action))
+        m.repack()
         self.r_pi = MlpRun(self.d_pi, B, True, dev)
         self.du = torch.zeros(1, B, m.action_dim, **f)
         self.r_pi.setup_backward(self.du)
@@ -69,4 +70,5 @@ class BCEngine:
         g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])
         self.st.state.copy_(snap[3]); self.st.stats.copy_(snap[4]); self.st.ring.copy_(snap[5])
         self.st.host_step = snap[6]
+        self.model.repack()
         self.graph = gr

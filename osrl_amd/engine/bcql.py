@@ -47,19 +47,14 @@ class BCQLEngine:
             self.noise[k] = self.noise_flat[o:o + n].view(shapes[k])
             o += n
 
-        def twin(mod, grp=None):
-            pre = None
-            if grp is not None:
-                pre = [f"{grp}.q1_nets.{i}" for i in range(len(mod.q1_nets))] + \
-                      [f"{grp}.q2_nets.{i}" for i in range(len(mod.q2_nets))]
-            return net_desc_seq(mod.all_nets(), 1.0, pre)
-
-        self.d_actor = net_desc_seq([m.actor.pi], 1.0, ["actor.pi"])
+        twin = lambda mod: net_desc_seq(mod.all_nets(), 1.0)  # noqa: E731
+        self.d_actor = net_desc_seq([m.actor.pi], 1.0)
         self.d_actor_old = net_desc_seq([m.actor_old.pi], 1.0)
-        self.d_critic, self.d_cost = twin(m.critic, "critic"), twin(m.cost_critic, "cost_critic")
+        self.d_critic, self.d_cost = twin(m.critic), twin(m.cost_critic)
         self.d_critic_old, self.d_cost_old = twin(m.critic_old), twin(m.cost_critic_old)
-        self.d_enc, self.d_dec = vae_enc_desc(m.vae, "vae"), vae_dec_desc(m.vae, "vae")
+        self.d_enc, self.d_dec = vae_enc_desc(m.vae), vae_dec_desc(m.vae)
         g = m.groups
+        m.repack()
 
         # vae phase
         self.r_enc, self.r_dec = MlpRun(self.d_enc, B, True, dev), MlpRun(self.d_dec, B, True, dev)
@@ -183,6 +178,7 @@ class BCQLEngine:
             g.p.copy_(p); g.m.copy_(mm); g.v.copy_(v)
             if t is not None:
                 g.tgt.copy_(t)
+        m.repack()
 
     def capture(self) -> None:
         snap = self._snapshot()

@@ -61,6 +61,10 @@ class FlatGroup:
         self._n = 0
         self.p = self.m = self.v = self.tgt = self.slabs = None
         self.n_splits = 0
+        self.weights: List[str] = []          # keys of [out,in] weights that get packed copies
+        self.pf = self.pb = self.tf = None    # packed fwd / packed W^T of p, packed fwd of tgt
+        self.f_off: Dict[str, int] = {}
+        self.b_off: Dict[str, int] = {}
 
     def add(self, key: str, shape: Sequence[int], align: bool = True) -> int:
         assert self.p is None, "FlatGroup already finalized"
@@ -74,12 +78,48 @@ class FlatGroup:
         self._n += n
         return off
 
+    def mark_weight(self, key: str) -> None:
+        """Register a 2-D [out,in] tensor (or packed-head alias) whose fragment-ordered copies the
+        MLP kernels read (csrc/mlp.hip pack_kernel)."""
+        assert len(self.layout[key][1]) == 2
+        if key not in self.weights:
+            self.weights.append(key)
+
     def finalize(self) -> None:
         n = max(_align4(self._n), 4)
         self.n = n
-        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)  # noqa: E731
+        z = lambda k=n: torch.zeros(k, dtype=torch.float32, device=self.device)  # noqa: E731
         self.p, self.m, self.v = z(), z(), z()
         self.tgt = z() if self.with_target else None
+        if self.weights:
+            r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+            nf = nb = 0
+            ents = (L.PackEntryT * len(self.weights))()
+            self._max_pack = 0
+            for i, k in enumerate(self.weights):
+                off, (o, ii) = self.layout[k]
+                self.f_off[k], self.b_off[k] = nf, nb
+                ents[i].src_off, ents[i].f_off, ents[i].b_off, ents[i].out, ents[i].in_ = off, nf, nb, o, ii
+                fs, bs = r16(ii) * r16(o), r16(o) * (r16(ii) + 16)
+                self._max_pack = max(self._max_pack, fs, bs)
+                nf += fs
+                nb += bs
+            self.pf, self.pb = z(nf), z(nb)
+            self.tf = z(nf) if self.with_target else None
+            self._ents = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(self.device)
+
+    def repack(self, params: bool = True, target: bool = True) -> None:
+        """Refresh the packed weight copies from the canonical buffers (async, current stream)."""
+        if not self.weights:
+            return
+        lib = L.load()
+        if params:
+            L.check(lib.osrl_pack_weights(self.p.data_ptr(), self.pf.data_ptr(), self.pb.data_ptr(),
+                                          self._ents.data_ptr(), len(self.weights), self._max_pack, cur_stream()),
+                    "osrl_pack_weights")
+        if target and self.tgt is not None:
+            L.check(lib.osrl_pack_weights(self.tgt.data_ptr(), self.tf.data_ptr(), None, self._ents.data_ptr(),
+                                          len(self.weights), self._max_pack, cur_stream()), "osrl_pack_weights")
 
     def ensure_slabs(self, n_splits: int) -> None:
         if self.slabs is None or self.n_splits < n_splits:
@@ -126,26 +166,46 @@ class FlatGroup:
                                    self.slabs.data_ptr(), self.cur_splits, self.n, self.n, lr, betas[0],
                                    betas[1], eps, weight_decay, tau, _ptr(gscale), st_ptr, cur_stream()),
                 "osrl_adam_step")
+        self.repack(True, polyak and self.tgt is not None)
+
+
+class LayerRef:
+    """One Linear layer of a net: canonical weight/bias tensors (views into ``group``) + the key of its
+    packed copies.  ``target=True`` reads the Polyak-target copy of the group."""
+    __slots__ = ("W", "b", "group", "key", "bkey", "target")
+
+    def __init__(self, W: torch.Tensor, b: torch.Tensor, group: FlatGroup, key: str, bkey: str,
+                 target: bool = False):
+        self.W, self.b, self.group, self.key, self.bkey, self.target = W, b, group, key, bkey, target
+
+    @property
+    def wf_ptr(self) -> int:
+        g = self.group
+        return (g.tf if self.target else g.pf).data_ptr() + 4 * g.f_off[self.key]
+
+    @property
+    def wb_ptr(self) -> Optional[int]:
+        g = self.group
+        return None if self.target else g.pb.data_ptr() + 4 * g.b_off[self.key]
 
 
 class NetDesc:
-    """An ensemble of identical MLPs: ``nets[e][l] = (W, b)`` tensors (views into a FlatGroup)."""
+    """An ensemble of identical MLPs: ``nets[e][l]`` = LayerRef."""
 
-    def __init__(self, nets: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]], acts: Sequence[str],
-                 out_scale: float = 1.0, keys: Optional[Sequence[Sequence[Tuple[str, str]]]] = None):
+    def __init__(self, nets: Sequence[Sequence[LayerRef]], acts: Sequence[str], out_scale: float = 1.0):
         E, nl = len(nets), len(nets[0])
         if not (1 <= E <= L.MAX_NETS) or not (1 <= nl <= L.MAX_LAYERS):
             raise ValueError(f"fused MLP supports <= {L.MAX_NETS} nets and <= {L.MAX_LAYERS} Linear layers "
                              f"(got {E} nets, {nl} layers)")
         self.E, self.nl = E, nl
-        dims = [nets[0][0][0].shape[1]] + [nets[0][l][0].shape[0] for l in range(nl)]
+        dims = [nets[0][0].W.shape[1]] + [nets[0][l].W.shape[0] for l in range(nl)]
         if max(dims) > L.MAX_WIDTH:
             raise ValueError(f"layer width {max(dims)} > {L.MAX_WIDTH} unsupported by the fused MLP kernels")
         self.dims = dims
         self.acts = [L.ACT_CODES[a] for a in acts]
         self.out_scale = float(out_scale)
         self.nets = nets
-        self.keys = keys
+        self.keys = [[(r.key, r.bkey) for r in net] for net in nets]
         d = L.MlpT()
         d.n_layers, d.n_nets = nl, E
         for i, v in enumerate(dims):
@@ -155,16 +215,27 @@ class NetDesc:
         d.out_scale = self.out_scale
         for e in range(E):
             for l in range(nl):
-                W, b = nets[e][l]
-                assert W.is_contiguous() and b.is_contiguous() and W.dtype == torch.float32
-                assert tuple(W.shape) == (dims[l + 1], dims[l]) and tuple(b.shape) == (dims[l + 1],)
-                d.W[e][l] = W.data_ptr()
-                d.b[e][l] = b.data_ptr()
+                r = nets[e][l]
+                assert r.b.is_contiguous() and r.W.dtype == torch.float32
+                assert tuple(r.W.shape) == (dims[l + 1], dims[l]) and tuple(r.b.shape) == (dims[l + 1],)
+                assert r.key in r.group.f_off, f"{r.key} has no packed copy (FlatGroup.mark_weight)"
+                d.Wf[e][l] = r.wf_ptr
+                d.Wb[e][l] = r.wb_ptr
+                d.b[e][l] = r.b.data_ptr()
         self.c = d
 
+    def groups(self):
+        seen = []
+        for net in self.nets:
+            for r in net:
+                if r.group not in seen:
+                    seen.append(r.group)
+        return seen
+
     def subset(self, idx: Sequence[int]) -> "NetDesc":
-        return NetDesc([self.nets[i] for i in idx], [_ACT_NAMES[a] for a in self.acts], self.out_scale,
-                       None if self.keys is None else [self.keys[i] for i in idx])
+        d = NetDesc([self.nets[i] for i in idx], [_ACT_NAMES[a] for a in self.acts], self.out_scale)
+        d.c.tile_rows = self.c.tile_rows
+        return d
 
 
 _ACT_NAMES = {L.ACT_ID: "id", L.ACT_RELU: "relu", L.ACT_TANH: "tanh"}
@@ -173,8 +244,7 @@ _ACT_NAMES = {L.ACT_ID: "id", L.ACT_RELU: "relu", L.ACT_TANH: "tanh"}
 def concat_nets(a: NetDesc, b: NetDesc) -> NetDesc:
     """One launch over two ensembles of identical shape (e.g. critic_old + cost_critic_old)."""
     assert a.dims == b.dims and a.acts == b.acts and a.out_scale == b.out_scale
-    keys = None if (a.keys is None or b.keys is None) else list(a.keys) + list(b.keys)
-    return NetDesc(list(a.nets) + list(b.nets), [_ACT_NAMES[x] for x in a.acts], a.out_scale, keys)
+    return NetDesc(list(a.nets) + list(b.nets), [_ACT_NAMES[x] for x in a.acts], a.out_scale)
 
 
 class MlpRun:

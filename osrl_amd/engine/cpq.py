@@ -56,15 +56,15 @@ class CPQEngine:
             o += n
 
         # network descriptors (pointers into the flat groups)
-        qp = lambda grp, n: [f"{grp}.q_nets.{i}" for i in range(n)]  # noqa: E731
-        self.d_actor = actor_head_desc(m.actor, "actor")
-        self.d_critic = net_desc_seq(list(m.critic.q_nets), 1.0, qp("critic", nq))
-        self.d_cost = net_desc_seq(list(m.cost_critic.q_nets), 1.0, qp("cost_critic", nqc))
+        self.d_actor = actor_head_desc(m.actor)
+        self.d_critic = net_desc_seq(list(m.critic.q_nets), 1.0)
+        self.d_cost = net_desc_seq(list(m.cost_critic.q_nets), 1.0)
         self.d_critic_old = net_desc_seq(list(m.critic_old.q_nets), 1.0)
         self.d_cost_old = net_desc_seq(list(m.cost_critic_old.q_nets), 1.0)
-        self.d_enc = vae_enc_desc(m.vae, "vae")
-        self.d_dec = vae_dec_desc(m.vae, "vae")
+        self.d_enc = vae_enc_desc(m.vae)
+        self.d_dec = vae_dec_desc(m.vae)
         g = m.groups
+        m.repack()
 
         # ---- vae phase
         self.r_enc = MlpRun(self.d_enc, B, True, dev)
@@ -236,6 +236,7 @@ class CPQEngine:
             g.v.copy_(v)
             if t is not None:
                 g.tgt.copy_(t)
+        m.repack()
 
     def attach_replay(self, store) -> None:
         """Sample minibatches on device from ``store`` (common/replay.py) inside the step itself."""

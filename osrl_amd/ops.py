@@ -40,6 +40,8 @@ class _FusedMLP(torch.autograd.Function):
         rows = x0.shape[0]
         need_grad = torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad) or
                                                  any(p.requires_grad for p in params))
+        for g in desc.groups():  # weights may have been edited since the last pack: refresh (cheap)
+            g.repack()
         run = MlpRun(desc, rows, need_grad, x0.device)
         run.forward(x0, x1)
         ctx.run, ctx.desc, ctx.has_x1 = run, desc, x1 is not None
@@ -59,8 +61,8 @@ class _FusedMLP(torch.autograd.Function):
         for e in range(desc.E):
             for l in range(desc.nl):
                 wk, bk = f"{e}.{l}.w", f"{e}.{l}.b"
-                grp.add(wk, desc.nets[e][l][0].shape)
-                grp.add(bk, desc.nets[e][l][1].shape)
+                grp.add(wk, desc.nets[e][l].W.shape)
+                grp.add(bk, desc.nets[e][l].b.shape)
                 a = run.x if l == 0 else run.h[e][l - 1]
                 entries.append((run.dz[e][l], a, wk, bk))
         grp.finalize()
@@ -80,7 +82,7 @@ def mlp_apply(desc: NetDesc, x0: torch.Tensor, x1: Optional[torch.Tensor] = None
     when the NetDesc was built from live ``nn.Parameter`` storage (pass the params for autograd)."""
     x0 = _chk(x0)
     x1 = None if x1 is None else _chk(x1)
-    params = [t for net in desc.nets for wb in net for t in wb]
+    params = [t for net in desc.nets for r in net for t in (r.W, r.b)]
     return _FusedMLP.apply(desc, x0, x1, *params)
 
 

@@ -53,7 +53,7 @@ MLP_CASES = [
 
 @pytest.mark.parametrize("ci", range(len(MLP_CASES)))
 def test_mlp_fwd_bwd(ci):
-    from osrl_amd.engine.core import DwPlan, FlatGroup, MlpRun, NetDesc
+    from osrl_amd.engine.core import DwPlan, FlatGroup, LayerRef, MlpRun, NetDesc
     E, dims, acts, oscale, rows, (d0, map0, div0, map1, div1), dxc = MLP_CASES[ci]
     dev = _dev()
     rs = np.random.RandomState(10 + ci)
@@ -62,21 +62,23 @@ def test_mlp_fwd_bwd(ci):
     for e in range(E):
         for l in range(len(dims) - 1):
             grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{e}.{l}.w")
             grp.add(f"{e}.{l}.b", (dims[l + 1],))
     grp.finalize()
-    nets, keys = [], []
+    nets, refs = [], []
     for e in range(E):
-        layers, kk = [], []
+        layers, rr = [], []
         for l in range(len(dims) - 1):
             k = 1 / math.sqrt(dims[l])
             W, b = grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")
             W.copy_(torch.tensor(rs.uniform(-k, k, W.shape), dtype=torch.float32))
             b.copy_(torch.tensor(rs.uniform(-k, k, b.shape), dtype=torch.float32))
             layers.append((W, b))
-            kk.append((f"{e}.{l}.w", f"{e}.{l}.b"))
+            rr.append(LayerRef(W, b, grp, f"{e}.{l}.w", f"{e}.{l}.b"))
         nets.append(layers)
-        keys.append(kk)
-    desc = NetDesc(nets, acts, oscale, keys)
+        refs.append(rr)
+    grp.repack()
+    desc = NetDesc(refs, acts, oscale)
     d1 = dims[0] - d0
     n0 = {0: rows, 1: div0, 2: (rows + div0 - 1) // div0}[map0]
     src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from osrl_amd import _lib as L  # noqa: E402
 from osrl_amd.engine import glue as G  # noqa: E402
-from osrl_amd.engine.core import DwPlan, FlatGroup, MlpRun, NetDesc, StepState  # noqa: E402
+from osrl_amd.engine.core import DwPlan, FlatGroup, LayerRef, MlpRun, NetDesc, StepState  # noqa: E402
 
 
 def timeit(fn, iters=20):
@@ -33,12 +33,14 @@ def mk(E, dims, acts, dev, tile_rows=0):
     for e in range(E):
         for l in range(len(dims) - 1):
             grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{e}.{l}.w")
             grp.add(f"{e}.{l}.b", (dims[l + 1],))
     grp.finalize()
     grp.p.uniform_(-0.05, 0.05)
-    nets = [[(grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")) for l in range(len(dims) - 1)] for e in range(E)]
-    keys = [[(f"{e}.{l}.w", f"{e}.{l}.b") for l in range(len(dims) - 1)] for e in range(E)]
-    d = NetDesc(nets, acts, 1.0, keys)
+    grp.repack()
+    nets = [[LayerRef(grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b"), grp, f"{e}.{l}.w", f"{e}.{l}.b")
+             for l in range(len(dims) - 1)] for e in range(E)]
+    d = NetDesc(nets, acts, 1.0)
     d.c.tile_rows = tile_rows
     return grp, d
 
