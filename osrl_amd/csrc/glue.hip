@@ -206,19 +206,33 @@ __device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t
       hist_add(hist, (key >> shift) & 255u, act);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int64_t kk = k;
-      uint32_t d = 0, acc = 0;
-      for (; d < 256; ++d) {
-        const uint32_t c = hist[d];
-        if (kk < (int64_t)c) break;
-        kk -= c;
-        acc += c;
+    if (threadIdx.x < 64) {
+      // wave-parallel bin search: lane l owns bins 4l..4l+3; shuffle prefix scan over the 64 lanes
+      const int l = threadIdx.x;
+      const uint32_t c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+      const uint32_t sl = c0 + c1 + c2 + c3;
+      uint32_t incl = sl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (l >= o) incl += t;
       }
-      bc[0] = d;
-      bc[1] = (uint32_t)kk;
-      bc[2] = acc;          // elements in lower bins of this pass
-      bc[3] = hist[d];      // elements in the chosen bin
+      const uint32_t excl = incl - sl;
+      const uint32_t kk0 = (uint32_t)k;
+      if (kk0 >= excl && kk0 < incl) {  // exactly one lane
+        uint32_t kk = kk0 - excl, d = 4 * l, below_d = excl, cd = c0;
+        if (kk >= c0) {
+          kk -= c0; below_d += c0; d++; cd = c1;
+          if (kk >= c1) {
+            kk -= c1; below_d += c1; d++; cd = c2;
+            if (kk >= c2) { kk -= c2; below_d += c2; d++; cd = c3; }
+          }
+        }
+        bc[0] = d;
+        bc[1] = kk;
+        bc[2] = below_d;  // elements in lower bins of this pass
+        bc[3] = cd;       // elements in the chosen bin
+      }
     }
     __syncthreads();
     prefix |= bc[0] << shift;
