@@ -168,22 +168,18 @@ __device__ __forceinline__ uint32_t f2key(float f) {  // order-preserving float 
 __device__ __forceinline__ float key2f(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
-// Histogram add with wave-level pre-aggregation: the top bytes of real-valued keys are concentrated in
-// a few bins, where per-lane LDS atomics on one address serialise (the first version of this kernel
-// spent 94 us there).  Up to 4 rounds elect a leader bin and add its popcount once; lanes still
-// unserved after that (spread-out bins, no contention) fall back to plain LDS atomics.
+// Histogram add.  One wave-level aggregation round for the first active lane's bin (the top bytes of
+// real-valued keys are concentrated in one or two bins, where per-lane LDS atomics on one address
+// would serialise), plain LDS atomics for everything else.
 __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t bin, bool active) {
-  unsigned long long remaining = __ballot(active);
-#pragma unroll 1
-  for (int round = 0; round < 4 && remaining; ++round) {
-    const int lead = __ffsll((long long)remaining) - 1;
-    const uint32_t lb = __shfl(bin, lead);
-    const unsigned long long m = __ballot(active && bin == lb);
-    if ((int)(threadIdx.x & 63) == lead) atomicAdd(&hist[lb], (uint32_t)__popcll(m));
-    if (bin == lb) active = false;
-    remaining &= ~m;
-  }
-  if (active) atomicAdd(&hist[bin], 1u);
+  const unsigned long long act = __ballot(active);
+  if (act == 0) return;
+  const int lead = __ffsll((long long)act) - 1;
+  const uint32_t lb = __shfl(bin, lead);
+  const bool same = active && bin == lb;
+  const unsigned long long m = __ballot(same);
+  if ((int)(threadIdx.x & 63) == lead) atomicAdd(&hist[lb], (uint32_t)__popcll(m));
+  if (active && !same) atomicAdd(&hist[bin], 1u);
 }
 
 // k-th smallest (0-based) key among x[0..n); every thread returns it.  hist: 256 uints in LDS.
@@ -195,8 +191,8 @@ __device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    const int64_t nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
-    for (int64_t i = threadIdx.x; i < nround; i += blockDim.x) {
+    const int nround = (int)((n + blockDim.x - 1) / blockDim.x * blockDim.x);
+    for (int i = threadIdx.x; i < nround; i += blockDim.x) {
       uint32_t key = 0;
       bool act = false;
       if (i < n) {

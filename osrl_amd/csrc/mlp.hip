@@ -389,56 +389,47 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ dz = E.dz;
   const float* __restrict__ av = E.a;
-  // branch-free fragment loads: clamped addresses + selects, double-buffered in registers so the
-  // next 16-row step's 32 dword loads are in flight while this step's 64 MFMAs run.
-  int oc[4], ic[4];
-  bool ook[4], iok[4];
+  for (int r0 = r_begin; r0 < r_end; r0 += 16) {
+    f32x4 af[4], bf[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int o = o0 + j * 16 + m, i = i0 + j * 16 + m;
-    ook[j] = j < nob && o < out;
-    iok[j] = j < nib && i < in;
-    oc[j] = ook[j] ? o : 0;
-    ic[j] = iok[j] ? i : 0;
-  }
-  auto load_frags = [&](int r0, f32x4 (&af)[4], f32x4 (&bf)[4]) {
+    for (int ob = 0; ob < 4; ++ob) {
+      af[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ob < nob) {
+        const int o = o0 + ob * 16 + m;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = r0 + 4 * kq + t;
-      const bool rok = r < r_end;
-      const size_t rc = rok ? (size_t)r : (size_t)(r_end - 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x = dz[rc * out + oc[j]];
-        const float y = av[rc * in + ic[j]];
-        af[j][t] = (rok && ook[j]) ? x : 0.f;
-        bf[j][t] = (rok && iok[j]) ? y : 0.f;
+        for (int t = 0; t < 4; ++t) {
+          const int r = r0 + 4 * kq + t;
+          if (o < out && r < r_end) af[ob][t] = dz[(size_t)r * out + o];
+        }
       }
     }
-  };
-  auto mma = [&](const f32x4 (&af)[4], const f32x4 (&bf)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int ib = 0; ib < 4; ++ib) {
+      bf[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ib < nib) {
+        const int i = i0 + ib * 16 + m;
 #pragma unroll
-      for (int ob = 0; ob < 4; ++ob)
+        for (int t = 0; t < 4; ++t) {
+          const int r = r0 + 4 * kq + t;
+          if (i < in && r < r_end) bf[ib][t] = av[(size_t)r * in + i];
+        }
+      }
+    }
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-          acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ob][t], bf[ib][t], acc[ob][ib], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        if (ob < nob) {
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib)
+            if (ib < nib)
+              acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ob][t], bf[ib][t], acc[ob][ib], 0, 0, 0);
+        }
+      }
+    }
     if (it == 0) {
 #pragma unroll
       for (int ob = 0; ob < 4; ++ob) dbacc[ob] += (af[ob][0] + af[ob][1]) + (af[ob][2] + af[ob][3]);
-    }
-  };
-  if (r_begin < r_end) {
-    f32x4 a0[4], b0[4], a1[4], b1[4];
-    load_frags(r_begin, a0, b0);
-    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
-      load_frags(r0 + 16 < r_end ? r0 + 16 : r0, a1, b1);
-      mma(a0, b0);
-      if (r0 + 16 < r_end) {
-        load_frags(r0 + 32 < r_end ? r0 + 32 : r0 + 16, a0, b0);
-        mma(a1, b1);
-      }
     }
   }
   float* __restrict__ slab = slabs + (size_t)s * slab_stride;

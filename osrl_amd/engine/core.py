@@ -382,6 +382,41 @@ class DwPlan:
                 "osrl_mlp_backward_dw")
 
 
+class Branches:
+    """Fork/join of independent parts of a step onto side streams.  Inside hipGraph capture this turns
+    into parallel graph branches (the 2048-row kernels occupy <= 256 workgroups each, so independent
+    phases overlap on the 256 CUs); disabled => everything runs in order on the current stream."""
+
+    def __init__(self, enabled: bool, n: int = 2):
+        self.enabled = enabled and torch.cuda.is_available()
+        self.side = [torch.cuda.Stream() for _ in range(n)] if self.enabled else []
+
+    def fork(self, i: int, after: Optional[int] = None) -> None:
+        """side[i] starts after everything enqueued so far on the current stream (or on side[after])."""
+        if self.enabled:
+            self.side[i].wait_stream(torch.cuda.current_stream() if after is None else self.side[after])
+
+    def on(self, i: int):
+        import contextlib
+        return torch.cuda.stream(self.side[i]) if self.enabled else contextlib.nullcontext()
+
+    def join(self, i: int) -> None:
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.side[i])
+
+    def mark(self, i: int):
+        """Event after the work enqueued so far on side[i]."""
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side[i])
+        return ev
+
+    def wait(self, ev) -> None:
+        if self.enabled and ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
 class StepState:
     """Device-resident step counter / bias corrections / statistics ring (csrc/optim.hip)."""
 

@@ -19,7 +19,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import DwPlan, MlpRun, StepState, concat_nets, randn_fill
+from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, randn_fill
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
@@ -111,7 +111,7 @@ class CPQEngine:
 
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
-        self._graph_failed = False
+        self.parallel_branches = True
 
     # ------------------------------------------------------------------ #
     def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
@@ -122,17 +122,45 @@ class CPQEngine:
             self.dist.allreduce_group(grp)
         grp.adam_step(m._lrs[name], self.st.ptr, tau=tau)
 
-    def body(self, device_noise: bool) -> None:
+    def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
+        """One step.  ``par`` (graph capture only) forks the independent parts onto side streams:
+        critic phase (cpq.py:137-153) and the cost-critic target pre-work (cpq.py:159-176) do not depend
+        on the VAE update, so they run beside the VAE phase; everything joins before the cost-critic
+        optimizer step (which Polyak-updates targets the critic branch reads)."""
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
+        par = par or Branches(False)
         st.tick()
         if self.replay is not None:
             self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
         if device_noise:
             randn_fill(self.noise_flat, self.seed, 0, st.ptr)
 
-        # ---- vae_loss  (cpq.py:125-135)
+        # ---- branch 0: critic_loss  (cpq.py:137-153)
+        par.fork(0)
+        with par.on(0):
+            head_next = self.r_actor_next.forward(self.nobs)[0]
+            par.fork(1, after=0)  # branch 1 needs head_next
+            G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
+            y_old = self.r_old_next.forward(self.nobs, self.a_next)
+            q = self.r_critic.forward(self.obs, self.act)
+            G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
+                              rg, self.dq, st.stat_ptr("loss/critic_loss"))
+            self.r_critic.backward_dz()
+            self._optim("critic", self.p_critic, m.tau)
+
+        # ---- branch 1: everything of cost_critic_loss that needs neither the new VAE nor a reduction
+        with par.on(1):
+            G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+            qc_old_next = self.r_costold_next.forward(self.nobs, self.a_next2)
+            head_obs = self.r_actor_obs.forward(self.obs)[0]
+            G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
+            ev_sampled = par.mark(1)
+            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+            qc = self.r_cost.forward(self.obs, self.act)
+
+        # ---- main: vae_loss  (cpq.py:125-135)
         head = self.r_enc.forward(self.obs, self.act)[0]
         G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
@@ -142,37 +170,24 @@ class CPQEngine:
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
 
-        # ---- critic_loss  (cpq.py:137-153)
-        head_next = self.r_actor_next.forward(self.nobs)[0]
-        G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
-        y_old = self.r_old_next.forward(self.nobs, self.a_next)
-        q = self.r_critic.forward(self.obs, self.act)
-        G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres, rg,
-                          self.dq, st.stat_ptr("loss/critic_loss"))
-        self.r_critic.backward_dz()
-        self._optim("critic", self.p_critic, m.tau)
-
-        # ---- cost_critic_loss  (cpq.py:155-201)
-        G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
-        qc_old_next = self.r_costold_next.forward(self.nobs, self.a_next2)
-        head_obs = self.r_actor_obs.forward(self.obs)[0]
-        G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
-        qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+        # ---- cost_critic_loss  (cpq.py:155-201): OOD scoring with the UPDATED vae
+        par.wait(ev_sampled)
         head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
         G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
         if self.dist is not None:
             self.dist.quantile(self.kl, 0.75, self.quant)
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
+        par.join(1)
         G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
         share = 1.0
         if self.dist is not None:
             self.dist.all_reduce_(self.ood_mean)
             share = 1.0 / self.dist.world
-        qc = self.r_cost.forward(self.obs, self.act)
         G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg,
                         share, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
+        par.join(0)  # the critic branch reads cost_critic_old, which the next optimizer step updates
         self._optim("cost_critic", self.p_cost, m.tau)
 
         # ---- actor_loss  (cpq.py:203-222)
@@ -202,14 +217,16 @@ class CPQEngine:
         """Capture one step (device-drawn noise) into a hipGraph.  Warm-up launches run first on a
         side stream as torch requires; the model state they advance is restored afterwards."""
         snap = self._snapshot()
+        par = Branches(self.parallel_branches, 2)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.body(True)
+            self.body(True, par)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.body(True)
+            self.body(True, par)
+        self._par = par  # keep the side streams alive with the graph
         torch.cuda.synchronize()
         self._restore(snap)
         self.graph = g

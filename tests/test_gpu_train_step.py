@@ -105,3 +105,21 @@ def test_graph_replay_is_deterministic_and_trains(name):
     p0 = {k: torch.from_numpy(v) for k, v in __import__("cases").make_params(c).items()}
     moved = sum(float((outs[0][0][k].cpu() - p0[k]).abs().max()) > 0 for k in p0)
     assert moved == len(p0)
+
+
+@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small"])
+def test_graph_with_parallel_branches_equals_eager_sequential(name):
+    """The captured graph (forked side-stream branches, device Philox noise) must produce exactly the same
+    parameters as the plain in-order launch sequence: same kernels, same inputs, no atomics."""
+    c = CASES[name]
+    res = []
+    for use_graph in (False, True):
+        m, tr, lg = build_gpu(c, stats_mode="none", use_graph=use_graph)
+        b = gpu_batch(c)
+        for s in range(4):
+            gpu_step(tr, c, b, s, with_noise=False)
+        torch.cuda.synchronize()
+        assert (m._engine.graph is not None) == use_graph
+        res.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), f"{name}: {k} differs between eager and graph execution"
