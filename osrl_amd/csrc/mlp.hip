@@ -38,6 +38,14 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef OSRL_PHASE_TIMING  // tools/mlp_phase.hip: per-phase cycle stamps of workgroup 0 (debug builds only)
+__device__ long long g_phase_t[4][64];
+#define PHASE_STAMP(i) \
+  if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_phase_t[threadIdx.x >> 6][i] = __builtin_readcyclecounter()
+#else
+#define PHASE_STAMP(i)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float act_fwd(int act, float x) {
@@ -75,7 +83,7 @@ __device__ __forceinline__ f32x4 load_bp(const float* __restrict__ P, int Np, in
 // fragments (ds_read_b128 from the LDS activation tile) are prefetched one step ahead.
 template <int NRB, int CNT, int STAGES>
 __device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
-                                              int col0, f32x4 (&acc)[NRB][CNT]) {
+                                              int col0, f32x4 (&acc)[NRB][CNT], int kc0 = 0) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
@@ -83,9 +91,9 @@ __device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int nk,
   // Every workgroup needs the SAME weight lines; each starts its k-walk at a different step so the
   // request streams are decorrelated (fp32 sum order changes per workgroup; fixed per (grid, tile)).
   const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u + (threadIdx.x >> 6)) % (unsigned)nk);
-  auto kstep = [&](int kc) {
+  auto kstep = [&](int kc) {  // nk steps starting at kc0 (split-K callers pass a sub-range)
     int k = kc + rot;
-    return k >= nk ? k - nk : k;
+    return kc0 + (k >= nk ? k - nk : k);
   };
   f32x4 b[STAGES][CNT];
   f32x4 a[2][NRB];
@@ -161,6 +169,53 @@ __device__ __forceinline__ void layer_mm(const float* lds, int lda, int nk, cons
   }
 }
 
+// Narrow layer (N <= 32, e.g. the 1-wide Q head or the 2*ad-wide policy head): instead of one wave
+// walking all of K alone, the 4 waves split K; partial tiles are summed through the (free) LDS
+// activation buffer.  On return lds[row][c], c < nblk*16, holds the raw sums (no bias/activation).
+// Requires lda >= 64 and nk >= 4.  Contains the barriers that protect the in-place overwrite.
+template <int NRB>
+__device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk, const float* __restrict__ P, int Np,
+                                                    int col_off, int nblk, int wave) {
+  const int lane = threadIdx.x & 63;
+  const int parts = 4 / nblk;            // waves per column block (nblk is 1 or 2)
+  const int blk = wave / parts, part = wave - blk * parts;
+  const int k_lo = (nk * part) / parts, k_hi = (nk * (part + 1)) / parts;
+  f32x4 t[NRB][1];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (k_hi > k_lo) layer_mm_core<NRB, 1, 3>(lds, lda, k_hi - k_lo, P, Np, col_off + blk * 16, t, k_lo);
+  __syncthreads();  // all reads of the input activations are done
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds[(rb * 16 + (lane >> 4) * 4 + r) * lda + wave * 16 + (lane & 15)] = t[rb][0][r];
+  __syncthreads();
+  constexpr int BM = 16 * NRB;
+  const int ncol = nblk * 16;
+  float v[(BM * 32 + 255) / 256];
+#pragma unroll
+  for (int j = 0; j < (BM * 32 + 255) / 256; ++j) {
+    const int e = j * 256 + (int)threadIdx.x;
+    float sacc = 0.f;
+    if (e < BM * ncol) {
+      const int r = e / ncol, c = e - r * ncol;
+      const int b = c >> 4, cc = c & 15;
+      for (int q = 0; q < parts; ++q) sacc += lds[r * lda + (b * parts + q) * 16 + cc];
+    }
+    v[j] = sacc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < (BM * 32 + 255) / 256; ++j) {
+    const int e = j * 256 + (int)threadIdx.x;
+    if (e < BM * ncol) {
+      const int r = e / ncol, c = e - r * ncol;
+      lds[r * lda + c] = v[j];
+    }
+  }
+  __syncthreads();
+}
+
 template <int NRB, int NCB>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRB][NCB]) {
 #pragma unroll
@@ -207,56 +262,100 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
   const int rows = a.in.rows, lda = a.lda;
   const int L = a.net.n_layers;
 
-  {  // stage cat(src0[map0(r)], src1[map1(r)]) zero-padded to a multiple of 16 columns
+  PHASE_STAMP(0);
+  {  // stage cat(src0[map0(r)], src1[map1(r)]) zero-padded to a multiple of 16 columns.
+     // 16 lanes walk one row (64-byte segments), 16 rows per pass; every load of a pass is issued
+     // before the first LDS store (branch-free clamped addresses), so the latencies overlap.
     const int K0 = a.net.dims[0], K0p = round16(K0);
     const int d0 = a.in.d0, d1 = a.in.d1;
-    for (int idx = tid; idx < BM * K0p; idx += 256) {
-      const int r = idx / K0p, c = idx - r * K0p;
+    const int cl = tid & 15, rl = tid >> 4;
+    const float* __restrict__ s0 = a.in.src0;
+    const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
+#pragma unroll 1
+    for (int r = rl; r < BM; r += 16) {
       const int gr = row0 + r;
-      float v = 0.f;
-      if (gr < rows) {
-        if (c < d0)
-          v = a.in.src0[(size_t)map_row(gr, a.in.map0, a.in.div0) * d0 + c];
-        else if (c < d0 + d1)
-          v = a.in.src1[(size_t)map_row(gr, a.in.map1, a.in.div1) * d1 + (c - d0)];
-      }
-      lds[r * lda + c] = v;
-    }
-    __syncthreads();
-    if (e == 0 && a.out.x) tile_to_global(lds, lda, BM, K0, a.out.x, row0, rows);
-  }
-
-  for (int l = 0; l < L; ++l) {
-    const int K = a.net.dims[l], N = a.net.dims[l + 1];
-    const int nblk = (N + 15) >> 4;
-    int cb0, cnt;
-    wave_blocks(nblk, wave, &cb0, &cnt);  // cnt may be 0 for idle waves
-    f32x4 acc[NRB][NCB];
-    zero_acc<NRB, NCB>(acc);
-    if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wf[e][l], round16(N), cb0 * 16, cnt, acc);
-    __syncthreads();  // every wave finished reading the previous activations
-    const float* __restrict__ bias = a.net.b[e][l];
-    const int act = a.net.acts[l];
-    const float oscale = (l == L - 1) ? a.net.out_scale : 1.0f;
+      const bool rok = gr < rows;
+      const int grc = rok ? gr : rows - 1;
+      const float* p0 = s0 + (size_t)map_row(grc, a.in.map0, a.in.div0) * d0;
+      const float* p1 = s1 + (size_t)map_row(grc, a.in.map1, a.in.div1) * d1 - d0;
+      for (int cbase = 0; cbase < K0p; cbase += 16 * 8) {
+        float v[8];
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-      if (c < cnt) {
-        const int col = (cb0 + c) * 16 + (lane & 15);
-        const float bv = col < N ? bias[col] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const int c = cbase + j * 16 + cl;
+          const bool in0 = c < d0, ok = rok && c < d0 + d1;
+          const float* p = in0 ? p0 + c : p1 + c;
+          v[j] = *(ok ? p : s0);
+          v[j] = ok ? v[j] : 0.f;
+        }
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = rb * 16 + (lane >> 4) * 4 + r;
-            float v = act_fwd(act, acc[rb][c][r] + bv) * oscale;
-            lds[row * lda + col] = col < N ? v : 0.f;  // zero the k-padding of the next layer
-          }
+        for (int j = 0; j < 8; ++j) {
+          const int c = cbase + j * 16 + cl;
+          if (c < K0p) lds[r * lda + c] = v[j];
         }
       }
     }
     __syncthreads();
+    if (e == 0 && a.out.x) tile_to_global(lds, lda, BM, K0, a.out.x, row0, rows);
+  }
+  PHASE_STAMP(1);
+
+  for (int l = 0; l < L; ++l) {
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    const int nblk = (N + 15) >> 4;
+    const float* __restrict__ bias = a.net.b[e][l];
+    const int act = a.net.acts[l];
+    const float oscale = (l == L - 1) ? a.net.out_scale : 1.0f;
+    const int nk = round16(K) >> 4;
+    if (nblk <= 2 && nk >= 4 && lda >= 64) {
+      // narrow layer: split K over the 4 waves, then bias/activation on the summed tile in LDS
+      narrow_layer_splitk<NRB>(lds, lda, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave);
+      PHASE_STAMP(2 + 4 * l);
+      PHASE_STAMP(3 + 4 * l);
+      const int ncol = nblk * 16;
+      for (int idx = tid; idx < BM * ncol; idx += 256) {
+        const int r = idx / ncol, c = idx - r * ncol;
+        const float v = c < N ? act_fwd(act, lds[r * lda + c] + bias[c]) * oscale : 0.f;
+        lds[r * lda + c] = v;
+      }
+    } else {
+      int cb0, cnt;
+      wave_blocks(nblk, wave, &cb0, &cnt);  // cnt may be 0 for idle waves
+      float bv[NCB];  // bias fetched before the k-loop so its latency hides behind the MFMAs
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        const int col = (cb0 + c) * 16 + (lane & 15);
+        const bool ok = c < cnt && col < N;
+        bv[c] = bias[ok ? col : 0];
+        bv[c] = ok ? bv[c] : 0.f;
+      }
+      f32x4 acc[NRB][NCB];
+      zero_acc<NRB, NCB>(acc);
+      if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, nk, a.net.Wf[e][l], round16(N), cb0 * 16, cnt, acc);
+      PHASE_STAMP(2 + 4 * l);
+      __syncthreads();  // every wave finished reading the previous activations
+      PHASE_STAMP(3 + 4 * l);
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        if (c < cnt) {
+          const int col = (cb0 + c) * 16 + (lane & 15);
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = rb * 16 + (lane >> 4) * 4 + r;
+              const float v = act_fwd(act, acc[rb][c][r] + bv[c]) * oscale;
+              lds[row * lda + col] = col < N ? v : 0.f;  // zero the k-padding of the next layer
+            }
+          }
+        }
+      }
+    }
+    PHASE_STAMP(4 + 4 * l);
+    __syncthreads();
     float* save = a.out.h[e][l];
     if (save) tile_to_global(lds, lda, BM, N, save, row0, rows);
+    PHASE_STAMP(5 + 4 * l);
   }
 }
 
@@ -304,13 +403,32 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
     const int nblk = (N + 15) >> 4;
     int cb0, cnt;
     wave_blocks(nblk, wave, &cb0, &cnt);
+    const float* __restrict__ h = a.saved.h[e][l - 1];
+    const int act = a.net.acts[l - 1];
+    // activation outputs needed by act'(.) in the epilogue: fetched BEFORE the k-loop (small tiles)
+    constexpr bool PREFETCH_H = NRB * NCB * 4 <= 32;
+    float hv[PREFETCH_H ? NRB : 1][PREFETCH_H ? NCB : 1][4];
+    if (PREFETCH_H) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        const int col = (cb0 + c) * 16 + (lane & 15);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gr = row0 + rb * 16 + (lane >> 4) * 4 + r;
+            const bool ok = c < cnt && col < N && gr < rows;
+            const float x = h[ok ? (size_t)gr * N + col : 0];
+            hv[PREFETCH_H ? rb : 0][PREFETCH_H ? c : 0][r] = ok ? x : 0.f;
+          }
+        }
+      }
+    }
     f32x4 acc[NRB][NCB];
     zero_acc<NRB, NCB>(acc);
     // packed W^T: contraction over the layer's outputs (K), columns = the layer's inputs (N) (+16 pad)
     if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt, acc);
     __syncthreads();
-    const float* __restrict__ h = a.saved.h[e][l - 1];
-    const int act = a.net.acts[l - 1];
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
       if (c < cnt) {
@@ -322,7 +440,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
             const int row = rb * 16 + (lane >> 4) * 4 + r;
             const int gr = row0 + row;
             float v = 0.f;
-            if (col < N && gr < rows) v = acc[rb][c][r] * act_bwd(act, h[(size_t)gr * N + col]);
+            if (PREFETCH_H) {
+              v = (col < N && gr < rows) ? acc[rb][c][r] * act_bwd(act, hv[PREFETCH_H ? rb : 0][PREFETCH_H ? c : 0][r]) : 0.f;
+            } else if (col < N && gr < rows) {
+              v = acc[rb][c][r] * act_bwd(act, h[(size_t)gr * N + col]);
+            }
             lds[row * lda + col] = v;
           }
         }
@@ -336,24 +458,29 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
     // dX[:, c0:c0+nc] = dZ_0 * W_0[:, c0:c0+nc]
     const int K = a.net.dims[1], nc = a.g.dx_cols;
     const int nblk = (nc + 15) >> 4;
-    int cb0, cnt;
-    wave_blocks(nblk, wave, &cb0, &cnt);
-    f32x4 acc[NRB][NCB];
-    zero_acc<NRB, NCB>(acc);
-    if (cnt > 0)
-      layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][0], round16(a.net.dims[0]) + 16,
-                         a.g.dx_col0 + cb0 * 16, cnt, acc);
+    const int nk = round16(K) >> 4;
+    const int Npb = round16(a.net.dims[0]) + 16;
     float* __restrict__ dx = a.g.dx[e];
+    if (nblk <= 2 && nk >= 4 && lda >= 64) {
+      narrow_layer_splitk<NRB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave);
+      tile_to_global(lds, lda, BM, nc, dx, row0, rows);
+    } else {
+      int cb0, cnt;
+      wave_blocks(nblk, wave, &cb0, &cnt);
+      f32x4 acc[NRB][NCB];
+      zero_acc<NRB, NCB>(acc);
+      if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0 + cb0 * 16, cnt, acc);
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-      if (c < cnt) {
-        const int col = (cb0 + c) * 16 + (lane & 15);
+      for (int c = 0; c < NCB; ++c) {
+        if (c < cnt) {
+          const int col = (cb0 + c) * 16 + (lane & 15);
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
+          for (int rb = 0; rb < NRB; ++rb) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int gr = row0 + rb * 16 + (lane >> 4) * 4 + r;
-            if (col < nc && gr < rows) dx[(size_t)gr * nc + col] = acc[rb][c][r];
+            for (int r = 0; r < 4; ++r) {
+              const int gr = row0 + rb * 16 + (lane >> 4) * 4 + r;
+              if (col < nc && gr < rows) dx[(size_t)gr * nc + col] = acc[rb][c][r];
+            }
           }
         }
       }

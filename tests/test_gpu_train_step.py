@@ -123,3 +123,39 @@ def test_graph_with_parallel_branches_equals_eager_sequential(name):
         res.append({k: v.clone() for k, v in m.state_dict().items()})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), f"{name}: {k} differs between eager and graph execution"
+
+
+def test_data_parallel_path_world1_nccl_matches_single():
+    """The DP wiring (slab pre-reduction -> RCCL all-reduce -> Adam on the reduced gradient, all-gather
+    quantile, scalar all-reduces) run as a 1-rank NCCL job must reproduce the plain single-GPU step
+    bit-for-bit (all reductions are identities at world_size 1)."""
+    import os
+    import torch.distributed as dist
+    from osrl_amd.engine.dist import DataParallel
+    c = CASES["cpq_small"]
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        res = []
+        for use_dp in (False, True):
+            m, tr, lg = build_gpu(c)
+            b = gpu_batch(c)
+            if use_dp:
+                dp = DataParallel()
+                eng = m.engine(c.B, rows_global=c.B * dp.world, dist=dp)
+                dp.broadcast_model(m)
+            for s in range(3):
+                gpu_step(tr, c, b, s)
+            torch.cuda.synchronize()
+            res.append(({k: v.clone() for k, v in m.state_dict().items()}, dict(lg.data)))
+        for k in res[0][0]:
+            assert torch.equal(res[0][0][k], res[1][0][k]), k
+        for k in res[0][1]:
+            assert [float(x) for x in res[0][1][k]] == [float(x) for x in res[1][1][k]], k
+    finally:
+        if created:
+            dist.destroy_process_group()
