@@ -222,7 +222,7 @@ def main():
                                    "hidden [256,256], VAE 400, N=10, num_q=num_qc=2; on-device replay sampling "
                                    "from a 2^20-transition HBM store + Philox noise inside the step",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "graph": bool(use_graph and world == 1)},
+                       "graph": bool(eng.graph is not None), "parallel_graph_branches": bool(world == 1)},
             "algorithmic_gflop_per_step": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / 1e9, 2),
             "step_tflops": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / (dt / args.steps) / 1e12, 3),
             "last_stats": {k: round(float(v), 5) for k, v in stats.items()},

@@ -30,6 +30,9 @@ class BCQLEngine:
         dev = torch.device(m.device)
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc = m.num_q, m.num_qc
+        if dist is not None:
+            raise NotImplementedError("BCQ-Lag data parallelism is not wired yet: the PID controller needs the "
+                                      "global mean of qc_pi before the loss gradient (SURVEY.md 8e item 2)")
         if 2 * nq + 2 * nqc > L.MAX_NETS:
             raise ValueError(f"2*num_q + 2*num_qc = {2 * nq + 2 * nqc} > {L.MAX_NETS} nets per fused launch")
         f = dict(dtype=torch.float32, device=dev)

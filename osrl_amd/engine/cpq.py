@@ -112,6 +112,7 @@ class CPQEngine:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
         self.parallel_branches = True
+        self._graph_failed = False
 
     # ------------------------------------------------------------------ #
     def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
@@ -217,7 +218,8 @@ class CPQEngine:
         """Capture one step (device-drawn noise) into a hipGraph.  Warm-up launches run first on a
         side stream as torch requires; the model state they advance is restored afterwards."""
         snap = self._snapshot()
-        par = Branches(self.parallel_branches, 2)
+        # collectives stay on the capture stream: no forked branches in the data-parallel graph
+        par = Branches(self.parallel_branches and self.dist is None, 2)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -260,16 +262,31 @@ class CPQEngine:
         self.replay = store
         self.graph = None
 
+    def _run(self, use_graph: bool) -> None:
+        """Replay the captured step (capturing it first).  With a DataParallel hook the RCCL collectives
+        are captured into the same hipGraph; if the runtime refuses (older RCCL), fall back to eager."""
+        if use_graph and not self._graph_failed:
+            if self.graph is None:
+                try:
+                    self.capture()
+                except Exception as e:  # pragma: no cover - depends on the RCCL build
+                    if self.dist is None:
+                        raise
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the data-parallel step failed ({e!r}); running eagerly")
+                    torch.cuda.synchronize()
+                    self._graph_failed = True
+                    self.graph = None
+            if self.graph is not None:
+                self.graph.replay()
+                self.st.host_step += 1
+                return
+        self.body(True)
+
     def step_replay(self, use_graph: bool = True) -> None:
         """One train step on a minibatch drawn on device from the attached replay store."""
         assert self.replay is not None
-        if use_graph and self.dist is None:
-            if self.graph is None:
-                self.capture()
-            self.graph.replay()
-            self.st.host_step += 1
-        else:
-            self.body(True)
+        self._run(use_graph)
 
     def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
              use_graph: bool = True) -> None:
@@ -280,10 +297,4 @@ class CPQEngine:
             self.load_noise(noise)
             self.body(False)
             return
-        if use_graph and self.dist is None:
-            if self.graph is None:
-                self.capture()
-            self.graph.replay()
-            self.st.host_step += 1
-        else:
-            self.body(True)
+        self._run(use_graph)

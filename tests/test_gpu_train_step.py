@@ -159,3 +159,36 @@ def test_data_parallel_path_world1_nccl_matches_single():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_data_parallel_graph_capture_world1():
+    """hipGraph capture of the DP step including its RCCL collectives (1-rank job): must either capture
+    and replay deterministically or fall back to eager with a warning -- never hang or corrupt state."""
+    import os
+    import torch.distributed as dist
+    from osrl_amd.engine.dist import DataParallel
+    c = CASES["cpq_small"]
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        outs = []
+        for rep in range(2):
+            m, tr, lg = build_gpu(c, stats_mode="none", use_graph=True)
+            dp = DataParallel()
+            eng = m.engine(c.B, rows_global=c.B, dist=dp)
+            b = gpu_batch(c)
+            for s in range(4):
+                gpu_step(tr, c, b, s, with_noise=False)
+            torch.cuda.synchronize()
+            assert eng.st.device_step() == 4
+            outs.append({k: v.clone() for k, v in m.state_dict().items()})
+            print("DP graph captured:", eng.graph is not None)
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()
