@@ -1,0 +1,265 @@
+"""CPU oracle for the Constrained Decision Transformer train step (TEST INFRASTRUCTURE ONLY --
+see oracle/osrl_oracle.py for the rules; pinned by tests/golden/cdt_*.npz captured from the reference).
+
+Restates, in numpy with a hand-derived backward pass:
+  * CDT.forward                      osrl/algorithms/cdt.py:166-265
+  * TransformerBlock.forward         osrl/common/net.py:422-441  (nn.MultiheadAttention recipe)
+  * DiagGaussianActor.forward        osrl/common/net.py:530-533
+  * CDTTrainer.train_one_step        osrl/algorithms/cdt.py:343-418  (AdamW + clip_grad_norm_ + LambdaLR warm-up
+                                     + temperature Adam)
+Supported configuration = the reference's train defaults (examples/configs/cdt_configs.py:22-89):
+time_emb, use_rew, use_cost, optional cost_transform, action_head_layers=1, no cost-feature variants, no
+cost prefix, stochastic or deterministic head, dropout 0 (parity) .
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+from scipy.special import erf
+
+from .osrl_oracle import Adam
+
+Array = np.ndarray
+State = Dict[str, Array]
+
+
+def layer_norm(x: Array, g: Array, b: Array, eps: float = 1e-5):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)  # biased variance (nn.LayerNorm)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mu) * rstd
+    return xhat * g + b, (xhat, rstd)
+
+
+def layer_norm_bwd(dy: Array, cache, g: Array):
+    xhat, rstd = cache
+    dxhat = dy * g
+    dx = rstd * (dxhat - dxhat.mean(-1, keepdims=True) - xhat * (dxhat * xhat).mean(-1, keepdims=True))
+    red = tuple(range(dy.ndim - 1))
+    return dx, (dy * xhat).sum(red), dy.sum(red)
+
+
+def gelu(x: Array) -> Array:  # nn.GELU() exact erf form
+    return 0.5 * x * (1.0 + erf(x / math.sqrt(2.0)))
+
+
+def gelu_grad(x: Array) -> Array:
+    return 0.5 * (1.0 + erf(x / math.sqrt(2.0))) + x * np.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+class OracleCDT:
+    def __init__(self, params: State, *, seq_len: int, num_heads: int, num_layers: int, max_action: float = 1.0,
+                 cost_transform: bool = True, stochastic: bool = True, init_temperature: float = 0.1,
+                 target_entropy: Optional[float] = None, learning_rate: float = 1e-4, weight_decay: float = 1e-4,
+                 betas=(0.9, 0.999), clip_grad: Optional[float] = 0.25, lr_warmup_steps: int = 500,
+                 loss_cost_weight: float = 0.02, loss_state_weight: float = 0.0, no_entropy: bool = False,
+                 dtype=np.float32):
+        self.p = {k: np.array(v, dtype=dtype) for k, v in params.items() if "causal_mask" not in k}
+        self.dtype = dtype
+        self.T, self.H, self.NL = seq_len, num_heads, num_layers
+        self.E = self.p["emb_norm.weight"].shape[0]
+        self.cost_transform, self.stochastic = cost_transform, stochastic
+        self.max_action = max_action
+        self.log_temperature = math.log(init_temperature)  # cdt.py:144
+        self.target_entropy = target_entropy
+        self.lr, self.warmup, self.clip = learning_rate, lr_warmup_steps, clip_grad
+        self.cw, self.sw, self.no_entropy = loss_cost_weight, loss_state_weight, no_entropy
+        self.opt = Adam(list(self.p.keys()), learning_rate, betas[0], betas[1], 1e-8, weight_decay)  # AdamW :321-326
+        self.opt_T = Adam(["log_temperature"], 1e-4, 0.9, 0.999)  # cdt.py:332-337
+        self.steps = 0
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, states, actions, returns, costs_to_go, time_steps, mask):
+        p, E, H = self.p, self.E, self.H
+        B, T, _ = states.shape
+        S = 4 * T
+        c = {}
+        te = p["timestep_emb.weight"][time_steps]  # [B,T,E]
+        ctg = (50.0 - costs_to_go) if self.cost_transform else costs_to_go  # cdt.py:78-81,187-188
+        c["ctg"] = ctg
+        r_e = returns[..., None] * p["return_emb.weight"][:, 0] + p["return_emb.bias"] + te
+        c_e = ctg[..., None] * p["cost_emb.weight"][:, 0] + p["cost_emb.bias"] + te
+        s_e = states @ p["state_emb.weight"].T + p["state_emb.bias"] + te
+        a_e = actions @ p["action_emb.weight"].T + p["action_emb.bias"] + te
+        seq = np.stack([r_e, c_e, s_e, a_e], 2).reshape(B, S, E)  # (r,c,s,a) per timestep  cdt.py:185-200
+        x, c["ln_emb"] = layer_norm(seq, p["emb_norm.weight"], p["emb_norm.bias"])
+        key_pad = np.repeat(mask <= 0, 4, axis=1)  # [B,S] True = ignore  cdt.py:202-205
+        causal = np.triu(np.ones((S, S), bool), 1)  # True = blocked  net.py:417-418
+        blocked = causal[None, None] | key_pad[:, None, None, :]
+        d = E // H
+        c["blocks"] = []
+        for l in range(self.NL):
+            pre = f"blocks.{l}."
+            bc = {"x_in": x}
+            n1, bc["ln1"] = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"])
+            qkv = n1 @ p[pre + "attention.in_proj_weight"].T + p[pre + "attention.in_proj_bias"]
+            q, k, v = (qkv[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
+            sc = (q @ k.transpose(0, 1, 3, 2)) / math.sqrt(d)
+            sc = np.where(blocked, -np.inf, sc)
+            sc = sc - sc.max(-1, keepdims=True)
+            P = np.exp(sc)
+            P = P / P.sum(-1, keepdims=True)
+            o = (P @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
+            att = o @ p[pre + "attention.out_proj.weight"].T + p[pre + "attention.out_proj.bias"]
+            x = x + att
+            n2, bc["ln2"] = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
+            hpre = n2 @ p[pre + "mlp.0.weight"].T + p[pre + "mlp.0.bias"]
+            h = gelu(hpre)
+            x = x + h @ p[pre + "mlp.2.weight"].T + p[pre + "mlp.2.bias"]
+            bc.update(n1=n1, q=q, k=k, v=v, P=P, o=o, n2=n2, hpre=hpre, h=h)
+            c["blocks"].append(bc)
+        out, c["ln_out"] = layer_norm(x, p["out_norm.weight"], p["out_norm.bias"])
+        out4 = out.reshape(B, T, 4, E)
+        sf, af = out4[:, :, 2], out4[:, :, 3]  # action head reads the STATE token  cdt.py:239-240
+        c.update(sf=sf, af=af)
+        res = {}
+        if self.stochastic:
+            res["mu"] = sf @ p["action_head.mu.weight"].T + p["action_head.mu.bias"]
+            res["ls"] = sf @ p["action_head.log_std.weight"].T + p["action_head.log_std.bias"]
+        else:
+            res["act"] = sf @ p["action_head.0.weight"].T + p["action_head.0.bias"]
+        logits = af @ p["cost_pred_head.weight"].T + p["cost_pred_head.bias"]
+        z = logits - logits.max(-1, keepdims=True)
+        res["cost_logp"] = z - np.log(np.exp(z).sum(-1, keepdims=True))
+        res["state_pred"] = af @ p["state_pred_head.weight"].T + p["state_pred_head.bias"]
+        return res, c
+
+    def act_mean(self, states, actions, returns, costs_to_go, time_steps, mask):
+        """Deterministic action prediction (mean) for every timestep of the window."""
+        res, _ = self.forward(*(np.asarray(a, self.dtype) if a.dtype.kind == "f" else a
+                                for a in (states, actions, returns, costs_to_go, time_steps, mask)))
+        return res["mu"] if self.stochastic else res["act"]
+
+    # ------------------------------------------------------------------ one train step
+    def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs):
+        dt = self.dtype
+        states, actions, returns, costs_return, mask = (np.asarray(a, dt) for a in
+                                                        (states, actions, returns, costs_return, mask))
+        time_steps = np.asarray(time_steps, np.int64)
+        costs_i = np.asarray(costs).astype(np.int64)
+        p, E, H = self.p, self.E, self.H
+        B, T, od = states.shape
+        ad = actions.shape[-1]
+        S, d = 4 * T, E // H
+        res, c = self.forward(states, actions, returns, costs_return, time_steps, mask)
+        valid = mask > 0
+        nv = max(int(valid.sum()), 1) * ad
+        stats = {}
+        g: State = {}
+        # ---- losses (cdt.py:357-394) and gradients wrt the head outputs
+        temp = math.exp(self.log_temperature)
+        if self.stochastic:
+            mu, ls = res["mu"], res["ls"]
+            std = np.exp(ls)
+            zz = (actions - mu) / std
+            logp = -0.5 * zz * zz - ls - 0.5 * math.log(2 * math.pi)
+            ll = (logp * valid[..., None]).sum() / nv
+            ent = ((0.5 + 0.5 * math.log(2 * math.pi) + ls) * valid[..., None]).sum() / nv
+            ent_reg = 0.0 if self.no_entropy else temp
+            act_loss = -(ll + ent_reg * ent)
+            dmu = -(zz / std) * valid[..., None] / nv            # d(-ll)/dmu
+            dls = (-(zz * zz - 1.0) - ent_reg) * valid[..., None] / nv  # d(-ll - reg*ent)/dls
+            stats.update(nll=-ll, ent=ent, ent_reg=ent_reg)
+        else:
+            pred = res["act"]
+            act_loss = (((pred - actions) ** 2) * mask[..., None]).mean()
+            dact = 2 * (pred - actions) * mask[..., None] / pred.size
+        lp = res["cost_logp"]
+        onehot = np.eye(2, dtype=dt)[costs_i]
+        cost_loss = (-(lp * onehot).sum(-1) * mask).mean()  # mean over ALL B*T  cdt.py:378-380
+        dlogits = (np.exp(lp) - onehot) * mask[..., None] / (B * T) * self.cw
+        pred_c = lp.argmax(-1)
+        acc = ((pred_c == costs_i) * mask).sum() / mask.sum()
+        sp = res["state_pred"]
+        diff = sp[:, :-1] - states[:, 1:]
+        state_loss = ((diff ** 2) * mask[:, :-1, None]).mean()
+        dsp = np.zeros_like(sp)
+        dsp[:, :-1] = 2 * diff * mask[:, :-1, None] / diff.size * self.sw
+        loss = act_loss + self.cw * cost_loss + self.sw * state_loss
+
+        # ---- heads backward
+        sf, af = c["sf"], c["af"]
+        f2 = lambda a: a.reshape(-1, a.shape[-1])  # noqa: E731
+        dsf = np.zeros_like(sf)
+        if self.stochastic:
+            for nm, dd in (("mu", dmu), ("log_std", dls)):
+                g[f"action_head.{nm}.weight"] = f2(dd).T @ f2(sf)
+                g[f"action_head.{nm}.bias"] = f2(dd).sum(0)
+                dsf = dsf + dd @ p[f"action_head.{nm}.weight"]
+        else:
+            g["action_head.0.weight"] = f2(dact).T @ f2(sf)
+            g["action_head.0.bias"] = f2(dact).sum(0)
+            dsf = dact @ p["action_head.0.weight"]
+        g["cost_pred_head.weight"] = f2(dlogits).T @ f2(af)
+        g["cost_pred_head.bias"] = f2(dlogits).sum(0)
+        g["state_pred_head.weight"] = f2(dsp).T @ f2(af)
+        g["state_pred_head.bias"] = f2(dsp).sum(0)
+        daf = dlogits @ p["cost_pred_head.weight"] + dsp @ p["state_pred_head.weight"]
+        dout = np.zeros((B, T, 4, E), dt)
+        dout[:, :, 2], dout[:, :, 3] = dsf, daf
+        dx, g["out_norm.weight"], g["out_norm.bias"] = layer_norm_bwd(dout.reshape(B, S, E), c["ln_out"],
+                                                                      p["out_norm.weight"])
+        # ---- blocks backward
+        for l in range(self.NL - 1, -1, -1):
+            pre, bc = f"blocks.{l}.", c["blocks"][l]
+            dm = dx  # x = x + mlp(n2)
+            g[pre + "mlp.2.weight"] = f2(dm).T @ f2(bc["h"])
+            g[pre + "mlp.2.bias"] = f2(dm).sum(0)
+            dh = dm @ p[pre + "mlp.2.weight"]
+            dhpre = dh * gelu_grad(bc["hpre"])
+            g[pre + "mlp.0.weight"] = f2(dhpre).T @ f2(bc["n2"])
+            g[pre + "mlp.0.bias"] = f2(dhpre).sum(0)
+            dn2 = dhpre @ p[pre + "mlp.0.weight"]
+            d2, g[pre + "norm2.weight"], g[pre + "norm2.bias"] = layer_norm_bwd(dn2, bc["ln2"], p[pre + "norm2.weight"])
+            dx = dx + d2
+            datt = dx  # x = x + att
+            g[pre + "attention.out_proj.weight"] = f2(datt).T @ f2(bc["o"])
+            g[pre + "attention.out_proj.bias"] = f2(datt).sum(0)
+            do = (datt @ p[pre + "attention.out_proj.weight"]).reshape(B, S, H, d).transpose(0, 2, 1, 3)
+            P, q, k, v = bc["P"], bc["q"], bc["k"], bc["v"]
+            dP = do @ v.transpose(0, 1, 3, 2)
+            dv = P.transpose(0, 1, 3, 2) @ do
+            dS = P * (dP - (dP * P).sum(-1, keepdims=True))
+            dq = dS @ k / math.sqrt(d)
+            dk = dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
+            dqkv = np.concatenate([t.transpose(0, 2, 1, 3).reshape(B, S, E) for t in (dq, dk, dv)], -1)
+            g[pre + "attention.in_proj_weight"] = f2(dqkv).T @ f2(bc["n1"])
+            g[pre + "attention.in_proj_bias"] = f2(dqkv).sum(0)
+            dn1 = dqkv @ p[pre + "attention.in_proj_weight"]
+            d1, g[pre + "norm1.weight"], g[pre + "norm1.bias"] = layer_norm_bwd(dn1, bc["ln1"], p[pre + "norm1.weight"])
+            dx = dx + d1
+        # ---- embeddings backward
+        dseq, g["emb_norm.weight"], g["emb_norm.bias"] = layer_norm_bwd(dx, c["ln_emb"], p["emb_norm.weight"])
+        d4 = dseq.reshape(B, T, 4, E)
+        dr, dc, ds, da = d4[:, :, 0], d4[:, :, 1], d4[:, :, 2], d4[:, :, 3]
+        g["return_emb.weight"] = (f2(dr) * returns.reshape(-1, 1)).sum(0)[:, None]
+        g["return_emb.bias"] = f2(dr).sum(0)
+        g["cost_emb.weight"] = (f2(dc) * c["ctg"].reshape(-1, 1)).sum(0)[:, None]
+        g["cost_emb.bias"] = f2(dc).sum(0)
+        g["state_emb.weight"] = f2(ds).T @ f2(states)
+        g["state_emb.bias"] = f2(ds).sum(0)
+        g["action_emb.weight"] = f2(da).T @ f2(actions)
+        g["action_emb.bias"] = f2(da).sum(0)
+        dte = np.zeros_like(p["timestep_emb.weight"])
+        np.add.at(dte, time_steps.reshape(-1), f2(dr + dc + ds + da))
+        g["timestep_emb.weight"] = dte
+
+        # ---- clip_grad_norm_ (cdt.py:398-399), AdamW with warm-up LR (cdt.py:321-330)
+        if self.clip is not None:
+            tot = math.sqrt(sum(float((np.asarray(v, np.float64) ** 2).sum()) for v in g.values()))
+            coef = min(1.0, self.clip / (tot + 1e-6))
+            if coef < 1.0:
+                g = {k: v * dt(coef) for k, v in g.items()}
+        lr_now = self.lr * min((self.steps + 1) / self.warmup, 1.0)
+        self.opt.step(p, g, lr=lr_now)
+        if self.stochastic:  # cdt.py:402-407
+            gT = {"log_temperature": np.array(math.exp(self.log_temperature) * (ent - self.target_entropy))}
+            pt = {"log_temperature": np.array(self.log_temperature, dtype=np.float64)}
+            self.opt_T.step(pt, gT)
+            self.log_temperature = float(pt["log_temperature"])
+        self.steps += 1
+        stats.update(all_loss=loss, act_loss=act_loss, cost_loss=cost_loss, cost_acc=acc, state_loss=state_loss,
+                     train_lr=self.lr * min((self.steps + 1) / self.warmup, 1.0))
+        return {k: float(v) for k, v in stats.items()}

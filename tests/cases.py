@@ -156,3 +156,108 @@ def hyper(c: Case) -> Dict[str, float]:
                     beta=0.5, qc_scalar=1.5)
     return dict(actor_lr=1e-3, critic_lr=1e-3, vae_lr=1e-3, gamma=0.99, tau=0.005, beta=0.5,
                 phi=0.05, lmbda=0.75, PID=(0.1, 0.003, 0.001))
+
+
+# --------------------------------------------------------------------------- #
+# CDT (osrl/algorithms/cdt.py) cases
+# --------------------------------------------------------------------------- #
+@dataclass
+class CDTCase:
+    name: str
+    od: int
+    ad: int
+    B: int
+    T: int
+    E: int
+    heads: int
+    layers: int
+    episode_len: int = 50
+    steps: int = 5
+    stochastic: bool = True
+    cost_transform: bool = True
+    warmup: int = 3
+    clip: float = 0.25
+    lr: float = 1e-4
+    wd: float = 1e-4
+    cost_w: float = 0.02
+    state_w: float = 0.0
+    seed: int = 0
+    algo: str = "cdt"
+
+
+CDT_CASES: Dict[str, CDTCase] = {c.name: c for c in [
+    CDTCase("cdt_small", od=5, ad=3, B=6, T=4, E=16, heads=2, layers=2, episode_len=20, steps=5, state_w=0.1),
+    CDTCase("cdt_det", od=4, ad=2, B=5, T=3, E=16, heads=4, layers=1, episode_len=12, steps=3, stochastic=False,
+            cost_transform=False, clip=1e9, warmup=1),
+    CDTCase("cdt_mid", od=11, ad=3, B=16, T=10, E=128, heads=8, layers=3, episode_len=1000, steps=1, warmup=500),
+]}
+
+
+def make_cdt_params(c: CDTCase) -> "OrderedDict[str, np.ndarray]":
+    """state_dict of the reference CDT (keys: SURVEY.md 8b).  Linear/Embedding ~ N(0,.02) as cdt.py:156-164;
+    biases and LayerNorm affine get small random values so their gradient paths are exercised."""
+    rs = np.random.RandomState(5000 + c.seed)
+    f = np.float32
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    E = c.E
+
+    def lin(name, out_f, in_f):
+        sd[name + ".weight"] = (rs.randn(out_f, in_f) * 0.02).astype(f)
+        sd[name + ".bias"] = (rs.randn(out_f) * 0.02).astype(f)
+
+    def ln(name):
+        sd[name + ".weight"] = (1 + rs.randn(E) * 0.05).astype(f)
+        sd[name + ".bias"] = (rs.randn(E) * 0.05).astype(f)
+
+    ln("emb_norm")
+    ln("out_norm")
+    sd["timestep_emb.weight"] = (rs.randn(c.episode_len + c.T, E) * 0.02).astype(f)
+    lin("state_emb", E, c.od)
+    lin("action_emb", E, c.ad)
+    lin("cost_emb", E, 1)
+    lin("return_emb", E, 1)
+    S = 4 * c.T
+    for l in range(c.layers):
+        pre = f"blocks.{l}"
+        sd[pre + ".causal_mask"] = ~np.tril(np.ones((S, S))).astype(bool)
+        ln(pre + ".norm1")
+        ln(pre + ".norm2")
+        sd[pre + ".attention.in_proj_weight"] = (rs.randn(3 * E, E) * 0.05).astype(f)
+        sd[pre + ".attention.in_proj_bias"] = (rs.randn(3 * E) * 0.02).astype(f)
+        lin(pre + ".attention.out_proj", E, E)
+        lin(pre + ".mlp.0", 4 * E, E)
+        lin(pre + ".mlp.2", E, 4 * E)
+    if c.stochastic:
+        lin("action_head.mu", c.ad, E)
+        lin("action_head.log_std", c.ad, E)
+    else:
+        lin("action_head.0", c.ad, E)
+    lin("state_pred_head", c.od, E)
+    lin("cost_pred_head", 2, E)
+    return sd
+
+
+def make_cdt_batch(c: CDTCase) -> Dict[str, np.ndarray]:
+    """states~N(0,1), actions~U(-1,1), returns~U(0,100)*0.1, costs_return~U(0,20),
+    time_steps=start+arange(T), mask ones with some rows tail-padded (zero-filled), costs~Bern(.1)."""
+    rs = np.random.RandomState(6000 + c.seed)
+    f = np.float32
+    B, T = c.B, c.T
+    start = rs.randint(0, c.episode_len, size=B)
+    mask = np.ones((B, T), f)
+    states = rs.randn(B, T, c.od).astype(f)
+    actions = rs.uniform(-1, 1, (B, T, c.ad)).astype(f)
+    returns = (rs.uniform(0, 100, (B, T)) * 0.1).astype(f)
+    ctg = rs.uniform(0, 20, (B, T)).astype(f)
+    costs = (rs.uniform(size=(B, T)) < 0.3).astype(f)
+    for b in range(0, B, 3):  # tail padding like SequenceDataset.__prepare_sample (dataset.py:764-773)
+        n = 1 + (b % (T - 1))
+        mask[b, T - n:] = 0
+        states[b, T - n:] = 0
+        actions[b, T - n:] = 0
+        returns[b, T - n:] = 0
+        ctg[b, T - n:] = 0
+        costs[b, T - n:] = 0
+    return dict(states=states, actions=actions, returns=returns, costs_return=ctg,
+                time_steps=(start[:, None] + np.arange(T)[None]).astype(np.int64), mask=mask,
+                episode_cost=rs.uniform(0, 20, B).astype(f), costs=costs)

@@ -25,7 +25,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from cases import CASES, hyper, make_batch, make_noise, make_params, noise_shapes  # noqa: E402
+from cases import (CASES, CDT_CASES, hyper, make_batch, make_cdt_batch, make_cdt_params, make_noise,  # noqa: E402
+                   make_params, noise_shapes)
 
 REF = os.environ.get("OSRL_REFERENCE", "/root/reference")
 
@@ -183,5 +184,60 @@ def main():
         print(f"{case.name}: {os.path.getsize(path) / 1024:.1f} KB  stats[0]={dict(zip(keys, out['stats'][0]))}")
 
 
+def main_cdt():
+    """CDT goldens: dropout 0 (the CDT class default, cdt.py:55-57), fp32 mask."""
+    Logger = _install_stubs()
+    sys.path.insert(0, REF)
+    import torch
+    import osrl.algorithms as algos
+
+    torch.set_num_threads(4)
+    for c in CDT_CASES.values():
+        m = algos.CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=c.episode_len, embedding_dim=c.E,
+                      num_layers=c.layers, num_heads=c.heads, attention_dropout=0.0, residual_dropout=0.0,
+                      embedding_dropout=0.0, time_emb=True, use_rew=True, use_cost=True,
+                      cost_transform=c.cost_transform, action_head_layers=1, cost_prefix=False,
+                      stochastic=c.stochastic, init_temperature=0.1, target_entropy=-c.ad)
+        lg = Logger()
+        tr = algos.CDTTrainer(m, None, lg, learning_rate=c.lr, weight_decay=c.wd, betas=(0.9, 0.999),
+                              clip_grad=c.clip, lr_warmup_steps=c.warmup, reward_scale=0.1, cost_scale=1.0,
+                              loss_cost_weight=c.cost_w, loss_state_weight=c.state_w)
+        sd = {k: torch.from_numpy(v.copy()) for k, v in make_cdt_params(c).items()}
+        res = m.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys, res
+        b = {k: torch.from_numpy(v) for k, v in make_cdt_batch(c).items()}
+        out = {}
+        for s in range(c.steps):
+            tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
+                              b["mask"], b["episode_cost"], b["costs"])
+            lg.flush()
+            if s + 1 in (1, c.steps):
+                for k, v in m.state_dict().items():
+                    if "causal_mask" in k:
+                        continue
+                    a = v.detach().numpy()
+                    if c.name == "cdt_mid":
+                        out[f"p{s + 1}/sum/{k}"] = np.float64(a.astype(np.float64).sum())
+                        out[f"p{s + 1}/smp/{k}"] = a.reshape(-1)[::97].copy()
+                    else:
+                        out[f"p{s + 1}/{k}"] = a.copy()
+                if c.stochastic:
+                    out[f"s{s + 1}/log_temperature"] = np.float64(m.log_temperature.item())
+        keys = sorted(lg.rows[0].keys())
+        out["stat_keys"] = np.array(keys)
+        out["stats"] = np.array([[r[k] for k in keys] for r in lg.rows], dtype=np.float64)
+        with torch.no_grad():
+            m.eval()
+            ap, _, _ = m(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
+                         ~b["mask"].to(torch.bool), b["episode_cost"])
+            out["act"] = (ap.mean if c.stochastic else ap).numpy()
+        out["meta"] = np.array([f"torch={torch.__version__}", f"numpy={np.__version__}", f"case={c}"])
+        path = os.path.join(HERE, c.name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{c.name}: {os.path.getsize(path) / 1024:.1f} KB stats[0]={dict(zip(keys, out['stats'][0]))}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--cdt-only" not in sys.argv:
+        main()
+    main_cdt()
