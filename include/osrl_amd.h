@@ -87,6 +87,7 @@ typedef struct {
   const float* a;  /* [rows, in]  */
   int64_t w_off, b_off; /* float offsets of dW / db inside one gradient slab */
   int32_t out, in;
+  int32_t ldz, lda;     /* row strides of dz / a in floats (0 = dense: out / in) */
 } osrl_dw_entry_t;
 
 /* Device-resident per-step scalars, advanced once per train step by osrl_step_tick(). */
@@ -103,6 +104,13 @@ typedef struct {
 int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, void* stream);
 int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                          const osrl_mlp_grads_t* g, void* stream);
+/* General linear layer on packed weights: Y[M,N] = A[M,K] * P (+ bias[N]) (+ resid[M,N]).  P is the forward
+ * pack of W[N,K] (y = x W^T; Np = round16(N), col0 = 0) or the backward pack of W[N',K'] for dx = dy W
+ * (then K = N', N = K' or a column slice starting at col0, Np = round16(K')+16).  K <= 1024; N is
+ * unbounded (column groups).  Replaces nn.Linear / addmm + residual adds of the CDT block
+ * (osrl/common/net.py:406-415,439-440, osrl/algorithms/cdt.py:96-141) and their input gradients. */
+int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, const float* P, int32_t Np, int32_t col0,
+                int32_t N, const float* bias, const float* resid, int64_t ldr, float* Y, int64_t ldy, void* stream);
 /* Refresh the packed copies of `n_entries` weights (entries in DEVICE memory).  Sizes in floats:
  * forward round16(in)*round16(out), backward round16(out)*(round16(in)+16).  max_elems = the largest
  * packed size among the entries (grid sizing).  Must run after every change of the canonical weights. */
@@ -211,6 +219,50 @@ int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_sam
 int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
                         int32_t rows, float qc_thres, float KP, float KI, float KD, int32_t rows_global,
                         float* pid, float* dq, float* dqc, float* stat, void* stream);
+
+/* ---- CDT (cdt.hip): the non-GEMM pieces of the Constrained Decision Transformer step ---- */
+/* Token embeddings + timestep embedding, (return, cost, state, action) interleave and emb LayerNorm
+ * (cdt.py:178-222).  BT = batch*seq_len; outputs: seq[4BT,E] (pre-LN), x0[4BT,E], stats[4BT,2] = (mean, rstd),
+ * ctg_t[BT] = the (optionally 50 - x transformed, cdt.py:78-81) cost-to-go fed to cost_emb. */
+int osrl_cdt_embed_ln(const float* states, const float* actions, const float* returns, const float* costs_to_go,
+                      const int64_t* time_steps, const float* Ws, const float* bs, const float* Wa, const float* ba,
+                      const float* Wc, const float* bc, const float* Wr, const float* br, const float* timestep_emb,
+                      const float* ln_g, const float* ln_b, int32_t BT, int32_t od, int32_t ad, int32_t E,
+                      int32_t cost_transform, float* seq, float* x0, float* stats, float* ctg_t, void* stream);
+/* nn.LayerNorm (eps 1e-5) of x (+ delta): y = LN(x + delta); xout = x + delta if non-NULL; stats = (mean, rstd). */
+int osrl_layernorm_fwd(const float* x, const float* delta, const float* gamma, const float* beta, float* xout,
+                       float* y, float* stats, int32_t M, int32_t E, void* stream);
+/* LayerNorm backward: dx = LN'(dy) (+ dres); dgamma/dbeta summed (fixed order, via partial_ws [n_parts, 2E]) into
+ * slab[g_off..], slab[b_off..]. */
+int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
+                       float* dx, float* partial_ws, int32_t n_parts, int32_t M, int32_t E, float* slab,
+                       int64_t g_off, int64_t b_off, void* stream);
+/* nn.MultiheadAttention core with the block's causal mask and key padding (net.py:417-435): qkv [B,S,3E] (q|k|v,
+ * heads split the E axis contiguously), mask [B, S/rep] (1 = valid timestep, each repeated rep times along S). */
+int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S, int32_t E, int32_t H, int32_t rep,
+                       float* o, void* stream);
+int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S, int32_t E,
+                       int32_t H, int32_t rep, float* dqkv, void* stream);
+/* nn.GELU() (exact erf) and its derivative; n a multiple of 4 */
+int osrl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int osrl_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+/* CDTTrainer losses (cdt.py:357-394): head = (mu|log_std)[BT,2ad] (stochastic) or action prediction [BT,ad];
+ * writes d head / d logits / d state_pred and stat[0..8] = nll, ent, ent_reg, all_loss, act_loss, cost_loss,
+ * cost_acc, state_loss, train_lr; ent_out[0] = entropy (input of the temperature step). */
+int osrl_cdt_loss(const float* head, const float* logits, const float* state_pred, const float* actions,
+                  const float* states, const float* mask, const float* costs, int32_t B, int32_t T, int32_t od,
+                  int32_t ad, int32_t stochastic, int32_t no_entropy, const float* log_temperature, float cost_w,
+                  float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, float* dhead, float* dlogits,
+                  float* dsp, float* stat, float* ent_out, void* stream);
+/* d timestep_emb[time_steps[bt]] += sum of the 4 token rows of dseq (atomic scatter) */
+int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t BT, int32_t E, float* dte,
+                              void* stream);
+/* torch.nn.utils.clip_grad_norm_ (cdt.py:398-399): out[0] = min(1, clip/(||grad||+1e-6)), out[1] = ||grad|| */
+int osrl_clip_grad_scale(const float* grad, int64_t n, float clip, float* partial_ws, int32_t n_parts, float* out,
+                         void* stream);
+/* Adam step on log_temperature with loss exp(logT)*(entropy - target) (cdt.py:402-407); moments = {m, v} */
+int osrl_cdt_temperature_step(float* log_temperature, float* moments, const float* entropy, float target_entropy,
+                              float lr, float beta1, float beta2, float eps, const osrl_step_state_t* st, void* stream);
 
 /* library identity */
 const char* osrl_version(void);

@@ -50,7 +50,7 @@ class GradsT(C.Structure):
 
 class DwEntryT(C.Structure):
     _fields_ = [("dz", _fp), ("a", _fp), ("w_off", C.c_int64), ("b_off", C.c_int64),
-                ("out", C.c_int32), ("in_", C.c_int32)]
+                ("out", C.c_int32), ("in_", C.c_int32), ("ldz", C.c_int32), ("lda", C.c_int32)]
 
 
 class PackEntryT(C.Structure):
@@ -70,6 +70,7 @@ _P = C.POINTER
 PROTOTYPES = {
     "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
+    "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
     "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
@@ -97,6 +98,17 @@ PROTOTYPES = {
     "osrl_bcq_critic_loss": [_fp, _i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
     "osrl_bcq_actor_loss": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _fp, _fp, _fp,
                             _fp, _vp],
+    "osrl_cdt_embed_ln": [_fp, _fp, _fp, _fp, _vp] + [_fp] * 11 + [_i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _vp],
+    "osrl_layernorm_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _vp],
+    "osrl_layernorm_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],
+    "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp, _vp],
+    "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp, _vp],
+    "osrl_gelu_fwd": [_fp, _fp, _i64, _vp],
+    "osrl_gelu_bwd": [_fp, _fp, _fp, _i64, _vp],
+    "osrl_cdt_loss": [_fp] * 7 + [_i32] * 6 + [_fp, _f32, _f32, _f32, _i32, _vp, _fp, _fp, _fp, _fp, _fp, _vp],
+    "osrl_cdt_timestep_scatter": [_fp, _vp, _i32, _i32, _fp, _vp],
+    "osrl_clip_grad_scale": [_fp, _i64, _f32, _fp, _i32, _fp, _vp],
+    "osrl_cdt_temperature_step": [_fp, _fp, _fp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
 }
 
 _LIB: Optional[C.CDLL] = None

@@ -1,0 +1,180 @@
+"""Constrained Decision Transformer on MI355X behind the reference's API (osrl/algorithms/cdt.py).
+
+``CDT`` keeps the constructor and ``state_dict`` layout of cdt.py:45-164 (the same torch container modules
+are created in the same order, so a seeded construction reproduces the reference's initial weights);
+``CDTTrainer.train_one_step`` keeps the signature of cdt.py:343.  Supported configuration = the reference's
+training defaults (time/return/cost embeddings, optional cost transform, 1-layer stochastic or
+deterministic head); the deprecated cost-feature / cost-prefix variants and dropout > 0 raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..common.logger import DummyLogger, store_stats
+from ..common.net import DiagGaussianActor, TransformerBlock, bind_group, mlp, plan_group
+from ..engine.core import FlatGroup, require_cuda
+
+
+class _Params(nn.Module):
+    """Holds the reference-named submodules so that plan_group/bind_group see keys without a prefix."""
+
+
+class CDT(nn.Module):
+    def __init__(self, state_dim: int, action_dim: int, max_action: float, seq_len: int = 10,
+                 episode_len: int = 1000, embedding_dim: int = 128, num_layers: int = 4, num_heads: int = 8,
+                 attention_dropout: float = 0.0, residual_dropout: float = 0.0, embedding_dropout: float = 0.0,
+                 time_emb: bool = True, use_rew: bool = False, use_cost: bool = False, cost_transform: bool = False,
+                 add_cost_feat: bool = False, mul_cost_feat: bool = False, cat_cost_feat: bool = False,
+                 action_head_layers: int = 1, cost_prefix: bool = False, stochastic: bool = False,
+                 init_temperature=0.1, target_entropy=None, device: str = "cuda"):
+        super().__init__()
+        unsupported = []
+        if max(attention_dropout, residual_dropout, embedding_dropout) > 0:
+            unsupported.append("dropout > 0")
+        if not (time_emb and use_rew and use_cost):
+            unsupported.append("time_emb/use_rew/use_cost = False")
+        if add_cost_feat or mul_cost_feat or cat_cost_feat or cost_prefix:
+            unsupported.append("cost feature / cost prefix variants")
+        if action_head_layers != 1:
+            unsupported.append("action_head_layers != 1")
+        if embedding_dim % num_heads or embedding_dim > 512 or 4 * embedding_dim > 1024 or 4 * seq_len > 128:
+            unsupported.append("embedding_dim > 256 or 4*seq_len > 128")
+        if unsupported:
+            raise NotImplementedError("osrl_amd CDT does not support: " + "; ".join(unsupported))
+        self.seq_len, self.embedding_dim = seq_len, embedding_dim
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.episode_len, self.max_action = episode_len, max_action
+        self.num_layers, self.num_heads = num_layers, num_heads
+        self.cost_transform_on = bool(cost_transform)
+        self.cost_transform = (lambda x: 50 - x) if cost_transform else None
+        self.add_cost_feat = self.mul_cost_feat = self.cat_cost_feat = False
+        self.stochastic = stochastic
+        self.time_emb, self.use_rew, self.use_cost, self.cost_prefix = True, True, True, False
+        self.seq_repeat = 4
+        self.device = str(device)
+        dev = require_cuda(device)
+
+        # container modules, created in the reference's order (cdt.py:87-141)
+        self.emb_drop = nn.Dropout(embedding_dropout)
+        self.emb_norm = nn.LayerNorm(embedding_dim)
+        self.out_norm = nn.LayerNorm(embedding_dim)
+        self.timestep_emb = nn.Embedding(episode_len + seq_len, embedding_dim)
+        self.state_emb = nn.Linear(state_dim, embedding_dim)
+        self.action_emb = nn.Linear(action_dim, embedding_dim)
+        self.cost_emb = nn.Linear(1, embedding_dim)
+        self.return_emb = nn.Linear(1, embedding_dim)
+        self.blocks = nn.ModuleList([TransformerBlock(4 * seq_len, embedding_dim, num_heads, attention_dropout,
+                                                      residual_dropout) for _ in range(num_layers)])
+        if stochastic:
+            self.action_head = DiagGaussianActor(embedding_dim, action_dim)
+        else:
+            self.action_head = mlp([embedding_dim, action_dim], activation=nn.GELU, output_activation=nn.Identity)
+        self.state_pred_head = nn.Linear(embedding_dim, state_dim)
+        self.cost_pred_head = nn.Linear(embedding_dim, 2)
+        self.apply(self._init_weights)
+
+        g = FlatGroup("cdt", dev)
+        plan_group(g, "cdt", self)
+        g.finalize()
+        bind_group(g, "cdt", self)
+        self.groups: Dict[str, FlatGroup] = {"cdt": g}
+        if stochastic:  # cdt.py:143-146: a plain tensor outside the state_dict
+            self.log_temperature = torch.full((1,), float(np.log(init_temperature)), dtype=torch.float32, device=dev)
+            self.target_entropy = target_entropy
+        self._engine = None
+
+    @staticmethod
+    def _init_weights(module: nn.Module):
+        """cdt.py:156-164."""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)
+            if isinstance(module, nn.Linear) and module.bias is not None:
+                torch.nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.LayerNorm):
+            torch.nn.init.zeros_(module.bias)
+            torch.nn.init.ones_(module.weight)
+
+    def temperature(self):
+        return self.log_temperature.exp() if self.stochastic else None
+
+    def repack(self) -> None:
+        for g in self.groups.values():
+            if g.device.type == "cuda":
+                g.repack()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        if assign:
+            raise RuntimeError("assign=True would detach parameters from their flat HBM group")
+        res = super().load_state_dict(state_dict, strict=strict)
+        self.repack()
+        return res
+
+    def _apply(self, fn, *a, **k):
+        raise RuntimeError("osrl_amd models are bound to their HIP device at construction (pass device=)")
+
+    def engine(self, batch_size: int, cfg: Optional[dict] = None):
+        from ..engine.cdt import CDTEngine
+        if self._engine is None or self._engine.B != batch_size or (cfg is not None and cfg != self._engine.cfg):
+            if cfg is None:
+                raise RuntimeError("build a CDTTrainer before training")
+            self._engine = CDTEngine(self, batch_size, cfg)
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, states, actions, returns_to_go, costs_to_go, time_steps, padding_mask=None,
+                episode_cost=None):
+        """Inference forward (cdt.py:166-265): returns (action_preds, cost_preds, state_preds) where
+        action_preds is ``torch.distributions.Normal(mu, std)`` for a stochastic head."""
+        B = states.shape[0]
+        cfg = self._engine.cfg if self._engine is not None else dict(
+            learning_rate=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), clip_grad=0.25, lr_warmup_steps=1,
+            loss_cost_weight=0.0, loss_state_weight=0.0, no_entropy=False)
+        from ..engine.cdt import CDTEngine
+        if getattr(self, "_infer", None) is None or self._infer.B != B or self._infer.T != states.shape[1]:
+            if states.shape[1] != self.seq_len:
+                raise NotImplementedError("inference windows shorter than seq_len: pad to seq_len with a mask")
+            self._infer = CDTEngine(self, B, cfg)
+        e = self._infer
+        mask = torch.ones(B, states.shape[1], device=states.device) if padding_mask is None else \
+            (~padding_mask.to(torch.bool)).float()
+        e.load_batch(states, actions, returns_to_go, costs_to_go, time_steps, mask, torch.zeros_like(mask))
+        self.repack()
+        e.forward()
+        T, ad, od = states.shape[1], self.action_dim, self.state_dim
+        if self.stochastic:
+            mu, ls = e.head[:, :ad].reshape(B, T, ad).clone(), e.head[:, ad:].reshape(B, T, ad).clone()
+            ap = torch.distributions.Normal(mu, ls.exp())
+        else:
+            ap = e.head.reshape(B, T, ad).clone()
+        return ap, torch.log_softmax(e.logits.reshape(B, T, 2), -1), e.sp.reshape(B, T, od).clone()
+
+
+class CDTTrainer:
+    """cdt.py:268-418."""
+
+    def __init__(self, model: CDT, env=None, logger=DummyLogger(), learning_rate: float = 1e-4,
+                 weight_decay: float = 1e-4, betas: Tuple[float, ...] = (0.9, 0.999), clip_grad: float = 0.25,
+                 lr_warmup_steps: int = 10000, reward_scale: float = 1.0, cost_scale: float = 1.0,
+                 loss_cost_weight: float = 0.0, loss_state_weight: float = 0.0, cost_reverse: bool = False,
+                 no_entropy: bool = False, device="cuda", stats_mode: str = "lazy", use_graph: bool = True) -> None:
+        self.model, self.logger, self.env = model, logger, env
+        self.clip_grad, self.reward_scale, self.cost_scale, self.device = clip_grad, reward_scale, cost_scale, device
+        self.cost_weight, self.state_weight = loss_cost_weight, loss_state_weight
+        self.cost_reverse, self.no_entropy = cost_reverse, no_entropy
+        self.stochastic = model.stochastic
+        self.max_action = model.max_action
+        self.stats_mode, self.use_graph = stats_mode, use_graph
+        self.cfg = dict(learning_rate=learning_rate, weight_decay=weight_decay, betas=tuple(betas),
+                        clip_grad=clip_grad, lr_warmup_steps=lr_warmup_steps, loss_cost_weight=loss_cost_weight,
+                        loss_state_weight=loss_state_weight, no_entropy=no_entropy)
+
+    def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs):
+        """cdt.py:343-418 (episode_cost only feeds the unsupported cost-prefix variant)."""
+        eng = self.model.engine(states.shape[0], self.cfg)
+        eng.step(states, actions, returns, costs_return, time_steps, mask, costs, use_graph=self.use_graph)
+        keys = None if self.stochastic else ["all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
+        store_stats(self.logger, eng.st, self.stats_mode, tab="train", keys=keys)

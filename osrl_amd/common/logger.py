@@ -102,24 +102,27 @@ class DummyLogger:
         pass
 
 
-def store_stats(logger, st, mode: str) -> None:
+def store_stats(logger, st, mode: str, tab=None, keys=None) -> None:
     """Hand the statistics of the step just enqueued to ``logger.store``."""
     if logger is None:
         return
+    kw = {} if tab is None else {"tab": tab}
+    use = list(st.keys) if keys is None else list(keys)
     if mode == "sync":
-        logger.store(**st.read_stats())
+        vals = st.read_stats()
+        logger.store(**kw, **{k: vals[k] for k in use})
     elif mode == "lazy":
         step = st.host_step
         pend = getattr(st, "_pending", None)
         if pend is None:
             pend = st._pending = []
-        vals = {k: LazyStat(st, step, k) for k in st.keys}
+        vals = {k: LazyStat(st, step, k) for k in use}
         pend.extend(vals.values())
         # materialise before the device ring wraps (amortised: one sync per ring_len/2 steps)
         if len(pend) >= (st.ring_len // 2) * max(len(st.keys), 1):
             for v in pend:
                 v.materialize()
             pend.clear()
-        logger.store(**vals)
+        logger.store(**kw, **vals)
     elif mode != "none":
         raise ValueError(mode)

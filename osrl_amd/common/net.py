@@ -152,6 +152,36 @@ class VAE(nn.Module):
         return ops.mlp_apply(vae_dec_desc(self), obs, z)[0]
 
 
+class TransformerBlock(nn.Module):
+    """Parameter container of the pre-LN GPT block (net.py:391-441); the arithmetic lives in engine/cdt.py."""
+
+    def __init__(self, seq_len: int, embedding_dim: int, num_heads: int, attention_dropout: float,
+                 residual_dropout: float):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(embedding_dim)
+        self.norm2 = nn.LayerNorm(embedding_dim)
+        self.drop = nn.Dropout(residual_dropout)
+        self.attention = nn.MultiheadAttention(embedding_dim, num_heads, attention_dropout, batch_first=True)
+        self.mlp = nn.Sequential(nn.Linear(embedding_dim, 4 * embedding_dim), nn.GELU(),
+                                 nn.Linear(4 * embedding_dim, embedding_dim), nn.Dropout(residual_dropout))
+        # True = not allowed to attend (same buffer as the reference, net.py:417-418; part of the state_dict)
+        self.register_buffer("causal_mask", ~torch.tril(torch.ones(seq_len, seq_len)).to(bool))
+        self.seq_len = seq_len
+
+
+class DiagGaussianActor(nn.Module):
+    """Parameter container of the diagonal-Gaussian head (net.py:509-533)."""
+
+    def __init__(self, hidden_dim, act_dim, log_std_bounds=(-5.0, 2.0)):
+        super().__init__()
+        self.mu = nn.Linear(hidden_dim, act_dim)
+        self.log_std = nn.Linear(hidden_dim, act_dim)
+        self.log_std_bounds = list(log_std_bounds)
+        for m in (self.mu, self.log_std):  # same RNG consumption as the reference's orthogonal init
+            nn.init.orthogonal_(m.weight.data)
+            m.bias.data.fill_(0.0)
+
+
 # --------------------------------------------------------------------------- #
 # NetDesc builders (pointers into the modules' flat-group storage; set up by bind_group)
 # --------------------------------------------------------------------------- #
@@ -193,7 +223,7 @@ def vae_dec_desc(vae: VAE) -> NetDesc:
 # --------------------------------------------------------------------------- #
 # materialisation: move a module's parameters into a FlatGroup (views)
 # --------------------------------------------------------------------------- #
-PACKED_PAIRS = (("mu_layer", "log_std_layer"), ("mean", "log_std"))
+PACKED_PAIRS = (("mu_layer", "log_std_layer"), ("mean", "log_std"), ("mu", "log_std"))
 
 
 def plan_group(group: FlatGroup, prefix: str, module: nn.Module) -> None:
@@ -223,7 +253,7 @@ def plan_group(group: FlatGroup, prefix: str, module: nn.Module) -> None:
             done.update({first + ".weight", first + ".bias", second + ".weight", second + ".bias"})
         else:
             group.add(prefix + "." + name, p.shape)
-            if leaf == "weight" and p.dim() == 2:
+            if leaf in ("weight", "in_proj_weight") and p.dim() == 2 and "timestep_emb" not in name:
                 group.mark_weight(prefix + "." + name)
             done.add(name)
 

@@ -1,0 +1,611 @@
+// cdt.hip -- the non-GEMM kernels of the Constrained Decision Transformer train step on gfx950.
+//
+// The transformer's projections run on the packed-weight MFMA kernels of mlp.hip (osrl_linear,
+// osrl_mlp_backward_dw); this file holds everything around them:
+//   * token embedding + timestep embedding + (r,c,s,a) interleave + emb LayerNorm   cdt.py:178-222
+//   * LayerNorm forward / backward (+ fused residual add)                            net.py:402-403,427,440
+//   * causal + key-padding softmax attention, forward and backward (80x80 score tiles at the
+//     BASELINE config: 4*seq_len tokens, head_dim 32; scores never leave LDS)       net.py:406-409,428-435
+//   * exact-erf GELU forward / backward                                              net.py:412
+//   * heads' loss: Gaussian NLL + entropy over valid tokens, 2-class cost NLL, shifted state MSE,
+//     accuracy, and the gradients that seed the backward pass                        cdt.py:357-394
+//   * timestep-embedding gradient scatter, global grad-norm clip factor              cdt.py:398-399
+//   * temperature (log_temperature) Adam step                                        cdt.py:402-407
+// All fp32.  Row-wise kernels use one wave64 per token row (E <= 512) with shuffle reductions; these
+// are HBM-streaming kernels (LayerNorm: 2 reads + 1-2 writes of [tokens, E] per call).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/osrl_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kMaxEPL = 8;  // features per lane: E <= 512
+constexpr float kLnEps = 1e-5f;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float block_sum1024(float v, float* sm) {
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+    sm[16] = t;
+  }
+  __syncthreads();
+  return sm[16];
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_g(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+}
+
+// LayerNorm of one row held as v[j] (feature lane + 64 j); returns mean / rstd, writes y
+__device__ __forceinline__ void ln_row(const float (&v)[kMaxEPL], int E, int lane, const float* __restrict__ g,
+                                       const float* __restrict__ b, float* __restrict__ y, float* mean_o,
+                                       float* rstd_o) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j)
+    if (lane + 64 * j < E) s += v[j];
+  const float mean = wsum(s) / (float)E;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j)
+    if (lane + 64 * j < E) q += (v[j] - mean) * (v[j] - mean);
+  const float rstd = 1.0f / sqrtf(wsum(q) / (float)E + kLnEps);
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j) {
+    const int f = lane + 64 * j;
+    if (f < E) y[f] = (v[j] - mean) * rstd * g[f] + b[f];
+  }
+  *mean_o = mean;
+  *rstd_o = rstd;
+}
+
+struct EmbedArgs {
+  const float *states, *actions, *returns, *ctg;
+  const int64_t* time_steps;
+  const float *Ws, *bs, *Wa, *ba, *Wc, *bc, *Wr, *br, *te, *g, *b;
+  float *seq, *x0, *stats, *ctg_t;
+  int32_t BT, od, ad, E, cost_transform;
+};
+
+// one wave per token; token order per timestep (return, cost, state, action)  cdt.py:185-200
+__global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.BT * 4) return;
+  const int bt = row >> 2, which = row & 3;
+  const float* __restrict__ te = a.te + (size_t)a.time_steps[bt] * a.E;
+  float v[kMaxEPL];
+  const float ret = a.returns[bt];
+  const float ctg = a.cost_transform ? 50.0f - a.ctg[bt] : a.ctg[bt];  // cdt.py:78-81,187-188
+  if (which == 1 && lane == 0) a.ctg_t[bt] = ctg;
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j) {
+    const int f = lane + 64 * j;
+    float x = 0.f;
+    if (f < a.E) {
+      if (which == 0) {
+        x = ret * a.Wr[f] + a.br[f];
+      } else if (which == 1) {
+        x = ctg * a.Wc[f] + a.bc[f];
+      } else if (which == 2) {
+        x = a.bs[f];
+        for (int i = 0; i < a.od; ++i) x += a.states[(size_t)bt * a.od + i] * a.Ws[(size_t)f * a.od + i];
+      } else {
+        x = a.ba[f];
+        for (int i = 0; i < a.ad; ++i) x += a.actions[(size_t)bt * a.ad + i] * a.Wa[(size_t)f * a.ad + i];
+      }
+      x += te[f];
+      a.seq[(size_t)row * a.E + f] = x;
+    }
+    v[j] = x;
+  }
+  float mean, rstd;
+  ln_row(v, a.E, lane, a.g, a.b, a.x0 + (size_t)row * a.E, &mean, &rstd);
+  if (lane == 0) {
+    a.stats[2 * row] = mean;
+    a.stats[2 * row + 1] = rstd;
+  }
+}
+
+// y = LN(x + delta); xout = x + delta (optional)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ delta,
+                                                     const float* __restrict__ g, const float* __restrict__ b,
+                                                     float* __restrict__ xout, float* __restrict__ y,
+                                                     float* __restrict__ stats, int M, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[kMaxEPL];
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j) {
+    const int f = lane + 64 * j;
+    float t = 0.f;
+    if (f < E) {
+      t = x[(size_t)row * E + f];
+      if (delta) t += delta[(size_t)row * E + f];
+      if (xout) xout[(size_t)row * E + f] = t;
+    }
+    v[j] = t;
+  }
+  float mean, rstd;
+  ln_row(v, E, lane, g, b, y + (size_t)row * E, &mean, &rstd);
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+// dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)) (+ dres); per-workgroup partial dgamma/dbeta
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ g,
+                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     float* __restrict__ partial, int M, int E) {
+  __shared__ float sm[4][2 * 64 * kMaxEPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[kMaxEPL], db[kMaxEPL];
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j) dg[j] = db[j] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[kMaxEPL], dxh[kMaxEPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxEPL; ++j) {
+      const int f = lane + 64 * j;
+      xh[j] = dxh[j] = 0.f;
+      if (f < E) {
+        const float d = dy[(size_t)row * E + f];
+        xh[j] = (x[(size_t)row * E + f] - mean) * rstd;
+        dxh[j] = d * g[f];
+        dg[j] += d * xh[j];
+        db[j] += d;
+        s1 += dxh[j];
+        s2 += dxh[j] * xh[j];
+      }
+    }
+    s1 = wsum(s1) / (float)E;
+    s2 = wsum(s2) / (float)E;
+#pragma unroll
+    for (int j = 0; j < kMaxEPL; ++j) {
+      const int f = lane + 64 * j;
+      if (f < E) {
+        float v = rstd * (dxh[j] - s1 - xh[j] * s2);
+        if (dres) v += dres[(size_t)row * E + f];
+        dx[(size_t)row * E + f] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxEPL; ++j) {
+    sm[wave][lane + 64 * j] = dg[j];
+    sm[wave][64 * kMaxEPL + lane + 64 * j] = db[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * E; i += 256) {
+    const int f = i < E ? i : 64 * kMaxEPL + (i - E);
+    partial[(size_t)blockIdx.x * 2 * E + i] = (sm[0][f] + sm[1][f]) + (sm[2][f] + sm[3][f]);
+  }
+}
+
+// dgamma -> slab[g_off + f], dbeta -> slab[b_off + f]  (fixed-order sum of the per-workgroup partials)
+__global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, int E, float* __restrict__ slab,
+                                       int64_t g_off, int64_t b_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * E) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 2 * E + i];
+  slab[(i < E ? g_off + i : b_off + (i - E))] = s;
+}
+
+// ---------------- attention: one workgroup per (batch, head); S = tokens (<= 128), d = head dim (<= 64)
+struct AttnArgs {
+  const float* qkv;   // [B, S, 3E]
+  const float* mask;  // [B, T] (1 = valid); token j is a padded key iff mask[b, j/rep] <= 0
+  float* o;           // fwd out [B, S, E]
+  const float* dout;  // bwd in  [B, S, E]
+  float* dqkv;        // bwd out [B, S, 3E]
+  int32_t B, S, E, H, rep;
+};
+
+__device__ __forceinline__ void attn_load(const AttnArgs& a, int b, int h, int d, float* Q, float* K, float* V, int ld) {
+  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
+    const int i = idx / d, c = idx - i * d;
+    const float* __restrict__ p = a.qkv + ((size_t)b * a.S + i) * 3 * a.E + h * d + c;
+    Q[i * ld + c] = p[0];
+    K[i * ld + c] = p[a.E];
+    V[i * ld + c] = p[2 * a.E];
+  }
+}
+// P[i][j] = softmax_j(q_i.k_j / sqrt(d)) over allowed j (j <= i and key j not padded); row i by one thread
+__device__ __forceinline__ void attn_probs(const AttnArgs& a, int b, int d, const float* Q, const float* K, float* P,
+                                           int ld, int ldp) {
+  const float scale = 1.0f / sqrtf((float)d);
+  for (int idx = threadIdx.x; idx < a.S * a.S; idx += blockDim.x) {
+    const int i = idx / a.S, j = idx - i * a.S;
+    float s = -INFINITY;
+    if (j <= i && a.mask[(size_t)b * (a.S / a.rep) + j / a.rep] > 0.f) {
+      s = 0.f;
+      for (int c = 0; c < d; ++c) s += Q[i * ld + c] * K[j * ld + c];
+      s *= scale;
+    }
+    P[i * ldp + j] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.S; i += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j <= i; ++j) mx = fmaxf(mx, P[i * ldp + j]);
+    float sum = 0.f;
+    for (int j = 0; j < a.S; ++j) {
+      const float e = (j <= i && P[i * ldp + j] > -INFINITY) ? expf(P[i * ldp + j] - mx) : 0.f;
+      P[i * ldp + j] = e;
+      sum += e;
+    }
+    const float inv = 1.0f / sum;  // key 0 is never padded (tail padding only) => sum > 0
+    for (int j = 0; j < a.S; ++j) P[i * ldp + j] *= inv;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int d = a.E / a.H, ld = d + 1, ldp = a.S + 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  float *Q = sm, *K = Q + a.S * ld, *V = K + a.S * ld, *P = V + a.S * ld;
+  attn_load(a, b, h, d, Q, K, V, ld);
+  __syncthreads();
+  attn_probs(a, b, d, Q, K, P, ld, ldp);
+  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
+    const int i = idx / d, c = idx - i * d;
+    float s = 0.f;
+    for (int j = 0; j <= i; ++j) s += P[i * ldp + j] * V[j * ld + c];
+    a.o[((size_t)b * a.S + i) * a.E + h * d + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int d = a.E / a.H, ld = d + 1, ldp = a.S + 1;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  float *Q = sm, *K = Q + a.S * ld, *V = K + a.S * ld, *dO = V + a.S * ld, *P = dO + a.S * ld, *dS = P + a.S * ldp;
+  attn_load(a, b, h, d, Q, K, V, ld);
+  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
+    const int i = idx / d, c = idx - i * d;
+    dO[i * ld + c] = a.dout[((size_t)b * a.S + i) * a.E + h * d + c];
+  }
+  __syncthreads();
+  attn_probs(a, b, d, Q, K, P, ld, ldp);
+  // dP = dO V^T ;  dS = P * (dP - rowsum(dP*P))
+  for (int idx = threadIdx.x; idx < a.S * a.S; idx += blockDim.x) {
+    const int i = idx / a.S, j = idx - i * a.S;
+    float s = 0.f;
+    if (j <= i)
+      for (int c = 0; c < d; ++c) s += dO[i * ld + c] * V[j * ld + c];
+    dS[i * ldp + j] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.S; i += blockDim.x) {
+    float r = 0.f;
+    for (int j = 0; j <= i; ++j) r += dS[i * ldp + j] * P[i * ldp + j];
+    for (int j = 0; j < a.S; ++j) dS[i * ldp + j] = P[i * ldp + j] * (dS[i * ldp + j] - r);
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)d);
+  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
+    const int i = idx / d, c = idx - i * d;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j <= i; ++j) dq += dS[i * ldp + j] * K[j * ld + c];
+    for (int j = i; j < a.S; ++j) {  // column i of dS / P: rows j >= i
+      dk += dS[j * ldp + i] * Q[j * ld + c];
+      dv += P[j * ldp + i] * dO[j * ld + c];
+    }
+    float* __restrict__ p = a.dqkv + ((size_t)b * a.S + i) * 3 * a.E + h * d + c;
+    p[0] = dq * scale;
+    p[a.E] = dk * scale;
+    p[2 * a.E] = dv;
+  }
+}
+
+// ---------------- GELU
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    reinterpret_cast<f32x4*>(y)[i] = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+  }
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i], g = reinterpret_cast<const f32x4*>(dy)[i];
+    reinterpret_cast<f32x4*>(dx)[i] = f32x4{g[0] * gelu_g(v[0]), g[1] * gelu_g(v[1]), g[2] * gelu_g(v[2]),
+                                           g[3] * gelu_g(v[3])};
+  }
+}
+
+// ---------------- heads' loss (cdt.py:357-394) ----------------
+struct LossArgs {
+  const float *head, *logits, *sp, *actions, *states, *mask, *costs;  // head = (mu|log_std) or the action prediction
+  float *dhead, *dlogits, *dsp, *stat, *ent_out;
+  const float* log_temp;
+  const osrl_step_state_t* st;
+  int32_t B, T, od, ad, stochastic, no_entropy, warmup;
+  float cost_w, state_w, lr;
+};
+// stat layout: 0 nll, 1 ent, 2 ent_reg, 3 all_loss, 4 act_loss, 5 cost_loss, 6 cost_acc, 7 state_loss, 8 train_lr
+__global__ __launch_bounds__(1024) void cdt_loss_kernel(const LossArgs a) {
+  __shared__ float sm[20];
+  const int BT = a.B * a.T, ad = a.ad, od = a.od;
+  float nvalid = 0.f, msum = 0.f;
+  for (int i = threadIdx.x; i < BT; i += 1024) {
+    nvalid += a.mask[i] > 0.f ? 1.f : 0.f;
+    msum += a.mask[i];
+  }
+  nvalid = block_sum1024(nvalid, sm);
+  msum = block_sum1024(msum, sm);
+  const float inv_nv = 1.0f / (fmaxf(nvalid, 1.f) * (float)ad);
+  const float temp = expf(a.log_temp ? a.log_temp[0] : 0.f);
+  const float ent_reg = (a.stochastic && !a.no_entropy) ? temp : 0.f;
+  float ll = 0.f, ent = 0.f, act_mse = 0.f, closs = 0.f, correct = 0.f, sloss = 0.f;
+  const float inv_bt = 1.0f / (float)BT;
+  const float inv_s = (a.T > 1) ? 1.0f / ((float)a.B * (float)(a.T - 1) * (float)od) : 0.f;
+  for (int i = threadIdx.x; i < BT; i += 1024) {
+    const float m = a.mask[i];
+    const bool valid = m > 0.f;
+    if (a.stochastic) {  // Normal(mu, exp(ls)).log_prob / entropy, mean over valid tokens x action dims
+      for (int k = 0; k < ad; ++k) {
+        const float mu = a.head[(size_t)i * 2 * ad + k], ls = a.head[(size_t)i * 2 * ad + ad + k];
+        const float sd = expf(ls), z = (a.actions[(size_t)i * ad + k] - mu) / sd;
+        if (valid) {
+          ll += -0.5f * z * z - ls - 0.9189385332046727f;
+          ent += 1.4189385332046727f + ls;
+        }
+        a.dhead[(size_t)i * 2 * ad + k] = valid ? -(z / sd) * inv_nv : 0.f;
+        a.dhead[(size_t)i * 2 * ad + ad + k] = valid ? (-(z * z - 1.0f) - ent_reg) * inv_nv : 0.f;
+      }
+    } else {  // F.mse_loss(...,'none') * mask, mean over ALL B*T*ad
+      for (int k = 0; k < ad; ++k) {
+        const float dlt = a.head[(size_t)i * ad + k] - a.actions[(size_t)i * ad + k];
+        act_mse += dlt * dlt * m;
+        a.dhead[(size_t)i * ad + k] = 2.0f * dlt * m * inv_bt / (float)ad;
+      }
+    }
+    // cost head: log_softmax over 2 classes, nll * mask, mean over ALL B*T
+    const float l0 = a.logits[2 * i], l1 = a.logits[2 * i + 1];
+    const float mx = fmaxf(l0, l1), lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+    const int cls = a.costs[i] > 0.5f ? 1 : 0;
+    closs += -((cls ? l1 : l0) - lse) * m;
+    correct += (((l1 > l0) ? 1 : 0) == cls) ? m : 0.f;
+    const float p0 = expf(l0 - lse), p1 = expf(l1 - lse);
+    a.dlogits[2 * i] = (p0 - (cls == 0 ? 1.f : 0.f)) * m * inv_bt * a.cost_w;
+    a.dlogits[2 * i + 1] = (p1 - (cls == 1 ? 1.f : 0.f)) * m * inv_bt * a.cost_w;
+    // state head: predict next state, mask[:, :-1]
+    const int t = i % a.T;
+    for (int k = 0; k < od; ++k) {
+      float gsp = 0.f;
+      if (t < a.T - 1) {
+        const float dlt = a.sp[(size_t)i * od + k] - a.states[(size_t)(i + 1) * od + k];
+        sloss += dlt * dlt * m;
+        gsp = 2.0f * dlt * m * inv_s * a.state_w;
+      }
+      a.dsp[(size_t)i * od + k] = gsp;
+    }
+  }
+  ll = block_sum1024(ll, sm);
+  ent = block_sum1024(ent, sm);
+  act_mse = block_sum1024(act_mse, sm);
+  closs = block_sum1024(closs, sm);
+  correct = block_sum1024(correct, sm);
+  sloss = block_sum1024(sloss, sm);
+  if (threadIdx.x == 0) {
+    ll *= inv_nv;
+    ent *= inv_nv;
+    const float act_loss = a.stochastic ? -(ll + ent_reg * ent) : act_mse * inv_bt / (float)ad;
+    const float cost_loss = closs * inv_bt, state_loss = sloss * inv_s;
+    float* s = a.stat;
+    s[0] = -ll;
+    s[1] = ent;
+    s[2] = ent_reg;
+    s[3] = act_loss + a.cost_w * cost_loss + a.state_w * state_loss;
+    s[4] = act_loss;
+    s[5] = cost_loss;
+    s[6] = correct / msum;
+    s[7] = state_loss;
+    // scheduler.get_last_lr() AFTER scheduler.step(): the factor of the NEXT optimizer step  cdt.py:409,417
+    const double tn = (double)(a.st->step + 1);
+    s[8] = a.lr * (a.warmup > 0 ? (float)fmin(tn / (double)a.warmup, 1.0) : 1.0f);
+    if (a.ent_out) a.ent_out[0] = ent;
+  }
+}
+
+// d timestep_emb[time[b,t]] += sum of the 4 token gradients of (b,t)   (scatter, fp32 atomics)
+__global__ void te_scatter_kernel(const float* __restrict__ dseq, const int64_t* __restrict__ time_steps, int BT, int E,
+                                  float* __restrict__ dte) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)BT * E) return;
+  const int bt = (int)(i / E), f = (int)(i - (int64_t)bt * E);
+  const float* __restrict__ p = dseq + (size_t)bt * 4 * E + f;
+  atomicAdd(&dte[(size_t)time_steps[bt] * E + f], (p[0] + p[E]) + (p[2 * E] + p[3 * E]));
+}
+
+// clip_grad_norm_: scale = min(1, clip / (||g||_2 + 1e-6))   two-stage deterministic reduction
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n4,
+                                                            float* __restrict__ partial) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ void clip_scale_kernel(const float* __restrict__ partial, int n, float clip, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += (double)partial[i];
+    const float norm = (float)sqrt(t);
+    out[0] = clip > 0.f ? fminf(1.0f, clip / (norm + 1e-6f)) : 1.0f;
+    out[1] = norm;
+  }
+}
+
+// Adam(lr) on the scalar log_temperature with loss = exp(logT) * (entropy - target)   cdt.py:402-407
+__global__ void temperature_step_kernel(float* logT, float* mv, const float* ent, float target, float lr, float b1,
+                                        float b2, float eps, const osrl_step_state_t* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float g = expf(logT[0]) * (ent[0] - target);
+    mv[0] = b1 * mv[0] + (1.0f - b1) * g;
+    mv[1] = b2 * mv[1] + (1.0f - b2) * g * g;
+    logT[0] -= (lr / st->bc1) * (mv[0] / (sqrtf(mv[1]) / st->bc2_sqrt + eps));
+  }
+}
+
+#define S ((hipStream_t)stream)
+#define CLEAR() (void)hipGetLastError()
+#define DONE() return (int)hipGetLastError()
+
+}  // namespace
+
+extern "C" {
+
+int osrl_cdt_embed_ln(const float* states, const float* actions, const float* returns, const float* costs_to_go,
+                      const int64_t* time_steps, const float* Ws, const float* bs, const float* Wa, const float* ba,
+                      const float* Wc, const float* bc, const float* Wr, const float* br, const float* timestep_emb,
+                      const float* ln_g, const float* ln_b, int32_t BT, int32_t od, int32_t ad, int32_t E,
+                      int32_t cost_transform, float* seq, float* x0, float* stats, float* ctg_t, void* stream) {
+  if (!states || !actions || !returns || !costs_to_go || !time_steps || !seq || !x0 || !stats || !ctg_t || BT < 1 ||
+      E < 1 || E > 64 * kMaxEPL)
+    return -1;
+  EmbedArgs a{states, actions, returns, costs_to_go, time_steps, Ws, bs, Wa, ba, Wc, bc, Wr, br, timestep_emb,
+              ln_g, ln_b, seq, x0, stats, ctg_t, BT, od, ad, E, cost_transform};
+  CLEAR();
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(BT), dim3(256), 0, S, a);
+  DONE();
+}
+
+int osrl_layernorm_fwd(const float* x, const float* delta, const float* gamma, const float* beta, float* xout,
+                       float* y, float* stats, int32_t M, int32_t E, void* stream) {
+  if (!x || !gamma || !beta || !y || !stats || M < 1 || E < 1 || E > 64 * kMaxEPL) return -1;
+  CLEAR();
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M, E);
+  DONE();
+}
+
+int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
+                       float* dx, float* partial_ws, int32_t n_parts, int32_t M, int32_t E, float* slab,
+                       int64_t g_off, int64_t b_off, void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !partial_ws || !slab || n_parts < 1 || M < 1 || E > 64 * kMaxEPL)
+    return -1;
+  CLEAR();
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 255) / 256), dim3(256), 0, S, partial_ws, n_parts, E, slab,
+                     g_off, b_off);
+  DONE();
+}
+
+static size_t attn_lds(int S_, int d, bool bwd) {
+  return sizeof(float) * ((size_t)(bwd ? 4 : 3) * S_ * (d + 1) + (size_t)(bwd ? 2 : 1) * S_ * (S_ + 1));
+}
+
+int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S_, int32_t E, int32_t H, int32_t rep,
+                       float* o, void* stream) {
+  if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 160 || E % H || E / H > 64 || S_ % rep) return -1;
+  AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep};
+  const size_t lds = attn_lds(S_, E / H, false);
+  CLEAR();
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, S, a);
+  DONE();
+}
+
+int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S_, int32_t E,
+                       int32_t H, int32_t rep, float* dqkv, void* stream) {
+  if (!qkv || !mask || !dout || !dqkv || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || S_ % rep) return -1;
+  AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep};
+  const size_t lds = attn_lds(S_, E / H, true);
+  CLEAR();
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, S, a);
+  DONE();
+}
+
+int osrl_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n < 4 || (n & 3)) return -1;
+  int64_t blocks = (n / 4 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  CLEAR();
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((int)blocks), dim3(256), 0, S, x, y, n / 4);
+  DONE();
+}
+
+int osrl_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  if (!dy || !x || !dx || n < 4 || (n & 3)) return -1;
+  int64_t blocks = (n / 4 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  CLEAR();
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((int)blocks), dim3(256), 0, S, dy, x, dx, n / 4);
+  DONE();
+}
+
+int osrl_cdt_loss(const float* head, const float* logits, const float* state_pred, const float* actions,
+                  const float* states, const float* mask, const float* costs, int32_t B, int32_t T, int32_t od,
+                  int32_t ad, int32_t stochastic, int32_t no_entropy, const float* log_temperature, float cost_w,
+                  float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, float* dhead, float* dlogits,
+                  float* dsp, float* stat, float* ent_out, void* stream) {
+  if (!head || !logits || !state_pred || !actions || !states || !mask || !costs || !st || !dhead || !dlogits || !dsp ||
+      !stat || B < 1 || T < 1)
+    return -1;
+  LossArgs a{head, logits, state_pred, actions, states, mask, costs, dhead, dlogits, dsp, stat, ent_out,
+             log_temperature, st, B, T, od, ad, stochastic, no_entropy, warmup, cost_w, state_w, lr};
+  CLEAR();
+  hipLaunchKernelGGL(cdt_loss_kernel, dim3(1), dim3(1024), 0, S, a);
+  DONE();
+}
+
+int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t BT, int32_t E, float* dte,
+                              void* stream) {
+  if (!dseq || !time_steps || !dte || BT < 1 || E < 1) return -1;
+  const int64_t n = (int64_t)BT * E;
+  CLEAR();
+  hipLaunchKernelGGL(te_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S, dseq, time_steps, BT, E,
+                     dte);
+  DONE();
+}
+
+int osrl_clip_grad_scale(const float* grad, int64_t n, float clip, float* partial_ws, int32_t n_parts, float* out,
+                         void* stream) {
+  if (!grad || !partial_ws || !out || n < 4 || (n & 3) || n_parts < 1 || n_parts > 4096) return -1;
+  CLEAR();
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(n_parts), dim3(256), 0, S, grad, n / 4, partial_ws);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, S, partial_ws, n_parts, clip, out);
+  DONE();
+}
+
+int osrl_cdt_temperature_step(float* log_temperature, float* moments, const float* entropy, float target_entropy,
+                              float lr, float beta1, float beta2, float eps, const osrl_step_state_t* st, void* stream) {
+  if (!log_temperature || !moments || !entropy || !st) return -1;
+  CLEAR();
+  hipLaunchKernelGGL(temperature_step_kernel, dim3(1), dim3(64), 0, S, log_temperature, moments, entropy,
+                     target_entropy, lr, beta1, beta2, eps, st);
+  DONE();
+}
+
+}  // extern "C"

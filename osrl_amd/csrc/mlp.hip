@@ -500,6 +500,7 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
   const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
   const osrl_dw_entry_t E = entries[ei];
   const int out = E.out, in = E.in;
+  const size_t ldz = E.ldz > 0 ? (size_t)E.ldz : (size_t)out, lda_g = E.lda > 0 ? (size_t)E.lda : (size_t)in;
   const int o0 = ot * 64, i0 = it * 64;
   const int s = blockIdx.y;
   const int r_begin = s * rows_per_split;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int r = r0 + 4 * kq + t;
-          if (o < out && r < r_end) af[ob][t] = dz[(size_t)r * out + o];
+          if (o < out && r < r_end) af[ob][t] = dz[(size_t)r * ldz + o];
         }
       }
     }
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int r = r0 + 4 * kq + t;
-          if (i < in && r < r_end) bf[ib][t] = av[(size_t)r * in + i];
+          if (i < in && r < r_end) bf[ib][t] = av[(size_t)r * lda_g + i];
         }
       }
     }
@@ -588,6 +589,116 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
   }
 }
 
+
+
+// ---- general linear layer  Y[M, N] = A[M, K] * P (+ bias) (+ resid)  ------------------------------
+// The transformer-sized sibling of mlp_fwd_kernel (CDT: QKV / out-proj / MLP projections and their
+// dX GEMMs, osrl/common/net.py:406-415,422-441): one launch = one GEMM, K up to 1024, N unbounded via
+// column groups of 16*4*NCB columns on blockIdx.y.  A is staged through LDS once per workgroup, P is
+// a packed weight (forward pack for y = x W^T, backward pack for dx = dy W), same MFMA core.
+struct LinArgs {
+  const float* A;
+  const float* P;
+  const float* bias;
+  const float* resid;
+  float* Y;
+  int64_t lda_g, ldr, ldy;
+  int32_t M, K, N, Np, col0, lda;
+};
+
+template <int NRB, int NCB>
+__global__ __launch_bounds__(256) void linear_kernel(const LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 16 * NRB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * BM, M = a.M, K = a.K, N = a.N, lda = a.lda;
+  const int Kp = round16(K);
+  {  // stage A[row0 : row0+BM, 0:K] zero padded; 16 lanes per row, float4 when the rows are 16-B aligned
+    const int cl = tid & 15, rl = tid >> 4;
+    const bool vec = ((K & 3) == 0) && ((a.lda_g & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+#pragma unroll 1
+    for (int r = rl; r < BM; r += 16) {
+      const int gr = row0 + r;
+      const bool rok = gr < M;
+      const float* __restrict__ src = a.A + (size_t)(rok ? gr : M - 1) * a.lda_g;
+      if (vec) {
+        for (int cbase = 0; cbase < Kp; cbase += 64 * 4) {
+          f32x4 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = cbase + j * 64 + cl * 4;
+            const bool ok = rok && c < K;
+            v[j] = *reinterpret_cast<const f32x4*>(src + (ok ? c : 0));
+            if (!ok) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = cbase + j * 64 + cl * 4;
+            if (c < Kp) *reinterpret_cast<f32x4*>(lds + r * lda + c) = v[j];
+          }
+        }
+      } else {
+        for (int cbase = 0; cbase < Kp; cbase += 16 * 8) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = cbase + j * 16 + cl;
+            const bool ok = rok && c < K;
+            v[j] = src[ok ? c : 0];
+            v[j] = ok ? v[j] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = cbase + j * 16 + cl;
+            if (c < Kp) lds[r * lda + c] = v[j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int nk = Kp >> 4;
+  const int nblk_tot = (N + 15) >> 4;
+  constexpr int GB = 4 * NCB;  // column blocks per workgroup
+  const int gb0 = blockIdx.y * GB;
+  int nblk = nblk_tot - gb0;
+  nblk = nblk > GB ? GB : nblk;
+  if (nblk_tot <= 2 && nk >= 4 && lda >= 64) {
+    narrow_layer_splitk<NRB>(lds, lda, nk, a.P, a.Np, a.col0, nblk_tot, wave);
+  } else {
+    int cb0, cnt;
+    wave_blocks(nblk, wave, &cb0, &cnt);
+    f32x4 acc[NRB][NCB];
+    zero_acc<NRB, NCB>(acc);
+    if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, nk, a.P, a.Np, a.col0 + (gb0 + cb0) * 16, cnt, acc);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      if (c < cnt) {
+        const int col = (cb0 + c) * 16 + (lane & 15);  // column inside this group's LDS tile
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[(rb * 16 + (lane >> 4) * 4 + r) * lda + col] = acc[rb][c][r];
+      }
+    }
+    __syncthreads();
+  }
+  // copy out: + bias + residual, coalesced
+  const int ncols = (nblk * 16 < N - gb0 * 16) ? nblk * 16 : N - gb0 * 16;
+  const int gcol0 = gb0 * 16;
+  for (int idx = tid; idx < BM * ncols; idx += 256) {
+    const int r = idx / ncols, c = idx - r * ncols;
+    const int gr = row0 + r;
+    if (gr < M) {
+      float v = lds[r * lda + c];
+      if (a.bias) v += a.bias[gcol0 + c];
+      if (a.resid) v += a.resid[(size_t)gr * a.ldr + gcol0 + c];
+      a.Y[(size_t)gr * a.ldy + gcol0 + c] = v;
+    }
+  }
+}
 
 // ---- weight packing ------------------------------------------------------------------------------
 // forward pack  PF[q = k/4][n][k%4],  n < round16(N), q < round16(K)/4        (y = x W^T, W [N,K])
@@ -728,6 +839,42 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
   const TileChoice t = choose_tile(net, rows, g->dx_cols);
   a.lda = t.lda;
   OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream);
+}
+
+
+extern "C" int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, const float* P, int32_t Np, int32_t col0,
+                           int32_t N, const float* bias, const float* resid, int64_t ldr, float* Y, int64_t ldy,
+                           void* stream) {
+  if (!A || !P || !Y || M < 1 || K < 1 || K > 1024 || N < 1 || Np < 16) return -1;
+  LinArgs a;
+  a.A = A; a.P = P; a.bias = bias; a.resid = resid; a.Y = Y;
+  a.lda_g = lda; a.ldr = ldr; a.ldy = ldy;
+  a.M = M; a.K = K; a.N = N; a.Np = Np; a.col0 = col0;
+  const int nblk = (N + 15) / 16;
+  const int ncb = nblk >= 16 ? 4 : ((nblk + 3) / 4 <= 1 ? 1 : (nblk + 3) / 4 <= 2 ? 2 : (nblk + 3) / 4 <= 4 ? 4 : 7);
+  const int gcols = nblk >= 16 ? 256 : nblk * 16;
+  const int wmax = round16h(K) > gcols ? round16h(K) : gcols;
+  a.lda = (wmax < 64 ? 64 : wmax) + 8;
+  const int nrb = (K > 512 || ncb == 7) ? 1 : 2;
+  const int BM = 16 * nrb;
+  const size_t lds_bytes = (size_t)BM * a.lda * sizeof(float);
+  dim3 grid((M + BM - 1) / BM, (nblk + 4 * ncb - 1) / (4 * ncb), 1);
+  (void)hipGetLastError();
+#define OSRL_LIN_LAUNCH(R, C)                                                                                   \
+  do {                                                                                                          \
+    if (lds_bytes > 64 * 1024)                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<R, C>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
+    hipLaunchKernelGGL((linear_kernel<R, C>), grid, dim3(256), lds_bytes, (hipStream_t)stream, a);              \
+  } while (0)
+  if (nrb == 2) {
+    if (ncb == 1) OSRL_LIN_LAUNCH(2, 1); else if (ncb == 2) OSRL_LIN_LAUNCH(2, 2); else OSRL_LIN_LAUNCH(2, 4);
+  } else {
+    if (ncb == 1) OSRL_LIN_LAUNCH(1, 1); else if (ncb == 2) OSRL_LIN_LAUNCH(1, 2);
+    else if (ncb == 4) OSRL_LIN_LAUNCH(1, 4); else OSRL_LIN_LAUNCH(1, 7);
+  }
+#undef OSRL_LIN_LAUNCH
+  return (int)hipGetLastError();
 }
 
 extern "C" int osrl_pack_weights(const float* src_flat, float* pf, float* pb, const osrl_pack_entry_t* d_entries,

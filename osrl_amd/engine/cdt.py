@@ -1,0 +1,281 @@
+"""The Constrained Decision Transformer train step as a static launch plan on MI355X.
+
+Follows ``CDTTrainer.train_one_step`` (osrl/algorithms/cdt.py:343-418) around ``CDT.forward``
+(:166-265) and ``TransformerBlock.forward`` (osrl/common/net.py:422-441): embeddings -> emb LayerNorm ->
+num_layers x [LN, QKV, causal+padding attention, out-proj, residual, LN, Linear-GELU-Linear, residual]
+-> out LayerNorm -> heads -> losses -> backward of all of it -> clip_grad_norm_ -> AdamW (warm-up LR)
+-> temperature Adam.  Projections and their dX / dW GEMMs run on the packed-weight fp32-MFMA kernels
+(csrc/mlp.hip: osrl_linear, osrl_mlp_backward_dw); everything else is csrc/cdt.hip.
+Dropout must be 0 (the CDT class default, cdt.py:55-57); the train-config default 0.1 is not wired yet.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import _lib as L
+from .core import DwPlan, FlatGroup, StepState, cur_stream
+
+STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
+
+
+def _r16(x: int) -> int:
+    return (x + 15) // 16 * 16
+
+
+class CDTEngine:
+    def __init__(self, model, batch_size: int, trainer_cfg: dict):
+        m = self.model = model
+        self.cfg = trainer_cfg
+        B, T, E, H, NL = int(batch_size), m.seq_len, m.embedding_dim, m.num_heads, m.num_layers
+        self.B, self.T, self.E, self.H, self.NL = B, T, E, H, NL
+        od, ad = m.state_dim, m.action_dim
+        dev = torch.device(m.device)
+        self.dev = dev
+        self.S = 4 * T
+        self.M = B * self.S
+        self.BT = B * T
+        M, BT = self.M, self.BT
+        f = dict(dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
+        self.st = StepState(dev, STAT_KEYS, betas=tuple(trainer_cfg["betas"]), warmup=trainer_cfg["lr_warmup_steps"])
+        g: FlatGroup = m.groups["cdt"]
+        self.g = g
+        # static inputs
+        self.states, self.actions = z(B, T, od), z(B, T, ad)
+        self.returns, self.ctg, self.mask, self.costs = z(B, T), z(B, T), z(B, T), z(B, T)
+        self.time_steps = torch.zeros(B, T, dtype=torch.int64, device=dev)
+        # forward activations
+        self.seq, self.x0, self.st_emb, self.ctg_t = z(M, E), z(M, E), z(M, 2), z(BT)
+        self.xin: List[torch.Tensor] = [self.x0] + [z(M, E) for _ in range(NL)]  # input of block l / final x
+        self.n1 = [z(M, E) for _ in range(NL)]
+        self.st1 = [z(M, 2) for _ in range(NL)]
+        self.qkv = [z(M, 3 * E) for _ in range(NL)]
+        self.o = [z(M, E) for _ in range(NL)]
+        self.att = z(M, E)
+        self.xmid = [z(M, E) for _ in range(NL)]
+        self.n2 = [z(M, E) for _ in range(NL)]
+        self.st2 = [z(M, 2) for _ in range(NL)]
+        self.hpre = [z(M, 4 * E) for _ in range(NL)]
+        self.h = [z(M, 4 * E) for _ in range(NL)]
+        self.mo = z(M, E)
+        self.out, self.st_out = z(M, E), z(M, 2)
+        nh = 2 * ad if m.stochastic else ad
+        self.head, self.logits, self.sp = z(BT, nh), z(BT, 2), z(BT, od)
+        # backward buffers
+        self.dhead, self.dlogits, self.dsp, self.ent = z(BT, nh), z(BT, 2), z(BT, od), z(4)
+        self.dout = z(M, E)
+        self.dxo = [z(M, E) for _ in range(NL + 1)]   # grad wrt xin[l]
+        self.dxm = [z(M, E) for _ in range(NL)]       # grad wrt xmid[l]
+        self.dh = z(M, 4 * E)
+        self.dhpre = [z(M, 4 * E) for _ in range(NL)]
+        self.dn = z(M, E)
+        self.do = z(M, E)
+        self.dqkv = [z(M, 3 * E) for _ in range(NL)]
+        self.dseq = z(M, E)
+        self.n_parts = 256
+        self.ln_ws = z(self.n_parts, 2 * E)
+        self.clip_ws, self.clip_out = z(1024), z(4)
+        self.temp_mv = z(2)
+
+        # dW plans
+        tok, bt = [], []
+        for l in range(NL):
+            p = f"cdt.blocks.{l}."
+            tok += [(self.dqkv[l], self.n1[l], p + "attention.in_proj_weight", p + "attention.in_proj_bias"),
+                    (self.dxm[l], self.o[l], p + "attention.out_proj.weight", p + "attention.out_proj.bias"),
+                    (self.dhpre[l], self.n2[l], p + "mlp.0.weight", p + "mlp.0.bias"),
+                    (self.dxo[l + 1], self.h[l], p + "mlp.2.weight", p + "mlp.2.bias")]
+        sf_ptr, af_ptr = self.out.data_ptr() + 4 * 2 * E, self.out.data_ptr() + 4 * 3 * E
+        hk = "cdt.action_head.head" if m.stochastic else "cdt.action_head.0"
+        ds = self.dseq.data_ptr()
+        bt += [(self.dhead.data_ptr(), sf_ptr, hk + ".weight", hk + ".bias", 0, 4 * E),
+               (self.dlogits.data_ptr(), af_ptr, "cdt.cost_pred_head.weight", "cdt.cost_pred_head.bias", 0, 4 * E),
+               (self.dsp.data_ptr(), af_ptr, "cdt.state_pred_head.weight", "cdt.state_pred_head.bias", 0, 4 * E),
+               (ds + 4 * 0 * E, self.returns.data_ptr(), "cdt.return_emb.weight", "cdt.return_emb.bias", 4 * E, 0),
+               (ds + 4 * 1 * E, self.ctg_t.data_ptr(), "cdt.cost_emb.weight", "cdt.cost_emb.bias", 4 * E, 0),
+               (ds + 4 * 2 * E, self.states.data_ptr(), "cdt.state_emb.weight", "cdt.state_emb.bias", 4 * E, 0),
+               (ds + 4 * 3 * E, self.actions.data_ptr(), "cdt.action_emb.weight", "cdt.action_emb.bias", 4 * E, 0)]
+        self.p_tok = DwPlan(g, tok, M, dev)
+        self.p_bt = DwPlan(g, bt, BT, dev)
+        self.n_splits = max(self.p_tok.n_splits, self.p_bt.n_splits)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        m.repack()
+
+    # ---- thin launch helpers -------------------------------------------------------------------
+    def _P(self, key: str, bwd: bool) -> int:
+        g = self.g
+        return (g.pb if bwd else g.pf).data_ptr() + 4 * (g.b_off if bwd else g.f_off)[key]
+
+    def _v(self, key: str) -> int:
+        return self.g.view(key).data_ptr()
+
+    def _lin(self, A, lda, Mrows, key, Y, ldy, bias=True, resid=None, ldr=0):
+        """Y = A W^T (+ b) (+ resid) with W = parameter ``key`` [N,K]."""
+        N, K = self.g.layout[key][1]
+        a = A if isinstance(A, int) else A.data_ptr()
+        y = Y if isinstance(Y, int) else Y.data_ptr()
+        r = None if resid is None else (resid if isinstance(resid, int) else resid.data_ptr())
+        bkey = key[:-len("weight")] + "bias" if key.endswith("weight") else key.replace("in_proj_weight", "in_proj_bias")
+        L.check(L.load().osrl_linear(a, lda, Mrows, K, self._P(key, False), _r16(N), 0, N,
+                                     self._v(bkey) if bias else None, r, ldr, y, ldy, cur_stream()), "osrl_linear")
+
+    def _lin_dx(self, dY, ldd, Mrows, key, Y, ldy, resid=None, ldr=0):
+        """Y = dY W (+ resid): input gradient of the layer with parameter ``key`` [N,K]."""
+        N, K = self.g.layout[key][1]
+        a = dY if isinstance(dY, int) else dY.data_ptr()
+        y = Y if isinstance(Y, int) else Y.data_ptr()
+        r = None if resid is None else (resid if isinstance(resid, int) else resid.data_ptr())
+        L.check(L.load().osrl_linear(a, ldd, Mrows, N, self._P(key, True), _r16(K) + 16, 0, K, None, r, ldr, y, ldy,
+                                     cur_stream()), "osrl_linear(dx)")
+
+    def _ln_fwd(self, x, delta, key, xout, y, stats):
+        L.check(L.load().osrl_layernorm_fwd(x.data_ptr(), None if delta is None else delta.data_ptr(),
+                                            self._v(key + ".weight"), self._v(key + ".bias"),
+                                            None if xout is None else xout.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                            self.M, self.E, cur_stream()), "osrl_layernorm_fwd")
+
+    def _ln_bwd(self, dy, x, stats, key, dres, dx):
+        g = self.g
+        L.check(L.load().osrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), self._v(key + ".weight"),
+                                            None if dres is None else dres.data_ptr(), dx.data_ptr(),
+                                            self.ln_ws.data_ptr(), self.n_parts, self.M, self.E, g.slabs.data_ptr(),
+                                            g.offset(key + ".weight"), g.offset(key + ".bias"), cur_stream()),
+                "osrl_layernorm_bwd")
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self) -> None:
+        m, lib, E, M, BT = self.model, L.load(), self.E, self.M, self.BT
+        v = self._v
+        L.check(lib.osrl_cdt_embed_ln(self.states.data_ptr(), self.actions.data_ptr(), self.returns.data_ptr(),
+                                      self.ctg.data_ptr(), self.time_steps.data_ptr(), v("cdt.state_emb.weight"),
+                                      v("cdt.state_emb.bias"), v("cdt.action_emb.weight"), v("cdt.action_emb.bias"),
+                                      v("cdt.cost_emb.weight"), v("cdt.cost_emb.bias"), v("cdt.return_emb.weight"),
+                                      v("cdt.return_emb.bias"), v("cdt.timestep_emb.weight"), v("cdt.emb_norm.weight"),
+                                      v("cdt.emb_norm.bias"), BT, m.state_dim, m.action_dim, E,
+                                      1 if m.cost_transform_on else 0, self.seq.data_ptr(), self.x0.data_ptr(),
+                                      self.st_emb.data_ptr(), self.ctg_t.data_ptr(), cur_stream()), "osrl_cdt_embed_ln")
+        for l in range(self.NL):
+            p = f"cdt.blocks.{l}."
+            if l == 0:
+                self._ln_fwd(self.xin[0], None, p + "norm1", None, self.n1[0], self.st1[0])
+            self._lin(self.n1[l], E, M, p + "attention.in_proj_weight", self.qkv[l], 3 * E)
+            L.check(lib.osrl_attention_fwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.B, self.S, E, self.H, 4,
+                                           self.o[l].data_ptr(), cur_stream()), "osrl_attention_fwd")
+            self._lin(self.o[l], E, M, p + "attention.out_proj.weight", self.att, E)
+            self._ln_fwd(self.xin[l], self.att, p + "norm2", self.xmid[l], self.n2[l], self.st2[l])
+            self._lin(self.n2[l], E, M, p + "mlp.0.weight", self.hpre[l], 4 * E)
+            L.check(lib.osrl_gelu_fwd(self.hpre[l].data_ptr(), self.h[l].data_ptr(), M * 4 * E, cur_stream()), "gelu")
+            self._lin(self.h[l], 4 * E, M, p + "mlp.2.weight", self.mo, E)
+            if l + 1 < self.NL:
+                self._ln_fwd(self.xmid[l], self.mo, f"cdt.blocks.{l + 1}.norm1", self.xin[l + 1], self.n1[l + 1],
+                             self.st1[l + 1])
+            else:
+                self._ln_fwd(self.xmid[l], self.mo, "cdt.out_norm", self.xin[l + 1], self.out, self.st_out)
+        sf, af = self.out.data_ptr() + 4 * 2 * E, self.out.data_ptr() + 4 * 3 * E
+        hk = "cdt.action_head.head.weight" if m.stochastic else "cdt.action_head.0.weight"
+        self._lin(sf, 4 * E, BT, hk, self.head, self.head.shape[1])
+        self._lin(af, 4 * E, BT, "cdt.cost_pred_head.weight", self.logits, 2)
+        self._lin(af, 4 * E, BT, "cdt.state_pred_head.weight", self.sp, m.state_dim)
+
+    # ---- one full train step -------------------------------------------------------------------
+    def body(self) -> None:
+        m, lib, cfg, g = self.model, L.load(), self.cfg, self.g
+        E, M, BT, NL = self.E, self.M, self.BT, self.NL
+        st = self.st
+        st.tick()
+        self.forward()
+        L.check(lib.osrl_cdt_loss(self.head.data_ptr(), self.logits.data_ptr(), self.sp.data_ptr(),
+                                  self.actions.data_ptr(), self.states.data_ptr(), self.mask.data_ptr(),
+                                  self.costs.data_ptr(), self.B, self.T, m.state_dim, m.action_dim,
+                                  1 if m.stochastic else 0, 1 if cfg["no_entropy"] else 0,
+                                  m.log_temperature.data_ptr() if m.stochastic else None, cfg["loss_cost_weight"],
+                                  cfg["loss_state_weight"], cfg["learning_rate"], cfg["lr_warmup_steps"], st.ptr,
+                                  self.dhead.data_ptr(), self.dlogits.data_ptr(), self.dsp.data_ptr(),
+                                  st.stats.data_ptr(), self.ent.data_ptr(), cur_stream()), "osrl_cdt_loss")
+        # ---- backward: heads -> dout (only the state / action token rows are non-zero)
+        self.dout.zero_()
+        hk = "cdt.action_head.head.weight" if m.stochastic else "cdt.action_head.0.weight"
+        d_sf, d_af = self.dout.data_ptr() + 4 * 2 * E, self.dout.data_ptr() + 4 * 3 * E
+        self._lin_dx(self.dhead, self.dhead.shape[1], BT, hk, d_sf, 4 * E)
+        self._lin_dx(self.dlogits, 2, BT, "cdt.cost_pred_head.weight", d_af, 4 * E)
+        self._lin_dx(self.dsp, m.state_dim, BT, "cdt.state_pred_head.weight", d_af, 4 * E, resid=d_af, ldr=4 * E)
+        self._ln_bwd(self.dout, self.xin[NL], self.st_out, "cdt.out_norm", None, self.dxo[NL])
+        for l in range(NL - 1, -1, -1):
+            p = f"cdt.blocks.{l}."
+            self._lin_dx(self.dxo[l + 1], E, M, p + "mlp.2.weight", self.dh, 4 * E)
+            L.check(lib.osrl_gelu_bwd(self.dh.data_ptr(), self.hpre[l].data_ptr(), self.dhpre[l].data_ptr(),
+                                      M * 4 * E, cur_stream()), "gelu_bwd")
+            self._lin_dx(self.dhpre[l], 4 * E, M, p + "mlp.0.weight", self.dn, E)
+            self._ln_bwd(self.dn, self.xmid[l], self.st2[l], p + "norm2", self.dxo[l + 1], self.dxm[l])
+            self._lin_dx(self.dxm[l], E, M, p + "attention.out_proj.weight", self.do, E)
+            L.check(lib.osrl_attention_bwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.do.data_ptr(), self.B,
+                                           self.S, E, self.H, 4, self.dqkv[l].data_ptr(), cur_stream()), "attn_bwd")
+            self._lin_dx(self.dqkv[l], 3 * E, M, p + "attention.in_proj_weight", self.dn, E)
+            self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l])
+        self._ln_bwd(self.dxo[0], self.seq, self.st_emb, "cdt.emb_norm", None, self.dseq)
+        # ---- parameter gradients
+        te_off, (te_rows, _) = g.layout["cdt.timestep_emb.weight"]
+        g.slabs[0, te_off:te_off + te_rows * E].zero_()
+        L.check(lib.osrl_cdt_timestep_scatter(self.dseq.data_ptr(), self.time_steps.data_ptr(), BT, E,
+                                              g.slabs.data_ptr() + 4 * te_off, cur_stream()), "te_scatter")
+        self.p_tok.launch()
+        self.p_bt.launch()
+        g.cur_splits = self.n_splits
+        # ---- clip_grad_norm_ + AdamW (cdt.py:396-400)
+        L.check(lib.osrl_reduce_slabs(g.slabs.data_ptr(), g.slabs.data_ptr(), g.cur_splits, g.n, g.n, cur_stream()),
+                "osrl_reduce_slabs")
+        g.cur_splits = 1
+        clip = cfg["clip_grad"]
+        gscale = None
+        if clip is not None:
+            L.check(lib.osrl_clip_grad_scale(g.slabs.data_ptr(), g.n, float(clip), self.clip_ws.data_ptr(), 512,
+                                             self.clip_out.data_ptr(), cur_stream()), "osrl_clip_grad_scale")
+            gscale = self.clip_out
+        g.adam_step(cfg["learning_rate"], st.ptr, betas=tuple(cfg["betas"]), weight_decay=cfg["weight_decay"],
+                    gscale=gscale, polyak=False)
+        if m.stochastic:  # cdt.py:402-407
+            L.check(lib.osrl_cdt_temperature_step(m.log_temperature.data_ptr(), self.temp_mv.data_ptr(),
+                                                  self.ent.data_ptr(), float(m.target_entropy), 1e-4, 0.9, 0.999, 1e-8,
+                                                  st.ptr, cur_stream()), "osrl_cdt_temperature_step")
+
+    def load_batch(self, states, actions, returns, costs_return, time_steps, mask, costs) -> None:
+        cp = lambda d, s: d.copy_(torch.as_tensor(s).reshape(d.shape), non_blocking=True)  # noqa: E731
+        cp(self.states, states)
+        cp(self.actions, actions)
+        cp(self.returns, returns)
+        cp(self.ctg, costs_return)
+        cp(self.time_steps, time_steps)
+        cp(self.mask, mask)
+        cp(self.costs, costs)
+
+    def step(self, states, actions, returns, costs_return, time_steps, mask, costs, use_graph: bool = True) -> None:
+        self.load_batch(states, actions, returns, costs_return, time_steps, mask, costs)
+        if use_graph:
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body()
+
+    def _capture(self) -> None:
+        m, g = self.model, self.g
+        snap = (g.p.clone(), g.m.clone(), g.v.clone(), self.st.state.clone(), self.st.stats.clone(),
+                self.st.ring.clone(), self.st.host_step, m.log_temperature.clone(), self.temp_mv.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.body()
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            self.body()
+        torch.cuda.synchronize()
+        g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])
+        self.st.state.copy_(snap[3]); self.st.stats.copy_(snap[4]); self.st.ring.copy_(snap[5])
+        self.st.host_step = snap[6]
+        m.log_temperature.copy_(snap[7]); self.temp_mv.copy_(snap[8])
+        m.repack()
+        self.graph = gr

@@ -353,10 +353,18 @@ class DwPlan:
         self.group, self.rows = group, rows
         arr = (L.DwEntryT * len(entries))()
         items: List[int] = []
-        for i, (dz, a, wk, bk) in enumerate(entries):
-            out_f, in_f = dz.shape[1], a.shape[1]
-            assert group.layout[wk][1] == (out_f, in_f), (wk, group.layout[wk], out_f, in_f)
-            arr[i].dz, arr[i].a = dz.data_ptr(), a.data_ptr()
+        for i, ent in enumerate(entries):
+            dz, a, wk, bk = ent[:4]
+            # optional 5th/6th items: (ptr, row stride, width) views for strided operands
+            out_f, in_f = group.layout[wk][1]
+            if len(ent) > 4:
+                ldz, lda_ = ent[4], ent[5]
+            else:
+                ldz = lda_ = 0
+                assert (dz.shape[1], a.shape[1]) == (out_f, in_f), (wk, group.layout[wk], dz.shape, a.shape)
+            arr[i].ldz, arr[i].lda = ldz, lda_
+            arr[i].dz = dz if isinstance(dz, int) else dz.data_ptr()
+            arr[i].a = a if isinstance(a, int) else a.data_ptr()
             arr[i].w_off, arr[i].b_off = group.offset(wk), group.offset(bk)
             arr[i].out, arr[i].in_ = out_f, in_f
             for ot in range((out_f + 63) // 64):
@@ -366,7 +374,7 @@ class DwPlan:
         raw = bytes(arr)
         self.d_entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.d_items = torch.tensor(items, dtype=torch.int32, device=device)
-        self._keep = [e[0] for e in entries] + [e[1] for e in entries]
+        self._keep = [e[0] for e in entries] + [e[1] for e in entries] + [e[6:] for e in entries if len(e) > 6]
         if n_splits is None:
             # fill ~2 waves of workgroups over 256 CUs, keep >= 64 rows per split
             wgs = (self.n_items + 3) // 4

@@ -1,0 +1,192 @@
+"""GPU parity of the CDT kernels and the CDT train step (osrl_amd, through the C ABI) against numpy
+references, the reference-generated goldens and the CDT oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from cases import CDT_CASES, make_cdt_batch, make_cdt_params
+from oracle_util import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(x):
+    return torch.as_tensor(x, device=DEV)
+
+
+def test_linear_kernel_shapes():
+    """osrl_linear on packed weights: forward pack, backward pack, strided A / Y, residual, column groups."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import FlatGroup, cur_stream
+    rs = np.random.RandomState(0)
+    r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+    for (M, K, N) in [(200, 256, 768), (96, 1024, 256), (130, 256, 1024), (77, 16, 6), (64, 128, 2), (50, 3, 40),
+                      (300, 768, 256), (33, 6, 128)]:
+        g = FlatGroup("t", DEV)
+        g.add("w", (N, K))
+        g.mark_weight("w")
+        g.add("b", (N,))
+        g.finalize()
+        W = rs.randn(N, K).astype(np.float32) * 0.1
+        b = rs.randn(N).astype(np.float32)
+        g.view("w").copy_(t(W))
+        g.view("b").copy_(t(b))
+        g.repack()
+        A = rs.randn(M, K).astype(np.float32)
+        R = rs.randn(M, N).astype(np.float32)
+        At, Rt, Y = t(A), t(R), torch.zeros(M, N, device=DEV)
+        L.check(L.load().osrl_linear(At.data_ptr(), K, M, K, g.pf.data_ptr(), r16(N), 0, N, g.view("b").data_ptr(),
+                                     Rt.data_ptr(), N, Y.data_ptr(), N, cur_stream()), "lin")
+        ref = A.astype(np.float64) @ W.T.astype(np.float64) + b + R
+        err = np.abs(Y.cpu().numpy() - ref).max()
+        assert err < 3e-5 * max(1, np.abs(ref).max()), (M, K, N, "fwd", err)
+        # dx = dY W  through the backward pack
+        dY = rs.randn(M, N).astype(np.float32)
+        dX = torch.zeros(M, K, device=DEV)
+        L.check(L.load().osrl_linear(t(dY).data_ptr(), N, M, N, g.pb.data_ptr(), r16(K) + 16, 0, K, None, None, 0,
+                                     dX.data_ptr(), K, cur_stream()), "lin dx")
+        ref = dY.astype(np.float64) @ W.astype(np.float64)
+        err = np.abs(dX.cpu().numpy() - ref).max()
+        assert err < 3e-5 * max(1, np.abs(ref).max()), (M, K, N, "dx", err)
+
+
+def test_layernorm_gelu_attention_kernels():
+    from oracle.cdt_oracle import gelu, gelu_grad, layer_norm, layer_norm_bwd
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import cur_stream
+    lib = L.load()
+    rs = np.random.RandomState(1)
+    for (M, E) in [(37, 16), (260, 128), (1000, 256)]:
+        x, d = rs.randn(M, E), rs.randn(M, E) * 0.3
+        gm, bt = 1 + 0.1 * rs.randn(E), 0.1 * rs.randn(E)
+        f = lambda a: t(np.asarray(a, np.float32))  # noqa: E731
+        xt, dt_, gt, btt = f(x), f(d), f(gm), f(bt)
+        xo, y, st = torch.zeros(M, E, device=DEV), torch.zeros(M, E, device=DEV), torch.zeros(M, 2, device=DEV)
+        L.check(lib.osrl_layernorm_fwd(xt.data_ptr(), dt_.data_ptr(), gt.data_ptr(), btt.data_ptr(), xo.data_ptr(),
+                                       y.data_ptr(), st.data_ptr(), M, E, cur_stream()), "ln")
+        xs = x.astype(np.float32).astype(np.float64) + d.astype(np.float32).astype(np.float64)
+        yr, cache = layer_norm(xs, gm.astype(np.float32).astype(np.float64), bt.astype(np.float32).astype(np.float64))
+        assert np.abs(y.cpu().numpy() - yr).max() < 2e-5 and np.abs(xo.cpu().numpy() - xs).max() < 1e-6
+        dy, dres = rs.randn(M, E), rs.randn(M, E)
+        dx = torch.zeros(M, E, device=DEV)
+        nparts = 7
+        ws, slab = torch.zeros(nparts, 2 * E, device=DEV), torch.zeros(4 * E + 8, device=DEV)
+        L.check(lib.osrl_layernorm_bwd(f(dy).data_ptr(), xo.data_ptr(), st.data_ptr(), gt.data_ptr(), f(dres).data_ptr(),
+                                       dx.data_ptr(), ws.data_ptr(), nparts, M, E, slab.data_ptr(), 4, 4 + 2 * E,
+                                       cur_stream()), "lnb")
+        dxr, dgr, dbr = layer_norm_bwd(dy.astype(np.float32).astype(np.float64), cache,
+                                       gm.astype(np.float32).astype(np.float64))
+        dxr = dxr + dres.astype(np.float32)
+        assert np.abs(dx.cpu().numpy() - dxr).max() < 5e-5, (M, E)
+        sl = slab.cpu().numpy()
+        assert np.abs(sl[4:4 + E] - dgr).max() < 1e-3 * max(1, np.abs(dgr).max())
+        assert np.abs(sl[4 + 2 * E:4 + 3 * E] - dbr).max() < 1e-3 * max(1, np.abs(dbr).max())
+    # gelu
+    x = (rs.randn(4096) * 2).astype(np.float32)
+    dy = rs.randn(4096).astype(np.float32)
+    y, dx = torch.zeros(4096, device=DEV), torch.zeros(4096, device=DEV)
+    L.check(lib.osrl_gelu_fwd(t(x).data_ptr(), y.data_ptr(), 4096, cur_stream()), "g")
+    L.check(lib.osrl_gelu_bwd(t(dy).data_ptr(), t(x).data_ptr(), dx.data_ptr(), 4096, cur_stream()), "gb")
+    assert np.abs(y.cpu().numpy() - gelu(x.astype(np.float64))).max() < 2e-6
+    assert np.abs(dx.cpu().numpy() - dy * gelu_grad(x.astype(np.float64))).max() < 5e-6
+    # attention fwd/bwd vs numpy
+    for (B, T, E, H) in [(3, 4, 16, 2), (2, 20, 256, 8), (5, 10, 128, 8)]:
+        S, d = 4 * T, E // H
+        qkv = rs.randn(B, S, 3 * E).astype(np.float32)
+        mask = np.ones((B, T), np.float32)
+        mask[0, T - 2:] = 0
+        do = rs.randn(B, S, E).astype(np.float32)
+        o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
+        qt, mt = t(qkv), t(mask)
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, o.data_ptr(), cur_stream()), "a")
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), t(do).data_ptr(), B, S, E, H, 4, dqkv.data_ptr(),
+                                       cur_stream()), "ab")
+        q64 = qkv.astype(np.float64)
+        q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
+        blocked = np.triu(np.ones((S, S), bool), 1)[None, None] | np.repeat(mask <= 0, 4, 1)[:, None, None, :]
+        sc = np.where(blocked, -np.inf, q @ k.transpose(0, 1, 3, 2) / math.sqrt(d))
+        P = np.exp(sc - sc.max(-1, keepdims=True))
+        P /= P.sum(-1, keepdims=True)
+        oref = (P @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
+        assert np.abs(o.cpu().numpy() - oref).max() < 2e-5, (B, T, E, H)
+        dO = do.astype(np.float64).reshape(B, S, H, d).transpose(0, 2, 1, 3)
+        dP = dO @ v.transpose(0, 1, 3, 2)
+        dv = P.transpose(0, 1, 3, 2) @ dO
+        dS = P * (dP - (dP * P).sum(-1, keepdims=True))
+        dq, dk = dS @ k / math.sqrt(d), dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
+        ref = np.concatenate([x.transpose(0, 2, 1, 3).reshape(B, S, E) for x in (dq, dk, dv)], -1)
+        assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), (B, T, E, H)
+
+
+def build_cdt_gpu(c, **kw):
+    from osrl_amd.algorithms import CDT, CDTTrainer
+    from osrl_amd.common.logger import DummyLogger
+    m = CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=c.episode_len, embedding_dim=c.E, num_layers=c.layers,
+            num_heads=c.heads, use_rew=True, use_cost=True, cost_transform=c.cost_transform, stochastic=c.stochastic,
+            init_temperature=0.1, target_entropy=-c.ad, device=DEV)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_cdt_params(c).items()})
+    lg = DummyLogger()
+    args = dict(stats_mode="sync", use_graph=False)
+    args.update(kw)
+    tr = CDTTrainer(m, None, lg, learning_rate=c.lr, weight_decay=c.wd, clip_grad=c.clip, lr_warmup_steps=c.warmup,
+                    reward_scale=0.1, loss_cost_weight=c.cost_w, loss_state_weight=c.state_w, device=DEV, **args)
+    return m, tr, lg
+
+
+@pytest.mark.parametrize("name", list(CDT_CASES))
+def test_cdt_train_step_matches_golden_and_oracle(name):
+    from test_oracle_cdt_golden import build_cdt_oracle
+    c = CDT_CASES[name]
+    g = load_golden(name)
+    keys = [str(k) for k in g["stat_keys"]]
+    m, tr, lg = build_cdt_gpu(c)
+    o = build_cdt_oracle(c)
+    b = {k: t(v) for k, v in make_cdt_batch(c).items()}
+    bn = make_cdt_batch(c)
+    for s in range(c.steps):
+        tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                          b["episode_cost"], b["costs"])
+        ost = o.train_one_step(bn["states"], bn["actions"], bn["returns"], bn["costs_return"], bn["time_steps"],
+                               bn["mask"], bn["episode_cost"], bn["costs"])
+        ref = dict(zip(keys, g["stats"][s]))
+        tol = 1e-5 if s == 0 else 1e-4
+        for k in keys:
+            got = lg.last("train/" + k)
+            for nm, r in (("golden", ref[k]), ("oracle", ost[k])):
+                assert abs(got - r) <= tol * max(1.0, abs(r)), f"{name} step {s} {k}: gpu {got} vs {nm} {r}"
+        if f"s{s + 1}/log_temperature" in g:
+            assert abs(m.log_temperature.item() - float(g[f"s{s + 1}/log_temperature"])) < 1e-6
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        for k, v in sd.items():
+            if f"p{s + 1}/{k}" in g:
+                d = np.abs(v - g[f"p{s + 1}/{k}"]).max()
+                assert d <= 2e-5, f"{name} step {s + 1} param {k}: max diff {d:.3e}"
+            elif f"p{s + 1}/smp/{k}" in g:
+                d = np.abs(v.reshape(-1)[::97] - g[f"p{s + 1}/smp/{k}"]).max()
+                assert d <= 2e-5, f"{name} step {s + 1} param sample {k}: {d:.3e}"
+    ap, cp, sp = m(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
+                   ~b["mask"].to(torch.bool), b["episode_cost"])
+    a = (ap.mean if c.stochastic else ap).cpu().numpy()
+    assert np.abs(a - g["act"]).max() <= 1e-4
+
+
+def test_cdt_graph_replay_matches_eager():
+    c = CDT_CASES["cdt_small"]
+    res = []
+    for use_graph in (False, True):
+        m, tr, lg = build_cdt_gpu(c, stats_mode="none", use_graph=use_graph)
+        b = {k: t(v) for k, v in make_cdt_batch(c).items()}
+        for s in range(3):
+            tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                              b["episode_cost"], b["costs"])
+        torch.cuda.synchronize()
+        res.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k in res[0]:
+        if "timestep_emb" in k:  # atomic scatter: order-dependent rounding
+            assert (res[0][k] - res[1][k]).abs().max() < 1e-6
+        else:
+            assert (res[0][k] - res[1][k]).abs().max() < 1e-6, k
