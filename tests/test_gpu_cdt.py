@@ -47,7 +47,8 @@ def test_linear_kernel_shapes():
         # dx = dY W  through the backward pack
         dY = rs.randn(M, N).astype(np.float32)
         dX = torch.zeros(M, K, device=DEV)
-        L.check(L.load().osrl_linear(t(dY).data_ptr(), N, M, N, g.pb.data_ptr(), r16(K) + 16, 0, K, None, None, 0,
+        dYt = t(dY)
+        L.check(L.load().osrl_linear(dYt.data_ptr(), N, M, N, g.pb.data_ptr(), r16(K) + 16, 0, K, None, None, 0,
                                      dX.data_ptr(), K, cur_stream()), "lin dx")
         ref = dY.astype(np.float64) @ W.astype(np.float64)
         err = np.abs(dX.cpu().numpy() - ref).max()
@@ -75,7 +76,8 @@ def test_layernorm_gelu_attention_kernels():
         dx = torch.zeros(M, E, device=DEV)
         nparts = 7
         ws, slab = torch.zeros(nparts, 2 * E, device=DEV), torch.zeros(4 * E + 8, device=DEV)
-        L.check(lib.osrl_layernorm_bwd(f(dy).data_ptr(), xo.data_ptr(), st.data_ptr(), gt.data_ptr(), f(dres).data_ptr(),
+        dyt, drt = f(dy), f(dres)  # keep the tensors alive: data_ptr() of a temporary dangles
+        L.check(lib.osrl_layernorm_bwd(dyt.data_ptr(), xo.data_ptr(), st.data_ptr(), gt.data_ptr(), drt.data_ptr(),
                                        dx.data_ptr(), ws.data_ptr(), nparts, M, E, slab.data_ptr(), 4, 4 + 2 * E,
                                        cur_stream()), "lnb")
         dxr, dgr, dbr = layer_norm_bwd(dy.astype(np.float32).astype(np.float64), cache,
@@ -89,8 +91,9 @@ def test_layernorm_gelu_attention_kernels():
     x = (rs.randn(4096) * 2).astype(np.float32)
     dy = rs.randn(4096).astype(np.float32)
     y, dx = torch.zeros(4096, device=DEV), torch.zeros(4096, device=DEV)
-    L.check(lib.osrl_gelu_fwd(t(x).data_ptr(), y.data_ptr(), 4096, cur_stream()), "g")
-    L.check(lib.osrl_gelu_bwd(t(dy).data_ptr(), t(x).data_ptr(), dx.data_ptr(), 4096, cur_stream()), "gb")
+    xg, dyg = t(x), t(dy)
+    L.check(lib.osrl_gelu_fwd(xg.data_ptr(), y.data_ptr(), 4096, cur_stream()), "g")
+    L.check(lib.osrl_gelu_bwd(dyg.data_ptr(), xg.data_ptr(), dx.data_ptr(), 4096, cur_stream()), "gb")
     assert np.abs(y.cpu().numpy() - gelu(x.astype(np.float64))).max() < 2e-6
     assert np.abs(dx.cpu().numpy() - dy * gelu_grad(x.astype(np.float64))).max() < 5e-6
     # attention fwd/bwd vs numpy
@@ -103,7 +106,8 @@ def test_layernorm_gelu_attention_kernels():
         o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
         qt, mt = t(qkv), t(mask)
         L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, o.data_ptr(), cur_stream()), "a")
-        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), t(do).data_ptr(), B, S, E, H, 4, dqkv.data_ptr(),
+        dot = t(do)
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, dqkv.data_ptr(),
                                        cur_stream()), "ab")
         q64 = qkv.astype(np.float64)
         q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
@@ -186,7 +190,7 @@ def test_cdt_graph_replay_matches_eager():
         torch.cuda.synchronize()
         res.append({k: v.clone() for k, v in m.state_dict().items()})
     for k in res[0]:
-        if "timestep_emb" in k:  # atomic scatter: order-dependent rounding
-            assert (res[0][k] - res[1][k]).abs().max() < 1e-6
-        else:
+        if res[0][k].dtype == torch.bool:
+            assert torch.equal(res[0][k], res[1][k])
+        else:  # the timestep-embedding scatter uses fp32 atomics: order-dependent rounding only
             assert (res[0][k] - res[1][k]).abs().max() < 1e-6, k
