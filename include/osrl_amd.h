@@ -148,6 +148,19 @@ int osrl_replay_gather(int32_t n_fields, const float* const* src, float* const* 
                        const float* scale, int64_t n_rows, int32_t batch, int32_t* idx_out, uint64_t seed,
                        uint32_t stream_id, const osrl_step_state_t* st, void* stream);
 
+/* CDT minibatch source -- SequenceDataset.__iter__/__prepare_sample (dataset.py:749-787) on device: per sample
+ * draw a trajectory (inverse CDF of `cdf`, or uniform when NULL) and a start ~ U{0..len-1}, slice seq_len steps
+ * of the concatenated trajectory tables (clipped at the trajectory end), zero-pad the tail, emit mask,
+ * time_steps = start + arange(T), returns*reward_scale, cost_returns*cost_scale, episode_cost =
+ * cost_returns[first step]*cost_scale.  idx_out (optional) receives (trajectory, start) per sample. */
+int osrl_seq_window_gather(const float* obs, const float* act, const float* returns, const float* cost_returns,
+                           const float* costs, const int64_t* traj_start, const int32_t* traj_len, const float* cdf,
+                           int32_t n_traj, int32_t B, int32_t T, int32_t od, int32_t ad, float reward_scale,
+                           float cost_scale, float* o_states, float* o_actions, float* o_returns,
+                           float* o_cost_returns, int64_t* o_time_steps, float* o_mask, float* o_episode_cost,
+                           float* o_costs, int32_t* idx_out, uint64_t seed, uint32_t stream_id,
+                           const osrl_step_state_t* st, void* stream);
+
 /* ---- glue (glue.hip): the elementwise / reduction tails of the loss functions ----
  * `rows_global` (0 = rows) is the data-parallel global batch used in every 1/B normalisation.
  * `stat` pointers are device floats (logged statistics), may be NULL. */

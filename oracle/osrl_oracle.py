@@ -575,3 +575,48 @@ class OracleBCQL:
         soft_update(p, "cost_critic_old", "cost_critic", self.tau)
         soft_update(p, "actor_old", "actor", self.tau)
         return stats
+
+
+# --------------------------------------------------------------------------- #
+# minibatch sources (osrl/common/dataset.py) -- used to check the on-device samplers
+# --------------------------------------------------------------------------- #
+def prepare_sequence_sample(traj: Dict[str, Array], start_idx: int, seq_len: int, reward_scale: float = 1.0,
+                            cost_scale: float = 1.0):
+    """SequenceDataset.__prepare_sample (dataset.py:749-775): slice, scale, tail zero-pad, mask."""
+    sl = slice(start_idx, start_idx + seq_len)
+    states, actions = np.asarray(traj["observations"][sl]), np.asarray(traj["actions"][sl])
+    returns = np.asarray(traj["returns"][sl]) * reward_scale
+    cost_returns = np.asarray(traj["cost_returns"][sl]) * cost_scale
+    costs = np.asarray(traj["costs"][sl])
+    time_steps = np.arange(start_idx, start_idx + seq_len)
+    episode_cost = traj["cost_returns"][0] * cost_scale
+    n = states.shape[0]
+    mask = np.hstack([np.ones(n), np.zeros(seq_len - n)])
+
+    def pad(a):
+        out = np.zeros((seq_len,) + a.shape[1:], a.dtype)
+        out[:n] = a
+        return out
+
+    return pad(states), pad(actions), pad(returns), pad(cost_returns), time_steps, mask, episode_cost, pad(costs)
+
+
+def transition_sample(data: Dict[str, Array], idx, reward_scale: float = 1.0, cost_scale: float = 1.0):
+    """TransitionDataset.__prepare_sample (dataset.py:832-842) for an index array."""
+    done = np.logical_or(np.asarray(data["terminals"]) == 1, np.asarray(data["timeouts"]) == 1).astype(np.float32)
+    return (data["observations"][idx], data["next_observations"][idx], data["actions"][idx],
+            data["rewards"][idx] * reward_scale, data["costs"][idx] * cost_scale, done[idx])
+
+
+def rollout(policy, env, episode_len: int, cost_scale: float = 1.0):
+    """XTrainer.rollout (cpq.py:330-347): policy(obs) -> action; returns (ret, len, cost)."""
+    obs, info = env.reset()
+    ret, cost, n = 0.0, 0.0, 0
+    for _ in range(episode_len):
+        obs, reward, terminated, truncated, info = env.step(policy(obs))
+        ret += reward
+        cost += info["cost"] * cost_scale
+        n += 1
+        if terminated or truncated:
+            break
+    return ret, n, cost

@@ -134,23 +134,35 @@ class CDT(nn.Module):
             learning_rate=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), clip_grad=0.25, lr_warmup_steps=1,
             loss_cost_weight=0.0, loss_state_weight=0.0, no_entropy=False)
         from ..engine.cdt import CDTEngine
-        if getattr(self, "_infer", None) is None or self._infer.B != B or self._infer.T != states.shape[1]:
-            if states.shape[1] != self.seq_len:
-                raise NotImplementedError("inference windows shorter than seq_len: pad to seq_len with a mask")
+        Tin, T = states.shape[1], self.seq_len
+        if Tin > T:
+            raise ValueError(f"window of {Tin} steps > seq_len {T}")
+        if getattr(self, "_infer", None) is None or self._infer.B != B:
             self._infer = CDTEngine(self, B, cfg)
         e = self._infer
-        mask = torch.ones(B, states.shape[1], device=states.device) if padding_mask is None else \
+        mask = torch.ones(B, Tin, device=states.device) if padding_mask is None else \
             (~padding_mask.to(torch.bool)).float()
+        if Tin < T:
+            # shorter windows (early rollout steps, cdt.py:485-489): left-align and zero-pad the tail; with the
+            # causal mask the first Tin positions are exactly the short-sequence result
+            def pad(x, val=0):
+                out = torch.full((B, T) + tuple(x.shape[2:]), val, dtype=x.dtype, device=x.device)
+                out[:, :Tin] = x
+                return out
+            states, actions, returns_to_go, costs_to_go = pad(states), pad(actions), pad(returns_to_go), pad(costs_to_go)
+            time_steps, mask = pad(time_steps), pad(mask)
         e.load_batch(states, actions, returns_to_go, costs_to_go, time_steps, mask, torch.zeros_like(mask))
         self.repack()
         e.forward()
-        T, ad, od = states.shape[1], self.action_dim, self.state_dim
+        ad, od = self.action_dim, self.state_dim
         if self.stochastic:
-            mu, ls = e.head[:, :ad].reshape(B, T, ad).clone(), e.head[:, ad:].reshape(B, T, ad).clone()
+            mu = e.head[:, :ad].reshape(B, T, ad)[:, :Tin].clone()
+            ls = e.head[:, ad:].reshape(B, T, ad)[:, :Tin].clone()
             ap = torch.distributions.Normal(mu, ls.exp())
         else:
-            ap = e.head.reshape(B, T, ad).clone()
-        return ap, torch.log_softmax(e.logits.reshape(B, T, 2), -1), e.sp.reshape(B, T, od).clone()
+            ap = e.head.reshape(B, T, ad)[:, :Tin].clone()
+        return (ap, torch.log_softmax(e.logits.reshape(B, T, 2)[:, :Tin], -1),
+                e.sp.reshape(B, T, od)[:, :Tin].clone())
 
 
 class CDTTrainer:
@@ -178,3 +190,51 @@ class CDTTrainer:
         eng.step(states, actions, returns, costs_return, time_steps, mask, costs, use_graph=self.use_graph)
         keys = None if self.stochastic else ["all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
         store_stats(self.logger, eng.st, self.stats_mode, tab="train", keys=keys)
+
+    def evaluate(self, num_rollouts, target_return, target_cost):
+        """cdt.py:420-434."""
+        self.model.eval()
+        rets, costs, lens = [], [], []
+        for _ in range(num_rollouts):
+            r, l, c = self.rollout(self.model, self.env, target_return, target_cost)
+            rets.append(r)
+            lens.append(l)
+            costs.append(c)
+        self.model.train()
+        return np.mean(rets) / self.reward_scale, np.mean(costs) / self.cost_scale, np.mean(lens)
+
+    @torch.no_grad()
+    def rollout(self, model: CDT, env, target_return: float, target_cost: float):
+        """cdt.py:436-518: autoregressive rollout on a sliding window of the last seq_len steps."""
+        dev = torch.device(model.device)
+        EL, T = model.episode_len, model.seq_len
+        states = torch.zeros(1, EL + 1, model.state_dim, device=dev)
+        actions = torch.zeros(1, EL, model.action_dim, device=dev)
+        returns = torch.zeros(1, EL + 1, device=dev)
+        costs = torch.zeros(1, EL + 1, device=dev)
+        time_steps = torch.arange(EL, dtype=torch.long, device=dev).view(1, -1)
+        obs, info = env.reset()
+        states[:, 0] = torch.as_tensor(obs, device=dev)
+        returns[:, 0] = float(target_return)
+        costs[:, 0] = float(target_cost)
+        epi_cost = torch.tensor([target_cost], dtype=torch.float, device=dev)
+        ep_ret, ep_cost, ep_len = 0.0, 0.0, 0
+        for step in range(EL):
+            lo = max(0, step + 1 - T)
+            acts, _, _ = model(states[:, lo:step + 1], actions[:, lo:step + 1], returns[:, lo:step + 1],
+                               costs[:, lo:step + 1], time_steps[:, lo:step + 1], None, epi_cost)
+            if self.stochastic:
+                acts = acts.mean
+            act = acts.clamp(-self.max_action, self.max_action)[0, -1].cpu().numpy()
+            obs_next, reward, terminated, truncated, info = env.step(act)
+            cost = ((1.0 - info["cost"]) if self.cost_reverse else info["cost"]) * self.cost_scale
+            actions[:, step] = torch.as_tensor(act, device=dev)
+            states[:, step + 1] = torch.as_tensor(obs_next, device=dev)
+            returns[:, step + 1] = returns[:, step] - float(reward)
+            costs[:, step + 1] = costs[:, step] - float(cost)
+            ep_ret += reward
+            ep_len += 1
+            ep_cost += info["cost"]
+            if terminated or truncated:
+                break
+        return ep_ret, ep_len, ep_cost

@@ -67,3 +67,41 @@ def synthetic_transitions(n: int, od: int, ad: int, seed: int = 1, max_action: f
                 actions=(rs.uniform(-1, 1, (n, ad)) * max_action).astype(f), rewards=rs.randn(n).astype(f),
                 costs=(rs.uniform(size=n) < 0.1).astype(f), terminals=(rs.uniform(size=n) < 0.01).astype(f),
                 timeouts=np.zeros(n, f))
+
+
+class SequenceStore:
+    """Device-resident trajectory store + on-device window sampler for CDT: replaces ``SequenceDataset``
+    (osrl/common/dataset.py:633-787; augmentation / Pareto constructor paths are out of scope) + DataLoader.
+    ``trajectories``: list of dicts with observations [L,od], actions [L,ad], returns [L] (return-to-go),
+    cost_returns [L] (cost-to-go), costs [L].  ``sample_prob``: optional per-trajectory probabilities
+    (dataset.py:439-459 ``compute_cost_sample_prob`` output); None = uniform."""
+
+    def __init__(self, trajectories, seq_len: int, device, reward_scale: float = 1.0, cost_scale: float = 1.0,
+                 sample_prob=None, seed: int = 0):
+        self.T, self.device = int(seq_len), torch.device(device)
+        cat = lambda k: torch.as_tensor(np.concatenate([np.asarray(t[k], np.float32).reshape(len(t["costs"]), -1)  # noqa: E731
+                                                        for t in trajectories]), device=self.device).contiguous()
+        self.obs, self.act = cat("observations"), cat("actions")
+        self.ret, self.cret, self.cost = cat("returns").view(-1), cat("cost_returns").view(-1), cat("costs").view(-1)
+        lens = np.array([len(t["costs"]) for t in trajectories], np.int64)
+        self.traj_len = torch.as_tensor(lens.astype(np.int32), device=self.device)
+        self.traj_start = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64), device=self.device)
+        self.n_traj = len(trajectories)
+        self.cdf = None
+        if sample_prob is not None:
+            c = np.cumsum(np.asarray(sample_prob, np.float64))
+            c /= c[-1]
+            self.cdf = torch.as_tensor(c.astype(np.float32), device=self.device)
+        self.reward_scale, self.cost_scale, self.seed = float(reward_scale), float(cost_scale), int(seed)
+        self.od, self.ad = self.obs.shape[1], self.act.shape[1]
+
+    def gather(self, states, actions, returns, cost_returns, time_steps, mask, episode_cost, costs, st_ptr,
+               idx_out=None, stream_id: int = 2) -> None:
+        B = states.shape[0]
+        L.check(L.load().osrl_seq_window_gather(
+            self.obs.data_ptr(), self.act.data_ptr(), self.ret.data_ptr(), self.cret.data_ptr(), self.cost.data_ptr(),
+            self.traj_start.data_ptr(), self.traj_len.data_ptr(), None if self.cdf is None else self.cdf.data_ptr(),
+            self.n_traj, B, self.T, self.od, self.ad, self.reward_scale, self.cost_scale, states.data_ptr(),
+            actions.data_ptr(), returns.data_ptr(), cost_returns.data_ptr(), time_steps.data_ptr(), mask.data_ptr(),
+            episode_cost.data_ptr(), costs.data_ptr(), None if idx_out is None else idx_out.data_ptr(), self.seed,
+            stream_id, st_ptr, cur_stream()), "osrl_seq_window_gather")

@@ -95,7 +95,91 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
   }
 }
 
+struct SeqArgs {
+  const float *obs, *act, *ret, *cret, *cost;  // concatenated trajectories [Ntot, .]
+  const int64_t* traj_start;
+  const int32_t* traj_len;
+  const float* cdf;  // inclusive cumulative trajectory-sampling probabilities, or NULL = uniform
+  float *states, *actions, *returns, *cost_returns, *mask, *episode_cost, *costs;
+  int64_t* time_steps;
+  int32_t* idx_out;  // optional [B,2] = (trajectory, start)
+  int32_t n_traj, B, T, od, ad;
+  float reward_scale, cost_scale;
+  uint32_t k0, k1, stream_id;
+  const osrl_step_state_t* st;
+};
+
+// SequenceDataset.__iter__/__prepare_sample (dataset.py:749-787): trajectory ~ sample_prob, start ~ U{0..len-1},
+// window [start, start+T) clipped to the trajectory, zero tail padding, mask, time_steps = start + arange(T).
+__global__ __launch_bounds__(256) void seq_window_kernel(const SeqArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const uint32_t step = a.st ? (uint32_t)a.st->step : 0u;
+  const U4 r = philox4x32_10(U4{(uint32_t)b, 0x5e9u, step, a.stream_id}, a.k0, a.k1);
+  int traj;
+  if (a.cdf) {  // inverse-CDF draw: first index with cdf[i] > u
+    const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+    int lo = 0, hi = a.n_traj - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (a.cdf[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    traj = lo;
+  } else {
+    traj = (int)__umul64hi(((uint64_t)r.x << 32) | r.y, (uint64_t)a.n_traj);
+  }
+  const int len = a.traj_len[traj];
+  const int start = (int)__umul64hi(((uint64_t)r.z << 32) | r.w, (uint64_t)len);
+  const int64_t base = a.traj_start[traj];
+  if (lane == 0) {
+    a.episode_cost[b] = a.cret[base] * a.cost_scale;
+    if (a.idx_out) {
+      a.idx_out[2 * b] = traj;
+      a.idx_out[2 * b + 1] = start;
+    }
+  }
+  const int T = a.T;
+  for (int t = lane; t < T; t += 64) {
+    const bool ok = start + t < len;
+    const int64_t src = base + start + t;
+    const size_t o = (size_t)b * T + t;
+    a.returns[o] = ok ? a.ret[src] * a.reward_scale : 0.f;
+    a.cost_returns[o] = ok ? a.cret[src] * a.cost_scale : 0.f;
+    a.costs[o] = ok ? a.cost[src] : 0.f;
+    a.mask[o] = ok ? 1.f : 0.f;
+    a.time_steps[o] = start + t;
+  }
+  for (int i = lane; i < T * a.od; i += 64) {
+    const int t = i / a.od, c = i - t * a.od;
+    a.states[(size_t)b * T * a.od + i] = (start + t < len) ? a.obs[(size_t)(base + start + t) * a.od + c] : 0.f;
+  }
+  for (int i = lane; i < T * a.ad; i += 64) {
+    const int t = i / a.ad, c = i - t * a.ad;
+    a.actions[(size_t)b * T * a.ad + i] = (start + t < len) ? a.act[(size_t)(base + start + t) * a.ad + c] : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int osrl_seq_window_gather(const float* obs, const float* act, const float* returns,
+                                      const float* cost_returns, const float* costs, const int64_t* traj_start,
+                                      const int32_t* traj_len, const float* cdf, int32_t n_traj, int32_t B, int32_t T,
+                                      int32_t od, int32_t ad, float reward_scale, float cost_scale, float* o_states,
+                                      float* o_actions, float* o_returns, float* o_cost_returns,
+                                      int64_t* o_time_steps, float* o_mask, float* o_episode_cost, float* o_costs,
+                                      int32_t* idx_out, uint64_t seed, uint32_t stream_id,
+                                      const osrl_step_state_t* st, void* stream) {
+  if (!obs || !act || !returns || !cost_returns || !costs || !traj_start || !traj_len || n_traj < 1 || B < 1 || T < 1 ||
+      !o_states || !o_actions || !o_returns || !o_cost_returns || !o_time_steps || !o_mask || !o_episode_cost || !o_costs)
+    return -1;
+  SeqArgs a{obs, act, returns, cost_returns, costs, traj_start, traj_len, cdf, o_states, o_actions, o_returns,
+            o_cost_returns, o_mask, o_episode_cost, o_costs, o_time_steps, idx_out, n_traj, B, T, od, ad,
+            reward_scale, cost_scale, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, st};
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(seq_window_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 
 extern "C" int osrl_randn_fill(float* out, int64_t n, uint64_t seed, uint32_t stream_id,
                                const osrl_step_state_t* st, void* stream) {

@@ -101,6 +101,8 @@ class CDTEngine:
         self.p_bt = DwPlan(g, bt, BT, dev)
         self.n_splits = max(self.p_tok.n_splits, self.p_bt.n_splits)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.episode_cost = z(B)
+        self.store = None
         m.repack()
 
     # ---- thin launch helpers -------------------------------------------------------------------
@@ -185,6 +187,9 @@ class CDTEngine:
         E, M, BT, NL = self.E, self.M, self.BT, self.NL
         st = self.st
         st.tick()
+        if self.store is not None:  # draw the minibatch of windows on device (SequenceDataset, dataset.py:749-787)
+            self.store.gather(self.states, self.actions, self.returns, self.ctg, self.time_steps, self.mask,
+                              self.episode_cost, self.costs, st.ptr)
         self.forward()
         L.check(lib.osrl_cdt_loss(self.head.data_ptr(), self.logits.data_ptr(), self.sp.data_ptr(),
                                   self.actions.data_ptr(), self.states.data_ptr(), self.mask.data_ptr(),
@@ -250,8 +255,22 @@ class CDTEngine:
         cp(self.mask, mask)
         cp(self.costs, costs)
 
+    def attach_store(self, store) -> None:
+        self.store = store
+        self.graph = None
+
+    def step_store(self, use_graph: bool = True) -> None:
+        """One train step on windows sampled on device from the attached SequenceStore."""
+        assert self.store is not None
+        self._go(use_graph)
+
     def step(self, states, actions, returns, costs_return, time_steps, mask, costs, use_graph: bool = True) -> None:
+        if self.store is not None:
+            raise RuntimeError("a SequenceStore is attached: call step_store()")
         self.load_batch(states, actions, returns, costs_return, time_steps, mask, costs)
+        self._go(use_graph)
+
+    def _go(self, use_graph: bool) -> None:
         if use_graph:
             if self.graph is None:
                 self._capture()
