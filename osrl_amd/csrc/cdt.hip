@@ -200,17 +200,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// dgamma -> slab[g_off + f], dbeta -> slab[b_off + f]  (fixed-order sum of the per-workgroup partials)
-__global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, int E, float* __restrict__ slab,
-                                       int64_t g_off, int64_t b_off) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * E) return;
+// dgamma -> slab[g_off + f], dbeta -> slab[b_off + f]  (fixed-order sum of the per-workgroup partials;
+// 64 columns per workgroup, the 4 waves split the partial rows, then a 4-way LDS reduction)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, int E,
+                                                              float* __restrict__ slab, int64_t g_off, int64_t b_off) {
+  __shared__ float sm[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 2 * E + i];
-  slab[(i < E ? g_off + i : b_off + (i - E))] = s;
+  if (i < 2 * E)
+    for (int p = grp; p < nparts; p += 4) s += partial[(size_t)p * 2 * E + i];
+  sm[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && i < 2 * E) slab[(i < E ? g_off + i : b_off + (i - E))] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
 }
 
-// ---------------- attention: one workgroup per (batch, head); S = tokens (<= 128), d = head dim (<= 64)
+// ---------------- attention: one workgroup (4 waves) per (batch, head), fp32 MFMA 16x16x4 -------------
+// S tokens (<= 128) x head dim d (<= 64).  Q, K, (V | V^T), dO live in LDS as row-major tiles padded to
+// multiples of 16 (row stride = width + 8 floats => conflict-free ds_read_b128 fragments, as in mlp.hip);
+// the S x S score / probability tiles never leave LDS.  Only the lower-triangular 16x16 blocks are
+// computed (causal mask, net.py:417-418); key padding (net.py:433) masks columns inside the blocks.
+// Fragment conventions (k-slot trick of mlp.hip): a "row fragment" takes 4 consecutive k of one row with a
+// single ds_read_b128, a "column fragment" takes them from 4 consecutive rows with 4 ds_read_b32.
 struct AttnArgs {
   const float* qkv;   // [B, S, 3E]
   const float* mask;  // [B, T] (1 = valid); token j is a padded key iff mask[b, j/rep] <= 0
@@ -220,101 +231,169 @@ struct AttnArgs {
   int32_t B, S, E, H, rep;
 };
 
-__device__ __forceinline__ void attn_load(const AttnArgs& a, int b, int h, int d, float* Q, float* K, float* V, int ld) {
-  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
-    const int i = idx / d, c = idx - i * d;
-    const float* __restrict__ p = a.qkv + ((size_t)b * a.S + i) * 3 * a.E + h * d + c;
-    Q[i * ld + c] = p[0];
-    K[i * ld + c] = p[a.E];
-    V[i * ld + c] = p[2 * a.E];
+__device__ __forceinline__ f32x4 frag_row(const float* base, int ld, int row0, int k0, int lane) {
+  return *reinterpret_cast<const f32x4*>(base + (row0 + (lane & 15)) * ld + k0 + 4 * (lane >> 4));
+}
+__device__ __forceinline__ f32x4 frag_col(const float* base, int ld, int k0, int col0, int lane) {
+  const float* p = base + (k0 + 4 * (lane >> 4)) * ld + col0 + (lane & 15);
+  return f32x4{p[0], p[ld], p[2 * ld], p[3 * ld]};
+}
+__device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void tri_decode(int blk, int* ib, int* jb) {  // blk -> (ib, jb), jb <= ib
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= blk) ++i;
+  *ib = i;
+  *jb = blk - i * (i + 1) / 2;
+}
+
+// load one [S, d] slice of qkv / dout into a zero-padded row-major LDS tile (and optionally its transpose)
+__device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, size_t row_stride, int S_, int d, int Sp,
+                                               int dp, float* dst, int ld, float* dst_t, int ld_t) {
+  for (int idx = threadIdx.x; idx < Sp * dp; idx += blockDim.x) {
+    const int i = idx / dp, c = idx - i * dp;
+    const float v = (i < S_ && c < d) ? src[(size_t)i * row_stride + c] : 0.f;
+    if (dst) dst[i * ld + c] = v;
+    if (dst_t) dst_t[c * ld_t + i] = v;
   }
 }
-// P[i][j] = softmax_j(q_i.k_j / sqrt(d)) over allowed j (j <= i and key j not padded); row i by one thread
-__device__ __forceinline__ void attn_probs(const AttnArgs& a, int b, int d, const float* Q, const float* K, float* P,
-                                           int ld, int ldp) {
+
+// P = softmax(mask(Q K^T / sqrt(d))) into Ps (lower-triangular blocks; everything else = 0)
+__device__ __forceinline__ void attn_probs_mfma(const AttnArgs& a, int b, int d, int Sp, int dp, const float* Qs,
+                                                const float* Ks, int ldq, float* Ps, int ldp, const float* kvalid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = Sp >> 4, ntri = nb * (nb + 1) / 2;
   const float scale = 1.0f / sqrtf((float)d);
-  for (int idx = threadIdx.x; idx < a.S * a.S; idx += blockDim.x) {
-    const int i = idx / a.S, j = idx - i * a.S;
-    float s = -INFINITY;
-    if (j <= i && a.mask[(size_t)b * (a.S / a.rep) + j / a.rep] > 0.f) {
-      s = 0.f;
-      for (int c = 0; c < d; ++c) s += Q[i * ld + c] * K[j * ld + c];
-      s *= scale;
+  for (int blk = wave; blk < ntri; blk += 4) {
+    int ib, jb;
+    tri_decode(blk, &ib, &jb);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < dp; kc += 16) mfma4(acc, frag_row(Qs, ldq, ib * 16, kc, lane), frag_row(Ks, ldq, jb * 16, kc, lane));
+    const int j = jb * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ib * 16 + 4 * (lane >> 4) + r;
+      Ps[i * ldp + j] = (j <= i && kvalid[j] > 0.f) ? acc[r] * scale : -INFINITY;
     }
-    P[i * ldp + j] = s;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.S; i += blockDim.x) {
-    float mx = -INFINITY;
-    for (int j = 0; j <= i; ++j) mx = fmaxf(mx, P[i * ldp + j]);
-    float sum = 0.f;
-    for (int j = 0; j < a.S; ++j) {
-      const float e = (j <= i && P[i * ldp + j] > -INFINITY) ? expf(P[i * ldp + j] - mx) : 0.f;
-      P[i * ldp + j] = e;
-      sum += e;
-    }
-    const float inv = 1.0f / sum;  // key 0 is never padded (tail padding only) => sum > 0
-    for (int j = 0; j < a.S; ++j) P[i * ldp + j] *= inv;
+  for (int i = wave; i < Sp; i += 4) {  // one wave per row; lanes over the columns of the computed blocks
+    const int jmax = ((i >> 4) + 1) << 4;
+    float v0 = (lane < jmax) ? Ps[i * ldp + lane] : -INFINITY;
+    float v1 = (lane + 64 < jmax) ? Ps[i * ldp + lane + 64] : -INFINITY;
+    float mx = fmaxf(v0, v1);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const bool live = i < a.S && mx > -INFINITY;
+    const float e0 = (live && v0 > -INFINITY) ? expf(v0 - mx) : 0.f;
+    const float e1 = (live && v1 > -INFINITY) ? expf(v1 - mx) : 0.f;
+    const float inv = live ? 1.0f / wsum(e0 + e1) : 0.f;
+    if (lane < Sp) Ps[i * ldp + lane] = e0 * inv;
+    if (lane + 64 < Sp) Ps[i * ldp + lane + 64] = e1 * inv;
   }
   __syncthreads();
 }
 
+__device__ __forceinline__ void attn_key_valid(const AttnArgs& a, int b, int Sp, float* kvalid) {
+  for (int j = threadIdx.x; j < Sp; j += blockDim.x)
+    kvalid[j] = (j < a.S && a.mask[(size_t)b * (a.S / a.rep) + j / a.rep] > 0.f) ? 1.f : 0.f;
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int d = a.E / a.H, ld = d + 1, ldp = a.S + 1;
+  const int d = a.E / a.H, dp = (d + 15) & ~15, Sp = (a.S + 15) & ~15;
+  const int ldq = dp + 8, ldp = Sp + 8;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  float *Q = sm, *K = Q + a.S * ld, *V = K + a.S * ld, *P = V + a.S * ld;
-  attn_load(a, b, h, d, Q, K, V, ld);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *Qs = sm, *Ks = Qs + Sp * ldq, *Vt = Ks + Sp * ldq, *Ps = Vt + dp * ldp, *kvalid = Ps + Sp * ldp;
+  const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
+  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, Qs, ldq, nullptr, 0);
+  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, Ks, ldq, nullptr, 0);
+  attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, nullptr, 0, Vt, ldp);
+  attn_key_valid(a, b, Sp, kvalid);
   __syncthreads();
-  attn_probs(a, b, d, Q, K, P, ld, ldp);
-  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
-    const int i = idx / d, c = idx - i * d;
-    float s = 0.f;
-    for (int j = 0; j <= i; ++j) s += P[i * ldp + j] * V[j * ld + c];
-    a.o[((size_t)b * a.S + i) * a.E + h * d + c] = s;
+  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid);
+  // O = P V : blocks (ib, cb); A = row fragments of P, B = row fragments of V^T
+  const int nb = Sp >> 4, ncb = dp >> 4;
+  for (int blk = wave; blk < nb * ncb; blk += 4) {
+    const int ib = blk / ncb, cb = blk - ib * ncb;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int jc = 0; jc <= ib; ++jc) mfma4(acc, frag_row(Ps, ldp, ib * 16, jc * 16, lane), frag_row(Vt, ldp, cb * 16, jc * 16, lane));
+    const int c = cb * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ib * 16 + 4 * (lane >> 4) + r;
+      if (i < a.S && c < d) a.o[((size_t)b * a.S + i) * a.E + h * d + c] = acc[r];
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int d = a.E / a.H, ld = d + 1, ldp = a.S + 1;
+  const int d = a.E / a.H, dp = (d + 15) & ~15, Sp = (a.S + 15) & ~15;
+  const int ldq = dp + 8, ldp = Sp + 8;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  float *Q = sm, *K = Q + a.S * ld, *V = K + a.S * ld, *dO = V + a.S * ld, *P = dO + a.S * ld, *dS = P + a.S * ldp;
-  attn_load(a, b, h, d, Q, K, V, ld);
-  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
-    const int i = idx / d, c = idx - i * d;
-    dO[i * ld + c] = a.dout[((size_t)b * a.S + i) * a.E + h * d + c];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *Qs = sm, *Ks = Qs + Sp * ldq, *Vs = Ks + Sp * ldq, *dOs = Vs + Sp * ldq, *Ps = dOs + Sp * ldq,
+        *dS = Ps + Sp * ldp, *kvalid = dS + Sp * ldp;
+  const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
+  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, Qs, ldq, nullptr, 0);
+  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, Ks, ldq, nullptr, 0);
+  attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, Vs, ldq, nullptr, 0);
+  attn_load_tile(a.dout + (size_t)b * a.S * a.E + h * d, a.E, a.S, d, Sp, dp, dOs, ldq, nullptr, 0);
+  attn_key_valid(a, b, Sp, kvalid);
+  __syncthreads();
+  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid);
+  const int nb = Sp >> 4, ncb = dp >> 4, ntri = nb * (nb + 1) / 2;
+  // dP = dO V^T on the lower-triangular blocks
+  for (int blk = wave; blk < ntri; blk += 4) {
+    int ib, jb;
+    tri_decode(blk, &ib, &jb);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < dp; kc += 16) mfma4(acc, frag_row(dOs, ldq, ib * 16, kc, lane), frag_row(Vs, ldq, jb * 16, kc, lane));
+    const int j = jb * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dS[(ib * 16 + 4 * (lane >> 4) + r) * ldp + j] = acc[r];
   }
   __syncthreads();
-  attn_probs(a, b, d, Q, K, P, ld, ldp);
-  // dP = dO V^T ;  dS = P * (dP - rowsum(dP*P))
-  for (int idx = threadIdx.x; idx < a.S * a.S; idx += blockDim.x) {
-    const int i = idx / a.S, j = idx - i * a.S;
-    float s = 0.f;
-    if (j <= i)
-      for (int c = 0; c < d; ++c) s += dO[i * ld + c] * V[j * ld + c];
-    dS[i * ldp + j] = s;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < a.S; i += blockDim.x) {
-    float r = 0.f;
-    for (int j = 0; j <= i; ++j) r += dS[i * ldp + j] * P[i * ldp + j];
-    for (int j = 0; j < a.S; ++j) dS[i * ldp + j] = P[i * ldp + j] * (dS[i * ldp + j] - r);
+  // dS = P * (dP - rowsum(dP * P)); zero outside the computed blocks
+  for (int i = wave; i < Sp; i += 4) {
+    const int jmax = ((i >> 4) + 1) << 4;
+    const float p0 = (lane < jmax) ? Ps[i * ldp + lane] : 0.f, p1 = (lane + 64 < jmax) ? Ps[i * ldp + lane + 64] : 0.f;
+    const float g0 = (lane < jmax) ? dS[i * ldp + lane] : 0.f, g1 = (lane + 64 < jmax) ? dS[i * ldp + lane + 64] : 0.f;
+    const float r = wsum(p0 * g0 + p1 * g1);
+    if (lane < Sp) {
+      dS[i * ldp + lane] = p0 * (g0 - r);
+      if (lane >= jmax) Ps[i * ldp + lane] = 0.f;
+    }
+    if (lane + 64 < Sp) {
+      dS[i * ldp + lane + 64] = p1 * (g1 - r);
+      if (lane + 64 >= jmax) Ps[i * ldp + lane + 64] = 0.f;
+    }
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)d);
-  for (int idx = threadIdx.x; idx < a.S * d; idx += blockDim.x) {
-    const int i = idx / d, c = idx - i * d;
-    float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int j = 0; j <= i; ++j) dq += dS[i * ldp + j] * K[j * ld + c];
-    for (int j = i; j < a.S; ++j) {  // column i of dS / P: rows j >= i
-      dk += dS[j * ldp + i] * Q[j * ld + c];
-      dv += P[j * ldp + i] * dO[j * ld + c];
+  // 3 * nb * ncb output blocks: dQ (ib, cb), dK (jb, cb), dV (jb, cb)
+  for (int blk = wave; blk < 3 * nb * ncb; blk += 4) {
+    const int which = blk / (nb * ncb), rem = blk - which * nb * ncb;
+    const int rb = rem / ncb, cb = rem - rb * ncb;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (which == 0) {  // dQ[i][c] = sum_{j <= i} dS[i][j] K[j][c]
+      for (int jc = 0; jc <= rb; ++jc) mfma4(acc, frag_row(dS, ldp, rb * 16, jc * 16, lane), frag_col(Ks, ldq, jc * 16, cb * 16, lane));
+    } else if (which == 1) {  // dK[j][c] = sum_{i >= j} dS[i][j] Q[i][c]
+      for (int ic = rb; ic < nb; ++ic) mfma4(acc, frag_col(dS, ldp, ic * 16, rb * 16, lane), frag_col(Qs, ldq, ic * 16, cb * 16, lane));
+    } else {  // dV[j][c] = sum_{i >= j} P[i][j] dO[i][c]
+      for (int ic = rb; ic < nb; ++ic) mfma4(acc, frag_col(Ps, ldp, ic * 16, rb * 16, lane), frag_col(dOs, ldq, ic * 16, cb * 16, lane));
     }
-    float* __restrict__ p = a.dqkv + ((size_t)b * a.S + i) * 3 * a.E + h * d + c;
-    p[0] = dq * scale;
-    p[a.E] = dk * scale;
-    p[2 * a.E] = dv;
+    const int c = cb * 16 + (lane & 15);
+    const float sc = which == 2 ? 1.0f : scale;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = rb * 16 + 4 * (lane >> 4) + r;
+      if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + which * a.E + h * d + c] = acc[r] * sc;
+    }
   }
 }
 
@@ -512,18 +591,20 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
     return -1;
   CLEAR();
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E);
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 255) / 256), dim3(256), 0, S, partial_ws, n_parts, E, slab,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(256), 0, S, partial_ws, n_parts, E, slab,
                      g_off, b_off);
   DONE();
 }
 
 static size_t attn_lds(int S_, int d, bool bwd) {
-  return sizeof(float) * ((size_t)(bwd ? 4 : 3) * S_ * (d + 1) + (size_t)(bwd ? 2 : 1) * S_ * (S_ + 1));
+  const size_t Sp = (S_ + 15) & ~15, dp = (d + 15) & ~15, ldq = dp + 8, ldp = Sp + 8;
+  const size_t fl = bwd ? 4 * Sp * ldq + 2 * Sp * ldp + Sp : 2 * Sp * ldq + dp * ldp + Sp * ldp + Sp;
+  return sizeof(float) * fl;
 }
 
 int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S_, int32_t E, int32_t H, int32_t rep,
                        float* o, void* stream) {
-  if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 160 || E % H || E / H > 64 || S_ % rep) return -1;
+  if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || S_ % rep) return -1;
   AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep};
   const size_t lds = attn_lds(S_, E / H, false);
   CLEAR();

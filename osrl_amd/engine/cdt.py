@@ -74,7 +74,7 @@ class CDTEngine:
         self.do = z(M, E)
         self.dqkv = [z(M, 3 * E) for _ in range(NL)]
         self.dseq = z(M, E)
-        self.n_parts = 256
+        self.n_parts = max(1, min(1024, (M + 31) // 32))  # ~8 rows per wave per LayerNorm-backward workgroup
         self.ln_ws = z(self.n_parts, 2 * E)
         self.clip_ws, self.clip_out = z(1024), z(4)
         self.temp_mv = z(2)
