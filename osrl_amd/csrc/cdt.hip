@@ -231,6 +231,33 @@ struct AttnArgs {
   int32_t B, S, E, H, rep;
 };
 
+// 16-lane (one DPP row) butterfly reductions: 4 VALU DPP ops instead of 4-6 ds_bpermute round trips
+__device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
+  const int x = __builtin_bit_cast(int, v);
+  int r;
+  switch (ctrl_sel) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break; // row_mirror
+  }
+  return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f(v, 0);
+  v += dpp_f(v, 1);
+  v += dpp_f(v, 2);
+  v += dpp_f(v, 3);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f(v, 0));
+  v = fmaxf(v, dpp_f(v, 1));
+  v = fmaxf(v, dpp_f(v, 2));
+  v = fmaxf(v, dpp_f(v, 3));
+  return v;
+}
+
 __device__ __forceinline__ f32x4 frag_row(const float* base, int ld, int row0, int k0, int lane) {
   return *reinterpret_cast<const f32x4*>(base + (row0 + (lane & 15)) * ld + k0 + 4 * (lane >> 4));
 }
@@ -249,14 +276,31 @@ __device__ __forceinline__ void tri_decode(int blk, int* ib, int* jb) {  // blk 
   *jb = blk - i * (i + 1) / 2;
 }
 
-// load one [S, d] slice of qkv / dout into a zero-padded row-major LDS tile (and optionally its transpose)
+// load one [S, d] slice of qkv / dout into a zero-padded row-major LDS tile (and optionally its transpose).
+// 8 independent global loads per thread are issued before the first LDS store so their latencies overlap
+// (one load per loop iteration serialises ~40 L2 round trips per workgroup: measured 3x slower kernels).
 __device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, size_t row_stride, int S_, int d, int Sp,
                                                int dp, float* dst, int ld, float* dst_t, int ld_t) {
-  for (int idx = threadIdx.x; idx < Sp * dp; idx += blockDim.x) {
-    const int i = idx / dp, c = idx - i * dp;
-    const float v = (i < S_ && c < d) ? src[(size_t)i * row_stride + c] : 0.f;
-    if (dst) dst[i * ld + c] = v;
-    if (dst_t) dst_t[c * ld_t + i] = v;
+  const int total = Sp * dp;
+  for (int base = 0; base < total; base += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = base + j * 256 + (int)threadIdx.x;
+      const int i = idx / dp, c = idx - i * dp;
+      const bool ok = idx < total && i < S_ && c < d;
+      v[j] = src[ok ? (size_t)i * row_stride + c : 0];
+      v[j] = ok ? v[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = base + j * 256 + (int)threadIdx.x;
+      if (idx < total) {
+        const int i = idx / dp, c = idx - i * dp;
+        if (dst) dst[i * ld + c] = v[j];
+        if (dst_t) dst_t[c * ld_t + i] = v[j];
+      }
+    }
   }
 }
 
@@ -279,19 +323,34 @@ __device__ __forceinline__ void attn_probs_mfma(const AttnArgs& a, int b, int d,
     }
   }
   __syncthreads();
-  for (int i = wave; i < Sp; i += 4) {  // one wave per row; lanes over the columns of the computed blocks
+  // softmax rows: 16 lanes per row (4 rows per wave at a time), each lane owns columns l16 + 16k
+  const int l16 = lane & 15, rsub = lane >> 4;
+  for (int i0 = wave * 4; i0 < Sp; i0 += 16) {
+    const int i = i0 + rsub;
     const int jmax = ((i >> 4) + 1) << 4;
-    float v0 = (lane < jmax) ? Ps[i * ldp + lane] : -INFINITY;
-    float v1 = (lane + 64 < jmax) ? Ps[i * ldp + lane + 64] : -INFINITY;
-    float mx = fmaxf(v0, v1);
+    float v[8];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    for (int k = 0; k < 8; ++k) {
+      const int j = l16 + 16 * k;
+      v[k] = (j < jmax && j < Sp) ? Ps[i * ldp + j] : -INFINITY;
+      mx = fmaxf(mx, v[k]);
+    }
+    mx = row16_max(mx);
     const bool live = i < a.S && mx > -INFINITY;
-    const float e0 = (live && v0 > -INFINITY) ? expf(v0 - mx) : 0.f;
-    const float e1 = (live && v1 > -INFINITY) ? expf(v1 - mx) : 0.f;
-    const float inv = live ? 1.0f / wsum(e0 + e1) : 0.f;
-    if (lane < Sp) Ps[i * ldp + lane] = e0 * inv;
-    if (lane + 64 < Sp) Ps[i * ldp + lane + 64] = e1 * inv;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = (live && v[k] > -INFINITY) ? expf(v[k] - mx) : 0.f;
+      sum += v[k];
+    }
+    sum = row16_sum(sum);
+    const float inv = live ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int j = l16 + 16 * k;
+      if (j < Sp) Ps[i * ldp + j] = v[k] * inv;
+    }
   }
   __syncthreads();
 }
@@ -359,18 +418,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   }
   __syncthreads();
   // dS = P * (dP - rowsum(dP * P)); zero outside the computed blocks
-  for (int i = wave; i < Sp; i += 4) {
-    const int jmax = ((i >> 4) + 1) << 4;
-    const float p0 = (lane < jmax) ? Ps[i * ldp + lane] : 0.f, p1 = (lane + 64 < jmax) ? Ps[i * ldp + lane + 64] : 0.f;
-    const float g0 = (lane < jmax) ? dS[i * ldp + lane] : 0.f, g1 = (lane + 64 < jmax) ? dS[i * ldp + lane + 64] : 0.f;
-    const float r = wsum(p0 * g0 + p1 * g1);
-    if (lane < Sp) {
-      dS[i * ldp + lane] = p0 * (g0 - r);
-      if (lane >= jmax) Ps[i * ldp + lane] = 0.f;
-    }
-    if (lane + 64 < Sp) {
-      dS[i * ldp + lane + 64] = p1 * (g1 - r);
-      if (lane + 64 >= jmax) Ps[i * ldp + lane + 64] = 0.f;
+  {
+    const int l16 = lane & 15, rsub = lane >> 4;
+    for (int i0 = wave * 4; i0 < Sp; i0 += 16) {
+      const int i = i0 + rsub;
+      const int jmax = ((i >> 4) + 1) << 4;
+      float pv[8], gv[8];
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = l16 + 16 * k;
+        const bool in = j < jmax && j < Sp;
+        pv[k] = in ? Ps[i * ldp + j] : 0.f;
+        gv[k] = in ? dS[i * ldp + j] : 0.f;
+        r += pv[k] * gv[k];
+      }
+      r = row16_sum(r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = l16 + 16 * k;
+        if (j < Sp) dS[i * ldp + j] = pv[k] * (gv[k] - r);
+      }
     }
   }
   __syncthreads();
