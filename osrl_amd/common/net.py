@@ -189,7 +189,7 @@ def _ref(lin: nn.Linear) -> LayerRef:
     if not hasattr(lin, "_osrl"):
         raise RuntimeError("module parameters are not bound to a FlatGroup (model not materialised)")
     grp, wkey, bkey, tgt = lin._osrl
-    return LayerRef(lin.weight.data, lin.bias.data, grp, wkey, bkey, tgt)
+    return LayerRef(lin.weight.data, lin.bias.data, grp, wkey, bkey, tgt, [lin.weight], [lin.bias])
 
 
 def net_desc_seq(seqs: Sequence[nn.Sequential], out_scale: float) -> NetDesc:
@@ -203,7 +203,8 @@ def _packed(first: nn.Linear, second: nn.Linear) -> LayerRef:
     if w1.data_ptr() != w0.data_ptr() + 4 * k * H or b1.data_ptr() != b0.data_ptr() + 4 * k:
         raise RuntimeError("packed head layers are not adjacent in HBM -- model was not materialised")
     grp, hw, hb, tgt = first._osrl_head
-    return LayerRef(torch.as_strided(w0, (2 * k, H), (H, 1)), torch.as_strided(b0, (2 * k,), (1,)), grp, hw, hb, tgt)
+    return LayerRef(torch.as_strided(w0, (2 * k, H), (H, 1)), torch.as_strided(b0, (2 * k,), (1,)), grp, hw, hb, tgt,
+                    [first.weight, second.weight], [first.bias, second.bias])
 
 
 def actor_head_desc(actor: SquashedGaussianMLPActor) -> NetDesc:

@@ -172,11 +172,13 @@ class FlatGroup:
 class LayerRef:
     """One Linear layer of a net: canonical weight/bias tensors (views into ``group``) + the key of its
     packed copies.  ``target=True`` reads the Polyak-target copy of the group."""
-    __slots__ = ("W", "b", "group", "key", "bkey", "target")
+    __slots__ = ("W", "b", "group", "key", "bkey", "target", "wparams", "bparams")
 
     def __init__(self, W: torch.Tensor, b: torch.Tensor, group: FlatGroup, key: str, bkey: str,
-                 target: bool = False):
+                 target: bool = False, wparams=None, bparams=None):
         self.W, self.b, self.group, self.key, self.bkey, self.target = W, b, group, key, bkey, target
+        # the nn.Parameters behind W / b (stacked along dim 0 for packed heads) -- autograd routing in ops.py
+        self.wparams, self.bparams = wparams, bparams
 
     @property
     def wf_ptr(self) -> int:

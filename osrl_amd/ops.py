@@ -38,8 +38,7 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, desc: NetDesc, x0: torch.Tensor, x1: Optional[torch.Tensor], *params):
         rows = x0.shape[0]
-        need_grad = torch.is_grad_enabled() and (x0.requires_grad or (x1 is not None and x1.requires_grad) or
-                                                 any(p.requires_grad for p in params))
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
         for g in desc.groups():  # weights may have been edited since the last pack: refresh (cheap)
             g.repack()
         run = MlpRun(desc, rows, need_grad, x0.device)
@@ -71,7 +70,19 @@ class _FusedMLP(torch.autograd.Function):
         grads = []
         for e in range(desc.E):
             for l in range(desc.nl):
-                grads += [grp.grad_view(f"{e}.{l}.w"), grp.grad_view(f"{e}.{l}.b")]
+                r = desc.nets[e][l]
+                gw, gb = grp.grad_view(f"{e}.{l}.w"), grp.grad_view(f"{e}.{l}.b")
+                # packed heads: split the stacked gradient back onto the individual nn.Parameters
+                ws = r.wparams if r.wparams is not None else [r.W]
+                bs = r.bparams if r.bparams is not None else [r.b]
+                o = 0
+                for w in ws:
+                    grads.append(gw[o:o + w.shape[0]].contiguous())
+                    o += w.shape[0]
+                o = 0
+                for bb in bs:
+                    grads.append(gb[o:o + bb.shape[0]].contiguous())
+                    o += bb.shape[0]
         dx = run.dx.sum(0)
         d0 = ctx.d0
         return (None, dx[:, :d0].contiguous(), dx[:, d0:].contiguous() if ctx.has_x1 else None, *grads)
@@ -82,7 +93,8 @@ def mlp_apply(desc: NetDesc, x0: torch.Tensor, x1: Optional[torch.Tensor] = None
     when the NetDesc was built from live ``nn.Parameter`` storage (pass the params for autograd)."""
     x0 = _chk(x0)
     x1 = None if x1 is None else _chk(x1)
-    params = [t for net in desc.nets for r in net for t in (r.W, r.b)]
+    params = [t for net in desc.nets for r in net
+              for t in ((r.wparams if r.wparams is not None else [r.W]) + (r.bparams if r.bparams is not None else [r.b]))]
     return _FusedMLP.apply(desc, x0, x1, *params)
 
 

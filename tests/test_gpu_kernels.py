@@ -233,3 +233,46 @@ def test_randn_and_gather():
     assert torch.equal(outs[0], tabs[0][ii]) and torch.equal(outs[1], tabs[1][ii])
     assert torch.equal(outs[2], tabs[2][ii] * 0.5)
     assert abs(ii.float().mean().item() / n_rows - 0.5) < 0.03
+
+
+def test_autograd_function_matches_torch():
+    """osrl_amd.ops.mlp_apply is a torch.autograd.Function over the HIP kernels: forward values and the
+    gradients w.r.t. inputs, weights and biases must match torch's own autograd on a CPU fp64 copy."""
+    from osrl_amd import ops
+    from osrl_amd.algorithms import CPQ
+    dev = _dev()
+    torch.manual_seed(3)
+    m = CPQ(7, 3, 1.0, [48, 32], [48, 32], 40, 3, num_q=2, num_qc=1, device=str(dev))
+    obs = torch.randn(37, 7, device=dev, requires_grad=True)
+    act = torch.randn(37, 3, device=dev, requires_grad=True)
+    for p in m.critic.parameters():
+        p.requires_grad_(True)
+    q_list = m.critic(obs, act)                      # EnsembleQCritic.forward -> fused HIP MLP
+    loss = sum((q * (i + 1.5)).pow(2).mean() for i, q in enumerate(q_list))
+    loss.backward()
+    # torch reference on CPU in fp64
+    ref_nets = []
+    for qn in m.critic.q_nets:
+        layers = []
+        for mod in qn:
+            if isinstance(mod, torch.nn.Linear):
+                l = torch.nn.Linear(mod.in_features, mod.out_features).double()
+                l.weight.data = mod.weight.data.detach().cpu().double().clone()
+                l.bias.data = mod.bias.data.detach().cpu().double().clone()
+                layers.append(l)
+            else:
+                layers.append(type(mod)())
+        ref_nets.append(torch.nn.Sequential(*layers))
+    o2 = obs.detach().cpu().double().requires_grad_(True)
+    a2 = act.detach().cpu().double().requires_grad_(True)
+    x = torch.cat([o2, a2], 1)
+    loss2 = sum((rn(x).squeeze(-1) * (i + 1.5)).pow(2).mean() for i, rn in enumerate(ref_nets))
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) < 1e-5 * max(1, abs(loss2.item()))
+    assert (obs.grad.cpu().double() - o2.grad).abs().max() < 1e-5
+    assert (act.grad.cpu().double() - a2.grad).abs().max() < 1e-5
+    for qn, rn in zip(m.critic.q_nets, ref_nets):
+        for mod, rmod in zip(qn, rn):
+            if isinstance(mod, torch.nn.Linear):
+                assert (mod.weight.grad.cpu().double() - rmod.weight.grad).abs().max() < 2e-5
+                assert (mod.bias.grad.cpu().double() - rmod.bias.grad).abs().max() < 2e-5
