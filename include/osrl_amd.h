@@ -265,8 +265,11 @@ int osrl_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* s
 int osrl_cdt_loss(const float* head, const float* logits, const float* state_pred, const float* actions,
                   const float* states, const float* mask, const float* costs, int32_t B, int32_t T, int32_t od,
                   int32_t ad, int32_t stochastic, int32_t no_entropy, const float* log_temperature, float cost_w,
-                  float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, float* dhead, float* dlogits,
-                  float* dsp, float* stat, float* ent_out, void* stream);
+                  float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, const float* counts,
+                  int32_t world, float* dhead, float* dlogits, float* dsp, float* stat, float* ent_out, void* stream);
+/* out = {#(mask > 0), sum(mask)}: the count-normalisers of cdt.py:358-359,386, to be all-reduced under data
+ * parallelism and handed to osrl_cdt_loss as `counts` (with `world` = number of equal-sized ranks). */
+int osrl_cdt_mask_counts(const float* mask, int32_t BT, float* out, void* stream);
 /* d timestep_emb[time_steps[bt]] += sum of the 4 token rows of dseq (atomic scatter) */
 int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t BT, int32_t E, float* dte,
                               void* stream);

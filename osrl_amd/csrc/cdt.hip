@@ -489,24 +489,32 @@ struct LossArgs {
   const osrl_step_state_t* st;
   int32_t B, T, od, ad, stochastic, no_entropy, warmup;
   float cost_w, state_w, lr;
+  const float* counts;  // data parallel: {global #valid tokens, global sum(mask)} (all-reduced); NULL = local
+  int32_t world;        // ranks (equal per-rank batches): every 1/(B*T) uses B*world
+  float stat_share;     // 1/world for the statistics that are already global
 };
 // stat layout: 0 nll, 1 ent, 2 ent_reg, 3 all_loss, 4 act_loss, 5 cost_loss, 6 cost_acc, 7 state_loss, 8 train_lr
 __global__ __launch_bounds__(1024) void cdt_loss_kernel(const LossArgs a) {
   __shared__ float sm[20];
   const int BT = a.B * a.T, ad = a.ad, od = a.od;
   float nvalid = 0.f, msum = 0.f;
-  for (int i = threadIdx.x; i < BT; i += 1024) {
-    nvalid += a.mask[i] > 0.f ? 1.f : 0.f;
-    msum += a.mask[i];
+  if (a.counts) {
+    nvalid = a.counts[0];
+    msum = a.counts[1];
+  } else {
+    for (int i = threadIdx.x; i < BT; i += 1024) {
+      nvalid += a.mask[i] > 0.f ? 1.f : 0.f;
+      msum += a.mask[i];
+    }
+    nvalid = block_sum1024(nvalid, sm);
+    msum = block_sum1024(msum, sm);
   }
-  nvalid = block_sum1024(nvalid, sm);
-  msum = block_sum1024(msum, sm);
   const float inv_nv = 1.0f / (fmaxf(nvalid, 1.f) * (float)ad);
   const float temp = expf(a.log_temp ? a.log_temp[0] : 0.f);
   const float ent_reg = (a.stochastic && !a.no_entropy) ? temp : 0.f;
   float ll = 0.f, ent = 0.f, act_mse = 0.f, closs = 0.f, correct = 0.f, sloss = 0.f;
-  const float inv_bt = 1.0f / (float)BT;
-  const float inv_s = (a.T > 1) ? 1.0f / ((float)a.B * (float)(a.T - 1) * (float)od) : 0.f;
+  const float inv_bt = 1.0f / ((float)BT * (float)a.world);
+  const float inv_s = (a.T > 1) ? 1.0f / ((float)a.B * (float)a.world * (float)(a.T - 1) * (float)od) : 0.f;
   for (int i = threadIdx.x; i < BT; i += 1024) {
     const float m = a.mask[i];
     const bool valid = m > 0.f;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(1024) void cdt_loss_kernel(const LossArgs a) {
     float* s = a.stat;
     s[0] = -ll;
     s[1] = ent;
-    s[2] = ent_reg;
+    s[2] = ent_reg * a.stat_share;
     s[3] = act_loss + a.cost_w * cost_loss + a.state_w * state_loss;
     s[4] = act_loss;
     s[5] = cost_loss;
@@ -571,8 +579,23 @@ __global__ __launch_bounds__(1024) void cdt_loss_kernel(const LossArgs a) {
     s[7] = state_loss;
     // scheduler.get_last_lr() AFTER scheduler.step(): the factor of the NEXT optimizer step  cdt.py:409,417
     const double tn = (double)(a.st->step + 1);
-    s[8] = a.lr * (a.warmup > 0 ? (float)fmin(tn / (double)a.warmup, 1.0) : 1.0f);
+    s[8] = a.stat_share * a.lr * (a.warmup > 0 ? (float)fmin(tn / (double)a.warmup, 1.0) : 1.0f);
     if (a.ent_out) a.ent_out[0] = ent;
+  }
+}
+
+__global__ __launch_bounds__(1024) void mask_counts_kernel(const float* __restrict__ mask, int BT, float* out) {
+  __shared__ float sm[20];
+  float nvalid = 0.f, msum = 0.f;
+  for (int i = threadIdx.x; i < BT; i += 1024) {
+    nvalid += mask[i] > 0.f ? 1.f : 0.f;
+    msum += mask[i];
+  }
+  nvalid = block_sum1024(nvalid, sm);
+  msum = block_sum1024(msum, sm);
+  if (threadIdx.x == 0) {
+    out[0] = nvalid;
+    out[1] = msum;
   }
 }
 
@@ -717,15 +740,23 @@ int osrl_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* s
 int osrl_cdt_loss(const float* head, const float* logits, const float* state_pred, const float* actions,
                   const float* states, const float* mask, const float* costs, int32_t B, int32_t T, int32_t od,
                   int32_t ad, int32_t stochastic, int32_t no_entropy, const float* log_temperature, float cost_w,
-                  float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, float* dhead, float* dlogits,
-                  float* dsp, float* stat, float* ent_out, void* stream) {
+                  float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, const float* counts,
+                  int32_t world, float* dhead, float* dlogits, float* dsp, float* stat, float* ent_out, void* stream) {
   if (!head || !logits || !state_pred || !actions || !states || !mask || !costs || !st || !dhead || !dlogits || !dsp ||
       !stat || B < 1 || T < 1)
     return -1;
   LossArgs a{head, logits, state_pred, actions, states, mask, costs, dhead, dlogits, dsp, stat, ent_out,
-             log_temperature, st, B, T, od, ad, stochastic, no_entropy, warmup, cost_w, state_w, lr};
+             log_temperature, st, B, T, od, ad, stochastic, no_entropy, warmup, cost_w, state_w, lr, counts,
+             world > 0 ? world : 1, 1.0f / (float)(world > 0 ? world : 1)};
   CLEAR();
   hipLaunchKernelGGL(cdt_loss_kernel, dim3(1), dim3(1024), 0, S, a);
+  DONE();
+}
+
+int osrl_cdt_mask_counts(const float* mask, int32_t BT, float* out, void* stream) {
+  if (!mask || !out || BT < 1) return -1;
+  CLEAR();
+  hipLaunchKernelGGL(mask_counts_kernel, dim3(1), dim3(1024), 0, S, mask, BT, out);
   DONE();
 }
 

@@ -25,9 +25,10 @@ def _r16(x: int) -> int:
 
 
 class CDTEngine:
-    def __init__(self, model, batch_size: int, trainer_cfg: dict):
+    def __init__(self, model, batch_size: int, trainer_cfg: dict, dist=None):
         m = self.model = model
         self.cfg = trainer_cfg
+        self.dist = dist
         B, T, E, H, NL = int(batch_size), m.seq_len, m.embedding_dim, m.num_heads, m.num_layers
         self.B, self.T, self.E, self.H, self.NL = B, T, E, H, NL
         od, ad = m.state_dim, m.action_dim
@@ -78,6 +79,8 @@ class CDTEngine:
         self.ln_ws = z(self.n_parts, 2 * E)
         self.clip_ws, self.clip_out = z(1024), z(4)
         self.temp_mv = z(2)
+        self.counts = z(4)
+        self._graph_failed = False
 
         # dW plans
         tok, bt = [], []
@@ -191,13 +194,18 @@ class CDTEngine:
             self.store.gather(self.states, self.actions, self.returns, self.ctg, self.time_steps, self.mask,
                               self.episode_cost, self.costs, st.ptr)
         self.forward()
+        counts, world = None, 1
+        if self.dist is not None:  # count-normalisers over the GLOBAL batch
+            L.check(lib.osrl_cdt_mask_counts(self.mask.data_ptr(), BT, self.counts.data_ptr(), cur_stream()), "counts")
+            self.dist.all_reduce_(self.counts)
+            counts, world = self.counts.data_ptr(), self.dist.world
         L.check(lib.osrl_cdt_loss(self.head.data_ptr(), self.logits.data_ptr(), self.sp.data_ptr(),
                                   self.actions.data_ptr(), self.states.data_ptr(), self.mask.data_ptr(),
                                   self.costs.data_ptr(), self.B, self.T, m.state_dim, m.action_dim,
                                   1 if m.stochastic else 0, 1 if cfg["no_entropy"] else 0,
                                   m.log_temperature.data_ptr() if m.stochastic else None, cfg["loss_cost_weight"],
                                   cfg["loss_state_weight"], cfg["learning_rate"], cfg["lr_warmup_steps"], st.ptr,
-                                  self.dhead.data_ptr(), self.dlogits.data_ptr(), self.dsp.data_ptr(),
+                                  counts, world, self.dhead.data_ptr(), self.dlogits.data_ptr(), self.dsp.data_ptr(),
                                   st.stats.data_ptr(), self.ent.data_ptr(), cur_stream()), "osrl_cdt_loss")
         # ---- backward: heads -> dout (only the state / action token rows are non-zero)
         self.dout.zero_()
@@ -232,6 +240,9 @@ class CDTEngine:
         L.check(lib.osrl_reduce_slabs(g.slabs.data_ptr(), g.slabs.data_ptr(), g.cur_splits, g.n, g.n, cur_stream()),
                 "osrl_reduce_slabs")
         g.cur_splits = 1
+        if self.dist is not None:  # ONE all-reduce of the flat gradient; the clip norm is of the reduced gradient
+            self.dist.all_reduce_(g.slabs[0])
+            self.dist.all_reduce_(self.ent)
         clip = cfg["clip_grad"]
         gscale = None
         if clip is not None:
@@ -244,6 +255,8 @@ class CDTEngine:
             L.check(lib.osrl_cdt_temperature_step(m.log_temperature.data_ptr(), self.temp_mv.data_ptr(),
                                                   self.ent.data_ptr(), float(m.target_entropy), 1e-4, 0.9, 0.999, 1e-8,
                                                   st.ptr, cur_stream()), "osrl_cdt_temperature_step")
+        if self.dist is not None:
+            self.dist.all_reduce_(st.stats)
 
     def load_batch(self, states, actions, returns, costs_return, time_steps, mask, costs) -> None:
         cp = lambda d, s: d.copy_(torch.as_tensor(s).reshape(d.shape), non_blocking=True)  # noqa: E731
@@ -271,13 +284,22 @@ class CDTEngine:
         self._go(use_graph)
 
     def _go(self, use_graph: bool) -> None:
-        if use_graph:
+        if use_graph and not self._graph_failed:
             if self.graph is None:
-                self._capture()
-            self.graph.replay()
-            self.st.host_step += 1
-        else:
-            self.body()
+                try:
+                    self._capture()
+                except Exception as e:  # pragma: no cover - depends on the RCCL build
+                    if self.dist is None:
+                        raise
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the data-parallel CDT step failed ({e!r}); running eagerly")
+                    torch.cuda.synchronize()
+                    self._graph_failed, self.graph = True, None
+            if self.graph is not None:
+                self.graph.replay()
+                self.st.host_step += 1
+                return
+        self.body()
 
     def _capture(self) -> None:
         m, g = self.model, self.g

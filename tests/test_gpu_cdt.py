@@ -194,3 +194,39 @@ def test_cdt_graph_replay_matches_eager():
             assert torch.equal(res[0][k], res[1][k])
         else:  # the timestep-embedding scatter uses fp32 atomics: order-dependent rounding only
             assert (res[0][k] - res[1][k]).abs().max() < 1e-6, k
+
+
+def test_cdt_data_parallel_world1_matches_single():
+    """CDT DP wiring (global count normalisers, flat-gradient all-reduce before the clip, entropy/stat reductions,
+    hipGraph capture incl. RCCL) as a 1-rank NCCL job == the plain single-GPU step."""
+    import os
+    import torch.distributed as dist
+    from osrl_amd.engine.dist import DataParallel
+    c = CDT_CASES["cdt_small"]
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29300 + os.getpid() % 500))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        res = []
+        for mode in ("single", "dp_eager", "dp_graph"):
+            m, tr, lg = build_cdt_gpu(c, use_graph=(mode == "dp_graph"))
+            if mode != "single":
+                m.engine(c.B, tr.cfg, dist=DataParallel())
+            b = {k: t(v) for k, v in make_cdt_batch(c).items()}
+            for s in range(3):
+                tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
+                                  b["mask"], b["episode_cost"], b["costs"])
+            torch.cuda.synchronize()
+            res.append(({k: v.clone() for k, v in m.state_dict().items()}, {k: [float(x) for x in v] for k, v in lg.data.items()}))
+        for other in res[1:]:
+            for k in res[0][0]:
+                if res[0][0][k].dtype != torch.bool:
+                    assert (res[0][0][k] - other[0][k]).abs().max() < 1e-6, k
+            for k in res[0][1]:
+                assert np.allclose(res[0][1][k], other[1][k], rtol=1e-5, atol=1e-6), k
+    finally:
+        if created:
+            dist.destroy_process_group()
