@@ -228,10 +228,15 @@ int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_sam
                          int32_t n_on, const float* base, const float* done, int32_t rows, float gamma,
                          float lmbda, int32_t rows_global, float* dq, float* stat, void* stream);
 /* BCQ-Lag actor loss (bcql.py:190-198 + PID net.py:376-387).  q/qc = [n1+n2][rows] (q1 nets then q2 nets).
- * pid = device {error_old, error_integral}; stat: [0]=loss [1]=qc_penalty [2]=multiplier. */
+ * pid = device {error_old, error_integral}; stat: [0]=loss [1]=qc_penalty [2]=multiplier.
+ * Data parallel: global_means = all-reduced {mean q_pi, mean qc_pi} from osrl_bcq_actor_sums (NULL = compute
+ * locally), stat_share = 1/world. */
+int osrl_bcq_actor_sums(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
+                        int32_t rows, int32_t rows_global, float* out, void* stream);
 int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
                         int32_t rows, float qc_thres, float KP, float KI, float KD, int32_t rows_global,
-                        float* pid, float* dq, float* dqc, float* stat, void* stream);
+                        const float* global_means, float stat_share, float* pid, float* dq, float* dqc, float* stat,
+                        void* stream);
 
 /* ---- CDT (cdt.hip): the non-GEMM pieces of the Constrained Decision Transformer step ---- */
 /* Token embeddings + timestep embedding, (return, cost, state, action) interleave and emb LayerNorm

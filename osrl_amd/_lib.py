@@ -98,8 +98,9 @@ PROTOTYPES = {
     "osrl_bcq_perturb": [_fp, _fp, _i32, _i32, _f32, _f32, _fp, _vp],
     "osrl_bcq_perturb_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _fp, _vp],
     "osrl_bcq_critic_loss": [_fp, _i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
-    "osrl_bcq_actor_loss": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _fp, _fp, _fp,
-                            _fp, _vp],
+    "osrl_bcq_actor_sums": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _fp, _vp],
+    "osrl_bcq_actor_loss": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _fp, _f32, _fp, _fp,
+                            _fp, _fp, _vp],
     "osrl_cdt_embed_ln": [_fp, _fp, _fp, _fp, _vp] + [_fp] * 11 + [_i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _vp],
     "osrl_layernorm_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _vp],
     "osrl_layernorm_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],

@@ -472,14 +472,12 @@ __device__ __forceinline__ float minmin(const float* __restrict__ q, int n1, int
   return fminf(m1, m2);
 }
 
-__global__ __launch_bounds__(kRed) void bcq_actor_loss_kernel(const float* __restrict__ q, int nq1, int nq2,
-                                                              const float* __restrict__ qc, int nc1, int nc2,
-                                                              int rows, float qc_thres, float KP, float KI, float KD,
-                                                              float inv_rows, float* __restrict__ pid,
-                                                              float* __restrict__ dq, float* __restrict__ dqc,
-                                                              float* __restrict__ stat) {
+// local sums of q_pi and qc_pi over the rows, pre-divided by the GLOBAL batch (data-parallel pre-pass of the
+// actor loss: the PID controller needs the global mean of qc_pi before any gradient is formed)
+__global__ __launch_bounds__(kRed) void bcq_actor_sums_kernel(const float* __restrict__ q, int nq1, int nq2,
+                                                              const float* __restrict__ qc, int nc1, int nc2, int rows,
+                                                              float inv_rows, float* __restrict__ out) {
   __shared__ float sm[20];
-  __shared__ float s_mult;
   float sq = 0.f, sqc = 0.f;
   int i1, i2;
   float w1;
@@ -490,8 +488,37 @@ __global__ __launch_bounds__(kRed) void bcq_actor_loss_kernel(const float* __res
   sq = block_sum(sq, sm);
   sqc = block_sum(sqc, sm);
   if (threadIdx.x == 0) {
+    out[0] = sq * inv_rows;
+    out[1] = sqc * inv_rows;
+  }
+}
+
+__global__ __launch_bounds__(kRed) void bcq_actor_loss_kernel(const float* __restrict__ q, int nq1, int nq2,
+                                                              const float* __restrict__ qc, int nc1, int nc2,
+                                                              int rows, float qc_thres, float KP, float KI, float KD,
+                                                              float inv_rows, const float* __restrict__ means_in,
+                                                              float stat_share, float* __restrict__ pid,
+                                                              float* __restrict__ dq, float* __restrict__ dqc,
+                                                              float* __restrict__ stat) {
+  __shared__ float sm[20];
+  __shared__ float s_mult;
+  float sq = 0.f, sqc = 0.f;
+  int i1, i2;
+  float w1;
+  if (!means_in) {
+    for (int b = threadIdx.x; b < rows; b += kRed) {
+      sq += minmin(q, nq1, nq2, rows, b, &i1, &i2, &w1);
+      sqc += minmin(qc, nc1, nc2, rows, b, &i1, &i2, &w1);
+    }
+    sq = block_sum(sq, sm) * inv_rows;
+    sqc = block_sum(sqc, sm) * inv_rows;
+  } else {  // all-reduced global means
+    sq = means_in[0];
+    sqc = means_in[1];
+  }
+  if (threadIdx.x == 0) {
     // LagrangianPIDController.control  net.py:376-387
-    const float e_new = sqc * inv_rows - qc_thres;
+    const float e_new = sqc - qc_thres;
     const float e_old = pid[0], integ = pid[1];
     const float diff = fmaxf(e_new - e_old, 0.f);
     const float integ_new = fmaxf(integ + e_new, 0.f);
@@ -499,11 +526,11 @@ __global__ __launch_bounds__(kRed) void bcq_actor_loss_kernel(const float* __res
     pid[1] = integ_new;
     const float mult = fmaxf(KP * fmaxf(e_new, 0.f) + KI * integ_new + KD * diff, 0.f);
     s_mult = mult;
-    const float penalty = (sqc * inv_rows - qc_thres) * mult;  // mean((qc_pi - thres)*mult)
+    const float penalty = (sqc - qc_thres) * mult;  // mean((qc_pi - thres)*mult)
     if (stat) {
-      stat[0] = -sq * inv_rows + penalty;
-      stat[1] = penalty;
-      stat[2] = mult;
+      stat[0] = (-sq + penalty) * stat_share;
+      stat[1] = penalty * stat_share;
+      stat[2] = mult * stat_share;
     }
   }
   __syncthreads();
@@ -673,13 +700,24 @@ int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_sam
   LAUNCH_CHECK();
 }
 
+int osrl_bcq_actor_sums(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
+                        int32_t rows, int32_t rows_global, float* out, void* stream) {
+  if (!q || !qc || !out || rows < 1) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(bcq_actor_sums_kernel, dim3(1), dim3(kRed), 0, S, q, nq1, nq2, qc, nc1, nc2, rows,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), out);
+  LAUNCH_CHECK();
+}
+
 int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
                         int32_t rows, float qc_thres, float KP, float KI, float KD, int32_t rows_global,
-                        float* pid, float* dq, float* dqc, float* stat, void* stream) {
+                        const float* global_means, float stat_share, float* pid, float* dq, float* dqc, float* stat,
+                        void* stream) {
   if (!q || !qc || !pid || !dq || !dqc || rows < 1) return -1;
-  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  (void)hipGetLastError();
   hipLaunchKernelGGL(bcq_actor_loss_kernel, dim3(1), dim3(kRed), 0, S, q, nq1, nq2, qc, nc1, nc2, rows, qc_thres,
-                     KP, KI, KD, 1.0f / (float)(rows_global > 0 ? rows_global : rows), pid, dq, dqc, stat);
+                     KP, KI, KD, 1.0f / (float)(rows_global > 0 ? rows_global : rows), global_means, stat_share, pid, dq,
+                     dqc, stat);
   LAUNCH_CHECK();
 }
 

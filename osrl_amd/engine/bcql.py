@@ -30,9 +30,6 @@ class BCQLEngine:
         dev = torch.device(m.device)
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc = m.num_q, m.num_qc
-        if dist is not None:
-            raise NotImplementedError("BCQ-Lag data parallelism is not wired yet: the PID controller needs the "
-                                      "global mean of qc_pi before the loss gradient (SURVEY.md 8e item 2)")
         if 2 * nq + 2 * nqc > L.MAX_NETS:
             raise ValueError(f"2*num_q + 2*num_qc = {2 * nq + 2 * nqc} > {L.MAX_NETS} nets per fused launch")
         f = dict(dtype=torch.float32, device=dev)
@@ -91,6 +88,7 @@ class BCQLEngine:
         self.dq_pi = z(2 * nq + 2 * nqc, B, 1)
         self.r_pi_q.setup_backward(self.dq_pi, need_dz=False, dx_cols=(od, ad))
         self.dt = z(1, B, ad)
+        self.pi_means = z(4)
         self.r_actor.setup_backward(self.dt)
         self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -150,12 +148,19 @@ class BCQLEngine:
         t = self.r_actor.forward(self.obs, dec)[0]
         G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
+        means, share = None, 1.0
+        if self.dist is not None:  # the PID controller acts on the GLOBAL mean of qc_pi
+            G.bcq_actor_sums(y[:2 * nq], nq, nq, y[2 * nq:], nqc, nqc, B, rg, self.pi_means)
+            self.dist.all_reduce_(self.pi_means)
+            means, share = self.pi_means, 1.0 / self.dist.world
         G.bcq_actor_loss(y[:2 * nq], nq, nq, y[2 * nq:], nqc, nqc, B, m.qc_thres, m.KP, m.KI, m.KD, rg, m.pid_state,
-                         self.dq_pi[:2 * nq], self.dq_pi[2 * nq:], st.stat_ptr("loss/actor_loss"))
+                         self.dq_pi[:2 * nq], self.dq_pi[2 * nq:], st.stat_ptr("loss/actor_loss"), means, share)
         self.r_pi_q.backward_dz()
         G.bcq_perturb_bwd(dec, t, self.r_pi_q.dx, 2 * nq + 2 * nqc, B, ad, m.phi, m.max_action, self.dt)
         self.r_actor.backward_dz()
         self._optim("actor", self.p_actor, m.tau)
+        if self.dist is not None:
+            self.dist.all_reduce_(st.stats)
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
         for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),

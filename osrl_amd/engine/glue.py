@@ -101,9 +101,16 @@ def bcq_critic_loss(q_t, n1, n2, n_samples, q_on, n_on, base, done, rows, gamma,
             "osrl_bcq_critic_loss")
 
 
-def bcq_actor_loss(q, nq1, nq2, qc, nc1, nc2, rows, qc_thres, KP, KI, KD, rows_global, pid, dq, dqc, stat):
+def bcq_actor_sums(q, nq1, nq2, qc, nc1, nc2, rows, rows_global, out):
+    L.check(L.load().osrl_bcq_actor_sums(_p(q), nq1, nq2, _p(qc), nc1, nc2, rows, rows_global, _p(out), cur_stream()),
+            "osrl_bcq_actor_sums")
+
+
+def bcq_actor_loss(q, nq1, nq2, qc, nc1, nc2, rows, qc_thres, KP, KI, KD, rows_global, pid, dq, dqc, stat,
+                   global_means=None, stat_share=1.0):
     L.check(L.load().osrl_bcq_actor_loss(_p(q), nq1, nq2, _p(qc), nc1, nc2, rows, qc_thres, KP, KI, KD, rows_global,
-                                         _p(pid), _p(dq), _p(dqc), _p(stat), cur_stream()), "osrl_bcq_actor_loss")
+                                         _p(global_means), stat_share, _p(pid), _p(dq), _p(dqc), _p(stat),
+                                         cur_stream()), "osrl_bcq_actor_loss")
 
 
 def clamp_(x, lo, hi):

@@ -52,14 +52,15 @@ def test_train_step_matches_golden_and_oracle(name):
         assert d <= 1e-4, f"{name} final param {k} vs oracle: {d:.3e}"
     # act()
     bb = make_batch(c)
-    if c.algo == "bc":
-        a = m.actor(b["observations"]).cpu().numpy()
-    elif c.algo == "cpq":
-        from osrl_amd import ops
-        a = ops.cpq_act(m, b["observations"], True)[0].cpu().numpy()
-    else:
-        z = torch.from_numpy(g["act_z"]).to(b["observations"].device).clamp(-0.5, 0.5)
-        a = m.actor(b["observations"], m.vae.decode(b["observations"], z)).cpu().numpy()
+    with torch.no_grad():
+        if c.algo == "bc":
+            a = m.actor(b["observations"]).cpu().numpy()
+        elif c.algo == "cpq":
+            from osrl_amd import ops
+            a = ops.cpq_act(m, b["observations"], True)[0].cpu().numpy()
+        else:
+            z = torch.from_numpy(g["act_z"]).to(b["observations"].device).clamp(-0.5, 0.5)
+            a = m.actor(b["observations"], m.vae.decode(b["observations"], z)).cpu().numpy()
     assert np.abs(a - g["act"]).max() <= 1e-4
     print(f"{name}: worst stat diff {worst:.3e}")
 
@@ -189,6 +190,39 @@ def test_data_parallel_graph_capture_world1():
             print("DP graph captured:", eng.graph is not None)
         for k in outs[0]:
             assert torch.equal(outs[0][k], outs[1][k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["bcql_pid", "bc_small"])
+def test_data_parallel_world1_other_algos(name):
+    """BCQ-Lag (global PID mean pre-pass) and BC under the DP hook as a 1-rank NCCL job == single GPU."""
+    import os
+    import torch.distributed as dist
+    from osrl_amd.engine.dist import DataParallel
+    c = CASES[name]
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29350 + os.getpid() % 500))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        res = []
+        for use_dp in (False, True):
+            m, tr, lg = build_gpu(c)
+            b = gpu_batch(c)
+            if use_dp:
+                m.engine(c.B, rows_global=c.B, dist=DataParallel())
+            for s in range(3):
+                gpu_step(tr, c, b, s)
+            torch.cuda.synchronize()
+            res.append(({k: v.clone() for k, v in m.state_dict().items()}, {k: [float(x) for x in v] for k, v in lg.data.items()}))
+        for k in res[0][0]:
+            assert torch.equal(res[0][0][k], res[1][0][k]), k
+        for k in res[0][1]:
+            assert np.allclose(res[0][1][k], res[1][1][k], rtol=1e-6, atol=1e-7), k
     finally:
         if created:
             dist.destroy_process_group()
