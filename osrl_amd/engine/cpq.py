@@ -138,11 +138,19 @@ class CPQEngine:
         if device_noise:
             randn_fill(self.noise_flat, self.seed, 0, st.ptr)
 
-        # ---- branch 0: critic_loss  (cpq.py:137-153)
+        # ---- side branch (ONE side stream: the runtime runs two graph branches concurrently, see
+        # profiles/r1_timeline.txt): first everything of cost_critic_loss (cpq.py:155-176) that needs neither
+        # the new VAE nor a reduction -- so the N*B sampled actions exist early -- then critic_loss (cpq.py:137-153).
         par.fork(0)
         with par.on(0):
             head_next = self.r_actor_next.forward(self.nobs)[0]
-            par.fork(1, after=0)  # branch 1 needs head_next
+            G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+            qc_old_next = self.r_costold_next.forward(self.nobs, self.a_next2)
+            head_obs = self.r_actor_obs.forward(self.obs)[0]
+            G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
+            ev_sampled = par.mark(0)
+            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+            qc = self.r_cost.forward(self.obs, self.act)
             G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
             y_old = self.r_old_next.forward(self.nobs, self.a_next)
             q = self.r_critic.forward(self.obs, self.act)
@@ -150,16 +158,6 @@ class CPQEngine:
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
             self._optim("critic", self.p_critic, m.tau)
-
-        # ---- branch 1: everything of cost_critic_loss that needs neither the new VAE nor a reduction
-        with par.on(1):
-            G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
-            qc_old_next = self.r_costold_next.forward(self.nobs, self.a_next2)
-            head_obs = self.r_actor_obs.forward(self.obs)[0]
-            G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
-            ev_sampled = par.mark(1)
-            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
-            qc = self.r_cost.forward(self.obs, self.act)
 
         # ---- main: vae_loss  (cpq.py:125-135)
         head = self.r_enc.forward(self.obs, self.act)[0]
@@ -179,7 +177,7 @@ class CPQEngine:
             self.dist.quantile(self.kl, 0.75, self.quant)
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
-        par.join(1)
+        par.join(0)  # side branch done (it also reads cost_critic_old, which the next optimizer step updates)
         G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
         share = 1.0
         if self.dist is not None:
@@ -188,7 +186,6 @@ class CPQEngine:
         G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg,
                         share, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
-        par.join(0)  # the critic branch reads cost_critic_old, which the next optimizer step updates
         self._optim("cost_critic", self.p_cost, m.tau)
 
         # ---- actor_loss  (cpq.py:203-222)
@@ -219,7 +216,7 @@ class CPQEngine:
         side stream as torch requires; the model state they advance is restored afterwards."""
         snap = self._snapshot()
         # collectives stay on the capture stream: no forked branches in the data-parallel graph
-        par = Branches(self.parallel_branches and self.dist is None, 2)
+        par = Branches(self.parallel_branches and self.dist is None, 1)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
