@@ -324,9 +324,12 @@ __global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restr
   const int nr = n_samples * rows;
   for (int b = threadIdx.x; b < rows; b += kRed) {
     float s = 0.f;
+    // unconditional loads (no branch on kl) so the N sample loads of a row are all in flight at once
+#pragma unroll 5
     for (int j = 0; j < n_samples; ++j) {
       const int i = j * rows + b;
-      if (kl[i] >= quant) s += min_over(qc_sampled, n_qc_old, nr, i);
+      const float v = min_over(qc_sampled, n_qc_old, nr, i);
+      s += kl[i] >= quant ? v : 0.f;
     }
     ood += s / (float)n_samples;
   }

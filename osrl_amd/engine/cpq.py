@@ -138,10 +138,21 @@ class CPQEngine:
         if device_noise:
             randn_fill(self.noise_flat, self.seed, 0, st.ptr)
 
+        par.fork(0)  # the side stream may start here; its launches are issued after the VAE phase's so the
+        # graph executor (which dispatches nodes in creation order) starts both branches at once
+        # ---- main: vae_loss  (cpq.py:125-135)
+        head = self.r_enc.forward(self.obs, self.act)[0]
+        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        u = self.r_dec.forward(self.obs, self.z)[0]
+        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+        self.r_dec.backward_dz()
+        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        self.r_enc.backward_dz()
+        self._optim("vae", self.p_vae, 0.0)
+
         # ---- side branch (ONE side stream: the runtime runs two graph branches concurrently, see
         # profiles/r1_timeline.txt): first everything of cost_critic_loss (cpq.py:155-176) that needs neither
         # the new VAE nor a reduction -- so the N*B sampled actions exist early -- then critic_loss (cpq.py:137-153).
-        par.fork(0)
         with par.on(0):
             head_next = self.r_actor_next.forward(self.nobs)[0]
             G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
@@ -158,16 +169,6 @@ class CPQEngine:
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
             self._optim("critic", self.p_critic, m.tau)
-
-        # ---- main: vae_loss  (cpq.py:125-135)
-        head = self.r_enc.forward(self.obs, self.act)[0]
-        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
-        u = self.r_dec.forward(self.obs, self.z)[0]
-        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        self.r_dec.backward_dz()
-        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
-        self.r_enc.backward_dz()
-        self._optim("vae", self.p_vae, 0.0)
 
         # ---- cost_critic_loss  (cpq.py:155-201): OOD scoring with the UPDATED vae
         par.wait(ev_sampled)
