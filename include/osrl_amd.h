@@ -99,6 +99,15 @@ typedef struct {
   float pad_;
 } osrl_step_state_t;
 
+/* One dropout site (HOST struct, read at launch): probability, site id (unique per nn.Dropout call site and
+ * layer), generator seed, and the device step state whose `step` decorrelates successive train steps. */
+typedef struct {
+  float p;
+  uint32_t site;
+  uint64_t seed;
+  const osrl_step_state_t* st;
+} osrl_dropout_t;
+
 /* ---- fused MLP (mlp.hip): replaces nn.Sequential(Linear,act,...) forward + its autograd ---- */
 /* lds_bytes / tile selection are internal; rows may be any value >= 1. */
 int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, void* stream);
@@ -258,9 +267,16 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
 /* nn.MultiheadAttention core with the block's causal mask and key padding (net.py:417-435): qkv [B,S,3E] (q|k|v,
  * heads split the E axis contiguously), mask [B, S/rep] (1 = valid timestep, each repeated rep times along S). */
 int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S, int32_t E, int32_t H, int32_t rep,
-                       float* o, void* stream);
+                       const osrl_dropout_t* drop, float* o, void* stream);
 int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S, int32_t E,
-                       int32_t H, int32_t rep, float* dqkv, void* stream);
+                       int32_t H, int32_t rep, const osrl_dropout_t* drop, float* dqkv, void* stream);
+/* nn.Dropout in training mode (cdt.py:87,222 embedding; net.py:404,439 residual; net.py:414 MLP tail):
+ * y[i] = x[i] * keep_i / (1-p), may run in place.  keep_i is a pure function of (seed, st->step, site, i)
+ * (Philox4x32-10), so calling it again on the incoming gradient IS the backward pass; nothing is stored.
+ * `drop` of the attention entry points is the attention-probability dropout of nn.MultiheadAttention
+ * (net.py:406-409), NULL or p = 0 = off; its logical mask layout is [B*H, S, 16, 8] with element
+ * ((bh*S + i)*16 + j%16)*8 + j/16 <-> P[bh][i][j], so osrl_dropout on a ones tensor of that size exports it. */
+int osrl_dropout(const float* x, float* y, int64_t n, const osrl_dropout_t* drop, void* stream);
 /* nn.GELU() (exact erf) and its derivative; n a multiple of 4 */
 int osrl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int osrl_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);

@@ -9,7 +9,9 @@ Restates, in numpy with a hand-derived backward pass:
                                      + temperature Adam)
 Supported configuration = the reference's train defaults (examples/configs/cdt_configs.py:22-89):
 time_emb, use_rew, use_cost, optional cost_transform, action_head_layers=1, no cost-feature variants, no
-cost prefix, stochastic or deterministic head, dropout 0 (parity) .
+cost prefix, stochastic or deterministic head.  Dropout: the caller passes the keep-multipliers (0 or 1/(1-p)) of
+every nn.Dropout site explicitly (``drop``: 'emb' [B,S,E]; per layer 'attn{l}' [B,H,S,S], 'res1_{l}', 'res2_{l}'
+[B,S,E]); ``None`` = eval mode / p = 0.
 """
 from __future__ import annotations
 
@@ -71,7 +73,9 @@ class OracleCDT:
         self.steps = 0
 
     # ------------------------------------------------------------------ forward
-    def forward(self, states, actions, returns, costs_to_go, time_steps, mask):
+    def forward(self, states, actions, returns, costs_to_go, time_steps, mask, drop=None):
+        drop = drop or {}
+        one = self.dtype(1.0)
         p, E, H = self.p, self.E, self.H
         B, T, _ = states.shape
         S = 4 * T
@@ -85,6 +89,7 @@ class OracleCDT:
         a_e = actions @ p["action_emb.weight"].T + p["action_emb.bias"] + te
         seq = np.stack([r_e, c_e, s_e, a_e], 2).reshape(B, S, E)  # (r,c,s,a) per timestep  cdt.py:185-200
         x, c["ln_emb"] = layer_norm(seq, p["emb_norm.weight"], p["emb_norm.bias"])
+        x = x * drop.get("emb", one)  # emb_drop  cdt.py:222
         key_pad = np.repeat(mask <= 0, 4, axis=1)  # [B,S] True = ignore  cdt.py:202-205
         causal = np.triu(np.ones((S, S), bool), 1)  # True = blocked  net.py:417-418
         blocked = causal[None, None] | key_pad[:, None, None, :]
@@ -101,14 +106,15 @@ class OracleCDT:
             sc = sc - sc.max(-1, keepdims=True)
             P = np.exp(sc)
             P = P / P.sum(-1, keepdims=True)
-            o = (P @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
+            Pd = P * drop.get(f"attn{l}", one)  # attention-probability dropout inside nn.MultiheadAttention
+            o = (Pd @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
             att = o @ p[pre + "attention.out_proj.weight"].T + p[pre + "attention.out_proj.bias"]
-            x = x + att
+            x = x + att * drop.get(f"res1_{l}", one)  # net.py:439
             n2, bc["ln2"] = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
             hpre = n2 @ p[pre + "mlp.0.weight"].T + p[pre + "mlp.0.bias"]
             h = gelu(hpre)
-            x = x + h @ p[pre + "mlp.2.weight"].T + p[pre + "mlp.2.bias"]
-            bc.update(n1=n1, q=q, k=k, v=v, P=P, o=o, n2=n2, hpre=hpre, h=h)
+            x = x + (h @ p[pre + "mlp.2.weight"].T + p[pre + "mlp.2.bias"]) * drop.get(f"res2_{l}", one)  # net.py:414
+            bc.update(n1=n1, q=q, k=k, v=v, P=P, Pd=Pd, o=o, n2=n2, hpre=hpre, h=h)
             c["blocks"].append(bc)
         out, c["ln_out"] = layer_norm(x, p["out_norm.weight"], p["out_norm.bias"])
         out4 = out.reshape(B, T, 4, E)
@@ -133,8 +139,11 @@ class OracleCDT:
         return res["mu"] if self.stochastic else res["act"]
 
     # ------------------------------------------------------------------ one train step
-    def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs):
+    def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs,
+                       drop=None):
         dt = self.dtype
+        drop = {k: np.asarray(v, dt) for k, v in (drop or {}).items()}
+        one = dt(1.0)
         states, actions, returns, costs_return, mask = (np.asarray(a, dt) for a in
                                                         (states, actions, returns, costs_return, mask))
         time_steps = np.asarray(time_steps, np.int64)
@@ -143,7 +152,7 @@ class OracleCDT:
         B, T, od = states.shape
         ad = actions.shape[-1]
         S, d = 4 * T, E // H
-        res, c = self.forward(states, actions, returns, costs_return, time_steps, mask)
+        res, c = self.forward(states, actions, returns, costs_return, time_steps, mask, drop)
         valid = mask > 0
         nv = max(int(valid.sum()), 1) * ad
         stats = {}
@@ -204,7 +213,7 @@ class OracleCDT:
         # ---- blocks backward
         for l in range(self.NL - 1, -1, -1):
             pre, bc = f"blocks.{l}.", c["blocks"][l]
-            dm = dx  # x = x + mlp(n2)
+            dm = dx * drop.get(f"res2_{l}", one)  # x = x + drop(mlp(n2))
             g[pre + "mlp.2.weight"] = f2(dm).T @ f2(bc["h"])
             g[pre + "mlp.2.bias"] = f2(dm).sum(0)
             dh = dm @ p[pre + "mlp.2.weight"]
@@ -214,13 +223,13 @@ class OracleCDT:
             dn2 = dhpre @ p[pre + "mlp.0.weight"]
             d2, g[pre + "norm2.weight"], g[pre + "norm2.bias"] = layer_norm_bwd(dn2, bc["ln2"], p[pre + "norm2.weight"])
             dx = dx + d2
-            datt = dx  # x = x + att
+            datt = dx * drop.get(f"res1_{l}", one)  # x = x + drop(att)
             g[pre + "attention.out_proj.weight"] = f2(datt).T @ f2(bc["o"])
             g[pre + "attention.out_proj.bias"] = f2(datt).sum(0)
             do = (datt @ p[pre + "attention.out_proj.weight"]).reshape(B, S, H, d).transpose(0, 2, 1, 3)
             P, q, k, v = bc["P"], bc["q"], bc["k"], bc["v"]
-            dP = do @ v.transpose(0, 1, 3, 2)
-            dv = P.transpose(0, 1, 3, 2) @ do
+            dP = (do @ v.transpose(0, 1, 3, 2)) * drop.get(f"attn{l}", one)
+            dv = bc["Pd"].transpose(0, 1, 3, 2) @ do
             dS = P * (dP - (dP * P).sum(-1, keepdims=True))
             dq = dS @ k / math.sqrt(d)
             dk = dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
@@ -231,7 +240,8 @@ class OracleCDT:
             d1, g[pre + "norm1.weight"], g[pre + "norm1.bias"] = layer_norm_bwd(dn1, bc["ln1"], p[pre + "norm1.weight"])
             dx = dx + d1
         # ---- embeddings backward
-        dseq, g["emb_norm.weight"], g["emb_norm.bias"] = layer_norm_bwd(dx, c["ln_emb"], p["emb_norm.weight"])
+        dseq, g["emb_norm.weight"], g["emb_norm.bias"] = layer_norm_bwd(dx * drop.get("emb", one), c["ln_emb"],
+                                                                        p["emb_norm.weight"])
         d4 = dseq.reshape(B, T, 4, E)
         dr, dc, ds, da = d4[:, :, 0], d4[:, :, 1], d4[:, :, 2], d4[:, :, 3]
         g["return_emb.weight"] = (f2(dr) * returns.reshape(-1, 1)).sum(0)[:, None]

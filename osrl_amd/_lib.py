@@ -58,6 +58,10 @@ class PackEntryT(C.Structure):
                 ("out", C.c_int32), ("in_", C.c_int32)]
 
 
+class DropoutT(C.Structure):
+    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64), ("st", C.c_void_p)]
+
+
 class StepStateT(C.Structure):
     _fields_ = [("step", C.c_int64), ("bc1", C.c_float), ("bc2_sqrt", C.c_float),
                 ("lr_scale", C.c_float), ("pad_", C.c_float)]
@@ -104,8 +108,9 @@ PROTOTYPES = {
     "osrl_cdt_embed_ln": [_fp, _fp, _fp, _fp, _vp] + [_fp] * 11 + [_i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _vp],
     "osrl_layernorm_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _vp],
     "osrl_layernorm_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],
-    "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp, _vp],
-    "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp, _vp],
+    "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
+    "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
+    "osrl_dropout": [_fp, _fp, _i64, _P(DropoutT), _vp],
     "osrl_gelu_fwd": [_fp, _fp, _i64, _vp],
     "osrl_gelu_bwd": [_fp, _fp, _fp, _i64, _vp],
     "osrl_cdt_loss": [_fp] * 7 + [_i32] * 6 + [_fp, _f32, _f32, _f32, _i32, _vp, _fp, _i32, _fp, _fp, _fp, _fp, _fp, _vp],

@@ -4,7 +4,7 @@
 are created in the same order, so a seeded construction reproduces the reference's initial weights);
 ``CDTTrainer.train_one_step`` keeps the signature of cdt.py:343.  Supported configuration = the reference's
 training defaults (time/return/cost embeddings, optional cost transform, 1-layer stochastic or
-deterministic head); the deprecated cost-feature / cost-prefix variants and dropout > 0 raise.
+deterministic head, dropout); the deprecated cost-feature / cost-prefix variants raise.
 """
 from __future__ import annotations
 
@@ -33,8 +33,8 @@ class CDT(nn.Module):
                  init_temperature=0.1, target_entropy=None, device: str = "cuda"):
         super().__init__()
         unsupported = []
-        if max(attention_dropout, residual_dropout, embedding_dropout) > 0:
-            unsupported.append("dropout > 0")
+        if not all(0.0 <= p < 1.0 for p in (attention_dropout, residual_dropout, embedding_dropout)):
+            raise ValueError("dropout probabilities must be in [0, 1)")
         if not (time_emb and use_rew and use_cost):
             unsupported.append("time_emb/use_rew/use_cost = False")
         if add_cost_feat or mul_cost_feat or cat_cost_feat or cost_prefix:
@@ -43,6 +43,12 @@ class CDT(nn.Module):
             unsupported.append("action_head_layers != 1")
         if embedding_dim % num_heads or embedding_dim > 512 or 4 * embedding_dim > 1024 or 4 * seq_len > 128:
             unsupported.append("embedding_dim > 256 or 4*seq_len > 128")
+        else:  # the attention backward keeps Q, K, V, dO and two score tiles of one (batch, head) in LDS (160 KB)
+            r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+            sp, dp = r16(4 * seq_len), r16(embedding_dim // num_heads)
+            if 4 * (4 * sp * (dp + 8) + 2 * sp * (sp + 8) + sp) > 160 * 1024:
+                unsupported.append(f"4*seq_len = {4 * seq_len} tokens with head_dim {embedding_dim // num_heads} "
+                                   "(attention backward tile > 160 KB LDS)")
         if unsupported:
             raise NotImplementedError("osrl_amd CDT does not support: " + "; ".join(unsupported))
         self.seq_len, self.embedding_dim = seq_len, embedding_dim
@@ -53,6 +59,8 @@ class CDT(nn.Module):
         self.cost_transform = (lambda x: 50 - x) if cost_transform else None
         self.add_cost_feat = self.mul_cost_feat = self.cat_cost_feat = False
         self.stochastic = stochastic
+        self.attention_dropout, self.residual_dropout = float(attention_dropout), float(residual_dropout)
+        self.embedding_dropout = float(embedding_dropout)
         self.time_emb, self.use_rew, self.use_cost, self.cost_prefix = True, True, True, False
         self.seq_repeat = 4
         self.device = str(device)
@@ -154,7 +162,9 @@ class CDT(nn.Module):
             time_steps, mask = pad(time_steps), pad(mask)
         e.load_batch(states, actions, returns_to_go, costs_to_go, time_steps, mask, torch.zeros_like(mask))
         self.repack()
-        e.forward()
+        if self.training and max(self.attention_dropout, self.residual_dropout, self.embedding_dropout) > 0:
+            e.st.tick()  # a model left in train() mode draws a fresh dropout mask per call, like nn.Dropout
+        e.forward(train=self.training)
         ad, od = self.action_dim, self.state_dim
         if self.stochastic:
             mu = e.head[:, :ad].reshape(B, T, ad)[:, :Tin].clone()
@@ -173,7 +183,8 @@ class CDTTrainer:
                  weight_decay: float = 1e-4, betas: Tuple[float, ...] = (0.9, 0.999), clip_grad: float = 0.25,
                  lr_warmup_steps: int = 10000, reward_scale: float = 1.0, cost_scale: float = 1.0,
                  loss_cost_weight: float = 0.0, loss_state_weight: float = 0.0, cost_reverse: bool = False,
-                 no_entropy: bool = False, device="cuda", stats_mode: str = "lazy", use_graph: bool = True) -> None:
+                 no_entropy: bool = False, device="cuda", stats_mode: str = "lazy", use_graph: bool = True,
+                 seed: int = 0) -> None:
         self.model, self.logger, self.env = model, logger, env
         self.clip_grad, self.reward_scale, self.cost_scale, self.device = clip_grad, reward_scale, cost_scale, device
         self.cost_weight, self.state_weight = loss_cost_weight, loss_state_weight
@@ -183,7 +194,7 @@ class CDTTrainer:
         self.stats_mode, self.use_graph = stats_mode, use_graph
         self.cfg = dict(learning_rate=learning_rate, weight_decay=weight_decay, betas=tuple(betas),
                         clip_grad=clip_grad, lr_warmup_steps=lr_warmup_steps, loss_cost_weight=loss_cost_weight,
-                        loss_state_weight=loss_state_weight, no_entropy=no_entropy)
+                        loss_state_weight=loss_state_weight, no_entropy=no_entropy, seed=int(seed))
 
     def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs):
         """cdt.py:343-418 (episode_cost only feeds the unsupported cost-prefix variant)."""

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/osrl_amd.h"
+#include "philox.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -229,7 +230,31 @@ struct AttnArgs {
   const float* dout;  // bwd in  [B, S, E]
   float* dqkv;        // bwd out [B, S, 3E]
   int32_t B, S, E, H, rep;
+  // attention-probability dropout (net.py:406-409): drop_scale = 1/(1-p), 0 thresh = off
+  uint32_t drop_thresh, drop_site, k0, k1;
+  float drop_scale;
+  const osrl_step_state_t* st;
 };
+
+// keep-multipliers of the (up to 8) probabilities P[bh][i][l16 + 16k] one lane owns in the softmax / dS passes.
+// Logical mask layout [B*H, S, 16, 8]: element ((bh*S + i)*16 + l16)*8 + k, so k = 0..3 share one Philox call.
+__device__ __forceinline__ void attn_drop_mult(const AttnArgs& a, int bh, int i, int l16, int nk, float (&m)[8]) {
+  const uint32_t step = a.st ? (uint32_t)a.st->step : 0u;
+  const uint64_t e4 = (((uint64_t)bh * a.S + i) * 16 + l16) * 2;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half * 4 < nk) {
+      const osrl_rng::U4 w = osrl_rng::drop_words(e4 + half, step, a.drop_site, a.k0, a.k1);
+      m[half * 4 + 0] = w.x >= a.drop_thresh ? a.drop_scale : 0.f;
+      m[half * 4 + 1] = w.y >= a.drop_thresh ? a.drop_scale : 0.f;
+      m[half * 4 + 2] = w.z >= a.drop_thresh ? a.drop_scale : 0.f;
+      m[half * 4 + 3] = w.w >= a.drop_thresh ? a.drop_scale : 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[half * 4 + k] = 0.f;
+    }
+  }
+}
 
 // 16-lane (one DPP row) butterfly reductions: 4 VALU DPP ops instead of 4-6 ds_bpermute round trips
 __device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
@@ -305,8 +330,11 @@ __device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, si
 }
 
 // P = softmax(mask(Q K^T / sqrt(d))) into Ps (lower-triangular blocks; everything else = 0)
+// (apply_drop: the forward kernel stores the dropped probabilities P*M/(1-p); the backward kernel keeps P and
+// applies the regenerated mask in its dS pass)
 __device__ __forceinline__ void attn_probs_mfma(const AttnArgs& a, int b, int d, int Sp, int dp, const float* Qs,
-                                                const float* Ks, int ldq, float* Ps, int ldp, const float* kvalid) {
+                                                const float* Ks, int ldq, float* Ps, int ldp, const float* kvalid,
+                                                bool apply_drop, int bh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nb = Sp >> 4, ntri = nb * (nb + 1) / 2;
   const float scale = 1.0f / sqrtf((float)d);
@@ -346,6 +374,12 @@ __device__ __forceinline__ void attn_probs_mfma(const AttnArgs& a, int b, int d,
     }
     sum = row16_sum(sum);
     const float inv = live ? 1.0f / sum : 0.f;
+    if (apply_drop && a.drop_thresh && i < a.S) {
+      float dm[8];
+      attn_drop_mult(a, bh, i, l16, jmax >> 4, dm);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= dm[k];
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int j = l16 + 16 * k;
@@ -373,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, nullptr, 0, Vt, ldp);
   attn_key_valid(a, b, Sp, kvalid);
   __syncthreads();
-  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid);
+  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid, true, blockIdx.x);
   // O = P V : blocks (ib, cb); A = row fragments of P, B = row fragments of V^T
   const int nb = Sp >> 4, ncb = dp >> 4;
   for (int blk = wave; blk < nb * ncb; blk += 4) {
@@ -404,7 +438,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   attn_load_tile(a.dout + (size_t)b * a.S * a.E + h * d, a.E, a.S, d, Sp, dp, dOs, ldq, nullptr, 0);
   attn_key_valid(a, b, Sp, kvalid);
   __syncthreads();
-  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid);
+  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid, false, blockIdx.x);
   const int nb = Sp >> 4, ncb = dp >> 4, ntri = nb * (nb + 1) / 2;
   // dP = dO V^T on the lower-triangular blocks
   for (int blk = wave; blk < ntri; blk += 4) {
@@ -432,6 +466,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
         pv[k] = in ? Ps[i * ldp + j] : 0.f;
         gv[k] = in ? dS[i * ldp + j] : 0.f;
         r += pv[k] * gv[k];
+      }
+      if (a.drop_thresh && i < a.S) {
+        // with dropout gv is dP' (grad wrt the dropped probabilities P' = P*M'):  dS = P'*dP' - P*sum_j(P'*dP'),
+        // and dV below needs P' -> Ps is overwritten with it (each element is owned by exactly this lane)
+        float dm[8], pd[8];
+        attn_drop_mult(a, blockIdx.x, i, l16, jmax >> 4, dm);
+        r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          pd[k] = pv[k] * dm[k];
+          r += pd[k] * gv[k];
+        }
+        r = row16_sum(r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = l16 + 16 * k;
+          if (j < Sp) {
+            dS[i * ldp + j] = pd[k] * gv[k] - pv[k] * r;
+            if (j < jmax) Ps[i * ldp + j] = pd[k];
+          }
+        }
+        continue;
       }
       r = row16_sum(r);
 #pragma unroll
@@ -461,6 +517,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int i = rb * 16 + 4 * (lane >> 4) + r;
       if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + which * a.E + h * d + c] = acc[r] * sc;
+    }
+  }
+}
+
+// ---------------- dropout (nn.Dropout: cdt.py:87,222; net.py:404,414,439)
+// y = x * keep/(1-p); the same call on the incoming gradient is the backward pass (the mask is a pure function of
+// (seed, step, site, element), philox.h).  HBM-streaming: one Philox call per float4.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                      uint32_t thresh, float scale, uint32_t site, uint32_t k0,
+                                                      uint32_t k1, const osrl_step_state_t* __restrict__ st) {
+  const uint32_t step = st ? (uint32_t)st->step : 0u;
+  const int64_t n4 = (n + 3) >> 2;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const osrl_rng::U4 w = osrl_rng::drop_words((uint64_t)i, step, site, k0, k1);
+    const float m[4] = {w.x >= thresh ? scale : 0.f, w.y >= thresh ? scale : 0.f, w.z >= thresh ? scale : 0.f,
+                        w.w >= thresh ? scale : 0.f};
+    const int64_t b = i * 4;
+    if (vec && b + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + b);
+      *reinterpret_cast<float4*>(y + b) = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (b + k < n) y[b + k] = x[b + k] * m[k];
     }
   }
 }
@@ -687,17 +767,46 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
   DONE();
 }
 
+constexpr size_t kMaxLds = 160 * 1024;  // LDS per workgroup on gfx950
 static size_t attn_lds(int S_, int d, bool bwd) {
   const size_t Sp = (S_ + 15) & ~15, dp = (d + 15) & ~15, ldq = dp + 8, ldp = Sp + 8;
   const size_t fl = bwd ? 4 * Sp * ldq + 2 * Sp * ldp + Sp : 2 * Sp * ldq + dp * ldp + Sp * ldp + Sp;
   return sizeof(float) * fl;
 }
 
+static bool attn_drop_args(const osrl_dropout_t* dr, AttnArgs* a) {
+  a->drop_thresh = 0;
+  a->drop_site = a->k0 = a->k1 = 0;
+  a->drop_scale = 1.0f;
+  a->st = nullptr;
+  if (!dr || dr->p <= 0.f) return true;
+  if (!(dr->p < 1.0f)) return false;
+  a->drop_thresh = osrl_rng::drop_thresh(dr->p);
+  a->drop_scale = 1.0f / (1.0f - dr->p);
+  a->drop_site = dr->site;
+  a->k0 = (uint32_t)dr->seed;
+  a->k1 = (uint32_t)(dr->seed >> 32);
+  a->st = dr->st;
+  return true;
+}
+
+int osrl_dropout(const float* x, float* y, int64_t n, const osrl_dropout_t* dr, void* stream) {
+  if (!x || !y || n < 1 || !dr || !(dr->p > 0.f) || !(dr->p < 1.0f)) return -1;
+  int64_t blocks = ((n + 3) / 4 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  CLEAR();
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, S, x, y, n, osrl_rng::drop_thresh(dr->p),
+                     1.0f / (1.0f - dr->p), dr->site, (uint32_t)dr->seed, (uint32_t)(dr->seed >> 32), dr->st);
+  DONE();
+}
+
 int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S_, int32_t E, int32_t H, int32_t rep,
-                       float* o, void* stream) {
+                       const osrl_dropout_t* drop, float* o, void* stream) {
   if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || S_ % rep) return -1;
   AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep};
+  if (!attn_drop_args(drop, &a)) return -1;
   const size_t lds = attn_lds(S_, E / H, false);
+  if (lds > kMaxLds) return -1;
   CLEAR();
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -707,10 +816,12 @@ int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S
 }
 
 int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S_, int32_t E,
-                       int32_t H, int32_t rep, float* dqkv, void* stream) {
+                       int32_t H, int32_t rep, const osrl_dropout_t* drop, float* dqkv, void* stream) {
   if (!qkv || !mask || !dout || !dqkv || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || S_ % rep) return -1;
   AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep};
+  if (!attn_drop_args(drop, &a)) return -1;
   const size_t lds = attn_lds(S_, E / H, true);
+  if (lds > kMaxLds) return -1;  // e.g. S = 128 with head_dim 32 needs 221 KB: not supported
   CLEAR();
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

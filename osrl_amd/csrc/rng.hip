@@ -14,32 +14,11 @@
 #include <stdint.h>
 
 #include "../../include/osrl_amd.h"
+#include "philox.h"
 
 namespace {
 
-struct U4 {
-  uint32_t x, y, z, w;
-};
-
-__host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
-    U4 n;
-    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-    n.y = (uint32_t)p1;
-    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-    n.w = (uint32_t)p0;
-    c = n;
-    k0 += W0;
-    k1 += W1;
-  }
-  return c;
-}
-
-__device__ inline float u01(uint32_t x) {  // (0,1]
-  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
-}
+using namespace osrl_rng;
 
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
                                                     uint32_t stream_id, const osrl_step_state_t* __restrict__ st) {

@@ -6,11 +6,14 @@ num_layers x [LN, QKV, causal+padding attention, out-proj, residual, LN, Linear-
 -> out LayerNorm -> heads -> losses -> backward of all of it -> clip_grad_norm_ -> AdamW (warm-up LR)
 -> temperature Adam.  Projections and their dX / dW GEMMs run on the packed-weight fp32-MFMA kernels
 (csrc/mlp.hip: osrl_linear, osrl_mlp_backward_dw); everything else is csrc/cdt.hip.
-Dropout must be 0 (the CDT class default, cdt.py:55-57); the train-config default 0.1 is not wired yet.
+Dropout (embedding cdt.py:222, attention probabilities net.py:406-409, residual net.py:414,439; train-config
+default 0.1, examples/configs/cdt_configs.py:28-30) uses stateless Philox masks keyed by (seed, step, site, element):
+the backward kernels regenerate them, nothing is stored; with p = 0 no extra kernel is launched.
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import ctypes
+from typing import Dict, List, Optional
 
 import torch
 
@@ -75,6 +78,12 @@ class CDTEngine:
         self.do = z(M, E)
         self.dqkv = [z(M, 3 * E) for _ in range(NL)]
         self.dseq = z(M, E)
+        # dropout: probabilities, generator seed; gradients of the dropped branches need their own buffers
+        # (the undropped gradient keeps flowing along the residual path)
+        self.p_emb, self.p_attn, self.p_res = m.embedding_dropout, m.attention_dropout, m.residual_dropout
+        self.seed = int(trainer_cfg.get("seed", 0))
+        self.datt = [z(M, E) if self.p_res > 0 else self.dxm[l] for l in range(NL)]      # grad wrt out_proj output
+        self.dmo = [z(M, E) if self.p_res > 0 else self.dxo[l + 1] for l in range(NL)]   # grad wrt mlp.2 output
         self.n_parts = max(1, min(1024, (M + 31) // 32))  # ~8 rows per wave per LayerNorm-backward workgroup
         self.ln_ws = z(self.n_parts, 2 * E)
         self.clip_ws, self.clip_out = z(1024), z(4)
@@ -87,9 +96,9 @@ class CDTEngine:
         for l in range(NL):
             p = f"cdt.blocks.{l}."
             tok += [(self.dqkv[l], self.n1[l], p + "attention.in_proj_weight", p + "attention.in_proj_bias"),
-                    (self.dxm[l], self.o[l], p + "attention.out_proj.weight", p + "attention.out_proj.bias"),
+                    (self.datt[l], self.o[l], p + "attention.out_proj.weight", p + "attention.out_proj.bias"),
                     (self.dhpre[l], self.n2[l], p + "mlp.0.weight", p + "mlp.0.bias"),
-                    (self.dxo[l + 1], self.h[l], p + "mlp.2.weight", p + "mlp.2.bias")]
+                    (self.dmo[l], self.h[l], p + "mlp.2.weight", p + "mlp.2.bias")]
         sf_ptr, af_ptr = self.out.data_ptr() + 4 * 2 * E, self.out.data_ptr() + 4 * 3 * E
         hk = "cdt.action_head.head" if m.stochastic else "cdt.action_head.0"
         ds = self.dseq.data_ptr()
@@ -149,10 +158,45 @@ class CDTEngine:
                                             g.offset(key + ".weight"), g.offset(key + ".bias"), cur_stream()),
                 "osrl_layernorm_bwd")
 
+    # ---- dropout sites: 0 = embedding; layer l: 1+3l attention probabilities, 2+3l / 3+3l the two residual branches
+    def _site(self, site: int, p: float):
+        return L.DropoutT(float(p), site, self.seed, self.st.ptr)
+
+    def _drop(self, x, y, site: int, p: float) -> None:
+        d = self._site(site, p)
+        L.check(L.load().osrl_dropout(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(d), cur_stream()),
+                "osrl_dropout")
+
+    def dropout_masks(self) -> Dict[str, torch.Tensor]:
+        """Keep-multipliers (0 or 1/(1-p)) of the most recent train step, in tensor layout: 'emb' [B,S,E],
+        'attn{l}' [B,H,S,S], 'res1_{l}' / 'res2_{l}' [B,S,E].  Regenerated from the counters (diagnostics, parity tests)."""
+        B, S, E, H = self.B, self.S, self.E, self.H
+        out: Dict[str, torch.Tensor] = {}
+        ones = torch.ones(self.M, E, device=self.dev)
+        if self.p_emb > 0:
+            out["emb"] = torch.empty_like(ones)
+            self._drop(ones, out["emb"], 0, self.p_emb)
+            out["emb"] = out["emb"].view(B, S, E)
+        for l in range(self.NL):
+            if self.p_attn > 0:
+                o1 = torch.ones(B * H, S, 16, 8, device=self.dev)
+                raw = torch.empty_like(o1)
+                self._drop(o1, raw, 1 + 3 * l, self.p_attn)
+                j = torch.arange(S, device=self.dev)
+                out[f"attn{l}"] = raw[:, :, j % 16, j // 16].reshape(B, H, S, S)
+            if self.p_res > 0:
+                for k, site in ((f"res1_{l}", 2 + 3 * l), (f"res2_{l}", 3 + 3 * l)):
+                    t = torch.empty_like(ones)
+                    self._drop(ones, t, site, self.p_res)
+                    out[k] = t.view(B, S, E)
+        return out
+
     # ---- forward -------------------------------------------------------------------------------
-    def forward(self) -> None:
+    def forward(self, train: bool = False) -> None:
+        """``train`` enables dropout (nn.Module.training of the reference model)."""
         m, lib, E, M, BT = self.model, L.load(), self.E, self.M, self.BT
         v = self._v
+        p_emb, p_attn, p_res = (self.p_emb, self.p_attn, self.p_res) if train else (0.0, 0.0, 0.0)
         L.check(lib.osrl_cdt_embed_ln(self.states.data_ptr(), self.actions.data_ptr(), self.returns.data_ptr(),
                                       self.ctg.data_ptr(), self.time_steps.data_ptr(), v("cdt.state_emb.weight"),
                                       v("cdt.state_emb.bias"), v("cdt.action_emb.weight"), v("cdt.action_emb.bias"),
@@ -161,18 +205,26 @@ class CDTEngine:
                                       v("cdt.emb_norm.bias"), BT, m.state_dim, m.action_dim, E,
                                       1 if m.cost_transform_on else 0, self.seq.data_ptr(), self.x0.data_ptr(),
                                       self.st_emb.data_ptr(), self.ctg_t.data_ptr(), cur_stream()), "osrl_cdt_embed_ln")
+        if p_emb > 0:
+            self._drop(self.x0, self.x0, 0, p_emb)
         for l in range(self.NL):
             p = f"cdt.blocks.{l}."
             if l == 0:
                 self._ln_fwd(self.xin[0], None, p + "norm1", None, self.n1[0], self.st1[0])
             self._lin(self.n1[l], E, M, p + "attention.in_proj_weight", self.qkv[l], 3 * E)
+            da = self._site(1 + 3 * l, p_attn)
             L.check(lib.osrl_attention_fwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.B, self.S, E, self.H, 4,
-                                           self.o[l].data_ptr(), cur_stream()), "osrl_attention_fwd")
+                                           ctypes.byref(da) if p_attn > 0 else None, self.o[l].data_ptr(),
+                                           cur_stream()), "osrl_attention_fwd")
             self._lin(self.o[l], E, M, p + "attention.out_proj.weight", self.att, E)
+            if p_res > 0:
+                self._drop(self.att, self.att, 2 + 3 * l, p_res)
             self._ln_fwd(self.xin[l], self.att, p + "norm2", self.xmid[l], self.n2[l], self.st2[l])
             self._lin(self.n2[l], E, M, p + "mlp.0.weight", self.hpre[l], 4 * E)
             L.check(lib.osrl_gelu_fwd(self.hpre[l].data_ptr(), self.h[l].data_ptr(), M * 4 * E, cur_stream()), "gelu")
             self._lin(self.h[l], 4 * E, M, p + "mlp.2.weight", self.mo, E)
+            if p_res > 0:
+                self._drop(self.mo, self.mo, 3 + 3 * l, p_res)
             if l + 1 < self.NL:
                 self._ln_fwd(self.xmid[l], self.mo, f"cdt.blocks.{l + 1}.norm1", self.xin[l + 1], self.n1[l + 1],
                              self.st1[l + 1])
@@ -193,7 +245,7 @@ class CDTEngine:
         if self.store is not None:  # draw the minibatch of windows on device (SequenceDataset, dataset.py:749-787)
             self.store.gather(self.states, self.actions, self.returns, self.ctg, self.time_steps, self.mask,
                               self.episode_cost, self.costs, st.ptr)
-        self.forward()
+        self.forward(train=True)
         counts, world = None, 1
         if self.dist is not None:  # count-normalisers over the GLOBAL batch
             L.check(lib.osrl_cdt_mask_counts(self.mask.data_ptr(), BT, self.counts.data_ptr(), cur_stream()), "counts")
@@ -217,16 +269,24 @@ class CDTEngine:
         self._ln_bwd(self.dout, self.xin[NL], self.st_out, "cdt.out_norm", None, self.dxo[NL])
         for l in range(NL - 1, -1, -1):
             p = f"cdt.blocks.{l}."
-            self._lin_dx(self.dxo[l + 1], E, M, p + "mlp.2.weight", self.dh, 4 * E)
+            if self.p_res > 0:
+                self._drop(self.dxo[l + 1], self.dmo[l], 3 + 3 * l, self.p_res)
+            self._lin_dx(self.dmo[l], E, M, p + "mlp.2.weight", self.dh, 4 * E)
             L.check(lib.osrl_gelu_bwd(self.dh.data_ptr(), self.hpre[l].data_ptr(), self.dhpre[l].data_ptr(),
                                       M * 4 * E, cur_stream()), "gelu_bwd")
             self._lin_dx(self.dhpre[l], 4 * E, M, p + "mlp.0.weight", self.dn, E)
             self._ln_bwd(self.dn, self.xmid[l], self.st2[l], p + "norm2", self.dxo[l + 1], self.dxm[l])
-            self._lin_dx(self.dxm[l], E, M, p + "attention.out_proj.weight", self.do, E)
+            if self.p_res > 0:
+                self._drop(self.dxm[l], self.datt[l], 2 + 3 * l, self.p_res)
+            self._lin_dx(self.datt[l], E, M, p + "attention.out_proj.weight", self.do, E)
+            da = self._site(1 + 3 * l, self.p_attn)
             L.check(lib.osrl_attention_bwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.do.data_ptr(), self.B,
-                                           self.S, E, self.H, 4, self.dqkv[l].data_ptr(), cur_stream()), "attn_bwd")
+                                           self.S, E, self.H, 4, ctypes.byref(da) if self.p_attn > 0 else None,
+                                           self.dqkv[l].data_ptr(), cur_stream()), "attn_bwd")
             self._lin_dx(self.dqkv[l], 3 * E, M, p + "attention.in_proj_weight", self.dn, E)
             self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l])
+        if self.p_emb > 0:
+            self._drop(self.dxo[0], self.dxo[0], 0, self.p_emb)
         self._ln_bwd(self.dxo[0], self.seq, self.st_emb, "cdt.emb_norm", None, self.dseq)
         # ---- parameter gradients
         te_off, (te_rows, _) = g.layout["cdt.timestep_emb.weight"]

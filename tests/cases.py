@@ -183,12 +183,15 @@ class CDTCase:
     state_w: float = 0.0
     seed: int = 0
     algo: str = "cdt"
+    dropout: float = 0.0  # attention / residual / embedding dropout (cdt_configs.py:28-30 default 0.1)
 
 
 CDT_CASES: Dict[str, CDTCase] = {c.name: c for c in [
     CDTCase("cdt_small", od=5, ad=3, B=6, T=4, E=16, heads=2, layers=2, episode_len=20, steps=5, state_w=0.1),
     CDTCase("cdt_det", od=4, ad=2, B=5, T=3, E=16, heads=4, layers=1, episode_len=12, steps=3, stochastic=False,
             cost_transform=False, clip=1e9, warmup=1),
+    CDTCase("cdt_drop", od=5, ad=3, B=6, T=5, E=16, heads=2, layers=2, episode_len=20, steps=4, state_w=0.1,
+            dropout=0.1, seed=3),
     CDTCase("cdt_mid", od=11, ad=3, B=16, T=10, E=128, heads=8, layers=3, episode_len=1000, steps=1, warmup=500),
 ]}
 
@@ -235,6 +238,22 @@ def make_cdt_params(c: CDTCase) -> "OrderedDict[str, np.ndarray]":
     lin("state_pred_head", c.od, E)
     lin("cost_pred_head", 2, E)
     return sd
+
+
+def cdt_drop_sites(c: CDTCase):
+    """(key, shape) of every nn.Dropout draw of one CDT forward, in the reference's call order."""
+    S = 4 * c.T
+    out = [("emb", (c.B, S, c.E))]
+    for l in range(c.layers):
+        out += [(f"attn{l}", (c.B, c.heads, S, S)), (f"res1_{l}", (c.B, S, c.E)), (f"res2_{l}", (c.B, S, c.E))]
+    return out
+
+
+def make_cdt_drop(c: CDTCase, step: int) -> Dict[str, np.ndarray]:
+    """Keep-multipliers (0 or 1/(1-p)) for train step ``step``."""
+    rs = np.random.RandomState(7000 + 131 * c.seed + step)
+    p = c.dropout
+    return {k: ((rs.uniform(size=shp) >= p) / (1.0 - p)).astype(np.float32) for k, shp in cdt_drop_sites(c)}
 
 
 def make_cdt_batch(c: CDTCase) -> Dict[str, np.ndarray]:

@@ -25,8 +25,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from cases import (CASES, CDT_CASES, hyper, make_batch, make_cdt_batch, make_cdt_params, make_noise,  # noqa: E402
-                   make_params, noise_shapes)
+from cases import (CASES, CDT_CASES, cdt_drop_sites, hyper, make_batch, make_cdt_batch, make_cdt_drop,  # noqa: E402
+                   make_cdt_params, make_noise, make_params, noise_shapes)
 
 REF = os.environ.get("OSRL_REFERENCE", "/root/reference")
 
@@ -184,18 +184,66 @@ def main():
         print(f"{case.name}: {os.path.getsize(path) / 1024:.1f} KB  stats[0]={dict(zip(keys, out['stats'][0]))}")
 
 
+class DropQueue:
+    """Feeds explicit keep-multipliers to every dropout draw of the reference, in its own call order.
+
+    nn.Dropout -> F.dropout is replaced by ``x * mask``.  The attention-probability dropout happens inside the
+    fused ``F.scaled_dot_product_attention`` that nn.MultiheadAttention calls (need_weights=False); that call is
+    replaced by its textbook definition softmax(QK^T/sqrt(d) + mask) -> dropout -> @V written with torch ops
+    (the dropout-free goldens pin the fused kernel itself).  Shapes are asserted.
+    """
+
+    def __init__(self, torch):
+        self.torch, self.q = torch, []
+
+    def push(self, c, step):
+        m = make_cdt_drop(c, step)
+        self.q += [(k, m[k]) for k, _ in cdt_drop_sites(c)]
+
+    def pop(self, shape):
+        k, v = self.q.pop(0)
+        assert tuple(v.shape) == tuple(shape), (k, v.shape, tuple(shape))
+        return self.torch.from_numpy(v)
+
+    def install(self):
+        torch, dq = self.torch, self
+        import math
+        F = torch.nn.functional
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            return x * dq.pop(x.shape) if (training and p > 0) else x
+
+        def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, **kw):
+            assert not is_causal
+            s = q @ k.transpose(-2, -1) / math.sqrt(q.shape[-1])
+            if attn_mask is not None:
+                s = s.masked_fill(~attn_mask, float("-inf")) if attn_mask.dtype == torch.bool else s + attn_mask
+            P = torch.softmax(s, -1)
+            if dropout_p > 0:
+                P = P * dq.pop(P.shape)
+            return P @ v
+
+        F.dropout = dropout
+        F.scaled_dot_product_attention = sdpa
+
+
 def main_cdt():
-    """CDT goldens: dropout 0 (the CDT class default, cdt.py:55-57), fp32 mask."""
+    """CDT goldens: fp32 mask; dropout 0 (the CDT class default, cdt.py:55-57) except the
+    ``dropout`` cases, which inject explicit masks through DropQueue."""
     Logger = _install_stubs()
     sys.path.insert(0, REF)
     import torch
     import osrl.algorithms as algos
 
     torch.set_num_threads(4)
-    for c in CDT_CASES.values():
+    dq = DropQueue(torch)
+    for c in sorted(CDT_CASES.values(), key=lambda c: c.dropout):  # patch the samplers only for the dropout cases
+        if c.dropout > 0 and not dq.q and getattr(dq, "_on", None) is None:
+            dq.install()
+            dq._on = True
         m = algos.CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=c.episode_len, embedding_dim=c.E,
-                      num_layers=c.layers, num_heads=c.heads, attention_dropout=0.0, residual_dropout=0.0,
-                      embedding_dropout=0.0, time_emb=True, use_rew=True, use_cost=True,
+                      num_layers=c.layers, num_heads=c.heads, attention_dropout=c.dropout,
+                      residual_dropout=c.dropout, embedding_dropout=c.dropout, time_emb=True, use_rew=True, use_cost=True,
                       cost_transform=c.cost_transform, action_head_layers=1, cost_prefix=False,
                       stochastic=c.stochastic, init_temperature=0.1, target_entropy=-c.ad)
         lg = Logger()
@@ -208,8 +256,11 @@ def main_cdt():
         b = {k: torch.from_numpy(v) for k, v in make_cdt_batch(c).items()}
         out = {}
         for s in range(c.steps):
+            if c.dropout > 0:
+                dq.push(c, s)
             tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
                               b["mask"], b["episode_cost"], b["costs"])
+            assert not dq.q, f"{c.name}: {len(dq.q)} dropout masks left unconsumed"
             lg.flush()
             if s + 1 in (1, c.steps):
                 for k, v in m.state_dict().items():

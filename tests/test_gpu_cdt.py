@@ -105,10 +105,11 @@ def test_layernorm_gelu_attention_kernels():
         do = rs.randn(B, S, E).astype(np.float32)
         o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
         qt, mt = t(qkv), t(mask)
-        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, o.data_ptr(), cur_stream()), "a")
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, None, o.data_ptr(), cur_stream()),
+                "a")
         dot = t(do)
-        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, dqkv.data_ptr(),
-                                       cur_stream()), "ab")
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, None,
+                                       dqkv.data_ptr(), cur_stream()), "ab")
         q64 = qkv.astype(np.float64)
         q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
         blocked = np.triu(np.ones((S, S), bool), 1)[None, None] | np.repeat(mask <= 0, 4, 1)[:, None, None, :]
@@ -126,11 +127,83 @@ def test_layernorm_gelu_attention_kernels():
         assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), (B, T, E, H)
 
 
+def test_dropout_kernels():
+    """osrl_dropout: keep-rate, scale, determinism in (seed, step, site), odd sizes / unaligned pointers; attention
+    probability dropout forward + backward against numpy with the exported mask."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import StepState, cur_stream
+    lib = L.load()
+    st = StepState(torch.device(DEV), ["x"])
+    st.tick()
+
+    def mask(n, p, site, seed=5, off=0):
+        x = torch.ones(n + off, device=DEV)[off:]
+        y = torch.full((n + off,), -1.0, device=DEV)[off:]
+        d = L.DropoutT(p, site, seed, st.ptr)
+        L.check(lib.osrl_dropout(x.data_ptr(), y.data_ptr(), n, C.byref(d), cur_stream()), "drop")
+        return y
+
+    n = 1 << 20
+    for p in (0.1, 0.5):
+        m0 = mask(n, p, 3)
+        vals = torch.unique(m0).cpu().numpy()
+        assert np.allclose(vals, [0.0, 1.0 / (1.0 - p)], rtol=1e-6), vals
+        keep = (m0 > 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n), (p, keep)
+        assert torch.equal(m0, mask(n, p, 3))                      # same (seed, step, site) -> same mask
+        assert not torch.equal(m0, mask(n, p, 4))                  # other site
+        assert not torch.equal(m0, mask(n, p, 3, seed=6))          # other seed
+        assert torch.equal(m0[:1001], mask(1001, p, 3))            # prefix-stable, ragged tail
+        assert torch.equal(m0[:1001], mask(1001, p, 3, off=1))     # unaligned pointers take the scalar path
+    m0 = mask(n, 0.1, 3)
+    st.tick()
+    assert not torch.equal(m0, mask(n, 0.1, 3))                    # next train step -> fresh mask
+    assert lib.osrl_dropout(m0.data_ptr(), m0.data_ptr(), n, C.byref(L.DropoutT(1.0, 0, 0, st.ptr)), cur_stream()) != 0
+
+    rs = np.random.RandomState(2)
+    for (B, T, E, H, p) in [(3, 4, 16, 2, 0.25), (2, 20, 256, 8, 0.1), (4, 24, 64, 2, 0.5)]:
+        S, d = 4 * T, E // H
+        qkv = rs.randn(B, S, 3 * E).astype(np.float32)
+        mk = np.ones((B, T), np.float32)
+        mk[0, T - 2:] = 0
+        do = rs.randn(B, S, E).astype(np.float32)
+        o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
+        qt, mt, dot = t(qkv), t(mk), t(do)
+        dr = L.DropoutT(p, 7, 11, st.ptr)
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, C.byref(dr), o.data_ptr(),
+                                       cur_stream()), "a")
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, C.byref(dr),
+                                       dqkv.data_ptr(), cur_stream()), "ab")
+        raw = torch.empty(B * H, S, 16, 8, device=DEV)
+        ones = torch.ones_like(raw)
+        L.check(lib.osrl_dropout(ones.data_ptr(), raw.data_ptr(), raw.numel(), C.byref(dr), cur_stream()), "m")
+        j = np.arange(S)
+        Mk = raw.cpu().numpy()[:, :, j % 16, j // 16].reshape(B, H, S, S).astype(np.float64)
+        q64 = qkv.astype(np.float64)
+        q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
+        blocked = np.triu(np.ones((S, S), bool), 1)[None, None] | np.repeat(mk <= 0, 4, 1)[:, None, None, :]
+        sc = np.where(blocked, -np.inf, q @ k.transpose(0, 1, 3, 2) / math.sqrt(d))
+        P = np.exp(sc - sc.max(-1, keepdims=True))
+        P /= P.sum(-1, keepdims=True)
+        Pd = P * Mk
+        oref = (Pd @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
+        assert np.abs(o.cpu().numpy() - oref).max() < 3e-5, (B, T, E, H)
+        dO = do.astype(np.float64).reshape(B, S, H, d).transpose(0, 2, 1, 3)
+        dP = (dO @ v.transpose(0, 1, 3, 2)) * Mk
+        dv = Pd.transpose(0, 1, 3, 2) @ dO
+        dS = P * (dP - (dP * P).sum(-1, keepdims=True))
+        dq, dk = dS @ k / math.sqrt(d), dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
+        ref = np.concatenate([x.transpose(0, 2, 1, 3).reshape(B, S, E) for x in (dq, dk, dv)], -1)
+        assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), (B, T, E, H)
+
+
 def build_cdt_gpu(c, **kw):
     from osrl_amd.algorithms import CDT, CDTTrainer
     from osrl_amd.common.logger import DummyLogger
     m = CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=c.episode_len, embedding_dim=c.E, num_layers=c.layers,
-            num_heads=c.heads, use_rew=True, use_cost=True, cost_transform=c.cost_transform, stochastic=c.stochastic,
+            num_heads=c.heads, attention_dropout=c.dropout, residual_dropout=c.dropout, embedding_dropout=c.dropout,
+            use_rew=True, use_cost=True, cost_transform=c.cost_transform, stochastic=c.stochastic,
             init_temperature=0.1, target_entropy=-c.ad, device=DEV)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_cdt_params(c).items()})
     lg = DummyLogger()
@@ -141,7 +214,7 @@ def build_cdt_gpu(c, **kw):
     return m, tr, lg
 
 
-@pytest.mark.parametrize("name", list(CDT_CASES))
+@pytest.mark.parametrize("name", [n for n, c in CDT_CASES.items() if c.dropout == 0])
 def test_cdt_train_step_matches_golden_and_oracle(name):
     from test_oracle_cdt_golden import build_cdt_oracle
     c = CDT_CASES[name]
@@ -176,6 +249,47 @@ def test_cdt_train_step_matches_golden_and_oracle(name):
                    ~b["mask"].to(torch.bool), b["episode_cost"])
     a = (ap.mean if c.stochastic else ap).cpu().numpy()
     assert np.abs(a - g["act"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_cdt_dropout_train_step_matches_oracle(use_graph):
+    """Dropout 0.1 at every site (the train-config default): the GPU step draws Philox masks; the oracle (pinned
+    against the reference with injected masks, tests/golden/cdt_drop.npz) replays the same masks, exported from
+    the generator after each step.  Also: eval-mode inference applies no dropout."""
+    from test_oracle_cdt_golden import build_cdt_oracle
+    c = CDT_CASES["cdt_drop"]
+    m, tr, lg = build_cdt_gpu(c, use_graph=use_graph, seed=1234)
+    o = build_cdt_oracle(c)
+    bn = make_cdt_batch(c)
+    b = {k: t(v) for k, v in bn.items()}
+    prev = None
+    for s in range(c.steps):
+        tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                          b["episode_cost"], b["costs"])
+        masks = {k: v.cpu().numpy() for k, v in m.engine(c.B).dropout_masks().items()}
+        assert set(masks) == {"emb"} | {f"{k}{l}" for l in range(c.layers) for k in ("attn", "res1_", "res2_")}
+        if prev is not None:
+            assert any((masks[k] != prev[k]).any() for k in masks), "dropout masks must change from step to step"
+        prev = masks
+        ost = o.train_one_step(bn["states"], bn["actions"], bn["returns"], bn["costs_return"], bn["time_steps"],
+                               bn["mask"], bn["episode_cost"], bn["costs"], drop=masks)
+        for k, r in ost.items():
+            got = lg.last("train/" + k)
+            assert abs(got - r) <= 1e-4 * max(1.0, abs(r)), f"step {s} {k}: gpu {got} vs oracle {r}"
+        assert abs(m.log_temperature.item() - o.log_temperature) < 1e-6
+        for k, v in m.state_dict().items():
+            if v.dtype != torch.bool:
+                d = np.abs(v.cpu().numpy() - o.p[k]).max()
+                assert d <= 2e-5, f"step {s + 1} param {k}: max diff {d:.3e}"
+    m.eval()
+    ap, _, _ = m(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
+                 ~b["mask"].to(torch.bool), b["episode_cost"])
+    ref = o.act_mean(bn["states"], bn["actions"], bn["returns"], bn["costs_return"], bn["time_steps"], bn["mask"])
+    assert np.abs(ap.mean.cpu().numpy() - ref).max() <= 1e-4
+    m.train()
+    a1 = m(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], ~b["mask"].to(torch.bool),
+           b["episode_cost"])[0].mean
+    assert (a1 - ap.mean).abs().max() > 1e-6, "a model in train() mode applies dropout in forward"
 
 
 def test_cdt_graph_replay_matches_eager():

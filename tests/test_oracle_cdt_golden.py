@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from cases import CDT_CASES, make_cdt_batch, make_cdt_params
+from cases import CDT_CASES, make_cdt_batch, make_cdt_drop, make_cdt_params
 from oracle.cdt_oracle import OracleCDT
 from oracle_util import load_golden
 
@@ -24,7 +24,7 @@ def test_cdt_oracle_matches_reference(name, dtype):
     b = make_cdt_batch(c)
     for s in range(c.steps):
         st = o.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
-                              b["episode_cost"], b["costs"])
+                              b["episode_cost"], b["costs"], drop=make_cdt_drop(c, s) if c.dropout > 0 else None)
         ref = dict(zip(keys, g["stats"][s]))
         tol = 1e-5 if s == 0 else 1e-4
         for k in keys:
