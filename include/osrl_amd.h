@@ -1,6 +1,6 @@
 /*
  * osrl_amd.h -- C ABI of libosrl_amd.so: the MI355X (gfx950) kernels behind the
- * OSRL Trainer.train_one_step() hot path (BC / CPQ / BCQ-Lag).
+ * OSRL Trainer.train_one_step() hot path (BC / CPQ / BCQ-Lag / CDT).
  *
  * The reference (liuzuxin/OSRL) is pure Python on PyTorch aten and has NO FFI seam
  * (SURVEY.md section 8b); the seam this library fills is "what aten did for the

@@ -37,6 +37,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # SimplifyCFG's store sinking merges "ring[i] = load" of sibling branches into a store through a
+           # pointer phi, after which the weight-ring arrays of mlp.hip can no longer be promoted to registers
+           # (they end up in scratch with an s_waitcnt vmcnt(0) right after the prefetch loads)
+           "-mllvm", "-sink-common-insts=false",
            "-Wno-pass-failed"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

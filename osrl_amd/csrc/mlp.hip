@@ -32,6 +32,7 @@
 //     split-K (over rows) MFMA GEMM dW = dZ^T A writing per-split slabs that the Adam kernel sums
 //     in a fixed order (deterministic, no atomics).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/osrl_amd.h"
@@ -40,10 +41,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef OSRL_PHASE_TIMING  // tools/mlp_phase.hip: per-phase cycle stamps of workgroup 0 (debug builds only)
 __device__ long long g_phase_t[4][64];
-#define PHASE_STAMP(i) \
-  if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_phase_t[threadIdx.x >> 6][i] = __builtin_readcyclecounter()
+__device__ long long g_phase_all[8192][4][16];  // every workgroup (first 8192), for phase averages
+#define PHASE_STAMP(i)                                                                                  \
+  if ((threadIdx.x & 63) == 0) {                                                                        \
+    const long long t_ = __builtin_readcyclecounter();                                                  \
+    const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                                \
+    if (wg_ < 8192 && (i) < 16) g_phase_all[wg_][threadIdx.x >> 6][i] = t_;                             \
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) g_phase_t[threadIdx.x >> 6][i] = t_;           \
+  }
+// residency log: (start, end) in 100 MHz ticks, HW_ID, XCC_ID of every workgroup
+__device__ long long g_wg_log[16384][4];
+#define WG_LOG(slot)                                                                                  \
+  if (threadIdx.x == 0) {                                                                             \
+    const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                              \
+    if (wg_ < 16384) {                                                                                \
+      g_wg_log[wg_][slot] = wall_clock64();                                                           \
+      g_wg_log[wg_][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   \
+      g_wg_log[wg_][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
+    }                                                                                                 \
+  }
 #else
 #define PHASE_STAMP(i)
+#define WG_LOG(slot)
 #endif
 
 namespace {
@@ -74,91 +93,185 @@ __device__ __forceinline__ void wave_blocks(int nblk, int wave, int* cb0, int* c
 
 // B fragment (4 consecutive k of column n) from the packed layout P[q = k/4][n][4], Np columns.
 __device__ __forceinline__ f32x4 load_bp(const float* __restrict__ P, int Np, int q, int n) {
+#ifdef OSRL_EXP_NO_BLOAD  // experiment (tools/mlp_phase.hip): no weight traffic, operands made up from the indices
+  const float v = (float)(q + n) * 1e-6f;
+  return f32x4{v, v + 1.f, v + 2.f, v + 3.f};
+#else
   return *reinterpret_cast<const f32x4*>(P + ((size_t)q * Np + n) * 4);
+#endif
+}
+// same fragment with the k-step part of the address kept scalar: P + kc*16*Np is wave-uniform (SGPR pair), the
+// lane part (kq*Np + n)*4 floats is a 32-bit VGPR offset computed once per layer -> global_load saddr+voffset
+__device__ __forceinline__ f32x4 load_bp_s(const float* __restrict__ Pk /*uniform*/, unsigned lane_off_bytes) {
+#ifdef OSRL_EXP_NO_BLOAD
+  const float v = (float)lane_off_bytes * 1e-6f;
+  return f32x4{v, v + 1.f, v + 2.f, v + 3.f};
+#else
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Pk) + lane_off_bytes);
+#endif
 }
 
+// ---- the MFMA core -------------------------------------------------------------------------------------
 // acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols n0 + c*16..)   over nk 16-deep k steps.
-// Software pipeline: a ring of STAGES B-fragment sets keeps STAGES-1 k-steps of weight loads in
-// flight (global -> VGPR, straight from L2) while the MFMAs of the current step run; the A
-// fragments (ds_read_b128 from the LDS activation tile) are prefetched one step ahead.
-template <int NRB, int CNT, int STAGES>
-__device__ __forceinline__ void layer_mm_core(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
-                                              int col0, f32x4 (&acc)[NRB][CNT], int kc0 = 0) {
+// Software pipeline: a ring of STAGES B-fragment sets keeps STAGES-1 k-steps of weight loads in flight
+// (global -> VGPR, straight from L2) while the MFMAs of the current step run; the A fragments
+// (ds_read_b128 from the LDS activation tile) are prefetched one step ahead.
+// The pipeline is split in two calls so that a layer's FIRST weight loads can be issued long before its
+// k-loop starts -- before the previous layer's barrier + epilogue, or before the input tile is staged:
+//   mm_prefetch  issues the loads of the first STAGES-1 k-steps into the ring (no waits);
+//   mm_run       runs the k-loop assuming exactly that.
+// Measured (tools/mlp_phase.hip, all workgroups): without this a wave spent 22k cycles in the 5-k-step first
+// layer (5k cycles of MFMA work) and 13k cycles staging its input with nothing else in flight.
+constexpr int kRing = 3;  // ring slots (STAGES <= kRing)
+
+// Every workgroup needs the SAME weight lines; each starts its k-walk at a different step so the
+// request streams are decorrelated (fp32 sum order changes per workgroup; fixed per (grid, tile)).
+// (wave index through readfirstlane: rot, every k index and the weight base address stay in SGPRs; a per-lane
+// k costs two 64-bit VALU multiply-adds per weight load, and VALU issue time adds to -- does not hide behind --
+// the MFMA time of the other waves on the SIMD: measured 2.7 VALU instructions per MFMA before this)
+__device__ __forceinline__ int k_rot(int nk) {
+  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  return (int)((blockIdx.x * 5u + blockIdx.y * 3u + w) % (unsigned)nk);
+}
+__device__ __forceinline__ int k_at(int kc, int rot, int nk, int kc0) {  // nk steps starting at kc0 (split-K sub-range)
+  const int k = kc + rot;
+  return kc0 + (k >= nk ? k - nk : k);
+}
+
+// experiment switches of tools/mlp_phase.hip (never defined in the product build)
+#ifdef OSRL_EXP_NO_MFMA
+__device__ __forceinline__ f32x4 EXP_MFMA(float a, float b, f32x4 c) {
+  c[0] += a * b;  // one VALU FMA keeps the operands alive; no matrix instruction
+  return c;
+}
+#else
+#define EXP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
+#ifdef OSRL_EXP_NO_AREAD
+#define EXP_AREAD(p) (f32x4{(float)(size_t)(p), 1.f, 2.f, 3.f})
+#else
+#define EXP_AREAD(p) (*reinterpret_cast<const f32x4*>(p))
+#endif
+
+template <int RW, int CNT, int STAGES>
+__device__ __forceinline__ void mm_prefetch(f32x4 (&b)[kRing][RW], int nk, const float* __restrict__ P, int Np, int col0,
+                                            int kc0 = 0) {
+  static_assert(CNT <= RW && STAGES <= kRing, "ring too small");
+  const int lane = threadIdx.x & 63;
+  const unsigned lane_off = (unsigned)(((lane >> 4) * Np + col0 + (lane & 15)) * 16);  // bytes
+  const int rot = k_rot(nk);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) {
+    const int kc = k_at(s < nk ? s : nk - 1, rot, nk, kc0);
+    const float* __restrict__ Pk = P + (size_t)kc * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[s][c] = load_bp_s(Pk, lane_off + c * 256);
+  }
+}
+
+// Only the first CNT (<= AW) column blocks of acc are touched, so a wave with fewer blocks runs a dense loop
+// on the same accumulator array.
+template <int NRB, int AW, int RW, int CNT, int STAGES>
+__device__ __forceinline__ void mm_run(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
+                                       f32x4 (&acc)[NRB][AW], f32x4 (&b)[kRing][RW], int kc0 = 0) {
+  static_assert(CNT <= AW && CNT <= RW && STAGES <= kRing, "tile shapes");
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
-  const int n0 = col0 + m;
-  // Every workgroup needs the SAME weight lines; each starts its k-walk at a different step so the
-  // request streams are decorrelated (fp32 sum order changes per workgroup; fixed per (grid, tile)).
-  const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u + (threadIdx.x >> 6)) % (unsigned)nk);
-  auto kstep = [&](int kc) {  // nk steps starting at kc0 (split-K callers pass a sub-range)
-    int k = kc + rot;
-    return kc0 + (k >= nk ? k - nk : k);
-  };
-  f32x4 b[STAGES][CNT];
+  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
+  const int rot = k_rot(nk);
   f32x4 a[2][NRB];
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) {
-    const int kc = kstep(s < nk ? s : nk - 1);
+  for (int rb = 0; rb < NRB; ++rb)
+    a[0][rb] = EXP_AREAD(arow + rb * 16 * lda + k_at(0, rot, nk, kc0) * 16);
+  // one k-step with compile-time ring / double-buffer slots (S = step index modulo U)
+  auto step = [&](auto s_c, int kc) {
+    constexpr int s = decltype(s_c)::value;
+    {  // issue the loads of k-step kc + STAGES - 1 into the ring slot freed by step kc - 1
+      int kl = kc + STAGES - 1;
+      kl = k_at(kl < nk ? kl : nk - 1, rot, nk, kc0);
+      const float* __restrict__ Pk = P + (size_t)kl * 16 * Np;
 #pragma unroll
-    for (int c = 0; c < CNT; ++c) b[s][c] = load_bp(P, Np, kc * 4 + kq, n0 + c * 16);
+      for (int c = 0; c < CNT; ++c) b[(s + STAGES - 1) % STAGES][c] = load_bp_s(Pk, lane_off + c * 256);
+      const int ka = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, kc0);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) a[(s + 1) & 1][rb] = EXP_AREAD(arow + rb * 16 * lda + ka * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb][c] = EXP_MFMA(a[s & 1][rb][t], b[s % STAGES][c][t], acc[rb][c]);
+  };
+  // Main loop: groups of U = 2*STAGES steps with NO per-step control flow (every taken branch costs the wave an
+  // instruction-buffer refill: with a conditional per unrolled step a lone wave reached 74% MFMA issue in a
+  // load-free loop, tools/mlp_phase.hip); the < U leftover steps run in a branchy tail.
+  constexpr int U = 2 * STAGES;
+  using std::integral_constant;
+  int kc = 0;
+  for (; kc + U <= nk; kc += U) {
+    step(integral_constant<int, 0>{}, kc);
+    step(integral_constant<int, 1>{}, kc + 1);
+    step(integral_constant<int, 2>{}, kc + 2);
+    step(integral_constant<int, 3>{}, kc + 3);
+    if constexpr (U > 4) {
+      step(integral_constant<int, 4>{}, kc + 4);
+      step(integral_constant<int, 5>{}, kc + 5);
+    }
   }
-#pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kstep(0) * 16);
-  for (int kb = 0; kb < nk; kb += 2 * STAGES) {
-#pragma unroll
-    for (int s = 0; s < 2 * STAGES; ++s) {
-      const int kc = kb + s;
-      if (kc < nk) {
-        {  // issue the loads of k-step kc + STAGES - 1 into the ring slot freed by step kc - 1
-          int kl = kc + STAGES - 1;
-          kl = kstep(kl < nk ? kl : nk - 1);
-#pragma unroll
-          for (int c = 0; c < CNT; ++c) b[(s + STAGES - 1) % STAGES][c] = load_bp(P, Np, kl * 4 + kq, n0 + c * 16);
-          const int ka = kstep(kc + 1 < nk ? kc + 1 : kc);
-#pragma unroll
-          for (int rb = 0; rb < NRB; ++rb)
-            a[(s + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ka * 16);
+  if (kc < nk) {
+    step(integral_constant<int, 0>{}, kc);
+    if (kc + 1 < nk) {
+      step(integral_constant<int, 1>{}, kc + 1);
+      if (kc + 2 < nk) {
+        step(integral_constant<int, 2>{}, kc + 2);
+        if constexpr (U > 4) {
+          if (kc + 3 < nk) {
+            step(integral_constant<int, 3>{}, kc + 3);
+            if (kc + 4 < nk) step(integral_constant<int, 4>{}, kc + 4);
+          }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < CNT; ++c)
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-              acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][rb][t], b[s % STAGES][c][t], acc[rb][c], 0, 0, 0);
       }
     }
   }
 }
 
-// cnt (<= NCB) column blocks starting at column col0 (= first block * 16 [+ dx_col0])
 template <int NRB, int NCB>
-__device__ __forceinline__ void layer_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
-                                         int col0, int cnt, f32x4 (&acc)[NRB][NCB]) {
-  constexpr int STAGES = (NRB * NCB >= 16) ? 2 : 3;  // short k-steps need a deeper load ring
+constexpr int mm_stages() { return (NRB * NCB >= 16 || NCB >= 7) ? 2 : 3; }  // short k-steps need a deeper load ring
+
+// cnt (<= NCB) column blocks starting at column col0 (= first block * 16 [+ dx_col0]); 0 = idle wave
+template <int NRB, int NCB>
+__device__ __forceinline__ void layer_prefetch(f32x4 (&ring)[kRing][NCB], int nk, const float* __restrict__ P, int Np,
+                                               int col0, int cnt) {
+  constexpr int ST = mm_stages<NRB, NCB>();
   if (cnt == NCB) {
-    layer_mm_core<NRB, NCB, STAGES>(lds, lda, nk, P, Np, col0, acc);
+    mm_prefetch<NCB, NCB, ST>(ring, nk, P, Np, col0);
+  } else if (NCB > 2 && cnt == NCB - 1) {
+    mm_prefetch<NCB, (NCB > 2 ? NCB - 1 : 1), ST>(ring, nk, P, Np, col0);
+  } else if (cnt > 0) {
+    mm_prefetch<NCB, 1, 3>(ring, nk, P, Np, col0);  // ragged wave: first block only
+  }
+}
+
+// requires layer_prefetch(ring, same arguments) to have been issued by this wave
+template <int NRB, int NCB>
+__device__ __forceinline__ void layer_run(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
+                                          int col0, int cnt, f32x4 (&acc)[NRB][NCB], f32x4 (&ring)[kRing][NCB]) {
+  constexpr int ST = mm_stages<NRB, NCB>();
+  if (cnt == NCB) {
+    mm_run<NRB, NCB, NCB, NCB, ST>(lds, lda, nk, P, Np, col0, acc, ring);
   } else if (NCB > 2 && cnt == NCB - 1) {
     // balanced split of e.g. 25 column blocks as 7/6/6/6: the 6-block waves keep a dense k-loop
-    constexpr int C1 = NCB > 2 ? NCB - 1 : 1;
-    f32x4 t[NRB][C1];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int c = 0; c < C1; ++c) t[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    layer_mm_core<NRB, C1, STAGES>(lds, lda, nk, P, Np, col0, t);
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int c = 0; c < C1; ++c) acc[rb][c] = t[rb][c];
+    mm_run<NRB, NCB, NCB, (NCB > 2 ? NCB - 1 : 1), ST>(lds, lda, nk, P, Np, col0, acc, ring);
   } else {
     // ragged wave (few column blocks, e.g. the 1-wide Q head): one block at a time
     for (int c = 0; c < cnt; ++c) {
       f32x4 t[NRB][1];
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      layer_mm_core<NRB, 1, 3>(lds, lda, nk, P, Np, col0 + c * 16, t);
+      if (c > 0) mm_prefetch<NCB, 1, 3>(ring, nk, P, Np, col0 + c * 16);
+      mm_run<NRB, 1, NCB, 1, 3>(lds, lda, nk, P, Np, col0 + c * 16, t, ring);
 #pragma unroll
       for (int cc = 0; cc < NCB; ++cc)
         if (cc == c) {
@@ -173,17 +286,32 @@ __device__ __forceinline__ void layer_mm(const float* lds, int lda, int nk, cons
 // walking all of K alone, the 4 waves split K; partial tiles are summed through the (free) LDS
 // activation buffer.  On return lds[row][c], c < nblk*16, holds the raw sums (no bias/activation).
 // Requires lda >= 64 and nk >= 4.  Contains the barriers that protect the in-place overwrite.
-template <int NRB>
-__device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk, const float* __restrict__ P, int Np,
-                                                    int col_off, int nblk, int wave) {
-  const int lane = threadIdx.x & 63;
-  const int parts = 4 / nblk;            // waves per column block (nblk is 1 or 2)
+struct NarrowPart {
+  int col, k_lo, k_n;
+};
+__device__ __forceinline__ NarrowPart narrow_part(int nk, int col_off, int nblk, int wave) {
+  const int parts = 4 / nblk;  // waves per column block (nblk is 1 or 2)
   const int blk = wave / parts, part = wave - blk * parts;
   const int k_lo = (nk * part) / parts, k_hi = (nk * (part + 1)) / parts;
+  return NarrowPart{col_off + blk * 16, k_lo, k_hi - k_lo};
+}
+template <int NCB>
+__device__ __forceinline__ void narrow_prefetch(f32x4 (&ring)[kRing][NCB], int nk, const float* __restrict__ P, int Np,
+                                                int col_off, int nblk, int wave) {
+  const NarrowPart np = narrow_part(nk, col_off, nblk, wave);
+  if (np.k_n > 0) mm_prefetch<NCB, 1, 3>(ring, np.k_n, P, Np, np.col, np.k_lo);
+}
+// requires narrow_prefetch(ring, same arguments)
+template <int NRB, int NCB>
+__device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk, const float* __restrict__ P, int Np,
+                                                    int col_off, int nblk, int wave, f32x4 (&ring)[kRing][NCB]) {
+  const int lane = threadIdx.x & 63;
+  const int parts = 4 / nblk;
+  const NarrowPart np = narrow_part(nk, col_off, nblk, wave);
   f32x4 t[NRB][1];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (k_hi > k_lo) layer_mm_core<NRB, 1, 3>(lds, lda, k_hi - k_lo, P, Np, col_off + blk * 16, t, k_lo);
+  if (np.k_n > 0) mm_run<NRB, 1, NCB, 1, 3>(lds, lda, np.k_n, P, Np, np.col, t, ring, np.k_lo);
   __syncthreads();  // all reads of the input activations are done
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
@@ -244,6 +372,41 @@ __device__ __forceinline__ void tile_to_global(const float* lds, int lda, int BM
   }
 }
 
+// activation (+ scale) of one wave's accumulators into the LDS tile (in place: next layer's input).  The bias is
+// already in the accumulators (they are initialised with it), the scale and the k-padding select are compiled
+// out when not needed: VALU instructions do not co-execute with the other waves' MFMAs on a SIMD
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every PMC pass), so each one here is paid in MFMA issue slots.
+template <int NRB, int NCB, int ACT, bool SCALE, bool RAGGED>
+__device__ __forceinline__ void fwd_epilogue_core(float* lds, int lda, const f32x4 (&acc)[NRB][NCB], int cb0, int cnt,
+                                                  int N, float oscale, int lane) {
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) {
+    if (c < cnt) {
+      const int col = (cb0 + c) * 16 + (lane & 15);
+      const bool live = col < N;
+      float* dst = lds + ((lane >> 4) * 4) * lda + col;
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = act_fwd(ACT, acc[rb][c][r]);
+          if (SCALE) v *= oscale;
+          if (RAGGED) v = live ? v : 0.f;  // zero the k-padding of the next layer
+          dst[(rb * 16 + r) * lda] = v;
+        }
+      }
+    }
+  }
+}
+template <int NRB, int NCB, int ACT>
+__device__ __forceinline__ void fwd_epilogue(float* lds, int lda, const f32x4 (&acc)[NRB][NCB], int cb0, int cnt, int N,
+                                             float oscale, int lane) {
+  if (oscale == 1.0f && (N & 15) == 0)
+    fwd_epilogue_core<NRB, NCB, ACT, false, false>(lds, lda, acc, cb0, cnt, N, oscale, lane);
+  else
+    fwd_epilogue_core<NRB, NCB, ACT, true, true>(lds, lda, acc, cb0, cnt, N, oscale, lane);
+}
+
 struct FwdArgs {
   osrl_mlp_t net;
   osrl_rows_t in;
@@ -251,8 +414,15 @@ struct FwdArgs {
   int32_t lda;
 };
 
+// waves per SIMD the register allocator must leave room for (512 VGPRs / waves): the accumulators need
+// NRB*NCB*4 registers and the weight ring STAGES*NCB*4; without the hint the allocator drifts to 170-200
+// registers (AGPR copies of loop invariants) and one fewer workgroup fits per CU
+constexpr int waves_per_simd(int nrb, int ncb) { return nrb * ncb >= 14 ? 2 : nrb * ncb >= 4 ? 3 : 4; }
+// the backward kernel also holds the prefetched activations of the epilogue: one wave less
+constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
+
 template <int NRB, int NCB>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -262,7 +432,22 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
   const int rows = a.in.rows, lda = a.lda;
   const int L = a.net.n_layers;
 
+  WG_LOG(0);
   PHASE_STAMP(0);
+  // first weight loads of layer l (issued before the previous layer's epilogue / before the input is staged)
+  f32x4 ring[kRing][NCB];
+  auto begin_layer = [&](int l) {
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    const int nblk = (N + 15) >> 4, nk = round16(K) >> 4;
+    if (nblk <= 2 && nk >= 4 && lda >= 64) {
+      narrow_prefetch<NCB>(ring, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave);
+    } else {
+      int cb0, cnt;
+      wave_blocks(nblk, wave, &cb0, &cnt);
+      layer_prefetch<NRB, NCB>(ring, nk, a.net.Wf[e][l], round16(N), cb0 * 16, cnt);
+    }
+  };
+  begin_layer(0);
   {  // stage cat(src0[map0(r)], src1[map1(r)]) zero-padded to a multiple of 16 columns.
      // 16 lanes walk one row (64-byte segments), 16 rows per pass; every load of a pass is issued
      // before the first LDS store (branch-free clamped addresses), so the latencies overlap.
@@ -309,7 +494,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
     const int nk = round16(K) >> 4;
     if (nblk <= 2 && nk >= 4 && lda >= 64) {
       // narrow layer: split K over the 4 waves, then bias/activation on the summed tile in LDS
-      narrow_layer_splitk<NRB>(lds, lda, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave);
+      narrow_layer_splitk<NRB, NCB>(lds, lda, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave, ring);
+      if (l + 1 < L) begin_layer(l + 1);
       PHASE_STAMP(2 + 4 * l);
       PHASE_STAMP(3 + 4 * l);
       const int ncol = nblk * 16;
@@ -329,34 +515,32 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const FwdArgs a) {
         bv[c] = bias[ok ? col : 0];
         bv[c] = ok ? bv[c] : 0.f;
       }
-      f32x4 acc[NRB][NCB];
-      zero_acc<NRB, NCB>(acc);
-      if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, nk, a.net.Wf[e][l], round16(N), cb0 * 16, cnt, acc);
+      f32x4 acc[NRB][NCB];  // start from the bias: no add in the epilogue
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{bv[c], bv[c], bv[c], bv[c]};
+      if (cnt > 0) layer_run<NRB, NCB>(lds, lda, nk, a.net.Wf[e][l], round16(N), cb0 * 16, cnt, acc, ring);
+      if (l + 1 < L) begin_layer(l + 1);  // the ring is free again: overlap the next layer's first fetch with the epilogue
       PHASE_STAMP(2 + 4 * l);
       __syncthreads();  // every wave finished reading the previous activations
       PHASE_STAMP(3 + 4 * l);
-#pragma unroll
-      for (int c = 0; c < NCB; ++c) {
-        if (c < cnt) {
-          const int col = (cb0 + c) * 16 + (lane & 15);
-#pragma unroll
-          for (int rb = 0; rb < NRB; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = rb * 16 + (lane >> 4) * 4 + r;
-              const float v = act_fwd(act, acc[rb][c][r] + bv[c]) * oscale;
-              lds[row * lda + col] = col < N ? v : 0.f;  // zero the k-padding of the next layer
-            }
-          }
-        }
-      }
+      // the activation switch is hoisted out of the element loop: with a per-element runtime switch every one of
+      // the NRB*NCB*4 values jumped over an inlined tanhf body (4 scalar branches each, ~14 KB of sparse code):
+      // measured 10-11k cycles per epilogue vs 17k for the whole first-layer k-loop (tools/mlp_phase.hip)
+      if (act == OSRL_ACT_RELU)
+        fwd_epilogue<NRB, NCB, OSRL_ACT_RELU>(lds, lda, acc, cb0, cnt, N, oscale, lane);
+      else if (act == OSRL_ACT_TANH)
+        fwd_epilogue<NRB, NCB, OSRL_ACT_TANH>(lds, lda, acc, cb0, cnt, N, oscale, lane);
+      else
+        fwd_epilogue<NRB, NCB, OSRL_ACT_ID>(lds, lda, acc, cb0, cnt, N, oscale, lane);
     }
     PHASE_STAMP(4 + 4 * l);
     __syncthreads();
     float* save = a.out.h[e][l];
     if (save) tile_to_global(lds, lda, BM, N, save, row0, rows);
     PHASE_STAMP(5 + 4 * l);
-  }
+  }  WG_LOG(1);
 }
 
 struct BwdArgs {
@@ -367,7 +551,7 @@ struct BwdArgs {
 };
 
 template <int NRB, int NCB>
-__global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(256, waves_per_simd_bwd(NRB, NCB)) void mlp_bwd_dz_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -377,6 +561,27 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
   const int rows = a.rows, lda = a.lda;
   const int L = a.net.n_layers;
 
+  // steps: l = L-1 .. 1 (dH_{l-1} = dZ_l W_l), then step 0 = the dX slice; begin_step issues a step's first weight loads
+  f32x4 ring[kRing][NCB];
+  auto begin_step = [&](int l) {
+    if (l >= 1) {
+      const int K = a.net.dims[l + 1], N = a.net.dims[l];
+      int cb0, cnt;
+      wave_blocks((N + 15) >> 4, wave, &cb0, &cnt);
+      layer_prefetch<NRB, NCB>(ring, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt);
+    } else if (a.g.dx[e]) {
+      const int nblk = (a.g.dx_cols + 15) >> 4, nk = round16(a.net.dims[1]) >> 4;
+      const int Npb = round16(a.net.dims[0]) + 16;
+      if (nblk <= 2 && nk >= 4 && lda >= 64) {
+        narrow_prefetch<NCB>(ring, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave);
+      } else {
+        int cb0, cnt;
+        wave_blocks(nblk, wave, &cb0, &cnt);
+        layer_prefetch<NRB, NCB>(ring, nk, a.net.Wb[e][0], Npb, a.g.dx_col0 + cb0 * 16, cnt);
+      }
+    }
+  };
+  begin_step(L - 1);
   {  // dZ_{L-1} = dY * out_scale * act'(Y / out_scale)
     const float oscale = a.net.out_scale, inv_oscale = 1.0f / a.net.out_scale;
     const int NL = a.net.dims[L], NLp = round16(NL);
@@ -427,29 +632,40 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
     f32x4 acc[NRB][NCB];
     zero_acc<NRB, NCB>(acc);
     // packed W^T: contraction over the layer's outputs (K), columns = the layer's inputs (N) (+16 pad)
-    if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt, acc);
+    if (cnt > 0) layer_run<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt, acc, ring);
+    begin_step(l - 1);
     __syncthreads();
+    // activation switch hoisted out of the element loop (see fwd_epilogue)
+    auto epilogue = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-      if (c < cnt) {
-        const int col = (cb0 + c) * 16 + (lane & 15);
+      for (int c = 0; c < NCB; ++c) {
+        if (c < cnt) {
+          const int col = (cb0 + c) * 16 + (lane & 15);
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
+          for (int rb = 0; rb < NRB; ++rb) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = rb * 16 + (lane >> 4) * 4 + r;
-            const int gr = row0 + row;
-            float v = 0.f;
-            if (PREFETCH_H) {
-              v = (col < N && gr < rows) ? acc[rb][c][r] * act_bwd(act, hv[PREFETCH_H ? rb : 0][PREFETCH_H ? c : 0][r]) : 0.f;
-            } else if (col < N && gr < rows) {
-              v = acc[rb][c][r] * act_bwd(act, h[(size_t)gr * N + col]);
+            for (int r = 0; r < 4; ++r) {
+              const int row = rb * 16 + (lane >> 4) * 4 + r;
+              const int gr = row0 + row;
+              float v = 0.f;
+              if (PREFETCH_H) {
+                v = (col < N && gr < rows) ? acc[rb][c][r] * act_bwd(ACT, hv[PREFETCH_H ? rb : 0][PREFETCH_H ? c : 0][r]) : 0.f;
+              } else if (col < N && gr < rows) {
+                v = acc[rb][c][r] * act_bwd(ACT, h[(size_t)gr * N + col]);
+              }
+              lds[row * lda + col] = v;
             }
-            lds[row * lda + col] = v;
           }
         }
       }
-    }
+    };
+    if (act == OSRL_ACT_RELU)
+      epilogue(std::integral_constant<int, OSRL_ACT_RELU>{});
+    else if (act == OSRL_ACT_TANH)
+      epilogue(std::integral_constant<int, OSRL_ACT_TANH>{});
+    else
+      epilogue(std::integral_constant<int, OSRL_ACT_ID>{});
     __syncthreads();
     if (a.g.dz[e][l - 1]) tile_to_global(lds, lda, BM, N, a.g.dz[e][l - 1], row0, rows);
   }
@@ -462,14 +678,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
     const int Npb = round16(a.net.dims[0]) + 16;
     float* __restrict__ dx = a.g.dx[e];
     if (nblk <= 2 && nk >= 4 && lda >= 64) {
-      narrow_layer_splitk<NRB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave);
+      narrow_layer_splitk<NRB, NCB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave, ring);
       tile_to_global(lds, lda, BM, nc, dx, row0, rows);
     } else {
       int cb0, cnt;
       wave_blocks(nblk, wave, &cb0, &cnt);
       f32x4 acc[NRB][NCB];
       zero_acc<NRB, NCB>(acc);
-      if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0 + cb0 * 16, cnt, acc);
+      if (cnt > 0) layer_run<NRB, NCB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0 + cb0 * 16, cnt, acc, ring);
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
         if (c < cnt) {
@@ -488,104 +704,137 @@ __global__ __launch_bounds__(256) void mlp_bwd_dz_kernel(const BwdArgs a) {
   }
 }
 
-// ---- dW = dZ^T A, db = colsum(dZ): split-K over rows, one 64x64 tile per wave ------------------
+// ---- dW = dZ^T A, db = colsum(dZ) ---------------------------------------------------------------
+// One workgroup = one 64x64 tile of one layer's dW for one split of the batch rows (blockIdx.y).  The 4 waves
+// split that row range again (the contraction runs over rows), each accumulating a full 64x64 partial in
+// registers with the k-slot trick (A^T / B fragments are 4 scalar loads of 64 B-contiguous lanes each);
+// the fragments of k-step i+1 are fetched while the 64 MFMAs of step i run (double buffer).  The 4 partials
+// are summed through LDS in a fixed order and ONE slab tile is written, coalesced: 4x fewer slab bytes for
+// the Adam kernel to re-read than one slab per wave.
+constexpr int kDwLd = 65;                                     // LDS row stride of a 64x64 partial
+constexpr size_t kDwLds = sizeof(float) * (4 * 64 * kDwLd + 4 * 64);
+
+struct DwFrag {
+  f32x4 a[4], b[4];
+};
+
+__device__ __forceinline__ void dw_load(DwFrag& f, const float* __restrict__ dz, const float* __restrict__ av,
+                                        size_t ldz, size_t lda_g, int r0, int r_end, int o0, int i0, int out, int in,
+                                        int nob, int nib, int m, int kq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = r0 + 4 * kq + t;
+    const bool rok = r < r_end;
+    const size_t rc = (size_t)(rok ? r : r_end - 1);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const int o = o0 + ob * 16 + m;
+      const bool ok = rok && ob < nob && o < out;
+      const float v = dz[rc * ldz + (o < out ? o : 0)];
+      f.a[ob][t] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const int i = i0 + ib * 16 + m;
+      const bool ok = rok && ib < nib && i < in;
+      const float v = av[rc * lda_g + (i < in ? i : 0)];
+      f.b[ib][t] = ok ? v : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void dw_mma(f32x4 (&acc)[4][4], float (&dbacc)[4], const DwFrag& f, int nob, int nib,
+                                       bool want_db) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      if (ob < nob) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+          if (ib < nib) acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ob][t], f.b[ib][t], acc[ob][ib], 0, 0, 0);
+      }
+    }
+  }
+  if (want_db) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) dbacc[ob] += (f.a[ob][0] + f.a[ob][1]) + (f.a[ob][2] + f.a[ob][3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __restrict__ entries,
                                                       const int32_t* __restrict__ items, int n_items, int rows,
                                                       int rows_per_split, float* __restrict__ slabs,
                                                       int64_t slab_stride) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= n_items) return;  // no barriers in this kernel
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][64][kDwLd] partials + [4][64] bias partials
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int item = blockIdx.x;
   const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
   const osrl_dw_entry_t E = entries[ei];
   const int out = E.out, in = E.in;
   const size_t ldz = E.ldz > 0 ? (size_t)E.ldz : (size_t)out, lda_g = E.lda > 0 ? (size_t)E.lda : (size_t)in;
   const int o0 = ot * 64, i0 = it * 64;
   const int s = blockIdx.y;
-  const int r_begin = s * rows_per_split;
-  int r_end = r_begin + rows_per_split;
+  const int rpw = rows_per_split >> 2;  // rows per wave (host keeps rows_per_split a multiple of 64)
+  const int r_begin = s * rows_per_split + wave * rpw;
+  int r_end = r_begin + rpw;
   r_end = r_end > rows ? rows : r_end;
   const int m = lane & 15, kq = lane >> 4;
   int nob = (out - o0 + 15) >> 4;
   nob = nob > 4 ? 4 : nob;
   int nib = (in - i0 + 15) >> 4;
   nib = nib > 4 ? 4 : nib;
+  const bool want_db = it == 0;
 
   f32x4 acc[4][4];
   zero_acc<4, 4>(acc);
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ dz = E.dz;
   const float* __restrict__ av = E.a;
-  for (int r0 = r_begin; r0 < r_end; r0 += 16) {
-    f32x4 af[4], bf[4];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-      af[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ob < nob) {
-        const int o = o0 + ob * 16 + m;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int r = r0 + 4 * kq + t;
-          if (o < out && r < r_end) af[ob][t] = dz[(size_t)r * ldz + o];
-        }
-      }
-    }
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
-      bf[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ib < nib) {
-        const int i = i0 + ib * 16 + m;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int r = r0 + 4 * kq + t;
-          if (i < in && r < r_end) bf[ib][t] = av[(size_t)r * lda_g + i];
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int ob = 0; ob < 4; ++ob) {
-        if (ob < nob) {
-#pragma unroll
-          for (int ib = 0; ib < 4; ++ib)
-            if (ib < nib)
-              acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ob][t], bf[ib][t], acc[ob][ib], 0, 0, 0);
-        }
-      }
-    }
-    if (it == 0) {
-#pragma unroll
-      for (int ob = 0; ob < 4; ++ob) dbacc[ob] += (af[ob][0] + af[ob][1]) + (af[ob][2] + af[ob][3]);
-    }
-  }
-  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
-#pragma unroll
-  for (int ob = 0; ob < 4; ++ob) {
-    if (ob < nob) {
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib) {
-        if (ib < nib) {
-          const int i = i0 + ib * 16 + m;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int o = o0 + ob * 16 + kq * 4 + r;
-            if (o < out && i < in) slab[E.w_off + (size_t)o * in + i] = acc[ob][ib][r];
-          }
-        }
+  if (r_begin < r_end) {
+    DwFrag f0, f1;
+    dw_load(f0, dz, av, ldz, lda_g, r_begin, r_end, o0, i0, out, in, nob, nib, m, kq);
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+      if (r0 + 16 < r_end) dw_load(f1, dz, av, ldz, lda_g, r0 + 16, r_end, o0, i0, out, in, nob, nib, m, kq);
+      dw_mma(acc, dbacc, f0, nob, nib, want_db);
+      if (r0 + 16 < r_end) {
+        if (r0 + 32 < r_end) dw_load(f0, dz, av, ldz, lda_g, r0 + 32, r_end, o0, i0, out, in, nob, nib, m, kq);
+        dw_mma(acc, dbacc, f1, nob, nib, want_db);
       }
     }
   }
-  if (it == 0) {
+  // ---- 4 partials -> LDS -> fixed-order sum -> one coalesced slab tile
+  float* mine = red + wave * 64 * kDwLd;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(ob * 16 + kq * 4 + r) * kDwLd + ib * 16 + m] = acc[ob][ib][r];
+  if (want_db) {
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
       float v = dbacc[ob];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      const int o = o0 + ob * 16 + m;
-      if (ob < nob && kq == 0 && o < out) slab[E.b_off + o] = v;
+      if (kq == 0) red[4 * 64 * kDwLd + wave * 64 + ob * 16 + m] = v;
     }
+  }
+  __syncthreads();
+  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+  const int il = tid & 63;
+#pragma unroll 4
+  for (int ol = tid >> 6; ol < 64; ol += 4) {
+    const int off = ol * kDwLd + il;
+    const float v = ((red[off] + red[64 * kDwLd + off]) + red[2 * 64 * kDwLd + off]) + red[3 * 64 * kDwLd + off];
+    const int o = o0 + ol, i = i0 + il;
+    if (o < out && i < in) slab[E.w_off + (size_t)o * in + i] = v;
+  }
+  if (want_db && tid < 64) {
+    const float* db = red + 4 * 64 * kDwLd;
+    const float v = ((db[tid] + db[64 + tid]) + db[128 + tid]) + db[192 + tid];
+    if (o0 + tid < out) slab[E.b_off + o0 + tid] = v;
   }
 }
 
@@ -614,6 +863,21 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * BM, M = a.M, K = a.K, N = a.N, lda = a.lda;
   const int Kp = round16(K);
+  const int nk = Kp >> 4;
+  const int nblk_tot = (N + 15) >> 4;
+  constexpr int GB = 4 * NCB;  // column blocks per workgroup
+  const int gb0 = blockIdx.y * GB;
+  int nblk = nblk_tot - gb0;
+  nblk = nblk > GB ? GB : nblk;
+  const bool narrow = nblk_tot <= 2 && nk >= 4 && lda >= 64;
+  int cb0 = 0, cnt = 0;
+  f32x4 ring[kRing][NCB];
+  if (narrow) {  // first weight loads go out before the A tile is staged
+    narrow_prefetch<NCB>(ring, nk, a.P, a.Np, a.col0, nblk_tot, wave);
+  } else {
+    wave_blocks(nblk, wave, &cb0, &cnt);
+    layer_prefetch<NRB, NCB>(ring, nk, a.P, a.Np, a.col0 + (gb0 + cb0) * 16, cnt);
+  }
   {  // stage A[row0 : row0+BM, 0:K] zero padded; 16 lanes per row, float4 when the rows are 16-B aligned
     const int cl = tid & 15, rl = tid >> 4;
     const bool vec = ((K & 3) == 0) && ((a.lda_g & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
@@ -658,20 +922,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a) {
     }
     __syncthreads();
   }
-  const int nk = Kp >> 4;
-  const int nblk_tot = (N + 15) >> 4;
-  constexpr int GB = 4 * NCB;  // column blocks per workgroup
-  const int gb0 = blockIdx.y * GB;
-  int nblk = nblk_tot - gb0;
-  nblk = nblk > GB ? GB : nblk;
-  if (nblk_tot <= 2 && nk >= 4 && lda >= 64) {
-    narrow_layer_splitk<NRB>(lds, lda, nk, a.P, a.Np, a.col0, nblk_tot, wave);
+  if (narrow) {
+    narrow_layer_splitk<NRB, NCB>(lds, lda, nk, a.P, a.Np, a.col0, nblk_tot, wave, ring);
   } else {
-    int cb0, cnt;
-    wave_blocks(nblk, wave, &cb0, &cnt);
     f32x4 acc[NRB][NCB];
     zero_acc<NRB, NCB>(acc);
-    if (cnt > 0) layer_mm<NRB, NCB>(lds, lda, nk, a.P, a.Np, a.col0 + (gb0 + cb0) * 16, cnt, acc);
+    if (cnt > 0) layer_run<NRB, NCB>(lds, lda, nk, a.P, a.Np, a.col0 + (gb0 + cb0) * 16, cnt, acc, ring);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
@@ -892,10 +1148,14 @@ extern "C" int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int3
                                     void* stream) {
   if (!d_entries || !d_items || n_items < 1 || rows < 1 || n_splits < 1 || !slabs) return -1;
   int rps = (rows + n_splits - 1) / n_splits;
-  rps = (rps + 15) & ~15;
-  dim3 grid((n_items + 3) / 4, n_splits, 1);
+  rps = (rps + 63) & ~63;  // 4 waves x whole 16-row k-steps
+  dim3 grid(n_items, n_splits, 1);
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_entries, d_items, n_items, rows,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel),  // 66 KB dynamic LDS: opt in
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwLds);
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(256), kDwLds, (hipStream_t)stream, d_entries, d_items, n_items, rows,
                      rps, slabs, slab_stride);
   return (int)hipGetLastError();
 }

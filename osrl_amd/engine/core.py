@@ -378,9 +378,10 @@ class DwPlan:
         self.d_items = torch.tensor(items, dtype=torch.int32, device=device)
         self._keep = [e[0] for e in entries] + [e[1] for e in entries] + [e[6:] for e in entries if len(e) > 6]
         if n_splits is None:
-            # fill ~2 waves of workgroups over 256 CUs, keep >= 64 rows per split
-            wgs = (self.n_items + 3) // 4
-            n_splits = max(1, min((512 + wgs - 1) // wgs, max(rows // 64, 1), 32))
+            # one workgroup per (tile, split): aim at >= 4 rounds of the 512 resident workgroups (2 per CU at
+            # 66 KB LDS) so the tail round is small, but keep >= 64 rows (4 k-steps) per wave; each split costs
+            # one slab write here and one slab read in the Adam kernel
+            n_splits = max(1, min((2048 + self.n_items - 1) // self.n_items, max(rows // 256, 1), 32))
         self.n_splits = n_splits
         group.ensure_slabs(n_splits)
 

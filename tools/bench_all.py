@@ -50,9 +50,11 @@ def main():
     args3 = (f(B, 33), f(B, 33), f(B, 8).clamp(-1, 1), f(B), (torch.rand(B, device=DEV) < 0.1).float(),
              (torch.rand(B, device=DEV) < 0.01).float())
     run("C3 BCQL (33,8)  B=4096", lambda: tr.train_one_step(*args3), 100, 10)
-    # C5 CDT (11,3) T=20 E=256 8 heads 3 layers B=1024 (dropout 0)
+    # C5 CDT (11,3) T=20 E=256 8 heads 3 layers B=1024, dropout 0.1 (cdt_configs.py:28-30; pass a 3rd argv to override)
     B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 20
-    m = CDT(11, 3, 1.0, seq_len=T, episode_len=1000, embedding_dim=256, num_layers=3, num_heads=8, use_rew=True,
+    pdrop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+    m = CDT(11, 3, 1.0, seq_len=T, episode_len=1000, embedding_dim=256, num_layers=3, num_heads=8,
+            attention_dropout=pdrop, residual_dropout=pdrop, embedding_dropout=pdrop, use_rew=True,
             use_cost=True, cost_transform=True, stochastic=True, target_entropy=-3, device=DEV)
     tr = CDTTrainer(m, None, None, learning_rate=1e-4, weight_decay=1e-4, clip_grad=0.25, lr_warmup_steps=500,
                     loss_cost_weight=0.02, stats_mode="none")

@@ -3,6 +3,7 @@
 #include "../osrl_amd/csrc/mlp.hip"
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 
 static int r16(int x) { return (x + 15) / 16 * 16; }
 
@@ -62,6 +63,102 @@ int main(int argc, char** argv) {
     printf("wave %d:", w);
     for (int i = 0; i < 13; ++i) printf(" %s=%lld", names[i], t[w][i + 1] - t[w][i]);
     printf("  total=%lld\n", t[w][13] - t[w][0]);
+  }
+  {  // phase durations averaged over every workgroup (wave 0..3)
+    static long long pa[8192][4][16];
+    (void)hipMemcpyFromSymbol(pa, HIP_SYMBOL(g_phase_all), sizeof(pa));
+    const int nw = ((rows + tile - 1) / tile) * E < 8192 ? ((rows + tile - 1) / tile) * E : 8192;
+    printf("mean cycles over %d workgroups:", nw);
+    double tot = 0;
+    for (int i = 0; i < 13; ++i) {
+      double sacc = 0;
+      for (int g = 0; g < nw; ++g)
+        for (int w = 0; w < 4; ++w) sacc += (double)(pa[g][w][i + 1] - pa[g][w][i]);
+      sacc /= 4.0 * nw;
+      tot += sacc;
+      printf(" %s=%.0f", names[i], sacc);
+    }
+    printf("  total=%.0f\n", tot);
+  }
+  // workgroup residency: how many workgroups does a CU really hold at once?
+  static long long wl[16384][4];
+  (void)hipMemcpyFromSymbol(wl, HIP_SYMBOL(g_wg_log), sizeof(wl));
+  const int BMt = tile, nwg = ((rows + BMt - 1) / BMt) * E;
+  const int n = nwg < 16384 ? nwg : 16384;
+  long long t0 = wl[0][0], t1 = 0;
+  for (int i = 0; i < n; ++i) {
+    if (wl[i][0] < t0) t0 = wl[i][0];
+    if (wl[i][1] > t1) t1 = wl[i][1];
+  }
+  // CU key = xcc(4b) | se(3b) | sh(1b) | cu(4b)
+  int maxc[4096] = {0}, cnt_at_mid[4096] = {0};
+  const long long mid = t0 + (t1 - t0) / 3;
+  double dur = 0;
+  for (int i = 0; i < n; ++i) {
+    const unsigned hw = (unsigned)wl[i][2], xcc = (unsigned)wl[i][3] & 15;
+    const int key = (int)((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15));
+    if (wl[i][0] <= mid && wl[i][1] > mid) cnt_at_mid[key]++;
+    dur += (double)(wl[i][1] - wl[i][0]);
+    (void)maxc;
+  }
+  int hist[16] = {0}, cus = 0;
+  for (int k = 0; k < 4096; ++k)
+    if (cnt_at_mid[k]) {
+      hist[cnt_at_mid[k] < 15 ? cnt_at_mid[k] : 15]++;
+      ++cus;
+    }
+  printf("kernel span %.2f us over %d workgroups; mean workgroup life %.2f us; at 1/3 of the span %d CUs hold:", (t1 - t0) / 100.0,
+         n, dur / n / 100.0, cus);
+  for (int c = 1; c < 16; ++c)
+    if (hist[c]) printf("  %d WGs on %d CUs", c, hist[c]);
+  printf("\n");
+  {  // lockstep metric: distance from a workgroup's start to the nearest other start on the SAME CU, in units of
+     // the mean life (0 = the CU's workgroups move in lockstep, 1/occupancy = evenly staggered)
+    std::vector<std::vector<long long>> starts(4096);
+    for (int i = 0; i < n; ++i) {
+      const unsigned hw = (unsigned)wl[i][2], xcc = (unsigned)wl[i][3] & 15;
+      starts[(xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)].push_back(wl[i][0]);
+    }
+    double acc = 0;
+    long cntp = 0;
+    for (auto& v : starts) {
+      std::sort(v.begin(), v.end());
+      for (size_t j = 0; j < v.size(); ++j) {
+        long long d = 1LL << 60;
+        if (j > 0) d = std::min(d, v[j] - v[j - 1]);
+        if (j + 1 < v.size()) d = std::min(d, v[j + 1] - v[j]);
+        if (d < (1LL << 59)) {
+          acc += (double)d;
+          ++cntp;
+        }
+      }
+    }
+    printf("lockstep metric: mean nearest-start distance on a CU = %.3f of the mean workgroup life\n",
+           acc / cntp / (dur / n));
+  }
+  {  // lifetime distribution, per XCD and per third of the kernel span
+    std::vector<double> life(n);
+    double xs[16] = {0}, ts[3] = {0};
+    int xn[16] = {0}, tn[3] = {0};
+    for (int i = 0; i < n; ++i) {
+      life[i] = (wl[i][1] - wl[i][0]) / 100.0;
+      const int x = (int)(wl[i][3] & 15);
+      xs[x] += life[i];
+      xn[x]++;
+      int th = (int)(3 * (wl[i][0] - t0) / (t1 - t0 + 1));
+      ts[th] += life[i];
+      tn[th]++;
+    }
+    std::vector<double> srt(life);
+    std::sort(srt.begin(), srt.end());
+    printf("workgroup life us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f |", srt[0], srt[n / 10], srt[n / 2],
+           srt[n * 9 / 10], srt[n - 1]);
+    printf(" by start third:");
+    for (int k = 0; k < 3; ++k) printf(" %.1f(n=%d)", tn[k] ? ts[k] / tn[k] : 0.0, tn[k]);
+    printf(" | by XCC:");
+    for (int x = 0; x < 16; ++x)
+      if (xn[x]) printf(" %.1f", xs[x] / xn[x]);
+    printf("\n");
   }
   return 0;
 }
