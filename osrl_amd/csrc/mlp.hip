@@ -417,7 +417,12 @@ struct FwdArgs {
 // waves per SIMD the register allocator must leave room for (512 VGPRs / waves): the accumulators need
 // NRB*NCB*4 registers and the weight ring STAGES*NCB*4; without the hint the allocator drifts to 170-200
 // registers (AGPR copies of loop invariants) and one fewer workgroup fits per CU
-constexpr int waves_per_simd(int nrb, int ncb) { return nrb * ncb >= 14 ? 2 : nrb * ncb >= 4 ? 3 : 4; }
+#ifndef OSRL_WPS_8
+#define OSRL_WPS_8 3  // <2,4>: 3 waves (<= 168 VGPRs); 4 spills into scratch inside the k-loop
+#endif
+constexpr int waves_per_simd(int nrb, int ncb) {
+  return nrb * ncb >= 14 ? 2 : nrb * ncb == 8 ? OSRL_WPS_8 : nrb * ncb >= 4 ? 3 : 4;
+}
 // the backward kernel also holds the prefetched activations of the epilogue: one wave less
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
 

@@ -11,7 +11,8 @@ rs = np.random.RandomState(0)
 f = lambda *s: torch.tensor(rs.randn(*s), dtype=torch.float32, device=DEV)
 if which == "cdt":
     B, T = 1024, 20
-    m = CDT(11, 3, 1.0, seq_len=T, episode_len=1000, embedding_dim=256, num_layers=3, num_heads=8, use_rew=True,
+    m = CDT(11, 3, 1.0, seq_len=T, episode_len=1000, embedding_dim=256, num_layers=3, num_heads=8,
+            attention_dropout=0.1, residual_dropout=0.1, embedding_dropout=0.1, use_rew=True,
             use_cost=True, cost_transform=True, stochastic=True, target_entropy=-3, device=DEV)
     tr = CDTTrainer(m, None, None, lr_warmup_steps=500, loss_cost_weight=0.02, stats_mode="none", use_graph=False)
     mask = torch.ones(B, T, device=DEV); mask[::10, T - 5:] = 0
