@@ -40,7 +40,8 @@ typedef struct {
   int32_t dims[OSRL_MAX_LAYERS + 1]; /* in, h1, ..., out */
   int32_t acts[OSRL_MAX_LAYERS];     /* activation after each layer */
   float out_scale;                   /* net output = out_scale * act(z)  (act_limit of net.py:62,85,339) */
-  int32_t tile_rows;                 /* tuning hint: rows per workgroup tile (0 = auto, else 16 / 32 / 64) */
+  int32_t tile_rows;                 /* tuning hint: rows per workgroup tile (0 = auto, else 16 / 32 / 64);
+                                      * -1 = forward-only launches may use the LDS-staged-weights kernel */
   /* PACKED weights (osrl_pack_weights): Wf feeds forward, Wb (packed W^T) feeds backward-dz.
    * Wf[e][l]: PF[k/4][n][k%4], n < round16(out), k < round16(in), zero padded.
    * Wb[e][l]: PB[o/4][i][o%4], i < round16(in)+16, o < round16(out), zero padded (NULL if unused). */

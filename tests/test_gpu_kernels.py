@@ -143,6 +143,72 @@ def test_mlp_fwd_bwd(ci):
             assert np.abs(got - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), f"case {ci} dx net {e}"
 
 
+BIG_CASES = [
+    # E, dims, acts, out_scale, rows, (d0, map0, div0)          -- forward-only launches with >= 4 row blocks per CU
+    (2, [78, 256, 256, 1], ["relu", "relu", "id"], 1.0, 20480, (76, 1, 2048)),     # C2 target cost-critics (80-row tiles)
+    (1, [78, 400, 400, 8], ["relu", "relu", "id"], 1.0, 20480, (76, 1, 2048)),     # C2 VAE encoder (48/32-row tiles)
+    (4, [41, 256, 256, 1], ["relu", "relu", "id"], 1.0, 8192 + 37, (33, 2, 10)),   # DIV map, ragged rows, 4 nets
+    (1, [80, 400, 400, 2], ["relu", "relu", "tanh"], 1.5, 16384 + 5, (76, 0, 1)),  # tanh * scale head, ragged
+    (2, [24, 96, 80, 40], ["tanh", "relu", "id"], 1.0, 33000, (20, 0, 1)),          # non-narrow last layer, odd widths
+    (1, [76, 256, 256, 24], ["relu", "relu", "id"], 1.0, 30000, (76, 0, 1)),        # 2-block narrow head, no 2nd source
+    (8, [12, 64, 64, 1], ["relu", "relu", "id"], 1.0, 6000, (8, 0, 1)),             # 8 small nets
+]
+
+
+@pytest.mark.parametrize("ci", range(len(BIG_CASES)))
+def test_mlp_fwd_big_rows(ci):
+    """The LDS-staged-weights forward kernel (mlp_fwd_big_kernel) (opt-in: tile_rows=-1) vs fp64 and vs the tile kernel (tile_rows=16); forward-only launches, as the N*B-row launches of CPQ / BCQ-Lag."""
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
+    E, dims, acts, oscale, rows, (d0, map0, div0) = BIG_CASES[ci]
+    dev = _dev()
+    rs = np.random.RandomState(100 + ci)
+    grp = FlatGroup("t", dev)
+    for e in range(E):
+        for l in range(len(dims) - 1):
+            grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{e}.{l}.w")
+            grp.add(f"{e}.{l}.b", (dims[l + 1],))
+    grp.finalize()
+    refs, Ws = [], []
+    for e in range(E):
+        rr, ww = [], []
+        for l in range(len(dims) - 1):
+            k = 1 / math.sqrt(dims[l])
+            W, b = grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")
+            W.copy_(torch.tensor(rs.uniform(-k, k, W.shape), dtype=torch.float32))
+            b.copy_(torch.tensor(rs.uniform(-k, k, b.shape), dtype=torch.float32))
+            rr.append(LayerRef(W, b, grp, f"{e}.{l}.w", f"{e}.{l}.b"))
+            ww.append((W.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)))
+        refs.append(rr)
+        Ws.append(ww)
+    grp.repack()
+    d1 = dims[0] - d0
+    n0 = {0: rows, 1: div0, 2: (rows + div0 - 1) // div0}[map0]
+    src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
+    src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
+    outs = []
+    for tile_rows in (-1, 16):
+        desc = NetDesc(refs, acts, oscale)
+        desc.c.tile_rows = tile_rows
+        run = MlpRun(desc, rows, False, dev)
+        y = run.forward(src0, src1, map0=map0, div0=div0)
+        torch.cuda.synchronize()
+        outs.append(torch.stack([t.clone() for t in y]).cpu().numpy() if isinstance(y, (list, tuple)) else y.clone().cpu().numpy())
+    idx0 = {0: np.arange(rows), 1: np.arange(rows) % div0, 2: np.arange(rows) // div0}[map0]
+    X = src0.cpu().numpy().astype(np.float64)[idx0]
+    if d1:
+        X = np.concatenate([X, src1.cpu().numpy().astype(np.float64)], 1)
+    for e in range(E):
+        h = X
+        for l, a in enumerate(acts):
+            h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
+        h = h * oscale
+        for nm, got in (("big", outs[0][e]), ("tile", outs[1][e])):
+            err = np.abs(got.reshape(h.shape) - h).max()
+            assert err < 3e-5 * max(1.0, np.abs(h).max()), f"case {ci} {nm} kernel net {e}: max err {err}"
+    assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
+
+
 def test_adam_polyak_matches_oracle():
     from oracle.osrl_oracle import Adam
     from osrl_amd.engine.core import FlatGroup, StepState

@@ -22,5 +22,5 @@ for rows in map(int, sys.argv[3:]):
     x1 = torch.randn(rows, dims[0] - d0, device=dev) if dims[0] > d0 else None
     run = MlpRun(d, rows, False, dev)
     t = timeit(lambda: run.forward(x0, x1))
-    print(f"{name} tile={tile} rows={rows:6d} wgs={(rows + tile - 1) // tile * E:5d}: {t:8.2f} us {2.0 * rows * E * lin / t / 1e6:7.2f} TF/s",
+    print(f"{name} tile={tile} rows={rows:6d} wgs={(rows + max(tile, 1) - 1) // max(tile, 1) * E:5d}: {t:8.2f} us {2.0 * rows * E * lin / t / 1e6:7.2f} TF/s",
           flush=True)

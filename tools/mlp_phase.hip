@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   net.acts[0] = net.acts[1] = OSRL_ACT_RELU;
   net.acts[2] = OSRL_ACT_ID;
   net.out_scale = 1.f;
-  net.tile_rows = tile;
+  net.tile_rows = tile;  // -1 = the LDS-staged-weights kernel (grid and tile heights chosen by the library)
   size_t ncan = 0, nf = 0;
   std::vector<osrl_pack_entry_t> ents;
   for (int e = 0; e < E; ++e)
@@ -67,7 +67,8 @@ int main(int argc, char** argv) {
   {  // phase durations averaged over every workgroup (wave 0..3)
     static long long pa[8192][4][16];
     (void)hipMemcpyFromSymbol(pa, HIP_SYMBOL(g_phase_all), sizeof(pa));
-    const int nw = ((rows + tile - 1) / tile) * E < 8192 ? ((rows + tile - 1) / tile) * E : 8192;
+    const int tl = tile > 0 ? tile : 64;
+    const int nw = ((rows + tl - 1) / tl) * E < 8192 ? ((rows + tl - 1) / tl) * E : 8192;
     printf("mean cycles over %d workgroups:", nw);
     double tot = 0;
     for (int i = 0; i < 13; ++i) {
@@ -83,7 +84,7 @@ int main(int argc, char** argv) {
   // workgroup residency: how many workgroups does a CU really hold at once?
   static long long wl[16384][4];
   (void)hipMemcpyFromSymbol(wl, HIP_SYMBOL(g_wg_log), sizeof(wl));
-  const int BMt = tile, nwg = ((rows + BMt - 1) / BMt) * E;
+  const int BMt = tile > 0 ? tile : 64, nwg = ((rows + BMt - 1) / BMt) * E;
   const int n = nwg < 16384 ? nwg : 16384;
   long long t0 = wl[0][0], t1 = 0;
   for (int i = 0; i < n; ++i) {
