@@ -143,6 +143,14 @@ int osrl_adam_step(float* p, float* m, float* v, float* tgt, const float* slabs,
                    int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
                    void* stream);
+/* Same step, and the packed weight copies (osrl_pack_weights layouts) are refreshed in the same pass:
+ * map_f[i] / map_b[i] = float index of flat parameter i inside pf / pb (-1 = not a packed weight; map_b may be
+ * NULL); tf (may be NULL) receives the Polyak target at map_f.  Padding of the packed buffers is not touched. */
+int osrl_adam_step_packed(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,
+                          int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
+                          const int32_t* map_f, const int32_t* map_b, float* pf, float* pb, float* tf,
+                          void* stream);
 /* flat[i] = sum_s slabs[s][i]  (pre-reduction before an RCCL all-reduce in the data-parallel path) */
 int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
                       void* stream);

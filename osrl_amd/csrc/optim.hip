@@ -65,12 +65,23 @@ __device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ slabs, int n
   return g;
 }
 
+// packed-weight refresh fused into the optimizer step: map_f / map_b give, per flat parameter, its position in the
+// fragment-ordered forward / backward copies (-1 = not a packed weight); the zero padding of those copies is
+// never touched.  Replaces two pack_kernel launches per optimizer group and step.
+struct PackMap {
+  const int32_t* map_f;
+  const int32_t* map_b;
+  float* pf;
+  float* pb;
+  float* tf;
+};
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ tgt,
                                                    const float* __restrict__ slabs, int n_splits,
                                                    int64_t slab_stride, int64_t n4, float lr, float b1, float b2,
                                                    float eps, float wd, float tau, const float* __restrict__ gscale,
-                                                   const osrl_step_state_t* __restrict__ st) {
+                                                   const osrl_step_state_t* __restrict__ st, const PackMap pk) {
   const float lr_t = lr * st->lr_scale;
   const float step_size = lr_t / st->bc1;
   const float bc2s = st->bc2_sqrt;
@@ -89,10 +100,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
+    f32x4 tv = pv;
     if (tgt) {
-      f32x4 tv = reinterpret_cast<f32x4*>(tgt)[i];
+      tv = reinterpret_cast<f32x4*>(tgt)[i];
       tv = tau * pv + (1.0f - tau) * tv;
       reinterpret_cast<f32x4*>(tgt)[i] = tv;
+    }
+    if (pk.map_f) {
+      const int4 mf = reinterpret_cast<const int4*>(pk.map_f)[i];
+      const int mfa[4] = {mf.x, mf.y, mf.z, mf.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (mfa[k] >= 0) {
+          pk.pf[mfa[k]] = pv[k];
+          if (tgt && pk.tf) pk.tf[mfa[k]] = tv[k];
+        }
+      if (pk.map_b) {
+        const int4 mb = reinterpret_cast<const int4*>(pk.map_b)[i];
+        const int mba[4] = {mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (mba[k] >= 0) pk.pb[mba[k]] = pv[k];
+      }
     }
   }
 }
@@ -121,15 +150,33 @@ extern "C" int osrl_step_tick(osrl_step_state_t* st, float beta1, float beta2, i
   return (int)hipGetLastError();
 }
 
+static int adam_launch(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,
+                       int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
+                       const PackMap& pk, void* stream) {
+  if (!p || !m || !v || !slabs || !st || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, tgt, slabs,
+                     n_splits, slab_stride, n / 4, lr, beta1, beta2, eps, weight_decay, tau, gscale, st, pk);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osrl_adam_step(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,
                               int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
                               float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
                               void* stream) {
-  if (!p || !m || !v || !slabs || !st || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
-  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, tgt, slabs,
-                     n_splits, slab_stride, n / 4, lr, beta1, beta2, eps, weight_decay, tau, gscale, st);
-  return (int)hipGetLastError();
+  return adam_launch(p, m, v, tgt, slabs, n_splits, slab_stride, n, lr, beta1, beta2, eps, weight_decay, tau, gscale,
+                     st, PackMap{nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+extern "C" int osrl_adam_step_packed(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,
+                                     int64_t slab_stride, int64_t n, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, float tau, const float* gscale,
+                                     const osrl_step_state_t* st, const int32_t* map_f, const int32_t* map_b,
+                                     float* pf, float* pb, float* tf, void* stream) {
+  if (!map_f || !pf || (map_b && !pb)) return -1;
+  return adam_launch(p, m, v, tgt, slabs, n_splits, slab_stride, n, lr, beta1, beta2, eps, weight_decay, tau, gscale,
+                     st, PackMap{map_f, map_b, pf, pb, tf}, stream);
 }
 
 extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,

@@ -107,6 +107,18 @@ class FlatGroup:
             self.pf, self.pb = z(nf), z(nb)
             self.tf = z(nf) if self.with_target else None
             self._ents = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(self.device)
+            # flat parameter -> position in the packed copies, for the optimizer step's fused refresh
+            import numpy as np
+            mf, mb = np.full(n, -1, np.int32), np.full(n, -1, np.int32)
+            for k in self.weights:
+                off, (o, ii) = self.layout[k]
+                r, c = np.meshgrid(np.arange(o), np.arange(ii), indexing="ij")
+                flat = (off + r * ii + c).ravel()
+                assert (mf[flat] < 0).all(), f"{k}: parameter packed twice"
+                mf[flat] = (self.f_off[k] + ((c // 4) * r16(o) + r) * 4 + c % 4).ravel()
+                mb[flat] = (self.b_off[k] + ((r // 4) * (r16(ii) + 16) + c) * 4 + r % 4).ravel()
+            self._map_f = torch.from_numpy(mf).to(self.device)
+            self._map_b = torch.from_numpy(mb).to(self.device)
 
     def repack(self, params: bool = True, target: bool = True) -> None:
         """Refresh the packed weight copies from the canonical buffers (async, current stream)."""
@@ -161,12 +173,19 @@ class FlatGroup:
                   weight_decay: float = 0.0, gscale: Optional[torch.Tensor] = None,
                   polyak: bool = True) -> None:
         lib = L.load()
-        L.check(lib.osrl_adam_step(self.p.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                   _ptr(self.tgt) if (polyak and self.tgt is not None) else None,
-                                   self.slabs.data_ptr(), self.cur_splits, self.n, self.n, lr, betas[0],
-                                   betas[1], eps, weight_decay, tau, _ptr(gscale), st_ptr, cur_stream()),
-                "osrl_adam_step")
-        self.repack(True, polyak and self.tgt is not None)
+        tgt = _ptr(self.tgt) if (polyak and self.tgt is not None) else None
+        if self.weights:  # parameters, Polyak targets and their packed copies in one pass
+            L.check(lib.osrl_adam_step_packed(self.p.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), tgt,
+                                              self.slabs.data_ptr(), self.cur_splits, self.n, self.n, lr, betas[0],
+                                              betas[1], eps, weight_decay, tau, _ptr(gscale), st_ptr,
+                                              self._map_f.data_ptr(), self._map_b.data_ptr(), self.pf.data_ptr(),
+                                              self.pb.data_ptr(), _ptr(self.tf) if tgt is not None else None,
+                                              cur_stream()), "osrl_adam_step_packed")
+        else:
+            L.check(lib.osrl_adam_step(self.p.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), tgt,
+                                       self.slabs.data_ptr(), self.cur_splits, self.n, self.n, lr, betas[0],
+                                       betas[1], eps, weight_decay, tau, _ptr(gscale), st_ptr, cur_stream()),
+                    "osrl_adam_step")
 
 
 class LayerRef:
