@@ -224,6 +224,12 @@ int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* 
                        const float* ood_mean, const float* cost, int32_t rows, float gamma, float qc_thres,
                        float alpha_lr, int32_t rows_global, float stat_share, float* log_alpha, float* dq,
                        float* stat, void* stream);
+/* Single-GPU fusion of osrl_cpq_ood_mean + osrl_cpq_cost_loss (cpq.py:184-199): the OOD mean is computed inside
+ * the loss launch (and written to ood_mean_out); no batch-global reduction can sit between the two. */
+int osrl_cpq_cost_loss_ood(const float* qc_sampled, int32_t n_qc_sampled, const float* kl, const float* quantile,
+                           int32_t n_samples, const float* qc_old_next, int32_t n_qc_old, const float* qc,
+                           int32_t n_qc, float* ood_mean_out, const float* cost, int32_t rows, float gamma,
+                           float qc_thres, float alpha_lr, float* log_alpha, float* dq, float* stat, void* stream);
 /* CPQ actor loss (cpq.py:210-212): loss = -mean(1[min qc <= thres] * min q); dq routed to arg-min net. */
 int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_qc, int32_t rows,
                         float q_thres, int32_t rows_global, float* dq, float* stat, void* stream);

@@ -314,11 +314,9 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
 }
 
 // mean over the (global) batch of qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184,187
-__global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restrict__ qc_sampled, int n_qc_old,
-                                                            const float* __restrict__ kl,
-                                                            const float* __restrict__ quantile, int n_samples,
-                                                            int rows, float inv_rows, float* __restrict__ out) {
-  __shared__ float sm[20];
+__device__ __forceinline__ float cpq_ood_mean_block(const float* __restrict__ qc_sampled, int n_qc_old,
+                                                    const float* __restrict__ kl, const float* __restrict__ quantile,
+                                                    int n_samples, int rows, float inv_rows, float* sm) {
   float ood = 0.f;
   const float quant = quantile[0];
   const int nr = n_samples * rows;
@@ -333,16 +331,34 @@ __global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restr
     }
     ood += s / (float)n_samples;
   }
-  ood = block_sum(ood, sm);
-  if (threadIdx.x == 0) out[0] = ood * inv_rows;
+  return block_sum(ood, sm) * inv_rows;
 }
+
+__global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restrict__ qc_sampled, int n_qc_old,
+                                                            const float* __restrict__ kl,
+                                                            const float* __restrict__ quantile, int n_samples,
+                                                            int rows, float inv_rows, float* __restrict__ out) {
+  __shared__ float sm[20];
+  const float ood = cpq_ood_mean_block(qc_sampled, n_qc_old, kl, quantile, n_samples, rows, inv_rows, sm);
+  if (threadIdx.x == 0) out[0] = ood;
+}
+
+struct OodArgs {  // non-NULL qc_sampled: compute the OOD mean here (single-GPU step: one launch less)
+  const float* qc_sampled;
+  const float* kl;
+  const float* quantile;
+  int32_t n_qc_old, n_samples;
+};
 
 __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
     const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
-    const float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
+    float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
     float alpha_lr, float inv_rows, float stat_share, float* __restrict__ log_alpha, float* __restrict__ dq,
-    float* __restrict__ stat) {
+    float* __restrict__ stat, const OodArgs oa) {
   __shared__ float sm[20];
+  float ood_here = 0.f;
+  if (oa.qc_sampled)
+    ood_here = cpq_ood_mean_block(oa.qc_sampled, oa.n_qc_old, oa.kl, oa.quantile, oa.n_samples, rows, inv_rows, sm);
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
     const float backup = cost[b] + gamma * min_over(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
@@ -354,7 +370,8 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
   }
   loss = block_sum(loss, sm);
   if (threadIdx.x == 0) {
-    const float ood_mean = ood_mean_p[0];
+    const float ood_mean = oa.qc_sampled ? ood_here : ood_mean_p[0];
+    if (oa.qc_sampled) ood_mean_p[0] = ood_here;
     float la = log_alpha[0];
     const float ea = expf(la);
     // cpq.py:186-187; under data parallelism the mse part is this rank's partial sum and the global
@@ -645,9 +662,24 @@ int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* 
                        float* stat, void* stream) {
   if (!qc_old_next || !qc || !ood_mean || !cost || !log_alpha || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc, ood_mean,
-                     cost, rows, gamma, qc_thres, alpha_lr, 1.0f / (float)(rows_global > 0 ? rows_global : rows),
-                     stat_share, log_alpha, dq, stat);
+  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
+                     const_cast<float*>(ood_mean), cost, rows, gamma, qc_thres, alpha_lr,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), stat_share, log_alpha, dq, stat,
+                     OodArgs{nullptr, nullptr, nullptr, 0, 0});
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_cost_loss_ood(const float* qc_sampled, int32_t n_qc_sampled, const float* kl, const float* quantile,
+                           int32_t n_samples, const float* qc_old_next, int32_t n_qc_old, const float* qc,
+                           int32_t n_qc, float* ood_mean_out, const float* cost, int32_t rows, float gamma,
+                           float qc_thres, float alpha_lr, float* log_alpha, float* dq, float* stat, void* stream) {
+  if (!qc_sampled || !kl || !quantile || n_samples < 1 || !qc_old_next || !qc || !ood_mean_out || !cost ||
+      !log_alpha || !dq || rows < 1)
+    return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc, ood_mean_out,
+                     cost, rows, gamma, qc_thres, alpha_lr, 1.0f / (float)rows, 1.0f, log_alpha, dq, stat,
+                     OodArgs{qc_sampled, kl, quantile, n_qc_sampled, n_samples});
   LAUNCH_CHECK();
 }
 

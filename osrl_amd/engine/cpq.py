@@ -160,6 +160,8 @@ class CPQEngine:
             head_obs = self.r_actor_obs.forward(self.obs)[0]
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
             ev_sampled = par.mark(0)
+            # the actor-phase sample (cpq.py:209) needs only this forward and its own noise: off the critical tail
+            G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
             qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
             qc = self.r_cost.forward(self.obs, self.act)
             G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
@@ -179,18 +181,22 @@ class CPQEngine:
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
         par.join(0)  # side branch done (it also reads cost_critic_old, which the next optimizer step updates)
-        G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
-        share = 1.0
-        if self.dist is not None:
-            self.dist.all_reduce_(self.ood_mean)
-            share = 1.0 / self.dist.world
-        G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg,
-                        share, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+        if self.dist is None and rg in (0, B):  # no batch-global reduction in between: one launch
+            G.cpq_cost_loss_ood(qc_s, nqc, self.kl, self.quant, N, qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost,
+                                B, m.gamma, m.qc_thres, m.alpha_lr, m.log_alpha, self.dqc,
+                                st.stat_ptr("loss/cost_critic_loss"))
+        else:
+            G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            share = 1.0
+            if self.dist is not None:
+                self.dist.all_reduce_(self.ood_mean)
+                share = 1.0 / self.dist.world
+            G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr,
+                            rg, share, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
         self._optim("cost_critic", self.p_cost, m.tau)
 
         # ---- actor_loss  (cpq.py:203-222)
-        G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
         G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
         self.r_pi_q.backward_dz()

@@ -75,6 +75,14 @@ def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows, gamma, 
                                         cur_stream()), "osrl_cpq_cost_loss")
 
 
+def cpq_cost_loss_ood(qc_sampled, n_qc_s, kl, quant, n_samples, qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows,
+                      gamma, qc_thres, alpha_lr, log_alpha, dq, stat):
+    L.check(L.load().osrl_cpq_cost_loss_ood(_p(qc_sampled), n_qc_s, _p(kl), _p(quant), n_samples, _p(qc_old_next),
+                                            n_qc_old, _p(qc), n_qc, _p(ood_mean), _p(cost), rows, gamma, qc_thres,
+                                            alpha_lr, _p(log_alpha), _p(dq), _p(stat), cur_stream()),
+            "osrl_cpq_cost_loss_ood")
+
+
 def cpq_actor_loss(q, n_q, qc, n_qc, rows, q_thres, rows_global, dq, stat):
     L.check(L.load().osrl_cpq_actor_loss(_p(q), n_q, _p(qc), n_qc, rows, q_thres, rows_global, _p(dq), _p(stat),
                                          cur_stream()), "osrl_cpq_actor_loss")
