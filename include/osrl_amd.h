@@ -112,6 +112,10 @@ typedef struct {
 /* ---- fused MLP (mlp.hip): replaces nn.Sequential(Linear,act,...) forward + its autograd ---- */
 /* lds_bytes / tile selection are internal; rows may be any value >= 1. */
 int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, void* stream);
+/* Two independent forward problems in one launch (e.g. the actor on next_obs and on obs, cpq.py:141,164): same
+ * results as two osrl_mlp_forward calls; falls back to exactly that when the two tile shapes differ. */
+int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
+                      const osrl_mlp_t* net1, const osrl_rows_t* in1, const osrl_mlp_acts_t* out1, void* stream);
 int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                          const osrl_mlp_grads_t* g, void* stream);
 /* General linear layer on packed weights: Y[M,N] = A[M,K] * P (+ bias[N]) (+ resid[M,N]).  P is the forward

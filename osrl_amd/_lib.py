@@ -73,6 +73,7 @@ _P = C.POINTER
 # name -> argtypes  (all return int except osrl_version); must match include/osrl_amd.h
 PROTOTYPES = {
     "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
+    "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
     "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],

@@ -431,12 +431,11 @@ constexpr int waves_per_simd(int nrb, int ncb) {
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
 
 template <int NRB, int NCB>
-__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_kernel(const FwdArgs a) {
+__device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int e = blockIdx.y;
   const int row0 = blockIdx.x * BM;
   const int rows = a.in.rows, lda = a.lda;
   const int L = a.net.n_layers;
@@ -550,6 +549,26 @@ __global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_kernel(
     if (save) tile_to_global(lds, lda, BM, N, save, row0, rows);
     PHASE_STAMP(5 + 4 * l);
   }  WG_LOG(1);
+}
+
+template <int NRB, int NCB>
+__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_kernel(const FwdArgs a) {
+  mlp_fwd_body<NRB, NCB>(a, blockIdx.y);
+}
+
+// Two independent forward problems (different networks / inputs, same tile shape) in ONE launch: the 2048-row
+// training launches of a step are 128 row tiles x 1-4 nets each, i.e. at most one workgroup per CU and a serial
+// latency chain inside it; pairing two of them fills the idle CUs and removes a launch from the critical path.
+template <int NRB, int NCB>
+__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd2_kernel(const FwdArgs a0, const FwdArgs a1,
+                                                                                 int nets0, int tiles0, int tiles1) {
+  if ((int)blockIdx.y < nets0) {
+    if ((int)blockIdx.x >= tiles0) return;  // whole workgroup leaves before any barrier
+    mlp_fwd_body<NRB, NCB>(a0, blockIdx.y);
+  } else {
+    if ((int)blockIdx.x >= tiles1) return;
+    mlp_fwd_body<NRB, NCB>(a1, blockIdx.y - nets0);
+  }
 }
 
 // ---- big-row forward: weights staged through LDS ----------------------------------------------------
@@ -1401,6 +1420,56 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
   const TileChoice t = choose_tile(net, in->rows, 0);
   a.lda = t.lda;
   OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream);
+}
+
+template <int NRB, int NCB>
+static int launch_fwd2(const FwdArgs& a0, const FwdArgs& a1, int nets0, int nets1, int rows0, int rows1, int lda,
+                       hipStream_t stream) {
+  const int BM = 16 * NRB;
+  const int t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
+  const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd2_kernel<NRB, NCB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((mlp_fwd2_kernel<NRB, NCB>), dim3(t0 > t1 ? t0 : t1, nets0 + nets1, 1), dim3(256), lds_bytes, stream,
+                     a0, a1, nets0, t0, t1);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
+                                 const osrl_mlp_t* net1, const osrl_rows_t* in1, const osrl_mlp_acts_t* out1,
+                                 void* stream) {
+  if (!valid_net(net0) || !valid_net(net1) || !in0 || !in1 || !out0 || !out1) return -1;
+  const TileChoice t0 = choose_tile(net0, in0->rows, 0), t1 = choose_tile(net1, in1->rows, 0);
+  // pair only 16-row-tile launches of the two common column shapes; anything else runs as two launches
+  const bool pair = t0.nrb == 1 && t1.nrb == 1 && t0.ncb == t1.ncb && (t0.ncb == 4 || t0.ncb == 7) &&
+                    net0->n_nets + net1->n_nets <= 2 * OSRL_MAX_NETS;
+  if (!pair) {
+    const int rc = osrl_mlp_forward(net0, in0, out0, stream);
+    return rc != 0 ? rc : osrl_mlp_forward(net1, in1, out1, stream);
+  }
+  for (int p = 0; p < 2; ++p) {
+    const osrl_mlp_t* net = p ? net1 : net0;
+    const osrl_rows_t* in = p ? in1 : in0;
+    const osrl_mlp_acts_t* out = p ? out1 : out0;
+    if (net->out_scale == 0.f || in->rows < 1 || in->d0 + in->d1 != net->dims[0]) return -1;
+    for (int e = 0; e < net->n_nets; ++e) {
+      if (!out->h[e][net->n_layers - 1]) return -1;
+      for (int l = 0; l < net->n_layers; ++l)
+        if (!net->Wf[e][l] || !net->b[e][l]) return -1;
+    }
+  }
+  FwdArgs a0, a1;
+  a0.net = *net0; a0.in = *in0; a0.out = *out0;
+  a1.net = *net1; a1.in = *in1; a1.out = *out1;
+  const int lda = t0.lda > t1.lda ? t0.lda : t1.lda;
+  a0.lda = a1.lda = lda;
+  if (t0.ncb == 4)
+    return launch_fwd2<1, 4>(a0, a1, net0->n_nets, net1->n_nets, in0->rows, in1->rows, lda, (hipStream_t)stream);
+  return launch_fwd2<1, 7>(a0, a1, net0->n_nets, net1->n_nets, in0->rows, in1->rows, lda, (hipStream_t)stream);
 }
 
 extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,

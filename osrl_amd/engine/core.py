@@ -301,6 +301,29 @@ class MlpRun:
         self.bwd_net = None
 
     # ---- forward ----
+    def _rows(self, src0: torch.Tensor, src1: Optional[torch.Tensor] = None, map0=L.MAP_ID, div0=1,
+              map1=L.MAP_ID, div1=1):
+        r = L.RowsT()
+        r.rows = self.rows
+        r.d0, r.map0, r.div0 = src0.shape[-1], map0, div0
+        r.src0 = src0.data_ptr()
+        if src1 is not None:
+            r.d1, r.map1, r.div1 = src1.shape[-1], map1, div1
+            r.src1 = src1.data_ptr()
+        else:
+            r.d1, r.map1, r.div1 = 0, L.MAP_ID, 1
+        assert r.d0 + r.d1 == self.net.dims[0], (r.d0, r.d1, self.net.dims)
+        return r
+
+    def forward_with(self, args, other: "MlpRun", other_args) -> Tuple[torch.Tensor, torch.Tensor]:
+        """This forward and an independent one of ``other`` in ONE launch (osrl_mlp_forward2);
+        ``args`` / ``other_args`` are the positional arguments of the two ``forward`` calls."""
+        r0, r1 = self._rows(*args), other._rows(*other_args)
+        L.check(L.load().osrl_mlp_forward2(C.byref(self.net.c), C.byref(r0), C.byref(self.acts_c),
+                                           C.byref(other.net.c), C.byref(r1), C.byref(other.acts_c), cur_stream()),
+                "osrl_mlp_forward2")
+        return self.y, other.y
+
     def forward(self, src0: torch.Tensor, src1: Optional[torch.Tensor] = None, map0=L.MAP_ID, div0=1,
                 map1=L.MAP_ID, div1=1) -> torch.Tensor:
         r = L.RowsT()

@@ -154,19 +154,20 @@ class CPQEngine:
         # profiles/r1_timeline.txt): first everything of cost_critic_loss (cpq.py:155-176) that needs neither
         # the new VAE nor a reduction -- so the N*B sampled actions exist early -- then critic_loss (cpq.py:137-153).
         with par.on(0):
-            head_next = self.r_actor_next.forward(self.nobs)[0]
+            # independent 2048-row forwards are launched in pairs (osrl_mlp_forward2): each alone is at most one
+            # workgroup per CU running a serial latency chain
+            hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
+            head_next, head_obs = hn[0], ho[0]
             G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
-            qc_old_next = self.r_costold_next.forward(self.nobs, self.a_next2)
-            head_obs = self.r_actor_obs.forward(self.obs)[0]
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
             ev_sampled = par.mark(0)
             # the actor-phase sample (cpq.py:209) needs only this forward and its own noise: off the critical tail
             G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
             qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
-            qc = self.r_cost.forward(self.obs, self.act)
+            qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
+                                                               (self.obs, self.act))
             G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
-            y_old = self.r_old_next.forward(self.nobs, self.a_next)
-            q = self.r_critic.forward(self.obs, self.act)
+            y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
@@ -230,6 +231,8 @@ class CPQEngine:
             self.body(True, par)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
+        # (capturing on a high-priority stream to favour the critical chain halves the throughput: measured 980 vs
+        # 1755 steps/s -- every kernel of the step ran ~2x slower)
         with torch.cuda.graph(g):
             self.body(True, par)
         self._par = par  # keep the side streams alive with the graph

@@ -209,6 +209,60 @@ def test_mlp_fwd_big_rows(ci):
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
 
 
+def test_mlp_forward_pair_equals_two_launches():
+    """osrl_mlp_forward2 (two independent problems, one launch) == two osrl_mlp_forward calls, incl. saved
+    activations, different row counts / net counts / input widths, and the fallback for unequal tile shapes."""
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
+    dev = _dev()
+    rs = np.random.RandomState(77)
+
+    def mk(E, dims, acts, name):
+        grp = FlatGroup(name, dev)
+        for e in range(E):
+            for l in range(len(dims) - 1):
+                grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+                grp.mark_weight(f"{e}.{l}.w")
+                grp.add(f"{e}.{l}.b", (dims[l + 1],))
+        grp.finalize()
+        refs = []
+        for e in range(E):
+            rr = []
+            for l in range(len(dims) - 1):
+                W, b = grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")
+                W.copy_(torch.tensor(rs.uniform(-0.2, 0.2, W.shape), dtype=torch.float32))
+                b.copy_(torch.tensor(rs.uniform(-0.2, 0.2, b.shape), dtype=torch.float32))
+                rr.append(LayerRef(W, b, grp, f"{e}.{l}.w", f"{e}.{l}.b"))
+            refs.append(rr)
+        grp.repack()
+        return grp, NetDesc(refs, acts, 1.0)
+
+    cases = [((1, [76, 256, 256, 4], 2048, True), (1, [76, 256, 256, 4], 2048, False)),      # actor on obs / next_obs
+             ((2, [78, 256, 256, 1], 2048, False), (2, [78, 256, 256, 1], 2048, True)),      # target + live cost critics
+             ((4, [78, 256, 256, 1], 1000, False), (2, [78, 256, 256, 1], 2048 + 7, True)),  # ragged, unequal rows
+             ((1, [78, 400, 400, 8], 300, True), (1, [80, 400, 400, 2], 500, False)),        # 7-block shape
+             ((1, [78, 400, 400, 8], 300, False), (2, [78, 256, 256, 1], 300, False))]       # shapes differ: fallback
+    for (E0, d0, r0, s0), (E1, d1, r1, s1) in cases:
+        g0, n0 = mk(E0, d0, ["relu", "relu", "id"], "a")
+        g1, n1 = mk(E1, d1, ["relu", "relu", "id"], "b")
+        x0, x1 = torch.randn(r0, d0[0], device=dev), torch.randn(r1, d1[0], device=dev)
+        ref0, ref1 = MlpRun(n0, r0, s0, dev), MlpRun(n1, r1, s1, dev)
+        ref0.forward(x0)
+        ref1.forward(x1)
+        p0, p1 = MlpRun(n0, r0, s0, dev), MlpRun(n1, r1, s1, dev)
+        y0, y1 = p0.forward_with((x0,), p1, (x1,))
+        torch.cuda.synchronize()
+        # (each workgroup starts its k-walk at a step derived from its block index, so the fp32 summation order of
+        # the second problem differs from a stand-alone launch: equal to round-off, not bit-equal)
+        close = lambda u, v: (u - v).abs().max().item() <= 2e-6 * max(1.0, v.abs().max().item())  # noqa: E731
+        for a, b in ((ref0, p0), (ref1, p1)):
+            assert close(a.y, b.y)
+            if a.save:
+                assert torch.equal(a.x, b.x)
+                for e in range(a.net.E):
+                    for l in range(a.net.nl):
+                        assert close(a.h[e][l], b.h[e][l])
+
+
 def test_adam_polyak_matches_oracle():
     from oracle.osrl_oracle import Adam
     from osrl_amd.engine.core import FlatGroup, StepState
