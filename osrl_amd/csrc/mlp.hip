@@ -84,9 +84,10 @@ __device__ __forceinline__ int map_row(int r, int map, int div) {
   return r;
 }
 __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
-// balanced split of nblk column blocks over the 4 waves: first (nblk%4) waves take one extra block
+// balanced split of nblk column blocks over the NW waves: the first (nblk % NW) waves take one extra block
+template <int NW = 4>
 __device__ __forceinline__ void wave_blocks(int nblk, int wave, int* cb0, int* cnt) {
-  const int base = nblk >> 2, rem = nblk & 3;
+  const int base = nblk / NW, rem = nblk % NW;
   *cnt = base + (wave < rem ? 1 : 0);
   *cb0 = wave * base + (wave < rem ? wave : rem);
 }
@@ -289,29 +290,30 @@ __device__ __forceinline__ void layer_run(const float* lds, int lda, int nk, con
 // Narrow layer (N <= 32, e.g. the 1-wide Q head or the 2*ad-wide policy head): instead of one wave
 // walking all of K alone, the 4 waves split K; partial tiles are summed through the (free) LDS
 // activation buffer.  On return lds[row][c], c < nblk*16, holds the raw sums (no bias/activation).
-// Requires lda >= 64 and nk >= 4.  Contains the barriers that protect the in-place overwrite.
+// Requires lda >= 16*NW and nk >= 4.  Contains the barriers that protect the in-place overwrite.
 struct NarrowPart {
   int col, k_lo, k_n;
 };
+template <int NW = 4>
 __device__ __forceinline__ NarrowPart narrow_part(int nk, int col_off, int nblk, int wave) {
-  const int parts = 4 / nblk;  // waves per column block (nblk is 1 or 2)
+  const int parts = NW / nblk;  // waves per column block (nblk is 1 or 2)
   const int blk = wave / parts, part = wave - blk * parts;
   const int k_lo = (nk * part) / parts, k_hi = (nk * (part + 1)) / parts;
   return NarrowPart{col_off + blk * 16, k_lo, k_hi - k_lo};
 }
-template <int NCB>
+template <int NCB, int NW = 4>
 __device__ __forceinline__ void narrow_prefetch(f32x4 (&ring)[kRing][NCB], int nk, const float* __restrict__ P, int Np,
                                                 int col_off, int nblk, int wave) {
-  const NarrowPart np = narrow_part(nk, col_off, nblk, wave);
+  const NarrowPart np = narrow_part<NW>(nk, col_off, nblk, wave);
   if (np.k_n > 0) mm_prefetch<NCB, 1, 3>(ring, np.k_n, P, Np, np.col, np.k_lo);
 }
 // requires narrow_prefetch(ring, same arguments)
-template <int NRB, int NCB>
+template <int NRB, int NCB, int NW = 4>
 __device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk, const float* __restrict__ P, int Np,
                                                     int col_off, int nblk, int wave, f32x4 (&ring)[kRing][NCB]) {
   const int lane = threadIdx.x & 63;
-  const int parts = 4 / nblk;
-  const NarrowPart np = narrow_part(nk, col_off, nblk, wave);
+  const int parts = NW / nblk;
+  const NarrowPart np = narrow_part<NW>(nk, col_off, nblk, wave);
   f32x4 t[NRB][1];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -324,10 +326,10 @@ __device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk,
   __syncthreads();
   constexpr int BM = 16 * NRB;
   const int ncol = nblk * 16;
-  float v[(BM * 32 + 255) / 256];
+  float v[(BM * 32 + 64 * NW - 1) / (64 * NW)];
 #pragma unroll
-  for (int j = 0; j < (BM * 32 + 255) / 256; ++j) {
-    const int e = j * 256 + (int)threadIdx.x;
+  for (int j = 0; j < (BM * 32 + 64 * NW - 1) / (64 * NW); ++j) {
+    const int e = j * 64 * NW + (int)threadIdx.x;
     float sacc = 0.f;
     if (e < BM * ncol) {
       const int r = e / ncol, c = e - r * ncol;
@@ -338,8 +340,8 @@ __device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk,
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < (BM * 32 + 255) / 256; ++j) {
-    const int e = j * 256 + (int)threadIdx.x;
+  for (int j = 0; j < (BM * 32 + 64 * NW - 1) / (64 * NW); ++j) {
+    const int e = j * 64 * NW + (int)threadIdx.x;
     if (e < BM * ncol) {
       const int r = e / ncol, c = e - r * ncol;
       lds[r * lda + c] = v[j];
@@ -362,14 +364,14 @@ __device__ __forceinline__ void tile_to_global(const float* lds, int lda, int BM
   const int tid = threadIdx.x;
   if ((N & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
     const int n4 = N >> 2;
-    for (int idx = tid; idx < BM * n4; idx += 256) {
+    for (int idx = tid; idx < BM * n4; idx += (int)blockDim.x) {
       const int r = idx / n4, c4 = idx - r * n4;
       if (row0 + r < rows)
         *reinterpret_cast<f32x4*>(dst + (size_t)(row0 + r) * N + 4 * c4) =
             *reinterpret_cast<const f32x4*>(lds + r * lda + 4 * c4);
     }
   } else {
-    for (int idx = tid; idx < BM * N; idx += 256) {
+    for (int idx = tid; idx < BM * N; idx += (int)blockDim.x) {
       const int r = idx / N, c = idx - r * N;
       if (row0 + r < rows) dst[(size_t)(row0 + r) * N + c] = lds[r * lda + c];
     }
@@ -430,7 +432,7 @@ constexpr int waves_per_simd(int nrb, int ncb) {
 // the backward kernel also holds the prefetched activations of the epilogue: one wave less
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
 
-template <int NRB, int NCB>
+template <int NRB, int NCB, int NW>
 __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
@@ -447,11 +449,11 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
   auto begin_layer = [&](int l) {
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
     const int nblk = (N + 15) >> 4, nk = round16(K) >> 4;
-    if (nblk <= 2 && nk >= 4 && lda >= 64) {
-      narrow_prefetch<NCB>(ring, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave);
+    if (nblk <= 2 && nk >= 4 && lda >= 16 * NW) {
+      narrow_prefetch<NCB, NW>(ring, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave);
     } else {
       int cb0, cnt;
-      wave_blocks(nblk, wave, &cb0, &cnt);
+      wave_blocks<NW>(nblk, wave, &cb0, &cnt);
       layer_prefetch<NRB, NCB>(ring, nk, a.net.Wf[e][l], round16(N), cb0 * 16, cnt);
     }
   };
@@ -465,7 +467,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
     const float* __restrict__ s0 = a.in.src0;
     const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
 #pragma unroll 1
-    for (int r = rl; r < BM; r += 16) {
+    for (int r = rl; r < BM; r += 4 * NW) {
       const int gr = row0 + r;
       const bool rok = gr < rows;
       const int grc = rok ? gr : rows - 1;
@@ -500,21 +502,21 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
     const int act = a.net.acts[l];
     const float oscale = (l == L - 1) ? a.net.out_scale : 1.0f;
     const int nk = round16(K) >> 4;
-    if (nblk <= 2 && nk >= 4 && lda >= 64) {
+    if (nblk <= 2 && nk >= 4 && lda >= 16 * NW) {
       // narrow layer: split K over the 4 waves, then bias/activation on the summed tile in LDS
-      narrow_layer_splitk<NRB, NCB>(lds, lda, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave, ring);
+      narrow_layer_splitk<NRB, NCB, NW>(lds, lda, nk, a.net.Wf[e][l], round16(N), 0, nblk, wave, ring);
       if (l + 1 < L) begin_layer(l + 1);
       PHASE_STAMP(2 + 4 * l);
       PHASE_STAMP(3 + 4 * l);
       const int ncol = nblk * 16;
-      for (int idx = tid; idx < BM * ncol; idx += 256) {
+      for (int idx = tid; idx < BM * ncol; idx += 64 * NW) {
         const int r = idx / ncol, c = idx - r * ncol;
         const float v = c < N ? act_fwd(act, lds[r * lda + c] + bias[c]) * oscale : 0.f;
         lds[r * lda + c] = v;
       }
     } else {
       int cb0, cnt;
-      wave_blocks(nblk, wave, &cb0, &cnt);  // cnt may be 0 for idle waves
+      wave_blocks<NW>(nblk, wave, &cb0, &cnt);  // cnt may be 0 for idle waves
       float bv[NCB];  // bias fetched before the k-loop so its latency hides behind the MFMAs
 #pragma unroll
       for (int c = 0; c < NCB; ++c) {
@@ -551,23 +553,23 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
   }  WG_LOG(1);
 }
 
-template <int NRB, int NCB>
-__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_kernel(const FwdArgs a) {
-  mlp_fwd_body<NRB, NCB>(a, blockIdx.y);
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd_kernel(const FwdArgs a) {
+  mlp_fwd_body<NRB, NCB, NW>(a, blockIdx.y);
 }
 
 // Two independent forward problems (different networks / inputs, same tile shape) in ONE launch: the 2048-row
 // training launches of a step are 128 row tiles x 1-4 nets each, i.e. at most one workgroup per CU and a serial
 // latency chain inside it; pairing two of them fills the idle CUs and removes a launch from the critical path.
-template <int NRB, int NCB>
-__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd2_kernel(const FwdArgs a0, const FwdArgs a1,
-                                                                                 int nets0, int tiles0, int tiles1) {
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd2_kernel(
+    const FwdArgs a0, const FwdArgs a1, int nets0, int tiles0, int tiles1) {
   if ((int)blockIdx.y < nets0) {
     if ((int)blockIdx.x >= tiles0) return;  // whole workgroup leaves before any barrier
-    mlp_fwd_body<NRB, NCB>(a0, blockIdx.y);
+    mlp_fwd_body<NRB, NCB, NW>(a0, blockIdx.y);
   } else {
     if ((int)blockIdx.x >= tiles1) return;
-    mlp_fwd_body<NRB, NCB>(a1, blockIdx.y - nets0);
+    mlp_fwd_body<NRB, NCB, NW>(a1, blockIdx.y - nets0);
   }
 }
 
@@ -826,8 +828,8 @@ struct BwdArgs {
   int32_t rows, lda;
 };
 
-template <int NRB, int NCB>
-__global__ __launch_bounds__(256, waves_per_simd_bwd(NRB, NCB)) void mlp_bwd_dz_kernel(const BwdArgs a) {
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -843,16 +845,16 @@ __global__ __launch_bounds__(256, waves_per_simd_bwd(NRB, NCB)) void mlp_bwd_dz_
     if (l >= 1) {
       const int K = a.net.dims[l + 1], N = a.net.dims[l];
       int cb0, cnt;
-      wave_blocks((N + 15) >> 4, wave, &cb0, &cnt);
+      wave_blocks<NW>((N + 15) >> 4, wave, &cb0, &cnt);
       layer_prefetch<NRB, NCB>(ring, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt);
     } else if (a.g.dx[e]) {
       const int nblk = (a.g.dx_cols + 15) >> 4, nk = round16(a.net.dims[1]) >> 4;
       const int Npb = round16(a.net.dims[0]) + 16;
-      if (nblk <= 2 && nk >= 4 && lda >= 64) {
-        narrow_prefetch<NCB>(ring, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave);
+      if (nblk <= 2 && nk >= 4 && lda >= 16 * NW) {
+        narrow_prefetch<NCB, NW>(ring, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave);
       } else {
         int cb0, cnt;
-        wave_blocks(nblk, wave, &cb0, &cnt);
+        wave_blocks<NW>(nblk, wave, &cb0, &cnt);
         layer_prefetch<NRB, NCB>(ring, nk, a.net.Wb[e][0], Npb, a.g.dx_col0 + cb0 * 16, cnt);
       }
     }
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(256, waves_per_simd_bwd(NRB, NCB)) void mlp_bwd_dz_
     const float* __restrict__ dy = a.g.dy[e];
     const float* __restrict__ y = a.saved.h[e][L - 1];
     const int act = a.net.acts[L - 1];
-    for (int idx = tid; idx < BM * NLp; idx += 256) {
+    for (int idx = tid; idx < BM * NLp; idx += 64 * NW) {
       const int r = idx / NLp, c = idx - r * NLp;
       const int gr = row0 + r;
       float v = 0.f;
@@ -883,7 +885,7 @@ __global__ __launch_bounds__(256, waves_per_simd_bwd(NRB, NCB)) void mlp_bwd_dz_
     const int K = a.net.dims[l + 1], N = a.net.dims[l];
     const int nblk = (N + 15) >> 4;
     int cb0, cnt;
-    wave_blocks(nblk, wave, &cb0, &cnt);
+    wave_blocks<NW>(nblk, wave, &cb0, &cnt);
     const float* __restrict__ h = a.saved.h[e][l - 1];
     const int act = a.net.acts[l - 1];
     // activation outputs needed by act'(.) in the epilogue: fetched BEFORE the k-loop (small tiles)
@@ -953,12 +955,12 @@ __global__ __launch_bounds__(256, waves_per_simd_bwd(NRB, NCB)) void mlp_bwd_dz_
     const int nk = round16(K) >> 4;
     const int Npb = round16(a.net.dims[0]) + 16;
     float* __restrict__ dx = a.g.dx[e];
-    if (nblk <= 2 && nk >= 4 && lda >= 64) {
-      narrow_layer_splitk<NRB, NCB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave, ring);
+    if (nblk <= 2 && nk >= 4 && lda >= 16 * NW) {
+      narrow_layer_splitk<NRB, NCB, NW>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave, ring);
       tile_to_global(lds, lda, BM, nc, dx, row0, rows);
     } else {
       int cb0, cnt;
-      wave_blocks(nblk, wave, &cb0, &cnt);
+      wave_blocks<NW>(nblk, wave, &cb0, &cnt);
       f32x4 acc[NRB][NCB];
       zero_acc<NRB, NCB>(acc);
       if (cnt > 0) layer_run<NRB, NCB>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0 + cb0 * 16, cnt, acc, ring);
@@ -1265,7 +1267,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
 inline int round16h(int x) { return (x + 15) & ~15; }
 
 struct TileChoice {
-  int nrb, ncb, lda;
+  int nrb, ncb, lda, nw;  // row blocks per tile, column blocks per wave, LDS row stride, waves per workgroup
 };
 
 // tile rows: keep >= ~2 workgroups per CU in flight when the row count allows it, otherwise shrink
@@ -1284,13 +1286,25 @@ inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) 
   // launch has >= 1024 of them (e.g. the N*B = 20480-row x 2-net OOD scoring of CPQ).
   const long wg32 = (long)((rows + 31) / 32) * net->n_nets;
   t.nrb = (t.ncb != 7 && wg32 >= 1024) ? 2 : 1;
-  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7))
+  t.nw = 4;
+  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7)) {
     t.nrb = net->tile_rows / 16;
+    return t;
+  }
+  // Launches with at most ~2 workgroups per CU (the 2048-row training launches: 128 row tiles x 1-4 nets) are
+  // serial latency chains inside each workgroup: give the workgroup 8 waves (2 per SIMD, half the column blocks
+  // each) so that two k-loops interleave on every SIMD and staging / epilogues use twice the lanes.
+  const long wg16 = (long)((rows + 15) / 16) * net->n_nets;
+  if (t.nrb == 1 && cpw > 2 && wg16 <= 2 * 256 && t.lda >= 128) {
+    t.nw = 8;
+    t.ncb = (nblk + 7) / 8 <= 2 ? 2 : 4;
+  }
   return t;
 }
 
 template <typename Args, typename K>
-int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int lda, hipStream_t stream) {
+int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int lda, hipStream_t stream,
+                 int threads = 256) {
   const int BM = 16 * nrb;
   const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
   dim3 grid((rows + BM - 1) / BM, nets, 1);
@@ -1300,12 +1314,16 @@ int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int ld
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, stream, args);
+  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds_bytes, stream, args);
   return (int)hipGetLastError();
 }
 
 #define OSRL_DISPATCH_TILE(KERNEL, ARGS, ROWS, NETS, T, STREAM)                         \
   do {                                                                                  \
+    if (T.nw == 8) {                                                                    \
+      if (T.ncb == 2) return launch_tiles(KERNEL<1, 2, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512); \
+      return launch_tiles(KERNEL<1, 4, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512);     \
+    }                                                                                   \
     if (T.ncb == 1) {                                                                   \
       if (T.nrb == 4) return launch_tiles(KERNEL<4, 1>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
       if (T.nrb == 2) return launch_tiles(KERNEL<2, 1>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
@@ -1422,20 +1440,20 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
   OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream);
 }
 
-template <int NRB, int NCB>
+template <int NRB, int NCB, int NW>
 static int launch_fwd2(const FwdArgs& a0, const FwdArgs& a1, int nets0, int nets1, int rows0, int rows1, int lda,
                        hipStream_t stream) {
   const int BM = 16 * NRB;
   const int t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
   const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd2_kernel<NRB, NCB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd2_kernel<NRB, NCB, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();
-  hipLaunchKernelGGL((mlp_fwd2_kernel<NRB, NCB>), dim3(t0 > t1 ? t0 : t1, nets0 + nets1, 1), dim3(256), lds_bytes, stream,
-                     a0, a1, nets0, t0, t1);
+  hipLaunchKernelGGL((mlp_fwd2_kernel<NRB, NCB, NW>), dim3(t0 > t1 ? t0 : t1, nets0 + nets1, 1), dim3(64 * NW),
+                     lds_bytes, stream, a0, a1, nets0, t0, t1);
   return (int)hipGetLastError();
 }
 
@@ -1443,10 +1461,10 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
                                  const osrl_mlp_t* net1, const osrl_rows_t* in1, const osrl_mlp_acts_t* out1,
                                  void* stream) {
   if (!valid_net(net0) || !valid_net(net1) || !in0 || !in1 || !out0 || !out1) return -1;
-  const TileChoice t0 = choose_tile(net0, in0->rows, 0), t1 = choose_tile(net1, in1->rows, 0);
-  // pair only 16-row-tile launches of the two common column shapes; anything else runs as two launches
-  const bool pair = t0.nrb == 1 && t1.nrb == 1 && t0.ncb == t1.ncb && (t0.ncb == 4 || t0.ncb == 7) &&
-                    net0->n_nets + net1->n_nets <= 2 * OSRL_MAX_NETS;
+  TileChoice t0 = choose_tile(net0, in0->rows, 0), t1 = choose_tile(net1, in1->rows, 0);
+  // pair only 16-row-tile launches of equal tile shape; anything else runs as two launches
+  const bool pair = t0.nrb == 1 && t1.nrb == 1 && t0.ncb == t1.ncb && t0.nw == t1.nw &&
+                    ((t0.nw == 8 && (t0.ncb == 2 || t0.ncb == 4)) || (t0.nw == 4 && (t0.ncb == 4 || t0.ncb == 7)));
   if (!pair) {
     const int rc = osrl_mlp_forward(net0, in0, out0, stream);
     return rc != 0 ? rc : osrl_mlp_forward(net1, in1, out1, stream);
@@ -1467,9 +1485,14 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
   a1.net = *net1; a1.in = *in1; a1.out = *out1;
   const int lda = t0.lda > t1.lda ? t0.lda : t1.lda;
   a0.lda = a1.lda = lda;
-  if (t0.ncb == 4)
-    return launch_fwd2<1, 4>(a0, a1, net0->n_nets, net1->n_nets, in0->rows, in1->rows, lda, (hipStream_t)stream);
-  return launch_fwd2<1, 7>(a0, a1, net0->n_nets, net1->n_nets, in0->rows, in1->rows, lda, (hipStream_t)stream);
+  const int n0 = net0->n_nets, n1 = net1->n_nets, r0 = in0->rows, r1 = in1->rows;
+  hipStream_t st = (hipStream_t)stream;
+  if (t0.nw == 8) {
+    if (t0.ncb == 2) return launch_fwd2<1, 2, 8>(a0, a1, n0, n1, r0, r1, lda, st);
+    return launch_fwd2<1, 4, 8>(a0, a1, n0, n1, r0, r1, lda, st);
+  }
+  if (t0.ncb == 4) return launch_fwd2<1, 4, 4>(a0, a1, n0, n1, r0, r1, lda, st);
+  return launch_fwd2<1, 7, 4>(a0, a1, n0, n1, r0, r1, lda, st);
 }
 
 extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
