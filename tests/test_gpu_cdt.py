@@ -25,7 +25,9 @@ def test_linear_kernel_shapes():
     rs = np.random.RandomState(0)
     r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
     for (M, K, N) in [(200, 256, 768), (96, 1024, 256), (130, 256, 1024), (77, 16, 6), (64, 128, 2), (50, 3, 40),
-                      (300, 768, 256), (33, 6, 128)]:
+                      (300, 768, 256), (33, 6, 128),
+                      # M >= 4096 with N % 256 == 0: the LDS-tiled linear_big_kernel (forward and dX)
+                      (4096 + 37, 256, 768), (5000, 1024, 256), (4608, 256, 1024), (4100, 16, 256)]:
         g = FlatGroup("t", DEV)
         g.add("w", (N, K))
         g.mark_weight("w")
