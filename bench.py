@@ -170,14 +170,20 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dp = None
-    if world > 1:
+    force_dp = world == 1 and os.environ.get("OSRL_FORCE_DP") == "1"  # debug: the data-parallel step on one rank
+    if world > 1 or force_dp:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if force_dp:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
         from osrl_amd.engine.dist import DataParallel
         dp = DataParallel()
 
     model, trainer, store = build(device, rank, world)
-    eng = model.engine(B, rows_global=B * world, seed=1234 + rank, dist=dp) if world > 1 else model.engine(B)
+    eng = model.engine(B, rows_global=B * world, seed=1234 + rank, dist=dp) if dp is not None else model.engine(B)
     eng.attach_replay(store)
     if dp is not None:
         dp.broadcast_model(model)
@@ -222,7 +228,7 @@ def main():
                                    "hidden [256,256], VAE 400, N=10, num_q=num_qc=2; on-device replay sampling "
                                    "from a 2^20-transition HBM store + Philox noise inside the step",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "graph": bool(eng.graph is not None), "parallel_graph_branches": bool(world == 1)},
+                       "graph": bool(eng.graph is not None), "parallel_graph_branches": True},
             "algorithmic_gflop_per_step": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / 1e9, 2),
             "step_tflops": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / (dt / args.steps) / 1e12, 3),
             "last_stats": {k: round(float(v), 5) for k, v in stats.items()},
@@ -233,7 +239,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

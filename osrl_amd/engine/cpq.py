@@ -115,13 +115,17 @@ class CPQEngine:
         self._graph_failed = False
 
     # ------------------------------------------------------------------ #
-    def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
+    def _update(self, name: str, tau: float) -> None:
+        """(data parallel: all-reduce of the flat gradient, then) the fused Adam + Polyak + repack of one group."""
         m = self.model
-        plan.launch()
         grp = m.groups[name]
         if self.dist is not None:
             self.dist.allreduce_group(grp)
         grp.adam_step(m._lrs[name], self.st.ptr, tau=tau)
+
+    def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
+        plan.launch()
+        self._update(name, tau)
 
     def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
         """One step.  ``par`` (graph capture only) forks the independent parts onto side streams:
@@ -171,7 +175,10 @@ class CPQEngine:
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
-            self._optim("critic", self.p_critic, m.tau)
+            if self.dist is None:
+                self._optim("critic", self.p_critic, m.tau)
+            else:  # collectives stay on the capture stream (same order on every rank): update after the join
+                self.p_critic.launch()
 
         # ---- cost_critic_loss  (cpq.py:155-201): OOD scoring with the UPDATED vae
         par.wait(ev_sampled)
@@ -182,6 +189,8 @@ class CPQEngine:
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
         par.join(0)  # side branch done (it also reads cost_critic_old, which the next optimizer step updates)
+        if self.dist is not None:
+            self._update("critic", m.tau)
         if self.dist is None and rg in (0, B):  # no batch-global reduction in between: one launch
             G.cpq_cost_loss_ood(qc_s, nqc, self.kl, self.quant, N, qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost,
                                 B, m.gamma, m.qc_thres, m.alpha_lr, m.log_alpha, self.dqc,
@@ -223,8 +232,9 @@ class CPQEngine:
         """Capture one step (device-drawn noise) into a hipGraph.  Warm-up launches run first on a
         side stream as torch requires; the model state they advance is restored afterwards."""
         snap = self._snapshot()
-        # collectives stay on the capture stream: no forked branches in the data-parallel graph
-        par = Branches(self.parallel_branches and self.dist is None, 1)
+        # data parallel: the side branch holds no collective (the critic group's all-reduce + Adam run on the
+        # capture stream after the join), so every rank issues its RCCL calls in the same order on one stream
+        par = Branches(self.parallel_branches, 1)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
