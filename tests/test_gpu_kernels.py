@@ -300,6 +300,42 @@ def test_adam_polyak_matches_oracle():
         np.testing.assert_allclose(grp.tgt_view(k).cpu().numpy(), tgt[k], atol=2e-6, rtol=0)
 
 
+def test_adam_step_refreshes_packed_copies():
+    """osrl_adam_step_packed: after an optimizer step the fragment-ordered copies pf / pb (and tf for the Polyak
+    target) equal a fresh osrl_pack_weights of the updated parameters, padding included (odd shapes, unaligned
+    row lengths, a packed two-head alias, non-weight tensors in between)."""
+    from osrl_amd.engine.core import FlatGroup, StepState
+    dev = _dev()
+    rs = np.random.RandomState(31)
+    grp = FlatGroup("g", dev, with_target=True)
+    grp.add("a.w", (37, 5))
+    grp.mark_weight("a.w")
+    grp.add("a.b", (37,))
+    grp.add("mu.w", (3, 50), align=True)
+    grp.add("ls.w", (3, 50), align=False)      # adjacent -> one [6, 50] packed head
+    grp.alias("head.w", "mu.w", (6, 50))
+    grp.mark_weight("head.w")
+    grp.add("c.w", (256, 78))
+    grp.mark_weight("c.w")
+    grp.add("c.b", (256,))
+    grp.finalize()
+    grp.p.copy_(torch.tensor(rs.randn(grp.n), dtype=torch.float32))
+    grp.tgt.copy_(torch.tensor(rs.randn(grp.n), dtype=torch.float32))
+    grp.repack()
+    grp.ensure_slabs(2)
+    grp.cur_splits = 2
+    st = StepState(dev, ["x"])
+    for _ in range(3):
+        grp.slabs.copy_(torch.tensor(rs.randn(2, grp.n), dtype=torch.float32))
+        st.tick()
+        grp.adam_step(1e-2, st.ptr, tau=0.3)
+    got = [t.clone() for t in (grp.pf, grp.pb, grp.tf)]
+    grp.repack()
+    torch.cuda.synchronize()
+    for name, a, b in zip(("pf", "pb", "tf"), got, (grp.pf, grp.pb, grp.tf)):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("n", [1, 7, 1000, 20480, 163840])
 def test_quantile_exact(n):
     from osrl_amd.engine import glue as G
