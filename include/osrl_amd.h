@@ -42,6 +42,9 @@ typedef struct {
   float out_scale;                   /* net output = out_scale * act(z)  (act_limit of net.py:62,85,339) */
   int32_t tile_rows;                 /* tuning hint: rows per workgroup tile (0 = auto, else 16 / 32 / 64);
                                       * -1 = forward-only launches may use the LDS-staged-weights kernel */
+  int32_t wg_cap;                    /* forward launches: at most this many workgroups in the grid (0 = one per
+                                      * tile); a capped launch walks its tiles, leaving CU slots to concurrent
+                                      * latency-critical launches */
   /* PACKED weights (osrl_pack_weights): Wf feeds forward, Wb (packed W^T) feeds backward-dz.
    * Wf[e][l]: PF[k/4][n][k%4], n < round16(out), k < round16(in), zero padded.
    * Wb[e][l]: PB[o/4][i][o%4], i < round16(in)+16, o < round16(out), zero padded (NULL if unused). */

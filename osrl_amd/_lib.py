@@ -28,7 +28,7 @@ _fp = C.c_void_p  # device float*
 class MlpT(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("n_nets", C.c_int32),
                 ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
-                ("out_scale", C.c_float), ("tile_rows", C.c_int32),
+                ("out_scale", C.c_float), ("tile_rows", C.c_int32), ("wg_cap", C.c_int32),
                 ("Wf", (_fp * MAX_LAYERS) * MAX_NETS), ("Wb", (_fp * MAX_LAYERS) * MAX_NETS),
                 ("b", (_fp * MAX_LAYERS) * MAX_NETS)]
 

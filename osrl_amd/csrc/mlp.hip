@@ -433,12 +433,12 @@ constexpr int waves_per_simd(int nrb, int ncb) {
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
 
 template <int NRB, int NCB, int NW>
-__device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
+__device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e, const int tile) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * BM;
+  const int row0 = tile * BM;
   const int rows = a.in.rows, lda = a.lda;
   const int L = a.net.n_layers;
 
@@ -555,7 +555,13 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e) {
 
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd_kernel(const FwdArgs a) {
-  mlp_fwd_body<NRB, NCB, NW>(a, blockIdx.y);
+  // gridDim.x may be capped below the tile count (osrl_mlp_t::wg_cap): a big launch that is NOT on the critical
+  // path then leaves CU slots and MFMA issue to the latency-critical 128-workgroup launches it runs beside
+  const int n_tiles = (a.in.rows + 16 * NRB - 1) / (16 * NRB);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    mlp_fwd_body<NRB, NCB, NW>(a, blockIdx.y, tile);
+    __syncthreads();  // the LDS tile is reused
+  }
 }
 
 // Two independent forward problems (different networks / inputs, same tile shape) in ONE launch: the 2048-row
@@ -566,10 +572,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
     const FwdArgs a0, const FwdArgs a1, int nets0, int tiles0, int tiles1) {
   if ((int)blockIdx.y < nets0) {
     if ((int)blockIdx.x >= tiles0) return;  // whole workgroup leaves before any barrier
-    mlp_fwd_body<NRB, NCB, NW>(a0, blockIdx.y);
+    mlp_fwd_body<NRB, NCB, NW>(a0, blockIdx.y, blockIdx.x);
   } else {
     if ((int)blockIdx.x >= tiles1) return;
-    mlp_fwd_body<NRB, NCB, NW>(a1, blockIdx.y - nets0);
+    mlp_fwd_body<NRB, NCB, NW>(a1, blockIdx.y - nets0, blockIdx.x);
   }
 }
 
@@ -1400,10 +1406,12 @@ inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) 
 
 template <typename Args, typename K>
 int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int lda, hipStream_t stream,
-                 int threads = 256) {
+                 int threads = 256, int wg_cap = 0) {
   const int BM = 16 * nrb;
   const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
-  dim3 grid((rows + BM - 1) / BM, nets, 1);
+  int tiles = (rows + BM - 1) / BM;
+  if (wg_cap > 0 && tiles * nets > wg_cap) tiles = (wg_cap + nets - 1) / nets;  // forward kernel loops over tiles
+  dim3 grid(tiles, nets, 1);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1414,29 +1422,29 @@ int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int ld
   return (int)hipGetLastError();
 }
 
-#define OSRL_DISPATCH_TILE(KERNEL, ARGS, ROWS, NETS, T, STREAM)                         \
+#define OSRL_DISPATCH_TILE(KERNEL, ARGS, ROWS, NETS, T, STREAM, CAP)                        \
   do {                                                                                  \
     if (T.nw == 8) {                                                                    \
-      if (T.ncb == 2) return launch_tiles(KERNEL<1, 2, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512); \
-      return launch_tiles(KERNEL<1, 4, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512);     \
+      if (T.ncb == 2) return launch_tiles(KERNEL<1, 2, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512, CAP); \
+      return launch_tiles(KERNEL<1, 4, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512, CAP);     \
     }                                                                                   \
     if (T.ncb == 1) {                                                                   \
-      if (T.nrb == 4) return launch_tiles(KERNEL<4, 1>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
-      if (T.nrb == 2) return launch_tiles(KERNEL<2, 1>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
-      return launch_tiles(KERNEL<1, 1>, ARGS, ROWS, NETS, 1, T.lda, STREAM);             \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 1>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 1>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+      return launch_tiles(KERNEL<1, 1>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
     }                                                                                   \
     if (T.ncb == 2) {                                                                   \
-      if (T.nrb == 4) return launch_tiles(KERNEL<4, 2>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
-      if (T.nrb == 2) return launch_tiles(KERNEL<2, 2>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
-      return launch_tiles(KERNEL<1, 2>, ARGS, ROWS, NETS, 1, T.lda, STREAM);             \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 2>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 2>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+      return launch_tiles(KERNEL<1, 2>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
     }                                                                                   \
     if (T.ncb == 4) {                                                                   \
-      if (T.nrb == 4) return launch_tiles(KERNEL<4, 4>, ARGS, ROWS, NETS, 4, T.lda, STREAM); \
-      if (T.nrb == 2) return launch_tiles(KERNEL<2, 4>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
-      return launch_tiles(KERNEL<1, 4>, ARGS, ROWS, NETS, 1, T.lda, STREAM);             \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 4>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 4>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+      return launch_tiles(KERNEL<1, 4>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
     }                                                                                   \
-    if (T.nrb == 2) return launch_tiles(KERNEL<2, 7>, ARGS, ROWS, NETS, 2, T.lda, STREAM); \
-    return launch_tiles(KERNEL<1, 7>, ARGS, ROWS, NETS, 1, T.lda, STREAM);               \
+    if (T.nrb == 2) return launch_tiles(KERNEL<2, 7>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+    return launch_tiles(KERNEL<1, 7>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);               \
   } while (0)
 
 bool valid_net(const osrl_mlp_t* n) {
@@ -1533,7 +1541,7 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
   a.out = *out;
   const TileChoice t = choose_tile(net, in->rows, 0);
   a.lda = t.lda;
-  OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream);
+  OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream, net->wg_cap);
 }
 
 template <int NRB, int NCB, int NW>
@@ -1609,7 +1617,7 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
   a.rows = rows;
   const TileChoice t = choose_tile(net, rows, g->dx_cols);
   a.lda = t.lda;
-  OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream);
+  OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream, 0);
 }
 
 

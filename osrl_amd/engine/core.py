@@ -275,8 +275,14 @@ class MlpRun:
     otherwise only the net outputs ``y`` [E, rows, out] are written.
     """
 
-    def __init__(self, net: NetDesc, rows: int, save: bool, device, save_nets: Optional[Sequence[int]] = None):
+    def __init__(self, net: NetDesc, rows: int, save: bool, device, save_nets: Optional[Sequence[int]] = None,
+                 wg_cap: int = 0):
         self.net, self.rows, self.save = net, rows, save
+        # forward descriptor of THIS use: a capped launch walks its tiles with at most wg_cap workgroups in flight
+        self.fwd_c = net.c
+        if wg_cap:
+            self.fwd_c = L.MlpT.from_buffer_copy(net.c)
+            self.fwd_c.wg_cap = int(wg_cap)
         f = dict(dtype=torch.float32, device=device)
         E, nl, dims = net.E, net.nl, net.dims
         self.y = torch.zeros(E, rows, dims[-1], **f)
@@ -336,7 +342,7 @@ class MlpRun:
         else:
             r.d1, r.map1, r.div1 = 0, L.MAP_ID, 1
         assert r.d0 + r.d1 == self.net.dims[0], (r.d0, r.d1, self.net.dims)
-        L.check(L.load().osrl_mlp_forward(C.byref(self.net.c), C.byref(r), C.byref(self.acts_c), cur_stream()),
+        L.check(L.load().osrl_mlp_forward(C.byref(self.fwd_c), C.byref(r), C.byref(self.acts_c), cur_stream()),
                 "osrl_mlp_forward")
         return self.y
 

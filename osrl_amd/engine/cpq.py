@@ -12,6 +12,7 @@ Common sub-expressions the reference recomputes are evaluated once (exact, not a
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -90,8 +91,11 @@ class CPQEngine:
         self.r_costold_next = MlpRun(self.d_cost_old, B, False, dev)
         self.r_actor_obs = MlpRun(self.d_actor, B, True, dev)  # also the actor forward of the actor phase
         self.sampled = z(N * B, ad)
-        self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev)
-        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev)
+        # off the critical path (it runs beside the VAE phase): capped so that phase's 128-workgroup launches keep
+        # CU slots and MFMA issue (OSRL_OOD_WG_CAP overrides; 0 = uncapped)
+        self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev,
+                                    wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "512")))
+        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev, wg_cap=int(os.environ.get("OSRL_ENC_WG_CAP", "0")))
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)
