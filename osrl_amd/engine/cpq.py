@@ -167,6 +167,8 @@ class CPQEngine:
             hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
             head_next, head_obs = hn[0], ho[0]
             G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+            G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)  # early: tiny launches
+            # issued while an N*B-row kernel holds the CU slots wait tens of microseconds for one
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
             ev_sampled = par.mark(0)
             # the actor-phase sample (cpq.py:209) needs only this forward and its own noise: off the critical tail
@@ -174,7 +176,6 @@ class CPQEngine:
             qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
             qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
                                                                (self.obs, self.act))
-            G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
