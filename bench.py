@@ -93,7 +93,9 @@ def roofline(eng):
     for name, (run, fn) in cands.items():
         t = time_kernel(fn)
         res[name] = dict(seconds=t, flops=mlp_fwd_flops(run))
-    dom = max(res, key=lambda k: res[k]["seconds"])
+    # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows); the other N*B launch
+    # is deliberately throttled in the step (wg_cap: it runs beside the latency-critical VAE phase) and is listed too
+    dom = max(res, key=lambda k: res[k]["flops"])
     ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -104,7 +106,8 @@ def roofline(eng):
             traffic = None
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-            "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)}
+            "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2),
+                            "wg_cap": int(cands[k][0].fwd_c.wg_cap)}
                         for k, v in res.items()}}
 
 

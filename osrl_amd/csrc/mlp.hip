@@ -555,11 +555,17 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e, cons
 
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd_kernel(const FwdArgs a) {
-  // gridDim.x may be capped below the tile count (osrl_mlp_t::wg_cap): a big launch that is NOT on the critical
-  // path then leaves CU slots and MFMA issue to the latency-critical 128-workgroup launches it runs beside
+  mlp_fwd_body<NRB, NCB, NW>(a, blockIdx.y, blockIdx.x);
+}
+
+// gridDim.x capped below the tile count (osrl_mlp_t::wg_cap): a big launch that is NOT on the critical path then
+// leaves CU slots and MFMA issue to the latency-critical 128-workgroup launches it runs beside.  (A separate
+// kernel: the tile loop costs the one-tile kernel ~12 more spilled registers and 3 % of its speed.)
+template <int NRB, int NCB>
+__global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_loop_kernel(const FwdArgs a) {
   const int n_tiles = (a.in.rows + 16 * NRB - 1) / (16 * NRB);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    mlp_fwd_body<NRB, NCB, NW>(a, blockIdx.y, tile);
+    mlp_fwd_body<NRB, NCB, 4>(a, blockIdx.y, tile);
     __syncthreads();  // the LDS tile is reused
   }
 }
@@ -1541,7 +1547,18 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
   a.out = *out;
   const TileChoice t = choose_tile(net, in->rows, 0);
   a.lda = t.lda;
-  OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream, net->wg_cap);
+  if (net->wg_cap > 0 && t.nw == 4 && (t.ncb == 4 || t.ncb == 7) && t.nrb <= 2 &&
+      (long)((in->rows + 16 * t.nrb - 1) / (16 * t.nrb)) * net->n_nets > net->wg_cap) {
+    hipStream_t st = (hipStream_t)stream;
+    const int cap = net->wg_cap, R = in->rows, E = net->n_nets;
+    if (t.ncb == 4) {
+      if (t.nrb == 2) return launch_tiles(mlp_fwd_loop_kernel<2, 4>, a, R, E, 2, t.lda, st, 256, cap);
+      return launch_tiles(mlp_fwd_loop_kernel<1, 4>, a, R, E, 1, t.lda, st, 256, cap);
+    }
+    if (t.nrb == 2) return launch_tiles(mlp_fwd_loop_kernel<2, 7>, a, R, E, 2, t.lda, st, 256, cap);
+    return launch_tiles(mlp_fwd_loop_kernel<1, 7>, a, R, E, 1, t.lda, st, 256, cap);
+  }
+  OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream, 0);
 }
 
 template <int NRB, int NCB, int NW>
