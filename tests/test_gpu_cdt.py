@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from cases import CDT_CASES, make_cdt_batch, make_cdt_params
+from cases import CDT_CASES, CDTCase, make_cdt_batch, make_cdt_params
 from oracle_util import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -253,13 +253,19 @@ def test_cdt_train_step_matches_golden_and_oracle(name):
     assert np.abs(a - g["act"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_cdt_dropout_train_step_matches_oracle(use_graph):
+# BASELINE.json C5 architecture (T=20 -> 80 tokens, E=256, 8 heads, 3 layers, dropout 0.1) on a 64-sample slice of
+# the batch: 5120 token rows reach linear_big_kernel (M >= 4096) and the bench-size attention / dW tiles.
+C5_SLICE = CDTCase("cdt_c5_slice", od=11, ad=3, B=64, T=20, E=256, heads=8, layers=3, episode_len=1000, steps=2,
+                   warmup=500, dropout=0.1, seed=5)
+
+
+@pytest.mark.parametrize("case,use_graph", [("cdt_drop", False), ("cdt_drop", True), ("cdt_c5_slice", False)])
+def test_cdt_dropout_train_step_matches_oracle(case, use_graph):
     """Dropout 0.1 at every site (the train-config default): the GPU step draws Philox masks; the oracle (pinned
     against the reference with injected masks, tests/golden/cdt_drop.npz) replays the same masks, exported from
     the generator after each step.  Also: eval-mode inference applies no dropout."""
     from test_oracle_cdt_golden import build_cdt_oracle
-    c = CDT_CASES["cdt_drop"]
+    c = C5_SLICE if case == "cdt_c5_slice" else CDT_CASES[case]
     m, tr, lg = build_cdt_gpu(c, use_graph=use_graph, seed=1234)
     o = build_cdt_oracle(c)
     bn = make_cdt_batch(c)
