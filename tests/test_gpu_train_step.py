@@ -157,11 +157,15 @@ def test_graph_replay_is_deterministic_and_trains(name):
     assert moved == len(p0)
 
 
-@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small"])
+@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full"])
 def test_graph_with_parallel_branches_equals_eager_sequential(name):
     """The captured graph (forked side-stream branches, device Philox noise) must produce exactly the same
     parameters as the plain in-order launch sequence: same kernels, same inputs, no atomics."""
-    c = CASES[name]
+    if name in CASES:
+        c = CASES[name]
+    else:  # bench-size CPQ: capped N*B launch beside the VAE phase, paired launches
+        from cases import Case
+        c = Case(name, episode_len=1000, **FULL_CASES[name])
     res = []
     for use_graph in (False, True):
         m, tr, lg = build_gpu(c, stats_mode="none", use_graph=use_graph)
