@@ -15,7 +15,7 @@ import torch
 from .. import _lib as L
 from ..common.net import net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import DwPlan, MlpRun, StepState, concat_nets, randn_fill
+from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, randn_fill
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/qc_penalty",
              "loss/lagrangian"]
@@ -70,6 +70,10 @@ class BCQLEngine:
         self.a_t = z(NB, ad)
         self.r_qold_t = MlpRun(self.d_critic_old, NB, False, dev)
         self.r_qcold_t = MlpRun(self.d_cost_old, NB, False, dev)
+        # second set of pipeline buffers: the cost-critic phase runs on a side graph branch beside the critic phase
+        self.r_dec_t2 = MlpRun(self.d_dec, NB, False, dev)
+        self.r_actor_old_t2 = MlpRun(self.d_actor_old, NB, False, dev)
+        self.a_t2 = z(NB, ad)
 
         self.r_critic = MlpRun(self.d_critic, B, True, dev)
         self.dq = z(2 * nq, B, 1)
@@ -101,15 +105,28 @@ class BCQLEngine:
             self.dist.allreduce_group(grp)
         grp.adam_step(self.model._lrs[name], self.st.ptr, tau=tau)
 
-    def _targets(self, zkey: str, r_q: MlpRun) -> torch.Tensor:
+    def _targets(self, zkey: str, r_q: MlpRun, second: bool = False) -> torch.Tensor:
         """bcql.py:138-142: Q_old(obs', actor_old(obs', vae.decode(obs'))) on the N*B repeated rows."""
         m, N, NB = self.model, self.model.sample_action_num, self.model.sample_action_num * self.B
-        dec = self.r_dec_t.forward(self.nobs, self.noise[zkey], map0=L.MAP_DIV, div0=N)[0]
-        t = self.r_actor_old_t.forward(self.nobs, dec, map0=L.MAP_DIV, div0=N)[0]
-        G.bcq_perturb(dec, t, NB, m.action_dim, m.phi, m.max_action, self.a_t)
-        return r_q.forward(self.nobs, self.a_t, map0=L.MAP_DIV, div0=N)
+        r_dec, r_act, a_t = (self.r_dec_t2, self.r_actor_old_t2, self.a_t2) if second else \
+            (self.r_dec_t, self.r_actor_old_t, self.a_t)
+        dec = r_dec.forward(self.nobs, self.noise[zkey], map0=L.MAP_DIV, div0=N)[0]
+        t = r_act.forward(self.nobs, dec, map0=L.MAP_DIV, div0=N)[0]
+        G.bcq_perturb(dec, t, NB, m.action_dim, m.phi, m.max_action, a_t)
+        return r_q.forward(self.nobs, a_t, map0=L.MAP_DIV, div0=N)
 
-    def body(self, device_noise: bool) -> None:
+    def _update(self, name: str, tau: float) -> None:
+        grp = self.model.groups[name]
+        if self.dist is not None:
+            self.dist.allreduce_group(grp)
+        grp.adam_step(self.model._lrs[name], self.st.ptr, tau=tau)
+
+    def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
+        """``par`` (graph capture): cost_critic_loss (bcql.py:157-179) reads only the updated VAE, actor_old and
+        cost_critic_old -- nothing the critic phase writes -- so it runs on a side branch beside critic_loss; its
+        optimizer step waits for the join (it Polyak-updates nothing the critic branch reads, but a data-parallel
+        all-reduce must stay on the capture stream)."""
+        par = par or Branches(False)
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
@@ -130,6 +147,7 @@ class BCQLEngine:
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
 
+        par.fork(0)
         q_t = self._targets("z_c", self.r_qold_t)
         q = self.r_critic.forward(self.obs, self.act)
         G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
@@ -137,12 +155,15 @@ class BCQLEngine:
         self.r_critic.backward_dz()
         self._optim("critic", self.p_critic, m.tau)
 
-        qc_t = self._targets("z_cc", self.r_qcold_t)
-        qc = self.r_cost.forward(self.obs, self.act)
-        G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
-                          st.stat_ptr("loss/cost_critic_loss"))
-        self.r_cost.backward_dz()
-        self._optim("cost_critic", self.p_cost, m.tau)
+        with par.on(0):
+            qc_t = self._targets("z_cc", self.r_qcold_t, second=True)
+            qc = self.r_cost.forward(self.obs, self.act)
+            G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
+                              st.stat_ptr("loss/cost_critic_loss"))
+            self.r_cost.backward_dz()
+            self.p_cost.launch()
+        par.join(0)
+        self._update("cost_critic", m.tau)
 
         dec = self.r_dec_b.forward(self.obs, nz["z_actor"])[0]
         t = self.r_actor.forward(self.obs, dec)[0]
@@ -195,9 +216,11 @@ class BCQLEngine:
         with torch.cuda.stream(s):
             self.body(True)
         torch.cuda.current_stream().wait_stream(s)
+        par = Branches(True, 1)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.body(True)
+            self.body(True, par)
+        self._par = par  # keep the side stream alive with the graph
         torch.cuda.synchronize()
         self._restore(snap)
         self.graph = g
