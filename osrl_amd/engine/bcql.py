@@ -162,12 +162,13 @@ class BCQLEngine:
                               st.stat_ptr("loss/cost_critic_loss"))
             self.r_cost.backward_dz()
             self.p_cost.launch()
+            # head of actor_loss (bcql.py:183-187): needs the updated VAE and the not-yet-updated actor only
+            dec = self.r_dec_b.forward(self.obs, nz["z_actor"])[0]
+            t = self.r_actor.forward(self.obs, dec)[0]
+            G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
         par.join(0)
         self._update("cost_critic", m.tau)
 
-        dec = self.r_dec_b.forward(self.obs, nz["z_actor"])[0]
-        t = self.r_actor.forward(self.obs, dec)[0]
-        G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
         means, share = None, 1.0
         if self.dist is not None:  # the PID controller acts on the GLOBAL mean of qc_pi
