@@ -92,17 +92,9 @@ __device__ __forceinline__ void wave_blocks(int nblk, int wave, int* cb0, int* c
   *cb0 = wave * base + (wave < rem ? wave : rem);
 }
 
-// B fragment (4 consecutive k of column n) from the packed layout P[q = k/4][n][4], Np columns.
-__device__ __forceinline__ f32x4 load_bp(const float* __restrict__ P, int Np, int q, int n) {
-#ifdef OSRL_EXP_NO_BLOAD  // experiment (tools/mlp_phase.hip): no weight traffic, operands made up from the indices
-  const float v = (float)(q + n) * 1e-6f;
-  return f32x4{v, v + 1.f, v + 2.f, v + 3.f};
-#else
-  return *reinterpret_cast<const f32x4*>(P + ((size_t)q * Np + n) * 4);
-#endif
-}
-// same fragment with the k-step part of the address kept scalar: P + kc*16*Np is wave-uniform (SGPR pair), the
-// lane part (kq*Np + n)*4 floats is a 32-bit VGPR offset computed once per layer -> global_load saddr+voffset
+// B fragment (4 consecutive k of column n) from the packed layout P[q = k/4][n][4], Np columns, with the k-step
+// part of the address kept scalar: P + kc*16*Np is wave-uniform (SGPR pair), the lane part (kq*Np + n)*16 bytes is a
+// 32-bit VGPR offset computed once per layer -> global_load_dwordx4 saddr+voffset
 __device__ __forceinline__ f32x4 load_bp_s(const float* __restrict__ Pk /*uniform*/, unsigned lane_off_bytes) {
 #ifdef OSRL_EXP_NO_BLOAD
   const float v = (float)lane_off_bytes * 1e-6f;
