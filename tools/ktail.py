@@ -17,7 +17,7 @@ E, dims, acts, d0 = CFG[name]
 dev = torch.device("cuda:0")
 lin = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
 for rows in map(int, sys.argv[3:]):
-    grp, d = mk(E, dims, acts, dev, -1 if tile == 0 else tile)
+    grp, d = mk(E, dims, acts, dev, tile)  # 0 = library default, -1 = opt-in LDS-staged kernel
     x0 = torch.randn(rows, d0, device=dev)
     x1 = torch.randn(rows, dims[0] - d0, device=dev) if dims[0] > d0 else None
     run = MlpRun(d, rows, False, dev)
