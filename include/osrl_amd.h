@@ -323,6 +323,26 @@ int osrl_clip_grad_scale(const float* grad, int64_t n, float clip, float* partia
 int osrl_cdt_temperature_step(float* log_temperature, float* moments, const float* entropy, float target_entropy,
                               float lr, float beta1, float beta2, float eps, const osrl_step_state_t* st, void* stream);
 
+/* ---- batched on-device evaluation ----
+ * The reference's Trainer.rollout (cpq.py:330-347, bcql.py:323-340, bc.py:125-145) steps ONE gym env per policy
+ * call and crosses host<->device every env step.  No gym env exists in either container, so the build owns a
+ * synthetic safe environment (osrl_amd/common/synthetic_env.py: s' = A s + Bm clip(a), reward = 1 - 0.1|s'-goal|^2,
+ * cost = 1[s'.w > threshold]); this is its vectorised device step: one row per episode.
+ *   state[E, state_dim]  in/out;  obs[E, obs_ld] receives s' in its first state_dim columns (the policy's input
+ *   buffer; extra columns, e.g. BC multi-task's cost_limit, are left alone);
+ *   acc[E,4] = {return, cost*cost_scale, length, done}: accumulated here, done latches at episode_len and freezes
+ *   the episode (state, obs and totals stop changing). */
+typedef struct {
+  const float* At;   /* A transposed:  At[j*state_dim + i] = A[i][j]   (coalesced per-output reads) */
+  const float* Bt;   /* Bm transposed: Bt[k*state_dim + i] = Bm[i][k] */
+  const float* w;    /* [state_dim] cost half-space normal */
+  const float* goal; /* [state_dim] */
+  int32_t state_dim, action_dim, episode_len, pad_;
+  float max_action, cost_threshold, cost_scale, pad2_;
+} osrl_env_t;
+int osrl_env_step(const osrl_env_t* env, const float* act, float* state, float* obs, int32_t obs_ld, float* acc,
+                  int32_t episodes, void* stream);
+
 /* library identity */
 const char* osrl_version(void);
 

@@ -62,6 +62,13 @@ class DropoutT(C.Structure):
     _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64), ("st", C.c_void_p)]
 
 
+class EnvT(C.Structure):
+    _fields_ = [("At", C.c_void_p), ("Bt", C.c_void_p), ("w", C.c_void_p), ("goal", C.c_void_p),
+                ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("episode_len", C.c_int32), ("pad_", C.c_int32),
+                ("max_action", C.c_float), ("cost_threshold", C.c_float), ("cost_scale", C.c_float),
+                ("pad2_", C.c_float)]
+
+
 class StepStateT(C.Structure):
     _fields_ = [("step", C.c_int64), ("bc1", C.c_float), ("bc2_sqrt", C.c_float),
                 ("lr_scale", C.c_float), ("pad_", C.c_float)]
@@ -73,6 +80,7 @@ _P = C.POINTER
 # name -> argtypes  (all return int except osrl_version); must match include/osrl_amd.h
 PROTOTYPES = {
     "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
+    "osrl_env_step": [_P(EnvT), _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],

@@ -86,6 +86,12 @@ class BCTrainer:
         store_stats(self.logger, eng.st, self.stats_mode)
 
     def evaluate(self, eval_episodes):
+        """bc.py:111-123.  A ``VecSyntheticSafeEnv`` as ``self.env`` runs the episodes as one batch on device."""
+        from ..common.synthetic_env import VecSyntheticSafeEnv
+        if isinstance(self.env, VecSyntheticSafeEnv):
+            from ..engine.rollout import evaluate_batched
+            extra = float(self.cost_limit) if self.bc_mode == "multi-task" else None
+            return evaluate_batched(self, "bc", eval_episodes, 1.0, extra)
         self.model.eval()
         rets, costs, lens = [], [], []
         for _ in range(eval_episodes):

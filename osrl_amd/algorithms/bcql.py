@@ -137,6 +137,13 @@ class BCQLTrainer:
         store_stats(self.logger, eng.st, self.stats_mode)
 
     def evaluate(self, eval_episodes):
+        """bcql.py:308-321.  A ``VecSyntheticSafeEnv`` as ``self.env`` runs the episodes as one batch on device
+        (the decode noise z is then drawn per env step from the device Philox stream)."""
+        from ..common.synthetic_env import VecSyntheticSafeEnv
+        if isinstance(self.env, VecSyntheticSafeEnv):
+            from ..engine.rollout import evaluate_batched
+            r, c, n = evaluate_batched(self, "bcql", eval_episodes, self.cost_scale)
+            return r / self.reward_scale, c / self.cost_scale, n
         self.model.eval()
         rets, costs, lens = [], [], []
         for _ in range(eval_episodes):

@@ -156,7 +156,13 @@ class CPQTrainer:
         store_stats(self.logger, eng.st, self.stats_mode)
 
     def evaluate(self, eval_episodes):
-        """cpq.py:315-328."""
+        """cpq.py:315-328.  With a ``VecSyntheticSafeEnv`` as ``self.env`` the episodes run as one batch on device
+        (engine/rollout.py); any other (gym-style) env takes the reference's episode-by-episode loop."""
+        from ..common.synthetic_env import VecSyntheticSafeEnv
+        if isinstance(self.env, VecSyntheticSafeEnv):
+            from ..engine.rollout import evaluate_batched
+            r, c, n = evaluate_batched(self, "cpq", eval_episodes, self.cost_scale)
+            return r / self.reward_scale, c / self.cost_scale, n
         self.model.eval()
         rets, costs, lens = [], [], []
         for _ in range(eval_episodes):

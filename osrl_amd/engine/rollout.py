@@ -1,0 +1,138 @@
+"""Batched, graph-captured policy rollouts for ``Trainer.evaluate()``.
+
+The reference evaluates one episode at a time, one B=1 policy call and one host<->device round trip per env step
+(``CPQTrainer.rollout`` cpq.py:330-347, ``BCQLTrainer.rollout`` bcql.py:323-340, ``BCTrainer.rollout``
+bc.py:125-145).  Here the ``eval_episodes`` episodes are the ROWS of one policy batch: one env step of all
+episodes = the policy's fused MLP forward(s) + its head kernel + one environment kernel (csrc/env.hip), captured
+``_CHUNK`` env steps at a time in a hipGraph that is replayed ``episode_len / _CHUNK`` times; the host reads the per-episode totals once at the end.
+
+Policies (same arithmetic as ``model.act``):
+  BC    ``act_limit * tanh(pi(obs))``                                 bc.py:57-64  (multi-task: obs ++ cost_limit, :132-138)
+  CPQ   ``max_action * tanh(mu(obs))`` (deterministic=True)           cpq.py:240-252, net.py:176-205
+  BCQL  ``actor(obs, vae.decode(obs, z)), z = clamp(N(0,1), +-0.5)``  bcql.py:236-243, net.py:328-339
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc
+from . import glue as G
+from .core import MlpRun, StepState, randn_fill
+
+_Z_STREAM = 11  # Philox stream id of the BCQL decode noise drawn during evaluation
+_CHUNK = 20     # env steps per captured graph: one replay costs ~25 us of launch latency, a step's kernels far less;
+                # episodes that finish inside a chunk are frozen by the env kernel's done latch, so overshoot is a no-op
+
+
+class BatchedRollout:
+    """``eval_episodes`` episodes of one vector environment driven by ``model``'s policy on device."""
+
+    def __init__(self, model, venv, kind: str, cost_scale: float = 1.0, extra_obs: Optional[float] = None,
+                 seed: int = 0, z: Optional[torch.Tensor] = None, use_graph: bool = True):
+        if kind not in ("bc", "cpq", "bcql"):
+            raise ValueError(kind)
+        m = self.model = model
+        self.venv, self.kind, self.seed, self.use_graph = venv, kind, int(seed), use_graph
+        dev = torch.device(m.device)
+        E, od, ad = venv.E, venv.state_dim, m.action_dim
+        f = dict(dtype=torch.float32, device=dev)
+        in_dim = od + (1 if extra_obs is not None else 0)
+        self.obs = torch.zeros(E, in_dim, **f)
+        if extra_obs is not None:
+            self.obs[:, od] = float(extra_obs)
+        self.a = torch.zeros(E, ad, **f)
+        self.env_c = venv.desc(m.episode_len, cost_scale)
+        self.st = StepState(dev, ["x"])
+        m.repack()
+        if kind == "bc":
+            if m.actor.pi[0].in_features != in_dim:
+                raise ValueError(f"policy expects {m.actor.pi[0].in_features} inputs, the environment gives {in_dim}")
+            self.r_pi = MlpRun(net_desc_seq([m.actor.pi], float(m.max_action)), E, False, dev)
+        elif kind == "cpq":
+            self.r_pi = MlpRun(actor_head_desc(m.actor), E, False, dev)
+        else:
+            Lz = m.latent_dim
+            self.r_dec = MlpRun(vae_dec_desc(m.vae), E, False, dev)
+            self.r_pi = MlpRun(net_desc_seq([m.actor.pi], 1.0), E, False, dev)
+            self.z = torch.zeros(E, Lz, **f)
+            self.z_fixed = z is not None
+            if z is not None:  # fixed decode noise (parity tests); clamped like VAE.decode does (net.py:334-335)
+                self.z.copy_(torch.as_tensor(z, **f).reshape(E, Lz))
+                G.clamp_(self.z, -0.5, 0.5)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def body(self) -> None:
+        m, E, ad = self.model, self.venv.E, self.model.action_dim
+        if self.kind == "bc":
+            act = self.r_pi.forward(self.obs)[0]
+        elif self.kind == "cpq":
+            head = self.r_pi.forward(self.obs)[0]
+            G.gauss_head(head, None, E, ad, float(m.max_action), a=self.a)
+            act = self.a
+        else:
+            if not self.z_fixed:
+                self.st.tick()
+                randn_fill(self.z, self.seed, _Z_STREAM, self.st.ptr)
+                G.clamp_(self.z, -0.5, 0.5)
+            dec = self.r_dec.forward(self.obs, self.z)[0]
+            t = self.r_pi.forward(self.obs, dec)[0]
+            G.bcq_perturb(dec, t, E, ad, float(m.actor.phi), float(m.max_action), self.a)
+            act = self.a
+        self.venv.step(self.env_c, act, self.obs)
+
+    def _capture(self) -> None:
+        snap = (self.venv.state.clone(), self.venv.acc.clone(), self.obs.clone(), self.st.state.clone(),
+                self.st.host_step)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.body()
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(_CHUNK):
+                self.body()
+        torch.cuda.synchronize()
+        self.venv.state.copy_(snap[0]); self.venv.acc.copy_(snap[1]); self.obs.copy_(snap[2])
+        self.st.state.copy_(snap[3])
+        self.st.host_step = snap[4]
+        self.graph = gr
+
+    @torch.no_grad()
+    def run(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """All episodes to completion -> per-episode (return, cost * cost_scale, length) as numpy arrays."""
+        self.venv.reset(self.obs)
+        steps = min(self.model.episode_len, self.venv.episode_len or self.model.episode_len)
+        if self.env_c.episode_len != steps:  # the env descriptor is a by-value launch argument of the captured graph
+            self.env_c.episode_len, self.graph = steps, None
+        if self.use_graph and self.graph is None:
+            self._capture()
+        if self.use_graph:
+            for _ in range((steps + _CHUNK - 1) // _CHUNK):
+                self.graph.replay()
+        else:
+            for _ in range(steps):
+                self.body()
+        acc = self.venv.acc.cpu().numpy()  # the one host sync of the rollout
+        return acc[:, 0].astype(np.float64), acc[:, 1].astype(np.float64), acc[:, 2].astype(np.float64)
+
+
+def evaluate_batched(trainer, kind: str, eval_episodes: int, cost_scale: float = 1.0,
+                     extra_obs: Optional[float] = None):
+    """``Trainer.evaluate`` on a ``VecSyntheticSafeEnv``: (mean return, mean cost * cost_scale, mean length).
+    The rollout object (buffers + captured graph) is cached on the trainer; it reads the model's packed weights in
+    place, so it stays valid across train steps."""
+    venv = trainer.env
+    if venv.E != eval_episodes:
+        raise ValueError(f"the vector environment holds {venv.E} episodes, evaluate() was asked for {eval_episodes}")
+    key = (id(venv), kind, float(cost_scale), extra_obs)
+    ro = getattr(trainer, "_rollout", None)
+    if ro is None or ro[0] != key:
+        ro = (key, BatchedRollout(trainer.model, venv, kind, cost_scale, extra_obs,
+                                  use_graph=getattr(trainer, "use_graph", True)))
+        trainer._rollout = ro
+    ret, cost, length = ro[1].run()
+    return float(ret.mean()), float(cost.mean()), float(length.mean())

@@ -100,3 +100,128 @@ def test_cdt_rollout_matches_oracle():
         r0 += reward
         c0 += info["cost"]
     assert ln == EL and abs(ret - r0 / tr.reward_scale) < 1e-3 * max(1, abs(r0)) and abs(cost - c0) < 0.5
+
+
+# --------------------------------------------------------------------------- #
+# batched on-device evaluate()
+# --------------------------------------------------------------------------- #
+def test_env_step_kernel_matches_numpy_env():
+    """csrc/env.hip vs the scalar numpy environment, episode by episode (clip, latch at episode_len, totals)."""
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    rs = np.random.RandomState(0)
+    for od, ad, E, EL in ((5, 2, 7, 9), (76, 2, 33, 6), (130, 8, 4, 5)):
+        env = SyntheticSafeEnv(od, ad, EL, seed=3, init_noise=0.5)
+        venv = VecSyntheticSafeEnv(env, E, DEV, base_seed=10)
+        obs = torch.full((E, od + 1), 7.0, device=DEV)  # one extra column that must stay untouched
+        venv.reset(obs)
+        d = venv.desc(EL, 2.0)
+        scal = [SyntheticSafeEnv(od, ad, EL, seed=3, init_noise=0.5) for _ in range(E)]
+        tot = np.zeros((E, 3))
+        for e, sc in enumerate(scal):
+            o0, _ = sc.reset(seed=10 + e)
+            np.testing.assert_array_equal(obs[e, :od].cpu().numpy(), o0)
+        for step in range(EL + 2):  # two steps past the end: finished episodes are frozen
+            a = (rs.randn(E, ad) * 1.5).astype(np.float32)
+            venv.step(d, torch.tensor(a, device=DEV), obs)
+            for e, sc in enumerate(scal):
+                if step < EL:
+                    o, r, term, trunc, info = sc.step(a[e])
+                    tot[e] += (r, info["cost"] * 2.0, 1)
+                    assert trunc == (step == EL - 1)
+            got = obs.cpu().numpy()
+            want = np.stack([sc.s for sc in scal])
+            np.testing.assert_allclose(got[:, :od], want, rtol=1e-5, atol=1e-5)
+            assert (got[:, od] == 7.0).all()
+        acc = venv.acc.cpu().numpy()
+        np.testing.assert_allclose(acc[:, 0], tot[:, 0], rtol=1e-5, atol=1e-4)
+        np.testing.assert_array_equal(acc[:, 1:3], tot[:, 1:3])
+        assert (acc[:, 3] == 1.0).all()
+
+
+def _oracle_episode(policy, env, seed, episode_len, cost_scale=1.0):
+    obs, _ = env.reset(seed=seed)
+    ret = cost = 0.0
+    n = 0
+    for _ in range(episode_len):
+        obs, r, term, trunc, info = env.step(policy(obs))
+        ret += r
+        cost += info["cost"] * cost_scale
+        n += 1
+        if term or trunc:
+            break
+    return ret, cost, n
+
+
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_small"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_batched_evaluate_matches_oracle_rollouts(name, use_graph):
+    """trainer.evaluate(E) on a VecSyntheticSafeEnv == the oracle policy rolled out episode by episode on the
+    scalar environment from the same E initial states."""
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    from osrl_amd.engine.rollout import BatchedRollout
+    c = CASES[name]
+    m, tr, lg = build_gpu(c, use_graph=use_graph)
+    o = build_oracle(c)
+    E, EL = 24, 30
+    m.episode_len = EL
+    env = SyntheticSafeEnv(c.od, c.ad, 50, seed=1, init_noise=0.7)
+    venv = VecSyntheticSafeEnv(env, E, DEV, base_seed=100)
+    tr.env = venv
+    cs = 1.0
+    if name == "bcql_small":
+        rs = np.random.RandomState(5)
+        z = rs.randn(E, m.latent_dim).astype(np.float32)  # one fixed decode noise per episode (incl. |z| > 0.5)
+        ro = BatchedRollout(m, venv, "bcql", cs, z=torch.tensor(z, device=DEV), use_graph=use_graph)
+        rets, costs, lens = ro.run()
+        pols = [(lambda ob, e=e: o.act(ob[None], z[e][None])[0]) for e in range(E)]
+    else:
+        ret, cost, ln = tr.evaluate(E)
+        rets, costs, lens = tr._rollout[1].run()  # second run of the cached rollout: reset + replay
+        assert abs(ret - rets.mean()) < 1e-6 and cost == costs.mean() and ln == lens.mean() == EL
+        pols = [(lambda ob: o.act(ob[None])[0])] * E
+    ref = np.array([_oracle_episode(pols[e], SyntheticSafeEnv(c.od, c.ad, 50, seed=1, init_noise=0.7), 100 + e, EL, cs)
+                    for e in range(E)])
+    np.testing.assert_array_equal(lens, ref[:, 2])
+    np.testing.assert_allclose(rets, ref[:, 0], rtol=1e-4, atol=1e-3)
+    assert np.abs(costs - ref[:, 1]).max() <= 1.0 and (costs != ref[:, 1]).mean() <= 0.1  # indicator at a threshold
+    assert np.unique(np.round(rets, 3)).size > E // 2, "episodes must differ (distinct initial states)"
+    with pytest.raises(ValueError):
+        tr.evaluate(E + 1)
+
+
+def test_batched_evaluate_bc_multitask_and_bcql_noise():
+    """BC multi-task appends cost_limit to every observation (bc.py:132-138); BCQL without a fixed z draws fresh
+    device noise per env step (two runs with the same seed agree, the episodes of one run do not)."""
+    from osrl_amd.algorithms import BC, BCTrainer
+    from osrl_amd.common.logger import DummyLogger
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    from osrl_amd.engine.rollout import BatchedRollout
+    od, ad, E, EL = 6, 2, 8, 12
+    torch.manual_seed(0)
+    m = BC(od + 1, ad, 1.0, [32, 32], EL, device=DEV)
+    tr = BCTrainer(m, None, DummyLogger(), actor_lr=1e-3, bc_mode="multi-task", cost_limit=20, device=DEV)
+    env = SyntheticSafeEnv(od, ad, EL, seed=4, init_noise=0.5)
+    tr.env = VecSyntheticSafeEnv(env, E, DEV, base_seed=0)
+    got = tr.evaluate(E)
+    tr2 = BCTrainer(m, SyntheticSafeEnv(od, ad, EL, seed=4, init_noise=0.5), DummyLogger(), actor_lr=1e-3,
+                    bc_mode="multi-task", cost_limit=20, device=DEV)
+    rets = []
+    for e in range(E):  # the reference-shaped scalar loop, same initial states
+        obs, _ = tr2.env.reset(seed=e)
+        ret = 0.0
+        for _ in range(EL):
+            obs, r, *_ = tr2.env.step(m.act(np.append(obs, 20.0).astype(np.float32)))
+            ret += r
+        rets.append(ret)
+    assert abs(got[0] - np.mean(rets)) < 1e-3 * max(1.0, abs(np.mean(rets))) and got[2] == EL
+
+    c = CASES["bcql_small"]
+    mb, trb, _ = build_gpu(c)
+    mb.episode_len = EL
+    venv = VecSyntheticSafeEnv(SyntheticSafeEnv(c.od, c.ad, EL, seed=2), E, DEV)  # identical initial states
+    ro = BatchedRollout(mb, venv, "bcql", seed=9)
+    r1 = ro.run()[0]
+    ro2 = BatchedRollout(mb, venv, "bcql", seed=9)
+    r2 = ro2.run()[0]
+    np.testing.assert_array_equal(r1, r2)
+    assert np.unique(r1).size > 1, "per-episode decode noise must differ"
