@@ -53,11 +53,13 @@ class BC(nn.Module):
         self._lrs = dict(actor=actor_lr)
 
     def engine(self, batch_size: int, **kw):
+        from ..common.checkpoint import engine_handoff
         from ..engine.bc import BCEngine
         if self._engine is None or self._engine.B != batch_size or kw:
             if self._lrs is None:
                 raise RuntimeError("call setup_optimizers() (or build a BCTrainer) before training")
-            self._engine = BCEngine(self, batch_size, **kw)
+            old, self._engine = self._engine, BCEngine(self, batch_size, **kw)
+            engine_handoff(self, self._engine, old)
         return self._engine
 
     @torch.no_grad()

@@ -100,11 +100,13 @@ class BCQL(nn.Module):
         self._lrs = dict(actor=actor_lr, critic=critic_lr, cost_critic=critic_lr, vae=vae_lr)
 
     def engine(self, batch_size: int, **kw):
+        from ..common.checkpoint import engine_handoff
         from ..engine.bcql import BCQLEngine
         if self._engine is None or self._engine.B != batch_size or kw:
             if self._lrs is None:
                 raise RuntimeError("call setup_optimizers() (or build a BCQLTrainer) before training")
-            self._engine = BCQLEngine(self, batch_size, **kw)
+            old, self._engine = self._engine, BCQLEngine(self, batch_size, **kw)
+            engine_handoff(self, self._engine, old)
         return self._engine
 
     def sync_weight(self):

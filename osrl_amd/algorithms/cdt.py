@@ -125,12 +125,14 @@ class CDT(nn.Module):
         raise RuntimeError("osrl_amd models are bound to their HIP device at construction (pass device=)")
 
     def engine(self, batch_size: int, cfg: Optional[dict] = None, dist=None):
+        from ..common.checkpoint import engine_handoff
         from ..engine.cdt import CDTEngine
         if self._engine is None or self._engine.B != batch_size or dist is not None or \
                 (cfg is not None and cfg != self._engine.cfg):
             if cfg is None:
                 raise RuntimeError("build a CDTTrainer before training")
-            self._engine = CDTEngine(self, batch_size, cfg, dist=dist)
+            old, self._engine = self._engine, CDTEngine(self, batch_size, cfg, dist=dist)
+            engine_handoff(self, self._engine, old)
         return self._engine
 
     @torch.no_grad()

@@ -106,11 +106,13 @@ class CPQ(nn.Module):
         self.alpha_lr = alpha_lr
 
     def engine(self, batch_size: int, **kw):
+        from ..common.checkpoint import engine_handoff
         from ..engine.cpq import CPQEngine
         if self._engine is None or self._engine.B != batch_size or kw:
             if self._lrs is None:
                 raise RuntimeError("call setup_optimizers() (or build a CPQTrainer) before training")
-            self._engine = CPQEngine(self, batch_size, **kw)
+            old, self._engine = self._engine, CPQEngine(self, batch_size, **kw)
+            engine_handoff(self, self._engine, old)
         return self._engine
 
     def sync_weight(self):

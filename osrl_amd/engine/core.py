@@ -65,6 +65,7 @@ class FlatGroup:
         self.pf = self.pb = self.tf = None    # packed fwd / packed W^T of p, packed fwd of tgt
         self.f_off: Dict[str, int] = {}
         self.b_off: Dict[str, int] = {}
+        self.aliases: set = set()
 
     def add(self, key: str, shape: Sequence[int], align: bool = True) -> int:
         assert self.p is None, "FlatGroup already finalized"
@@ -144,6 +145,28 @@ class FlatGroup:
     def alias(self, key: str, first_key: str, shape: Sequence[int]) -> None:
         """Name a contiguous range that spans several adjacent tensors (packed mu|log_std heads)."""
         self.layout[key] = (self.layout[first_key][0], tuple(int(s) for s in shape))
+        self.aliases.add(key)
+
+    # ---- optimizer state by parameter key (checkpoint / resume; common/checkpoint.py) ----
+    def optim_state(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        """Adam moments per parameter key, in ``torch.optim.Adam``'s vocabulary (host copies)."""
+        keys = [k for k in self.layout if k not in self.aliases]
+        return {"exp_avg": {k: self._view(self.m, k).cpu().clone() for k in keys},
+                "exp_avg_sq": {k: self._view(self.v, k).cpu().clone() for k in keys}}
+
+    def load_optim_state(self, state: Dict[str, Dict[str, torch.Tensor]]) -> None:
+        keys = [k for k in self.layout if k not in self.aliases]
+        for name, buf in (("exp_avg", self.m), ("exp_avg_sq", self.v)):
+            missing = [k for k in keys if k not in state[name]]
+            extra = [k for k in state[name] if k not in keys]
+            if missing or extra:
+                raise KeyError(f"optimizer state of group {self.name!r}: missing {missing}, unexpected {extra}")
+            for k in keys:
+                dst = self._view(buf, k)
+                src = torch.as_tensor(state[name][k], dtype=torch.float32)
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"{name}[{k}]: shape {tuple(src.shape)} != {tuple(dst.shape)}")
+                dst.copy_(src)
 
     def _view(self, buf: torch.Tensor, key: str) -> torch.Tensor:
         off, shape = self.layout[key]
@@ -502,6 +525,12 @@ class StepState:
                                         self.ring.data_ptr(), self.n_stats, self.ring_len, cur_stream()),
                 "osrl_step_tick")
         self.host_step += 1
+
+    def set_step(self, step: int) -> None:
+        """Continue counting from ``step`` completed train steps (engine rebuild, checkpoint resume): the next
+        tick makes it step+1 and recomputes the bias corrections / warm-up scale from that."""
+        self.state[:8].view(torch.int64).fill_(int(step))
+        self.host_step = int(step)
 
     def device_step(self) -> int:
         return int(self.state[:8].view(torch.int64).item())

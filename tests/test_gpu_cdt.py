@@ -352,3 +352,33 @@ def test_cdt_data_parallel_world1_matches_single():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_cdt_checkpoint_resume_is_bit_identical(tmp_path):
+    """CDT with dropout 0.1: the masks, the LR warm-up and the temperature optimizer all hang off the step count
+    the checkpoint carries (osrl_amd/common/checkpoint.py)."""
+    from osrl_amd.common.checkpoint import load_checkpoint, save_checkpoint
+    c = CDT_CASES["cdt_drop"]
+    b = {k: t(v) for k, v in make_cdt_batch(c).items()}
+
+    def run(tr, n):
+        for _ in range(n):
+            tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                              b["episode_cost"], b["costs"])
+
+    m_a, tr_a, _ = build_cdt_gpu(c)
+    run(tr_a, 5)
+    m_b, tr_b, _ = build_cdt_gpu(c)
+    run(tr_b, 3)
+    path = str(tmp_path / "cdt.pt")
+    save_checkpoint(m_b, path)
+    m_c, tr_c, _ = build_cdt_gpu(c)
+    load_checkpoint(m_c, path)
+    run(tr_c, 2)
+    torch.cuda.synchronize()
+    for k, v in m_a.state_dict().items():
+        assert torch.equal(v, m_c.state_dict()[k]), k
+    g_a, g_c = m_a.groups["cdt"], m_c.groups["cdt"]
+    assert torch.equal(g_a.m, g_c.m) and torch.equal(g_a.v, g_c.v)
+    assert torch.equal(m_a.log_temperature, m_c.log_temperature)
+    assert torch.equal(m_a._engine.temp_mv, m_c._engine.temp_mv)

@@ -279,3 +279,65 @@ def test_data_parallel_world1_other_algos(name):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------- #
+# checkpoint round trip + resume (osrl_amd/common/checkpoint.py)
+# --------------------------------------------------------------------------- #
+def _train_state(m):
+    out = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for name, g in m.groups.items():
+        out["m/" + name], out["v/" + name] = g.m.clone(), g.v.clone()
+    for k in ("log_alpha", "pid_state"):
+        if isinstance(getattr(m, k, None), torch.Tensor):
+            out[k] = getattr(m, k).clone()
+    return out
+
+
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_pid"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_checkpoint_resume_is_bit_identical(name, use_graph, tmp_path):
+    """3 steps -> save -> load into a fresh model -> 2 steps  ==  5 uninterrupted steps, bit for bit (parameters,
+    targets, Adam moments, log_alpha / PID state); the noise is the device Philox stream, keyed by the step count
+    the checkpoint carries.  The file keeps the reference's {"model_state": ...} layout."""
+    from osrl_amd.common.checkpoint import load_checkpoint, save_checkpoint
+    c = CASES[name]
+    b = gpu_batch(c)
+    m_a, tr_a, _ = build_gpu(c, use_graph=use_graph)
+    for s in range(5):
+        gpu_step(tr_a, c, b, s, with_noise=False)
+    m_b, tr_b, _ = build_gpu(c, use_graph=use_graph)
+    for s in range(3):
+        gpu_step(tr_b, c, b, s, with_noise=False)
+    path = str(tmp_path / "model.pt")
+    save_checkpoint(m_b, path)
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(raw) == {"model_state", "osrl_amd"} and raw["osrl_amd"]["step"] == 3
+    assert set(raw["model_state"]) == set(m_b.state_dict())
+    m_c, tr_c, _ = build_gpu(c, use_graph=use_graph)
+    load_checkpoint(m_c, path)
+    for s in range(3, 5):
+        gpu_step(tr_c, c, b, s, with_noise=False)
+    torch.cuda.synchronize()
+    sa, sc = _train_state(m_a), _train_state(m_c)
+    assert set(sa) == set(sc)
+    for k in sa:
+        assert torch.equal(sa[k], sc[k]), k
+    assert m_c._engine.st.device_step() == 5
+    # weights only (what a reference checkpoint holds): loads, the optimizer starts fresh
+    m_d, tr_d, _ = build_gpu(c)
+    load_checkpoint(m_d, {"model_state": raw["model_state"]})
+    for k, v in m_d.state_dict().items():
+        assert torch.equal(v.cpu(), raw["model_state"][k]), k
+    assert all(float(g.m.abs().max()) == 0.0 for g in m_d.groups.values())
+
+
+def test_engine_rebuild_keeps_the_step_count():
+    """A new batch size rebuilds the launch plan; Adam's step count (bias correction) must carry over."""
+    c = CASES["bc_small"]
+    m, tr, _ = build_gpu(c)
+    b = gpu_batch(c)
+    for s in range(3):
+        tr.train_one_step(b["observations"], b["actions"])
+    tr.train_one_step(b["observations"][:16], b["actions"][:16])
+    assert m._engine.B == 16 and m._engine.st.device_step() == 4
