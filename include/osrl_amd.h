@@ -323,6 +323,39 @@ int osrl_clip_grad_scale(const float* grad, int64_t n, float clip, float* partia
 int osrl_cdt_temperature_step(float* log_temperature, float* moments, const float* entropy, float target_entropy,
                               float lr, float beta1, float beta2, float eps, const osrl_step_state_t* st, void* stream);
 
+/* ---- dataset ingestion on device (osrl/common/dataset.py) ----
+ * The flat DSRL arrays (observations, actions, rewards, costs, terminals, timeouts) are uploaded once; these calls
+ * produce, in HBM, what the reference computes in host python loops before training.  `ws` is an int32 workspace of
+ * osrl_ingest_ws_elems(n) elements; n < 2^31.  Index outputs are exact, fp32 recurrences bit-identical to numpy. */
+int64_t osrl_ingest_ws_elems(int64_t n);
+/* Episode split at `terminals == 1 || timeouts == 1` (dataset.py:60, :165): ep_end[e] = index of the e-th done
+ * flag, ep_start[e] = ep_end[e-1] + 1, ep_len[e]; *n_episodes = number of COMPLETE episodes (transitions after the
+ * last done flag belong to none, as in process_sequence_dataset dataset.py:156-175).  ep_* are sized n. */
+int osrl_episode_segments(const float* terminals, const float* timeouts, int64_t n, int64_t* ep_end, int64_t* ep_start,
+                          int32_t* ep_len, int32_t* n_episodes, int32_t* ws, void* stream);
+/* discounted_cumsum (dataset.py:19-27) per episode: out[t] = x[t] + gamma*out[t+1].  reverse: x -> 1 - x first
+ * (cost_reverse, dataset.py:161-162; x_out, optional, receives the transformed x).  broadcast_first: every step of
+ * the episode gets out[first step] (process_bc_dataset dataset.py:63-70; steps outside episodes are not written). */
+int osrl_episode_returns(const float* x, const int64_t* ep_start, const int32_t* ep_len, int32_t n_episodes,
+                         float gamma, int32_t reverse, int32_t broadcast_first, float* out, float* x_out, void* stream);
+/* compute_cost_sample_prob (dataset.py:439-459): prob[e] = max(T(c_e), 0) / sum, c_e = cost_returns[ep_start[e]],
+ * T(c) = a*c + b (OSRL_COST_AFFINE; the reference default 50 - c, train_cdt.py:139 70 - c) or 1/(c + b)
+ * (OSRL_COST_RECIPROCAL; train_cdt.py:139 1/(c + 10)); cdf (optional) = its running sum, for
+ * osrl_seq_window_gather. */
+enum { OSRL_COST_AFFINE = 0, OSRL_COST_RECIPROCAL = 1 };
+int osrl_cost_sample_prob(const float* cost_returns, const int64_t* ep_start, int32_t n_episodes, int32_t kind,
+                          float a, float b, float* prob, float* cdf, void* stream);
+/* process_bc_dataset's selection (dataset.py:108-124) as a stable compaction: idx[0..*n_keep) = kept transition
+ * indices in order.  ALL: every one; SAFE: cr <= t0; RISKY: cr >= t0; BOUNDARY: t0 < cr <= t1 (the caller passes
+ * the thresholds cost_limit, 2 x cost_limit, (0.5, 1.5) x cost_limit rounded to fp32 as numpy does). */
+enum { OSRL_BC_ALL = 0, OSRL_BC_SAFE = 1, OSRL_BC_RISKY = 2, OSRL_BC_BOUNDARY = 3 };
+int osrl_bc_select(const float* cost_returns, int64_t n, int32_t mode, float t0, float t1, int64_t* idx,
+                   int32_t* n_keep, int32_t* ws, void* stream);
+/* dst[j, :width] = src[idx[j], :width]; extra (optional): dst[j, width] = extra[idx[j]] (BC multi-task appends the
+ * cost return to the observation, dataset.py:128-130). */
+int osrl_gather_rows(const float* src, int32_t width, const int64_t* idx, int64_t n_rows, float* dst, int32_t dst_ld,
+                     const float* extra, void* stream);
+
 /* ---- batched on-device evaluation ----
  * The reference's Trainer.rollout (cpq.py:330-347, bcql.py:323-340, bc.py:125-145) steps ONE gym env per policy
  * call and crosses host<->device every env step.  No gym env exists in either container, so the build owns a

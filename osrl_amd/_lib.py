@@ -81,6 +81,12 @@ _P = C.POINTER
 PROTOTYPES = {
     "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_env_step": [_P(EnvT), _vp, _vp, _vp, _i32, _vp, _i32, _vp],
+    "osrl_ingest_ws_elems": [_i64],
+    "osrl_episode_segments": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "osrl_episode_returns": [_vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp],
+    "osrl_cost_sample_prob": [_vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
+    "osrl_bc_select": [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "osrl_gather_rows": [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp],
     "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
@@ -136,6 +142,9 @@ PROTOTYPES = {
 _LIB: Optional[C.CDLL] = None
 
 
+RESTYPES = {"osrl_ingest_ws_elems": C.c_int64}  # everything else returns int (0 = ok)
+
+
 def lib_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libosrl_amd.so")
 
@@ -158,7 +167,7 @@ def load() -> C.CDLL:
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = RESTYPES.get(name, C.c_int)
     lib.osrl_version.restype = C.c_char_p
     lib.osrl_version.argtypes = []
     _LIB = lib

@@ -30,7 +30,10 @@ class ReplayStore:
         and either ``done`` or ``terminals``+``timeouts``)."""
         d = dict(data)
         if "done" not in d:
-            d["done"] = np.logical_or(np.asarray(d["terminals"]) == 1, np.asarray(d["timeouts"]) == 1)
+            if torch.is_tensor(d["terminals"]):  # device tables of common.ingest.process_bc_dataset
+                d["done"] = torch.logical_or(d["terminals"] == 1, d["timeouts"] == 1)
+            else:
+                d["done"] = np.logical_or(np.asarray(d["terminals"]) == 1, np.asarray(d["timeouts"]) == 1)
         n = len(d["observations"])
         sl = slice(rank, n, world) if world > 1 else slice(None)
         self.tables = []
@@ -94,6 +97,32 @@ class SequenceStore:
             self.cdf = torch.as_tensor(c.astype(np.float32), device=self.device)
         self.reward_scale, self.cost_scale, self.seed = float(reward_scale), float(cost_scale), int(seed)
         self.od, self.ad = self.obs.shape[1], self.act.shape[1]
+
+    @classmethod
+    def from_tables(cls, tables: Dict[str, torch.Tensor], seq_len: int, reward_scale: float = 1.0,
+                    cost_scale: float = 1.0, cdf: Optional[torch.Tensor] = None, seed: int = 0) -> "SequenceStore":
+        """Wrap the flat device tables of ``common.ingest.process_sequence_dataset`` (nothing is copied)."""
+        self = cls.__new__(cls)
+        self.T, self.device = int(seq_len), tables["observations"].device
+        self.obs, self.act = tables["observations"].contiguous(), tables["actions"].contiguous()
+        self.ret, self.cret, self.cost = tables["returns"], tables["cost_returns"], tables["costs"]
+        self.traj_start, self.traj_len = tables["traj_start"], tables["traj_len"]
+        self.n_traj = int(self.traj_start.shape[0])
+        self.cdf = cdf
+        self.reward_scale, self.cost_scale, self.seed = float(reward_scale), float(cost_scale), int(seed)
+        self.od, self.ad = self.obs.shape[1], self.act.shape[1]
+        return self
+
+    @classmethod
+    def from_dataset(cls, dataset, seq_len: int, device, reward_scale: float = 1.0, cost_scale: float = 1.0,
+                     cost_reverse: bool = False, cost_sample: bool = False,
+                     cost_transform=("affine", -1.0, 50.0), seed: int = 0) -> "SequenceStore":
+        """``SequenceDataset(dataset, seq_len, reward_scale, cost_scale, cost_reverse=, cost_sample=,
+        cost_transform=)`` (dataset.py:633-741, no augmentation) with the whole preprocessing on device."""
+        from .ingest import compute_cost_sample_prob, process_sequence_dataset
+        tables = process_sequence_dataset(dataset, cost_reverse, device)
+        cdf = compute_cost_sample_prob(tables, cost_transform, with_cdf=True)[1] if cost_sample else None
+        return cls.from_tables(tables, seq_len, reward_scale, cost_scale, cdf, seed)
 
     def gather(self, states, actions, returns, cost_returns, time_steps, mask, episode_cost, costs, st_ptr,
                idx_out=None, stream_id: int = 2) -> None:

@@ -280,3 +280,31 @@ def make_cdt_batch(c: CDTCase) -> Dict[str, np.ndarray]:
     return dict(states=states, actions=actions, returns=returns, costs_return=ctg,
                 time_steps=(start[:, None] + np.arange(T)[None]).astype(np.int64), mask=mask,
                 episode_cost=rs.uniform(0, 20, B).astype(f), costs=costs)
+
+
+# --------------------------------------------------------------------------- #
+# dataset ingestion: a small DSRL-shaped dataset with ragged episodes
+# --------------------------------------------------------------------------- #
+def make_ingest_dataset(seed: int = 0, n: int = 1500, od: int = 4, ad: int = 2, max_len: int = 60,
+                        tail: int = 17) -> Dict[str, np.ndarray]:
+    """Episodes of length 1..max_len ending in a timeout or (1 in 4) a terminal, one episode where both flags are
+    set, a trailing partial episode of ``tail`` transitions without a done flag; costs ~ Bernoulli(0.25)."""
+    rs = np.random.RandomState(seed)
+    f = np.float32
+    term, tout = np.zeros(n, f), np.zeros(n, f)
+    i, k = 0, 0
+    while True:
+        L_ = int(rs.randint(1, max_len + 1))
+        if i + L_ > n - tail:
+            break
+        i += L_
+        if k % 4 == 3:
+            term[i - 1] = 1
+        else:
+            tout[i - 1] = 1
+        if k == 5:
+            term[i - 1] = tout[i - 1] = 1
+        k += 1
+    return dict(observations=rs.randn(n, od).astype(f), next_observations=rs.randn(n, od).astype(f),
+                actions=rs.uniform(-1, 1, (n, ad)).astype(f), rewards=rs.uniform(0, 2, n).astype(f),
+                costs=(rs.uniform(size=n) < 0.25).astype(f), terminals=term, timeouts=tout)

@@ -225,3 +225,100 @@ def test_batched_evaluate_bc_multitask_and_bcql_noise():
     r2 = ro2.run()[0]
     np.testing.assert_array_equal(r1, r2)
     assert np.unique(r1).size > 1, "per-episode decode noise must differ"
+
+
+# --------------------------------------------------------------------------- #
+# dataset ingestion on device vs the reference's outputs (golden) and the numpy oracle
+# --------------------------------------------------------------------------- #
+def _np(t):
+    return t.cpu().numpy()
+
+
+def test_ingest_sequence_dataset_matches_reference_golden():
+    from cases import make_ingest_dataset
+    from oracle_util import load_golden
+    from osrl_amd.common.ingest import compute_cost_sample_prob, process_sequence_dataset
+    g = load_golden("ingest")
+    for rev, tag in ((False, "fwd"), (True, "rev")):
+        tb = process_sequence_dataset(make_ingest_dataset(), rev, DEV)
+        lens = g[f"seq_{tag}_len"]
+        assert np.array_equal(_np(tb["traj_len"]), lens)
+        assert np.array_equal(_np(tb["traj_start"]), np.concatenate([[0], np.cumsum(lens)[:-1]]))
+        for k in ("observations", "actions", "rewards", "costs", "returns", "cost_returns"):
+            assert np.array_equal(_np(tb[k]), g[f"seq_{tag}_{k}"]), (tag, k)  # bit-exact, incl. the fp32 recurrences
+        for name, ct in (("prob50", ("affine", -1.0, 50.0)), ("prob8", ("affine", -1.0, 8.0)),
+                         ("probinv", ("reciprocal", 10.0))):
+            p, cdf = compute_cost_sample_prob(tb, ct, with_cdf=True)
+            np.testing.assert_allclose(_np(p), g[f"seq_{tag}_{name}"], rtol=2e-6, atol=1e-9)
+            np.testing.assert_allclose(_np(cdf), np.cumsum(g[f"seq_{tag}_{name}"].astype(np.float64)), rtol=0, atol=2e-6)
+            assert abs(float(cdf[-1]) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["all", "multi-task", "safe", "risky", "boundary"])
+def test_ingest_bc_dataset_matches_reference_golden(mode):
+    from cases import make_ingest_dataset
+    from oracle_util import load_golden
+    from osrl_amd.common.ingest import process_bc_dataset
+    g = load_golden("ingest")
+    for gamma in (1.0, 0.99):
+        out = process_bc_dataset(make_ingest_dataset(), 6.0, gamma, mode, DEV)
+        tag = f"bc_{mode}_{gamma}"
+        assert np.array_equal(_np(out["index"]), g[f"{tag}_index"]), tag
+        for k in ("observations", "cost_returns", "rew_returns", "rewards"):
+            assert np.array_equal(_np(out[k]), g[f"{tag}_{k}"]), (tag, k)
+    with pytest.raises(NotImplementedError):
+        process_bc_dataset(make_ingest_dataset(), 6.0, 1.0, "frontier", DEV)
+
+
+def test_ingest_large_matches_oracle_and_feeds_the_samplers():
+    """300k transitions (73 scan tiles, > 1024 episodes, 1-step episodes, no trailing partial episode) against the
+    numpy oracle; then the device tables drive SequenceStore / ReplayStore directly."""
+    from oracle import ingest_oracle as IO
+    from osrl_amd.common.ingest import compute_cost_sample_prob, process_bc_dataset, process_sequence_dataset
+    from osrl_amd.common.replay import ReplayStore, SequenceStore
+    from osrl_amd.engine.core import StepState
+    rs = np.random.RandomState(7)
+    n, od, ad = 300_000, 6, 2
+    f = np.float32
+    data = dict(observations=rs.randn(n, od).astype(f), next_observations=rs.randn(n, od).astype(f),
+                actions=rs.uniform(-1, 1, (n, ad)).astype(f), rewards=rs.uniform(0, 1, n).astype(f),
+                costs=(rs.uniform(size=n) < 0.1).astype(f), terminals=(rs.uniform(size=n) < 0.004).astype(f),
+                timeouts=(rs.uniform(size=n) < 0.004).astype(f))
+    data["timeouts"][-1] = 1
+    data["terminals"][100:103] = 1  # three 1-step episodes in a row
+    tb = process_sequence_dataset(data, False, DEV)
+    ref = IO.process_sequence_dataset(data, False)
+    assert int(tb["traj_len"].shape[0]) == len(ref) > 1024
+    assert np.array_equal(_np(tb["traj_len"]), np.array([len(t["costs"]) for t in ref]))
+    for k in ("returns", "cost_returns", "costs"):
+        assert np.array_equal(_np(tb[k]), np.concatenate([t[k] for t in ref])), k
+    p = compute_cost_sample_prob(tb, ("affine", -1.0, 30.0))
+    np.testing.assert_allclose(_np(p), IO.compute_cost_sample_prob(ref, lambda x: 30 - x), rtol=5e-6, atol=1e-10)
+
+    out = process_bc_dataset(data, 20.0, 0.99, "boundary", DEV)
+    want = IO.process_bc_dataset(dict(data, index=np.arange(n)), 20.0, 0.99, "boundary")
+    assert np.array_equal(_np(out["index"]), want["index"]) and 0 < len(want["index"]) < n
+    for k in ("observations", "actions", "cost_returns", "rew_returns", "terminals"):
+        assert np.array_equal(_np(out[k]), want[k]), k
+
+    # the device tables feed the samplers without a host round trip
+    store = SequenceStore.from_dataset(data, 8, DEV, reward_scale=0.1, cost_scale=1.0, cost_sample=True,
+                                       cost_transform=("affine", -1.0, 30.0), seed=3)
+    st = StepState(DEV, ["x"])
+    st.tick()
+    B, T = 256, 8
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+    outs = (z(B, T, od), z(B, T, ad), z(B, T), z(B, T), z(B, T, dt=torch.int64), z(B, T), z(B), z(B, T))
+    idx = z(B, 2, dt=torch.int32)
+    store.gather(*outs, st.ptr, idx_out=idx)
+    torch.cuda.synchronize()
+    ii = idx.cpu().numpy()
+    o = [x.cpu().numpy() for x in outs]
+    for b in range(0, B, 16):
+        want_s = prepare_sequence_sample(ref[int(ii[b, 0])], int(ii[b, 1]), T, 0.1, 1.0)
+        for got, w in zip(o, want_s):
+            np.testing.assert_allclose(got[b], np.asarray(w, np.float64), rtol=1e-6, atol=1e-6)
+    safe = process_bc_dataset(data, 20.0, 0.99, "safe", DEV)
+    rstore = ReplayStore({k: safe[k] for k in ("observations", "next_observations", "actions", "rewards", "costs",
+                                               "terminals", "timeouts")}, DEV)
+    assert rstore.n_rows == int(safe["index"].shape[0])

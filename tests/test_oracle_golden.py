@@ -53,3 +53,32 @@ def test_oracle_matches_reference(name, dtype):
     else:
         a = o.act(b["observations"])
     np.testing.assert_allclose(a, g["act"], rtol=0, atol=1e-4)
+
+
+# --------------------------------------------------------------------------- #
+# dataset ingestion oracle (oracle/ingest_oracle.py) vs the reference's own functions (tests/golden/ingest.npz)
+# --------------------------------------------------------------------------- #
+def test_ingest_oracle_matches_golden():
+    from cases import make_ingest_dataset
+    from oracle import ingest_oracle as IO
+    g = load_golden("ingest")
+    for rev, tag in ((False, "fwd"), (True, "rev")):
+        traj = IO.process_sequence_dataset(make_ingest_dataset(), rev)
+        assert np.array_equal(np.array([len(t["costs"]) for t in traj]), g[f"seq_{tag}_len"])
+        for k in ("observations", "actions", "rewards", "costs", "returns", "cost_returns"):
+            got = np.concatenate([t[k] for t in traj])
+            assert got.dtype == g[f"seq_{tag}_{k}"].dtype == np.float32
+            assert np.array_equal(got, g[f"seq_{tag}_{k}"]), (tag, k)  # bit-exact: same fp32 recurrence
+        for name, fn in (("prob50", lambda x: 50 - x), ("prob8", lambda x: 8 - x), ("probinv", lambda x: 1 / (x + 10))):
+            np.testing.assert_allclose(IO.compute_cost_sample_prob(traj, fn), g[f"seq_{tag}_{name}"], rtol=1e-6, atol=0)
+    for mode in IO.BC_MODES:
+        for gamma in (1.0, 0.99):
+            data = make_ingest_dataset()
+            data["index"] = np.arange(data["rewards"].shape[0])
+            out = IO.process_bc_dataset(data, 6.0, gamma, mode)
+            tag = f"bc_{mode}_{gamma}"
+            assert np.array_equal(out["index"], g[f"{tag}_index"]), tag
+            for k in ("observations", "cost_returns", "rew_returns", "rewards"):
+                assert np.array_equal(out[k], g[f"{tag}_{k}"]), (tag, k)
+    with pytest.raises(NotImplementedError):
+        IO.process_bc_dataset(make_ingest_dataset(), 6.0, 1.0, "frontier")
