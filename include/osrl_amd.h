@@ -374,7 +374,23 @@ typedef struct {
   float max_action, cost_threshold, cost_scale, pad2_;
 } osrl_env_t;
 int osrl_env_step(const osrl_env_t* env, const float* act, float* state, float* obs, int32_t obs_ld, float* acc,
-                  int32_t episodes, void* stream);
+                  float* step_out /* optional [E,2]: this step's (reward, raw cost) */, int32_t episodes, void* stream);
+
+/* CDTTrainer.rollout (cdt.py:436-518) with E episodes as batch rows.  The reference keeps the whole history and
+ * slices its last seq_len steps per env step; here the CDT engine's [E, seq_len] batch buffers are the window
+ * itself: left-aligned and growing (mask = 1 on the filled prefix) until full, then sliding by one per env step.
+ * cursor: device int32 = env steps taken so far (identical for all episodes).
+ *   pick: act[e] = clamp(head[e, last filled position, :action_dim], +-max_action)     (cdt.py:489-493)
+ *   push (after osrl_env_step): actions[last] = act; append (obs', returns - reward, costs_to_go - cost*cost_scale
+ *         [1 - cost under cost_reverse], time step + 1, zero dummy action) (cdt.py:496-508); ++cursor.  The pick at
+ *         cursor == episode_len reads the last window; callers stop there. */
+int osrl_cdt_rollout_pick(const float* head, int32_t head_width, int32_t action_dim, int32_t episodes,
+                          int32_t seq_len, const int32_t* cursor, float max_action, float* act, void* stream);
+int osrl_cdt_rollout_push(float* states, float* actions, float* returns, float* costs_to_go, int64_t* time_steps,
+                          float* mask, int32_t episodes, int32_t seq_len, int32_t state_dim, int32_t action_dim,
+                          const float* act, const float* obs, int32_t obs_ld, const float* step_out, float cost_scale,
+                          int32_t cost_reverse, int32_t* cursor, int32_t episode_len /* no-op once cursor reaches it */,
+                          void* stream);
 
 /* library identity */
 const char* osrl_version(void);

@@ -80,7 +80,10 @@ _P = C.POINTER
 # name -> argtypes  (all return int except osrl_version); must match include/osrl_amd.h
 PROTOTYPES = {
     "osrl_mlp_forward": [_P(MlpT), _P(RowsT), _P(ActsT), _vp],
-    "osrl_env_step": [_P(EnvT), _vp, _vp, _vp, _i32, _vp, _i32, _vp],
+    "osrl_env_step": [_P(EnvT), _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp],
+    "osrl_cdt_rollout_pick": [_vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp],
+    "osrl_cdt_rollout_push": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _f32, _i32,
+                              _vp, _i32, _vp],
     "osrl_ingest_ws_elems": [_i64],
     "osrl_episode_segments": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "osrl_episode_returns": [_vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp],

@@ -206,7 +206,20 @@ class CDTTrainer:
         store_stats(self.logger, eng.st, self.stats_mode, tab="train", keys=keys)
 
     def evaluate(self, num_rollouts, target_return, target_cost):
-        """cdt.py:420-434."""
+        """cdt.py:420-434.  With a ``VecSyntheticSafeEnv`` as ``self.env`` the ``num_rollouts`` episodes run as one
+        batch on device (engine/rollout.py ``CDTBatchedRollout``)."""
+        from ..common.synthetic_env import VecSyntheticSafeEnv
+        if isinstance(self.env, VecSyntheticSafeEnv):
+            from ..engine.rollout import CDTBatchedRollout
+            if self.env.E != num_rollouts:
+                raise ValueError(f"the vector environment holds {self.env.E} episodes, evaluate() was asked for "
+                                 f"{num_rollouts}")
+            ro = getattr(self, "_rollout", None)
+            if ro is None or ro[0] != id(self.env):
+                ro = self._rollout = (id(self.env), CDTBatchedRollout(self.model, self.env, self.cost_scale,
+                                                                      self.cost_reverse, self.use_graph))
+            r, c, n = ro[1].run(target_return, target_cost)
+            return float(r.mean()) / self.reward_scale, float(c.mean()) / self.cost_scale, float(n.mean())
         self.model.eval()
         rets, costs, lens = [], [], []
         for _ in range(num_rollouts):

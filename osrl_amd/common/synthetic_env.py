@@ -83,8 +83,11 @@ class VecSyntheticSafeEnv:
         obs_out[:, :self.state_dim].copy_(self.state0)
         self.acc.zero_()
 
-    def step(self, desc, actions, obs_out) -> None:
+    def step(self, desc, actions, obs_out, step_out=None) -> None:
+        """``step_out`` (optional [E,2]) receives this step's (reward, raw cost) -- CDT's to-go bookkeeping."""
         from .. import _lib as L
         from ..engine.core import cur_stream
         L.check(L.load().osrl_env_step(desc, actions.data_ptr(), self.state.data_ptr(), obs_out.data_ptr(),
-                                       obs_out.stride(0), self.acc.data_ptr(), self.E, cur_stream()), "osrl_env_step")
+                                       obs_out.stride(0), self.acc.data_ptr(),
+                                       None if step_out is None else step_out.data_ptr(), self.E, cur_stream()),
+                "osrl_env_step")

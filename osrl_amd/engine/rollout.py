@@ -10,6 +10,7 @@ Policies (same arithmetic as ``model.act``):
   BC    ``act_limit * tanh(pi(obs))``                                 bc.py:57-64  (multi-task: obs ++ cost_limit, :132-138)
   CPQ   ``max_action * tanh(mu(obs))`` (deterministic=True)           cpq.py:240-252, net.py:176-205
   BCQL  ``actor(obs, vae.decode(obs, z)), z = clamp(N(0,1), +-0.5)``  bcql.py:236-243, net.py:328-339
+  CDT   windowed autoregression on the last seq_len steps             cdt.py:436-518 (``CDTBatchedRollout``)
 """
 from __future__ import annotations
 
@@ -136,3 +137,92 @@ def evaluate_batched(trainer, kind: str, eval_episodes: int, cost_scale: float =
         trainer._rollout = ro
     ret, cost, length = ro[1].run()
     return float(ret.mean()), float(cost.mean()), float(length.mean())
+
+
+class CDTBatchedRollout:
+    """``CDTTrainer.rollout`` (cdt.py:436-518) for E episodes at once.  The reference re-slices the last ``seq_len``
+    steps of a full-history buffer every env step; here an inference ``CDTEngine`` with batch = E holds the window
+    in its batch buffers (left-aligned while it fills, sliding afterwards; csrc/env.hip ``cdt_push_kernel``), so one
+    env step of all episodes = transformer forward -> pick the mean action at the last filled position -> env
+    kernel -> window push, ``_CHUNK`` steps per captured graph."""
+
+    def __init__(self, model, venv, cost_scale: float = 1.0, cost_reverse: bool = False, use_graph: bool = True):
+        from .cdt import CDTEngine
+        m = self.model = model
+        self.venv, self.use_graph = venv, use_graph
+        self.cost_scale, self.cost_reverse = float(cost_scale), bool(cost_reverse)
+        dev = torch.device(m.device)
+        E = venv.E
+        cfg = m._engine.cfg if m._engine is not None else dict(
+            learning_rate=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), clip_grad=0.25, lr_warmup_steps=1,
+            loss_cost_weight=0.0, loss_state_weight=0.0, no_entropy=False)
+        self.eng = CDTEngine(m, E, cfg)
+        f = dict(dtype=torch.float32, device=dev)
+        self.obs = torch.zeros(E, venv.state_dim, **f)
+        self.act = torch.zeros(E, m.action_dim, **f)
+        self.step_out = torch.zeros(E, 2, **f)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.env_c = venv.desc(m.episode_len, 1.0)  # acc[:,1] = raw cost sum, as cdt.py:513 accumulates it
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _reset(self, target_return: float, target_cost: float) -> None:
+        e = self.eng
+        self.venv.reset(self.obs)
+        for t in (e.states, e.actions, e.returns, e.ctg, e.mask, e.costs):
+            t.zero_()
+        e.time_steps.zero_()
+        e.states[:, 0].copy_(self.obs)
+        e.returns[:, 0] = float(target_return)
+        e.ctg[:, 0] = float(target_cost)
+        e.mask[:, 0] = 1.0
+        self.cursor.zero_()
+
+    def body(self) -> None:
+        from .. import _lib as L
+        from .core import cur_stream
+        m, e, E, lib = self.model, self.eng, self.venv.E, L.load()
+        e.forward(train=False)
+        L.check(lib.osrl_cdt_rollout_pick(e.head.data_ptr(), e.head.shape[1], m.action_dim, E, m.seq_len,
+                                          self.cursor.data_ptr(), float(m.max_action), self.act.data_ptr(),
+                                          cur_stream()), "osrl_cdt_rollout_pick")
+        self.venv.step(self.env_c, self.act, self.obs, self.step_out)
+        L.check(lib.osrl_cdt_rollout_push(e.states.data_ptr(), e.actions.data_ptr(), e.returns.data_ptr(),
+                                          e.ctg.data_ptr(), e.time_steps.data_ptr(), e.mask.data_ptr(), E, m.seq_len,
+                                          m.state_dim, m.action_dim, self.act.data_ptr(), self.obs.data_ptr(),
+                                          self.obs.stride(0), self.step_out.data_ptr(), self.cost_scale,
+                                          int(self.cost_reverse), self.cursor.data_ptr(), int(self.env_c.episode_len),
+                                          cur_stream()),
+                "osrl_cdt_rollout_push")
+
+    def _capture(self) -> None:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.body()
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(_CHUNK):
+                self.body()
+        torch.cuda.synchronize()
+        self.graph = gr
+
+    @torch.no_grad()
+    def run(self, target_return: float, target_cost: float) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Per-episode (return, raw cost sum, length)."""
+        m = self.model
+        steps = min(m.episode_len, self.venv.episode_len or m.episode_len)
+        if self.env_c.episode_len != steps:
+            self.env_c.episode_len, self.graph = steps, None
+        m.repack()
+        if self.use_graph and self.graph is None:
+            self._capture()  # runs the body on scratch state; _reset below starts the real rollout
+        self._reset(target_return, target_cost)
+        if self.use_graph:
+            for _ in range((steps + _CHUNK - 1) // _CHUNK):
+                self.graph.replay()
+        else:
+            for _ in range(steps):
+                self.body()
+        acc = self.venv.acc.cpu().numpy()
+        return acc[:, 0].astype(np.float64), acc[:, 1].astype(np.float64), acc[:, 2].astype(np.float64)

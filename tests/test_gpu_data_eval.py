@@ -322,3 +322,46 @@ def test_ingest_large_matches_oracle_and_feeds_the_samplers():
     rstore = ReplayStore({k: safe[k] for k in ("observations", "next_observations", "actions", "rewards", "costs",
                                                "terminals", "timeouts")}, DEV)
     assert rstore.n_rows == int(safe["index"].shape[0])
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_cdt_batched_evaluate_matches_oracle_rollouts(use_graph):
+    """CDTTrainer.evaluate on a VecSyntheticSafeEnv (window held in the engine's batch buffers, growing then sliding)
+    == the numpy oracle re-slicing a full history per env step (cdt.py:436-518), episode by episode; the episode is
+    longer than 2x seq_len and not a multiple of the graph chunk."""
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    from test_gpu_cdt import build_cdt_gpu
+    from test_oracle_cdt_golden import build_cdt_oracle
+    c = CDT_CASES["cdt_small"]
+    m, tr, lg = build_cdt_gpu(c, use_graph=use_graph)
+    o = build_cdt_oracle(c)
+    E, EL, T = 5, 2 * c.T + 3, c.T
+    m.episode_len = EL
+    tr.cost_scale = 2.0
+    env = SyntheticSafeEnv(c.od, c.ad, EL, seed=2, init_noise=0.6)
+    tr.env = VecSyntheticSafeEnv(env, E, DEV, base_seed=40)
+    for rep in range(2):  # the second call replays the cached graph after a reset
+        ret, cost, ln = tr.evaluate(E, target_return=30.0, target_cost=5.0)
+    rets, costs, lens = tr._rollout[1].run(30.0, 5.0)
+    assert abs(ret - rets.mean() / tr.reward_scale) < 1e-5 and ln == EL and abs(cost - costs.mean() / 2.0) < 1e-6
+    for e in range(E):
+        S, A = np.zeros((EL + 1, c.od), np.float32), np.zeros((EL, c.ad), np.float32)
+        R, C = np.zeros(EL + 1, np.float32), np.zeros(EL + 1, np.float32)
+        obs, _ = env.reset(seed=40 + e)
+        S[0], R[0], C[0] = obs, 30.0, 5.0
+        r0 = c0 = 0.0
+        for step in range(EL):
+            lo = max(0, step + 1 - T)
+            n = step + 1 - lo
+            pad = lambda x: np.concatenate([x, np.zeros((T - n,) + x.shape[1:], x.dtype)])[None]  # noqa: E731
+            acts = o.act_mean(pad(S[lo:step + 1]), pad(A[lo:step + 1]), pad(R[lo:step + 1]), pad(C[lo:step + 1]),
+                              pad(np.arange(lo, step + 1)), pad(np.ones(n, np.float32)))
+            act = np.clip(acts[0, n - 1], -1, 1)
+            obs, reward, term, trunc, info = env.step(act)
+            A[step], S[step + 1] = act, obs
+            R[step + 1], C[step + 1] = R[step] - reward, C[step] - info["cost"] * 2.0
+            r0 += reward
+            c0 += info["cost"]
+        assert lens[e] == EL and abs(rets[e] - r0) < 1e-3 * max(1, abs(r0)) and abs(costs[e] - c0) <= 1.0, \
+            (e, rets[e], r0, costs[e], c0)
+    assert np.unique(np.round(rets, 3)).size == E

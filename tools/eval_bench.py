@@ -66,6 +66,30 @@ def main():
             dt = time.perf_counter() - t0
             out["rows"].append(dict(algo=algo, path="cpu oracle policy + numpy env", episodes=a.scalar_episodes,
                                     s_per_eval=round(dt, 5), env_steps_per_s=round(a.scalar_episodes * a.len / dt, 1)))
+    # CDT at the C5 architecture (obs 11, act 3, T=20, E=256, 3 layers, 8 heads), 100-step episodes
+    from osrl_amd.algorithms import CDT, CDTTrainer
+    torch.manual_seed(0)
+    EL = 100
+    m = CDT(11, 3, 1.0, seq_len=20, episode_len=EL, embedding_dim=256, num_layers=3, num_heads=8, use_rew=True,
+            use_cost=True, cost_transform=True, stochastic=True, device=dev)
+    tr = CDTTrainer(m, None, DummyLogger(), device=dev)
+    env = SyntheticSafeEnv(11, 3, EL, seed=1, init_noise=0.5)
+    for E in (1, 64, 256):
+        tr.env = VecSyntheticSafeEnv(env, E, dev)
+        tr.evaluate(E, 30.0, 5.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = tr.evaluate(E, 30.0, 5.0)
+        dt = time.perf_counter() - t0
+        out["rows"].append(dict(algo="cdt", path="batched-graph", episodes=E, episode_len=EL, s_per_eval=round(dt, 5),
+                                env_steps_per_s=round(E * EL / dt, 1), us_per_env_step_launch=round(dt / EL * 1e6, 2),
+                                mean_return=round(r[0], 4)))
+    tr.env = env
+    t0 = time.perf_counter()
+    tr.evaluate(1, 30.0, 5.0)
+    dt = time.perf_counter() - t0
+    out["rows"].append(dict(algo="cdt", path="episode-loop (B=1, host round trip per step)", episodes=1, episode_len=EL,
+                            s_per_eval=round(dt, 5), env_steps_per_s=round(EL / dt, 1)))
     print(json.dumps(out, indent=1))
 
 
