@@ -323,6 +323,37 @@ int osrl_clip_grad_scale(const float* grad, int64_t n, float clip, float* partia
 int osrl_cdt_temperature_step(float* log_temperature, float* moments, const float* entropy, float target_entropy,
                               float lr, float beta1, float beta2, float eps, const osrl_step_state_t* st, void* stream);
 
+/* ---- BEAR-Lagrangian glue (osrl/algorithms/bearl.py) ----
+ * Rows are batch-major: row b*M + j = sample j of batch element b (repeat_interleave, bearl.py:224-226).
+ * osrl_bear_mmd: u = mu + exp(clamp(log_std)) * eps from the actor head [B*M, 2*ad] (net.py:176-186);
+ *   mmd[b] = mmd_loss_gaussian / mmd_loss_laplacian(raw_vae[b], u[b], sigma) (bearl.py:277-312);
+ *   du = d mmd[b] / d u (unscaled); tanh_u = tanh(u); a0[b] = tanh(u[b, 0]) (the critics' action, bearl.py:243-245).
+ *   M <= 64, ad <= 16. */
+enum { OSRL_MMD_GAUSSIAN = 0, OSRL_MMD_LAPLACIAN = 1 };
+int osrl_bear_mmd(const float* raw_vae, const float* head, const float* eps, int32_t rows, int32_t n_samples,
+                  int32_t ad, float sigma, int32_t kernel, float* mmd, float* du, float* tanh_u, float* a0,
+                  void* stream);
+/* out = {mean min(q1,q2), mean min(qc1,qc2), mean mmd} over rows / rows_global: the data-parallel pre-pass (the PID
+ * controller and the dual step need GLOBAL means); all-reduce it and pass it as global_means below. */
+int osrl_bear_actor_sums(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
+                         const float* mmd, int32_t rows, int32_t rows_global, float* out, void* stream);
+/* The scalar side of BEARL.actor_loss (bearl.py:246-275): PID multiplier (net.py:376-387, state pid[2]); loss =
+ * mean(-q [only once n_train_steps = st->step - 1 >= start_update_policy_step] + exp(log_alpha)*(mmd - thresh)) +
+ * mean((qc - qc_thres) * multiplier); dq / dqc = d loss / d (every Q-net output) with torch.min's routing;
+ * coef[0] = exp(log_alpha) / rows_global BEFORE the dual step log_alpha += alpha_lr*exp(log_alpha)*mean(mmd - thresh),
+ * clamp [-5, 5]; stat[0..5) = actor_loss, mmd_loss, qc_penalty, lagrangian, alpha_value (x stat_share). */
+int osrl_bear_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* qc, int32_t nc1, int32_t nc2,
+                         const float* mmd, int32_t rows, float qc_thres, float KP, float KI, float KD,
+                         float target_mmd_thresh, float alpha_lr, int64_t start_update_policy_step,
+                         int32_t rows_global, const float* global_means, float stat_share,
+                         const osrl_step_state_t* st, float* pid, float* log_alpha, float* dq, float* dqc, float* coef,
+                         float* stat, void* stream);
+/* dhead[B*M, 2*ad] = d loss / d (mu, log_std): du = coef[0]*du_mmd + [sample 0] sum_nets da_nets[n, b] * (1 - tanh_u^2);
+ * d mu = du, d log_std = du * eps * std inside the clamp range (net.py:180). */
+int osrl_bear_head_bwd(const float* head, const float* eps, const float* tanh_u, const float* du_mmd, const float* coef,
+                       const float* da_nets, int32_t n_nets, int32_t rows, int32_t n_samples, int32_t ad, float* dhead,
+                       void* stream);
+
 /* ---- dataset ingestion on device (osrl/common/dataset.py) ----
  * The flat DSRL arrays (observations, actions, rewards, costs, terminals, timeouts) are uploaded once; these calls
  * produce, in HBM, what the reference computes in host python loops before training.  `ws` is an int32 workspace of

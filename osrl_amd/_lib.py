@@ -84,6 +84,11 @@ PROTOTYPES = {
     "osrl_cdt_rollout_pick": [_vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp],
     "osrl_cdt_rollout_push": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _f32, _i32,
                               _vp, _i32, _vp],
+    "osrl_bear_mmd": [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "osrl_bear_actor_sums": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
+    "osrl_bear_actor_loss": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _i64,
+                             _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "osrl_bear_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "osrl_ingest_ws_elems": [_i64],
     "osrl_episode_segments": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "osrl_episode_returns": [_vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp],

@@ -217,6 +217,12 @@ def vae_enc_desc(vae: VAE) -> NetDesc:
     return NetDesc([[_ref(vae.e1), _ref(vae.e2), _packed(vae.mean, vae.log_std)]], ["relu", "relu", "id"], 1.0)
 
 
+def vae_dec_raw_desc(vae: VAE) -> NetDesc:
+    """The decoder WITHOUT its tanh: ``d3(relu(d2(relu(d1(.)))))`` -- the second return value of
+    ``VAE.decode_multiple`` (net.py:342-353), which BEAR-L's MMD term consumes."""
+    return NetDesc([[_ref(vae.d1), _ref(vae.d2), _ref(vae.d3)]], ["relu", "relu", "id"], 1.0)
+
+
 def vae_dec_desc(vae: VAE) -> NetDesc:
     return NetDesc([[_ref(vae.d1), _ref(vae.d2), _ref(vae.d3)]], ["relu", "relu", "tanh"], float(vae.act_lim))
 

@@ -96,6 +96,15 @@ def make_params(c: Case) -> "OrderedDict[str, np.ndarray]":
         _vae(rs, sd, c.od, c.ad, c.vae_hidden)
         for i in range(c.num_qc):
             _seq(rs, sd, f"cost_critic.q_nets.{i}", [c.od + c.ad] + c.hidden + [1])
+    elif c.algo == "bearl":  # creation order of bearl.py:97-109: actor, critic, cost_critic, vae
+        _seq(rs, sd, "actor.net", [c.od] + c.hidden)
+        _named(rs, sd, "actor.mu_layer", c.ad, c.hidden[-1])
+        _named(rs, sd, "actor.log_std_layer", c.ad, c.hidden[-1])
+        for grp, n in (("critic", c.num_q), ("cost_critic", c.num_qc)):
+            for which in ("q1_nets", "q2_nets"):
+                for i in range(n):
+                    _seq(rs, sd, f"{grp}.{which}.{i}", [c.od + c.ad] + c.hidden + [1])
+        _vae(rs, sd, c.od, c.ad, c.vae_hidden)
     elif c.algo == "bcql":
         _seq(rs, sd, "actor.pi", [c.od + c.ad] + c.hidden + [c.ad])
         for grp, n in (("critic", c.num_q), ("cost_critic", c.num_qc)):
@@ -139,6 +148,10 @@ def noise_shapes(c: Case):
     if c.algo == "bcql":
         return [("eps_vae", (B, 2 * ad)), ("z_c", (N * B, 2 * ad)), ("z_cc", (N * B, 2 * ad)),
                 ("z_actor", (B, 2 * ad))]
+    if c.algo == "bearl":  # oracle/bearl_oracle.py header
+        M = int(c.hp.get("M", 10))
+        return [("eps_vae", (B, 2 * ad)), ("eps_c", (N * B, ad)), ("eps_cc", (N * B, ad)),
+                ("z_mmd", (B, M, 2 * ad)), ("eps_pi", (B * M, ad))]
     return []
 
 
@@ -154,8 +167,24 @@ def hyper(c: Case) -> Dict[str, float]:
     if c.algo == "cpq":
         return dict(actor_lr=1e-4, critic_lr=1e-3, alpha_lr=1e-4, vae_lr=1e-3, gamma=0.99, tau=0.005,
                     beta=0.5, qc_scalar=1.5)
+    if c.algo == "bearl":  # bearl_configs.py:31-57
+        d = dict(actor_lr=1e-3, critic_lr=1e-3, vae_lr=1e-3, alpha_lr=1e-3, gamma=0.99, tau=0.005, beta=0.5, lmbda=0.75,
+                 mmd_sigma=50.0, target_mmd_thresh=0.05, M=10, start=0, kernel="gaussian", PID=(0.1, 0.003, 0.001))
+        d.update(c.hp)
+        return d
     return dict(actor_lr=1e-3, critic_lr=1e-3, vae_lr=1e-3, gamma=0.99, tau=0.005, beta=0.5,
                 phi=0.05, lmbda=0.75, PID=(0.1, 0.003, 0.001))
+
+
+# BEAR-Lagrangian; kept apart from CASES so the older fixtures need no regeneration
+BEARL_CASES: Dict[str, Case] = {c.name: c for c in [
+    Case("bearl_small", "bearl", od=6, ad=3, B=16, hidden=[32, 32], vae_hidden=48, N=4, steps=10, episode_len=200,
+         hp=dict(M=5, mmd_sigma=2.0)),
+    Case("bearl_lap", "bearl", od=4, ad=2, B=16, hidden=[24, 24], vae_hidden=32, N=3, num_q=1, num_qc=2, steps=5,
+         episode_len=200, cost_limit=-4.0, max_action=1.5, seed=1,
+         hp=dict(M=4, kernel="laplacian", mmd_sigma=1.5, start=3, alpha_lr=0.05)),
+    Case("bearl_wide", "bearl", od=33, ad=8, B=32, hidden=[256, 256], vae_hidden=400, N=10, steps=1, episode_len=200),
+]}
 
 
 # --------------------------------------------------------------------------- #

@@ -25,7 +25,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from cases import (CASES, CDT_CASES, cdt_drop_sites, hyper, make_batch, make_cdt_batch, make_cdt_drop,  # noqa: E402
+from cases import (BEARL_CASES, CASES, CDT_CASES, cdt_drop_sites, hyper, make_batch, make_cdt_batch, make_cdt_drop,  # noqa: E402
                    make_cdt_params, make_noise, make_params, noise_shapes)
 
 REF = os.environ.get("OSRL_REFERENCE", "/root/reference")
@@ -103,6 +103,12 @@ def build(case, torch, algos, Logger):
                       case.N, hp["gamma"], hp["tau"], hp["beta"], case.num_q, case.num_qc,
                       hp["qc_scalar"], case.cost_limit, case.episode_len)
         tr = algos.CPQTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["alpha_lr"], hp["vae_lr"])
+    elif case.algo == "bearl":
+        m = algos.BEARL(case.od, case.ad, case.max_action, case.hidden, case.hidden, case.vae_hidden, case.N,
+                        hp["gamma"], hp["tau"], hp["beta"], hp["lmbda"], hp["mmd_sigma"], hp["target_mmd_thresh"],
+                        hp["M"], list(hp["PID"]), hp["kernel"], case.num_q, case.num_qc, case.cost_limit,
+                        case.episode_len, hp["start"])
+        tr = algos.BEARLTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["alpha_lr"], hp["vae_lr"])
     else:
         m = algos.BCQL(case.od, case.ad, case.max_action, case.hidden, case.hidden, case.vae_hidden,
                        case.N, hp["gamma"], hp["tau"], hp["phi"], hp["lmbda"], hp["beta"],
@@ -114,7 +120,8 @@ def build(case, torch, algos, Logger):
     return m, tr, lg
 
 
-def main():
+def main(cases=None):
+    cases = CASES if cases is None else cases
     Logger = _install_stubs()
     sys.path.insert(0, REF)
     import torch
@@ -123,7 +130,7 @@ def main():
     torch.set_num_threads(4)
     nq = NoiseQueue(torch)
     nq.install()
-    for case in CASES.values():
+    for case in cases.values():
         m, tr, lg = build(case, torch, algos, Logger)
         b = {k: torch.from_numpy(v) for k, v in make_batch(case).items()}
         out = {}
@@ -147,9 +154,9 @@ def main():
                         out[f"p{s + 1}/smp/{k}"] = a.reshape(-1)[::97].copy()
                     else:
                         out[f"p{s + 1}/{k}"] = a.copy()
-                if case.algo == "cpq":
+                if case.algo in ("cpq", "bearl"):
                     out[f"s{s + 1}/log_alpha"] = np.float64(m.log_alpha.item())
-                if case.algo == "bcql":
+                if case.algo in ("bcql", "bearl"):
                     out[f"s{s + 1}/pid_error_old"] = np.float64(float(m.controller.error_old))
                     out[f"s{s + 1}/pid_error_integral"] = np.float64(float(m.controller.error_integral))
         keys = sorted(lg.rows[0].keys())
@@ -169,7 +176,7 @@ def main():
         with torch.no_grad():
             if case.algo == "bc":
                 out["act"] = m.actor(b["observations"]).numpy()
-            elif case.algo == "cpq":
+            elif case.algo in ("cpq", "bearl"):
                 a, _ = m._actor_forward(b["observations"], True, True)
                 out["act"] = a.numpy()
             else:
@@ -289,6 +296,10 @@ def main_cdt():
 
 
 if __name__ == "__main__":
-    if "--cdt-only" not in sys.argv:
-        main()
-    main_cdt()
+    if "--bearl-only" in sys.argv:
+        main(BEARL_CASES)
+    else:
+        if "--cdt-only" not in sys.argv:
+            main()
+            main(BEARL_CASES)
+        main_cdt()

@@ -6,7 +6,7 @@ from cases import Case, hyper, make_batch, make_noise, make_params
 
 
 def build_gpu(c: Case, device="cuda:0", **trainer_kw):
-    from osrl_amd.algorithms import BC, BCQL, CPQ, BCQLTrainer, BCTrainer, CPQTrainer
+    from osrl_amd.algorithms import BC, BCQL, BEARL, CPQ, BCQLTrainer, BCTrainer, BEARLTrainer, CPQTrainer
     from osrl_amd.common.logger import DummyLogger
     hp = hyper(c)
     lg = DummyLogger()
@@ -20,6 +20,12 @@ def build_gpu(c: Case, device="cuda:0", **trainer_kw):
                 hp["beta"], c.num_q, c.num_qc, hp["qc_scalar"], c.cost_limit, c.episode_len, device=device)
         tr = CPQTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["alpha_lr"], hp["vae_lr"],
                         device=device, **kw)
+    elif c.algo == "bearl":
+        m = BEARL(c.od, c.ad, c.max_action, c.hidden, c.hidden, c.vae_hidden, c.N, hp["gamma"], hp["tau"], hp["beta"],
+                  hp["lmbda"], hp["mmd_sigma"], hp["target_mmd_thresh"], hp["M"], list(hp["PID"]), hp["kernel"],
+                  c.num_q, c.num_qc, c.cost_limit, c.episode_len, hp["start"], device=device)
+        tr = BEARLTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["alpha_lr"], hp["vae_lr"], device=device,
+                          **kw)
     else:
         m = BCQL(c.od, c.ad, c.max_action, c.hidden, c.hidden, c.vae_hidden, c.N, hp["gamma"], hp["tau"],
                  hp["phi"], hp["lmbda"], hp["beta"], list(hp["PID"]), c.num_q, c.num_qc, c.cost_limit,

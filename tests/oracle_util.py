@@ -4,6 +4,7 @@ import os
 import numpy as np
 
 from cases import Case, hyper, make_batch, make_noise, make_params
+from oracle.bearl_oracle import OracleBEARL
 from oracle.osrl_oracle import OracleBC, OracleBCQL, OracleCPQ
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -24,6 +25,13 @@ def build_oracle(c: Case, dtype=np.float32):
                          cost_limit=c.cost_limit, episode_len=c.episode_len, actor_lr=hp["actor_lr"],
                          critic_lr=hp["critic_lr"], alpha_lr=hp["alpha_lr"], vae_lr=hp["vae_lr"],
                          dtype=dtype)
+    if c.algo == "bearl":
+        return OracleBEARL(sd, max_action=c.max_action, sample_action_num=c.N, gamma=hp["gamma"], tau=hp["tau"],
+                           beta=hp["beta"], lmbda=hp["lmbda"], mmd_sigma=hp["mmd_sigma"],
+                           target_mmd_thresh=hp["target_mmd_thresh"], num_samples_mmd_match=hp["M"],
+                           PID_gains=hp["PID"], kernel=hp["kernel"], cost_limit=c.cost_limit,
+                           episode_len=c.episode_len, start_update_policy_step=hp["start"], actor_lr=hp["actor_lr"],
+                           critic_lr=hp["critic_lr"], alpha_lr=hp["alpha_lr"], vae_lr=hp["vae_lr"], dtype=dtype)
     return OracleBCQL(sd, max_action=c.max_action, sample_action_num=c.N, gamma=hp["gamma"],
                       tau=hp["tau"], phi=hp["phi"], lmbda=hp["lmbda"], beta=hp["beta"],
                       PID_gains=hp["PID"], cost_limit=c.cost_limit, episode_len=c.episode_len,

@@ -5,16 +5,16 @@ import numpy as np
 import pytest
 import torch
 
-from cases import CASES, make_batch
+from cases import BEARL_CASES, CASES, make_batch
 from gpu_util import build_gpu, gpu_batch, gpu_step
 from oracle_util import build_oracle, load_golden, oracle_step
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(CASES) + list(BEARL_CASES))
 def test_train_step_matches_golden_and_oracle(name):
-    c = CASES[name]
+    c = CASES[name] if name in CASES else BEARL_CASES[name]
     g = load_golden(name)
     keys = [str(k) for k in g["stat_keys"]]
     m, tr, lg = build_gpu(c)
@@ -55,7 +55,7 @@ def test_train_step_matches_golden_and_oracle(name):
     with torch.no_grad():
         if c.algo == "bc":
             a = m.actor(b["observations"]).cpu().numpy()
-        elif c.algo == "cpq":
+        elif c.algo in ("cpq", "bearl"):
             from osrl_amd import ops
             a = ops.cpq_act(m, b["observations"], True)[0].cpu().numpy()
         else:
@@ -157,12 +157,13 @@ def test_graph_replay_is_deterministic_and_trains(name):
     assert moved == len(p0)
 
 
-@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full"])
+@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full", "bearl_small",
+                                  "bearl_wide"])
 def test_graph_with_parallel_branches_equals_eager_sequential(name):
     """The captured graph (forked side-stream branches, device Philox noise) must produce exactly the same
     parameters as the plain in-order launch sequence: same kernels, same inputs, no atomics."""
-    if name in CASES:
-        c = CASES[name]
+    if name in CASES or name in BEARL_CASES:
+        c = CASES[name] if name in CASES else BEARL_CASES[name]
     else:  # bench-size CPQ: capped N*B launch beside the VAE phase, paired launches
         from cases import Case
         c = Case(name, episode_len=1000, **FULL_CASES[name])
@@ -294,14 +295,14 @@ def _train_state(m):
     return out
 
 
-@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_pid"])
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_pid", "bearl_lap"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_checkpoint_resume_is_bit_identical(name, use_graph, tmp_path):
     """3 steps -> save -> load into a fresh model -> 2 steps  ==  5 uninterrupted steps, bit for bit (parameters,
     targets, Adam moments, log_alpha / PID state); the noise is the device Philox stream, keyed by the step count
     the checkpoint carries.  The file keeps the reference's {"model_state": ...} layout."""
     from osrl_amd.common.checkpoint import load_checkpoint, save_checkpoint
-    c = CASES[name]
+    c = CASES[name] if name in CASES else BEARL_CASES[name]
     b = gpu_batch(c)
     m_a, tr_a, _ = build_gpu(c, use_graph=use_graph)
     for s in range(5):

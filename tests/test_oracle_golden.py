@@ -6,14 +6,14 @@ parameters <= 1e-4 (observed ~1e-6)."""
 import numpy as np
 import pytest
 
-from cases import CASES, make_batch
+from cases import BEARL_CASES, CASES, make_batch
 from oracle_util import build_oracle, load_golden, oracle_step
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(CASES) + list(BEARL_CASES))
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_oracle_matches_reference(name, dtype):
-    c = CASES[name]
+    c = CASES[name] if name in CASES else BEARL_CASES[name]
     g = load_golden(name)
     keys = [str(k) for k in g["stat_keys"]]
     o = build_oracle(c, dtype)

@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from osrl_amd.algorithms import BC, BCQL, CDT, CPQ, BCQLTrainer, BCTrainer, CDTTrainer, CPQTrainer  # noqa: E402
+from osrl_amd.algorithms import (BC, BCQL, BEARL, CDT, CPQ, BCQLTrainer, BCTrainer, BEARLTrainer, CDTTrainer,  # noqa: E402
+                                 CPQTrainer)
 
 DEV = "cuda:0"
 
@@ -50,6 +51,13 @@ def main():
     args3 = (f(B, 33), f(B, 33), f(B, 8).clamp(-1, 1), f(B), (torch.rand(B, device=DEV) < 0.1).float(),
              (torch.rand(B, device=DEV) < 0.01).float())
     run("C3 BCQL (33,8)  B=4096", lambda: tr.train_one_step(*args3), 100, 10)
+    # BEAR-Lag at its train-config defaults (bearl_configs.py: B=512, N=M=10, hidden 256, vae 400) on the C3 dims
+    m = BEARL(33, 8, 1.0, [256, 256], [256, 256], 400, 10, 0.99, 0.005, 0.5, 0.75, 50.0, 0.05, 10, [0.1, 0.003, 0.001],
+              "gaussian", 2, 2, 10, 300, 0, device=DEV)
+    tr = BEARLTrainer(m, None, None, 1e-3, 1e-3, 1e-3, 1e-3, stats_mode="none")
+    for B in (512, 4096):
+        argsb = tuple(t[:B].contiguous() for t in args3)
+        run(f"BEAR-L  (33,8)  B={B:<4d}", lambda: tr.train_one_step(*argsb), 100, 10)
     # C5 CDT (11,3) T=20 E=256 8 heads 3 layers B=1024, dropout 0.1 (cdt_configs.py:28-30; pass a 3rd argv to override)
     B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 20
     pdrop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
