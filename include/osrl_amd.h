@@ -354,6 +354,38 @@ int osrl_bear_head_bwd(const float* head, const float* eps, const float* tanh_u,
                        const float* da_nets, int32_t n_nets, int32_t rows, int32_t n_samples, int32_t ad, float* dhead,
                        void* stream);
 
+/* ---- COptiDICE glue (osrl/algorithms/coptidice.py) ----
+ * nu2 / chi2 = EnsembleQCritic outputs [n_nets, 2*rows] on the stacked rows [obs; next_obs].
+ * leaves = float[6] {tau, m, v, lmbda, m, v}: the raw scalar leaves (coptidice.py:96-97) with their Adam moments;
+ * work = float[4] {softplus(lmbda), softplus(tau), weighted_c, -} of the current step. */
+enum { OSRL_F_CHI2 = 0, OSRL_F_SOFTCHI = 1, OSRL_F_KL = 2 }; /* get_f_div_fn, coptidice.py:15-38 */
+/* _optimal_w (coptidice.py:122-131): e = r - lambda' c + gamma (1-d) min nu(s') - min nu(s), w = relu(f'^-1(e/alpha)).
+ * use_saved_lambda = 0: lambda' = softplus(leaves[3]) and work[0..1] are (re)written (top of update(), :138);
+ * 1: lambda' = work[0] (policy extraction after the lambda step, :211-213).  e may be NULL. */
+int osrl_dice_optimal_w(const float* nu2, int32_t n_nu, int32_t rows, const float* rew, const float* cost,
+                        const float* done, const float* leaves, float* work, int32_t use_saved_lambda, float alpha,
+                        float gamma, int32_t f_type, float* e, float* w, void* stream);
+/* coptidice.py:149-185: ell, the softmax over the WHOLE batch, D_kl, weighted_c -> work[2], chi_loss and its gradient
+ * dchi [n_chi, 2*rows] (weights are not detached in the reference), Adam step on tau; stat[0..3) = chi_loss, tau_loss,
+ * D_kl.  chi2 == NULL (cost_ub_epsilon == 0): weighted_c = mean(w c), zero stats, no update. */
+int osrl_dice_chi_step(const float* chi2, int32_t n_chi, int32_t rows, const float* w, const float* cost,
+                       const float* done, const float* is_init, float gamma, float init_state_propotion,
+                       float cost_ub_epsilon, float scalar_lr, const osrl_step_state_t* st, float* leaves, float* work,
+                       float* ell_ws, float* dchi, float* stat, void* stream);
+/* coptidice.py:147,188-201: Df, td_error, nu_loss and dnu [n_nu, 2*rows]; lmbda_loss and the Adam step on lmbda;
+ * stat[0..7) = Df, td_error, nu_loss, lmbda_loss, (untouched: actor_loss), tau', lambda'. */
+int osrl_dice_nu_step(const float* nu2, int32_t n_nu, int32_t rows, const float* e, const float* w, const float* done,
+                      const float* is_init, int32_t f_type, float gamma, float alpha, float init_state_propotion,
+                      float qc_thres, float scalar_lr, const osrl_step_state_t* st, float* leaves, const float* work,
+                      float* dnu, float* stat, void* stream);
+/* out = x + eps * std[col] * scale (coptidice.py:204-205; std is [1, dim]) */
+int osrl_dice_perturb(const float* x, const float* eps, const float* std, int32_t rows, int32_t dim, float scale,
+                      float* out, void* stream);
+/* coptidice.py:207-215: actor_loss = -mean(w * sum Normal(mu, exp(clamp(log_std))).log_prob(act)) (pre-tanh Gaussian),
+ * dhead [rows, 2*ad] = its gradient w.r.t. (mu, log_std); stat[0] = actor_loss. */
+int osrl_dice_actor_loss(const float* head, const float* act, const float* w, int32_t rows, int32_t ad, float* dhead,
+                         float* stat, void* stream);
+
 /* ---- dataset ingestion on device (osrl/common/dataset.py) ----
  * The flat DSRL arrays (observations, actions, rewards, costs, terminals, timeouts) are uploaded once; these calls
  * produce, in HBM, what the reference computes in host python loops before training.  `ws` is an int32 workspace of

@@ -13,7 +13,8 @@ reference's loader ignores:
     {"model_state": {...reference layout...},
      "osrl_amd": {"version": 1, "algo": "CPQ", "step": 1234,
                   "optim": {group: {"exp_avg": {param_key: tensor}, "exp_avg_sq": {...}}},
-                  "scalars": {"log_alpha" | "pid_state" | "log_temperature" | "temperature_moments": tensor}}}
+                  "scalars": {"log_alpha" | "pid_state" | "log_temperature" | "temperature_moments" |
+                              "scalar_leaves" (COptiDICE tau / lmbda + moments): tensor}}}
 
 The device noise streams are functions of (seed, step), so a resumed run draws the noise the uninterrupted run
 would have drawn: save -> load -> continue is bit-identical to not stopping (tests/test_gpu_train_step.py).
@@ -25,7 +26,7 @@ from typing import Any, Dict, Optional
 import torch
 
 VERSION = 1
-_SCALARS = ("log_alpha", "pid_state", "log_temperature")
+_SCALARS = ("log_alpha", "pid_state", "log_temperature", "scalar_leaves")
 
 
 def engine_handoff(model, new_engine, old_engine) -> None:

@@ -1,0 +1,174 @@
+"""The COptiDICE train step as a static launch plan on MI355X.
+
+Follows ``COptiDICE.update`` (osrl/algorithms/coptidice.py:135-232): optimal weights w* :122-131 -> (chi, tau)
+upper-bound estimator :149-185 -> nu loss :188-194 -> lambda loss :197-201 -> weighted-likelihood policy
+extraction :204-217.  The nu and chi ensembles read the stacked rows ``[obs; next_obs]`` (2B rows), so one saved
+forward per network serves the s and the s' terms and one backward + dW pass serves both gradients.
+
+Batch-global statistics (the softmax over the batch in the chi loss, every mean) are computed by single-workgroup
+kernels; a data-parallel version would have to all-gather ``ell`` and is not wired: ``dist`` raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib as L
+from ..common.net import actor_head_desc, net_desc_seq
+from .core import DwPlan, MlpRun, StepState, cur_stream, randn_fill
+
+STAT_KEYS = ["loss/chi_loss", "loss/tau_loss", "loss/D_kl", "loss/Df", "loss/td_error", "loss/nu_loss",
+             "loss/lmbda_loss", "loss/actor_loss", "loss/tau", "loss/lmbda"]
+NOISE_KEYS = ["obs_eps", "act_eps"]
+F_TYPES = {"chi2": 0, "softchi": 1, "kl": 2}  # include/osrl_amd.h OSRL_F_*
+
+
+class COptiDICEEngine:
+    def __init__(self, model, batch_size: int, seed: int = 0, dist=None):
+        if dist is not None:
+            raise NotImplementedError("COptiDICE's chi loss takes a softmax over the global batch; the data-parallel "
+                                      "exchange for it is not wired")
+        m = self.model = model
+        B = self.B = int(batch_size)
+        self.seed = seed
+        dev = torch.device(m.device)
+        od, ad = m.state_dim, m.action_dim
+        f = dict(dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
+        self.st = StepState(dev, STAT_KEYS)
+        self.x2 = z(2 * B, od)  # [obs; next_obs]
+        self.obs, self.nobs = self.x2[:B], self.x2[B:]
+        self.act, self.rew, self.cost, self.done, self.init = z(B, ad), z(B), z(B), z(B), z(B)
+        tot = B * od + B * ad
+        self.noise_flat = z((tot + 3) // 4 * 4)
+        self.noise: Dict[str, torch.Tensor] = {"obs_eps": self.noise_flat[:B * od].view(B, od),
+                                               "act_eps": self.noise_flat[B * od:tot].view(B, ad)}
+        self.d_nu = net_desc_seq(list(m.nu_network.q_nets), 1.0)
+        self.d_chi = net_desc_seq(list(m.chi_network.q_nets), 1.0)
+        self.d_actor = actor_head_desc(m.actor)
+        g = m.groups
+        m.repack()
+        nn_, nc = m.num_nu, m.num_chi
+        self.r_nu = MlpRun(self.d_nu, 2 * B, True, dev)
+        self.dnu = z(nn_, 2 * B, 1)
+        self.r_nu.setup_backward(self.dnu)
+        self.p_nu = DwPlan(g["nu_network"], self.r_nu.dw_entries(), 2 * B, dev)
+        self.r_nu_b = MlpRun(self.d_nu, 2 * B, False, dev)  # second evaluation with the updated nu (policy extraction)
+        self.use_chi = m.cost_ub_epsilon != 0
+        if self.use_chi:
+            self.r_chi = MlpRun(self.d_chi, 2 * B, True, dev)
+            self.dchi = z(nc, 2 * B, 1)
+            self.r_chi.setup_backward(self.dchi)
+            self.p_chi = DwPlan(g["chi_network"], self.r_chi.dw_entries(), 2 * B, dev)
+        self.e, self.w, self.w2, self.ell = z(B), z(B), z(B), z(B)
+        self.work = z(4)
+        self.obs_n, self.act_n = z(B, od), z(B, ad)
+        self.r_actor = MlpRun(self.d_actor, B, True, dev)
+        self.dhead = z(1, B, 2 * ad)
+        self.r_actor.setup_backward(self.dhead)
+        self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _adam(self, name: str, plan: DwPlan) -> None:
+        plan.launch()
+        self.model.groups[name].adam_step(self.model._lrs[name], self.st.ptr)
+
+    def body(self, device_noise: bool) -> None:
+        m, st, B, lib = self.model, self.st, self.B, L.load()
+        od, ad = m.state_dim, m.action_dim
+        nn_, nc, ft = m.num_nu, m.num_chi, F_TYPES[m.f_type]
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        s = cur_stream
+        st.tick()
+        if device_noise:
+            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+        leaves = m.scalar_leaves
+
+        nu2 = self.r_nu.forward(self.x2)
+        L.check(lib.osrl_dice_optimal_w(p(nu2), nn_, B, p(self.rew), p(self.cost), p(self.done), p(leaves),
+                                        p(self.work), 0, float(m.alpha), float(m.gamma), ft, p(self.e), p(self.w), s()),
+                "osrl_dice_optimal_w")
+        chi2 = self.r_chi.forward(self.x2) if self.use_chi else None
+        L.check(lib.osrl_dice_chi_step(p(chi2), nc, B, p(self.w), p(self.cost), p(self.done), p(self.init),
+                                       float(m.gamma), float(m.init_state_propotion), float(m.cost_ub_epsilon),
+                                       float(m.scalar_lr), st.ptr, p(leaves), p(self.work), p(self.ell),
+                                       p(self.dchi) if self.use_chi else None, st.stat_ptr("loss/chi_loss"), s()),
+                "osrl_dice_chi_step")
+        if self.use_chi:
+            self.r_chi.backward_dz()
+            self._adam("chi_network", self.p_chi)
+        L.check(lib.osrl_dice_nu_step(p(nu2), nn_, B, p(self.e), p(self.w), p(self.done), p(self.init), ft,
+                                      float(m.gamma), float(m.alpha), float(m.init_state_propotion), float(m.qc_thres),
+                                      float(m.scalar_lr), st.ptr, p(leaves), p(self.work), p(self.dnu),
+                                      st.stat_ptr("loss/Df"), s()), "osrl_dice_nu_step")
+        self.r_nu.backward_dz()
+        self._adam("nu_network", self.p_nu)
+
+        # 2. policy extraction: noisy observations / actions, w* re-evaluated with the updated nu network
+        L.check(lib.osrl_dice_perturb(p(self.obs), p(self.noise["obs_eps"]), p(m.observations_std), B, od, 0.1,
+                                      p(self.obs_n), s()), "osrl_dice_perturb")
+        L.check(lib.osrl_dice_perturb(p(self.act), p(self.noise["act_eps"]), p(m.actions_std), B, ad, 0.1,
+                                      p(self.act_n), s()), "osrl_dice_perturb")
+        head = self.r_actor.forward(self.obs_n)[0]
+        nu2b = self.r_nu_b.forward(self.x2)
+        L.check(lib.osrl_dice_optimal_w(p(nu2b), nn_, B, p(self.rew), p(self.cost), p(self.done), p(leaves),
+                                        p(self.work), 1, float(m.alpha), float(m.gamma), ft, None, p(self.w2), s()),
+                "osrl_dice_optimal_w")
+        L.check(lib.osrl_dice_actor_loss(p(head), p(self.act_n), p(self.w2), B, ad, p(self.dhead),
+                                         st.stat_ptr("loss/actor_loss"), s()), "osrl_dice_actor_loss")
+        self.r_actor.backward_dz()
+        self._adam("actor", self.p_actor)
+
+    def load_batch(self, observations, next_observations, actions, rewards, costs, done, is_init) -> None:
+        for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
+                         (self.rew, rewards), (self.cost, costs), (self.done, done), (self.init, is_init)):
+            dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+
+    def _snapshot(self):
+        m = self.model
+        snap = {"leaves": m.scalar_leaves.clone(), "state": self.st.state.clone(), "host": self.st.host_step,
+                "stats": self.st.stats.clone(), "ring": self.st.ring.clone()}
+        for n, g in m.groups.items():
+            snap[n] = (g.p.clone(), g.m.clone(), g.v.clone())
+        return snap
+
+    def _restore(self, snap) -> None:
+        m = self.model
+        m.scalar_leaves.copy_(snap["leaves"])
+        self.st.state.copy_(snap["state"]); self.st.stats.copy_(snap["stats"]); self.st.ring.copy_(snap["ring"])
+        self.st.host_step = snap["host"]
+        for n, g in m.groups.items():
+            pp, mm, v = snap[n]
+            g.p.copy_(pp); g.m.copy_(mm); g.v.copy_(v)
+        m.repack()
+
+    def capture(self) -> None:
+        snap = self._snapshot()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.body(True)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.body(True)
+        torch.cuda.synchronize()
+        self._restore(snap)
+        self.graph = g
+
+    def step(self, observations, next_observations, actions, rewards, costs, done, is_init, noise=None,
+             use_graph: bool = True) -> None:
+        self.load_batch(observations, next_observations, actions, rewards, costs, done, is_init)
+        if noise is not None:
+            for k in NOISE_KEYS:
+                self.noise[k].copy_(torch.as_tensor(noise[k]).reshape(self.noise[k].shape), non_blocking=True)
+            self.body(False)
+            return
+        if use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body(True)

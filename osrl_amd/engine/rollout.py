@@ -8,7 +8,8 @@ episodes = the policy's fused MLP forward(s) + its head kernel + one environment
 
 Policies (same arithmetic as ``model.act``):
   BC    ``act_limit * tanh(pi(obs))``                                 bc.py:57-64  (multi-task: obs ++ cost_limit, :132-138)
-  CPQ   ``max_action * tanh(mu(obs))`` (deterministic=True)           cpq.py:240-252, net.py:176-205
+  CPQ   ``max_action * tanh(mu(obs))`` (deterministic=True)           cpq.py:240-252, net.py:176-205 (BEAR-L too)
+  DICE  ``tanh(mu(obs))``                                             coptidice.py:244-256
   BCQL  ``actor(obs, vae.decode(obs, z)), z = clamp(N(0,1), +-0.5)``  bcql.py:236-243, net.py:328-339
   CDT   windowed autoregression on the last seq_len steps             cdt.py:436-518 (``CDTBatchedRollout``)
 """
@@ -33,7 +34,7 @@ class BatchedRollout:
 
     def __init__(self, model, venv, kind: str, cost_scale: float = 1.0, extra_obs: Optional[float] = None,
                  seed: int = 0, z: Optional[torch.Tensor] = None, use_graph: bool = True):
-        if kind not in ("bc", "cpq", "bcql"):
+        if kind not in ("bc", "cpq", "dice", "bcql"):
             raise ValueError(kind)
         m = self.model = model
         self.venv, self.kind, self.seed, self.use_graph = venv, kind, int(seed), use_graph
@@ -52,7 +53,7 @@ class BatchedRollout:
             if m.actor.pi[0].in_features != in_dim:
                 raise ValueError(f"policy expects {m.actor.pi[0].in_features} inputs, the environment gives {in_dim}")
             self.r_pi = MlpRun(net_desc_seq([m.actor.pi], float(m.max_action)), E, False, dev)
-        elif kind == "cpq":
+        elif kind in ("cpq", "dice"):
             self.r_pi = MlpRun(actor_head_desc(m.actor), E, False, dev)
         else:
             Lz = m.latent_dim
@@ -69,9 +70,9 @@ class BatchedRollout:
         m, E, ad = self.model, self.venv.E, self.model.action_dim
         if self.kind == "bc":
             act = self.r_pi.forward(self.obs)[0]
-        elif self.kind == "cpq":
+        elif self.kind in ("cpq", "dice"):  # COptiDICE.act does not scale by max_action (coptidice.py:252)
             head = self.r_pi.forward(self.obs)[0]
-            G.gauss_head(head, None, E, ad, float(m.max_action), a=self.a)
+            G.gauss_head(head, None, E, ad, float(m.max_action) if self.kind == "cpq" else 1.0, a=self.a)
             act = self.a
         else:
             if not self.z_fixed:

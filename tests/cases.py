@@ -96,6 +96,14 @@ def make_params(c: Case) -> "OrderedDict[str, np.ndarray]":
         _vae(rs, sd, c.od, c.ad, c.vae_hidden)
         for i in range(c.num_qc):
             _seq(rs, sd, f"cost_critic.q_nets.{i}", [c.od + c.ad] + c.hidden + [1])
+    elif c.algo == "coptidice":  # creation order of coptidice.py:98-111: actor, nu_network, chi_network (no targets)
+        _seq(rs, sd, "actor.net", [c.od] + c.hidden)
+        _named(rs, sd, "actor.mu_layer", c.ad, c.hidden[-1])
+        _named(rs, sd, "actor.log_std_layer", c.ad, c.hidden[-1])
+        for grp, n in (("nu_network", c.num_q), ("chi_network", c.num_qc)):
+            for i in range(n):
+                _seq(rs, sd, f"{grp}.q_nets.{i}", [c.od] + c.hidden + [1])
+        return sd
     elif c.algo == "bearl":  # creation order of bearl.py:97-109: actor, critic, cost_critic, vae
         _seq(rs, sd, "actor.net", [c.od] + c.hidden)
         _named(rs, sd, "actor.mu_layer", c.ad, c.hidden[-1])
@@ -135,6 +143,8 @@ def make_batch(c: Case) -> Dict[str, np.ndarray]:
         done=(rs.uniform(size=c.B) < 0.01).astype(f),
     )
     b["done"][:: max(c.B // 3, 1)] = 1.0
+    if c.algo == "coptidice":  # TransitionDataset(state_init=True) adds the initial-state flag (dataset.py:817-820)
+        b["is_init"] = (rs.uniform(size=c.B) < 0.15).astype(f)
     return b
 
 
@@ -148,6 +158,10 @@ def noise_shapes(c: Case):
     if c.algo == "bcql":
         return [("eps_vae", (B, 2 * ad)), ("z_c", (N * B, 2 * ad)), ("z_cc", (N * B, 2 * ad)),
                 ("z_actor", (B, 2 * ad))]
+    if c.algo == "coptidice":  # oracle/coptidice_oracle.py header
+        # the third draw is the actor's rsample inside forward(deterministic=False) (coptidice.py:207): only the
+        # distribution is used, the sample is discarded -- result-irrelevant but it consumes RNG
+        return [("obs_eps", (B, c.od)), ("act_eps", (B, ad)), ("eps_pi_unused", (B, ad))]
     if c.algo == "bearl":  # oracle/bearl_oracle.py header
         M = int(c.hp.get("M", 10))
         return [("eps_vae", (B, 2 * ad)), ("eps_c", (N * B, ad)), ("eps_cc", (N * B, ad)),
@@ -167,6 +181,11 @@ def hyper(c: Case) -> Dict[str, float]:
     if c.algo == "cpq":
         return dict(actor_lr=1e-4, critic_lr=1e-3, alpha_lr=1e-4, vae_lr=1e-3, gamma=0.99, tau=0.005,
                     beta=0.5, qc_scalar=1.5)
+    if c.algo == "coptidice":  # coptidice_configs.py:31-47
+        d = dict(actor_lr=1e-4, critic_lr=1e-4, scalar_lr=1e-4, gamma=0.99, alpha=0.5, cost_ub_epsilon=0.01,
+                 f_type="softchi", init_state_propotion=0.15)
+        d.update(c.hp)
+        return d
     if c.algo == "bearl":  # bearl_configs.py:31-57
         d = dict(actor_lr=1e-3, critic_lr=1e-3, vae_lr=1e-3, alpha_lr=1e-3, gamma=0.99, tau=0.005, beta=0.5, lmbda=0.75,
                  mmd_sigma=50.0, target_mmd_thresh=0.05, M=10, start=0, kernel="gaussian", PID=(0.1, 0.003, 0.001))
@@ -337,3 +356,23 @@ def make_ingest_dataset(seed: int = 0, n: int = 1500, od: int = 4, ad: int = 2, 
     return dict(observations=rs.randn(n, od).astype(f), next_observations=rs.randn(n, od).astype(f),
                 actions=rs.uniform(-1, 1, (n, ad)).astype(f), rewards=rs.uniform(0, 2, n).astype(f),
                 costs=(rs.uniform(size=n) < 0.25).astype(f), terminals=term, timeouts=tout)
+
+
+def dice_stds(c: Case):
+    """observations_std / actions_std as TransitionDataset.get_dataset_states returns them (dataset.py:827-829)."""
+    rs = np.random.RandomState(5000 + c.seed)
+    return (rs.uniform(0.5, 1.5, (1, c.od)).astype(np.float32), rs.uniform(0.3, 0.8, (1, c.ad)).astype(np.float32))
+
+
+# COptiDICE (SURVEY.md 8f-3).  num_q = num_nu, num_qc = num_chi.  Learning rates above the config's 1e-4 so that ten
+# steps move the scalars and networks by more than the test tolerance.
+COPTIDICE_CASES: Dict[str, Case] = {c.name: c for c in [
+    Case("coptidice_small", "coptidice", od=6, ad=3, B=32, hidden=[32, 32], steps=10, episode_len=200,
+         hp=dict(actor_lr=1e-3, critic_lr=1e-3, scalar_lr=1e-2)),
+    Case("coptidice_chi2", "coptidice", od=5, ad=2, B=24, hidden=[24, 24], num_q=1, num_qc=3, steps=5, episode_len=200,
+         cost_limit=40.0, seed=1, hp=dict(f_type="chi2", alpha=0.8, cost_ub_epsilon=0.0, actor_lr=1e-3, critic_lr=1e-3,
+                                          scalar_lr=1e-2)),
+    Case("coptidice_kl", "coptidice", od=4, ad=2, B=16, hidden=[16, 16], num_q=3, num_qc=1, steps=5, episode_len=100,
+         seed=2, hp=dict(f_type="kl", cost_ub_epsilon=0.05, actor_lr=1e-3, critic_lr=1e-3, scalar_lr=1e-2)),
+    Case("coptidice_wide", "coptidice", od=33, ad=8, B=512, hidden=[256, 256], steps=1, episode_len=300),
+]}

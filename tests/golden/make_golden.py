@@ -25,7 +25,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from cases import (BEARL_CASES, CASES, CDT_CASES, cdt_drop_sites, hyper, make_batch, make_cdt_batch, make_cdt_drop,  # noqa: E402
+from cases import (BEARL_CASES, CASES, CDT_CASES, COPTIDICE_CASES, dice_stds, cdt_drop_sites, hyper, make_batch, make_cdt_batch, make_cdt_drop,  # noqa: E402
                    make_cdt_params, make_noise, make_params, noise_shapes)
 
 REF = os.environ.get("OSRL_REFERENCE", "/root/reference")
@@ -103,6 +103,12 @@ def build(case, torch, algos, Logger):
                       case.N, hp["gamma"], hp["tau"], hp["beta"], case.num_q, case.num_qc,
                       hp["qc_scalar"], case.cost_limit, case.episode_len)
         tr = algos.CPQTrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["alpha_lr"], hp["vae_lr"])
+    elif case.algo == "coptidice":
+        ostd, astd = dice_stds(case)
+        m = algos.COptiDICE(case.od, case.ad, case.max_action, hp["f_type"], hp["init_state_propotion"], ostd, astd,
+                            case.hidden, case.hidden, hp["gamma"], hp["alpha"], hp["cost_ub_epsilon"], case.num_q,
+                            case.num_qc, case.cost_limit, case.episode_len)
+        tr = algos.COptiDICETrainer(m, None, lg, hp["actor_lr"], hp["critic_lr"], hp["scalar_lr"])
     elif case.algo == "bearl":
         m = algos.BEARL(case.od, case.ad, case.max_action, case.hidden, case.hidden, case.vae_hidden, case.N,
                         hp["gamma"], hp["tau"], hp["beta"], hp["lmbda"], hp["mmd_sigma"], hp["target_mmd_thresh"],
@@ -139,6 +145,9 @@ def main(cases=None):
             nq.push_step(case, s)
             if case.algo == "bc":
                 tr.train_one_step(b["observations"], b["actions"])
+            elif case.algo == "coptidice":
+                tr.train_one_step([b[k] for k in ("observations", "next_observations", "actions", "rewards", "costs",
+                                                  "done", "is_init")])
             else:
                 tr.train_one_step(b["observations"], b["next_observations"], b["actions"],
                                   b["rewards"], b["costs"], b["done"])
@@ -156,6 +165,9 @@ def main(cases=None):
                         out[f"p{s + 1}/{k}"] = a.copy()
                 if case.algo in ("cpq", "bearl"):
                     out[f"s{s + 1}/log_alpha"] = np.float64(m.log_alpha.item())
+                if case.algo == "coptidice":
+                    out[f"s{s + 1}/tau"] = np.float64(m.tau.item())
+                    out[f"s{s + 1}/lmbda"] = np.float64(m.lmbda.item())
                 if case.algo in ("bcql", "bearl"):
                     out[f"s{s + 1}/pid_error_old"] = np.float64(float(m.controller.error_old))
                     out[f"s{s + 1}/pid_error_integral"] = np.float64(float(m.controller.error_integral))
@@ -163,12 +175,14 @@ def main(cases=None):
         out["stat_keys"] = np.array(keys)
         out["stats"] = np.array([[r[k] for k in keys] for r in lg.rows], dtype=np.float64)
         # one Adam moment pair per optimizer (first parameter of each)
-        for oname in ("actor_optim", "critic_optim", "cost_critic_optim", "vae_optim"):
+        for oname in ("actor_optim", "critic_optim", "cost_critic_optim", "vae_optim", "nu_optim", "chi_optim"):
             opt = getattr(m, oname, None)
             if opt is None:
                 continue
             p0 = opt.param_groups[0]["params"][0]
             st = opt.state[p0]
+            if "exp_avg" not in st:  # an optimizer that never stepped (COptiDICE's chi with cost_ub_epsilon == 0)
+                continue
             out[f"adam/{oname}/exp_avg"] = st["exp_avg"].numpy().copy()
             out[f"adam/{oname}/exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
             out[f"adam/{oname}/step"] = np.float64(float(st["step"]))
@@ -179,6 +193,8 @@ def main(cases=None):
             elif case.algo in ("cpq", "bearl"):
                 a, _ = m._actor_forward(b["observations"], True, True)
                 out["act"] = a.numpy()
+            elif case.algo == "coptidice":
+                out["act"] = m.actor.forward(b["observations"], True, True)[0].numpy()
             else:
                 z = np.random.RandomState(4000 + case.seed).randn(case.B, 2 * case.ad).astype(np.float32)
                 dec = m.vae.decode(b["observations"], torch.from_numpy(z).clamp(-0.5, 0.5))
@@ -298,8 +314,11 @@ def main_cdt():
 if __name__ == "__main__":
     if "--bearl-only" in sys.argv:
         main(BEARL_CASES)
+    elif "--coptidice-only" in sys.argv:
+        main(COPTIDICE_CASES)
     else:
         if "--cdt-only" not in sys.argv:
             main()
             main(BEARL_CASES)
+            main(COPTIDICE_CASES)
         main_cdt()

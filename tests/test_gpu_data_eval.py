@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from cases import CASES, CDT_CASES, make_cdt_params
+from cases import BEARL_CASES, CASES, CDT_CASES, COPTIDICE_CASES, make_cdt_params
 from gpu_util import build_gpu
 from oracle.osrl_oracle import prepare_sequence_sample, rollout
 from oracle_util import build_oracle
@@ -152,14 +152,14 @@ def _oracle_episode(policy, env, seed, episode_len, cost_scale=1.0):
     return ret, cost, n
 
 
-@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_small"])
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_small", "bearl_lap", "coptidice_small"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_batched_evaluate_matches_oracle_rollouts(name, use_graph):
     """trainer.evaluate(E) on a VecSyntheticSafeEnv == the oracle policy rolled out episode by episode on the
     scalar environment from the same E initial states."""
     from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
     from osrl_amd.engine.rollout import BatchedRollout
-    c = CASES[name]
+    c = {**CASES, **BEARL_CASES, **COPTIDICE_CASES}[name]
     m, tr, lg = build_gpu(c, use_graph=use_graph)
     o = build_oracle(c)
     E, EL = 24, 30

@@ -5,16 +5,18 @@ import numpy as np
 import pytest
 import torch
 
-from cases import BEARL_CASES, CASES, make_batch
+from cases import BEARL_CASES, CASES, COPTIDICE_CASES, make_batch
+
+ALL_CASES = {**CASES, **BEARL_CASES, **COPTIDICE_CASES}
 from gpu_util import build_gpu, gpu_batch, gpu_step
 from oracle_util import build_oracle, load_golden, oracle_step
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", list(CASES) + list(BEARL_CASES))
+@pytest.mark.parametrize("name", list(ALL_CASES))
 def test_train_step_matches_golden_and_oracle(name):
-    c = CASES[name] if name in CASES else BEARL_CASES[name]
+    c = ALL_CASES[name]
     g = load_golden(name)
     keys = [str(k) for k in g["stat_keys"]]
     m, tr, lg = build_gpu(c)
@@ -34,6 +36,9 @@ def test_train_step_matches_golden_and_oracle(name):
                 assert d <= tol * max(1.0, abs(r)), f"{name} step {s} {k}: gpu {got} vs {nm} {r} (diff {d:.3e})"
         if f"s{s + 1}/log_alpha" in g:
             assert abs(m.log_alpha.item() - float(g[f"s{s + 1}/log_alpha"])) < 1e-6
+        if f"s{s + 1}/tau" in g:
+            assert abs(m.tau.item() - float(g[f"s{s + 1}/tau"])) < 1e-5
+            assert abs(m.lmbda.item() - float(g[f"s{s + 1}/lmbda"])) < 1e-5
         if f"s{s + 1}/pid_error_old" in g:
             assert abs(m.controller.error_old - float(g[f"s{s + 1}/pid_error_old"])) < 1e-5
             assert abs(m.controller.error_integral - float(g[f"s{s + 1}/pid_error_integral"])) < 1e-5
@@ -58,6 +63,8 @@ def test_train_step_matches_golden_and_oracle(name):
         elif c.algo in ("cpq", "bearl"):
             from osrl_amd import ops
             a = ops.cpq_act(m, b["observations"], True)[0].cpu().numpy()
+        elif c.algo == "coptidice":
+            a = m.actor(b["observations"], True, True)[0].cpu().numpy()
         else:
             z = torch.from_numpy(g["act_z"]).to(b["observations"].device).clamp(-0.5, 0.5)
             a = m.actor(b["observations"], m.vae.decode(b["observations"], z)).cpu().numpy()
@@ -158,12 +165,12 @@ def test_graph_replay_is_deterministic_and_trains(name):
 
 
 @pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full", "bearl_small",
-                                  "bearl_wide"])
+                                  "bearl_wide", "coptidice_small", "coptidice_wide"])
 def test_graph_with_parallel_branches_equals_eager_sequential(name):
     """The captured graph (forked side-stream branches, device Philox noise) must produce exactly the same
     parameters as the plain in-order launch sequence: same kernels, same inputs, no atomics."""
-    if name in CASES or name in BEARL_CASES:
-        c = CASES[name] if name in CASES else BEARL_CASES[name]
+    if name in ALL_CASES:
+        c = ALL_CASES[name]
     else:  # bench-size CPQ: capped N*B launch beside the VAE phase, paired launches
         from cases import Case
         c = Case(name, episode_len=1000, **FULL_CASES[name])
@@ -289,20 +296,20 @@ def _train_state(m):
     out = {k: v.detach().clone() for k, v in m.state_dict().items()}
     for name, g in m.groups.items():
         out["m/" + name], out["v/" + name] = g.m.clone(), g.v.clone()
-    for k in ("log_alpha", "pid_state"):
+    for k in ("log_alpha", "pid_state", "scalar_leaves"):
         if isinstance(getattr(m, k, None), torch.Tensor):
             out[k] = getattr(m, k).clone()
     return out
 
 
-@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_pid", "bearl_lap"])
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_pid", "bearl_lap", "coptidice_small"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_checkpoint_resume_is_bit_identical(name, use_graph, tmp_path):
     """3 steps -> save -> load into a fresh model -> 2 steps  ==  5 uninterrupted steps, bit for bit (parameters,
     targets, Adam moments, log_alpha / PID state); the noise is the device Philox stream, keyed by the step count
     the checkpoint carries.  The file keeps the reference's {"model_state": ...} layout."""
     from osrl_amd.common.checkpoint import load_checkpoint, save_checkpoint
-    c = CASES[name] if name in CASES else BEARL_CASES[name]
+    c = ALL_CASES[name]
     b = gpu_batch(c)
     m_a, tr_a, _ = build_gpu(c, use_graph=use_graph)
     for s in range(5):

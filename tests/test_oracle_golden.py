@@ -6,14 +6,16 @@ parameters <= 1e-4 (observed ~1e-6)."""
 import numpy as np
 import pytest
 
-from cases import BEARL_CASES, CASES, make_batch
+from cases import BEARL_CASES, CASES, COPTIDICE_CASES, make_batch
+
+ALL_CASES = {**CASES, **BEARL_CASES, **COPTIDICE_CASES}
 from oracle_util import build_oracle, load_golden, oracle_step
 
 
-@pytest.mark.parametrize("name", list(CASES) + list(BEARL_CASES))
+@pytest.mark.parametrize("name", list(ALL_CASES))
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_oracle_matches_reference(name, dtype):
-    c = CASES[name] if name in CASES else BEARL_CASES[name]
+    c = ALL_CASES[name]
     g = load_golden(name)
     keys = [str(k) for k in g["stat_keys"]]
     o = build_oracle(c, dtype)
@@ -25,6 +27,8 @@ def test_oracle_matches_reference(name, dtype):
             assert abs(st[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (name, s, k, st[k], ref[k])
         if f"s{s + 1}/log_alpha" in g:
             assert abs(o.log_alpha - float(g[f"s{s + 1}/log_alpha"])) < 1e-6
+        if f"s{s + 1}/tau" in g:
+            assert abs(o.tau - float(g[f"s{s + 1}/tau"])) < 1e-5 and abs(o.lmbda - float(g[f"s{s + 1}/lmbda"])) < 1e-5
         if f"s{s + 1}/pid_error_old" in g:
             assert abs(o.controller.error_old - float(g[f"s{s + 1}/pid_error_old"])) < 1e-5
             assert abs(o.controller.error_integral - float(g[f"s{s + 1}/pid_error_integral"])) < 1e-5
@@ -38,6 +42,7 @@ def test_oracle_matches_reference(name, dtype):
     for oname, opt in (("actor_optim", getattr(o, "opt_actor", getattr(o, "opt", None))),
                        ("critic_optim", getattr(o, "opt_critic", None)),
                        ("cost_critic_optim", getattr(o, "opt_cost", None)),
+                       ("nu_optim", getattr(o, "opt_nu", None)), ("chi_optim", getattr(o, "opt_chi", None)),
                        ("vae_optim", getattr(o, "opt_vae", None))):
         if opt is None or f"adam/{oname}/exp_avg" not in g:
             continue

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from osrl_amd.algorithms import (BC, BCQL, BEARL, CDT, CPQ, BCQLTrainer, BCTrainer, BEARLTrainer, CDTTrainer,  # noqa: E402
-                                 CPQTrainer)
+                                 COptiDICE, COptiDICETrainer, CPQTrainer)
 
 DEV = "cuda:0"
 
@@ -58,6 +58,13 @@ def main():
     for B in (512, 4096):
         argsb = tuple(t[:B].contiguous() for t in args3)
         run(f"BEAR-L  (33,8)  B={B:<4d}", lambda: tr.train_one_step(*argsb), 100, 10)
+    # COptiDICE at its train-config defaults (coptidice_configs.py: B=512, hidden 256, 2 nu + 2 chi nets, softchi)
+    m = COptiDICE(33, 8, 1.0, "softchi", 0.01, np.ones((1, 33), np.float32), np.ones((1, 8), np.float32), [256, 256],
+                  [256, 256], 0.99, 0.5, 0.01, 2, 2, 10, 300, device=DEV)
+    tr = COptiDICETrainer(m, None, None, 1e-4, 1e-4, 1e-4, stats_mode="none")
+    B = 512
+    batch = [t[:B].contiguous() for t in args3] + [(torch.rand(B, device=DEV) < 0.01).float()]
+    run("COptiDICE (33,8) B=512", lambda: tr.train_one_step(batch), 300, 20)
     # C5 CDT (11,3) T=20 E=256 8 heads 3 layers B=1024, dropout 0.1 (cdt_configs.py:28-30; pass a 3rd argv to override)
     B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 20
     pdrop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
