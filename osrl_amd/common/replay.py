@@ -25,38 +25,64 @@ FIELDS = ("observations", "next_observations", "actions", "rewards", "costs", "d
 
 class ReplayStore:
     def __init__(self, data: Dict[str, "np.ndarray | torch.Tensor"], device, reward_scale: float = 1.0,
-                 cost_scale: float = 1.0, seed: int = 0, rank: int = 0, world: int = 1):
+                 cost_scale: float = 1.0, seed: int = 0, rank: int = 0, world: int = 1, state_init: bool = False):
         """``data`` uses the DSRL dataset keys (observations, next_observations, actions, rewards, costs,
-        and either ``done`` or ``terminals``+``timeouts``)."""
+        and either ``done`` or ``terminals``+``timeouts``).  ``state_init`` (TransitionDataset(state_init=True),
+        dataset.py:817-820, used by COptiDICE): a 7th table ``is_init`` = ``done`` shifted by one transition with
+        ``is_init[0] = 1``, computed on the FULL dataset before any sharding."""
         d = dict(data)
+        self.state_init = bool(state_init)
         if "done" not in d:
             if torch.is_tensor(d["terminals"]):  # device tables of common.ingest.process_bc_dataset
                 d["done"] = torch.logical_or(d["terminals"] == 1, d["timeouts"] == 1)
             else:
                 d["done"] = np.logical_or(np.asarray(d["terminals"]) == 1, np.asarray(d["timeouts"]) == 1)
         n = len(d["observations"])
+        fields = FIELDS
+        if self.state_init:
+            dn = d["done"]
+            dn = dn.detach().cpu().numpy() if torch.is_tensor(dn) else np.asarray(dn)
+            init = np.asarray(dn, np.float32).reshape(-1).copy()
+            init[1:] = init[:-1]
+            init[0] = 1.0
+            d["is_init"] = init
+            fields = FIELDS + ("is_init",)
+            # TransitionDataset.get_dataset_states (dataset.py:822-830): what COptiDICE's constructor is fed
+            as_np = lambda x: x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)  # noqa: E731
+            self.init_state_propotion = float(init.mean())
+            self.observations_std = as_np(d["observations"]).std(0, keepdims=True)
+            self.actions_std = as_np(d["actions"]).std(0, keepdims=True)
         sl = slice(rank, n, world) if world > 1 else slice(None)
         self.tables = []
-        for k in FIELDS:
+        for k in fields:
             t = torch.as_tensor(np.asarray(d[k])[sl] if not torch.is_tensor(d[k]) else d[k][sl])
             t = t.to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous()
             self.tables.append(t)
         self.n_rows = self.tables[0].shape[0]
         self.widths = [t.shape[1] for t in self.tables]
-        self.scales = [1.0, 1.0, 1.0, float(reward_scale), float(cost_scale), 1.0]
+        self.scales = [1.0, 1.0, 1.0, float(reward_scale), float(cost_scale), 1.0] + ([1.0] if self.state_init else [])
         self.seed = int(seed) * 1000003 + rank
         self.device = torch.device(device)
-        self._src = (C.c_void_p * 6)(*[t.data_ptr() for t in self.tables])
-        self._w = (C.c_int32 * 6)(*self.widths)
-        self._s = (C.c_float * 6)(*self.scales)
+        nf = self.n_fields = len(self.tables)
+        self._src = (C.c_void_p * nf)(*[t.data_ptr() for t in self.tables])
+        self._w = (C.c_int32 * nf)(*self.widths)
+        self._s = (C.c_float * nf)(*self.scales)
         self.bytes_per_row = 4 * sum(self.widths)
+
+    def get_dataset_states(self):
+        """(init_state_propotion, observations_std, actions_std) -- dataset.py:822-830; needs ``state_init``."""
+        if not self.state_init:
+            raise RuntimeError("build the store with state_init=True")
+        return self.init_state_propotion, self.observations_std, self.actions_std
 
     def gather(self, dst: Sequence[torch.Tensor], st_ptr: Optional[int], idx_out: Optional[torch.Tensor] = None,
                stream_id: int = 1) -> None:
-        """dst = (obs, next_obs, act, rew, cost, done) batch buffers; asynchronous on the current stream."""
+        """dst = (obs, next_obs, act, rew, cost, done[, is_init]) batch buffers; asynchronous on the current stream."""
         B = dst[0].shape[0]
-        d = (C.c_void_p * 6)(*[t.data_ptr() for t in dst])
-        L.check(L.load().osrl_replay_gather(6, self._src, d, self._w, self._s, self.n_rows, B,
+        if len(dst) != self.n_fields:
+            raise ValueError(f"the store holds {self.n_fields} tables, {len(dst)} destination buffers were given")
+        d = (C.c_void_p * self.n_fields)(*[t.data_ptr() for t in dst])
+        L.check(L.load().osrl_replay_gather(self.n_fields, self._src, d, self._w, self._s, self.n_rows, B,
                                             None if idx_out is None else idx_out.data_ptr(), self.seed, stream_id,
                                             st_ptr, cur_stream()), "osrl_replay_gather")
 

@@ -69,6 +69,7 @@ class COptiDICEEngine:
         self.r_actor.setup_backward(self.dhead)
         self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.replay = None
 
     def _adam(self, name: str, plan: DwPlan) -> None:
         plan.launch()
@@ -81,6 +82,8 @@ class COptiDICEEngine:
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         s = cur_stream
         st.tick()
+        if self.replay is not None:  # TransitionDataset(state_init=True) + DataLoader + H2D, folded into the step
+            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done, self.init), st.ptr)
         if device_noise:
             randn_fill(self.noise_flat, self.seed, 0, st.ptr)
         leaves = m.scalar_leaves
@@ -157,8 +160,27 @@ class COptiDICEEngine:
         self._restore(snap)
         self.graph = g
 
+    def attach_replay(self, store) -> None:
+        """Sample minibatches on device from ``store`` (a ``ReplayStore(..., state_init=True)``) inside the step."""
+        if store is not None and not store.state_init:
+            raise ValueError("COptiDICE needs the is_init flag: build the ReplayStore with state_init=True")
+        self.replay = store
+        self.graph = None
+
+    def step_replay(self, use_graph: bool = True) -> None:
+        assert self.replay is not None
+        if use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body(True)
+
     def step(self, observations, next_observations, actions, rewards, costs, done, is_init, noise=None,
              use_graph: bool = True) -> None:
+        if self.replay is not None:
+            raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done, is_init)
         if noise is not None:
             for k in NOISE_KEYS:

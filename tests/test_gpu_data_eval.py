@@ -365,3 +365,51 @@ def test_cdt_batched_evaluate_matches_oracle_rollouts(use_graph):
         assert lens[e] == EL and abs(rets[e] - r0) < 1e-3 * max(1, abs(r0)) and abs(costs[e] - c0) <= 1.0, \
             (e, rets[e], r0, costs[e], c0)
     assert np.unique(np.round(rets, 3)).size == E
+
+
+def test_replay_store_state_init_and_coptidice_step_replay():
+    """ReplayStore(state_init=True) == TransitionDataset(state_init=True) (dataset.py:817-830): is_init = done
+    shifted by one with is_init[0] = 1, get_dataset_states(); COptiDICE draws its 7-field minibatch on device."""
+    from osrl_amd.algorithms import COptiDICE, COptiDICETrainer
+    from osrl_amd.common.logger import DummyLogger
+    from osrl_amd.common.replay import ReplayStore, synthetic_transitions
+    from osrl_amd.engine.core import StepState
+    data = synthetic_transitions(4000, 6, 2, seed=3)
+    data["timeouts"][::97] = 1
+    store = ReplayStore(data, DEV, reward_scale=0.1, state_init=True, seed=5)
+    done = np.logical_or(data["terminals"] == 1, data["timeouts"] == 1).astype(np.float32)
+    init = done.copy()
+    init[1:] = init[:-1]
+    init[0] = 1.0
+    p0, ostd, astd = store.get_dataset_states()
+    assert abs(p0 - init.mean()) < 1e-7 and ostd.shape == (1, 6) and astd.shape == (1, 2)
+    np.testing.assert_allclose(ostd, data["observations"].std(0, keepdims=True), rtol=1e-6)
+    B = 512
+    st = StepState(DEV, ["x"])
+    st.tick()
+    z = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    outs = (z(B, 6), z(B, 6), z(B, 2), z(B), z(B), z(B), z(B))
+    idx = torch.zeros(B, dtype=torch.int32, device=DEV)
+    store.gather(outs, st.ptr, idx_out=idx)
+    ii = idx.cpu().numpy()
+    np.testing.assert_array_equal(outs[6].cpu().numpy(), init[ii])
+    np.testing.assert_array_equal(outs[5].cpu().numpy(), done[ii])
+    np.testing.assert_allclose(outs[3].cpu().numpy(), data["rewards"][ii] * 0.1, rtol=1e-6)
+    with pytest.raises(ValueError):
+        store.gather(outs[:6], st.ptr)
+
+    torch.manual_seed(0)
+    m = COptiDICE(6, 2, 1.0, "softchi", p0, ostd, astd, [32, 32], [32, 32], num_nu=2, num_chi=2, device=DEV)
+    tr = COptiDICETrainer(m, None, DummyLogger(), 1e-3, 1e-3, 1e-2, device=DEV)
+    eng = m.engine(B)
+    with pytest.raises(ValueError):
+        eng.attach_replay(ReplayStore(data, DEV))
+    eng.attach_replay(store)
+    p_before = m.groups["nu_network"].p.clone()
+    for _ in range(5):
+        eng.step_replay()
+    torch.cuda.synchronize()
+    stats = eng.st.read_stats()
+    assert eng.graph is not None and eng.st.device_step() == 5
+    assert all(np.isfinite(v) for v in stats.values()) and not torch.equal(p_before, m.groups["nu_network"].p)
+    assert abs(m.tau.item() - 1.0) > 1e-3 and abs(m.lmbda.item() - 1.0) > 1e-3

@@ -256,13 +256,14 @@ def test_data_parallel_graph_capture_world1():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["bcql_pid", "bc_small"])
+@pytest.mark.parametrize("name", ["bcql_pid", "bc_small", "bearl_lap"])
 def test_data_parallel_world1_other_algos(name):
-    """BCQ-Lag (global PID mean pre-pass) and BC under the DP hook as a 1-rank NCCL job == single GPU."""
+    """BCQ-Lag / BEAR-Lag (global-mean pre-pass for the PID controller and the dual step) and BC under the DP hook as
+    a 1-rank NCCL job == single GPU."""
     import os
     import torch.distributed as dist
     from osrl_amd.engine.dist import DataParallel
-    c = CASES[name]
+    c = ALL_CASES[name]
     created = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
