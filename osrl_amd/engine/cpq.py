@@ -134,8 +134,8 @@ class CPQEngine:
     def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
         """One step.  ``par`` (graph capture only) forks the independent parts onto side streams:
         critic phase (cpq.py:137-153) and the cost-critic target pre-work (cpq.py:159-176) do not depend
-        on the VAE update, so they run beside the VAE phase; everything joins before the cost-critic
-        optimizer step (which Polyak-updates targets the critic branch reads)."""
+        on the VAE update, so they run beside the VAE phase; the cost-critic update waits for the side branch's
+        forwards (the readers of the targets it Polyak-updates), the actor phase for the whole branch."""
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
@@ -177,6 +177,7 @@ class CPQEngine:
             qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
                                                                (self.obs, self.act))
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
+            ev_fwd = par.mark(0)  # every forward of the side branch (all readers of cost_critic_old) is enqueued
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
@@ -193,9 +194,14 @@ class CPQEngine:
             self.dist.quantile(self.kl, 0.75, self.quant)
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
-        par.join(0)  # side branch done (it also reads cost_critic_old, which the next optimizer step updates)
         if self.dist is not None:
+            par.join(0)
             self._update("critic", m.tau)
+        else:
+            # the cost-critic update needs the side branch's FORWARDS only (its products, and they are the last
+            # readers of cost_critic_old, which this phase's optimizer step Polyak-updates): it runs beside the
+            # critic's loss / backward / dW / Adam chain instead of after it; the join moves to the actor phase
+            par.wait(ev_fwd)
         if self.dist is None and rg in (0, B):  # no batch-global reduction in between: one launch
             G.cpq_cost_loss_ood(qc_s, nqc, self.kl, self.quant, N, qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost,
                                 B, m.gamma, m.qc_thres, m.alpha_lr, m.log_alpha, self.dqc,
@@ -211,7 +217,9 @@ class CPQEngine:
         self.r_cost.backward_dz()
         self._optim("cost_critic", self.p_cost, m.tau)
 
-        # ---- actor_loss  (cpq.py:203-222)
+        # ---- actor_loss  (cpq.py:203-222): needs the updated critic (side branch) and cost critic
+        if self.dist is None:
+            par.join(0)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
         G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
         self.r_pi_q.backward_dz()
