@@ -413,3 +413,76 @@ def test_replay_store_state_init_and_coptidice_step_replay():
     assert eng.graph is not None and eng.st.device_step() == 5
     assert all(np.isfinite(v) for v in stats.values()) and not torch.equal(p_before, m.groups["nu_network"].p)
     assert abs(m.tau.item() - 1.0) > 1e-3 and abs(m.lmbda.item() - 1.0) > 1e-3
+
+
+# --------------------------------------------------------------------------- #
+# the metric's "cost-return gap vs ref" (SURVEY.md 8c-iii): fixture = the REFERENCE trainers' rollout() loops driving
+# the synthetic env with the reference models' act() (tests/golden/make_golden_eval.py)
+# --------------------------------------------------------------------------- #
+EVAL = dict(episodes=12, episode_len=25, env_seed=1, init_noise=0.7, base_seed=100, cost_scale=2.0)
+
+
+def _check_gap(name, rets, costs, lens, ref):
+    ret_gap = np.abs(rets - ref[:, 0]) / np.maximum(1.0, np.abs(ref[:, 0]))
+    assert np.array_equal(lens, ref[:, 2]), name
+    assert ret_gap.max() <= 1e-3, (name, ret_gap.max())
+    # the cost is an indicator at a threshold: allow one flipped step in at most one episode
+    flips = np.abs(costs - ref[:, 1])
+    assert (flips > 0).sum() <= 1 and flips.max() <= EVAL["cost_scale"], (name, costs, ref[:, 1])
+    print(f"{name}: mean return {rets.mean():.4f} vs ref {ref[:, 0].mean():.4f}; mean cost {costs.mean():.3f} vs "
+          f"{ref[:, 1].mean():.3f}")
+
+
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_small", "bearl_lap", "coptidice_small"])
+def test_evaluate_cost_return_gap_vs_reference(name):
+    from oracle_util import load_golden
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    from osrl_amd.engine.rollout import BatchedRollout
+    g = load_golden("eval_rollouts")
+    c = {**CASES, **BEARL_CASES, **COPTIDICE_CASES}[name]
+    m, tr, lg = build_gpu(c, use_graph=True)
+    E, EL = EVAL["episodes"], EVAL["episode_len"]
+    m.episode_len = EL
+    cs = EVAL["cost_scale"] if c.algo != "bc" else 1.0
+    tr.cost_scale = cs
+    env = SyntheticSafeEnv(c.od, c.ad, 50, seed=EVAL["env_seed"], init_noise=EVAL["init_noise"])
+    venv = VecSyntheticSafeEnv(env, E, DEV, base_seed=EVAL["base_seed"])
+    tr.env = venv
+    if c.algo == "bcql":
+        ro = BatchedRollout(m, venv, "bcql", cs, z=torch.tensor(g[name + "_z"], device=DEV))
+        rets, costs, lens = ro.run()
+    else:
+        tr.evaluate(E)
+        rets, costs, lens = tr._rollout[1].run()
+    _check_gap(name, rets, costs, lens, g[name])
+
+
+def test_cdt_evaluate_cost_return_gap_vs_reference():
+    from oracle_util import load_golden
+    from osrl_amd.algorithms import CDT, CDTTrainer
+    from osrl_amd.common.logger import DummyLogger
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    g = load_golden("eval_rollouts")
+    c = CDT_CASES["cdt_small"]
+    E, EL = EVAL["episodes"], EVAL["episode_len"]
+    m = CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=EL, embedding_dim=c.E, num_layers=c.layers, num_heads=c.heads,
+            use_rew=True, use_cost=True, cost_transform=c.cost_transform, stochastic=c.stochastic, init_temperature=0.1,
+            target_entropy=-c.ad, device=DEV)
+    sd = make_cdt_params(c)
+    te, need = sd["timestep_emb.weight"], EL + c.T
+    sd["timestep_emb.weight"] = np.concatenate([te] * (need // te.shape[0] + 1))[:need]  # as make_golden_eval.py
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    tr = CDTTrainer(m, None, DummyLogger(), reward_scale=0.1, cost_scale=EVAL["cost_scale"], device=DEV)
+    env = SyntheticSafeEnv(c.od, c.ad, 50, seed=EVAL["env_seed"], init_noise=EVAL["init_noise"])
+    tr.env = VecSyntheticSafeEnv(env, E, DEV, base_seed=EVAL["base_seed"])
+    ret, cost, ln = tr.evaluate(E, target_return=30.0, target_cost=5.0)
+    rets, costs, lens = tr._rollout[1].run(30.0, 5.0)
+    ref = g["cdt_small"]
+    # CDTTrainer.rollout accumulates the RAW cost (cdt.py:513) while the windows carry cost * cost_scale
+    saved = EVAL["cost_scale"]
+    EVAL["cost_scale"] = 1.0
+    try:
+        _check_gap("cdt_small", rets, costs, lens, ref)
+    finally:
+        EVAL["cost_scale"] = saved
+    assert abs(ret - ref[:, 0].mean() / 0.1) <= 1e-3 * abs(ref[:, 0].mean() / 0.1)
