@@ -42,6 +42,8 @@ class BCEngine:
         if self.dist is not None:
             self.dist.allreduce_group(grp)
         grp.adam_step(m._lrs["actor"], self.st.ptr)
+        if self.dist is not None:  # per-rank partial of the globally normalised loss -> the global value
+            self.dist.all_reduce_(self.st.stats)
 
     def step(self, observations, actions, use_graph: bool = True) -> None:
         self.obs.copy_(torch.as_tensor(observations).reshape(self.obs.shape), non_blocking=True)
