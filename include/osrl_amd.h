@@ -231,6 +231,13 @@ int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* 
                        const float* ood_mean, const float* cost, int32_t rows, float gamma, float qc_thres,
                        float alpha_lr, int32_t rows_global, float stat_share, float* log_alpha, float* dq,
                        float* stat, void* stream);
+/* ood_mean == NULL in osrl_cpq_cost_loss defers the dual step: stat[0] = the MSE part only and log_alpha is left
+ * alone (the gradient dq never depends on ood_mean, cpq.py:186-199 -- qc_ood is under no_grad and log_alpha has no
+ * grad); osrl_cpq_alpha_step then applies it once the GLOBAL ood_mean is known: stat[0] -= share*exp(la)*(ood-thres),
+ * log_alpha += alpha_lr*exp(la)*(thres - ood), clamp +-5, stat[1] = share*exp(log_alpha).  Data parallelism uses
+ * this to fold the ood_mean reduction into the gradient all-reduce of the phase. */
+int osrl_cpq_alpha_step(const float* ood_mean, float qc_thres, float alpha_lr, float stat_share, float* log_alpha,
+                        float* stat, void* stream);
 /* Single-GPU fusion of osrl_cpq_ood_mean + osrl_cpq_cost_loss (cpq.py:184-199): the OOD mean is computed inside
  * the loss launch (and written to ood_mean_out); no batch-global reduction can sit between the two. */
 int osrl_cpq_cost_loss_ood(const float* qc_sampled, int32_t n_qc_sampled, const float* kl, const float* quantile,

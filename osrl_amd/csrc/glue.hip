@@ -402,7 +402,9 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
     }
   }
   loss = block_sum(loss, sm);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !oa.qc_sampled && !ood_mean_p) {  // dual step deferred (osrl_cpq_alpha_step)
+    if (stat) stat[0] = loss * inv_rows;
+  } else if (threadIdx.x == 0) {
     const float ood_mean = oa.qc_sampled ? ood_here : ood_mean_p[0];
     if (oa.qc_sampled) ood_mean_p[0] = ood_here;
     float la = log_alpha[0];
@@ -415,6 +417,19 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
     log_alpha[0] = la;
     if (stat) stat[1] = stat_share * expf(la);
   }
+}
+
+// the dual step of cpq.py:186-195 on its own: stat[0] (the MSE part written by cpq_cost_loss_kernel) gets the
+// -exp(log_alpha)*(ood_mean - thres) term, log_alpha ascends and is clamped, stat[1] = exp(log_alpha)
+__global__ void cpq_alpha_step_kernel(const float* __restrict__ ood_mean, float qc_thres, float alpha_lr,
+                                      float stat_share, float* __restrict__ log_alpha, float* __restrict__ stat) {
+  float la = log_alpha[0];
+  const float ea = expf(la);
+  if (stat) stat[0] -= stat_share * ea * (ood_mean[0] - qc_thres);
+  la += alpha_lr * ea * (qc_thres - ood_mean[0]);
+  la = fminf(fmaxf(la, -5.0f), 5.0f);
+  log_alpha[0] = la;
+  if (stat) stat[1] = stat_share * expf(la);
 }
 
 __global__ __launch_bounds__(kRed) void cpq_actor_loss_kernel(const float* __restrict__ q, int n_q,
@@ -693,12 +708,21 @@ int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* 
                        const float* ood_mean, const float* cost, int32_t rows, float gamma, float qc_thres,
                        float alpha_lr, int32_t rows_global, float stat_share, float* log_alpha, float* dq,
                        float* stat, void* stream) {
-  if (!qc_old_next || !qc || !ood_mean || !cost || !log_alpha || !dq || rows < 1) return -1;
+  if (!qc_old_next || !qc || !cost || (ood_mean && !log_alpha) || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
                      const_cast<float*>(ood_mean), cost, rows, gamma, qc_thres, alpha_lr,
                      1.0f / (float)(rows_global > 0 ? rows_global : rows), stat_share, log_alpha, dq, stat,
                      OodArgs{nullptr, nullptr, nullptr, 0, 0});
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_alpha_step(const float* ood_mean, float qc_thres, float alpha_lr, float stat_share, float* log_alpha,
+                        float* stat, void* stream) {
+  if (!ood_mean || !log_alpha) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(cpq_alpha_step_kernel, dim3(1), dim3(1), 0, S, ood_mean, qc_thres, alpha_lr, stat_share,
+                     log_alpha, stat);
   LAUNCH_CHECK();
 }
 

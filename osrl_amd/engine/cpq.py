@@ -195,8 +195,7 @@ class CPQEngine:
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
         if self.dist is not None:
-            par.join(0)
-            self._update("critic", m.tau)
+            par.join(0)  # collectives stay on the capture stream; the critic group is reduced with the cost group
         else:
             # the cost-critic update needs the side branch's FORWARDS only (its products, and they are the last
             # readers of cost_critic_old, which this phase's optimizer step Polyak-updates): it runs beside the
@@ -206,16 +205,27 @@ class CPQEngine:
             G.cpq_cost_loss_ood(qc_s, nqc, self.kl, self.quant, N, qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost,
                                 B, m.gamma, m.qc_thres, m.alpha_lr, m.log_alpha, self.dqc,
                                 st.stat_ptr("loss/cost_critic_loss"))
-        else:
+        elif self.dist is None:
             G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
-            share = 1.0
-            if self.dist is not None:
-                self.dist.all_reduce_(self.ood_mean)
-                share = 1.0 / self.dist.world
             G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr,
-                            rg, share, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+                            rg, 1.0, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+        else:
+            # data parallel: the gradient does not depend on the global qc_ood mean (it only drives the dual step
+            # and the logged loss), so its reduction rides in the same collective as the two critics' gradients
+            G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0,
+                            None, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
-        self._optim("cost_critic", self.p_cost, m.tau)
+        if self.dist is None:
+            self._optim("cost_critic", self.p_cost, m.tau)
+        else:
+            self.p_cost.launch()
+            gc, gcc = m.groups["critic"], m.groups["cost_critic"]
+            self.dist.all_reduce_many_([self.dist.reduce_local(gc), self.dist.reduce_local(gcc), self.ood_mean])
+            gc.adam_step(m._lrs["critic"], st.ptr, tau=m.tau)
+            gcc.adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau)
+            G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0 / self.dist.world, m.log_alpha,
+                             st.stat_ptr("loss/cost_critic_loss"))
 
         # ---- actor_loss  (cpq.py:203-222): needs the updated critic (side branch) and cost critic
         if self.dist is None:
@@ -226,9 +236,13 @@ class CPQEngine:
         G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
                          self.dhead_actor)
         self.r_actor_obs.backward_dz()
-        self._optim("actor", self.p_actor, m.tau)
-        if self.dist is not None:  # per-rank partial statistics -> global values
-            self.dist.all_reduce_(st.stats)
+        if self.dist is None:
+            self._optim("actor", self.p_actor, m.tau)
+        else:  # actor gradient and the per-rank partial statistics in one collective
+            self.p_actor.launch()
+            ga = m.groups["actor"]
+            self.dist.all_reduce_many_([self.dist.reduce_local(ga), st.stats])
+            ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
 
     # ------------------------------------------------------------------ #
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:

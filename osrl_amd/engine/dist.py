@@ -8,8 +8,11 @@ GLOBAL batch, and exchanges exactly what a single device would have reduced over
   * per optimizer phase: the flat gradient of that group -- ONE all-reduce(SUM) of 0.3-1.6 MB right
     before the group's fused Adam kernel (message-latency bound on xGMI, so one bucket per phase);
   * CPQ: the N*B KL values for the batch-global 0.75-quantile (all-gather, 80 KB/rank) and the scalar
-    mean of qc_ood that drives the log_alpha ascent (all-reduce of 1 float);
-  * logged statistics: one all-reduce of the <=8-float stats vector at the end of the step.
+    mean of qc_ood that drives the log_alpha ascent;
+  * logged statistics: the <=8-float stats vector at the end of the step.
+  Everything is latency-bound, so CPQ coalesces what has no dependency in between into one launch
+  (``all_reduce_many_``): [critic grads | cost-critic grads | qc_ood mean] and [actor grads | statistics] --
+  4 collectives per step (VAE grads, KL gather, those two) instead of 7.
 
 Oracle for correctness: a sharded step on W x B rows == the single-device step on the concatenated
 batch (tests/test_dist_cpu.py checks the reduction algebra with gloo, world_size 2, on CPU).
@@ -38,6 +41,18 @@ class DataParallel:
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def all_reduce_many_(self, ts) -> None:
+        """all-reduce(SUM) of several tensors as ONE collective launch (ncclGroupStart/End coalescing): the step's
+        messages are 4 B - 1.6 MB, i.e. latency-bound on xGMI, so the count of collectives is what costs."""
+        ts = [t for t in ts if t is not None]
+        if len(ts) > 1 and ts[0].is_cuda and dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+            with dist._coalescing_manager(group=self.group, device=ts[0].device, async_ops=False):
+                for t in ts:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            for t in ts:
+                self.all_reduce_(t)
 
     def all_gather_concat(self, t: torch.Tensor) -> torch.Tensor:
         n = t.numel()

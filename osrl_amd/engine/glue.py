@@ -75,6 +75,11 @@ def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows, gamma, 
                                         cur_stream()), "osrl_cpq_cost_loss")
 
 
+def cpq_alpha_step(ood_mean, qc_thres, alpha_lr, stat_share, log_alpha, stat):
+    L.check(L.load().osrl_cpq_alpha_step(_p(ood_mean), qc_thres, alpha_lr, stat_share, _p(log_alpha), _p(stat),
+                                         cur_stream()), "osrl_cpq_alpha_step")
+
+
 def cpq_cost_loss_ood(qc_sampled, n_qc_s, kl, quant, n_samples, qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows,
                       gamma, qc_thres, alpha_lr, log_alpha, dq, stat):
     L.check(L.load().osrl_cpq_cost_loss_ood(_p(qc_sampled), n_qc_s, _p(kl), _p(quant), n_samples, _p(qc_old_next),
