@@ -236,8 +236,8 @@ extern "C" int osrl_episode_segments(const float* terminals, const float* timeou
 extern "C" int osrl_episode_returns(const float* x, const int64_t* ep_start, const int32_t* ep_len,
                                     int32_t n_episodes, float gamma, int32_t reverse, int32_t broadcast_first,
                                     float* out, float* x_out, void* stream) {
+  if (n_episodes == 0) return 0;  // no complete episode: nothing is written (out keeps the caller's zeros)
   if (!x || !ep_start || !ep_len || !out || n_episodes < 0) return -1;
-  if (n_episodes == 0) return 0;
   (void)hipGetLastError();
   hipLaunchKernelGGL(episode_returns_kernel, dim3((n_episodes + 63) / 64), dim3(64), 0, S, x, ep_start, ep_len,
                      n_episodes, gamma, reverse, broadcast_first, out, x_out);
@@ -265,8 +265,8 @@ extern "C" int osrl_bc_select(const float* cost_returns, int64_t n, int32_t mode
 
 extern "C" int osrl_gather_rows(const float* src, int32_t width, const int64_t* idx, int64_t n_rows, float* dst,
                                 int32_t dst_ld, const float* extra, void* stream) {
+  if (n_rows == 0) return 0;  // an empty selection (e.g. bc_mode="risky" on a safe dataset): nothing to move
   if (!src || !idx || !dst || width < 1 || n_rows < 0 || dst_ld < width + (extra ? 1 : 0)) return -1;
-  if (n_rows == 0) return 0;
   (void)hipGetLastError();
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_rows * (width + (extra ? 1 : 0)), 256)), dim3(256), 0, S, src,
                      width, idx, n_rows, dst, dst_ld, extra);

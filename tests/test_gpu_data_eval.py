@@ -486,3 +486,43 @@ def test_cdt_evaluate_cost_return_gap_vs_reference():
     finally:
         EVAL["cost_scale"] = saved
     assert abs(ret - ref[:, 0].mean() / 0.1) <= 1e-3 * abs(ref[:, 0].mean() / 0.1)
+
+
+@pytest.mark.parametrize("pattern", ["none", "all", "single", "last_only", "random_dense"])
+def test_ingest_edge_cases(pattern):
+    """Episode segmentation / returns / BC selection on degenerate done patterns: no done flag at all (zero complete
+    episodes), every transition an episode, a one-transition dataset, one episode covering everything, dense flags."""
+    from oracle import ingest_oracle as IO
+    from osrl_amd.common.ingest import Episodes, process_bc_dataset, process_sequence_dataset
+    rs = np.random.RandomState(11)
+    n = 1 if pattern == "single" else 9000  # > 2 scan tiles
+    f = np.float32
+    term = np.zeros(n, f)
+    tout = np.zeros(n, f)
+    if pattern == "all":
+        tout[:] = 1
+    elif pattern in ("single", "last_only"):
+        term[-1] = 1
+    elif pattern == "random_dense":
+        term[rs.uniform(size=n) < 0.3] = 1
+        tout[rs.uniform(size=n) < 0.3] = 1
+    data = dict(observations=rs.randn(n, 3).astype(f), next_observations=rs.randn(n, 3).astype(f),
+                actions=rs.randn(n, 2).astype(f), rewards=rs.uniform(0, 1, n).astype(f),
+                costs=(rs.uniform(size=n) < 0.3).astype(f), terminals=term, timeouts=tout)
+    ep = Episodes(data, DEV)
+    starts, lens = IO.episode_segments(IO.done_flags(data))
+    assert ep.n_episodes == len(starts)
+    assert np.array_equal(_np(ep.start), starts) and np.array_equal(_np(ep.length), lens)
+    tb = process_sequence_dataset(data, True, DEV)
+    ref = IO.process_sequence_dataset(data, True)
+    if ref:
+        for k in ("returns", "cost_returns", "costs", "observations"):
+            assert np.array_equal(_np(tb[k]), np.concatenate([t[k] for t in ref])), (pattern, k)
+    else:
+        assert tb["returns"].numel() == 0 and tb["traj_len"].numel() == 0
+    for mode in ("safe", "risky", "multi-task"):
+        out = process_bc_dataset(data, 1.0, 0.97, mode, DEV)
+        want = IO.process_bc_dataset(dict(data, index=np.arange(n)), 1.0, 0.97, mode)
+        assert np.array_equal(_np(out["index"]), want["index"]), (pattern, mode)
+        assert np.array_equal(_np(out["observations"]), want["observations"]), (pattern, mode)
+        assert np.array_equal(_np(out["cost_returns"]), want["cost_returns"]), (pattern, mode)

@@ -78,6 +78,9 @@ FULL_CASES = {
     # the capped tile-loop kernel), the paired launches and the 8-wave kernels at bench size.
     "cpq_c2_full": dict(algo="cpq", od=76, ad=2, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=21),
     "bcql_c3_full": dict(algo="bcql", od=33, ad=8, B=4096, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=22),
+    # BEAR-Lag at its train-config size (bearl_configs.py: batch 512, N = M = 10)
+    "bearl_full": dict(algo="bearl", od=33, ad=8, B=512, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=23,
+                       hp=dict(mmd_sigma=20.0)),
 }
 
 
@@ -117,7 +120,7 @@ def test_full_size_train_step_matches_oracle(name):
         d = np.abs(sd[k] - v).reshape(-1)
         assert d.max() <= 2.5 * lr * c.steps + 1e-6, f"{name} final param {k} vs oracle: max {d.max():.3e}"
         assert np.median(d) <= 2e-6, f"{name} final param {k}: median diff {np.median(d):.3e}"
-    if c.algo == "cpq":
+    if c.algo in ("cpq", "bearl"):
         assert abs(m.log_alpha.item() - o.log_alpha) < 1e-5
 
 
