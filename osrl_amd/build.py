@@ -36,16 +36,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    # one builder at a time (torchrun starts N ranks that all import the package): the others wait on the lock and
+    # then find the library fresh
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            # SimplifyCFG's store sinking merges "ring[i] = load" of sibling branches into a store through a
            # pointer phi, after which the weight-ring arrays of mlp.hip can no longer be promoted to registers
            # (they end up in scratch with an s_waitcnt vmcnt(0) right after the prefetch loads)
            "-mllvm", "-sink-common-insts=false",
-           "-Wno-pass-failed"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+           "-Wno-pass-failed"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + f".tmp{os.getpid()}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(LIB + f".tmp{os.getpid()}", LIB)
     return LIB
 
 
