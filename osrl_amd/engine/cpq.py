@@ -194,13 +194,11 @@ class CPQEngine:
             self.dist.quantile(self.kl, 0.75, self.quant)
         else:
             G.quantile(self.kl, N * B, 0.75, self.quant)
-        if self.dist is not None:
-            par.join(0)  # collectives stay on the capture stream; the critic group is reduced with the cost group
-        else:
-            # the cost-critic update needs the side branch's FORWARDS only (its products, and they are the last
-            # readers of cost_critic_old, which this phase's optimizer step Polyak-updates): it runs beside the
-            # critic's loss / backward / dW / Adam chain instead of after it; the join moves to the actor phase
-            par.wait(ev_fwd)
+        # the cost-critic update needs the side branch's FORWARDS only (its products, and they are the last readers
+        # of cost_critic_old, which this phase's optimizer step Polyak-updates): it runs beside the critic's loss /
+        # backward / dW (/ Adam) chain instead of after it; the join moves to the actor phase -- or, under data
+        # parallelism, to the coalesced gradient all-reduce of the two critics (collectives stay on this stream)
+        par.wait(ev_fwd)
         if self.dist is None and rg in (0, B):  # no batch-global reduction in between: one launch
             G.cpq_cost_loss_ood(qc_s, nqc, self.kl, self.quant, N, qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost,
                                 B, m.gamma, m.qc_thres, m.alpha_lr, m.log_alpha, self.dqc,
@@ -220,6 +218,7 @@ class CPQEngine:
             self._optim("cost_critic", self.p_cost, m.tau)
         else:
             self.p_cost.launch()
+            par.join(0)  # the critic's dW (side branch) is complete
             gc, gcc = m.groups["critic"], m.groups["cost_critic"]
             self.dist.all_reduce_many_([self.dist.reduce_local(gc), self.dist.reduce_local(gcc), self.ood_mean])
             gc.adam_step(m._lrs["critic"], st.ptr, tau=m.tau)
