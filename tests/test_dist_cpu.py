@@ -52,6 +52,11 @@ def _worker(rank, world, port, q):
         allv = dp.all_gather_concat(torch.from_numpy(kl[rank].copy()))
         assert allv.numel() == kl.size
         assert quantile_linear(allv.numpy(), 0.75) == quantile_linear(kl.reshape(-1), 0.75)
+        # coalesced all-reduce of several tensors (CPQ: [critic grads | cost grads | qc_ood mean], [actor | stats]);
+        # on gloo it degrades to one all-reduce per tensor, same result
+        ts = [torch.full((5,), float(rank + 1)), torch.tensor([10.0 * (rank + 1)]), None, torch.ones(3) * rank]
+        dp.all_reduce_many_(ts)
+        assert torch.equal(ts[0], torch.full((5,), 3.0)) and float(ts[1]) == 30.0 and torch.equal(ts[3], torch.ones(3))
         # broadcast_model-style broadcast
         t = torch.full((4,), float(rank))
         dist.broadcast(t, src=0)
