@@ -63,6 +63,24 @@ __global__ __launch_bounds__(256) void k16_ab(float* out, int iters, const float
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// 4x4x1 (16 independent 4x4 blocks per instruction: with A broadcast over the blocks it is a 4-row x 64-column
+// rank-1 update -- the candidate for <= 4096-row launches where 16-row tiles leave half the CUs idle)
+template <int NACC>
+__global__ __launch_bounds__(256) void k4(float* out, int iters, float a0, float b0) {
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
+  float a = a0 + threadIdx.x, b = b0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 float run(F launch) {
   hipEvent_t e0, e1;
@@ -98,6 +116,11 @@ int main() {
     printf("16x16x4 acc=16 blocks/CU=%d: %7.2f TF/s\n", bpc, tf16(16, ms));
     ms = run([&] { hipLaunchKernelGGL(k16_ab, dim3(grid), dim3(256), 0, 0, out, iters, src); });
     printf("16x16x4 4x4 frag blocks/CU=%d: %7.2f TF/s\n", bpc, tf16(16, ms));
+    auto tf4 = [&](int nacc, float ms) { return 2.0 * 16 * 4 * 4 * 1 * 4.0 * nacc * iters * (grid * 4.0) / (ms * 1e-3) / 1e12; };
+    ms = run([&] { hipLaunchKernelGGL(k4<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    printf("4x4x1   acc=4  blocks/CU=%d: %7.2f TF/s\n", bpc, tf4(4, ms));
+    ms = run([&] { hipLaunchKernelGGL(k4<16>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    printf("4x4x1   acc=16 blocks/CU=%d: %7.2f TF/s\n", bpc, tf4(16, ms));
     ms = run([&] { hipLaunchKernelGGL(k32<1>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
     printf("32x32x2 acc=1  blocks/CU=%d: %7.2f TF/s\n", bpc, tf32(1, ms));
     ms = run([&] { hipLaunchKernelGGL(k32<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
