@@ -308,6 +308,8 @@ class CPQEngine:
     def _run(self, use_graph: bool) -> None:
         """Replay the captured step (capturing it first).  With a DataParallel hook the RCCL collectives
         are captured into the same hipGraph; if the runtime refuses (older RCCL), fall back to eager."""
+        if self.dist is not None and os.environ.get("OSRL_DP_EAGER") == "1":
+            use_graph = False  # operator override: run the data-parallel step without capturing its collectives
         if use_graph and not self._graph_failed:
             if self.graph is None:
                 try:
