@@ -51,6 +51,37 @@ MLP_CASES = [
 ]
 
 
+def _random_mlp_cases(n, seed=2024):
+    """Seeded random shapes inside the C ABI's limits (1-4 layers, widths 1..448, 1-8 nets, 1..6000 rows, every row
+    map, with / without a second source and a dx slice): shapes no engine uses must work too -- the tile choice
+    (16/32/64-row tiles, 4/8 waves, narrow heads, capped loop kernel) is a function of the shape."""
+    rs = np.random.RandomState(seed)
+    acts_all = ["relu", "tanh", "id"]
+    out = []
+    for i in range(n):
+        L_ = int(rs.randint(1, 5))
+        widths = [int(rs.choice([1, 3, 8, 17, 32, 64, 100, 256, 300, 400, 448])) for _ in range(L_)]
+        k0 = int(rs.choice([1, 2, 5, 16, 33, 78, 130]))
+        dims = [k0] + widths
+        acts = [acts_all[int(rs.randint(0, 3))] for _ in range(L_)]
+        E = int(rs.choice([1, 1, 2, 3, 4, 8]))
+        rows = int(rs.choice([1, 2, 15, 16, 17, 31, 100, 513, 2048, 2500, 6000]))
+        if E * rows * max(dims) > 6_000_000:  # keep the fp64 reference cheap
+            rows = max(1, 6_000_000 // (E * max(dims)))
+        d0 = int(rs.randint(1, k0 + 1))
+        mode = int(rs.randint(0, 3))
+        div0 = {0: 1, 1: int(rs.randint(1, rows + 1)), 2: int(rs.randint(1, 12))}[mode]
+        dxc = None
+        if rs.rand() < 0.6:
+            c0 = int(rs.randint(0, k0))
+            dxc = (c0, int(rs.randint(1, k0 - c0 + 1)))
+        out.append((E, dims, acts, float(rs.choice([1.0, 0.5, 2.0])), rows, (d0, mode, div0, 0, 1), dxc))
+    return out
+
+
+MLP_CASES += _random_mlp_cases(28)
+
+
 @pytest.mark.parametrize("ci", range(len(MLP_CASES)))
 def test_mlp_fwd_bwd(ci):
     from osrl_amd.engine.core import DwPlan, FlatGroup, LayerRef, MlpRun, NetDesc
