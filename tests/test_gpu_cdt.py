@@ -382,3 +382,69 @@ def test_cdt_checkpoint_resume_is_bit_identical(tmp_path):
     assert torch.equal(g_a.m, g_c.m) and torch.equal(g_a.v, g_c.v)
     assert torch.equal(m_a.log_temperature, m_c.log_temperature)
     assert torch.equal(m_a._engine.temp_mv, m_c._engine.temp_mv)
+
+
+def test_linear_and_attention_random_shapes():
+    """Seeded random shapes through osrl_linear (both packs, incl. the LDS-tiled big path and ragged M / K / N) and
+    osrl_attention_fwd/bwd (head dims 4..64, S up to 96, tail padding in several rows)."""
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import FlatGroup, cur_stream
+    lib = L.load()
+    rs = np.random.RandomState(77)
+    r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+    for _ in range(14):
+        M = int(rs.choice([1, 5, 16, 63, 257, 1000, 4096, 4500, 6001]))
+        K = int(rs.choice([1, 3, 16, 30, 64, 200, 256, 448]))
+        N = int(rs.choice([1, 2, 6, 16, 40, 256, 300, 512, 768]))
+        g = FlatGroup("t", DEV)
+        g.add("w", (N, K))
+        g.mark_weight("w")
+        g.add("b", (N,))
+        g.finalize()
+        W, b = rs.randn(N, K).astype(np.float32) * 0.1, rs.randn(N).astype(np.float32)
+        g.view("w").copy_(t(W))
+        g.view("b").copy_(t(b))
+        g.repack()
+        A, R = rs.randn(M, K).astype(np.float32), rs.randn(M, N).astype(np.float32)
+        At, Rt, Y = t(A), t(R), torch.zeros(M, N, device=DEV)
+        L.check(lib.osrl_linear(At.data_ptr(), K, M, K, g.pf.data_ptr(), r16(N), 0, N, g.view("b").data_ptr(),
+                                Rt.data_ptr(), N, Y.data_ptr(), N, cur_stream()), "lin")
+        ref = A.astype(np.float64) @ W.T.astype(np.float64) + b + R
+        assert np.abs(Y.cpu().numpy() - ref).max() < 3e-5 * max(1, np.abs(ref).max()), (M, K, N, "fwd")
+        dY = rs.randn(M, N).astype(np.float32)
+        dX, dYt = torch.zeros(M, K, device=DEV), t(dY)
+        L.check(lib.osrl_linear(dYt.data_ptr(), N, M, N, g.pb.data_ptr(), r16(K) + 16, 0, K, None, None, 0,
+                                dX.data_ptr(), K, cur_stream()), "lin dx")
+        ref = dY.astype(np.float64) @ W.astype(np.float64)
+        assert np.abs(dX.cpu().numpy() - ref).max() < 3e-5 * max(1, np.abs(ref).max()), (M, K, N, "dx")
+    for _ in range(8):
+        H = int(rs.choice([1, 2, 4, 8]))
+        d = int(rs.choice([4, 8, 16, 24, 32, 64]))
+        T = int(rs.choice([1, 2, 5, 12, 20, 24]))
+        B = int(rs.randint(1, 6))
+        E, S = H * d, 4 * T
+        qkv = rs.randn(B, S, 3 * E).astype(np.float32)
+        mask = np.ones((B, T), np.float32)
+        for bb in range(B):
+            mask[bb, T - int(rs.randint(0, T)):] = 0  # 0 .. T-1 padded steps at the tail
+        do = rs.randn(B, S, E).astype(np.float32)
+        o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
+        qt, mt, dot = t(qkv), t(mask), t(do)
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, None, o.data_ptr(), cur_stream()), "a")
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, None,
+                                       dqkv.data_ptr(), cur_stream()), "ab")
+        q64 = qkv.astype(np.float64)
+        q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
+        blocked = np.triu(np.ones((S, S), bool), 1)[None, None] | np.repeat(mask <= 0, 4, 1)[:, None, None, :]
+        sc = np.where(blocked, -np.inf, q @ k.transpose(0, 1, 3, 2) / math.sqrt(d))
+        P = np.exp(sc - sc.max(-1, keepdims=True))
+        P /= P.sum(-1, keepdims=True)
+        oref = (P @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
+        assert np.abs(o.cpu().numpy() - oref).max() < 2e-5, (B, T, E, H, "o")
+        dO = do.astype(np.float64).reshape(B, S, H, d).transpose(0, 2, 1, 3)
+        dP = dO @ v.transpose(0, 1, 3, 2)
+        dv = P.transpose(0, 1, 3, 2) @ dO
+        dS = P * (dP - (dP * P).sum(-1, keepdims=True))
+        dq, dk = dS @ k / math.sqrt(d), dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
+        ref = np.concatenate([x.transpose(0, 2, 1, 3).reshape(B, S, E) for x in (dq, dk, dv)], -1)
+        assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), (B, T, E, H, "dqkv")
