@@ -463,3 +463,42 @@ def test_autograd_function_matches_torch():
             if isinstance(mod, torch.nn.Linear):
                 assert (mod.weight.grad.cpu().double() - rmod.weight.grad).abs().max() < 2e-5
                 assert (mod.bias.grad.cpu().double() - rmod.bias.grad).abs().max() < 2e-5
+
+
+def test_bear_mmd_kernel_random_shapes():
+    """osrl_bear_mmd against the fp64 oracle (oracle/bearl_oracle.py mmd_and_grad) at the kernel's limits: M = 1 and
+    64 samples, action dims 1..16, both kernels, rows not a multiple of the 4 rows a workgroup handles; plus u,
+    tanh(u) and the sample-0 action."""
+    from oracle.bearl_oracle import mmd_and_grad
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import cur_stream
+    dev = _dev()
+    lib = L.load()
+    rs = np.random.RandomState(5)
+    for (B, M, ad, sigma, kern) in [(1, 1, 1, 0.7, 0), (7, 64, 16, 20.0, 0), (33, 10, 8, 50.0, 0), (5, 3, 2, 1.5, 1),
+                                    (130, 10, 3, 2.0, 1), (9, 64, 1, 0.3, 1), (4, 17, 16, 5.0, 0)]:
+        x = rs.randn(B * M, ad).astype(np.float32)
+        head = np.concatenate([rs.randn(B * M, ad), rs.uniform(-3, 1, (B * M, ad))], 1).astype(np.float32)
+        head[0, ad] = 5.0  # log_std above the clamp (2.0)
+        eps = rs.randn(B * M, ad).astype(np.float32)
+        tt = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+        xt, ht, et = tt(x), tt(head), tt(eps)
+        mmd, du = torch.zeros(B, device=dev), torch.zeros(B * M, ad, device=dev)
+        tu, a0 = torch.zeros(B * M, ad, device=dev), torch.zeros(B, ad, device=dev)
+        L.check(lib.osrl_bear_mmd(xt.data_ptr(), ht.data_ptr(), et.data_ptr(), B, M, ad, sigma, kern, mmd.data_ptr(),
+                                  du.data_ptr(), tu.data_ptr(), a0.data_ptr(), cur_stream()), "mmd")
+        mu, ls = head[:, :ad].astype(np.float64), np.clip(head[:, ad:].astype(np.float64), -20, 2)
+        u = mu + np.exp(ls) * eps
+        ref, dref = mmd_and_grad(x.astype(np.float64).reshape(B, M, ad), u.reshape(B, M, ad), sigma,
+                                 "gaussian" if kern == 0 else "laplacian")
+        np.testing.assert_allclose(mmd.cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=str((B, M, ad, kern)))
+        sc = max(1e-3, np.abs(dref).max())
+        assert np.abs(du.cpu().numpy().reshape(B, M, ad) - dref).max() < 2e-3 * sc, (B, M, ad, kern)
+        np.testing.assert_allclose(tu.cpu().numpy(), np.tanh(u), atol=2e-6)
+        np.testing.assert_allclose(a0.cpu().numpy(), np.tanh(u).reshape(B, M, ad)[:, 0], atol=2e-6)
+    # limits are enforced
+    z = torch.zeros(8, device=dev)
+    assert lib.osrl_bear_mmd(z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 65, 1, 1.0, 0, z.data_ptr(), z.data_ptr(),
+                             z.data_ptr(), z.data_ptr(), cur_stream()) == -1
+    assert lib.osrl_bear_mmd(z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 2, 17, 1.0, 0, z.data_ptr(), z.data_ptr(),
+                             z.data_ptr(), z.data_ptr(), cur_stream()) == -1
