@@ -502,3 +502,55 @@ def test_bear_mmd_kernel_random_shapes():
                              z.data_ptr(), z.data_ptr(), cur_stream()) == -1
     assert lib.osrl_bear_mmd(z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 2, 17, 1.0, 0, z.data_ptr(), z.data_ptr(),
                              z.data_ptr(), z.data_ptr(), cur_stream()) == -1
+
+
+@pytest.mark.parametrize("B,n_chi,scale", [(1, 1, 1.0), (37, 3, 1.0), (3000, 2, 1.0), (2500, 2, 40.0)])
+def test_dice_chi_step_kernel(B, n_chi, scale):
+    """osrl_dice_chi_step vs fp64 numpy: the batch softmax (also with logits of magnitude ~1e3: max-subtraction),
+    D_kl, weighted_c, chi_loss, its gradient through the NOT-detached weights with the min-routing of predict, and
+    the Adam step on tau; B beyond one pass of the 1024-thread workgroup."""
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import StepState, cur_stream
+    dev = _dev()
+    lib = L.load()
+    rs = np.random.RandomState(B)
+    gamma, p0, eps_ub, lr = 0.99, 0.07, 0.01, 1e-2
+    chi2 = (rs.randn(n_chi, 2 * B) * scale).astype(np.float32)
+    w = np.abs(rs.randn(B)).astype(np.float32)
+    cost = (rs.uniform(size=B) < 0.3).astype(np.float32)
+    done = (rs.uniform(size=B) < 0.1).astype(np.float32)
+    init = (rs.uniform(size=B) < 0.2).astype(np.float32)
+    tt = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    leaves = tt(np.array([0.4, 0, 0, 1.0, 0, 0], np.float32))
+    tau_p = float(np.logaddexp(0.0, 0.4))
+    work = tt(np.array([1.3, tau_p, 0, 0], np.float32))
+    st = StepState(dev, ["a", "b", "c"])
+    st.tick()
+    ell_ws, dchi = torch.zeros(B, device=dev), torch.zeros(n_chi, 2 * B, device=dev)
+    c2, wt, ct, dt_, it = tt(chi2), tt(w), tt(cost), tt(done), tt(init)
+    L.check(lib.osrl_dice_chi_step(c2.data_ptr(), n_chi, B, wt.data_ptr(), ct.data_ptr(), dt_.data_ptr(), it.data_ptr(),
+                                   gamma, p0, eps_ub, lr, st.ptr, leaves.data_ptr(), work.data_ptr(), ell_ws.data_ptr(),
+                                   dchi.data_ptr(), st.stats.data_ptr(), cur_stream()), "chi")
+    c64 = chi2.astype(np.float64)
+    i_s, i_n = c64[:, :B].argmin(0), c64[:, B:].argmin(0)
+    cs, cn = c64[:, :B].min(0), c64[:, B:].min(0)
+    ell = (1 - gamma) * cs * init / p0 + w * (cost + gamma * (1 - done) * cn - cs)
+    z = ell / tau_p - (ell / tau_p).max()
+    lsm = z - np.log(np.exp(z).sum())
+    sm = np.exp(lsm)
+    wts = sm * B
+    dkl = (wts * (lsm + np.log(B)) - wts + 1).mean()
+    wc, cl = (wts * w * cost).mean(), (wts * ell).mean()
+    dl = sm * (1 + (ell - cl) / tau_p)
+    ref = np.zeros((n_chi, 2 * B))
+    ref[i_s, np.arange(B)] = dl * ((1 - gamma) * init / p0 - w)
+    ref[i_n, B + np.arange(B)] = dl * w * gamma * (1 - done)
+    got = st.stats.cpu().numpy()
+    tol = 2e-4 if scale > 1 else 2e-5
+    assert abs(got[0] - cl) <= tol * max(1, abs(cl)) and abs(got[2] - dkl) <= tol * max(1, abs(dkl)), (got, cl, dkl)
+    assert abs(got[1] - tau_p * (eps_ub - dkl)) <= tol * max(1, abs(dkl) * tau_p)
+    assert abs(work[2].item() - wc) <= tol * max(1, abs(wc))
+    np.testing.assert_allclose(dchi.cpu().numpy(), ref, rtol=5e-4 if scale > 1 else 5e-5, atol=1e-7 * max(1, scale))
+    g = (1 / (1 + np.exp(-0.4))) * (eps_ub - dkl)  # first Adam step: p -= lr * sign-like m/(sqrt(v)+eps)
+    want = 0.4 - lr * g / (abs(g) + 1e-8)
+    assert abs(leaves[0].item() - want) < 1e-5, (leaves[0].item(), want)
