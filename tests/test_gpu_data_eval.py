@@ -526,3 +526,29 @@ def test_ingest_edge_cases(pattern):
         assert np.array_equal(_np(out["index"]), want["index"]), (pattern, mode)
         assert np.array_equal(_np(out["observations"]), want["observations"]), (pattern, mode)
         assert np.array_equal(_np(out["cost_returns"]), want["cost_returns"]), (pattern, mode)
+
+
+def test_ingest_scan_beyond_one_offset_chunk():
+    """4.3 M transitions = 1050 scan tiles: the tile-offset pass carries across its 1024-wide chunks; episode
+    bounds and the compaction indices stay exact."""
+    from oracle import ingest_oracle as IO
+    from osrl_amd.common.ingest import Episodes, process_bc_dataset
+    rs = np.random.RandomState(3)
+    n = 4_300_000
+    f = np.float32
+    data = dict(terminals=(rs.uniform(size=n) < 0.002).astype(f), timeouts=np.zeros(n, f))
+    data["timeouts"][-5] = 1
+    ep = Episodes(data, DEV)
+    starts, lens = IO.episode_segments(IO.done_flags(data))
+    assert ep.n_episodes == len(starts) > 4096
+    assert np.array_equal(_np(ep.start), starts) and np.array_equal(_np(ep.length), lens)
+    full = dict(data, observations=rs.randn(n, 1).astype(f), next_observations=np.zeros((n, 1), f),
+                actions=np.zeros((n, 1), f), rewards=np.ones(n, f), costs=(rs.uniform(size=n) < 0.01).astype(f))
+    out = process_bc_dataset(full, 4.0, 1.0, "risky", DEV)
+    cr = np.zeros(n, f)
+    csum = np.concatenate([[0], np.cumsum(full["costs"], dtype=np.float64)])
+    for s, l in zip(starts, lens):
+        cr[s:s + l] = csum[s + l] - csum[s]  # gamma = 1: the episode's cost sum (exact in fp32: small integers)
+    keep = np.flatnonzero(cr >= 8.0)
+    assert np.array_equal(_np(out["index"]), keep) and 0 < len(keep) < n
+    assert np.array_equal(_np(out["observations"])[:, 0], full["observations"][keep, 0])
