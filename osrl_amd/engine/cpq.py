@@ -145,12 +145,24 @@ class CPQEngine:
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         par = par or Branches(False)
         st.tick()
-        if self.replay is not None:
+        if par.enabled and device_noise and self.replay is not None:
+            # prologue: the noise fill (side stream) and the minibatch gather are independent -- +1 % step
+            par.fork(0)
+            with par.on(0):
+                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+                ev_r = par.mark(0)
             self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-        if device_noise:
-            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
-
-        par.fork(0)  # the side stream may start here; its launches are issued after the VAE phase's so the
+            ev_g = torch.cuda.Event()
+            ev_g.record()
+            par.wait(ev_r)
+            par.side[0].wait_event(ev_g)
+        else:
+            if self.replay is not None:
+                self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
+            if device_noise:
+                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+            par.fork(0)
+        # the side stream may start here; its launches are issued after the VAE phase's so the
         # graph executor (which dispatches nodes in creation order) starts both branches at once
         # ---- main: vae_loss  (cpq.py:125-135)
         head = self.r_enc.forward(self.obs, self.act)[0]
