@@ -95,3 +95,61 @@ def test_lazy_stat_and_logger():
     lg.store(a=LazyStat(FakeSt(), 3, "a"))
     lg.store(a=1.0)
     assert lg.get_mean("a") == 3.5 and float(lg.data["a"][0]) == 6.0
+
+
+def test_header_is_plain_c():
+    """include/osrl_amd.h is the drop-in boundary: it must compile as C99 (no C++ constructs, no torch types) and a
+    C translation unit must be able to take the address of every entry point it declares."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "osrl_amd.h")
+    names = sorted(set(re.findall(r"\b(osrl_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "use.c")
+        with open(src, "w") as f:
+            f.write('#include "osrl_amd.h"\n#include <stddef.h>\nconst void* osrl_table[] = {\n')
+            f.write("".join(f"  (const void*)&{n},\n" for n in names))
+            f.write("  NULL};\nint main(void) { return osrl_table[0] == NULL; }\n")
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic",
+                            "-I", os.path.dirname(hdr), "-c", src, "-o", os.path.join(d, "use.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_struct_layouts_match_the_compiled_header():
+    """sizeof / field offsets of every struct of include/osrl_amd.h as a C compiler sees them == the ctypes mirrors
+    in osrl_amd/_lib.py (the binding INTEGRATION.md shows is exactly these classes)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import tempfile
+    from osrl_amd import _lib as L
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    pairs = [("osrl_mlp_t", L.MlpT), ("osrl_pack_entry_t", L.PackEntryT), ("osrl_rows_t", L.RowsT),
+             ("osrl_mlp_acts_t", L.ActsT), ("osrl_mlp_grads_t", L.GradsT), ("osrl_dw_entry_t", L.DwEntryT),
+             ("osrl_step_state_t", L.StepStateT), ("osrl_dropout_t", L.DropoutT), ("osrl_env_t", L.EnvT)]
+    hdr_dir = os.path.join(ROOT, "include")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "sz.c"), os.path.join(d, "sz")
+        with open(src, "w") as f:
+            f.write('#include "osrl_amd.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void) {\n')
+            for cname, cls in pairs:
+                f.write(f'  printf("{cname} %zu", sizeof({cname}));\n')
+                for fname, _ in cls._fields_:
+                    cfield = {"in_": "in"}.get(fname, fname)  # `in` is a Python keyword: the mirror spells it in_
+                    f.write(f'  printf(" %zu", offsetof({cname}, {cfield}));\n')
+                f.write('  printf("\\n");\n')
+            f.write("  return 0;\n}\n")
+        subprocess.run([gcc, "-std=c99", "-I", hdr_dir, src, "-o", exe], check=True, capture_output=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line, (cname, cls) in zip(out, pairs):
+        tok = line.split()
+        assert tok[0] == cname
+        want = [C.sizeof(cls)] + [getattr(cls, fname).offset for fname, _ in cls._fields_]
+        assert [int(x) for x in tok[1:]] == want, (cname, tok[1:], want)
