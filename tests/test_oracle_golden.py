@@ -87,3 +87,21 @@ def test_ingest_oracle_matches_golden():
                 assert np.array_equal(out[k], g[f"{tag}_{k}"]), (tag, k)
     with pytest.raises(NotImplementedError):
         IO.process_bc_dataset(make_ingest_dataset(), 6.0, 1.0, "frontier")
+
+
+@pytest.mark.parametrize("kernel", ["gaussian", "laplacian"])
+def test_bearl_oracle_mmd_gradient_by_finite_differences(kernel):
+    """The hand-derived d MMD / d y of oracle/bearl_oracle.py against central differences (fp64), independent of the
+    goldens."""
+    from oracle.bearl_oracle import mmd_and_grad
+    rs = np.random.RandomState(0)
+    B, M, d = 3, 5, 4
+    x, y = rs.randn(B, M, d), rs.randn(B, M, d)
+    _, g = mmd_and_grad(x, y, 1.7, kernel)
+    h = 1e-6
+    for (b, j, k) in [(0, 0, 0), (1, 3, 2), (2, 4, 3), (0, 2, 1)]:
+        yp, ym = y.copy(), y.copy()
+        yp[b, j, k] += h
+        ym[b, j, k] -= h
+        fd = (mmd_and_grad(x, yp, 1.7, kernel)[0][b] - mmd_and_grad(x, ym, 1.7, kernel)[0][b]) / (2 * h)
+        assert abs(fd - g[b, j, k]) < 1e-6 * max(1.0, abs(fd)), (kernel, b, j, k, fd, g[b, j, k])
