@@ -153,7 +153,10 @@ class BCQLEngine:
         G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
                           st.stat_ptr("loss/critic_loss"))
         self.r_critic.backward_dz()
-        self._optim("critic", self.p_critic, m.tau)
+        if self.dist is None:
+            self._optim("critic", self.p_critic, m.tau)
+        else:  # reduced together with the cost critic's gradient after the join: one collective instead of two
+            self.p_critic.launch()
 
         with par.on(0):
             qc_t = self._targets("z_cc", self.r_qcold_t, second=True)
@@ -167,7 +170,13 @@ class BCQLEngine:
             t = self.r_actor.forward(self.obs, dec)[0]
             G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
         par.join(0)
-        self._update("cost_critic", m.tau)
+        if self.dist is None:
+            self._update("cost_critic", m.tau)
+        else:
+            gc, gcc = m.groups["critic"], m.groups["cost_critic"]
+            self.dist.all_reduce_many_([self.dist.reduce_local(gc), self.dist.reduce_local(gcc)])
+            gc.adam_step(m._lrs["critic"], st.ptr, tau=m.tau)
+            gcc.adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau)
 
         y = self.r_pi_q.forward(self.obs, self.a_pi)
         means, share = None, 1.0
@@ -180,9 +189,13 @@ class BCQLEngine:
         self.r_pi_q.backward_dz()
         G.bcq_perturb_bwd(dec, t, self.r_pi_q.dx, 2 * nq + 2 * nqc, B, ad, m.phi, m.max_action, self.dt)
         self.r_actor.backward_dz()
-        self._optim("actor", self.p_actor, m.tau)
-        if self.dist is not None:
-            self.dist.all_reduce_(st.stats)
+        if self.dist is None:
+            self._optim("actor", self.p_actor, m.tau)
+        else:  # actor gradient and the per-rank partial statistics in one collective
+            self.p_actor.launch()
+            ga = m.groups["actor"]
+            self.dist.all_reduce_many_([self.dist.reduce_local(ga), st.stats])
+            ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
         for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),

@@ -144,7 +144,10 @@ class BEARLEngine:
         G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
                           st.stat_ptr("loss/critic_loss"))  # same lambda-mix / max-over-N backup as BCQ-L
         self.r_critic.backward_dz()
-        self._optim("critic", self.p_critic, m.tau)
+        if self.dist is None:
+            self._optim("critic", self.p_critic, m.tau)
+        else:  # reduced together with the cost critic's gradient after the join: one collective instead of two
+            self.p_critic.launch()
 
         with par.on(0):
             qc_t = self._targets("eps_cc", self.r_qcold_t, 1)
@@ -161,7 +164,13 @@ class BEARLEngine:
                                       self.du_mmd.data_ptr(), self.tanh_u.data_ptr(), self.a0.data_ptr(),
                                       cur_stream()), "osrl_bear_mmd")
         par.join(0)
-        self._update("cost_critic", m.tau)
+        if self.dist is None:
+            self._update("cost_critic", m.tau)
+        else:
+            gc, gcc = m.groups["critic"], m.groups["cost_critic"]
+            self.dist.all_reduce_many_([self.dist.reduce_local(gc), self.dist.reduce_local(gcc)])
+            gc.adam_step(m._lrs["critic"], st.ptr, tau=m.tau)
+            gcc.adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau)
 
         y = self.r_pi_q.forward(self.obs, self.a0)
         yq, yqc = y[:2 * nq], y[2 * nq:]
@@ -185,9 +194,13 @@ class BEARLEngine:
                                        2 * nq + 2 * nqc, B, M, ad, self.dhead.data_ptr(), cur_stream()),
                 "osrl_bear_head_bwd")
         self.r_actor.backward_dz()
-        self._optim("actor", self.p_actor, m.tau)
-        if self.dist is not None:
-            self.dist.all_reduce_(st.stats)
+        if self.dist is None:
+            self._optim("actor", self.p_actor, m.tau)
+        else:  # actor gradient and the per-rank partial statistics in one collective
+            self.p_actor.launch()
+            ga = m.groups["actor"]
+            self.dist.all_reduce_many_([self.dist.reduce_local(ga), st.stats])
+            ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
         for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
