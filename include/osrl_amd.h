@@ -374,24 +374,34 @@ int osrl_dice_optimal_w(const float* nu2, int32_t n_nu, int32_t rows, const floa
                         float gamma, int32_t f_type, float* e, float* w, void* stream);
 /* coptidice.py:149-185: ell, the softmax over the WHOLE batch, D_kl, weighted_c -> work[2], chi_loss and its gradient
  * dchi [n_chi, 2*rows] (weights are not detached in the reference), Adam step on tau; stat[0..3) = chi_loss, tau_loss,
- * D_kl.  chi2 == NULL (cost_ub_epsilon == 0): weighted_c = mean(w c), zero stats, no update. */
+ * D_kl.  chi2 == NULL (cost_ub_epsilon == 0): weighted_c = mean(w c), zero stats, no update.
+ * Data parallel: osrl_dice_chi_ell writes this rank's ell [rows]; the caller all-gathers it into ell_all
+ * [rows_global] and passes it with this rank's first row row0: the softmax statistics are then the GLOBAL ones
+ * (identical on every rank, written x stat_share because the statistics vector is all-reduced), work[2] is this
+ * rank's share of weighted_c (all-reduce it), dchi covers this rank's rows.  ell_all == NULL: one GPU. */
+int osrl_dice_chi_ell(const float* chi2, int32_t n_chi, int32_t rows, const float* w, const float* cost,
+                      const float* done, const float* is_init, float gamma, float init_state_propotion, float* ell,
+                      void* stream);
 int osrl_dice_chi_step(const float* chi2, int32_t n_chi, int32_t rows, const float* w, const float* cost,
                        const float* done, const float* is_init, float gamma, float init_state_propotion,
                        float cost_ub_epsilon, float scalar_lr, const osrl_step_state_t* st, float* leaves, float* work,
-                       float* ell_ws, float* dchi, float* stat, void* stream);
-/* coptidice.py:147,188-201: Df, td_error, nu_loss and dnu [n_nu, 2*rows]; lmbda_loss and the Adam step on lmbda;
- * stat[0..7) = Df, td_error, nu_loss, lmbda_loss, (untouched: actor_loss), tau', lambda'. */
+                       float* ell_ws, float* dchi, const float* ell_all, int32_t rows_global, int32_t row0,
+                       float stat_share, float* stat, void* stream);
+/* coptidice.py:147,188-201: Df, td_error, nu_loss (this rank's share of the global means: 1/rows_global) and dnu
+ * [n_nu, 2*rows]; lmbda_loss and the Adam step on lmbda from the GLOBAL weighted_c in work[2];
+ * stat[0..7) = Df, td_error, nu_loss, lmbda_loss, (untouched: actor_loss), tau', lambda' (the last three x stat_share). */
 int osrl_dice_nu_step(const float* nu2, int32_t n_nu, int32_t rows, const float* e, const float* w, const float* done,
                       const float* is_init, int32_t f_type, float gamma, float alpha, float init_state_propotion,
-                      float qc_thres, float scalar_lr, const osrl_step_state_t* st, float* leaves, const float* work,
-                      float* dnu, float* stat, void* stream);
+                      float qc_thres, float scalar_lr, int32_t rows_global, float stat_share,
+                      const osrl_step_state_t* st, float* leaves, const float* work, float* dnu, float* stat,
+                      void* stream);
 /* out = x + eps * std[col] * scale (coptidice.py:204-205; std is [1, dim]) */
 int osrl_dice_perturb(const float* x, const float* eps, const float* std, int32_t rows, int32_t dim, float scale,
                       float* out, void* stream);
-/* coptidice.py:207-215: actor_loss = -mean(w * sum Normal(mu, exp(clamp(log_std))).log_prob(act)) (pre-tanh Gaussian),
- * dhead [rows, 2*ad] = its gradient w.r.t. (mu, log_std); stat[0] = actor_loss. */
-int osrl_dice_actor_loss(const float* head, const float* act, const float* w, int32_t rows, int32_t ad, float* dhead,
-                         float* stat, void* stream);
+/* coptidice.py:207-215: actor_loss = -mean(w * sum Normal(mu, exp(clamp(log_std))).log_prob(act)) (pre-tanh Gaussian,
+ * mean over rows_global), dhead [rows, 2*ad] = its gradient w.r.t. (mu, log_std); stat[0] = actor_loss (share). */
+int osrl_dice_actor_loss(const float* head, const float* act, const float* w, int32_t rows, int32_t ad,
+                         int32_t rows_global, float* dhead, float* stat, void* stream);
 
 /* ---- dataset ingestion on device (osrl/common/dataset.py) ----
  * The flat DSRL arrays (observations, actions, rewards, costs, terminals, timeouts) are uploaded once; these calls

@@ -90,12 +90,13 @@ PROTOTYPES = {
                              _i32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "osrl_bear_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "osrl_dice_optimal_w": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp, _vp, _vp],
+    "osrl_dice_chi_ell": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp],
     "osrl_dice_chi_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
-                           _vp],
-    "osrl_dice_nu_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp,
-                          _vp, _vp],
+                           _i32, _i32, _f32, _vp, _vp],
+    "osrl_dice_nu_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp,
+                          _vp, _vp, _vp, _vp],
     "osrl_dice_perturb": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp],
-    "osrl_dice_actor_loss": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "osrl_dice_actor_loss": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "osrl_ingest_ws_elems": [_i64],
     "osrl_episode_segments": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "osrl_episode_returns": [_vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp],

@@ -126,17 +126,37 @@ struct ChiArgs {
   const osrl_step_state_t* st;
   float* leaves;
   float* work;
-  float* ell;   // [B] scratch
+  float* ell;   // [B] scratch (single GPU) / this rank's ell (data parallel, filled by dice_chi_ell_kernel)
   float* dchi;  // [n_chi, 2B]
   float* stat;  // chi_loss, tau_loss, D_kl
+  // data parallel: the softmax runs over the GLOBAL batch -- ell_all = all-gathered ell [Bg], this rank's rows start
+  // at row0; global scalars are written x stat_share (the statistics vector is all-reduced with SUM)
+  const float* ell_all;
+  int Bg, row0;
+  float stat_share;
 };
+
+__device__ __forceinline__ float chi_ell(const ChiArgs& a, int b, int* i1, int* i2) {
+  const int B = a.B;
+  const float cs = net_min(a.chi2, a.n_chi, 2 * B, b, i1), cn = net_min(a.chi2, a.n_chi, 2 * B, B + b, i2);
+  return (1.f - a.gamma) * cs * a.init[b] / a.p0 + a.w[b] * (a.cost[b] + a.gamma * (1.f - a.done[b]) * cn - cs);
+}
+
+// ell of this rank's rows (data parallel: all-gathered before dice_chi_kernel)
+__global__ void dice_chi_ell_kernel(ChiArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  int i1, i2;
+  a.ell[b] = chi_ell(a, b, &i1, &i2);
+}
 
 // coptidice.py:149-185 in one workgroup (the softmax runs over the whole batch: "dim=0")
 __global__ __launch_bounds__(kRed) void dice_chi_kernel(ChiArgs a) {
   __shared__ float sm[20];
   const int B = a.B;
-  const float invB = 1.f / (float)B;
-  if (!a.chi2) {  // cost_ub_epsilon == 0: weighted_c = mean(w c), no chi / tau update
+  const int Bg = a.Bg;  // global batch (== B on one GPU)
+  const float invB = 1.f / (float)Bg;
+  if (!a.chi2) {  // cost_ub_epsilon == 0: weighted_c = mean(w c) (this rank's share), no chi / tau update
     float s = 0.f;
     for (int b = threadIdx.x; b < B; b += kRed) s += a.w[b] * a.cost[b];
     s = block_red<false>(s, sm);
@@ -147,35 +167,39 @@ __global__ __launch_bounds__(kRed) void dice_chi_kernel(ChiArgs a) {
     return;
   }
   const float tau = a.work[1];
-  float mx = -INFINITY;
-  for (int b = threadIdx.x; b < B; b += kRed) {
-    int i1, i2;
-    const float cs = net_min(a.chi2, a.n_chi, 2 * B, b, &i1), cn = net_min(a.chi2, a.n_chi, 2 * B, B + b, &i2);
-    const float l = (1.f - a.gamma) * cs * a.init[b] / a.p0 +
-                    a.w[b] * (a.cost[b] + a.gamma * (1.f - a.done[b]) * cn - cs);
-    a.ell[b] = l;
-    mx = fmaxf(mx, l / tau);
+  if (!a.ell_all) {
+    for (int b = threadIdx.x; b < B; b += kRed) {
+      int i1, i2;
+      a.ell[b] = chi_ell(a, b, &i1, &i2);
+    }
+    __syncthreads();
   }
+  const float* __restrict__ ell = a.ell_all ? a.ell_all : a.ell;  // the GLOBAL batch
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < Bg; i += kRed) mx = fmaxf(mx, ell[i] / tau);
   mx = block_red<true>(mx, sm);
   float se = 0.f;
-  for (int b = threadIdx.x; b < B; b += kRed) se += expf(a.ell[b] / tau - mx);
+  for (int i = threadIdx.x; i < Bg; i += kRed) se += expf(ell[i] / tau - mx);
   se = block_red<false>(se, sm);
-  const float lse = logf(se), logB = logf((float)B);
-  float dkl = 0.f, wc = 0.f, cl = 0.f;
-  for (int b = threadIdx.x; b < B; b += kRed) {
-    const float lsm = a.ell[b] / tau - mx - lse;
-    const float wt = expf(lsm) * (float)B;
+  const float lse = logf(se), logB = logf((float)Bg);
+  float dkl = 0.f, cl = 0.f;
+  for (int i = threadIdx.x; i < Bg; i += kRed) {
+    const float lsm = ell[i] / tau - mx - lse;
+    const float wt = expf(lsm) * (float)Bg;
     dkl += wt * (lsm + logB) - wt + 1.f;
-    wc += wt * a.w[b] * a.cost[b];
-    cl += wt * a.ell[b];
+    cl += wt * ell[i];
   }
   dkl = block_red<false>(dkl, sm) * invB;
-  wc = block_red<false>(wc, sm) * invB;
   cl = block_red<false>(cl, sm) * invB;
-  // d chi_loss / d ell_i = s_i (1 + (ell_i - chi_loss) / tau'): `weights` is not detached (coptidice.py:165,173)
+  // this rank's rows: weighted_c share and d chi_loss / d ell_i = s_i (1 + (ell_i - chi_loss) / tau') -- `weights` is
+  // not detached in the reference (coptidice.py:165,173)
+  const int row0 = a.row0;
+  float wc = 0.f;
   for (int b = threadIdx.x; b < B; b += kRed) {
-    const float s = expf(a.ell[b] / tau - mx - lse);
-    const float dl = s * (1.f + (a.ell[b] - cl) / tau);
+    const float l = ell[row0 + b];
+    const float sft = expf(l / tau - mx - lse);
+    wc += sft * (float)Bg * a.w[b] * a.cost[b];
+    const float dl = sft * (1.f + (l - cl) / tau);
     int i1, i2;
     net_min(a.chi2, a.n_chi, 2 * B, b, &i1);
     net_min(a.chi2, a.n_chi, 2 * B, B + b, &i2);
@@ -186,11 +210,12 @@ __global__ __launch_bounds__(kRed) void dice_chi_kernel(ChiArgs a) {
       a.dchi[(size_t)k * 2 * B + B + b] = k == i2 ? dn : 0.f;
     }
   }
+  wc = block_red<false>(wc, sm) * invB;
   if (threadIdx.x == 0) {
-    a.work[2] = wc;
-    a.stat[0] = cl;
-    a.stat[1] = tau * (a.eps_ub - dkl);  // tau_loss (coptidice.py:180)
-    a.stat[2] = dkl;
+    a.work[2] = wc;  // data parallel: this rank's share (all-reduced by the caller)
+    a.stat[0] = cl * a.stat_share;
+    a.stat[1] = tau * (a.eps_ub - dkl) * a.stat_share;  // tau_loss (coptidice.py:180)
+    a.stat[2] = dkl * a.stat_share;
     scalar_adam(a.leaves + 0, sigmoid(a.leaves[0]) * (a.eps_ub - dkl), a.scalar_lr, a.st);
   }
 }
@@ -202,6 +227,7 @@ struct NuArgs {
   const float* done;
   const float* init;
   int n_nu, B, f_type;
+  float inv_rows, stat_share;  // 1 / global batch; share of the global scalars in the all-reduced statistics
   float gamma, alpha, p0, qc_thres, scalar_lr;
   const osrl_step_state_t* st;
   float* leaves;
@@ -214,7 +240,7 @@ struct NuArgs {
 __global__ __launch_bounds__(kRed) void dice_nu_kernel(NuArgs a) {
   __shared__ float sm[20];
   const int B = a.B;
-  const float invB = 1.f / (float)B;
+  const float invB = a.inv_rows;
   float df = 0.f, td = 0.f, nl = 0.f;
   for (int b = threadIdx.x; b < B; b += kRed) {
     int i1, i2;
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(kRed) void dice_nu_kernel(NuArgs a) {
     const float x = e / a.alpha;
     const float dwde = g_fn(a.f_type, x) > 0.f ? g_prime(a.f_type, x) / a.alpha : 0.f;
     const float de = (w + (e - a.alpha * f_prime(a.f_type, w)) * dwde) * invB;
-    const float ds = (1.f - a.gamma) * a.init[b] / (a.p0 * (float)B) - de;
+    const float ds = (1.f - a.gamma) * a.init[b] * invB / a.p0 - de;
     const float dn = de * a.gamma * (1.f - a.done[b]);
     for (int k = 0; k < a.n_nu; ++k) {
       a.dnu[(size_t)k * 2 * B + b] = k == i1 ? ds : 0.f;
@@ -244,9 +270,9 @@ __global__ __launch_bounds__(kRed) void dice_nu_kernel(NuArgs a) {
     a.stat[0] = df;
     a.stat[1] = td;
     a.stat[2] = nl;
-    a.stat[3] = lam * (a.qc_thres - wc);  // lmbda_loss (coptidice.py:197)
-    a.stat[5] = a.work[1];                // tau' and lambda' of the top of the step (coptidice.py:229-230)
-    a.stat[6] = lam;
+    a.stat[3] = lam * (a.qc_thres - wc) * a.stat_share;  // lmbda_loss (coptidice.py:197)
+    a.stat[5] = a.work[1] * a.stat_share;  // tau' and lambda' of the top of the step (coptidice.py:229-230)
+    a.stat[6] = lam * a.stat_share;
     scalar_adam(a.leaves + 3, sigmoid(a.leaves[3]) * (a.qc_thres - wc), a.scalar_lr, a.st);
   }
 }
@@ -262,10 +288,9 @@ __global__ void dice_perturb_kernel(const float* __restrict__ x, const float* __
 
 // actor_loss = -mean(w * sum_k Normal(mu, sigma).log_prob(a)) on the PRE-tanh Gaussian (coptidice.py:207-215)
 __global__ __launch_bounds__(kRed) void dice_actor_kernel(const float* __restrict__ head, const float* __restrict__ act,
-                                                          const float* __restrict__ w, int B, int ad,
+                                                          const float* __restrict__ w, int B, int ad, float invB,
                                                           float* __restrict__ dhead, float* __restrict__ stat) {
   __shared__ float sm[20];
-  const float invB = 1.f / (float)B;
   float loss = 0.f;
   for (int b = threadIdx.x; b < B; b += kRed) {
     float lp = 0.f;
@@ -302,30 +327,55 @@ extern "C" int osrl_dice_optimal_w(const float* nu2, int32_t n_nu, int32_t rows,
   return (int)hipGetLastError();
 }
 
+static bool chi_args(ChiArgs* a, const float* chi2, int32_t n_chi, int32_t rows, const float* w, const float* cost,
+                     const float* done, const float* is_init, float gamma, float p0, float* ell) {
+  if (!chi2 || !w || !cost || !done || !is_init || !ell || rows < 1 || n_chi < 1 || !(p0 > 0.f)) return false;
+  *a = ChiArgs{};
+  a->chi2 = chi2; a->w = w; a->cost = cost; a->done = done; a->init = is_init;
+  a->n_chi = n_chi; a->B = rows; a->gamma = gamma; a->p0 = p0; a->ell = ell;
+  return true;
+}
+
+extern "C" int osrl_dice_chi_ell(const float* chi2, int32_t n_chi, int32_t rows, const float* w, const float* cost,
+                                 const float* done, const float* is_init, float gamma, float init_state_propotion,
+                                 float* ell, void* stream) {
+  ChiArgs a;
+  if (!chi_args(&a, chi2, n_chi, rows, w, cost, done, is_init, gamma, init_state_propotion, ell)) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(dice_chi_ell_kernel, dim3((rows + 255) / 256), dim3(256), 0, S, a);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osrl_dice_chi_step(const float* chi2, int32_t n_chi, int32_t rows, const float* w, const float* cost,
                                   const float* done, const float* is_init, float gamma, float init_state_propotion,
                                   float cost_ub_epsilon, float scalar_lr, const osrl_step_state_t* st, float* leaves,
-                                  float* work, float* ell_ws, float* dchi, float* stat, void* stream) {
+                                  float* work, float* ell_ws, float* dchi, const float* ell_all, int32_t rows_global,
+                                  int32_t row0, float stat_share, float* stat, void* stream) {
   if (!w || !cost || !done || !is_init || !st || !leaves || !work || !stat || rows < 1) return -1;
   if (chi2 && (!ell_ws || !dchi || n_chi < 1 || !(init_state_propotion > 0.f))) return -1;
+  if (ell_all && (rows_global < rows || row0 < 0 || row0 + rows > rows_global)) return -1;
   (void)hipGetLastError();
-  ChiArgs a{chi2, w, cost, done, is_init, n_chi, rows, gamma, init_state_propotion, cost_ub_epsilon, scalar_lr, st,
-            leaves, work, ell_ws, dchi, stat};
+  ChiArgs a{};
+  a.chi2 = chi2; a.w = w; a.cost = cost; a.done = done; a.init = is_init;
+  a.n_chi = n_chi; a.B = rows; a.gamma = gamma; a.p0 = init_state_propotion; a.eps_ub = cost_ub_epsilon;
+  a.scalar_lr = scalar_lr; a.st = st; a.leaves = leaves; a.work = work; a.ell = ell_ws; a.dchi = dchi; a.stat = stat;
+  a.ell_all = ell_all; a.row0 = ell_all ? row0 : 0; a.stat_share = stat_share;
+  a.Bg = ((ell_all || !chi2) && rows_global > rows) ? rows_global : rows;  // (no chi: this rank's share of mean(w c))
   hipLaunchKernelGGL(dice_chi_kernel, dim3(1), dim3(kRed), 0, S, a);
   return (int)hipGetLastError();
 }
 
 extern "C" int osrl_dice_nu_step(const float* nu2, int32_t n_nu, int32_t rows, const float* e, const float* w,
                                  const float* done, const float* is_init, int32_t f_type, float gamma, float alpha,
-                                 float init_state_propotion, float qc_thres, float scalar_lr,
-                                 const osrl_step_state_t* st, float* leaves, const float* work, float* dnu, float* stat,
-                                 void* stream) {
+                                 float init_state_propotion, float qc_thres, float scalar_lr, int32_t rows_global,
+                                 float stat_share, const osrl_step_state_t* st, float* leaves, const float* work,
+                                 float* dnu, float* stat, void* stream) {
   if (!nu2 || !e || !w || !done || !is_init || !st || !leaves || !work || !dnu || !stat || rows < 1 || n_nu < 1 ||
       !(init_state_propotion > 0.f) || f_type < OSRL_F_CHI2 || f_type > OSRL_F_KL)
     return -1;
   (void)hipGetLastError();
-  NuArgs a{nu2, e, w, done, is_init, n_nu, rows, f_type, gamma, alpha, init_state_propotion, qc_thres, scalar_lr, st,
-           leaves, work, dnu, stat};
+  NuArgs a{nu2, e, w, done, is_init, n_nu, rows, f_type, 1.0f / (float)(rows_global > 0 ? rows_global : rows),
+           stat_share, gamma, alpha, init_state_propotion, qc_thres, scalar_lr, st, leaves, work, dnu, stat};
   hipLaunchKernelGGL(dice_nu_kernel, dim3(1), dim3(kRed), 0, S, a);
   return (int)hipGetLastError();
 }
@@ -340,9 +390,10 @@ extern "C" int osrl_dice_perturb(const float* x, const float* eps, const float* 
 }
 
 extern "C" int osrl_dice_actor_loss(const float* head, const float* act, const float* w, int32_t rows, int32_t ad,
-                                    float* dhead, float* stat, void* stream) {
+                                    int32_t rows_global, float* dhead, float* stat, void* stream) {
   if (!head || !act || !w || !dhead || !stat || rows < 1 || ad < 1) return -1;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(dice_actor_kernel, dim3(1), dim3(kRed), 0, S, head, act, w, rows, ad, dhead, stat);
+  hipLaunchKernelGGL(dice_actor_kernel, dim3(1), dim3(kRed), 0, S, head, act, w, rows, ad,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), dhead, stat);
   return (int)hipGetLastError();
 }

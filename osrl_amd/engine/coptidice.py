@@ -6,7 +6,10 @@ extraction :204-217.  The nu and chi ensembles read the stacked rows ``[obs; nex
 forward per network serves the s and the s' terms and one backward + dW pass serves both gradients.
 
 Batch-global statistics (the softmax over the batch in the chi loss, every mean) are computed by single-workgroup
-kernels; a data-parallel version would have to all-gather ``ell`` and is not wired: ``dist`` raises.
+kernels.  Data parallel (``dist``): every 1/B is the global batch; each rank all-gathers its ``ell`` rows so that the
+softmax statistics (D_kl, chi_loss, the weights) are the GLOBAL ones on every rank (the scalar leaves tau / lmbda then
+step identically everywhere); collectives per step: the ell gather, [chi grads | weighted_c share], nu grads,
+[actor grads | statistics].
 """
 from __future__ import annotations
 
@@ -25,13 +28,13 @@ F_TYPES = {"chi2": 0, "softchi": 1, "kl": 2}  # include/osrl_amd.h OSRL_F_*
 
 
 class COptiDICEEngine:
-    def __init__(self, model, batch_size: int, seed: int = 0, dist=None):
-        if dist is not None:
-            raise NotImplementedError("COptiDICE's chi loss takes a softmax over the global batch; the data-parallel "
-                                      "exchange for it is not wired")
+    def __init__(self, model, batch_size: int, rows_global: int = 0, seed: int = 0, dist=None):
         m = self.model = model
         B = self.B = int(batch_size)
-        self.seed = seed
+        self.seed, self.dist = seed, dist
+        self.rows_global = int(rows_global) if dist is not None else 0
+        if dist is not None and self.rows_global != B * dist.world:
+            raise ValueError("data parallel COptiDICE needs rows_global = batch_size * world (equal shards)")
         dev = torch.device(m.device)
         od, ad = m.state_dim, m.action_dim
         f = dict(dtype=torch.float32, device=dev)
@@ -71,9 +74,13 @@ class COptiDICEEngine:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
 
-    def _adam(self, name: str, plan: DwPlan) -> None:
+    def _adam(self, name: str, plan: DwPlan, extra=()) -> None:
+        """dW, (data parallel: all-reduce of the flat gradient and of ``extra`` in one collective), Adam."""
         plan.launch()
-        self.model.groups[name].adam_step(self.model._lrs[name], self.st.ptr)
+        grp = self.model.groups[name]
+        if self.dist is not None:
+            self.dist.all_reduce_many_([self.dist.reduce_local(grp), *extra])
+        grp.adam_step(self.model._lrs[name], self.st.ptr)
 
     def body(self, device_noise: bool) -> None:
         m, st, B, lib = self.model, self.st, self.B, L.load()
@@ -81,6 +88,8 @@ class COptiDICEEngine:
         nn_, nc, ft = m.num_nu, m.num_chi, F_TYPES[m.f_type]
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         s = cur_stream
+        dp, rg = self.dist, self.rows_global
+        share = 1.0 if dp is None else 1.0 / dp.world
         st.tick()
         if self.replay is not None:  # TransitionDataset(state_init=True) + DataLoader + H2D, folded into the step
             self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done, self.init), st.ptr)
@@ -93,17 +102,27 @@ class COptiDICEEngine:
                                         p(self.work), 0, float(m.alpha), float(m.gamma), ft, p(self.e), p(self.w), s()),
                 "osrl_dice_optimal_w")
         chi2 = self.r_chi.forward(self.x2) if self.use_chi else None
+        ell_all = None
+        if dp is not None and self.use_chi:  # the softmax of the chi loss runs over the GLOBAL batch
+            L.check(lib.osrl_dice_chi_ell(p(chi2), nc, B, p(self.w), p(self.cost), p(self.done), p(self.init),
+                                          float(m.gamma), float(m.init_state_propotion), p(self.ell), s()),
+                    "osrl_dice_chi_ell")
+            ell_all = dp.all_gather_concat(self.ell)
         L.check(lib.osrl_dice_chi_step(p(chi2), nc, B, p(self.w), p(self.cost), p(self.done), p(self.init),
                                        float(m.gamma), float(m.init_state_propotion), float(m.cost_ub_epsilon),
                                        float(m.scalar_lr), st.ptr, p(leaves), p(self.work), p(self.ell),
-                                       p(self.dchi) if self.use_chi else None, st.stat_ptr("loss/chi_loss"), s()),
+                                       p(self.dchi) if self.use_chi else None, p(ell_all), rg,
+                                       0 if dp is None else dp.rank * B, share, st.stat_ptr("loss/chi_loss"), s()),
                 "osrl_dice_chi_step")
+        wc = self.work[2:3]  # this rank's share of weighted_c -> global
         if self.use_chi:
             self.r_chi.backward_dz()
-            self._adam("chi_network", self.p_chi)
+            self._adam("chi_network", self.p_chi, extra=(wc,) if dp is not None else ())
+        elif dp is not None:
+            dp.all_reduce_(wc)
         L.check(lib.osrl_dice_nu_step(p(nu2), nn_, B, p(self.e), p(self.w), p(self.done), p(self.init), ft,
                                       float(m.gamma), float(m.alpha), float(m.init_state_propotion), float(m.qc_thres),
-                                      float(m.scalar_lr), st.ptr, p(leaves), p(self.work), p(self.dnu),
+                                      float(m.scalar_lr), rg, share, st.ptr, p(leaves), p(self.work), p(self.dnu),
                                       st.stat_ptr("loss/Df"), s()), "osrl_dice_nu_step")
         self.r_nu.backward_dz()
         self._adam("nu_network", self.p_nu)
@@ -118,10 +137,10 @@ class COptiDICEEngine:
         L.check(lib.osrl_dice_optimal_w(p(nu2b), nn_, B, p(self.rew), p(self.cost), p(self.done), p(leaves),
                                         p(self.work), 1, float(m.alpha), float(m.gamma), ft, None, p(self.w2), s()),
                 "osrl_dice_optimal_w")
-        L.check(lib.osrl_dice_actor_loss(p(head), p(self.act_n), p(self.w2), B, ad, p(self.dhead),
+        L.check(lib.osrl_dice_actor_loss(p(head), p(self.act_n), p(self.w2), B, ad, rg, p(self.dhead),
                                          st.stat_ptr("loss/actor_loss"), s()), "osrl_dice_actor_loss")
         self.r_actor.backward_dz()
-        self._adam("actor", self.p_actor)
+        self._adam("actor", self.p_actor, extra=(st.stats,) if dp is not None else ())
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done, is_init) -> None:
         for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
@@ -169,7 +188,7 @@ class COptiDICEEngine:
 
     def step_replay(self, use_graph: bool = True) -> None:
         assert self.replay is not None
-        if use_graph:
+        if use_graph and self.dist is None:
             if self.graph is None:
                 self.capture()
             self.graph.replay()
@@ -187,7 +206,7 @@ class COptiDICEEngine:
                 self.noise[k].copy_(torch.as_tensor(noise[k]).reshape(self.noise[k].shape), non_blocking=True)
             self.body(False)
             return
-        if use_graph:
+        if use_graph and self.dist is None:
             if self.graph is None:
                 self.capture()
             self.graph.replay()

@@ -68,7 +68,7 @@ class DataParallel:
             for buf in (g.p, g.m, g.v, g.tgt):
                 if buf is not None:
                     dist.broadcast(buf, src=0, group=self.group)
-        for name in ("log_alpha", "pid_state", "log_temperature"):
+        for name in ("log_alpha", "pid_state", "log_temperature", "scalar_leaves"):
             if isinstance(getattr(model, name, None), torch.Tensor):
                 dist.broadcast(getattr(model, name), src=0, group=self.group)
         model.repack()  # the kernels read fragment-ordered copies of the weights: refresh them from the new values

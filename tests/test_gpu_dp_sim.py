@@ -78,6 +78,12 @@ DP_CASES = {
     "bearl": Case("dp_bearl", "bearl", od=4, ad=2, B=32, hidden=[24, 24], vae_hidden=32, N=3, num_q=1, num_qc=2, steps=3,
                   episode_len=200, cost_limit=-4.0, seed=9, hp=dict(M=4, kernel="laplacian", mmd_sigma=1.5, alpha_lr=0.05)),
     "bc": Case("dp_bc", "bc", od=8, ad=2, B=32, hidden=[32, 32], steps=3, seed=10),
+    # COptiDICE: the chi loss takes a softmax over the GLOBAL batch (all-gathered ell); with and without the chi net
+    "coptidice": Case("dp_dice", "coptidice", od=5, ad=2, B=32, hidden=[24, 24], steps=3, episode_len=200, seed=11,
+                      hp=dict(actor_lr=1e-3, critic_lr=1e-3, scalar_lr=1e-2)),
+    "coptidice_nochi": Case("dp_dice0", "coptidice", od=5, ad=2, B=32, hidden=[24, 24], num_q=1, num_qc=2, steps=3,
+                            episode_len=200, cost_limit=40.0, seed=12,
+                            hp=dict(f_type="kl", cost_ub_epsilon=0.0, actor_lr=1e-3, critic_lr=1e-3, scalar_lr=1e-2)),
 }
 
 
@@ -88,17 +94,17 @@ def test_world2_sharded_step_equals_concatenated_batch(algo):
     Bl = B // W
     batch = make_batch(c)
     keys = ("observations", "actions") if algo == "bc" else \
-        ("observations", "next_observations", "actions", "rewards", "costs", "done")
+        ("observations", "next_observations", "actions", "rewards", "costs", "done") + \
+        (("is_init",) if c.algo == "coptidice" else ())
+    step = (lambda tr, args, nz: tr.train_one_step(list(args), noise=nz)) if c.algo == "coptidice" else \
+        (lambda tr, args, nz: tr.train_one_step(*args) if algo == "bc" else tr.train_one_step(*args, noise=nz))
     t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
 
     # single device, concatenated batch
     m1, tr1, lg1 = build_gpu(c)
     for s in range(c.steps):
         nz = {k: t(v) for k, v in make_noise(c, s).items()}
-        if algo == "bc":
-            tr1.train_one_step(*[t(batch[k]) for k in keys])
-        else:
-            tr1.train_one_step(*[t(batch[k]) for k in keys], noise=nz)
+        step(tr1, [t(batch[k]) for k in keys], nz)
     torch.cuda.synchronize()
 
     # two replicas, each on its half
@@ -113,11 +119,8 @@ def test_world2_sharded_step_equals_concatenated_batch(algo):
                 m.engine(Bl, rows_global=B, dist=sim)
                 args = [t(batch[k][r * Bl:(r + 1) * Bl]) for k in keys]
                 for s in range(c.steps):
-                    if algo == "bc":
-                        tr.train_one_step(*args)
-                    else:
-                        nz = {k: t(_shard(v, k, r, W, B, N, M)) for k, v in make_noise(c, s).items()}
-                        tr.train_one_step(*args, noise=nz)
+                    nz = {k: t(_shard(v, k, r, W, B, N, M)) for k, v in make_noise(c, s).items()}
+                    step(tr, args, nz)
                 torch.cuda.current_stream().synchronize()
         except BaseException as e:  # noqa: BLE001
             shared.errors.append((r, repr(e)))
@@ -138,7 +141,7 @@ def test_world2_sharded_step_equals_concatenated_batch(algo):
         for k, v in m.state_dict().items():
             d = np.abs(v.detach().cpu().numpy() - sd1[k]).max()
             assert d <= 2e-5, f"{algo} rank {r} param {k}: sharded vs concatenated differ by {d:.3e}"
-        for name in ("log_alpha", "pid_state"):
+        for name in ("log_alpha", "pid_state", "scalar_leaves"):
             if hasattr(m, name):
                 a, b = getattr(m, name).cpu().numpy(), getattr(m1, name).cpu().numpy()
                 assert np.abs(a - b).max() <= 1e-5, (algo, r, name, a, b)

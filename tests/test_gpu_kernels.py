@@ -530,7 +530,43 @@ def test_dice_chi_step_kernel(B, n_chi, scale):
     c2, wt, ct, dt_, it = tt(chi2), tt(w), tt(cost), tt(done), tt(init)
     L.check(lib.osrl_dice_chi_step(c2.data_ptr(), n_chi, B, wt.data_ptr(), ct.data_ptr(), dt_.data_ptr(), it.data_ptr(),
                                    gamma, p0, eps_ub, lr, st.ptr, leaves.data_ptr(), work.data_ptr(), ell_ws.data_ptr(),
-                                   dchi.data_ptr(), st.stats.data_ptr(), cur_stream()), "chi")
+                                   dchi.data_ptr(), None, 0, 0, 1.0, st.stats.data_ptr(), cur_stream()), "chi")
+    if B % 2 == 0 or B > 100:
+        # data-parallel form: two "ranks" hold the halves, ell is gathered, every rank sees the global statistics
+        # (x share 1/2) and the gradient of its own rows
+        h = B // 2
+        parts = [(0, h), (h, B - h)]
+        ells = []
+        keep = []
+        for r0, n in parts:
+            sub = np.concatenate([chi2[:, r0:r0 + n], chi2[:, B + r0:B + r0 + n]], 1).copy()
+            e_r = torch.zeros(n, device=dev)
+            args = (tt(sub), tt(w[r0:r0 + n]), tt(cost[r0:r0 + n]), tt(done[r0:r0 + n]), tt(init[r0:r0 + n]))
+            L.check(lib.osrl_dice_chi_ell(args[0].data_ptr(), n_chi, n, args[1].data_ptr(), args[2].data_ptr(),
+                                          args[3].data_ptr(), args[4].data_ptr(), gamma, p0, e_r.data_ptr(),
+                                          cur_stream()), "ell")
+            ells.append(e_r)
+            keep.append(args)
+        ell_all = torch.cat(ells)
+        wc_sum, stats_sum = 0.0, np.zeros(3)
+        for (r0, n), args, e_r in zip(parts, keep, ells):
+            lv = tt(np.array([0.4, 0, 0, 1.0, 0, 0], np.float32))
+            wk = tt(np.array([1.3, tau_p, 0, 0], np.float32))
+            st2 = StepState(dev, ["a", "b", "c"])
+            st2.tick()
+            dc = torch.zeros(n_chi, 2 * n, device=dev)
+            L.check(lib.osrl_dice_chi_step(args[0].data_ptr(), n_chi, n, args[1].data_ptr(), args[2].data_ptr(),
+                                           args[3].data_ptr(), args[4].data_ptr(), gamma, p0, eps_ub, lr, st2.ptr,
+                                           lv.data_ptr(), wk.data_ptr(), e_r.data_ptr(), dc.data_ptr(), ell_all.data_ptr(),
+                                           B, r0, 0.5, st2.stats.data_ptr(), cur_stream()), "chi dp")
+            wc_sum += wk[2].item()
+            stats_sum += st2.stats.cpu().numpy()
+            full = dchi.cpu().numpy()
+            np.testing.assert_allclose(dc.cpu().numpy()[:, :n], full[:, r0:r0 + n], rtol=2e-4, atol=1e-7 * max(1, scale))
+            np.testing.assert_allclose(dc.cpu().numpy()[:, n:], full[:, B + r0:B + r0 + n], rtol=2e-4, atol=1e-7 * max(1, scale))
+            assert abs(lv[0].item() - leaves[0].item()) < 1e-6  # every rank steps tau identically
+        np.testing.assert_allclose(stats_sum, st.stats.cpu().numpy(), rtol=2e-4, atol=1e-6)
+        assert abs(wc_sum - work[2].item()) <= 2e-4 * max(1.0, abs(work[2].item()))
     c64 = chi2.astype(np.float64)
     i_s, i_n = c64[:, :B].argmin(0), c64[:, B:].argmin(0)
     cs, cn = c64[:, :B].min(0), c64[:, B:].min(0)
