@@ -87,6 +87,19 @@ class ReplayStore:
                                             st_ptr, cur_stream()), "osrl_replay_gather")
 
 
+    def gather_fields(self, fields: Sequence[int], dst: Sequence[torch.Tensor], st_ptr: Optional[int],
+                      stream_id: int = 1) -> None:
+        """The same draw as ``gather`` (the row indices are a function of (seed, step, row) only) restricted to some
+        of the tables -- (0, 2) = observations, actions is all BC reads (train_bc.py:121)."""
+        n, B = len(fields), dst[0].shape[0]
+        src = (C.c_void_p * n)(*[self.tables[i].data_ptr() for i in fields])
+        d = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
+        w = (C.c_int32 * n)(*[self.widths[i] for i in fields])
+        sc = (C.c_float * n)(*[self.scales[i] for i in fields])
+        L.check(L.load().osrl_replay_gather(n, src, d, w, sc, self.n_rows, B, None, self.seed, stream_id, st_ptr,
+                                            cur_stream()), "osrl_replay_gather")
+
+
 def synthetic_transitions(n: int, od: int, ad: int, seed: int = 1, max_action: float = 1.0) -> Dict[str, np.ndarray]:
     """Synthetic DSRL-shaped data: obs~N(0,1), act~U(-1,1), rew~N(0,1), cost~Bern(.1),
     terminals~Bern(.01)."""

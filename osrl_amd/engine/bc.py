@@ -29,10 +29,32 @@ class BCEngine:
         self.r_pi.setup_backward(self.du)
         self.plan = DwPlan(m.groups["actor"], self.r_pi.dw_entries(), B, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.replay = None
+
+    def attach_replay(self, store) -> None:
+        """Sample (observations, actions) minibatches on device from ``store`` (common/replay.py) inside the step:
+        TransitionDataset + DataLoader + H2D of train_bc.py:105-121 folded into the captured graph."""
+        if store is not None and store.widths[0] != self.obs.shape[1]:
+            raise ValueError(f"the store's observations have {store.widths[0]} columns, the policy reads "
+                             f"{self.obs.shape[1]} (bc_mode='multi-task' appends the cost return: process_bc_dataset)")
+        self.replay = store
+        self.graph = None
+
+    def step_replay(self, use_graph: bool = True) -> None:
+        assert self.replay is not None
+        if use_graph and self.dist is None:
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
+            self.st.host_step += 1
+        else:
+            self.body()
 
     def body(self) -> None:
         m, B, ad = self.model, self.B, self.model.action_dim
         self.st.tick()
+        if self.replay is not None:
+            self.replay.gather_fields((0, 2), (self.obs, self.act), self.st.ptr)
         pred = self.r_pi.forward(self.obs)[0]
         ng = (self.rows_global or B) * ad
         G.mse_loss(pred, self.act, B * ad, ng, self.du, self.st.stat_ptr("loss/actor_loss"))
@@ -46,6 +68,8 @@ class BCEngine:
             self.dist.all_reduce_(self.st.stats)
 
     def step(self, observations, actions, use_graph: bool = True) -> None:
+        if self.replay is not None:
+            raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.obs.copy_(torch.as_tensor(observations).reshape(self.obs.shape), non_blocking=True)
         self.act.copy_(torch.as_tensor(actions).reshape(self.act.shape), non_blocking=True)
         if use_graph and self.dist is None:

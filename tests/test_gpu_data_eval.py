@@ -552,3 +552,69 @@ def test_ingest_scan_beyond_one_offset_chunk():
     keep = np.flatnonzero(cr >= 8.0)
     assert np.array_equal(_np(out["index"]), keep) and 0 < len(keep) < n
     assert np.array_equal(_np(out["observations"])[:, 0], full["observations"][keep, 0])
+
+
+# --------------------------------------------------------------------------- #
+# end to end on device: dataset ingestion -> resident store -> training -> batched evaluate -> checkpoint
+# --------------------------------------------------------------------------- #
+def _expert_dataset(env, n_ep, seed):
+    """Episodes of a noisy goal-seeking controller on the synthetic env (DSRL-shaped dict)."""
+    rs = np.random.RandomState(seed)
+    obs, nobs, act, rew, cost, term, tout = [], [], [], [], [], [], []
+    pinv = np.linalg.pinv(env.Bm)
+    for e in range(n_ep):
+        o, _ = env.reset(seed=1000 + e)
+        noise = 0.1 if e % 2 == 0 else 1.5  # careful and sloppy demonstrators: episode costs from 0 to ~10
+        for t in range(env.episode_len):
+            a = np.clip(pinv @ (env.goal - env.A @ o) + noise * rs.randn(env.action_dim), -1, 1).astype(np.float32)
+            o2, r, te, tr_, info = env.step(a)
+            obs.append(o); nobs.append(o2); act.append(a); rew.append(r); cost.append(info["cost"])
+            term.append(0.0); tout.append(float(tr_))
+            o = o2
+    f = np.float32
+    return dict(observations=np.array(obs, f), next_observations=np.array(nobs, f), actions=np.array(act, f),
+                rewards=np.array(rew, f), costs=np.array(cost, f), terminals=np.array(term, f), timeouts=np.array(tout, f))
+
+
+def test_end_to_end_bc_safe_on_device(tmp_path):
+    """BC-Safe as train_bc.py runs it, entirely on device: process_bc_dataset(mode="safe") -> ReplayStore -> BC steps
+    drawing their minibatches inside the captured graph -> batched evaluate -> checkpoint round trip.  The cloned
+    policy must beat the untrained one on the synthetic env, and the reloaded model must evaluate identically."""
+    from osrl_amd.algorithms import BC, BCTrainer
+    from osrl_amd.common.checkpoint import load_checkpoint, save_checkpoint
+    from osrl_amd.common.ingest import process_bc_dataset
+    from osrl_amd.common.logger import DummyLogger
+    from osrl_amd.common.replay import ReplayStore
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    od, ad, EL = 6, 2, 30
+    env = SyntheticSafeEnv(od, ad, EL, seed=6, init_noise=0.5)
+    data = _expert_dataset(env, 120, 0)
+    safe = process_bc_dataset(data, cost_limit=1.0, gamma=1.0, bc_mode="safe", device=DEV)
+    n_safe = int(safe["index"].shape[0])
+    assert 0 < n_safe < len(data["rewards"]) and n_safe % EL == 0  # whole episodes are kept or dropped
+    store = ReplayStore({k: safe[k] for k in ("observations", "next_observations", "actions", "rewards", "costs",
+                                              "terminals", "timeouts")}, DEV, seed=1)
+    torch.manual_seed(0)
+    m = BC(od, ad, 1.0, [64, 64], EL, device=DEV)
+    tr = BCTrainer(m, None, DummyLogger(), actor_lr=3e-3, device=DEV, stats_mode="none")
+    tr.env = VecSyntheticSafeEnv(env, 32, DEV, base_seed=5000)
+    before = tr.evaluate(32)
+    eng = m.engine(256)
+    eng.attach_replay(store)
+    for _ in range(400):
+        eng.step_replay()
+    torch.cuda.synchronize()
+    assert eng.graph is not None and eng.st.device_step() == 400
+    loss = eng.st.read_stats()["loss/actor_loss"]
+    after = tr.evaluate(32)
+    assert loss < 0.05 and after[0] > before[0] + 1.0, (loss, before, after)
+    path = str(tmp_path / "bc.pt")
+    save_checkpoint(m, path)
+    torch.manual_seed(1)
+    m2 = BC(od, ad, 1.0, [64, 64], EL, device=DEV)
+    tr2 = BCTrainer(m2, None, DummyLogger(), actor_lr=3e-3, device=DEV)
+    load_checkpoint(m2, path)
+    tr2.env = tr.env
+    assert tr2.evaluate(32) == after
+    with pytest.raises(RuntimeError):
+        eng.step(safe["observations"][:256], safe["actions"][:256])
