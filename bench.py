@@ -164,6 +164,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: everything else any library writes to fd 1 (RCCL prints a version
+    # banner through C stdio, flushed only at exit, i.e. AFTER a Python-level print) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -241,7 +246,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp is not None:
         import torch.distributed as dist
         barrier()  # rank 0 is still timing its roofline kernel: nobody tears the communicator down before it is done
