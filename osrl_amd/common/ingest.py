@@ -8,7 +8,7 @@ tensors), outputs are device tensors.  There is no CPU path: a missing HIP libra
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional, Tuple, Union
+from typing import Dict, Optional, Tuple, Union
 
 import numpy as np
 import torch
