@@ -2,7 +2,9 @@
 episode-by-episode loop (one B=1 policy call + host round trip per env step) and against the CPU oracle policy
 driving the numpy environment.  CPQ at the C2 dimensions (obs 76, act 2, hidden [256,256]).
 
-    python tools/eval_bench.py [--episodes 1024] [--len 200] > profiles/rN_eval_bench.json
+    python tests/bench_eval.py [--episodes 1024] [--len 200] > profiles/rN_eval_bench.json
+
+(Kept under tests/: its CPU leg runs the oracle, which only tests/, smoke() and bench.py's cpu_baseline may use.)
 """
 import argparse
 import json
@@ -14,7 +16,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():

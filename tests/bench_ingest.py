@@ -1,7 +1,9 @@
 """One-off dataset ingestion timings: device kernels (csrc/ingest.hip) vs the numpy oracle on the host.
 1 M transitions at the C2 dimensions (obs 76, act 2), ~1000-step episodes.
 
-    python tools/ingest_bench.py > profiles/rN_ingest_bench.json
+    python tests/bench_ingest.py > profiles/rN_ingest_bench.json
+
+(Kept under tests/: its CPU leg runs the oracle, which only tests/, smoke() and bench.py's cpu_baseline may use.)
 """
 import json
 import os
