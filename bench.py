@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- grad-steps/sec of the OSRL CPQ train step on MI355X (BASELINE.json metric).
+"""bench.py -- grad-steps/sec of the OSRL train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5]
 
-Workload (BASELINE.json configs[1]): CPQ, (obs_dim, act_dim) = (76, 2) [OfflinePointGoal1], batch 2048
-per GPU, hidden [256,256], VAE 400, N=10 sampled actions, num_q = num_qc = 2, fp32, train-config
-learning rates -- every phase of CPQTrainer.train_one_step (vae, critic, cost-critic incl. the
-N*B OOD scoring + quantile, actor, Adam x4, Polyak x3) plus the on-device minibatch draw from a
-HBM-resident synthetic transition store and the Gaussian noise generation are INSIDE the timed step.
-One "step" (unit) = one 2048-transition gradient step; with N GPUs the job is data parallel (global
-batch 2048*N, gradient all-reduce over RCCL) so value = N * global-steps/s  ("scaling": "weak").
+N > 1 without a torchrun environment re-executes itself under ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`` (one rank per GPU, RCCL); launched BY torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment as usual.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+Default workload (BASELINE.json configs[1], the one the metric is quoted on): c2 = CPQ, (obs_dim, act_dim) =
+(76, 2) [OfflinePointGoal1], batch 2048 per GPU, hidden [256,256], VAE 400, N=10 sampled actions, num_q = num_qc = 2,
+fp32, train-config learning rates -- every phase of CPQTrainer.train_one_step (vae, critic, cost-critic incl. the
+N*B OOD scoring + quantile, actor, Adam x4, Polyak x3) plus the on-device minibatch draw from a HBM-resident
+synthetic transition store and the Gaussian noise generation are INSIDE the timed step.  The other configs of
+BASELINE.json run with --config: c1 BC (8,2) B=256, c3 BCQ-Lag (33,8) B=4096, c4 CPQ (17,6) 2048 rows per GPU
+(global 16384 at 8 GPUs), c5 CDT (11,3) T=20 E=256 8 heads 3 layers B=1024.
+
+Unit: one step = one gradient step on one GPU's batch.  With N GPUs the job is data parallel (global batch = N x
+per-GPU batch, one optimizer step per iteration, gradient all-reduce over RCCL), so ``value`` = N x optimizer-steps/s
+= per-GPU-batch gradient steps per second over the whole job ("scaling": "weak"); ``optimizer_steps_per_s`` and
+``transitions_per_s`` are printed beside it.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` and ``cpu_baseline``.
 Nothing here reads /root/reference.
 """
 from __future__ import annotations
@@ -20,6 +28,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,36 +38,158 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OD, AD, B, HID, VAE_H, NS = 76, 2, 2048, [256, 256], 400, 10
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
+HID, VAE_H, NS = [256, 256], 400, 10
+
+# BASELINE.json configs -> shapes ("Config shorthand")
+CONFIGS = {
+    "c1": dict(algo="bc", od=8, ad=2, B=256, episode_len=300,
+               desc="BC-Safe train_one_step, OfflineCarCircle-shaped (obs 8, act 2), batch 256/GPU, MLP [256,256]"),
+    "c2": dict(algo="cpq", od=76, ad=2, B=2048, episode_len=1000,
+               desc="CPQ train_one_step, OfflinePointGoal1-shaped (obs 76, act 2), batch 2048/GPU, hidden [256,256], "
+                    "VAE 400, N=10, num_q=num_qc=2"),
+    "c3": dict(algo="bcql", od=33, ad=8, B=4096, episode_len=200,
+               desc="BCQ-Lag train_one_step, OfflineAntRun-shaped (obs 33, act 8), batch 4096/GPU, hidden [256,256], "
+                    "VAE 400, N=10, twin critics + twin cost critics"),
+    "c4": dict(algo="cpq", od=17, ad=6, B=2048, episode_len=1000,
+               desc="CPQ train_one_step, OfflineHalfCheetah-shaped (obs 17, act 6), batch 2048/GPU (global 16384 at 8 "
+                    "GPUs), hidden [256,256], VAE 400, N=10, num_q=num_qc=2"),
+    "c5": dict(algo="cdt", od=11, ad=3, B=1024, episode_len=1000, T=20, E=256, heads=8, layers=3,
+               desc="CDT train_one_step, OfflineHopper-shaped (obs 11, act 3), seq_len 20, embed 256, 8 heads, 3 layers, "
+                    "dropout 0.1, batch 1024/GPU"),
+}
 
 
 def lin(sizes):
     return sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
 
 
-def cpq_flops_per_step(od, ad, Bsz, H, V, N, nq, nqc):
-    """Algorithmic FLOPs of one reference CPQ step (SURVEY.md 8d formula; 1 MAC = 2 FLOP)."""
-    actor = lin([od] + H) + 2 * H[-1] * ad
-    q = lin([od + ad] + H + [1])
-    vae = lin([od + ad, V, V]) + 2 * V * 2 * ad + lin([od + 2 * ad, V, V, ad])
-    step = 3 * vae + (3 * nq * q + actor + nq * q + nqc * q) + \
-        (3 * nqc * q + 2 * actor + nqc * q + N * nqc * q + N * vae) + (3 * actor + 2 * nq * q + nqc * q)
-    return 2.0 * step * Bsz
+def flops_per_step(cfg) -> float:
+    """Algorithmic FLOPs of one reference step on one GPU's batch (SURVEY.md 8d formulas; 1 MAC = 2 FLOP)."""
+    od, ad, Bsz, H, V, N = cfg["od"], cfg["ad"], cfg["B"], HID, VAE_H, NS
+    if cfg["algo"] == "bc":
+        return 2.0 * 3 * lin([od] + H + [ad]) * Bsz
+    if cfg["algo"] == "cpq":
+        nq = nqc = 2
+        actor = lin([od] + H) + 2 * H[-1] * ad
+        q = lin([od + ad] + H + [1])
+        vae = lin([od + ad, V, V]) + 2 * V * 2 * ad + lin([od + 2 * ad, V, V, ad])
+        step = 3 * vae + (3 * nq * q + actor + nq * q + nqc * q) + \
+            (3 * nqc * q + 2 * actor + nqc * q + N * nqc * q + N * vae) + (3 * actor + 2 * nq * q + nqc * q)
+        return 2.0 * step * Bsz
+    if cfg["algo"] == "bcql":
+        nq = nqc = 2
+        actor = lin([od + ad] + H + [ad])
+        q = lin([od + ad] + H + [1])
+        dec = lin([od + 2 * ad, V, V, ad])
+        vae = lin([od + ad, V, V]) + 2 * V * 2 * ad + dec
+        step = 3 * vae + 2 * (3 * 2 * nq * q + N * (dec + actor + 2 * nq * q)) + (dec + 3 * actor + 2 * 2 * nq * q + 2 * 2 * nqc * q)
+        return 2.0 * step * Bsz
+    T, E, Lyr = cfg["T"], cfg["E"], cfg["layers"]
+    per = 3 * (Lyr * (12 * E * E + 2 * (4 * T) * E) * 4 * T + T * (od + ad + 2) * E + T * E * (2 * ad + od + 2))
+    return 2.0 * per * Bsz
 
 
-def build(device, rank, world, seed=0, n_store=1 << 20):
-    from osrl_amd.algorithms import CPQ, CPQTrainer
-    from osrl_amd.common.replay import ReplayStore, synthetic_transitions
-    torch.manual_seed(seed)
-    model = CPQ(OD, AD, 1.0, HID, HID, VAE_H, NS, 0.99, 0.005, 0.5, 2, 2, 1.5, 10, 1000, device=str(device))
-    trainer = CPQTrainer(model, None, None, actor_lr=1e-4, critic_lr=1e-3, alpha_lr=1e-4, vae_lr=1e-3,
-                         reward_scale=0.1, cost_scale=1.0, device=str(device), stats_mode="none")
-    shard = n_store // world
-    store = ReplayStore(synthetic_transitions(shard, OD, AD, seed=1 + rank), device, reward_scale=0.1,
-                        cost_scale=1.0, seed=1, rank=rank, world=1)
-    return model, trainer, store
+class Workload:
+    """One BASELINE config as ``step()`` = one train step on a minibatch drawn on device from a HBM-resident store."""
+
+    def __init__(self, name: str, device, rank: int, world: int, dp, n_store: int = 1 << 20, seed: int = 0,
+                 use_graph: bool = True):
+        from osrl_amd.common.replay import ReplayStore, SequenceStore, synthetic_transitions
+        cfg = self.cfg = CONFIGS[name]
+        self.name, self.device, self.use_graph = name, device, use_graph
+        od, ad, B = cfg["od"], cfg["ad"], cfg["B"]
+        dev = str(device)
+        torch.manual_seed(seed)
+        kw = dict(rows_global=B * world, dist=dp) if dp is not None else {}
+        if cfg["algo"] in ("cpq", "bcql"):
+            kw_seed = dict(seed=1234, **kw) if dp is not None else {}
+        shard = n_store // max(world, 1)
+        if cfg["algo"] == "cpq":
+            from osrl_amd.algorithms import CPQ, CPQTrainer
+            self.model = CPQ(od, ad, 1.0, HID, HID, VAE_H, NS, 0.99, 0.005, 0.5, 2, 2, 1.5, 10, cfg["episode_len"], device=dev)
+            self.trainer = CPQTrainer(self.model, None, None, actor_lr=1e-4, critic_lr=1e-3, alpha_lr=1e-4, vae_lr=1e-3,
+                                      reward_scale=0.1, cost_scale=1.0, device=dev, stats_mode="none")
+            self.eng = self.model.engine(B, **kw_seed)
+        elif cfg["algo"] == "bcql":
+            from osrl_amd.algorithms import BCQL, BCQLTrainer
+            self.model = BCQL(od, ad, 1.0, HID, HID, VAE_H, NS, 0.99, 0.005, 0.05, 0.75, 0.5, [0.1, 0.003, 0.001], 2, 2,
+                              10, cfg["episode_len"], device=dev)
+            self.trainer = BCQLTrainer(self.model, None, None, 1e-3, 1e-3, 1e-3, stats_mode="none")
+            self.eng = self.model.engine(B, **kw_seed)
+        elif cfg["algo"] == "bc":
+            from osrl_amd.algorithms import BC, BCTrainer
+            self.model = BC(od, ad, 1.0, HID, cfg["episode_len"], device=dev)
+            self.trainer = BCTrainer(self.model, None, None, actor_lr=1e-3, stats_mode="none")
+            self.eng = self.model.engine(B, **kw)
+        else:
+            from osrl_amd.algorithms import CDT, CDTTrainer
+            T = cfg["T"]
+            self.model = CDT(od, ad, 1.0, seq_len=T, episode_len=cfg["episode_len"], embedding_dim=cfg["E"],
+                             num_layers=cfg["layers"], num_heads=cfg["heads"], attention_dropout=0.1, residual_dropout=0.1,
+                             embedding_dropout=0.1, use_rew=True, use_cost=True, cost_transform=True, stochastic=True,
+                             target_entropy=-ad, device=dev)
+            self.trainer = CDTTrainer(self.model, None, None, learning_rate=1e-4, weight_decay=1e-4, clip_grad=0.25,
+                                      lr_warmup_steps=500, loss_cost_weight=0.02, stats_mode="none", seed=1234)
+            self.eng = self.model.engine(B, self.trainer.cfg, dist=dp)
+        if cfg["algo"] == "cdt":
+            rs = np.random.RandomState(1 + rank)
+            n_traj, EL = max(64, (shard >> 3) // cfg["episode_len"]), cfg["episode_len"]
+            trajs = []
+            for _ in range(n_traj):
+                c = (rs.uniform(size=EL) < 0.1).astype(np.float32)
+                r = rs.uniform(0, 1, EL).astype(np.float32)
+                trajs.append(dict(observations=rs.randn(EL, od).astype(np.float32),
+                                  actions=rs.uniform(-1, 1, (EL, ad)).astype(np.float32),
+                                  returns=np.cumsum(r[::-1])[::-1].copy(), cost_returns=np.cumsum(c[::-1])[::-1].copy(),
+                                  costs=c))
+            self.store = SequenceStore(trajs, T, device, reward_scale=0.1, cost_scale=1.0, seed=1, rank=rank)
+            self.eng.attach_store(self.store)
+            self._step = lambda: self.eng.step_store(self.use_graph)
+        else:
+            self.store = ReplayStore(synthetic_transitions(shard, od, ad, seed=1 + rank), device, reward_scale=0.1,
+                                     cost_scale=1.0, seed=1, rank=rank, world=1)
+            self.eng.attach_replay(self.store)
+            self._step = lambda: self.eng.step_replay(self.use_graph)
+
+    def step(self) -> None:
+        self._step()
+
+    def api_batch(self):
+        """Device-resident synthetic batch for the Trainer-API path (train_one_step(tensors))."""
+        cfg, dev = self.cfg, self.device
+        B, od, ad = cfg["B"], cfg["od"], cfg["ad"]
+        g = torch.Generator(device="cpu").manual_seed(5)
+        f = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+        u = lambda *s: torch.rand(*s, generator=g).to(dev)  # noqa: E731
+        if cfg["algo"] == "bc":
+            return (f(B, od), (u(B, ad) * 2 - 1))
+        if cfg["algo"] == "cdt":
+            T = cfg["T"]
+            start = torch.randint(0, cfg["episode_len"], (B, 1), generator=g).to(dev)
+            mask = torch.ones(B, T, device=dev)
+            mask[::10, T - 5:] = 0
+            return (f(B, T, od), u(B, T, ad) * 2 - 1, u(B, T) * 10, u(B, T) * 20,
+                    start + torch.arange(T, device=dev)[None], mask, u(B) * 20, (u(B, T) < 0.1).float())
+        return (f(B, od), f(B, od), u(B, ad) * 2 - 1, f(B), (u(B) < 0.1).float(), (u(B) < 0.01).float())
+
+
+def timed_steps(step, steps: int, warmup: int, barrier=None):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 def time_kernel(fn, iters=30):
@@ -80,8 +211,31 @@ def mlp_fwd_flops(run):
     return 2.0 * run.rows * run.net.E * lin(d)
 
 
-def roofline(eng):
-    """Dominant kernels of the step: the two N*B-row forward launches (69% of the step's FLOPs)."""
+def in_step_us(eng, iters=40):
+    """Duration of the dominant launch AS IT RUNS INSIDE THE STEP: the step body is issued eagerly on the same two
+    streams the captured graph uses (main + side branch), with HIP events recorded on the main stream right around
+    the launch, so whatever the side branch runs beside it (the paired 2048-row critic forwards) runs beside it here
+    too.  The rocprofv3 --kernel-trace --stats summary of this command (profiles/) lists the same kernel's average
+    over graph replays."""
+    from osrl_amd.engine.core import Branches
+    par = Branches(True, 1)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    snap = eng._snapshot()
+    try:
+        for i in range(3 + iters):
+            eng._probe = evs[i - 3] if i >= 3 else None
+            eng.body(True, par)
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    finally:
+        eng._probe = None
+        torch.cuda.synchronize()
+        eng._restore(snap)
+    return float(np.mean(ts)), float(ts[len(ts) // 2])
+
+
+def roofline(eng, flops_step: float, ms_per_step: float):
+    """Dominant kernels of the CPQ step: the two N*B-row forward launches (69% of the step's FLOPs)."""
     from osrl_amd import _lib as L
     cands = {
         "mlp_fwd<vae-encoder, N*B rows>": (eng.r_enc_ood, lambda: eng.r_enc_ood.forward(
@@ -93,10 +247,10 @@ def roofline(eng):
     for name, (run, fn) in cands.items():
         t = time_kernel(fn)
         res[name] = dict(seconds=t, flops=mlp_fwd_flops(run))
-    # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows); the other N*B launch
-    # is deliberately throttled in the step (wg_cap: it runs beside the latency-critical VAE phase) and is listed too
+    # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows)
     dom = max(res, key=lambda k: res[k]["flops"])
     ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
+    mean_us, med_us = in_step_us(eng)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -106,6 +260,10 @@ def roofline(eng):
             traffic = None
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+            "isolated_us": round(res[dom]["seconds"] * 1e6, 2),
+            "in_step_us": round(mean_us, 2), "in_step_us_median": round(med_us, 2),
+            "in_step_frac": round(res[dom]["flops"] / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
+            "step_frac": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
             "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2),
                             "wg_cap": int(cands[k][0].fwd_c.wg_cap)}
                         for k, v in res.items()}}
@@ -117,7 +275,9 @@ def cpu_baseline(budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cases import Case, make_batch, make_noise
     from oracle_util import build_oracle
-    c = Case("bench_c2", "cpq", od=OD, ad=AD, B=B, hidden=HID, vae_hidden=VAE_H, N=NS, steps=1, episode_len=1000)
+    cfg = CONFIGS["c2"]
+    c = Case("bench_c2", "cpq", od=cfg["od"], ad=cfg["ad"], B=cfg["B"], hidden=HID, vae_hidden=VAE_H, N=NS, steps=1,
+             episode_len=1000)
     o = build_oracle(c)
     b, nz = make_batch(c), make_noise(c, 0)
     args = (b["observations"], b["next_observations"], b["actions"], b["rewards"], b["costs"], b["done"], nz)
@@ -155,15 +315,29 @@ def cpu_baseline(budget_s=20.0):
                       f"{probe[min(cands)][0] / probe[min(cands)][1]:.2f} steps/s at {min(cands)})"}
 
 
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip api_path / other_configs (N=1 extras)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the N-rank job (one process per GPU over RCCL)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, cmd)
     # stdout carries exactly ONE line, the JSON: everything else any library writes to fd 1 (RCCL prints a version
     # banner through C stdio, flushed only at exit, i.e. AFTER a Python-level print) is sent to stderr instead
     sys.stdout.flush()
@@ -173,47 +347,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dp = None
+    dp, rccl_ranks = None, 0
     force_dp = world == 1 and os.environ.get("OSRL_FORCE_DP") == "1"  # debug: the data-parallel step on one rank
     if world > 1 or force_dp:
         import torch.distributed as dist
         if force_dp:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         else:
             dist.init_process_group("nccl", device_id=device)
         from osrl_amd.engine.dist import DataParallel
         dp = DataParallel()
+        rccl_ranks = dist.get_world_size()
 
-    model, trainer, store = build(device, rank, world)
-    eng = model.engine(B, rows_global=B * world, seed=1234 + rank, dist=dp) if dp is not None else model.engine(B)
-    eng.attach_replay(store)
-    if dp is not None:
-        dp.broadcast_model(model)
+    wl = Workload(args.config, device, rank, world, dp, use_graph=not args.eager)
+    cfg, eng = wl.cfg, wl.eng
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    use_graph = not args.eager
-    for _ in range(args.warmup):
-        eng.step_replay(use_graph)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step_replay(use_graph)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(wl.step, args.steps, args.warmup, barrier)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -226,31 +385,80 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
+        fl = flops_per_step(cfg)
+        B = cfg["B"]
         out = {
             "metric": "grad-steps/sec", "value": round(world * args.steps / dt, 2),
-            "unit": "grad-steps/s (one step = one 2048-transition CPQ gradient step)",
+            "unit": f"grad-steps/s, one step = one gradient step on one GPU's {B}-row batch; aggregate over the job = "
+                    f"n_gpus x optimizer steps/s (each optimizer step consumes a global batch of {B} x n_gpus)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "CPQ train_one_step, OfflinePointGoal1-shaped (obs 76, act 2), batch 2048/GPU, "
-                                   "hidden [256,256], VAE 400, N=10, num_q=num_qc=2; on-device replay sampling "
-                                   "from a 2^20-transition HBM store + Philox noise inside the step",
-                       "global_batch": B * world, "parallelism": f"dp{world}",
-                       "graph": bool(eng.graph is not None), "parallel_graph_branches": True},
-            "algorithmic_gflop_per_step": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / 1e9, 2),
-            "step_tflops": round(cpq_flops_per_step(OD, AD, B, HID, VAE_H, NS, 2, 2) / (dt / args.steps) / 1e12, 3),
+            "config": {"workload": cfg["desc"] + "; on-device minibatch sampling from a HBM-resident synthetic store + "
+                                                 "Philox noise inside the step",
+                       "name": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "graph": bool(getattr(eng, "graph", None) is not None)},
+            "optimizer_steps_per_s": round(args.steps / dt, 2),
+            "transitions_per_s": round(world * B * args.steps / dt, 1),
+            "rccl_ranks": rccl_ranks,
+            "algorithmic_gflop_per_step": round(fl / 1e9, 2),
+            "step_tflops": round(fl / (dt / args.steps) / 1e12, 3),
+            "step_frac": round(fl / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
             "last_stats": {k: round(float(v), 5) for k, v in stats.items()},
         }
-        if not args.no_roofline:
-            out["roofline"] = roofline(eng)
+        if not args.no_roofline and cfg["algo"] == "cpq":
+            out["roofline"] = roofline(eng, fl, ms)
+        if world == 1 and not force_dp and not args.no_extras:
+            out["api_path"] = api_path(wl)
+            del wl, eng
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(args.config, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if args.config == "c2":
+                out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp is not None:
         import torch.distributed as dist
         barrier()  # rank 0 is still timing its roofline kernel: nobody tears the communicator down before it is done
         dist.destroy_process_group()
+
+
+def api_path(wl, steps=200, warmup=20):
+    """The same step through the boundary a reference train script uses: ``trainer.train_one_step(device tensors)``
+    (examples/train/train_cpq.py:143) with lazily materialised statistics -- adds the batch copies into the engine's
+    static buffers and the logger bookkeeping to the replayed graph."""
+    from osrl_amd.common.logger import DummyLogger
+    eng, tr = wl.eng, wl.trainer
+    if wl.cfg["algo"] == "cdt":
+        eng.attach_store(None)
+    else:
+        eng.attach_replay(None)
+    tr.logger, tr.stats_mode = DummyLogger(), "lazy"
+    batch = wl.api_batch()
+    dt = timed_steps(lambda: tr.train_one_step(*batch), steps, warmup)
+    return {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
+            "what": "trainer.train_one_step(device tensors), stats_mode='lazy', DummyLogger"}
+
+
+def other_configs(skip: str, device):
+    """Short runs of the other single-GPU BASELINE configs (same step definition), so the driver's line carries them."""
+    res = {}
+    for name, (steps, warm) in (("c1", (500, 50)), ("c2", (200, 20)), ("c3", (60, 10)), ("c4", (200, 20)), ("c5", (10, 3))):
+        if name == skip:
+            continue
+        try:
+            w = Workload(name, device, 0, 1, None, n_store=1 << 18)
+            dt = timed_steps(w.step, steps, warm)
+            fl = flops_per_step(w.cfg)
+            res[name] = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
+                         "gflop_per_step": round(fl / 1e9, 2),
+                         "step_frac": round(fl / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4)}
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:  # a failing side measurement must not take the headline line down
+            res[name] = {"error": repr(e)[:200]}
+    return res
 
 
 if __name__ == "__main__":

@@ -177,9 +177,13 @@ int osrl_replay_gather(int32_t n_fields, const float* const* src, float* const* 
  * draw a trajectory (inverse CDF of `cdf`, or uniform when NULL) and a start ~ U{0..len-1}, slice seq_len steps
  * of the concatenated trajectory tables (clipped at the trajectory end), zero-pad the tail, emit mask,
  * time_steps = start + arange(T), returns*reward_scale, cost_returns*cost_scale, episode_cost =
- * cost_returns[first step]*cost_scale.  idx_out (optional) receives (trajectory, start) per sample. */
+ * cost_returns[first step]*cost_scale.  idx_out (optional) receives (trajectory, start) per sample.
+ * start_cdf (optional, [total rows]): inclusive cumulative start-index probabilities inside each trajectory
+ * (SequenceDataset(start_sampling=True), dataset.py:742-744,781-783; osrl_start_index_prob) -- NULL = uniform starts.
+ * idx_in (optional, [B,2]): (trajectory, start) pairs given by the caller instead of drawn (fixed evaluation windows). */
 int osrl_seq_window_gather(const float* obs, const float* act, const float* returns, const float* cost_returns,
                            const float* costs, const int64_t* traj_start, const int32_t* traj_len, const float* cdf,
+                           const float* start_cdf, const int32_t* idx_in,
                            int32_t n_traj, int32_t B, int32_t T, int32_t od, int32_t ad, float reward_scale,
                            float cost_scale, float* o_states, float* o_actions, float* o_returns,
                            float* o_cost_returns, int64_t* o_time_steps, float* o_mask, float* o_episode_cost,
@@ -425,6 +429,11 @@ int osrl_episode_returns(const float* x, const int64_t* ep_start, const int32_t*
 enum { OSRL_COST_AFFINE = 0, OSRL_COST_RECIPROCAL = 1 };
 int osrl_cost_sample_prob(const float* cost_returns, const int64_t* ep_start, int32_t n_episodes, int32_t kind,
                           float a, float b, float* prob, float* cdf, void* stream);
+/* compute_start_index_sample_prob (dataset.py:472-494): per trajectory, p[i] ~ (costs (*) gauss_kernel(10,10))[i] + x
+ * with x balancing cost / no-cost steps for the target proportion `prob`; p_out / cdf_out are [total rows] laid out
+ * like the trajectory tables (either may be NULL); cdf_out feeds osrl_seq_window_gather's start_cdf. */
+int osrl_start_index_prob(const float* costs, const int64_t* ep_start, const int32_t* ep_len, int32_t n_episodes,
+                          double prob, float* p_out, float* cdf_out, void* stream);
 /* process_bc_dataset's selection (dataset.py:108-124) as a stable compaction: idx[0..*n_keep) = kept transition
  * indices in order.  ALL: every one; SAFE: cr <= t0; RISKY: cr >= t0; BOUNDARY: t0 < cr <= t1 (the caller passes
  * the thresholds cost_limit, 2 x cost_limit, (0.5, 1.5) x cost_limit rounded to fp32 as numpy does). */

@@ -3,8 +3,9 @@ return-to-go / cost-to-go, BC trajectory filters, CDT cost-weighted trajectory s
 
 TEST INFRASTRUCTURE ONLY (same rules as osrl_oracle.py): nothing under ``osrl_amd/`` may import it.
 numpy restatement; every function cites the reference file:line it follows.  PINNED by
-``tests/golden/ingest.npz`` -- outputs of the reference's own functions, captured by importing the reference
-(``tests/golden/make_golden_ingest.py``) -- see ``tests/test_oracle_golden.py::test_ingest_oracle_matches_golden``.
+``tests/golden/ingest.npz`` / ``samples.npz`` -- outputs of the reference's own functions, captured by importing the
+reference (``tests/golden/make_golden_ingest.py``) -- see ``tests/test_oracle_golden.py::test_ingest_oracle_matches_golden``
+and ``::test_minibatch_builders_match_reference_samples``.
 """
 from __future__ import annotations
 
@@ -66,6 +67,23 @@ def compute_cost_sample_prob(trajs: List[Dict[str, Array]], cost_transform=lambd
     p = np.array([cost_transform(t["cost_returns"][0]) for t in trajs])
     p = np.where(p < 0, 0, p)
     return p / p.sum()
+
+
+def compute_start_index_sample_prob(trajs: List[Dict[str, Array]], prob: float = 0.4) -> List[Array]:
+    """dataset.py:472-494 (+ gauss_kernel :462-469): per trajectory, the start-index distribution of
+    ``SequenceDataset(start_sampling=True)``: costs smoothed by exp(-j^2/10), |j| <= 10, plus an offset x that balances
+    cost / no-cost steps for the target proportion ``prob``.  Pinned by tests/golden/samples.npz."""
+    kern = np.exp(-(np.linspace(-10, 10, 21) ** 2 / 10.0))
+    out = []
+    for t in trajs:
+        c = np.asarray(t["costs"])
+        n, l = np.sum(c), len(c)
+        x = 100 if prob * l - n <= 0 else n * (1 - prob) / (prob * l - n)
+        if x <= 0:
+            x = 1
+        w = np.convolve(c, kern)[10:-10] + x
+        out.append(w / w.sum())
+    return out
 
 
 BC_MODES = ("all", "multi-task", "safe", "risky", "boundary")

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "osrl_episode_segments": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "osrl_episode_returns": [_vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp],
     "osrl_cost_sample_prob": [_vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
+    "osrl_start_index_prob": [_vp, _vp, _vp, _i32, C.c_double, _vp, _vp, _vp],
     "osrl_bc_select": [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "osrl_gather_rows": [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp],
     "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
@@ -116,7 +117,7 @@ PROTOTYPES = {
     "osrl_reduce_slabs": [_fp, _fp, _i32, _i64, _i64, _vp],
     "osrl_randn_fill": [_fp, _i64, _u64, _u32, _vp, _vp],
     "osrl_replay_gather": [_i32, _P(_fp), _P(_fp), _P(_i32), _P(_f32), _i64, _i32, _vp, _u64, _u32, _vp, _vp],
-    "osrl_seq_window_gather": [_fp, _fp, _fp, _fp, _fp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _fp, _fp,
+    "osrl_seq_window_gather": [_fp, _fp, _fp, _fp, _fp, _vp, _vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _fp, _fp,
                                _fp, _fp, _vp, _fp, _fp, _fp, _vp, _u64, _u32, _vp, _vp],
     "osrl_gauss_head": [_fp, _fp, _i32, _i32, _f32, _fp, _fp, _fp, _vp],
     "osrl_gauss_head_bwd": [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _f32, _fp, _vp],

@@ -72,7 +72,7 @@ class BC(nn.Module):
 class BCTrainer:
     """bc.py:67-145."""
 
-    def __init__(self, model: BC, env=None, logger=DummyLogger(), actor_lr: float = 1e-4, bc_mode: str = "all",
+    def __init__(self, model: BC, env=None, logger=None, actor_lr: float = 1e-4, bc_mode: str = "all",
                  cost_limit: int = 10, device="cuda", stats_mode: str = "lazy", use_graph: bool = True):
         self.model, self.logger, self.env, self.device = model, logger, env, device
         self.bc_mode, self.cost_limit = bc_mode, cost_limit

@@ -124,7 +124,7 @@ class BCQL(nn.Module):
 class BCQLTrainer:
     """bcql.py:246-340."""
 
-    def __init__(self, model: BCQL, env=None, logger=DummyLogger(), actor_lr: float = 1e-4,
+    def __init__(self, model: BCQL, env=None, logger=None, actor_lr: float = 1e-4,
                  critic_lr: float = 1e-4, vae_lr: float = 1e-4, reward_scale: float = 1.0,
                  cost_scale: float = 1.0, device="cuda", stats_mode: str = "lazy", use_graph: bool = True):
         self.model, self.logger, self.env = model, logger, env

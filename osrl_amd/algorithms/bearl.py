@@ -123,7 +123,7 @@ class BEARL(nn.Module):
 class BEARLTrainer:
     """bearl.py:353-455."""
 
-    def __init__(self, model: BEARL, env=None, logger=DummyLogger(), actor_lr: float = 1e-3, critic_lr: float = 1e-3,
+    def __init__(self, model: BEARL, env=None, logger=None, actor_lr: float = 1e-3, critic_lr: float = 1e-3,
                  alpha_lr: float = 1e-3, vae_lr: float = 1e-3, reward_scale: float = 1.0, cost_scale: float = 1.0,
                  device="cuda", stats_mode: str = "lazy", use_graph: bool = True):
         self.model, self.logger, self.env = model, logger, env

@@ -149,7 +149,7 @@ class CDT(nn.Module):
         if Tin > T:
             raise ValueError(f"window of {Tin} steps > seq_len {T}")
         if getattr(self, "_infer", None) is None or self._infer.B != B:
-            self._infer = CDTEngine(self, B, cfg)
+            self._infer = CDTEngine(self, B, cfg, inference=True)
         e = self._infer
         mask = torch.ones(B, Tin, device=states.device) if padding_mask is None else \
             (~padding_mask.to(torch.bool)).float()
@@ -181,7 +181,7 @@ class CDT(nn.Module):
 class CDTTrainer:
     """cdt.py:268-418."""
 
-    def __init__(self, model: CDT, env=None, logger=DummyLogger(), learning_rate: float = 1e-4,
+    def __init__(self, model: CDT, env=None, logger=None, learning_rate: float = 1e-4,
                  weight_decay: float = 1e-4, betas: Tuple[float, ...] = (0.9, 0.999), clip_grad: float = 0.25,
                  lr_warmup_steps: int = 10000, reward_scale: float = 1.0, cost_scale: float = 1.0,
                  loss_cost_weight: float = 0.0, loss_state_weight: float = 0.0, cost_reverse: bool = False,

@@ -113,7 +113,7 @@ class COptiDICE(nn.Module):
 class COptiDICETrainer:
     """coptidice.py:259-321."""
 
-    def __init__(self, model: COptiDICE, env=None, logger=DummyLogger(), actor_lr: float = 1e-3,
+    def __init__(self, model: COptiDICE, env=None, logger=None, actor_lr: float = 1e-3,
                  critic_lr: float = 1e-3, scalar_lr: float = 1e-3, reward_scale: float = 1.0, cost_scale: float = 1.0,
                  device="cuda", stats_mode: str = "lazy", use_graph: bool = True):
         self.model, self.logger, self.env = model, logger, env

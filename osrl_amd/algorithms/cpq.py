@@ -133,7 +133,7 @@ class CPQTrainer:
     reference (one host sync per step); "lazy" (default) stores ``LazyStat`` objects that read the
     device statistics ring only when converted to float, so the step loop never blocks."""
 
-    def __init__(self, model: CPQ, env=None, logger=DummyLogger(), actor_lr: float = 1e-4,
+    def __init__(self, model: CPQ, env=None, logger=None, actor_lr: float = 1e-4,
                  critic_lr: float = 1e-4, alpha_lr: float = 1e-4, vae_lr: float = 1e-4,
                  reward_scale: float = 1.0, cost_scale: float = 1.0, device="cuda",
                  stats_mode: str = "lazy", use_graph: bool = True) -> None:

@@ -28,7 +28,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, "..", "include", "osrl_amd.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, "..", "include", "osrl_amd.h"),
+                                                       os.path.join(CSRC, "philox.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -44,22 +45,44 @@ def build(force: bool = False, verbose: bool = False) -> str:
         try:
             if not force and not _stale():
                 return LIB
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose: bool) -> str:
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # SimplifyCFG's store sinking merges "ring[i] = load" of sibling branches into a store through a
-           # pointer phi, after which the weight-ring arrays of mlp.hip can no longer be promoted to registers
-           # (they end up in scratch with an s_waitcnt vmcnt(0) right after the prefetch loads)
-           "-mllvm", "-sink-common-insts=false",
-           "-Wno-pass-failed"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + f".tmp{os.getpid()}"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         # SimplifyCFG's store sinking merges "ring[i] = load" of sibling branches into a store through a
+         # pointer phi, after which the weight-ring arrays of mlp.hip can no longer be promoted to registers
+         # (they end up in scratch with an s_waitcnt vmcnt(0) right after the prefetch loads)
+         "-mllvm", "-sink-common-insts=false", "-Wno-pass-failed"]
+OBJDIR = os.path.join(LIBDIR, "obj")  # git-ignored (*.o); the objects are a build cache only
+
+
+def _build_locked(verbose: bool, force: bool = False) -> str:
+    """One object per translation unit (compiled in parallel, re-compiled only when its source, philox.h or the
+    header is newer), then one link."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    hip = _hipcc()
+    common = [os.path.join(PKG, "..", "include", "osrl_amd.h"), os.path.join(CSRC, "philox.h"), __file__]
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + common)
+        if stale:
+            cmd = [hip] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((s, subprocess.Popen(cmd)))
+    failed = [s for s, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [hip, "--offload-arch=gfx950", "-shared", "-fPIC"] + \
+        [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + f".tmp{os.getpid()}", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -41,6 +41,9 @@ def engine_handoff(model, new_engine, old_engine) -> None:
         src = getattr(old_engine, "temp_mv", None) if old_engine is not None else getattr(model, "_resume_temp_mv", None)
         if src is not None:
             new_engine.temp_mv.copy_(torch.as_tensor(src, dtype=torch.float32))
+    dp = getattr(new_engine, "dist", None)
+    if dp is not None:  # data parallel: every replica starts from rank 0's state (weights, moments, scalars, step count)
+        dp.broadcast_model(model, new_engine)
 
 
 def train_step_count(model) -> int:

@@ -97,6 +97,21 @@ def compute_cost_sample_prob(tables: Dict[str, torch.Tensor], cost_transform: Co
     return (prob, cdf) if with_cdf else prob
 
 
+def compute_start_index_sample_prob(tables: Dict[str, torch.Tensor], prob: float = 0.4, with_cdf: bool = False):
+    """dataset.py:472-494 on device: the per-trajectory start-index distribution of
+    ``SequenceDataset(start_sampling=True)`` as ONE flat fp32 table [total rows] laid out like the trajectory tables
+    (the reference returns a python list of per-trajectory fp64 arrays); ``with_cdf`` also returns the inclusive
+    running sums inside each trajectory, which is what the window sampler reads."""
+    costs = tables["costs"].contiguous()
+    n_traj = int(tables["traj_start"].shape[0])
+    p = torch.zeros_like(costs)
+    cdf = torch.zeros_like(costs)
+    L.check(L.load().osrl_start_index_prob(costs.data_ptr(), tables["traj_start"].data_ptr(),
+                                           tables["traj_len"].data_ptr(), n_traj, float(prob), p.data_ptr(),
+                                           cdf.data_ptr(), cur_stream()), "osrl_start_index_prob")
+    return (p, cdf) if with_cdf else p
+
+
 def process_bc_dataset(dataset: Dict[str, "np.ndarray | torch.Tensor"], cost_limit: float, gamma: float, bc_mode: str,
                        device="cuda") -> Dict[str, torch.Tensor]:
     """dataset.py:30-134 on device (all modes but "frontier", which needs oapackage's Pareto search): per-episode

@@ -66,23 +66,41 @@ class LazyStat:
 
 
 class DummyLogger:
-    def __init__(self, *a, **k):
+    """``max_keep``: entries kept per key; older ones are folded into a running (sum, count) so ``get_mean`` stays
+    exact while a logger that is never ``write()``-n (the trainers' default) cannot grow without bound."""
+
+    def __init__(self, *a, max_keep: int = 4096, **k):
         self.data: Dict[str, List] = {}
+        self._folded: Dict[str, List[float]] = {}
+        self.max_keep = int(max_keep)
         self.checkpoint_fn = None
 
     def store(self, tab=None, **kwargs):
         for k, v in kwargs.items():
-            self.data.setdefault(k if tab is None else f"{tab}/{k}", []).append(v)
+            key = k if tab is None else f"{tab}/{k}"
+            lst = self.data.setdefault(key, [])
+            lst.append(v)
+            if len(lst) > 2 * self.max_keep:  # fold the older half (materialises LazyStats that are still readable)
+                old, self.data[key] = lst[:-self.max_keep], lst[-self.max_keep:]
+                acc = self._folded.setdefault(key, [0.0, 0])
+                for x in old:
+                    try:
+                        acc[0] += float(x)
+                        acc[1] += 1
+                    except RuntimeError:  # its ring slot was overwritten long ago: drop it from the mean
+                        pass
 
     def get_mean(self, key: str) -> float:
         v = self.data.get(key, [])
-        return sum(float(x) for x in v) / max(len(v), 1)
+        s, n = self._folded.get(key, (0.0, 0))
+        return (s + sum(float(x) for x in v)) / max(n + len(v), 1)
 
     def last(self, key: str) -> float:
         return float(self.data[key][-1])
 
     def reset(self):
         self.data = {}
+        self._folded = {}
 
     def write(self, step=None, display=False, **k):
         out = {k_: self.get_mean(k_) for k_ in self.data}
@@ -118,8 +136,9 @@ def store_stats(logger, st, mode: str, tab=None, keys=None) -> None:
             pend = st._pending = []
         vals = {k: LazyStat(st, step, k) for k in use}
         pend.extend(vals.values())
-        # materialise before the device ring wraps (amortised: one sync per ring_len/2 steps)
-        if len(pend) >= (st.ring_len // 2) * max(len(st.keys), 1):
+        # materialise before the device ring wraps (amortised: one sync per ring_len/2 steps).  The trigger is the
+        # AGE of the oldest pending step, not the entry count: with a `keys` subset the count grows slower than the ring
+        if step - pend[0]._step >= st.ring_len // 2:
             for v in pend:
                 v.materialize()
             pend.clear()

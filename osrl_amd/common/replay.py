@@ -119,7 +119,7 @@ class SequenceStore:
     (dataset.py:439-459 ``compute_cost_sample_prob`` output); None = uniform."""
 
     def __init__(self, trajectories, seq_len: int, device, reward_scale: float = 1.0, cost_scale: float = 1.0,
-                 sample_prob=None, seed: int = 0):
+                 sample_prob=None, seed: int = 0, rank: int = 0, start_sampling: bool = False, prob: float = 0.4):
         self.T, self.device = int(seq_len), torch.device(device)
         cat = lambda k: torch.as_tensor(np.concatenate([np.asarray(t[k], np.float32).reshape(len(t["costs"]), -1)  # noqa: E731
                                                         for t in trajectories]), device=self.device).contiguous()
@@ -134,12 +134,31 @@ class SequenceStore:
             c = np.cumsum(np.asarray(sample_prob, np.float64))
             c /= c[-1]
             self.cdf = torch.as_tensor(c.astype(np.float32), device=self.device)
-        self.reward_scale, self.cost_scale, self.seed = float(reward_scale), float(cost_scale), int(seed)
+        self.reward_scale, self.cost_scale = float(reward_scale), float(cost_scale)
+        self.base_seed = int(seed)
+        self.set_rank(rank)
         self.od, self.ad = self.obs.shape[1], self.act.shape[1]
+        self.start_cdf = None
+        if start_sampling:
+            self.enable_start_sampling(prob)
+
+    def enable_start_sampling(self, prob: float = 0.4) -> None:
+        """``SequenceDataset(start_sampling=True, prob=...)`` (dataset.py:742-744,781-783): window starts are drawn
+        from ``compute_start_index_sample_prob`` instead of uniformly (computed on device, csrc/ingest.hip)."""
+        from .ingest import compute_start_index_sample_prob
+        tables = dict(costs=self.cost, traj_start=self.traj_start, traj_len=self.traj_len)
+        self.start_cdf = compute_start_index_sample_prob(tables, prob, with_cdf=True)[1]
+
+    def set_rank(self, rank: int) -> None:
+        """Data parallel: every rank draws its own windows (same mixing as ReplayStore); the CDT engine calls this
+        from ``attach_store`` when it runs under a DataParallel hook."""
+        self.rank = int(rank)
+        self.seed = self.base_seed * 1000003 + self.rank if self.rank else self.base_seed
 
     @classmethod
     def from_tables(cls, tables: Dict[str, torch.Tensor], seq_len: int, reward_scale: float = 1.0,
-                    cost_scale: float = 1.0, cdf: Optional[torch.Tensor] = None, seed: int = 0) -> "SequenceStore":
+                    cost_scale: float = 1.0, cdf: Optional[torch.Tensor] = None, seed: int = 0,
+                    rank: int = 0, start_sampling: bool = False, prob: float = 0.4) -> "SequenceStore":
         """Wrap the flat device tables of ``common.ingest.process_sequence_dataset`` (nothing is copied)."""
         self = cls.__new__(cls)
         self.T, self.device = int(seq_len), tables["observations"].device
@@ -148,28 +167,36 @@ class SequenceStore:
         self.traj_start, self.traj_len = tables["traj_start"], tables["traj_len"]
         self.n_traj = int(self.traj_start.shape[0])
         self.cdf = cdf
-        self.reward_scale, self.cost_scale, self.seed = float(reward_scale), float(cost_scale), int(seed)
+        self.reward_scale, self.cost_scale = float(reward_scale), float(cost_scale)
+        self.base_seed = int(seed)
+        self.set_rank(rank)
         self.od, self.ad = self.obs.shape[1], self.act.shape[1]
+        self.start_cdf = None
+        if start_sampling:
+            self.enable_start_sampling(prob)
         return self
 
     @classmethod
     def from_dataset(cls, dataset, seq_len: int, device, reward_scale: float = 1.0, cost_scale: float = 1.0,
                      cost_reverse: bool = False, cost_sample: bool = False,
-                     cost_transform=("affine", -1.0, 50.0), seed: int = 0) -> "SequenceStore":
+                     cost_transform=("affine", -1.0, 50.0), seed: int = 0, rank: int = 0,
+                     start_sampling: bool = False, prob: float = 0.4) -> "SequenceStore":
         """``SequenceDataset(dataset, seq_len, reward_scale, cost_scale, cost_reverse=, cost_sample=,
         cost_transform=)`` (dataset.py:633-741, no augmentation) with the whole preprocessing on device."""
         from .ingest import compute_cost_sample_prob, process_sequence_dataset
         tables = process_sequence_dataset(dataset, cost_reverse, device)
         cdf = compute_cost_sample_prob(tables, cost_transform, with_cdf=True)[1] if cost_sample else None
-        return cls.from_tables(tables, seq_len, reward_scale, cost_scale, cdf, seed)
+        return cls.from_tables(tables, seq_len, reward_scale, cost_scale, cdf, seed, rank, start_sampling, prob)
 
     def gather(self, states, actions, returns, cost_returns, time_steps, mask, episode_cost, costs, st_ptr,
-               idx_out=None, stream_id: int = 2) -> None:
+               idx_out=None, stream_id: int = 2, idx_in=None) -> None:
+        """``idx_in``: optional int32 [B,2] device tensor of (trajectory, start) pairs to use instead of drawing."""
         B = states.shape[0]
         L.check(L.load().osrl_seq_window_gather(
             self.obs.data_ptr(), self.act.data_ptr(), self.ret.data_ptr(), self.cret.data_ptr(), self.cost.data_ptr(),
             self.traj_start.data_ptr(), self.traj_len.data_ptr(), None if self.cdf is None else self.cdf.data_ptr(),
-            self.n_traj, B, self.T, self.od, self.ad, self.reward_scale, self.cost_scale, states.data_ptr(),
+            None if self.start_cdf is None else self.start_cdf.data_ptr(),
+            None if idx_in is None else idx_in.data_ptr(), self.n_traj, B, self.T, self.od, self.ad, self.reward_scale, self.cost_scale, states.data_ptr(),
             actions.data_ptr(), returns.data_ptr(), cost_returns.data_ptr(), time_steps.data_ptr(), mask.data_ptr(),
             episode_cost.data_ptr(), costs.data_ptr(), None if idx_out is None else idx_out.data_ptr(), self.seed,
             stream_id, st_ptr, cur_stream()), "osrl_seq_window_gather")

@@ -193,6 +193,66 @@ __global__ __launch_bounds__(kScanThreads) void cost_sample_prob_kernel(const fl
   }
 }
 
+// compute_start_index_sample_prob (dataset.py:472-494), one workgroup per trajectory: n = sum(costs), l = len,
+// x = 100 if prob*l - n <= 0 else n(1-prob)/(prob*l - n), x = 1 if x <= 0; w[i] = sum_{|j|<=10} costs[i+j] *
+// exp(-(j*j)/10) + x (np.convolve with gauss_kernel(10, 10), its 10-sample skirts cut off); p = w / sum(w).
+// fp64 like numpy (costs are fp32 inputs, the kernel and all sums are fp64 there); cdf = inclusive running sum.
+__global__ __launch_bounds__(kScanThreads) void start_index_prob_kernel(const float* __restrict__ costs,
+                                                                       const int64_t* __restrict__ ep_start,
+                                                                       const int32_t* __restrict__ ep_len, double prob,
+                                                                       float* __restrict__ p_out,
+                                                                       float* __restrict__ cdf_out) {
+  __shared__ double part[kScanThreads];
+  __shared__ double kern[21];
+  const int e = blockIdx.x;
+  const int64_t s = ep_start[e];
+  const int len = ep_len[e];
+  const float* __restrict__ c = costs + s;
+  if (threadIdx.x < 21) {
+    const double x = (double)((int)threadIdx.x - 10);
+    kern[threadIdx.x] = exp(-(x * x / 10.0));
+  }
+  const int chunk = (len + kScanThreads - 1) / kScanThreads;
+  const int i0 = threadIdx.x * chunk, i1 = min(len, i0 + chunk);
+  auto block_sum = [&](double mine) {  // inclusive scan of the per-thread partials; returns the total
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < kScanThreads; o <<= 1) {
+      const double t = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0.0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    return part[kScanThreads - 1];
+  };
+  double mine = 0.0;
+  for (int i = i0; i < i1; ++i) mine += (double)c[i];
+  const double n = block_sum(mine);
+  __syncthreads();
+  const double den = prob * (double)len - n;
+  double x = den <= 0.0 ? 100.0 : n * (1.0 - prob) / den;
+  if (x <= 0.0) x = 1.0;
+  auto weight = [&](int i) {
+    double w = 0.0;
+    // np.convolve(costs, kernel)[10 + i] = sum_m costs[m] * kernel[10 + i - m]
+    for (int j = -10; j <= 10; ++j) {
+      const int m = i + j;
+      if (m >= 0 && m < len) w += (double)c[m] * kern[10 - j];
+    }
+    return w + x;
+  };
+  mine = 0.0;
+  for (int i = i0; i < i1; ++i) mine += weight(i);
+  const double total = block_sum(mine);
+  double run = part[threadIdx.x] - mine;
+  for (int i = i0; i < i1; ++i) {
+    const double w = weight(i);
+    run += w;
+    if (p_out) p_out[s + i] = (float)(w / total);
+    if (cdf_out) cdf_out[s + i] = (float)(run / total);
+  }
+}
+
 // dst[j, :width] = src[idx[j], :width] (+ one appended column extra[idx[j]]: BC multi-task, dataset.py:128-130)
 __global__ void gather_rows_kernel(const float* __restrict__ src, int width, const int64_t* __restrict__ idx,
                                    int64_t n_rows, float* __restrict__ dst, int dst_ld,
@@ -251,6 +311,15 @@ extern "C" int osrl_cost_sample_prob(const float* cost_returns, const int64_t* e
   (void)hipGetLastError();
   hipLaunchKernelGGL(cost_sample_prob_kernel, dim3(1), dim3(kScanThreads), 0, S, cost_returns, ep_start, n_episodes,
                      kind, a, b, prob, cdf);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_start_index_prob(const float* costs, const int64_t* ep_start, const int32_t* ep_len,
+                                     int32_t n_episodes, double prob, float* p_out, float* cdf_out, void* stream) {
+  if (!costs || !ep_start || !ep_len || n_episodes < 1 || (!p_out && !cdf_out)) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(start_index_prob_kernel, dim3(n_episodes), dim3(kScanThreads), 0, S, costs, ep_start, ep_len,
+                     prob, p_out, cdf_out);
   return (int)hipGetLastError();
 }
 

@@ -79,6 +79,8 @@ struct SeqArgs {
   const int64_t* traj_start;
   const int32_t* traj_len;
   const float* cdf;  // inclusive cumulative trajectory-sampling probabilities, or NULL = uniform
+  const float* start_cdf;  // [Ntot] inclusive cumulative start-index probabilities inside each trajectory, or NULL
+  const int32_t* idx_in;   // optional [B,2] = (trajectory, start) given by the caller instead of drawn
   float *states, *actions, *returns, *cost_returns, *mask, *episode_cost, *costs;
   int64_t* time_steps;
   int32_t* idx_out;  // optional [B,2] = (trajectory, start)
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(256) void seq_window_kernel(const SeqArgs a) {
   const uint32_t step = a.st ? (uint32_t)a.st->step : 0u;
   const U4 r = philox4x32_10(U4{(uint32_t)b, 0x5e9u, step, a.stream_id}, a.k0, a.k1);
   int traj;
-  if (a.cdf) {  // inverse-CDF draw: first index with cdf[i] > u
+  if (a.idx_in) {
+    traj = a.idx_in[2 * b];
+  } else if (a.cdf) {  // inverse-CDF draw: first index with cdf[i] > u
     const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
     int lo = 0, hi = a.n_traj - 1;
     while (lo < hi) {
@@ -109,8 +113,23 @@ __global__ __launch_bounds__(256) void seq_window_kernel(const SeqArgs a) {
     traj = (int)__umul64hi(((uint64_t)r.x << 32) | r.y, (uint64_t)a.n_traj);
   }
   const int len = a.traj_len[traj];
-  const int start = (int)__umul64hi(((uint64_t)r.z << 32) | r.w, (uint64_t)len);
   const int64_t base = a.traj_start[traj];
+  int start;
+  if (a.idx_in) {
+    start = a.idx_in[2 * b + 1];
+    start = start < 0 ? 0 : start >= len ? len - 1 : start;
+  } else if (a.start_cdf) {  // start_sampling (dataset.py:781-783): start ~ start_idx_sample_prob[traj]
+    const float u = (float)(r.z >> 8) * (1.0f / 16777216.0f);
+    const float* __restrict__ c = a.start_cdf + base;
+    int lo = 0, hi = len - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (c[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    start = lo;
+  } else {
+    start = (int)__umul64hi(((uint64_t)r.z << 32) | r.w, (uint64_t)len);
+  }
   if (lane == 0) {
     a.episode_cost[b] = a.cret[base] * a.cost_scale;
     if (a.idx_out) {
@@ -143,7 +162,8 @@ __global__ __launch_bounds__(256) void seq_window_kernel(const SeqArgs a) {
 
 extern "C" int osrl_seq_window_gather(const float* obs, const float* act, const float* returns,
                                       const float* cost_returns, const float* costs, const int64_t* traj_start,
-                                      const int32_t* traj_len, const float* cdf, int32_t n_traj, int32_t B, int32_t T,
+                                      const int32_t* traj_len, const float* cdf, const float* start_cdf,
+                                      const int32_t* idx_in, int32_t n_traj, int32_t B, int32_t T,
                                       int32_t od, int32_t ad, float reward_scale, float cost_scale, float* o_states,
                                       float* o_actions, float* o_returns, float* o_cost_returns,
                                       int64_t* o_time_steps, float* o_mask, float* o_episode_cost, float* o_costs,
@@ -152,7 +172,7 @@ extern "C" int osrl_seq_window_gather(const float* obs, const float* act, const 
   if (!obs || !act || !returns || !cost_returns || !costs || !traj_start || !traj_len || n_traj < 1 || B < 1 || T < 1 ||
       !o_states || !o_actions || !o_returns || !o_cost_returns || !o_time_steps || !o_mask || !o_episode_cost || !o_costs)
     return -1;
-  SeqArgs a{obs, act, returns, cost_returns, costs, traj_start, traj_len, cdf, o_states, o_actions, o_returns,
+  SeqArgs a{obs, act, returns, cost_returns, costs, traj_start, traj_len, cdf, start_cdf, idx_in, o_states, o_actions, o_returns,
             o_cost_returns, o_mask, o_episode_cost, o_costs, o_time_steps, idx_out, n_traj, B, T, od, ad,
             reward_scale, cost_scale, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, st};
   (void)hipGetLastError();

@@ -26,7 +26,8 @@ class BCQLEngine:
     def __init__(self, model, batch_size: int, rows_global: int = 0, seed: int = 0, dist=None):
         m = self.model = model
         B = self.B = int(batch_size)
-        self.rows_global, self.seed, self.dist = int(rows_global), seed, dist
+        self.rows_global, self.dist = int(rows_global), dist
+        self.seed = seed if dist is None else dist.rank_seed(seed)  # independent noise per rank
         dev = torch.device(m.device)
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc = m.num_q, m.num_qc

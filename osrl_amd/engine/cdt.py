@@ -28,7 +28,7 @@ def _r16(x: int) -> int:
 
 
 class CDTEngine:
-    def __init__(self, model, batch_size: int, trainer_cfg: dict, dist=None):
+    def __init__(self, model, batch_size: int, trainer_cfg: dict, dist=None, inference: bool = False):
         m = self.model = model
         self.cfg = trainer_cfg
         self.dist = dist
@@ -82,6 +82,8 @@ class CDTEngine:
         # (the undropped gradient keeps flowing along the residual path)
         self.p_emb, self.p_attn, self.p_res = m.embedding_dropout, m.attention_dropout, m.residual_dropout
         self.seed = int(trainer_cfg.get("seed", 0))
+        if dist is not None:  # independent dropout masks per rank
+            self.seed = dist.rank_seed(self.seed)
         self.datt = [z(M, E) if self.p_res > 0 else self.dxm[l] for l in range(NL)]      # grad wrt out_proj output
         self.dmo = [z(M, E) if self.p_res > 0 else self.dxo[l + 1] for l in range(NL)]   # grad wrt mlp.2 output
         self.n_parts = max(1, min(1024, (M + 31) // 32))  # ~8 rows per wave per LayerNorm-backward workgroup
@@ -109,9 +111,12 @@ class CDTEngine:
                (ds + 4 * 1 * E, self.ctg_t.data_ptr(), "cdt.cost_emb.weight", "cdt.cost_emb.bias", 4 * E, 0),
                (ds + 4 * 2 * E, self.states.data_ptr(), "cdt.state_emb.weight", "cdt.state_emb.bias", 4 * E, 0),
                (ds + 4 * 3 * E, self.actions.data_ptr(), "cdt.action_emb.weight", "cdt.action_emb.bias", 4 * E, 0)]
-        self.p_tok = DwPlan(g, tok, M, dev)
-        self.p_bt = DwPlan(g, bt, BT, dev)
-        self.n_splits = max(self.p_tok.n_splits, self.p_bt.n_splits)
+        # an inference engine (CDT.forward, CDTBatchedRollout) never launches dW: no plans, no gradient slabs
+        self.inference = bool(inference)
+        if not self.inference:
+            self.p_tok = DwPlan(g, tok, M, dev)
+            self.p_bt = DwPlan(g, bt, BT, dev)
+            self.n_splits = max(self.p_tok.n_splits, self.p_bt.n_splits)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.episode_cost = z(B)
         self.store = None
@@ -241,6 +246,8 @@ class CDTEngine:
         m, lib, cfg, g = self.model, L.load(), self.cfg, self.g
         E, M, BT, NL = self.E, self.M, self.BT, self.NL
         st = self.st
+        if self.inference:
+            raise RuntimeError("this CDTEngine was built for inference (no dW plans): it cannot run a train step")
         st.tick()
         if self.store is not None:  # draw the minibatch of windows on device (SequenceDataset, dataset.py:749-787)
             self.store.gather(self.states, self.actions, self.returns, self.ctg, self.time_steps, self.mask,
@@ -329,6 +336,8 @@ class CDTEngine:
         cp(self.costs, costs)
 
     def attach_store(self, store) -> None:
+        if store is not None and self.dist is not None:
+            store.set_rank(self.dist.rank)  # each rank samples its own windows
         self.store = store
         self.graph = None
 
@@ -346,6 +355,7 @@ class CDTEngine:
     def _go(self, use_graph: bool) -> None:
         if use_graph and not self._graph_failed:
             if self.graph is None:
+                ok = True
                 try:
                     self._capture()
                 except Exception as e:  # pragma: no cover - depends on the RCCL build
@@ -353,8 +363,9 @@ class CDTEngine:
                         raise
                     import warnings
                     warnings.warn(f"hipGraph capture of the data-parallel CDT step failed ({e!r}); running eagerly")
-                    torch.cuda.synchronize()
-                    self._graph_failed, self.graph = True, None
+                    ok = False
+                if self.dist is not None and not self.dist.all_agree(ok, self.dev):
+                    self._graph_failed, self.graph = True, None  # every rank runs eagerly, or none does
             if self.graph is not None:
                 self.graph.replay()
                 self.st.host_step += 1
@@ -365,18 +376,20 @@ class CDTEngine:
         m, g = self.model, self.g
         snap = (g.p.clone(), g.m.clone(), g.v.clone(), self.st.state.clone(), self.st.stats.clone(),
                 self.st.ring.clone(), self.st.host_step, m.log_temperature.clone(), self.temp_mv.clone())
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.body()
-        torch.cuda.current_stream().wait_stream(s)
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            self.body()
-        torch.cuda.synchronize()
-        g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])
-        self.st.state.copy_(snap[3]); self.st.stats.copy_(snap[4]); self.st.ring.copy_(snap[5])
-        self.st.host_step = snap[6]
-        m.log_temperature.copy_(snap[7]); self.temp_mv.copy_(snap[8])
-        m.repack()
+        try:  # warm-up + capture both run a real step: the snapshot goes back even when the capture is refused
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.body()
+            torch.cuda.current_stream().wait_stream(s)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self.body()
+        finally:
+            torch.cuda.synchronize()
+            g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])
+            self.st.state.copy_(snap[3]); self.st.stats.copy_(snap[4]); self.st.ring.copy_(snap[5])
+            self.st.host_step = snap[6]
+            m.log_temperature.copy_(snap[7]); self.temp_mv.copy_(snap[8])
+            m.repack()
         self.graph = gr

@@ -31,7 +31,8 @@ class COptiDICEEngine:
     def __init__(self, model, batch_size: int, rows_global: int = 0, seed: int = 0, dist=None):
         m = self.model = model
         B = self.B = int(batch_size)
-        self.seed, self.dist = seed, dist
+        self.dist = dist
+        self.seed = seed if dist is None else dist.rank_seed(seed)  # independent noise per rank
         self.rows_global = int(rows_global) if dist is not None else 0
         if dist is not None and self.rows_global != B * dist.world:
             raise ValueError("data parallel COptiDICE needs rows_global = batch_size * world (equal shards)")

@@ -66,6 +66,7 @@ class FlatGroup:
         self.f_off: Dict[str, int] = {}
         self.b_off: Dict[str, int] = {}
         self.aliases: set = set()
+        self._retired_slabs: list = []        # see ensure_slabs
 
     def add(self, key: str, shape: Sequence[int], align: bool = True) -> int:
         assert self.p is None, "FlatGroup already finalized"
@@ -135,7 +136,13 @@ class FlatGroup:
                                           len(self.weights), self._max_pack, cur_stream()), "osrl_pack_weights")
 
     def ensure_slabs(self, n_splits: int) -> None:
+        """Grow-only.  A hipGraph captured by an earlier engine on this group holds the RAW address of the slab
+        tensor it was captured with (dW writes, slab reduction and Adam reads all use that one address, so the graph
+        stays self-consistent); the replaced tensor is therefore kept alive for the group's lifetime instead of
+        going back to the caching allocator, where a replay would read and write freed memory."""
         if self.slabs is None or self.n_splits < n_splits:
+            if self.slabs is not None:
+                self._retired_slabs.append(self.slabs)
             self.slabs = torch.zeros(n_splits, self.n, dtype=torch.float32, device=self.device)
             self.n_splits = n_splits
 

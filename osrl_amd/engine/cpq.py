@@ -31,7 +31,8 @@ class CPQEngine:
         m = self.model = model
         B = self.B = int(batch_size)
         self.rows_global = int(rows_global)
-        self.seed = seed
+        # data parallel: the ranks' rows are different samples of one global batch -> independent noise streams
+        self.seed = seed if dist is None else dist.rank_seed(seed)
         self.dist = dist
         dev = torch.device(m.device)
         self.dev = dev
@@ -121,6 +122,7 @@ class CPQEngine:
         self.replay = None
         self.parallel_branches = True
         self._graph_failed = False
+        self._probe = None
 
     # ------------------------------------------------------------------ #
     def _update(self, name: str, tau: float) -> None:
@@ -204,7 +206,11 @@ class CPQEngine:
 
         # ---- cost_critic_loss  (cpq.py:155-201): OOD scoring with the UPDATED vae
         par.wait(ev_sampled)
+        if self._probe is not None:  # bench.py: HIP events around the dominant launch as it runs inside the step
+            self._probe[0].record()
         head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
+        if self._probe is not None:
+            self._probe[1].record()
         G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
         if self.dist is not None:
             self.dist.quantile(self.kl, 0.75, self.quant)
@@ -277,19 +283,22 @@ class CPQEngine:
         # data parallel: the side branch holds no collective (the critic group's all-reduce + Adam run on the
         # capture stream after the join), so every rank issues its RCCL calls in the same order on one stream
         par = Branches(self.parallel_branches, 1)
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.body(True, par)
-        torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        # (capturing on a high-priority stream to favour the critical chain halves the throughput: measured 980 vs
-        # 1755 steps/s -- every kernel of the step ran ~2x slower)
-        with torch.cuda.graph(g):
-            self.body(True, par)
-        self._par = par  # keep the side streams alive with the graph
-        torch.cuda.synchronize()
-        self._restore(snap)
+        try:  # the warm-up pass and the capture pass both advance the model: ALWAYS put the snapshot back, also
+            # when the capture is refused and the caller falls back to eager launches
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.body(True, par)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            # (capturing on a high-priority stream to favour the critical chain halves the throughput: measured 980
+            # vs 1755 steps/s -- every kernel of the step ran ~2x slower)
+            with torch.cuda.graph(g):
+                self.body(True, par)
+            self._par = par  # keep the side streams alive with the graph
+        finally:
+            torch.cuda.synchronize()
+            self._restore(snap)
         self.graph = g
 
     def _snapshot(self):
@@ -328,6 +337,7 @@ class CPQEngine:
             use_graph = False  # operator override: run the data-parallel step without capturing its collectives
         if use_graph and not self._graph_failed:
             if self.graph is None:
+                ok = True
                 try:
                     self.capture()
                 except Exception as e:  # pragma: no cover - depends on the RCCL build
@@ -335,9 +345,9 @@ class CPQEngine:
                         raise
                     import warnings
                     warnings.warn(f"hipGraph capture of the data-parallel step failed ({e!r}); running eagerly")
-                    torch.cuda.synchronize()
-                    self._graph_failed = True
-                    self.graph = None
+                    ok = False
+                if self.dist is not None and not self.dist.all_agree(ok, self.dev):
+                    self._graph_failed, self.graph = True, None  # every rank runs eagerly, or none does
             if self.graph is not None:
                 self.graph.replay()
                 self.st.host_step += 1

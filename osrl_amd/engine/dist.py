@@ -35,7 +35,14 @@ class DataParallel:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # broadcasts name their source by GLOBAL rank: rank 0 of a sub-group is not global rank 0
+        self.src0 = dist.get_global_rank(group, 0) if group is not None else 0
         self._gather_buf = None
+
+    def rank_seed(self, seed: int) -> int:
+        """Philox key of this rank's noise / dropout / sampling streams: the ranks' rows are different samples of one
+        global batch, so their draws must be independent (same mixing as ReplayStore's per-rank seed)."""
+        return int(seed) * 1000003 + self.rank
 
     # ---- collectives (plain torch.distributed; work on CPU tensors with gloo as well) ----
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
@@ -62,15 +69,36 @@ class DataParallel:
         dist.all_gather_into_tensor(self._gather_buf, t.reshape(-1), group=self.group)
         return self._gather_buf
 
-    def broadcast_model(self, model) -> None:
-        """Make every replica bit-identical to rank 0 (parameters, targets, optimizer moments, scalars)."""
+    def all_agree(self, ok: bool, device) -> bool:
+        """True iff EVERY rank passes ``ok`` (eager collective, outside any capture): used to settle graph replay vs
+        eager launches for the whole group -- one rank replaying a graph with captured collectives while a peer
+        issues them eagerly would still match up on the wire, but a rank that fell back must not be the only one."""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=device)
+        self.all_reduce_(t)
+        return bool(float(t.item()) >= self.world - 0.5)
+
+    def broadcast_(self, t: torch.Tensor) -> torch.Tensor:
+        dist.broadcast(t, src=self.src0, group=self.group)
+        return t
+
+    def broadcast_model(self, model, engine=None) -> None:
+        """Make every replica bit-identical to the group's rank 0: parameters, targets, optimizer moments, scalar
+        state and -- with ``engine`` -- the train-step counter (Adam bias correction, warm-up LR, Philox offsets) and
+        CDT's temperature moments.  The step engines call this from their constructor hand-off
+        (common/checkpoint.py ``engine_handoff``), so a data-parallel engine never starts from diverged replicas."""
         for g in model.groups.values():
             for buf in (g.p, g.m, g.v, g.tgt):
                 if buf is not None:
-                    dist.broadcast(buf, src=0, group=self.group)
+                    self.broadcast_(buf)
         for name in ("log_alpha", "pid_state", "log_temperature", "scalar_leaves"):
             if isinstance(getattr(model, name, None), torch.Tensor):
-                dist.broadcast(getattr(model, name), src=0, group=self.group)
+                self.broadcast_(getattr(model, name))
+        if engine is not None:
+            step = torch.tensor([engine.st.device_step()], dtype=torch.int64, device=engine.st.state.device)
+            self.broadcast_(step)
+            engine.st.set_step(int(step.item()))
+            if getattr(engine, "temp_mv", None) is not None:
+                self.broadcast_(engine.temp_mv)
         model.repack()  # the kernels read fragment-ordered copies of the weights: refresh them from the new values
 
     # ---- hooks used by the step engines ----

@@ -157,7 +157,7 @@ class CDTBatchedRollout:
         cfg = m._engine.cfg if m._engine is not None else dict(
             learning_rate=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), clip_grad=0.25, lr_warmup_steps=1,
             loss_cost_weight=0.0, loss_state_weight=0.0, no_entropy=False)
-        self.eng = CDTEngine(m, E, cfg)
+        self.eng = CDTEngine(m, E, cfg, inference=True)
         f = dict(dtype=torch.float32, device=dev)
         self.obs = torch.zeros(E, venv.state_dim, **f)
         self.act = torch.zeros(E, m.action_dim, **f)

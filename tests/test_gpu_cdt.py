@@ -300,6 +300,77 @@ def test_cdt_dropout_train_step_matches_oracle(case, use_graph):
     assert (a1 - ap.mean).abs().max() > 1e-6, "a model in train() mode applies dropout in forward"
 
 
+C5_FULL = CDTCase("cdt_c5_full", od=11, ad=3, B=1024, T=20, E=256, heads=8, layers=3, episode_len=1000, steps=2,
+                  warmup=500, dropout=0.1, seed=6)
+
+
+def test_cdt_c5_full_batch_forward_stats_and_graph():
+    """BASELINE.json C5 at its full batch (B = 1024 -> 81920 token rows): the only run of linear_big_kernel's
+    640-workgroup grids, the 81920-row dW launch and the 8192 attention workgroups under test.
+    (a) step-1 logged statistics vs a forward-only fp64 pass of the pinned oracle with the GPU's own dropout masks
+    replayed (the forward is per-sample independent, so the host evaluates it in 64-sample chunks);
+    (b) finite statistics; (c) captured graph == eager launches after 2 steps."""
+    import math
+    from test_oracle_cdt_golden import build_cdt_oracle
+    c = C5_FULL
+    bn = make_cdt_batch(c)
+    b = {k: t(v) for k, v in bn.items()}
+    args = (b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"], b["episode_cost"],
+            b["costs"])
+    m, tr, lg = build_cdt_gpu(c, use_graph=False, seed=77)
+    o = build_cdt_oracle(c, np.float64)
+    tr.train_one_step(*args)
+    got = {k: lg.last("train/" + k) for k in ("nll", "ent", "cost_loss", "cost_acc", "state_loss", "act_loss", "all_loss")}
+    assert all(np.isfinite(v) for v in got.values()), got
+    masks = m.engine(c.B).dropout_masks()
+    f8 = lambda a: np.asarray(a, np.float64)  # noqa: E731
+    acc = dict(ll=0.0, ent=0.0, nv=0.0, cl=0.0, hit=0.0, msum=0.0, sl=0.0)
+    CH = 64
+    for i in range(0, c.B, CH):
+        sl = slice(i, i + CH)
+        drop = {k: v[sl].cpu().numpy().astype(np.float64) for k, v in masks.items()}
+        st_, ac_, mk_ = f8(bn["states"][sl]), f8(bn["actions"][sl]), f8(bn["mask"][sl])
+        res, _ = o.forward(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_, drop)
+        valid = (mk_ > 0)[..., None]
+        zz = (ac_ - res["mu"]) / np.exp(res["ls"])
+        acc["ll"] += ((-0.5 * zz * zz - res["ls"] - 0.5 * math.log(2 * math.pi)) * valid).sum()
+        acc["ent"] += ((0.5 + 0.5 * math.log(2 * math.pi) + res["ls"]) * valid).sum()
+        acc["nv"] += valid.sum() * c.ad
+        ci = bn["costs"][sl].astype(np.int64)
+        lp = res["cost_logp"]
+        acc["cl"] += (-(np.take_along_axis(lp, ci[..., None], -1)[..., 0]) * mk_).sum()
+        acc["hit"] += ((lp.argmax(-1) == ci) * mk_).sum()
+        acc["msum"] += mk_.sum()
+        diff = res["state_pred"][:, :-1] - st_[:, 1:]
+        acc["sl"] += ((diff ** 2) * mk_[:, :-1, None]).sum()
+    temp = 0.1  # init_temperature of build_cdt_gpu / build_cdt_oracle
+    want = dict(nll=-acc["ll"] / acc["nv"], ent=acc["ent"] / acc["nv"], cost_loss=acc["cl"] / (c.B * c.T),
+                cost_acc=acc["hit"] / acc["msum"], state_loss=acc["sl"] / (c.B * (c.T - 1) * c.od))
+    want["act_loss"] = want["nll"] - temp * want["ent"]
+    want["all_loss"] = want["act_loss"] + c.cost_w * want["cost_loss"] + c.state_w * want["state_loss"]
+    for k, r in want.items():
+        assert abs(got[k] - r) <= 1e-4 * max(1.0, abs(r)), f"C5 full batch {k}: gpu {got[k]} vs fp64 oracle forward {r}"
+    del masks, m, tr
+    torch.cuda.empty_cache()
+    res = []
+    for use_graph in (False, True):
+        m, tr, lg = build_cdt_gpu(c, stats_mode="none", use_graph=use_graph, seed=77)
+        for s in range(2):
+            tr.train_one_step(*args)
+        torch.cuda.synchronize()
+        assert (m._engine.graph is not None) == use_graph
+        st = m._engine.st.read_stats()
+        assert all(np.isfinite(v) for v in st.values()), st
+        res.append({k: v.clone() for k, v in m.state_dict().items()})
+        del m, tr
+        torch.cuda.empty_cache()
+    for k in res[0]:
+        if res[0][k].dtype == torch.bool:
+            assert torch.equal(res[0][k], res[1][k])
+        else:  # the timestep-embedding scatter uses fp32 atomics: order-dependent rounding only
+            assert (res[0][k] - res[1][k]).abs().max() < 1e-6, k
+
+
 def test_cdt_graph_replay_matches_eager():
     c = CDT_CASES["cdt_small"]
     res = []

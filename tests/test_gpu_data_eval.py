@@ -654,3 +654,110 @@ def test_end_to_end_cdt_on_device():
     assert eng.graph is not None and all(np.isfinite(v) for v in last.values())
     assert last["act_loss"] < first - 0.5, (first, last["act_loss"])
     assert after[0] > before[0] + 10.0 and after[2] == EL, (before, after)
+
+
+# --------------------------------------------------------------------------------------------------------------- #
+# the device minibatch builders against outputs of the REFERENCE's own builders (tests/golden/samples.npz, generated by
+# importing SequenceDataset / TransitionDataset: tests/golden/make_golden_ingest.py::make_samples)
+# --------------------------------------------------------------------------------------------------------------- #
+def test_sequence_store_matches_reference_prepare_sample():
+    """SequenceDataset._SequenceDataset__prepare_sample (dataset.py:749-775) on fixed (trajectory, start) pairs: the
+    device window gather, fed the same pairs, is bit-exact (slices, tail zero-padding, mask, time_steps, scaling)."""
+    from cases import make_ingest_dataset
+    from oracle_util import load_golden
+    from osrl_amd.common.replay import SequenceStore
+    g = load_golden("samples")
+    T, RS, CS = 12, 0.1, 2.0
+    names = ("states", "actions", "returns", "cost_returns", "time_steps", "mask", "episode_cost", "costs")
+    for rev, tag in ((False, "fwd"), (True, "rev")):
+        store = SequenceStore.from_dataset(make_ingest_dataset(), T, DEV, reward_scale=RS, cost_scale=CS, cost_reverse=rev)
+        pairs = g[f"seq_{tag}_pairs"]
+        B, od, ad = len(pairs), store.od, store.ad
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+        outs = (z(B, T, od), z(B, T, ad), z(B, T), z(B, T), z(B, T, dt=torch.int64), z(B, T), z(B), z(B, T))
+        idx_in = torch.tensor(pairs, dtype=torch.int32, device=DEV)
+        idx_out = z(B, 2, dt=torch.int32)
+        store.gather(*outs, None, idx_out=idx_out, idx_in=idx_in)
+        torch.cuda.synchronize()
+        assert torch.equal(idx_out, idx_in)
+        for n, got in zip(names, outs):
+            want = g[f"seq_{tag}_{n}"]
+            got = got.cpu().numpy()
+            assert got.shape == want.shape, (tag, n)
+            assert np.array_equal(got.astype(want.dtype), want), (tag, n)
+
+
+@pytest.mark.parametrize("init", [False, True])
+def test_replay_store_matches_reference_prepare_sample(init):
+    """TransitionDataset._TransitionDataset__prepare_sample (dataset.py:832-842) on a fixed index list: every golden
+    index is among the rows the device sampler draws (65536 draws from 1500 transitions) and its row is bit-exact."""
+    from cases import make_ingest_dataset
+    from oracle_util import load_golden
+    from osrl_amd.common.replay import ReplayStore
+    from osrl_amd.engine.core import StepState
+    g = load_golden("samples")
+    tag = "init" if init else "plain"
+    store = ReplayStore(make_ingest_dataset(), DEV, reward_scale=0.1, cost_scale=2.0, seed=5, state_init=init)
+    names = ("observations", "next_observations", "actions", "rewards", "costs", "done") + (("is_init",) if init else ())
+    B = 65536
+    st = StepState(DEV, ["x"])
+    st.tick()
+    dst = [torch.zeros(B, w, device=DEV) for w in store.widths]
+    idx = torch.zeros(B, dtype=torch.int32, device=DEV)
+    store.gather(dst, st.ptr, idx_out=idx)
+    torch.cuda.synchronize()
+    ii = idx.cpu().numpy()
+    assert ii.min() >= 0 and ii.max() < store.n_rows
+    for j, want_i in enumerate(g[f"trans_{tag}_idx"]):
+        rows = np.flatnonzero(ii == want_i)
+        assert len(rows), f"index {want_i} never drawn"
+        for k, d in zip(names, dst):
+            got = d[int(rows[0])].cpu().numpy().reshape(-1)
+            want = np.asarray(g[f"trans_{tag}_{k}"][j], np.float32).reshape(-1)
+            assert np.array_equal(got, want), (tag, k, int(want_i), got, want)
+    if init:
+        p, os_, as_ = store.get_dataset_states()
+        ref = g["trans_init_states"]
+        od = store.widths[0]
+        assert abs(p - ref[0]) < 1e-7
+        np.testing.assert_allclose(np.ravel(os_), ref[1:1 + od], rtol=1e-6)
+        np.testing.assert_allclose(np.ravel(as_), ref[1 + od:], rtol=1e-6)
+
+
+def test_start_sampling_matches_reference():
+    """SequenceDataset(start_sampling=True) (dataset.py:742-744,781-783): the device start-index distribution equals
+    compute_start_index_sample_prob of the reference (golden), its per-trajectory cdf ends at 1, and the sampler's
+    empirical start histogram follows it."""
+    from cases import make_ingest_dataset
+    from oracle_util import load_golden
+    from osrl_amd.common.ingest import compute_start_index_sample_prob, process_sequence_dataset
+    from osrl_amd.common.replay import SequenceStore
+    from osrl_amd.engine.core import StepState
+    g = load_golden("samples")
+    for rev, tag in ((False, "fwd"), (True, "rev")):
+        tb = process_sequence_dataset(make_ingest_dataset(), rev, DEV)
+        for prob in (0.4, 0.05):
+            p, cdf = compute_start_index_sample_prob(tb, prob, with_cdf=True)
+            want = g[f"seq_{tag}_startprob_{prob}"]
+            np.testing.assert_allclose(_np(p), want, rtol=2e-6, atol=1e-9)
+            ends = (_np(tb["traj_start"]) + _np(tb["traj_len"]) - 1).astype(np.int64)
+            assert np.abs(_np(cdf)[ends] - 1.0).max() < 1e-6
+    T, B = 12, 1 << 17
+    store = SequenceStore.from_dataset(make_ingest_dataset(), T, DEV, start_sampling=True, prob=0.4, seed=9)
+    st = StepState(DEV, ["x"])
+    st.tick()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+    outs = (z(B, T, store.od), z(B, T, store.ad), z(B, T), z(B, T), z(B, T, dt=torch.int64), z(B, T), z(B), z(B, T))
+    idx = z(B, 2, dt=torch.int32)
+    store.gather(*outs, st.ptr, idx_out=idx)
+    torch.cuda.synchronize()
+    ii = idx.cpu().numpy()
+    lens, starts = _np(store.traj_len), _np(store.traj_start)
+    want = g["seq_fwd_startprob_0.4"]
+    tr = int(np.argmax(lens))  # the longest trajectory: its conditional start histogram vs the golden distribution
+    sel = ii[ii[:, 0] == tr, 1]
+    assert len(sel) > 1500 and sel.min() >= 0 and sel.max() < lens[tr]
+    emp = np.bincount(sel, minlength=lens[tr]) / len(sel)
+    ref = want[starts[tr]:starts[tr] + lens[tr]]
+    assert np.abs(emp - ref).max() < 5 * np.sqrt(ref.max() / len(sel)) + 2e-3
+    assert (ii[:, 1] < lens[ii[:, 0]]).all()

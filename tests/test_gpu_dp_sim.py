@@ -30,7 +30,11 @@ def make_sim(shared, rank):
 
     class SimDist(DataParallel):
         def __init__(self):  # no process group: the exchange happens through `shared`
-            self.group, self.world, self.rank, self._gather_buf = None, shared.world, rank, None
+            self.group, self.world, self.rank, self._gather_buf, self.src0 = None, shared.world, rank, None, 0
+
+        def broadcast_(self, t):
+            t.copy_(self._exchange(t)[0])
+            return t
 
         def _exchange(self, t):
             torch.cuda.current_stream().synchronize()
@@ -73,6 +77,10 @@ def _shard(v, key, r, W, B, N, M=1):
 
 DP_CASES = {
     "cpq": Case("dp_cpq", "cpq", od=5, ad=2, B=32, hidden=[32, 32], vae_hidden=48, N=4, steps=3, episode_len=1000, seed=7),
+    # BASELINE.json C4 at its real widths: (17, 6), hidden [256,256], VAE 400, N=10, 2 x 1024 rows -- the world-2
+    # equivalence through 256/400-wide tiles, the capped N*B launches and split-K dW with rows_global != rows
+    "cpq_c4": Case("dp_cpq_c4", "cpq", od=17, ad=6, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=2,
+                   episode_len=1000, seed=13),
     "bcql": Case("dp_bcql", "bcql", od=4, ad=2, B=32, hidden=[24, 24], vae_hidden=32, N=3, num_q=1, num_qc=2, steps=3,
                  episode_len=200, cost_limit=-4.0, max_action=1.5, seed=8),  # PID active
     "bearl": Case("dp_bearl", "bearl", od=4, ad=2, B=32, hidden=[24, 24], vae_hidden=32, N=3, num_q=1, num_qc=2, steps=3,
@@ -136,11 +144,29 @@ def test_world2_sharded_step_equals_concatenated_batch(algo):
     torch.cuda.synchronize()
 
     sd1 = {k: v.detach().cpu().numpy() for k, v in m1.state_dict().items()}
+    big = c.B >= 1024
     for r in range(W):
         m, tr, lg = reps[r]
         for k, v in m.state_dict().items():
-            d = np.abs(v.detach().cpu().numpy() - sd1[k]).max()
-            assert d <= 2e-5, f"{algo} rank {r} param {k}: sharded vs concatenated differ by {d:.3e}"
+            d = np.abs(v.detach().cpu().numpy() - sd1[k])
+            if not big:
+                assert d.max() <= 2e-5, f"{algo} rank {r} param {k}: sharded vs concatenated differ by {d.max():.3e}"
+            else:
+                # at real widths Adam moves an element whose gradient is round-off noise around zero by ~lr per step
+                # whatever its size, in either direction (tests/test_gpu_train_step.py full-size note): the parameters
+                # get the loose bound + a tight median, the GRADIENTS (Adam first moments) are compared below
+                assert d.max() <= 2.5 * 1e-3 * c.steps + 1e-6 and np.median(d) <= 2e-6, \
+                    f"{algo} rank {r} param {k}: max {d.max():.3e} median {np.median(d):.3e}"
+        if big:
+            for gname, grp in m.groups.items():
+                gate = 5e-3 if gname == "actor" else 5e-5  # the actor gradient is a cancelling batch sum
+                for k in grp.layout:
+                    if k in grp.aliases:
+                        continue
+                    a, b = grp._view(grp.m, k).cpu().numpy(), m1.groups[gname]._view(m1.groups[gname].m, k).cpu().numpy()
+                    scale = max(np.abs(b).max(), 1e-12)
+                    assert np.abs(a - b).max() <= gate * scale, \
+                        f"{algo} rank {r} first moment {k}: {np.abs(a - b).max():.3e} vs scale {scale:.3e}"
         for name in ("log_alpha", "pid_state", "scalar_leaves"):
             if hasattr(m, name):
                 a, b = getattr(m, name).cpu().numpy(), getattr(m1, name).cpu().numpy()
@@ -208,3 +234,127 @@ def test_world2_cdt_sharded_step_equals_concatenated_batch():
         assert abs(float(m.log_temperature) - float(m1.log_temperature)) < 1e-6
         for k, vals in lg1.data.items():
             assert np.allclose([float(x) for x in lg.data[k]], [float(x) for x in vals], rtol=1e-4, atol=1e-5), (r, k)
+
+
+# --------------------------------------------------------------------------------------------------------------- #
+# The CAPTURED data-parallel step with a peer.  Two real RCCL ranks cannot share the one GPU of the test box (RCCL
+# refuses: "Duplicate GPU detected : rank 0 and rank 1 both on CUDA device"), so the peer is a second replica in this
+# process and the two collectives the engines use are graph-capturable device ops on the capture stream: both
+# replicas' step bodies (their forked side branches included) are captured into ONE hipGraph, the bodies interleaved
+# at every collective by greenlets (replica r runs up to its next collective, parks; when all are parked the exchange
+# is enqueued and every replica continues).  What this covers beyond the threaded eager test above: the data-parallel
+# launch plan inside a replayed graph -- two-branch fork/join around collectives, static collective buffers, the
+# split update of the two critic groups after the join -- with a peer whose values differ.  (RCCL's own kernels as
+# graph nodes are covered by the 1-rank NCCL capture tests; RCCL peer traffic inside a graph needs >1 GPU.)
+class _Hub:
+    def __init__(self, world):
+        self.world, self.slots, self.parent = world, [None] * world, None
+
+    def run(self, fns):
+        import greenlet
+        self.parent = greenlet.getcurrent()
+        gs = [greenlet.greenlet(f) for f in fns]
+        for g in gs:
+            g.switch()  # up to its first collective (or to the end)
+        while not all(g.dead for g in gs):
+            assert not any(g.dead for g in gs) and all(s is not None for s in self.slots), \
+                "replicas issued different numbers of collectives"
+            parts = [s.clone() for s in self.slots]  # stream order makes every deposit visible here
+            self.slots = [None] * self.world
+            for g in gs:
+                g.switch(parts)
+
+
+def make_green(hub, rank):
+    from osrl_amd.engine.dist import DataParallel
+
+    class GreenDist(DataParallel):
+        def __init__(self):
+            self.group, self.world, self.rank, self._gather_buf, self.src0 = None, hub.world, rank, None, 0
+
+        def _exchange(self, t):
+            hub.slots[rank] = t
+            return hub.parent.switch()
+
+        def all_reduce_(self, t):
+            parts = self._exchange(t)
+            acc = parts[0]
+            for p in parts[1:]:
+                acc = acc + p
+            t.copy_(acc)
+            return t
+
+        def broadcast_(self, t):
+            t.copy_(self._exchange(t)[0])
+            return t
+
+        def all_agree(self, ok, device):
+            return bool(ok)
+
+        def all_gather_concat(self, t):
+            return torch.cat([p.reshape(-1) for p in self._exchange(t)])
+
+    return GreenDist()
+
+
+@pytest.mark.parametrize("algo", ["cpq", "cpq_c4"])
+def test_world2_captured_graph_equals_concatenated_batch(algo):
+    from osrl_amd.engine.core import Branches
+    c = DP_CASES[algo]
+    W, B, N = 2, c.B, c.N
+    Bl = B // W
+    batch = make_batch(c)
+    keys = ("observations", "next_observations", "actions", "rewards", "costs", "done")
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+    m1, tr1, lg1 = build_gpu(c)
+    for s in range(c.steps):
+        tr1.train_one_step(*[t(batch[k]) for k in keys], noise={k: t(v) for k, v in make_noise(c, s).items()})
+    torch.cuda.synchronize()
+
+    hub = _Hub(W)
+    reps = [build_gpu(c) for _ in range(W)]
+    engs = [None] * W
+
+    def build(r):
+        engs[r] = reps[r][0].engine(Bl, rows_global=B, dist=make_green(hub, r))
+    hub.run([lambda r=r: build(r) for r in range(W)])
+    pars = [Branches(True, 1) for _ in range(W)]
+    bodies = [lambda r=r: engs[r].body(False, pars[r]) for r in range(W)]
+    snaps = [e._snapshot() for e in engs]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hub.run(bodies)  # warm-up pass (torch requires one before capture)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hub.run(bodies)
+    torch.cuda.synchronize()
+    for e, sn in zip(engs, snaps):
+        e._restore(sn)
+    for s in range(c.steps):
+        nz = make_noise(c, s)
+        for r, e in enumerate(engs):
+            e.load_batch(*[t(batch[k][r * Bl:(r + 1) * Bl]) for k in keys])
+            e.load_noise({k: t(_shard(v, k, r, W, B, N)) for k, v in nz.items() if k in e.noise})
+        graph.replay()
+        for e in engs:
+            e.st.host_step += 1
+        torch.cuda.synchronize()
+        for r, e in enumerate(engs):
+            got = e.st.read_stats()
+            for k, vals in lg1.data.items():
+                assert abs(got[k] - float(vals[s])) <= 1e-4 * max(1.0, abs(float(vals[s]))), (algo, r, s, k, got[k], float(vals[s]))
+    big = c.B >= 1024
+    sd1 = {k: v.detach().cpu().numpy() for k, v in m1.state_dict().items()}
+    for r in range(W):
+        m = reps[r][0]
+        for k, v in m.state_dict().items():
+            d = np.abs(v.detach().cpu().numpy() - sd1[k])
+            if big:
+                assert d.max() <= 2.5 * 1e-3 * c.steps + 1e-6 and np.median(d) <= 2e-6, (algo, r, k, d.max())
+            else:
+                assert d.max() <= 2e-5, f"{algo} rank {r} param {k}: {d.max():.3e}"
+        assert abs(float(m.log_alpha) - float(m1.log_alpha)) <= 1e-5
+    for k, v in reps[0][0].state_dict().items():
+        assert torch.equal(v, reps[1][0].state_dict()[k]), f"{algo}: replicas diverged in {k}"

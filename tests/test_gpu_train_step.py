@@ -1,6 +1,8 @@
 """GPU parity of whole train steps: osrl_amd (HIP, through the C ABI) vs (a) the golden vectors
 captured from the reference and (b) the numpy oracle on the same seeded inputs and injected noise.
 Gates: step-1 stats <= 1e-5, <=10-step stats / parameters <= 1e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -72,12 +74,27 @@ def test_train_step_matches_golden_and_oracle(name):
     print(f"{name}: worst stat diff {worst:.3e}")
 
 
+GROUP_GATE = 2e-5  # critic / cost-critic / VAE first moments, relative to each tensor's scale
+
+
+def _note(msg: str) -> None:
+    """Observed margins, kept next to the GPU run's other outputs (gpurun_out/ travels back from the GPU box)."""
+    print(msg)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_margins.txt"), "a") as f:
+            f.write(msg + "\n")
+
+
 FULL_CASES = {
     # BASELINE.json C2 / C3 shapes at their full batch sizes: no reference golden (the fixtures stay small), the
     # pinned oracle is the checker.  These are the only parity runs that reach the N*B-row launches (32-row tiles,
     # the capped tile-loop kernel), the paired launches and the 8-wave kernels at bench size.
     "cpq_c2_full": dict(algo="cpq", od=76, ad=2, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=21),
     "bcql_c3_full": dict(algo="bcql", od=33, ad=8, B=4096, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=22),
+    # BASELINE.json C4 per-GPU shape: CPQ on OfflineHalfCheetah dims (17, 6) -> latent 12, VAE inputs 23 / 29 wide,
+    # q inputs 23 wide: other paddings / column-block splits than C2 (cpq_configs.py:359 task)
+    "cpq_c4_full": dict(algo="cpq", od=17, ad=6, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=24),
     # BEAR-Lag at its train-config size (bearl_configs.py: batch 512, N = M = 10)
     "bearl_full": dict(algo="bearl", od=33, ad=8, B=512, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=23,
                        hp=dict(mmd_sigma=20.0)),
@@ -105,15 +122,23 @@ def test_full_size_train_step_matches_oracle(name):
     from cases import hyper
     hp = hyper(c)
     opts = {"actor": o.opt_actor, "critic": o.opt_critic, "cost_critic": o.opt_cost, "vae": o.opt_vae}
+    # Per-group gates on max|m_gpu - m_oracle| / max|m_oracle| per tensor.  Critic / cost-critic / VAE gradients are
+    # plain batch means of O(1) terms: fp32 vs fp64 agree to ~1e-6..1e-5, so a 1e-3 relative error in one of their
+    # kernels (32-row tiles, the tile-loop kernel, the paired launches, the 8-wave variants all first run here) fails.
+    # The actor gradient is a heavily cancelling sum over the batch (|g| ~ 1e-5 from terms ~1e-3), so fp32 carries
+    # ~1e-3 relative round-off in it whatever the kernel does: it keeps the loose gate.
+    gates = {"actor": 3e-3, "critic": GROUP_GATE, "cost_critic": GROUP_GATE, "vae": GROUP_GATE}
+    worst = {}
     for gname, opt in opts.items():
         grp = m.groups[gname]
         for k, mo in opt.m.items():
             mg = grp._view(grp.m, k).cpu().numpy()
             scale = max(np.abs(mo).max(), 1e-12)
             d = np.abs(mg - mo).max()
-            # (the actor gradient is a heavily cancelling sum over the batch: |g| ~ 1e-5 from terms ~1e-3, so fp32
-            # carries ~1e-3 relative round-off in it; critics / VAE agree to ~1e-5)
-            assert d <= 3e-3 * scale, f"{name} Adam first moment {k}: max diff {d:.3e} vs scale {scale:.3e}"
+            worst[gname] = max(worst.get(gname, 0.0), d / scale)
+            assert d <= gates[gname] * scale, \
+                f"{name} Adam first moment {k} ({gname}): max diff {d:.3e} vs scale {scale:.3e} (gate {gates[gname]:.0e})"
+    _note(f"{name} worst first-moment diff / scale per group: " + ", ".join(f"{g}={v:.2e}" for g, v in worst.items()))
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     for k, v in o.p.items():
         lr = hp.get(k.split(".")[0].replace("cost_critic", "critic") + "_lr", max(x for n, x in hp.items() if n.endswith("_lr")))
@@ -167,7 +192,7 @@ def test_graph_replay_is_deterministic_and_trains(name):
     assert moved == len(p0)
 
 
-@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full", "bearl_small",
+@pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full", "cpq_c4_full", "bearl_small",
                                   "bearl_wide", "coptidice_small", "coptidice_wide"])
 def test_graph_with_parallel_branches_equals_eager_sequential(name):
     """The captured graph (forked side-stream branches, device Philox noise) must produce exactly the same

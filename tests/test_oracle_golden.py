@@ -89,6 +89,35 @@ def test_ingest_oracle_matches_golden():
         IO.process_bc_dataset(make_ingest_dataset(), 6.0, 1.0, "frontier")
 
 
+def test_minibatch_builders_match_reference_samples():
+    """oracle.prepare_sequence_sample / transition_sample / compute_start_index_sample_prob vs outputs of the
+    reference's OWN SequenceDataset.__prepare_sample, TransitionDataset.__prepare_sample and
+    compute_start_index_sample_prob (tests/golden/samples.npz, generated by importing the reference)."""
+    from cases import make_ingest_dataset
+    from oracle import ingest_oracle as IO
+    from oracle.osrl_oracle import prepare_sequence_sample, transition_sample
+    g = load_golden("samples")
+    T, RS, CS = 12, 0.1, 2.0
+    names = ("states", "actions", "returns", "cost_returns", "time_steps", "mask", "episode_cost", "costs")
+    for rev, tag in ((False, "fwd"), (True, "rev")):
+        traj = IO.process_sequence_dataset(make_ingest_dataset(), rev)
+        for j, (tr, st) in enumerate(g[f"seq_{tag}_pairs"]):
+            got = prepare_sequence_sample(traj[int(tr)], int(st), T, RS, CS)
+            for n, v in zip(names, got):
+                want = g[f"seq_{tag}_{n}"][j]
+                assert np.asarray(v).shape == want.shape, (tag, n, j)
+                assert np.array_equal(np.asarray(v, want.dtype), want), (tag, n, int(tr), int(st))
+        for prob in (0.4, 0.05):
+            got = np.concatenate(IO.compute_start_index_sample_prob(traj, prob))
+            np.testing.assert_allclose(got, g[f"seq_{tag}_startprob_{prob}"], rtol=1e-12, atol=0)
+    data = make_ingest_dataset()
+    for tag in ("plain", "init"):
+        idx = g[f"trans_{tag}_idx"]
+        got = transition_sample(data, idx, RS, CS)
+        for k, v in zip(("observations", "next_observations", "actions", "rewards", "costs", "done"), got):
+            assert np.array_equal(np.asarray(v, np.float32), g[f"trans_{tag}_{k}"].astype(np.float32)), (tag, k)
+
+
 @pytest.mark.parametrize("kernel", ["gaussian", "laplacian"])
 def test_bearl_oracle_mmd_gradient_by_finite_differences(kernel):
     """The hand-derived d MMD / d y of oracle/bearl_oracle.py against central differences (fp64), independent of the
