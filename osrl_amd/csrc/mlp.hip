@@ -419,7 +419,10 @@ struct FwdArgs {
 #define OSRL_WPS_8 3  // <2,4>: 3 waves (<= 168 VGPRs); 4 spills into scratch inside the k-loop
 #endif
 constexpr int waves_per_simd(int nrb, int ncb) {
-  return nrb * ncb >= 14 ? 2 : nrb * ncb == 8 ? OSRL_WPS_8 : nrb * ncb >= 4 ? 3 : 4;
+  // nrb >= 5: the 80-row tiles of the N*B-row launches -- ONE 4-wave workgroup per CU (its LDS tile alone is
+  // 84-131 KB), one wave per SIMD with the whole 512-register file: tools/loop_probe.hip reaches 94 % of the MFMA
+  // roof with one such wave per SIMD and 66-75 % as soon as 2-3 workgroups share a CU
+  return nrb >= 5 ? 1 : nrb * ncb >= 14 ? 2 : nrb * ncb == 8 ? OSRL_WPS_8 : nrb * ncb >= 4 ? 3 : 4;
 }
 // the backward kernel also holds the prefetched activations of the epilogue: one wave less
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
@@ -1387,7 +1390,8 @@ inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) 
   const long wg32 = (long)((rows + 31) / 32) * net->n_nets;
   t.nrb = (t.ncb != 7 && wg32 >= 1024) ? 2 : 1;
   t.nw = 4;
-  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7)) {
+  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7) ||
+      (net->tile_rows == 80 && (t.ncb == 4 || t.ncb == 7))) {
     t.nrb = net->tile_rows / 16;
     return t;
   }
@@ -1550,6 +1554,10 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
     if (t.nrb == 2) return launch_tiles(mlp_fwd_loop_kernel<2, 7>, a, R, E, 2, t.lda, st, 256, cap);
     return launch_tiles(mlp_fwd_loop_kernel<1, 7>, a, R, E, 1, t.lda, st, 256, cap);
   }
+  if (t.nrb == 5) {  // forward only: the backward dispatch never sees tile_rows = 80 (choose_tile is told so)
+    if (t.ncb == 4) return launch_tiles(mlp_fwd_kernel<5, 4>, a, in->rows, net->n_nets, 5, t.lda, (hipStream_t)stream, 256, 0);
+    return launch_tiles(mlp_fwd_kernel<5, 7>, a, in->rows, net->n_nets, 5, t.lda, (hipStream_t)stream, 256, 0);
+  }
   OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream, 0);
 }
 
@@ -1624,7 +1632,8 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
   a.saved = *saved;
   a.g = *g;
   a.rows = rows;
-  const TileChoice t = choose_tile(net, rows, g->dx_cols);
+  TileChoice t = choose_tile(net, rows, g->dx_cols);
+  if (t.nrb == 5) t.nrb = 1;  // 80-row tiles exist for the forward kernel only
   a.lda = t.lda;
   OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream, 0);
 }

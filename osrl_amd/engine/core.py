@@ -306,13 +306,16 @@ class MlpRun:
     """
 
     def __init__(self, net: NetDesc, rows: int, save: bool, device, save_nets: Optional[Sequence[int]] = None,
-                 wg_cap: int = 0):
+                 wg_cap: int = 0, tile_rows: int = 0):
         self.net, self.rows, self.save = net, rows, save
-        # forward descriptor of THIS use: a capped launch walks its tiles with at most wg_cap workgroups in flight
+        # forward descriptor of THIS use: a capped launch walks its tiles with at most wg_cap workgroups in flight;
+        # tile_rows picks the forward row tile (80 = one 4-wave workgroup per CU, csrc/mlp.hip waves_per_simd)
         self.fwd_c = net.c
-        if wg_cap:
+        if wg_cap or tile_rows:
             self.fwd_c = L.MlpT.from_buffer_copy(net.c)
             self.fwd_c.wg_cap = int(wg_cap)
+            if tile_rows:
+                self.fwd_c.tile_rows = int(tile_rows)
         f = dict(dtype=torch.float32, device=device)
         E, nl, dims = net.E, net.nl, net.dims
         self.y = torch.zeros(E, rows, dims[-1], **f)

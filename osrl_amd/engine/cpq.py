@@ -98,9 +98,12 @@ class CPQEngine:
         self.sampled = z(N * B, ad)
         # off the critical path (it runs beside the VAE phase): capped so that phase's 128-workgroup launches keep
         # CU slots and MFMA issue (OSRL_OOD_WG_CAP overrides; 0 = uncapped)
+        ood_tile = int(os.environ.get("OSRL_OOD_TILE", "0"))
         self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev,
-                                    wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "512")))
-        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev, wg_cap=int(os.environ.get("OSRL_ENC_WG_CAP", "0")))
+                                    wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "0" if ood_tile else "512")),
+                                    tile_rows=ood_tile)
+        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev, wg_cap=int(os.environ.get("OSRL_ENC_WG_CAP", "0")),
+                                tile_rows=int(os.environ.get("OSRL_ENC_TILE", str(ood_tile))))
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)

@@ -55,8 +55,10 @@ def main():
             ("dec", 1, [80, 400, 400, 2], ["relu", "relu", "tanh"], 76)]
     for name, E, dims, acts, d0 in cfgs:
         for rows in (2048, 20480):
-            for tr in (16, 32, 64):
+            for tr in (16, 32, 64, 80):
                 if tr == 64 and max(dims) > 256:
+                    continue
+                if tr == 80 and (rows == 2048 or max(dims) < 256):
                     continue
                 grp, d = mk(E, dims, acts, dev, tr)
                 x0 = torch.randn(rows, d0, device=dev)
