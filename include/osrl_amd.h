@@ -482,6 +482,44 @@ int osrl_cdt_rollout_push(float* states, float* actions, float* returns, float* 
                           void* stream);
 
 /* library identity */
+/* ---- B = 1 .. OSRL_POLICY_MAX_ROWS act() latency path (act.hip) -----------------------------------------------
+ * Replaces one `model.act(obs)` of the reference's episode loop (XTrainer.rollout, cpq.py:330-347): H2D copy of the
+ * observation + 3-6 aten kernels + two D2H syncs (cpq.py:240-252, bcql.py:236-243, bc.py:66-76) become ONE launch:
+ * the observation rows are read from a pinned host buffer mapped into the device, the whole policy (1-2 chained MLPs
+ * as GEMVs over the packed forward weights + the distribution head) runs in one workgroup, action / log-prob land
+ * in pinned memory and the host spins on a sequence number.  THE ONE EXCEPTION to this header's conventions: a policy
+ * handle owns a small pinned host allocation (osrl_policy_create / _destroy) and osrl_policy_act RETURNS AFTER the
+ * kernel has published its results (it is the synchronous call the episode loop needs).  Wf / b are DEVICE pointers. */
+#define OSRL_POLICY_MAX_ROWS 4
+enum { OSRL_POLICY_MLP = 0, OSRL_POLICY_GAUSS = 1, OSRL_POLICY_BCQ = 2 };
+typedef struct {
+  int32_t n_layers;
+  int32_t dims[OSRL_MAX_LAYERS + 1];
+  int32_t acts[OSRL_MAX_LAYERS];
+  float out_scale;                  /* net output = out_scale * act(z) */
+  const float* Wf[OSRL_MAX_LAYERS]; /* PACKED forward weights PF[k/4][n][k%4] (osrl_pack_weights / the fused optimizer
+                                     * step keep them in step with the canonical parameters) */
+  const float* b[OSRL_MAX_LAYERS];  /* canonical bias [dims[l+1]] */
+} osrl_gemv_net_t;
+typedef struct {
+  int32_t kind;       /* MLP:   a = net0(obs)                               (BC, MLPActor net.py:65-85)
+                       * GAUSS: (mu | log_std) = net0(obs); a = max_action * tanh(mu + exp(clamp(ls)) * eps), logp
+                       *                                                    (SquashedGaussianMLPActor net.py:152-205)
+                       * BCQ:   a0 = net0([obs, clamp(z, +-0.5)]) (VAE.decode net.py:331-339), t = net1([obs, a0]),
+                       *        a = clamp(a0 + phi * max_action * t, +-max_action)       (net.py:33-62, bcql.py:236-243) */
+  int32_t obs_dim, act_dim, latent_dim;
+  float max_action, phi;
+  osrl_gemv_net_t net[2];
+} osrl_policy_t;
+int osrl_policy_create(const osrl_policy_t* desc, void** handle);
+/* HOST pointers into the handle's pinned block: obs [MAX_ROWS, obs_dim] (caller writes), noise [MAX_ROWS, act_dim |
+ * latent_dim] (caller writes when host_noise = 1), act [MAX_ROWS, act_dim] and logp [MAX_ROWS] (kernel writes). */
+int osrl_policy_io(void* handle, float** obs, float** noise, float** act, float** logp);
+/* rows <= OSRL_POLICY_MAX_ROWS.  deterministic: eps = 0 (GAUSS).  host_noise: read eps / z from the noise block
+ * instead of drawing it in the kernel (Philox keyed by `seed` and the handle's call counter). */
+int osrl_policy_act(void* handle, int32_t rows, int32_t deterministic, int32_t host_noise, uint64_t seed, void* stream);
+int osrl_policy_destroy(void* handle);
+
 const char* osrl_version(void);
 
 #ifdef __cplusplus

@@ -69,6 +69,20 @@ class EnvT(C.Structure):
                 ("pad2_", C.c_float)]
 
 
+class GemvNetT(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("acts", C.c_int32 * MAX_LAYERS),
+                ("out_scale", C.c_float), ("Wf", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS)]
+
+
+class PolicyT(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("latent_dim", C.c_int32),
+                ("max_action", C.c_float), ("phi", C.c_float), ("net", GemvNetT * 2)]
+
+
+POLICY_MLP, POLICY_GAUSS, POLICY_BCQ = 0, 1, 2
+POLICY_MAX_ROWS = 4
+
+
 class StepStateT(C.Structure):
     _fields_ = [("step", C.c_int64), ("bc1", C.c_float), ("bc2_sqrt", C.c_float),
                 ("lr_scale", C.c_float), ("pad_", C.c_float)]
@@ -100,6 +114,10 @@ PROTOTYPES = {
     "osrl_ingest_ws_elems": [_i64],
     "osrl_episode_segments": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "osrl_episode_returns": [_vp, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp],
+    "osrl_policy_create": [_P(PolicyT), _P(C.c_void_p)],
+    "osrl_policy_io": [_vp, _P(_P(C.c_float)), _P(_P(C.c_float)), _P(_P(C.c_float)), _P(_P(C.c_float))],
+    "osrl_policy_act": [_vp, _i32, _i32, _i32, _u64, _vp],
+    "osrl_policy_destroy": [_vp],
     "osrl_cost_sample_prob": [_vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
     "osrl_start_index_prob": [_vp, _vp, _vp, _i32, C.c_double, _vp, _vp, _vp],
     "osrl_bc_select": [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
@@ -173,9 +191,15 @@ def load() -> C.CDLL:
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    alt = os.environ.get("OSRL_LIB")  # tuning aid: load an alternative build of the same sources (A/B kernel variants)
     try:
-        from . import build as _build
-        path = _build.build()
+        if alt:
+            if not os.path.exists(alt):
+                raise RuntimeError(f"OSRL_LIB={alt} does not exist")
+            path = alt
+        else:
+            from . import build as _build
+            path = _build.build()
     except Exception as e:  # no hipcc on this machine: use the prebuilt library if present
         if not os.path.exists(path):
             raise RuntimeError(

@@ -63,10 +63,18 @@ class BC(nn.Module):
         return self._engine
 
     @torch.no_grad()
+    def fast_policy(self):
+        """The B = 1 latency path (engine/act.py): one kernel launch per ``act()``, pinned-memory I/O."""
+        if getattr(self, "_fast", None) is None:
+            from ..common.net import net_desc_seq
+            from ..engine.act import FastPolicy
+            self._fast = FastPolicy("mlp", self.device, self.actor.pi[0].in_features, self.action_dim,
+                                    net_desc_seq([self.actor.pi], float(self.actor.act_limit)))
+        return self._fast
+
     def act(self, obs):
-        """bc.py:57-64."""
-        o = torch.as_tensor(np.asarray(obs)[None, ...], dtype=torch.float32, device=self.device)
-        return np.squeeze(self.actor(o).cpu().numpy(), axis=0)
+        """bc.py:57-64: single observation -> action (numpy)."""
+        return self.fast_policy().act(obs)[0]
 
 
 class BCTrainer:

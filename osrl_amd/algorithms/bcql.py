@@ -116,9 +116,14 @@ class BCQL(nn.Module):
     @torch.no_grad()
     def act(self, obs, deterministic=False, with_logprob=False, z=None):
         """bcql.py:236-243 (stochastic: decode draws z unless given)."""
-        o = torch.as_tensor(np.asarray(obs)[None, ...], dtype=torch.float32, device=self.device)
-        a = self.actor(o, self.vae.decode(o, z))
-        return np.squeeze(a.cpu().numpy(), axis=0), None
+        if getattr(self, "_fast", None) is None:
+            from ..common.net import net_desc_seq, vae_dec_desc
+            from ..engine.act import FastPolicy
+            self._fast = FastPolicy("bcq", self.device, self.state_dim, self.action_dim, vae_dec_desc(self.vae),
+                                    max_action=float(self.actor.act_limit), net1=net_desc_seq([self.actor.pi], 1.0),
+                                    latent_dim=self.latent_dim, phi=float(self.actor.phi))
+        zz = None if z is None else (z.detach().cpu().numpy() if torch.is_tensor(z) else np.asarray(z))
+        return self._fast.act(obs, deterministic, noise=zz)[0], None
 
 
 class BCQLTrainer:

@@ -114,10 +114,12 @@ class BEARL(nn.Module):
     @torch.no_grad()
     def act(self, obs: np.ndarray, deterministic: bool = False, with_logprob: bool = False):
         """bearl.py:337-350: single observation -> (max_action * tanh(u), logp)."""
-        from .. import ops
-        o = torch.as_tensor(np.asarray(obs)[None, ...], dtype=torch.float32, device=self.device)
-        a, logp = ops.cpq_act(self, o, deterministic)
-        return np.squeeze(a.cpu().numpy(), axis=0), np.squeeze(logp.cpu().numpy())
+        if getattr(self, "_fast", None) is None:
+            from ..common.net import actor_head_desc
+            from ..engine.act import FastPolicy
+            self._fast = FastPolicy("gauss", self.device, self.state_dim, self.action_dim, actor_head_desc(self.actor),
+                                    max_action=self.max_action)
+        return self._fast.act(obs, deterministic)
 
 
 class BEARLTrainer:

@@ -105,9 +105,12 @@ class COptiDICE(nn.Module):
     @torch.no_grad()
     def act(self, obs: np.ndarray, deterministic: bool = False, with_logprob: bool = False):
         """coptidice.py:244-256: ``actor.forward`` directly -- tanh(u) WITHOUT max_action scaling."""
-        o = torch.as_tensor(np.asarray(obs)[None, ...], dtype=torch.float32, device=self.device)
-        a, logp = self.actor(o, deterministic, True)
-        return np.squeeze(a.cpu().numpy(), axis=0), np.squeeze(logp.cpu().numpy())
+        if getattr(self, "_fast", None) is None:
+            from ..common.net import actor_head_desc
+            from ..engine.act import FastPolicy
+            self._fast = FastPolicy("gauss", self.device, self.state_dim, self.action_dim, actor_head_desc(self.actor),
+                                    max_action=1.0)
+        return self._fast.act(obs, deterministic)
 
 
 class COptiDICETrainer:

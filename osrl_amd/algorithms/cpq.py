@@ -80,6 +80,7 @@ class CPQ(nn.Module):
         self.q_thres = cost_limit * (1 - self.gamma ** self.episode_len) / (1 - self.gamma) / self.episode_len
         self.qc_thres = qc_scalar * self.q_thres
         self._engine = None
+        self._fast = None
         self._lrs: Optional[dict] = None
 
     def repack(self) -> None:
@@ -120,12 +121,19 @@ class CPQ(nn.Module):
         train_one_step (same result: no target is read between its group's step and the step end)."""
         return None
 
-    def act(self, obs: np.ndarray, deterministic: bool = False, with_logprob: bool = False):
-        """cpq.py:240-252: single observation -> (action, logp)."""
-        from .. import ops
-        o = torch.as_tensor(np.asarray(obs)[None, ...], dtype=torch.float32, device=self.device)
-        a, logp = ops.cpq_act(self, o, deterministic)
-        return np.squeeze(a.cpu().numpy(), axis=0), np.squeeze(logp.cpu().numpy())
+    def fast_policy(self):
+        """The B = 1 latency path (engine/act.py): one kernel launch per ``act()``, pinned-memory I/O."""
+        if self._fast is None:
+            from ..common.net import actor_head_desc
+            from ..engine.act import FastPolicy
+            self._fast = FastPolicy("gauss", self.device, self.state_dim, self.action_dim, actor_head_desc(self.actor),
+                                    max_action=self.max_action)
+        return self._fast
+
+    def act(self, obs: np.ndarray, deterministic: bool = False, with_logprob: bool = False, eps=None):
+        """cpq.py:240-252: single observation -> (max_action * tanh(u), logp).  ``eps``: optional explicit noise."""
+        fp = self._fast if self._fast is not None else self.fast_policy()
+        return fp.act1(obs, deterministic) if eps is None else fp.act(obs, deterministic, noise=eps)
 
 
 class CPQTrainer:

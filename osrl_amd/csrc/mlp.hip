@@ -116,6 +116,10 @@ __device__ __forceinline__ f32x4 load_bp_s(const float* __restrict__ Pk /*unifor
 // Measured (tools/mlp_phase.hip, all workgroups): without this a wave spent 22k cycles in the 5-k-step first
 // layer (5k cycles of MFMA work) and 13k cycles staging its input with nothing else in flight.
 constexpr int kRing = 3;  // ring slots (STAGES <= kRing)
+#ifndef OSRL_PIN_ROWS
+#define OSRL_PIN_ROWS 5
+#endif
+constexpr int kPinRows = OSRL_PIN_ROWS;  // row blocks per tile from which mm_run pins its in-step instruction order
 
 // Every workgroup needs the SAME weight lines; each starts its k-walk at a different step so the
 // request streams are decorrelated (fp32 sum order changes per workgroup; fixed per (grid, tile)).
@@ -196,6 +200,15 @@ __device__ __forceinline__ void mm_run(const float* lds, int lda, int nk, const 
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[rb][c] = EXP_MFMA(a[s & 1][rb][t], b[s % STAGES][c][t], acc[rb][c]);
+    if constexpr (NRB >= kPinRows) {
+      // One wave per SIMD (80-row tiles): nothing else hides a load's latency, so the order inside a k-step is pinned:
+      // the next ring slot's weight loads and the next step's ds_reads go out FIRST, then this step's MFMAs.  Left to
+      // itself the machine scheduler sinks the loads to ~35 MFMAs (~1100 cycles) before their first use to save
+      // registers, and the wave then sits in s_waitcnt vmcnt at the top of every k-step.
+      __builtin_amdgcn_sched_group_barrier(0x020, CNT, 0);           // VMEM reads
+      __builtin_amdgcn_sched_group_barrier(0x100, NRB, 0);           // DS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRB * CNT, 0); // MFMA
+    }
   };
   // Main loop: groups of U = 2*STAGES steps with NO per-step control flow (every taken branch costs the wave an
   // instruction-buffer refill: with a conditional per unrolled step a lone wave reached 74% MFMA issue in a

@@ -24,9 +24,15 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def cur_stream() -> int:
+    """hipStream_t of torch's current stream on the current device (as an int for ctypes)."""
     if not torch.cuda.is_available():
         raise RuntimeError("osrl_amd: kernels need a HIP device (no CPU fallback)")
+    if _raw_stream is not None:  # ~0.2 us instead of ~3 us for building a torch.cuda.Stream object per launch
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--episodes", type=int, default=1024)
     ap.add_argument("--len", type=int, default=200)
-    ap.add_argument("--scalar-episodes", type=int, default=2)
+    ap.add_argument("--scalar-episodes", type=int, default=20)
     a = ap.parse_args()
     from osrl_amd.algorithms import BCQL, CPQ, BCQLTrainer, CPQTrainer
     from osrl_amd.common.logger import DummyLogger

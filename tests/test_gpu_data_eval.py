@@ -761,3 +761,59 @@ def test_start_sampling_matches_reference():
     ref = want[starts[tr]:starts[tr] + lens[tr]]
     assert np.abs(emp - ref).max() < 5 * np.sqrt(ref.max() / len(sel)) + 2e-3
     assert (ii[:, 1] < lens[ii[:, 0]]).all()
+
+
+# --------------------------------------------------------------------------------------------------------------- #
+# the B = 1 .. 8 act() latency path (csrc/act.hip, engine/act.py)
+# --------------------------------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", ["bc_small", "bc_c1", "cpq_small", "cpq_odd", "cpq_wide", "bcql_small", "bcql_pid", "bcql_wide",
+                                  "bearl_small", "coptidice_small"])
+def test_fast_policy_matches_oracle_and_batched_path(name):
+    """model.act(obs) through ONE GEMV kernel on pinned I/O == the oracle policy == the batched fused-MLP path, for
+    1 and 4 rows, deterministic and with explicit noise; stays in step with the parameters after train steps."""
+    from gpu_util import gpu_batch, gpu_step
+    c = {**CASES, **BEARL_CASES, **COPTIDICE_CASES}[name]
+    m, tr, lg = build_gpu(c)
+    o = build_oracle(c)
+    rs = np.random.RandomState(4)
+    b = gpu_batch(c)
+    for rnd in range(2):
+        obs = rs.randn(4, c.od).astype(np.float32)
+        if c.algo == "bc":
+            want = o.act(obs)
+            got1 = np.stack([m.act(obs[i]) for i in range(4)])
+            gotn = m.fast_policy().act(obs)[0]
+            assert got1.shape == (4, c.ad) and np.abs(got1 - want).max() <= 1e-5 and np.abs(gotn - want).max() <= 1e-5
+        elif c.algo == "bcql":
+            z = rs.randn(4, 2 * c.ad).astype(np.float32)
+            want = np.stack([o.act(obs[i][None], z[i][None])[0] for i in range(4)])
+            got1 = np.stack([m.act(obs[i], z=z[i])[0] for i in range(4)])
+            assert np.abs(got1 - want).max() <= 1e-5, np.abs(got1 - want).max()
+            gotn = m._fast.act(obs, True, noise=z)[0]
+            assert np.abs(gotn - want).max() <= 1e-5
+            a = np.stack([m.act(obs[0])[0] for _ in range(3)])  # z drawn in the kernel: a fresh draw per call
+            assert np.isfinite(a).all() and np.abs(a).max() <= c.max_action + 1e-6 and (a[0] != a[1]).any()
+        else:
+            want = np.stack([o.act(obs[i][None])[0] for i in range(4)])
+            pairs = [m.act(obs[i], True, True) for i in range(4)]
+            got1 = np.stack([p[0] for p in pairs])
+            assert np.abs(got1 - want).max() <= 1e-5, np.abs(got1 - want).max()
+            # log-prob and the stochastic branch against the batched HIP path with the same explicit noise
+            from osrl_amd import ops
+            eps = rs.randn(4, c.ad).astype(np.float32)
+            t = lambda a: torch.tensor(a, device=DEV)  # noqa: E731
+            ab, lpb = m.actor(t(obs), False, True, eps=t(eps))
+            scale = 1.0 if c.algo == "coptidice" else c.max_action
+            fp = m._fast
+            an, lpn = fp.act(obs, False, noise=eps)
+            assert np.abs(an - ab.cpu().numpy() * scale).max() <= 1e-5
+            assert np.abs(lpn - lpb.cpu().numpy()).max() <= 1e-4
+            lp_det = np.array([float(p[1]) for p in pairs])
+            assert np.abs(lp_det - m.actor(t(obs), True, True)[1].cpu().numpy()).max() <= 1e-4
+            s = np.stack([m.act(obs[0], False)[0] for _ in range(3)])
+            assert np.isfinite(s).all() and (s[0] != s[1]).any(), "stochastic act() must draw fresh noise per call"
+        # move the parameters: the latency path reads the canonical weights, nothing to refresh
+        for st in range(2):
+            gpu_step(tr, c, b, 2 * rnd + st)
+            from oracle_util import oracle_step
+            oracle_step(o, c, 2 * rnd + st)

@@ -218,7 +218,8 @@ def test_mlp_fwd_big_rows(ci):
     src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
     src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
     outs = []
-    for tile_rows in (-1, 16):
+    for tile_rows in (-1, 16, 80):  # 80: one 4-wave workgroup per CU (falls back to the default tile when the widest
+        # layer needs neither 4 nor 7 column blocks per wave)
         desc = NetDesc(refs, acts, oscale)
         desc.c.tile_rows = tile_rows
         run = MlpRun(desc, rows, False, dev)
@@ -234,7 +235,7 @@ def test_mlp_fwd_big_rows(ci):
         for l, a in enumerate(acts):
             h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
         h = h * oscale
-        for nm, got in (("big", outs[0][e]), ("tile", outs[1][e])):
+        for nm, got in (("big", outs[0][e]), ("tile", outs[1][e]), ("tile80", outs[2][e])):
             err = np.abs(got.reshape(h.shape) - h).max()
             assert err < 3e-5 * max(1.0, np.abs(h).max()), f"case {ci} {nm} kernel net {e}: max err {err}"
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
