@@ -141,7 +141,118 @@ class CPQEngine:
         self._update(name, tau)
 
     def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
-        """One step.  ``par`` (graph capture only) forks the independent parts onto side streams:
+        """One step.  Data parallel: ``body_dp`` (collectives pin the launch order).  Single GPU: the launch plan below.
+
+        What the plan exploits (cpq.py:155-201): everything the OOD penalty is made of -- the N*B sampled actions, the
+        target cost critics on them, the VAE encoder on them, the KL rows, their 0.75-quantile, ``qc_ood`` -- sits
+        under ``torch.no_grad()`` and enters the cost-critic loss as ``- exp(log_alpha) * (qc_ood.mean() - thres)``,
+        a term with NO gradient to any network.  It moves ``log_alpha`` and the logged loss, nothing else.  So the
+        69 % of the step's FLOPs that live in the two N*B-row launches are not on the path of any parameter update,
+        and the plan keeps them off the latency chain:
+
+          main  : vae phase -> cost-critic phase (MSE part only) -> [critic updated] -> actor phase
+          side  : actor forwards + heads -> target cost critics on the N*B rows -> critic phase ->
+                  (vae updated) encoder on the N*B rows -> KL -> quantile -> qc_ood mean -> dual step + logged loss
+
+        The side branch joins at the END of the step.  Ordering constraints kept by events: the cost-critic Adam also
+        Polyak-updates ``cost_critic_old``, so it waits for the side branch's last reader of the targets; the encoder on
+        the N*B rows waits for the VAE's Adam; the actor phase waits for the critic's Adam."""
+        if self.dist is not None:
+            return self.body_dp(device_noise, par)
+        m, st, nz, B = self.model, self.st, self.noise, self.B
+        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
+        nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
+        par = par or Branches(False)
+        st.tick()
+        if par.enabled and device_noise and self.replay is not None:
+            # prologue: the noise fill (side stream) and the minibatch gather are independent -- +1 % step
+            par.fork(0)
+            with par.on(0):
+                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+                ev_r = par.mark(0)
+            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
+            ev_g = torch.cuda.Event()
+            ev_g.record()
+            par.wait(ev_r)
+            par.side[0].wait_event(ev_g)
+        else:
+            if self.replay is not None:
+                self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
+            if device_noise:
+                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+            par.fork(0)
+        # ---- main: vae_loss  (cpq.py:125-135)
+        head = self.r_enc.forward(self.obs, self.act)[0]
+        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        u = self.r_dec.forward(self.obs, self.z)[0]
+        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+        self.r_dec.backward_dz()
+        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        self.r_enc.backward_dz()
+        self._optim("vae", self.p_vae, 0.0)
+        ev_vae = torch.cuda.Event() if par.enabled else None
+        if ev_vae is not None:
+            ev_vae.record()
+
+        # ---- side branch, first half: everything that needs neither the new VAE nor a reduction
+        with par.on(0):
+            hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
+            head_next, head_obs = hn[0], ho[0]
+            G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+            ev_next2 = par.mark(0)
+            G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
+            G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
+            # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
+            G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
+            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+            # critic_loss (cpq.py:137-153)
+            y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
+            ev_tgt = par.mark(0)  # the side branch's last reader of cost_critic_old is enqueued
+            G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
+                              rg, self.dq, st.stat_ptr("loss/critic_loss"))
+            self.r_critic.backward_dz()
+            self._optim("critic", self.p_critic, m.tau)
+            ev_critic = par.mark(0)
+
+        # ---- main: cost_critic_loss (cpq.py:155-201), the part with a gradient: Bellman MSE of the online cost critics
+        par.wait(ev_next2)
+        qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost, (self.obs, self.act))
+        G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0, None,
+                        self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+        self.r_cost.backward_dz()
+        self.p_cost.launch()
+        par.wait(ev_tgt)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the side branch
+        self._update("cost_critic", m.tau)
+
+        # ---- side branch, second half: the OOD statistic with the UPDATED vae, then the dual step
+        with par.on(0):
+            if ev_vae is not None:
+                par.side[0].wait_event(ev_vae)
+            if self._probe is not None:  # bench.py: HIP events around the dominant launch as it runs inside the step
+                self._probe[0].record()
+            head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
+            if self._probe is not None:
+                self._probe[1].record()
+            G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
+            G.quantile(self.kl, N * B, 0.75, self.quant)
+            G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+
+        # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch) and cost critic (here)
+        par.wait(ev_critic)
+        y = self.r_pi_q.forward(self.obs, self.a_pi)
+        G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
+        self.r_pi_q.backward_dz()
+        G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
+                         self.dhead_actor)
+        self.r_actor_obs.backward_dz()
+        self._optim("actor", self.p_actor, m.tau)
+        par.join(0)
+        # dual step + the OOD term of the logged loss (cpq.py:186-195): after the join, so that the side branch has no
+        # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains)
+        G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
+
+    def body_dp(self, device_noise: bool, par: Optional[Branches] = None) -> None:
+        """One data-parallel step (also the single-GPU plan of round 1).  ``par`` (graph capture only) forks the independent parts onto side streams:
         critic phase (cpq.py:137-153) and the cost-critic target pre-work (cpq.py:159-176) do not depend
         on the VAE update, so they run beside the VAE phase; the cost-critic update waits for the side branch's
         forwards (the readers of the targets it Polyak-updates), the actor phase for the whole branch."""

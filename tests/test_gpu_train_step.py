@@ -74,7 +74,8 @@ def test_train_step_matches_golden_and_oracle(name):
     print(f"{name}: worst stat diff {worst:.3e}")
 
 
-GROUP_GATE = 5e-4  # critic / cost-critic / VAE first moments, relative to each tensor's scale
+GROUP_GATE = 2e-5  # Adam first moments (= gradients), relative to each tensor's scale
+LOOSE_GATES = {"cpq_c2_full": {"actor": 5e-3, "critic": 5e-4}}  # cancelling batch sums, see the test
 
 
 def _note(msg: str) -> None:
@@ -122,12 +123,14 @@ def test_full_size_train_step_matches_oracle(name):
     from cases import hyper
     hp = hyper(c)
     opts = {"actor": o.opt_actor, "critic": o.opt_critic, "cost_critic": o.opt_cost, "vae": o.opt_vae}
-    # Per-group gates on max|m_gpu - m_oracle| / max|m_oracle| per tensor.  Critic / cost-critic / VAE gradients are
-    # plain batch means of O(1) terms: fp32 vs fp64 agree to ~1e-6..1e-5, so a 1e-3 relative error in one of their
-    # kernels (32-row tiles, the tile-loop kernel, the paired launches, the 8-wave variants all first run here) fails.
-    # The actor gradient is a heavily cancelling sum over the batch (|g| ~ 1e-5 from terms ~1e-3), so fp32 carries
-    # ~1e-3 relative round-off in it whatever the kernel does: it keeps the loose gate.
-    gates = {"actor": 3e-3, "critic": GROUP_GATE, "cost_critic": GROUP_GATE, "vae": GROUP_GATE}
+    # Per-group gates on max|m_gpu - m_oracle| / max|m_oracle| per tensor.  Measured on MI355X (gpurun_out/
+    # parity_margins.txt, round 2): every group of every case agrees with the fp64 oracle to 3.4e-7 .. 6.4e-7 of its
+    # scale, EXCEPT two groups of cpq_c2_full whose gradients at this seed are heavily cancelling batch sums (actor:
+    # |g| ~ 1e-5 from terms ~1e-3 -> 2.8e-3; critic head weight: scale 3.9e-4 -> 1.5e-4).  So the gate is 2e-5
+    # everywhere -- a 1e-3 relative error in any kernel that first runs at this size (32-row tiles, the tile-loop
+    # kernel, the paired launches, the 8-wave variants) fails -- and the two cancellation cases carry their own.
+    gates = {g: GROUP_GATE for g in ("actor", "critic", "cost_critic", "vae")}
+    gates.update(LOOSE_GATES.get(name, {}))
     worst = {}
     for gname, opt in opts.items():
         grp = m.groups[gname]
