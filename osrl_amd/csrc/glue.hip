@@ -51,6 +51,7 @@ __device__ __forceinline__ float softplus(float x) {  // log(1+exp(x)), F.softpl
 __global__ void gauss_head_kernel(const float* __restrict__ head, const float* __restrict__ eps, int rows, int ad,
                                   float max_a, float* __restrict__ a, float* __restrict__ tanh_u,
                                   float* __restrict__ logp) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float lp = 0.f;
@@ -73,6 +74,7 @@ __global__ void gauss_head_kernel(const float* __restrict__ head, const float* _
 __global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
                                       const float* __restrict__ tanh_u, const float* __restrict__ da_nets,
                                       int n_nets, int rows, int ad, float max_a, float* __restrict__ dhead) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * ad) return;
   const int r = i / ad, j = i - r * ad;
@@ -89,6 +91,7 @@ __global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const floa
 
 __global__ void gauss_ood_kernel(const float* __restrict__ head, const float* __restrict__ eps, int n_samples,
                                  int rows, int ad, float* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)n_samples * rows * ad;
   if (i >= total) return;
@@ -102,6 +105,7 @@ __global__ void gauss_ood_kernel(const float* __restrict__ head, const float* __
 // ---------------- VAE tails ----------------
 __global__ void vae_latent_kernel(const float* __restrict__ head, const float* __restrict__ eps, int rows, int L,
                                   float* __restrict__ z) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * L) return;
   const int r = i / L, k = i - r * L;
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict_
                                                         const float* __restrict__ head, int rows, int ad, int L,
                                                         float beta, float inv_rows, float* __restrict__ du,
                                                         float* __restrict__ stat) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   __shared__ float sm[20];
   float rec = 0.f, kl = 0.f;
   const float ia = inv_rows / (float)ad, il = inv_rows / (float)L;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict_
 __global__ void vae_latent_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
                                       const float* __restrict__ dz, int rows, int L, float beta, float inv_rows,
                                       float* __restrict__ dhead) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * L) return;
   const int r = i / L, k = i - r * L;
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
                                                                const float* __restrict__ done, int rows,
                                                                float gamma, float q_thres, float inv_rows,
                                                                float* __restrict__ dq, float* __restrict__ stat) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   __shared__ float sm[20];
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
     float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
     float alpha_lr, float inv_rows, float stat_share, float* __restrict__ log_alpha, float* __restrict__ dq,
     float* __restrict__ stat, const OodArgs oa) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   __shared__ float sm[20];
   float ood_here = 0.f;
   if (oa.qc_sampled)
@@ -436,6 +444,7 @@ __global__ __launch_bounds__(kRed) void cpq_actor_loss_kernel(const float* __res
                                                               const float* __restrict__ qc, int n_qc, int rows,
                                                               float q_thres, float inv_rows,
                                                               float* __restrict__ dq, float* __restrict__ stat) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   __shared__ float sm[20];
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {

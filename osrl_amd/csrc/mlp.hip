@@ -65,6 +65,14 @@ __device__ long long g_wg_log[16384][4];
 #define WG_LOG(slot)
 #endif
 
+// Wave priority (s_setprio 0..3, default 0): launches on at most OSRL_CHAIN_PRIO rows -- the 2048-row latency chain of a
+// train step: forwards with saved activations, backward-dz, dW -- raise theirs to 3, so that on a CU they share with
+// the N*B-row inference launches (the step's filler work, priority 0) the instruction arbiter serves the chain first.
+// Measured on the CPQ step: +1.3 % (1945 -> 1970 steps/s); 0 disables.
+#ifndef OSRL_CHAIN_PRIO
+#define OSRL_CHAIN_PRIO 4096
+#endif
+
 namespace {
 
 __device__ __forceinline__ float act_fwd(int act, float x) {
@@ -432,10 +440,7 @@ struct FwdArgs {
 #define OSRL_WPS_8 3  // <2,4>: 3 waves (<= 168 VGPRs); 4 spills into scratch inside the k-loop
 #endif
 constexpr int waves_per_simd(int nrb, int ncb) {
-  // nrb >= 5: the 80-row tiles of the N*B-row launches -- ONE 4-wave workgroup per CU (its LDS tile alone is
-  // 84-131 KB), one wave per SIMD with the whole 512-register file: tools/loop_probe.hip reaches 94 % of the MFMA
-  // roof with one such wave per SIMD and 66-75 % as soon as 2-3 workgroups share a CU
-  return nrb >= 5 ? 1 : nrb * ncb >= 14 ? 2 : nrb * ncb == 8 ? OSRL_WPS_8 : nrb * ncb >= 4 ? 3 : 4;
+  return nrb * ncb >= 14 ? 2 : nrb * ncb == 8 ? OSRL_WPS_8 : nrb * ncb >= 4 ? 3 : 4;
 }
 // the backward kernel also holds the prefetched activations of the epilogue: one wave less
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
@@ -449,6 +454,10 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e, cons
   const int row0 = tile * BM;
   const int rows = a.in.rows, lda = a.lda;
   const int L = a.net.n_layers;
+#if OSRL_CHAIN_PRIO > 0
+  // latency-chain launches (training rows) outrank the N*B-row filler launches they share CUs with
+  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
 
   WG_LOG(0);
   PHASE_STAMP(0);
@@ -841,6 +850,241 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_big_kernel(const BigArgs a) {
   WG_LOG(1);
 }
 
+// ---- N*B-row forward: 80-row tiles, ONE 4-wave workgroup per CU ------------------------------------------
+// The inference-only launches of a step (CPQ: target cost critics and the VAE encoder on the N*B = 20480 sampled
+// rows; BCQ-Lag / BEAR-Lag: decoder, actor, target critics on N*B rows) carry 69 % of the step's FLOPs.  With the tile
+// kernel above, 2-3 workgroups share a CU and the k-loop sits at 53-58 % of the fp32 MFMA roof; tools/loop_probe2.hip
+// shows why a different shape wins: ONE wave per SIMD with an 80-row x (64 | 112)-column register tile (80-140
+// accumulator registers out of the wave's 512) runs the same loop at 93-96 % -- 5 ds_read_b128 + 4-7
+// global_load_dwordx4 feed 80-140 MFMAs per k-step, weight traffic per FLOP is 2.5-5x lower than with 16/32-row tiles,
+// and with the in-step order pinned (loads of the next step first) one k-step of MFMAs (2560-4480 cycles) covers the
+// L2 latency with no second wave needed.
+// This kernel is that loop plus the least it needs around it: the input tile is staged with every load in flight at
+// once, each wide layer is  bias-initialised accumulators -> k-loop -> barrier -> activation into the LDS tile (in
+// place), the narrow head (<= 32 outputs, always the last layer) splits K over the 4 waves with ALL its weight
+// fragments preloaded before the previous layer's epilogue, partial tiles meet in LDS and go straight to global.
+// Eligibility (host): no saved activations, hidden layers of 13-16 (NCB = 4) or 25-28 (NCB = 7) column blocks, narrow
+// last layer with >= 4 k-steps; anything else takes mlp_fwd_kernel.
+struct NbArgs {
+  osrl_mlp_t net;
+  osrl_rows_t in;
+  float* y[OSRL_MAX_NETS];
+  int32_t lda;
+};
+
+constexpr int kNbRb = 5;  // row blocks per tile (80 rows)
+
+template <int CNT>
+__device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
+                                      f32x4 (&acc)[kNbRb][CNT]) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* arow = lds + m * lda + 4 * kq;
+  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
+  const int rot = k_rot(nk);
+  f32x4 b[2][CNT], a[2][kNbRb];
+  {
+    const int k0 = k_at(0, rot, nk, 0);
+    const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
+  }
+  auto step = [&](auto s_c, int kc) {
+    constexpr int s = decltype(s_c)::value;
+    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
+    const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb)
+          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rb][t], b[s][c][t], acc[rb][c], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, CNT, 0);                // VMEM reads of the next step first
+    __builtin_amdgcn_sched_group_barrier(0x100, kNbRb, 0);              // its DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT, 0);    // then this step's MFMAs
+  };
+  using std::integral_constant;
+  int kc = 0;
+  for (; kc + 2 <= nk; kc += 2) {
+    step(integral_constant<int, 0>{}, kc);
+    step(integral_constant<int, 1>{}, kc + 1);
+  }
+  if (kc < nk) step(integral_constant<int, 0>{}, kc);
+}
+
+template <int CNT, int ACT>
+__device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&acc)[kNbRb][CNT], int cb0, int N, int lane) {
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) {
+    const int col = (cb0 + c) * 16 + (lane & 15);
+    const bool live = col < N;
+    float* dst = lds + ((lane >> 4) * 4) * lda + col;
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = act_fwd(ACT, acc[rb][c][r]);
+        dst[(rb * 16 + r) * lda] = live ? v : 0.f;  // zero = k padding of the next layer
+      }
+  }
+}
+
+template <int CNT>
+__device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
+                                              const float* __restrict__ bias, int act, int cb0, int lane) {
+  f32x4 acc[kNbRb][CNT];
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) {
+    const int col = (cb0 + c) * 16 + (lane & 15);
+    const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) acc[rb][c] = f32x4{bv, bv, bv, bv};
+  }
+  nb_mm<CNT>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, acc);
+  __syncthreads();  // every wave finished reading the previous activations
+  if (act == OSRL_ACT_RELU)
+    nb_epilogue<CNT, OSRL_ACT_RELU>(lds, lda, acc, cb0, N, lane);
+  else if (act == OSRL_ACT_TANH)
+    nb_epilogue<CNT, OSRL_ACT_TANH>(lds, lda, acc, cb0, N, lane);
+  else
+    nb_epilogue<CNT, OSRL_ACT_ID>(lds, lda, acc, cb0, N, lane);
+  __syncthreads();
+}
+
+template <int NCB>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 16 * kNbRb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e = blockIdx.y, row0 = blockIdx.x * BM;
+  const int rows = a.in.rows, lda = a.lda, L = a.net.n_layers;
+  WG_LOG(0);
+  PHASE_STAMP(0);
+  {  // ---- stage cat(src0[map0(r)], src1[map1(r)]) zero padded to a multiple of 16 columns: every load of the tile
+     // is issued before the first LDS store.  16 lanes walk one row (64-byte segments), 16 rows per pass, 5 passes;
+     // no per-element division (80 x K0p / 256 of them cost 23k cycles in the first version of this kernel).
+    const int K0 = a.net.dims[0], K0p = round16(K0);
+    const int d0 = a.in.d0, d1 = a.in.d1;
+    const int cl = tid & 15, rl = tid >> 4;
+    const float* __restrict__ s0 = a.in.src0;
+    const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
+    constexpr int kColChunks = 8;  // K0 <= 128 (host-checked)
+    float v[kNbRb][kColChunks];
+#pragma unroll
+    for (int p = 0; p < kNbRb; ++p) {
+      const int gr = row0 + p * 16 + rl;
+      const bool rok = gr < rows;
+      const int grc = rok ? gr : rows - 1;
+      const float* p0 = s0 + (size_t)map_row(grc, a.in.map0, a.in.div0) * d0;
+      const float* p1 = s1 + (size_t)map_row(grc, a.in.map1, a.in.div1) * d1 - d0;
+#pragma unroll
+      for (int j = 0; j < kColChunks; ++j) {
+        const int c = j * 16 + cl;
+        const bool ok = rok && c < K0;
+        const float* q = c < d0 ? p0 + c : p1 + c;
+        v[p][j] = *(ok ? q : s0);
+        v[p][j] = ok ? v[p][j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kNbRb; ++p)
+#pragma unroll
+      for (int j = 0; j < kColChunks; ++j) {
+        const int c = j * 16 + cl;
+        if (c < K0p) lds[(p * 16 + rl) * lda + c] = v[p][j];
+      }
+    __syncthreads();
+  }
+  PHASE_STAMP(1);
+  for (int l = 0; l + 1 < L; ++l) {  // wide layers
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    int cb0, cnt;
+    wave_blocks<4>((N + 15) >> 4, wave, &cb0, &cnt);
+    if (cnt == NCB)
+      nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+    else
+      nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+    PHASE_STAMP(2 + 4 * l);
+    PHASE_STAMP(3 + 4 * l);
+    PHASE_STAMP(4 + 4 * l);
+    PHASE_STAMP(5 + 4 * l);
+  }
+  {  // ---- narrow head: K split over the 4 waves, every weight fragment of a wave's share loaded up front
+    const int l = L - 1;
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    const int Np = round16(N), nblk = Np >> 4, nk = round16(K) >> 4;
+    const int k_lo = (nk * wave) / 4, k_hi = (nk * (wave + 1)) / 4;
+    constexpr int kMaxSteps = 8;  // nk <= 32 (widths <= 448 -> nk <= 28 -> <= 7 steps per wave)
+    const float* __restrict__ P = a.net.Wf[e][l];
+    const int m = lane & 15, kq = lane >> 4;
+    f32x4 t[kNbRb][2];
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) t[rb][0] = t[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bw[kMaxSteps][2];
+#pragma unroll
+    for (int sI = 0; sI < kMaxSteps; ++sI) {
+      const int ks = k_lo + sI < k_hi ? k_lo + sI : k_hi - 1;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        bw[sI][c] = (c < nblk) ? *reinterpret_cast<const f32x4*>(P + ((size_t)(ks * 4 + kq) * Np + c * 16 + m) * 4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* arow = lds + m * lda + 4 * kq;
+#pragma unroll
+    for (int sI = 0; sI < kMaxSteps; ++sI) {
+      if (k_lo + sI < k_hi) {
+        const int ks = k_lo + sI;
+        f32x4 af[kNbRb];
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb) af[rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ks * 16);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int rb = 0; rb < kNbRb; ++rb) {
+            t[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rb][tt], bw[sI][0][tt], t[rb][0], 0, 0, 0);
+            if (nblk > 1) t[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rb][tt], bw[sI][1][tt], t[rb][1], 0, 0, 0);
+          }
+      }
+    }
+    PHASE_STAMP(2 + 4 * l);
+    __syncthreads();  // all reads of the activations are done: the tile's first 4 * Np columns take the partials
+    PHASE_STAMP(3 + 4 * l);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (c < nblk) {
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            lds[(rb * 16 + kq * 4 + r) * lda + wave * Np + c * 16 + m] = t[rb][c][r];
+      }
+    __syncthreads();
+    PHASE_STAMP(4 + 4 * l);
+    const float* __restrict__ bias = a.net.b[e][l];
+    const int act = a.net.acts[l];
+    const float oscale = a.net.out_scale;
+    float* __restrict__ y = a.y[e];
+    for (int idx = tid; idx < BM * N; idx += 256) {
+      const int r = idx / N, c = idx - r * N;
+      if (row0 + r < rows) {
+        const float* p = lds + r * lda + c;
+        const float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
+        y[(size_t)(row0 + r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
+      }
+    }
+    PHASE_STAMP(5 + 4 * l);
+  }
+  WG_LOG(1);
+}
+
 struct BwdArgs {
   osrl_mlp_t net;
   osrl_mlp_acts_t saved;
@@ -858,6 +1102,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
   const int row0 = blockIdx.x * BM;
   const int rows = a.rows, lda = a.lda;
   const int L = a.net.n_layers;
+#if OSRL_CHAIN_PRIO > 0
+  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
 
   // steps: l = L-1 .. 1 (dH_{l-1} = dZ_l W_l), then step 0 = the dX slice; begin_step issues a step's first weight loads
   f32x4 ring[kRing][NCB];
@@ -1068,6 +1315,9 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int item = blockIdx.x;
+#if OSRL_CHAIN_PRIO > 0
+  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
   const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
   const osrl_dw_entry_t E = entries[ei];
   const int out = E.out, in = E.in;
@@ -1403,8 +1653,7 @@ inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) 
   const long wg32 = (long)((rows + 31) / 32) * net->n_nets;
   t.nrb = (t.ncb != 7 && wg32 >= 1024) ? 2 : 1;
   t.nw = 4;
-  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7) ||
-      (net->tile_rows == 80 && (t.ncb == 4 || t.ncb == 7))) {
+  if (net->tile_rows == 16 || net->tile_rows == 32 || (net->tile_rows == 64 && t.ncb != 7)) {
     t.nrb = net->tile_rows / 16;
     return t;
   }
@@ -1536,6 +1785,47 @@ static int launch_fwd_big(const osrl_mlp_t* net, const osrl_rows_t* in, const os
   return launch_big<3, 7>(a, tiles, nets, lds_bytes, stream);
 }
 
+// ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
+template <int NCB>
+static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
+  return (int)hipGetLastError();
+}
+
+static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream) {
+  const int L = net->n_layers, nets = net->n_nets;
+  if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNotBig;
+  for (int e = 0; e < nets; ++e)
+    for (int l = 0; l + 1 < L; ++l)
+      if (out->h[e][l]) return kNotBig;  // training launches keep hidden activations: mlp_fwd_kernel
+  int ncb = 0, wmax = net->dims[0];
+  for (int l = 0; l + 1 < L; ++l) {  // wide layers: every wave owns NCB or NCB - 1 column blocks
+    const int N = net->dims[l + 1], nblk = (N + 15) / 16;
+    const int need = nblk >= 13 && nblk <= 16 ? 4 : nblk >= 25 && nblk <= 28 ? 7 : 0;
+    if (!need || (ncb && need != ncb)) return kNotBig;
+    ncb = need;
+    wmax = N > wmax ? N : wmax;
+  }
+  const int NL = net->dims[L], nkl = (((net->dims[L - 1] + 15) & ~15) >> 4);
+  if (NL > 32 || nkl < 4 || nkl > 32) return kNotBig;  // narrow head, K split over 4 waves (<= 8 steps each)
+  const int lda = ((wmax + 15) & ~15) + 8;
+  if (lda < 4 * ((NL + 15) & ~15)) return kNotBig;  // the head's 4 partial tiles live in the activation tile
+  size_t lds_bytes = (size_t)80 * lda * sizeof(float);
+  if (lds_bytes <= 80 * 1024) lds_bytes = 80 * 1024 + 256;  // more than half of the 160 KB: one workgroup per CU
+  if (lds_bytes > kLdsMax) return kNotBig;
+  NbArgs a;
+  a.net = *net;
+  a.in = *in;
+  for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
+  a.lda = lda;
+  const int tiles = (in->rows + 79) / 80;
+  return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
+}
+
 }  // namespace
 
 extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
@@ -1547,7 +1837,9 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
       if (!net->Wf[e][l] || !net->b[e][l]) return -1;
   }
   {
-    const int rc = launch_fwd_big(net, in, out, (hipStream_t)stream);
+    int rc = launch_fwd_big(net, in, out, (hipStream_t)stream);
+    if (rc != kNotBig) return rc;
+    rc = launch_fwd_nb(net, in, out, (hipStream_t)stream);
     if (rc != kNotBig) return rc;
   }
   FwdArgs a;
@@ -1566,10 +1858,6 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
     }
     if (t.nrb == 2) return launch_tiles(mlp_fwd_loop_kernel<2, 7>, a, R, E, 2, t.lda, st, 256, cap);
     return launch_tiles(mlp_fwd_loop_kernel<1, 7>, a, R, E, 1, t.lda, st, 256, cap);
-  }
-  if (t.nrb == 5) {  // forward only: the backward dispatch never sees tile_rows = 80 (choose_tile is told so)
-    if (t.ncb == 4) return launch_tiles(mlp_fwd_kernel<5, 4>, a, in->rows, net->n_nets, 5, t.lda, (hipStream_t)stream, 256, 0);
-    return launch_tiles(mlp_fwd_kernel<5, 7>, a, in->rows, net->n_nets, 5, t.lda, (hipStream_t)stream, 256, 0);
   }
   OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream, 0);
 }
@@ -1645,8 +1933,7 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
   a.saved = *saved;
   a.g = *g;
   a.rows = rows;
-  TileChoice t = choose_tile(net, rows, g->dx_cols);
-  if (t.nrb == 5) t.nrb = 1;  // 80-row tiles exist for the forward kernel only
+  const TileChoice t = choose_tile(net, rows, g->dx_cols);
   a.lda = t.lda;
   OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream, 0);
 }

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    int64_t slab_stride, int64_t n4, float lr, float b1, float b2,
                                                    float eps, float wd, float tau, const float* __restrict__ gscale,
                                                    const osrl_step_state_t* __restrict__ st, const PackMap pk) {
+  __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const float lr_t = lr * st->lr_scale;
   const float step_size = lr_t / st->bc1;
   const float bc2s = st->bc2_sqrt;

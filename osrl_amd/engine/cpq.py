@@ -102,8 +102,12 @@ class CPQEngine:
         self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev,
                                     wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "0" if ood_tile else "512")),
                                     tile_rows=ood_tile)
+        # the VAE encoder on the N*B rows runs late on the side branch, beside the short cost-critic / actor launches:
+        # the 80-row one-workgroup-per-CU kernel (csrc/mlp.hip mlp_fwd_nb_kernel; 78.6 vs 87.8 us alone, 1968 vs 1941
+        # steps/s in the step); the target cost critics on the N*B rows run beside the VAE phase, where the capped
+        # 32-row tile loop disturbs the chain least (80-row tiles there: 1876 steps/s)
         self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev, wg_cap=int(os.environ.get("OSRL_ENC_WG_CAP", "0")),
-                                tile_rows=int(os.environ.get("OSRL_ENC_TILE", str(ood_tile))))
+                                tile_rows=int(os.environ.get("OSRL_ENC_TILE", str(ood_tile or 80))))
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)
@@ -126,6 +130,7 @@ class CPQEngine:
         self.parallel_branches = True
         self._graph_failed = False
         self._probe = None
+        self.ood_first = os.environ.get("OSRL_OOD_FIRST", "1") == "1"
 
     # ------------------------------------------------------------------ #
     def _update(self, name: str, tau: float) -> None:
@@ -204,15 +209,18 @@ class CPQEngine:
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
             # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
             G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
-            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+            if self.ood_first:
+                qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
             # critic_loss (cpq.py:137-153)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
-            ev_tgt = par.mark(0)  # the side branch's last reader of cost_critic_old is enqueued
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
             self._optim("critic", self.p_critic, m.tau)
             ev_critic = par.mark(0)
+            if not self.ood_first:  # beside the cost-critic phase instead of beside the VAE's dW
+                qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+            ev_tgt = par.mark(0)  # the side branch's last reader of cost_critic_old is enqueued
 
         # ---- main: cost_critic_loss (cpq.py:155-201), the part with a gradient: Bellman MSE of the online cost critics
         par.wait(ev_next2)
