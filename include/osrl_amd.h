@@ -41,7 +41,8 @@ typedef struct {
   int32_t acts[OSRL_MAX_LAYERS];     /* activation after each layer */
   float out_scale;                   /* net output = out_scale * act(z)  (act_limit of net.py:62,85,339) */
   int32_t tile_rows;                 /* tuning hint: rows per workgroup tile (0 = auto, else 16 / 32 / 64);
-                                      * -1 = forward-only launches may use the LDS-staged-weights kernel */
+                                      * 80 = forward-only launches take the one-workgroup-per-CU kernel when the
+                                      * network's shape allows it */
   int32_t wg_cap;                    /* forward launches: at most this many workgroups in the grid (0 = one per
                                       * tile); a capped launch walks its tiles, leaving CU slots to concurrent
                                       * latency-critical launches */
@@ -137,6 +138,11 @@ int osrl_pack_weights(const float* src_flat, float* pf, float* pb, const osrl_pa
  * 64x64 tiles; slabs = [n_splits][slab_stride] partial gradients (deterministic split-K over rows). */
 int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
                          int32_t rows, int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
+/* The same contract for items given in units of 128 (out) x 64 (in) tiles that lie fully inside their dW (only
+ * full tiles may be listed): one wave per tile and row split, 128-register accumulator tiles, one wave per SIMD -- the big-row-count (token matrix) variant; db of an entry is written by its it == 0 tiles.
+ * Splits beyond a plan's own n_splits are never written (the caller keeps them zero). */
+int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items, int32_t rows,
+                             int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
 
 /* ---- optimizer (optim.hip): torch.optim.Adam/AdamW.step + _soft_update (cpq.py:107-113,232-238) ---- */
 /* Advance the device step state (t += 1, bias corrections, LR-warmup factor).  If stats_cur/ring are

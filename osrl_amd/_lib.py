@@ -127,6 +127,7 @@ PROTOTYPES = {
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
     "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
+    "osrl_mlp_backward_dw_big": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
     "osrl_adam_step": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,
                        _vp, _vp],

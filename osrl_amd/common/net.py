@@ -4,7 +4,9 @@
 These modules hold parameters only -- as VIEWS into flat HBM optimizer groups
 (engine/core.py FlatGroup) -- plus thin ``forward`` methods that call the fused HIP
 MLP through ``osrl_amd.ops`` (a ``torch.autograd.Function`` over libosrl_amd.so).
-There is no aten arithmetic here and no CPU path.
+There is no CPU path, and no aten arithmetic on the train-step path; the one aten op in this file is the
+element-wise ``torch.minimum`` over an ensemble's outputs in ``predict()`` (an inference convenience the step plans
+never call: they take the minimum inside their loss kernels).
 
 Construction mirrors the reference's module/parameter creation ORDER (nn.Linear default
 init draws from the global torch RNG), so ``torch.manual_seed(s)`` followed by building a
@@ -101,8 +103,14 @@ class EnsembleQCritic(nn.Module):
         return [y[e, :, 0] for e in range(len(self.q_nets))]
 
     def predict(self, obs, act):
+        """net.py:235-238: (element-wise minimum over the ensemble, list of the members' values).  The minimum is a
+        view-free reduction over <= 8 [rows] vectors: torch.minimum on device tensors (memory plumbing, like the
+        stacking the reference does); the networks themselves run on the fused HIP kernels."""
         q_list = self.forward(obs, act)
-        return torch.min(torch.vstack(q_list), dim=0).values, q_list
+        qmin = q_list[0]
+        for q in q_list[1:]:
+            qmin = torch.minimum(qmin, q)
+        return qmin, q_list
 
 
 class EnsembleDoubleQCritic(nn.Module):

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/osrl_amd.h"
 
@@ -602,254 +603,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
   }
 }
 
-// ---- big-row forward: weights staged through LDS ----------------------------------------------------
-// mlp_fwd_kernel streams every layer's packed weights from L2 into registers once per 16-32-row tile; at the
-// N*B-row launches that is ~10 TB/s of L2->CU traffic at full MFMA rate and the pattern saturates near 7 TB/s
-// (tools/loop_probe.hip).  This kernel is the same fused network for launches with >= ~4 row blocks per CU and no
-// saved hidden activations:
-//   * one workgroup = 8 waves = 2 row groups x 4 column groups on a tile of h row blocks (h chosen on the host so
-//     that tiles x nets is a whole number of rounds over the 256 CUs: e.g. 20480 rows x 2 nets -> 512 tiles of 80 rows);
-//   * the activation tile stays in LDS (in place, layer by layer) AND each 16-deep k-slab of the packed weights
-//     (a contiguous 64*Np-byte chunk of PF[k/4][n][k%4]) is copied global -> registers -> LDS once per workgroup,
-//     so both MFMA operands are ds_read_b128; the next slab (also across a layer boundary) is in flight in
-//     registers while the current one is consumed; L2 traffic per FLOP drops ~3-5x (tools/lds_gemm_probe.hip: 82-89 %
-//     of the fp32 roof in the bare loop vs 66-71 %);
-//   * a narrow head layer (<= 32 outputs) splits K over the 4 column-group waves with weights straight from L2
-//     (16 KB per workgroup), as in mlp_fwd_kernel.
-struct BigArgs {
-  osrl_mlp_t net;
-  osrl_rows_t in;
-  osrl_mlp_acts_t out;
-  int32_t lda;        // LDS row stride (floats)
-  int32_t h_hi, n_hi; // tile heights in row blocks: blockIdx.x < n_hi -> h_hi, else h_hi - 1
-  int32_t w_off;      // float offset of the weight slab inside the LDS allocation
-};
-
-constexpr int kSlabChunks = 4;  // f32x4 per thread per slab: 4*Np f32x4 / 512 threads, Np <= 512
-
-template <int NRB, int NCB>
-__global__ __launch_bounds__(512, 2) void mlp_fwd_big_kernel(const BigArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int e = blockIdx.y;
-  const int rows = a.in.rows, lda = a.lda;
-  const int L = a.net.n_layers;
-  const int bx = blockIdx.x;
-  const int h = bx < a.n_hi ? a.h_hi : a.h_hi - 1;
-  const int rb_first = bx < a.n_hi ? bx * a.h_hi : a.n_hi * a.h_hi + (bx - a.n_hi) * (a.h_hi - 1);
-  const int row0 = rb_first * 16, BM = h * 16;
-  const int h0 = (h + 1) >> 1;                       // row blocks of row group 0
-  const int my_nrb = wr == 0 ? h0 : h - h0;          // this wave's active row blocks (<= NRB)
-  const int my_row = (wr == 0 ? 0 : h0) * 16;        // its first row inside the tile
-  float* W = lds + a.w_off;
-
-  // ---- weight-slab staging: slab s of layer l = PF + s*16*Np floats, 4*Np f32x4, thread t owns chunks t + 512*j
-  f32x4 stg[kSlabChunks];
-  auto slab_load = [&](int l, int ks) {
-    const int Np4 = 4 * round16(a.net.dims[l + 1]);
-    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.net.Wf[e][l]) + (size_t)ks * Np4;
-#pragma unroll
-    for (int j = 0; j < kSlabChunks; ++j) {
-      const int i = tid + 512 * j;
-      stg[j] = src[i < Np4 ? i : 0];
-    }
-  };
-  auto slab_store = [&](int l) {
-    const int Np4 = 4 * round16(a.net.dims[l + 1]);
-#pragma unroll
-    for (int j = 0; j < kSlabChunks; ++j) {
-      const int i = tid + 512 * j;
-      if (i < Np4) reinterpret_cast<f32x4*>(W)[i] = stg[j];
-    }
-  };
-  auto is_narrow = [&](int l) {
-    return ((a.net.dims[l + 1] + 15) >> 4) <= 2 && (round16(a.net.dims[l]) >> 4) >= 4 && lda >= 64;
-  };
-  WG_LOG(0);
-  PHASE_STAMP(0);
-  if (!is_narrow(0)) slab_load(0, 0);
-
-  {  // ---- stage cat(src0[map0(r)], src1[map1(r)]) zero-padded to a multiple of 16 columns (see mlp_fwd_kernel)
-    const int K0 = a.net.dims[0], K0p = round16(K0);
-    const int d0 = a.in.d0, d1 = a.in.d1;
-    const int cl = tid & 15, rl = tid >> 4;
-    const float* __restrict__ s0 = a.in.src0;
-    const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
-#pragma unroll 1
-    for (int r = rl; r < BM; r += 32) {
-      const int gr = row0 + r;
-      const bool rok = gr < rows;
-      const int grc = rok ? gr : rows - 1;
-      const float* p0 = s0 + (size_t)map_row(grc, a.in.map0, a.in.div0) * d0;
-      const float* p1 = s1 + (size_t)map_row(grc, a.in.map1, a.in.div1) * d1 - d0;
-      for (int cbase = 0; cbase < K0p; cbase += 16 * 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = cbase + j * 16 + cl;
-          const bool in0 = c < d0, ok = rok && c < d0 + d1;
-          const float* p = in0 ? p0 + c : p1 + c;
-          v[j] = *(ok ? p : s0);
-          v[j] = ok ? v[j] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = cbase + j * 16 + cl;
-          if (c < K0p) lds[r * lda + c] = v[j];
-        }
-      }
-    }
-  }
-
-  PHASE_STAMP(1);
-  f32x4 ring[kRing][1];  // narrow-layer weight ring (weights straight from L2)
-  for (int l = 0; l < L; ++l) {
-    const int K = a.net.dims[l], N = a.net.dims[l + 1];
-    const int Np = round16(N);
-    const int nblk = (N + 15) >> 4, nk = round16(K) >> 4;
-    const float* __restrict__ bias = a.net.b[e][l];
-    const int act = a.net.acts[l];
-    const float oscale = (l == L - 1) ? a.net.out_scale : 1.0f;
-    float* tile = lds + my_row * lda;  // this row group's rows
-    if (is_narrow(l)) {
-      // ---- narrow head: the 4 column-group waves of a row group split K (weights from L2), partials summed in LDS
-      __syncthreads();  // previous epilogue (or the staging) is visible
-      const NarrowPart np = narrow_part(nk, 0, nblk, wc);
-      f32x4 t[NRB][1];
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) t[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (np.k_n > 0) {
-        mm_prefetch<1, 1, 3>(ring, np.k_n, a.net.Wf[e][l], Np, np.col, np.k_lo);
-        mm_run<NRB, 1, 1, 1, 3>(tile, lda, np.k_n, a.net.Wf[e][l], Np, np.col, t, ring, np.k_lo);
-      }
-      PHASE_STAMP(2 + 4 * l);
-      __syncthreads();  // all reads of the input activations are done
-      PHASE_STAMP(3 + 4 * l);
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb)
-        if (rb < my_nrb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tile[(rb * 16 + (lane >> 4) * 4 + r) * lda + wc * 16 + (lane & 15)] = t[rb][0][r];
-        }
-      __syncthreads();
-      const int parts = 4 / nblk, ncol = nblk * 16;
-      constexpr int PER = (32 * NRB * 32 + 511) / 512;
-      float v[PER];
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        const int idx = j * 512 + tid;
-        float sacc = 0.f;
-        if (idx < BM * ncol) {
-          const int r = idx / ncol, c = idx - r * ncol;
-          const int b = c >> 4, cc = c & 15;
-          for (int q = 0; q < parts; ++q) sacc += lds[r * lda + (b * parts + q) * 16 + cc];
-          sacc = c < N ? act_fwd(act, sacc + bias[c]) * oscale : 0.f;
-        }
-        v[j] = sacc;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        const int idx = j * 512 + tid;
-        if (idx < BM * ncol) {
-          const int r = idx / ncol, c = idx - r * ncol;
-          lds[r * lda + c] = v[j];
-        }
-      }
-      if (l + 1 < L && !is_narrow(l + 1)) slab_load(l + 1, 0);
-      PHASE_STAMP(4 + 4 * l);
-      PHASE_STAMP(5 + 4 * l);
-    } else {
-      int cb0, cnt;
-      wave_blocks(nblk, wc, &cb0, &cnt);
-      float bv[NCB];
-#pragma unroll
-      for (int c = 0; c < NCB; ++c) {
-        const int col = (cb0 + c) * 16 + (lane & 15);
-        const bool ok = c < cnt && col < N;
-        bv[c] = bias[ok ? col : 0];
-        bv[c] = ok ? bv[c] : 0.f;
-      }
-      f32x4 acc[NRB][NCB];
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{bv[c], bv[c], bv[c], bv[c]};
-      const float* arow = tile + (lane & 15) * lda + 4 * (lane >> 4);
-      const float* wfrag = W + ((lane >> 4) * Np + cb0 * 16 + (lane & 15)) * 4;
-      for (int ks = 0; ks < nk; ++ks) {
-        __syncthreads();  // the previous slab (and, at ks == 0, the previous layer's activations) fully consumed / written
-        slab_store(l);
-        __syncthreads();
-        if (ks + 1 < nk) {
-          slab_load(l, ks + 1);
-        } else if (l + 1 < L && !is_narrow(l + 1)) {
-          slab_load(l + 1, 0);  // next layer's first slab rides through the epilogue in registers
-        }
-        f32x4 af[NRB], bf[NCB];
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) af[rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ks * 16);
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) bf[c] = *reinterpret_cast<const f32x4*>(wfrag + (c < cnt ? c : 0) * 64);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < NCB; ++c)
-            if (c < cnt) {
-#pragma unroll
-              for (int rb = 0; rb < NRB; ++rb)
-                if (rb < my_nrb) acc[rb][c] = EXP_MFMA(af[rb][t], bf[c][t], acc[rb][c]);
-            }
-      }
-      PHASE_STAMP(2 + 4 * l);
-      __syncthreads();  // every wave finished reading the activations of this layer
-      PHASE_STAMP(3 + 4 * l);
-      auto epilogue = [&](auto act_c) {
-        constexpr int ACT = decltype(act_c)::value;
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-          if (c < cnt) {
-            const int col = (cb0 + c) * 16 + (lane & 15);
-            const bool live = col < N;
-            float* dst = tile + ((lane >> 4) * 4) * lda + col;
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-              if (rb < my_nrb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float v = act_fwd(ACT, acc[rb][c][r]) * oscale;
-                  dst[(rb * 16 + r) * lda] = live ? v : 0.f;  // zero the k-padding of the next layer
-                }
-              }
-            }
-          }
-        }
-      };
-      if (act == OSRL_ACT_RELU)
-        epilogue(std::integral_constant<int, OSRL_ACT_RELU>{});
-      else if (act == OSRL_ACT_TANH)
-        epilogue(std::integral_constant<int, OSRL_ACT_TANH>{});
-      else
-        epilogue(std::integral_constant<int, OSRL_ACT_ID>{});
-      PHASE_STAMP(4 + 4 * l);
-      PHASE_STAMP(5 + 4 * l);
-    }
-  }
-  __syncthreads();
-  {  // the net output tile [BM][N_L] -> global
-    const int N = a.net.dims[L];
-    float* __restrict__ dst = a.out.h[e][L - 1];
-    for (int idx = tid; idx < BM * N; idx += 512) {
-      const int r = idx / N, c = idx - r * N;
-      if (row0 + r < rows) dst[(size_t)(row0 + r) * N + c] = lds[r * lda + c];
-    }
-  }
-  PHASE_STAMP(14);
-  WG_LOG(1);
-}
-
 // ---- N*B-row forward: 80-row tiles, ONE 4-wave workgroup per CU ------------------------------------------
 // The inference-only launches of a step (CPQ: target cost critics and the VAE encoder on the N*B = 20480 sampled
 // rows; BCQ-Lag / BEAR-Lag: decoder, actor, target critics on N*B rows) carry 69 % of the step's FLOPs.  With the tile
@@ -1388,6 +1141,126 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
 
 
 
+// ---- dW for big row counts: one wave = one 128x128 tile, one wave per SIMD ------------------------------------
+// mlp_dw_kernel above is built for B = 2048-4096 rows (many small tiles, 4 waves splitting a few hundred rows).  At
+// token-matrix sizes (CDT: M = 81920 rows, dW tiles of 768x256 ... 256x1024) its k-loop is the regime tools/
+// loop_probe2.hip diagnoses: 64x64 tiles per wave, 2 waves per SIMD, 32 fragment loads per 64 MFMAs -> 58 % of the roof.
+// Here every wave owns a 128x64 output tile (128 accumulator registers) for one split of the rows: 48 fragment loads
+// feed 128 MFMAs per 16-row k-step, the next step's loads are issued before this step's MFMAs (order pinned), four
+// independent waves form a workgroup (no LDS traffic, no barriers; the LDS request only keeps it at one workgroup per
+// CU = one wave per SIMD), and the host picks the split count so that tiles x splits fill the 256 CUs in one round.
+// Takes the (entry, 128-row block, 64-column block) items whose tile lies fully inside dW; the rest of the plan
+// (ragged edges, narrow layers, biases of layers with no full tile) stays with mlp_dw_kernel.
+constexpr int kDwbO = 8, kDwbI = 4;  // 16-wide blocks per wave tile: 128 (out) x 64 (in); 8 x 8 (256 accumulators)
+                                      // spills 373 registers around the loop even at 512 per lane
+
+struct DwBigFrag {
+  f32x4 a[kDwbO], b[kDwbI];
+};
+
+__device__ __forceinline__ void dwb_load(DwBigFrag& f, const float* __restrict__ dz, const float* __restrict__ av,
+                                         size_t ldz, size_t lda_g, int r0, int r_end, int m, int kq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = r0 + 4 * kq + t;
+    const bool rok = r < r_end;
+    const size_t rc = (size_t)(rok ? r : r_end - 1);
+    const float* __restrict__ pz = dz + rc * ldz + m;
+    const float* __restrict__ pa = av + rc * lda_g + m;
+#pragma unroll
+    for (int ob = 0; ob < kDwbO; ++ob) {
+      const float v = pz[ob * 16];
+      f.a[ob][t] = rok ? v : 0.f;
+    }
+#pragma unroll
+    for (int ib = 0; ib < kDwbI; ++ib) {
+      const float v = pa[ib * 16];
+      f.b[ib][t] = rok ? v : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_dw_big_kernel(const osrl_dw_entry_t* __restrict__ entries,
+                                                            const int32_t* __restrict__ items, int n_items, int rows,
+                                                            int rows_per_split, float* __restrict__ slabs,
+                                                            int64_t slab_stride) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_items) return;  // whole wave; the kernel has no barrier
+  const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
+  const osrl_dw_entry_t E = entries[ei];
+  const int out = E.out, in = E.in;
+  const size_t ldz = E.ldz > 0 ? (size_t)E.ldz : (size_t)out, lda_g = E.lda > 0 ? (size_t)E.lda : (size_t)in;
+  const int o0 = ot * 16 * kDwbO, i0 = it * 16 * kDwbI;
+  const int s = blockIdx.y;
+  const int r_begin = s * rows_per_split;
+  int r_end = r_begin + rows_per_split;
+  r_end = r_end > rows ? rows : r_end;
+  const int m = lane & 15, kq = lane >> 4;
+  const bool want_db = it == 0;
+  const float* __restrict__ dz = E.dz + o0;
+  const float* __restrict__ av = E.a + i0;
+
+  f32x4 acc[kDwbO][kDwbI];
+#pragma unroll
+  for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < kDwbI; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc[kDwbO];
+#pragma unroll
+  for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] = 0.f;
+  if (r_begin < r_end) {
+    DwBigFrag f[2];
+    dwb_load(f[0], dz, av, ldz, lda_g, r_begin, r_end, m, kq);
+    auto step = [&](auto s_c, int r0) {
+      constexpr int c = decltype(s_c)::value;
+      // the next step's fragments first (rows past r_end load a clamped row and become zeros)
+      dwb_load(f[c ^ 1], dz, av, ldz, lda_g, r0 + 16, r_end, m, kq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+          for (int ib = 0; ib < kDwbI; ++ib)
+            acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[c].a[ob][t], f[c].b[ib][t], acc[ob][ib], 0, 0, 0);
+      if (want_db) {
+#pragma unroll
+        for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] += (f[c].a[ob][0] + f[c].a[ob][1]) + (f[c].a[ob][2] + f[c].a[ob][3]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 4 * (kDwbO + kDwbI), 0);  // VMEM reads of the next step
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kDwbO * kDwbI, 0);    // this step's MFMAs
+    };
+    using std::integral_constant;
+    int r0 = r_begin;
+    for (; r0 + 32 <= r_end; r0 += 32) {
+      step(integral_constant<int, 0>{}, r0);
+      step(integral_constant<int, 1>{}, r0 + 16);
+    }
+    if (r0 < r_end) {
+      step(integral_constant<int, 0>{}, r0);
+      if (r0 + 16 < r_end) step(integral_constant<int, 1>{}, r0 + 16);
+    }
+  }
+  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+#pragma unroll
+  for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < kDwbI; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        slab[E.w_off + (size_t)(o0 + ob * 16 + kq * 4 + r) * in + i0 + ib * 16 + m] = acc[ob][ib][r];
+  if (want_db) {
+#pragma unroll
+    for (int ob = 0; ob < kDwbO; ++ob) {
+      float v = dbacc[ob];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0) slab[E.b_off + o0 + ob * 16 + m] = v;
+    }
+  }
+}
+
 // ---- general linear layer  Y[M, N] = A[M, K] * P (+ bias) (+ resid)  ------------------------------
 // The transformer-sized sibling of mlp_fwd_kernel (CDT: QKV / out-proj / MLP projections and their
 // dX GEMMs, osrl/common/net.py:406-415,422-441): one launch = one GEMM, K up to 1024, N unbounded via
@@ -1514,6 +1387,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a) {
 // (double buffered, one barrier per k-step), every wave reads its fragments with ds_read_b128 and issues 64 MFMAs.
 // L2 -> CU traffic per FLOP is 4x lower than with 32-row tiles.  Requires K % 16 == 0, N % 256 == 0 (per launch
 // column group), 16-byte aligned A rows.
+// (Round 2, measured and removed: (i) GELU fused into this kernel's epilogue -- forward writing pre-activation and
+// gelu(pre-activation), backward multiplying the dX of mlp.2 by gelu'(hpre): the 64-byte-segment epilogue with erff /
+// expf per element costs what the separate streaming GELU passes cost (CDT step 18.75 -> 18.84 ms); (ii) a
+// one-wave-per-SIMD variant in the style of mlp_fwd_nb_kernel (80-row slice of A resident in LDS, 4 column blocks per
+// wave): 380 us per call vs 311 us here -- with 16 k-steps per column group / K chunk the exposed stage-in, loop start
+// and 80-store epilogues of a lone wave outweigh the better k-loop.)
 struct LinBigArgs {
   const float* A;
   const float* P;
@@ -1720,70 +1599,8 @@ bool valid_net(const osrl_mlp_t* n) {
 }
 
 
-// ---- host side of mlp_fwd_big_kernel: eligibility, tile-height plan, launch ------------------------------
 constexpr int kNotBig = -12345;
-constexpr int kCUs = 256;                 // MI355X
 constexpr size_t kLdsMax = 160 * 1024;
-
-template <int NRB, int NCB>
-static int launch_big(const BigArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_big_kernel<NRB, NCB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return (int)e;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL((mlp_fwd_big_kernel<NRB, NCB>), dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
-  return (int)hipGetLastError();
-}
-
-static int launch_fwd_big(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream) {
-  const int L = net->n_layers, nets = net->n_nets;
-  // opt-in (tile_rows = -1) until it beats mlp_fwd_kernel end to end: measured 103 vs 85 us on the C2 cost-critic
-  // launch -- one workgroup per CU leaves staging / epilogues / slab barriers unhidden
-  if (net->tile_rows != -1 || out->x || (kCUs % nets) != 0) return kNotBig;
-  for (int e = 0; e < nets; ++e)
-    for (int l = 0; l + 1 < L; ++l)
-      if (out->h[e][l]) return kNotBig;  // training launches keep hidden activations: mlp_fwd_kernel
-  int wmax = 0, nmax = 0;
-  for (int l = 0; l <= L; ++l) wmax = net->dims[l] > wmax ? net->dims[l] : wmax;
-  for (int l = 1; l <= L; ++l) nmax = net->dims[l] > nmax ? net->dims[l] : nmax;
-  const int lda = ((wmax + 15) & ~15) + 8;
-  const int Npmax = (nmax + 15) & ~15;
-  const int ncb = (((nmax + 15) >> 4) + 3) / 4;  // column blocks per column-group wave
-  if (lda < 72 || Npmax > 448 || ncb > 7) return kNotBig;
-  const int rb_total = (in->rows + 15) / 16;
-  const int per_cu = (rb_total * nets + kCUs - 1) / kCUs;  // row blocks x nets per CU
-  if (per_cu < 4) return kNotBig;                          // small launches: one workgroup per CU anyway
-  // tallest tile the LDS holds: h*16 activation rows + one slab + 16 guard rows (inactive row blocks read past the tile)
-  const size_t slab = (size_t)16 * Npmax * 4;
-  const int nrb_max = ncb > 4 ? 3 : 4;
-  int h_max = (int)((kLdsMax - slab) / ((size_t)16 * lda * 4)) - 1;
-  h_max = h_max > 2 * nrb_max ? 2 * nrb_max : h_max;
-  if (h_max < 2) return kNotBig;
-  const int rounds = (per_cu + h_max - 1) / h_max;
-  int tiles = kCUs * rounds / nets;  // per net: tiles x nets = a whole number of rounds over the CUs
-  if (tiles > rb_total) tiles = rb_total;
-  const int h_hi = (rb_total + tiles - 1) / tiles;
-  const int n_hi = rb_total - (h_hi - 1) * tiles;  // tiles of height h_hi; the rest h_hi - 1 (>= 1 when n_hi < tiles)
-  if (h_hi > h_max || (h_hi == 1 && n_hi < tiles)) return kNotBig;
-  BigArgs a;
-  a.net = *net;
-  a.in = *in;
-  a.out = *out;
-  a.lda = lda;
-  a.h_hi = h_hi;
-  a.n_hi = n_hi;
-  a.w_off = (h_hi + 1) * 16 * lda;
-  const size_t lds_bytes = ((size_t)a.w_off + (size_t)16 * Npmax) * 4;
-  if (lds_bytes > kLdsMax) return kNotBig;
-  const int nrb = (h_hi + 1) / 2;
-  if (ncb <= 4) {
-    if (nrb <= 2) return launch_big<2, 4>(a, tiles, nets, lds_bytes, stream);
-    if (nrb == 3) return launch_big<3, 4>(a, tiles, nets, lds_bytes, stream);
-    return launch_big<4, 4>(a, tiles, nets, lds_bytes, stream);
-  }
-  if (nrb <= 2) return launch_big<2, 7>(a, tiles, nets, lds_bytes, stream);
-  return launch_big<3, 7>(a, tiles, nets, lds_bytes, stream);
-}
 
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
 template <int NCB>
@@ -1837,9 +1654,7 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
       if (!net->Wf[e][l] || !net->b[e][l]) return -1;
   }
   {
-    int rc = launch_fwd_big(net, in, out, (hipStream_t)stream);
-    if (rc != kNotBig) return rc;
-    rc = launch_fwd_nb(net, in, out, (hipStream_t)stream);
+    const int rc = launch_fwd_nb(net, in, out, (hipStream_t)stream);
     if (rc != kNotBig) return rc;
   }
   FwdArgs a;
@@ -1990,6 +1805,22 @@ extern "C" int osrl_pack_weights(const float* src_flat, float* pf, float* pb, co
   bx = bx < 1 ? 1 : bx > 64 ? 64 : bx;
   (void)hipGetLastError();
   hipLaunchKernelGGL(pack_kernel, dim3(bx, n_entries), dim3(256), 0, (hipStream_t)stream, src_flat, pf, pb, d_entries);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
+                                        int32_t rows, int32_t n_splits, float* slabs, int64_t slab_stride,
+                                        void* stream) {
+  if (!d_entries || !d_items || n_items < 1 || rows < 1 || n_splits < 1 || !slabs) return -1;
+  int rps = (rows + n_splits - 1) / n_splits;
+  rps = (rps + 15) & ~15;  // whole 16-row k-steps
+  constexpr int kLds = 96 * 1024;  // unused: more than half of the CU's LDS -> one workgroup (one wave per SIMD) per CU
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_big_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(mlp_dw_big_kernel, dim3((n_items + 3) / 4, n_splits, 1), dim3(256), kLds, (hipStream_t)stream,
+                     d_entries, d_items, n_items, rows, rps, slabs, slab_stride);
   return (int)hipGetLastError();
 }
 

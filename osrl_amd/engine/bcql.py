@@ -66,14 +66,16 @@ class BCQLEngine:
 
         # target pipeline buffers (shared by the critic and the cost-critic phases)
         NB = N * B
-        self.r_dec_t = MlpRun(self.d_dec, NB, False, dev)
-        self.r_actor_old_t = MlpRun(self.d_actor_old, NB, False, dev)
+        import os
+        tr = int(os.environ.get("OSRL_BCQ_TILE", "0"))  # 80: the one-workgroup-per-CU forward (csrc/mlp.hip nb kernel)
+        self.r_dec_t = MlpRun(self.d_dec, NB, False, dev, tile_rows=tr)
+        self.r_actor_old_t = MlpRun(self.d_actor_old, NB, False, dev, tile_rows=tr)
         self.a_t = z(NB, ad)
-        self.r_qold_t = MlpRun(self.d_critic_old, NB, False, dev)
-        self.r_qcold_t = MlpRun(self.d_cost_old, NB, False, dev)
+        self.r_qold_t = MlpRun(self.d_critic_old, NB, False, dev, tile_rows=tr)
+        self.r_qcold_t = MlpRun(self.d_cost_old, NB, False, dev, tile_rows=tr)
         # second set of pipeline buffers: the cost-critic phase runs on a side graph branch beside the critic phase
-        self.r_dec_t2 = MlpRun(self.d_dec, NB, False, dev)
-        self.r_actor_old_t2 = MlpRun(self.d_actor_old, NB, False, dev)
+        self.r_dec_t2 = MlpRun(self.d_dec, NB, False, dev, tile_rows=tr)
+        self.r_actor_old_t2 = MlpRun(self.d_actor_old, NB, False, dev, tile_rows=tr)
         self.a_t2 = z(NB, ad)
 
         self.r_critic = MlpRun(self.d_critic, B, True, dev)
@@ -231,7 +233,8 @@ class BCQLEngine:
         with torch.cuda.stream(s):
             self.body(True)
         torch.cuda.current_stream().wait_stream(s)
-        par = Branches(True, 1)
+        import os
+        par = Branches(os.environ.get("OSRL_BCQ_SERIAL", "0") != "1", 1)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.body(True, par)

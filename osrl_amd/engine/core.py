@@ -437,11 +437,15 @@ class MlpRun:
 class DwPlan:
     """Static work list for osrl_mlp_backward_dw over one optimizer group."""
 
+    BIG_ROWS = 8192  # from this many rows on, fully 128x128-tiled layers take the one-wave-per-tile kernel
+
     def __init__(self, group: FlatGroup, entries: Sequence[Tuple[torch.Tensor, torch.Tensor, str, str]],
-                 rows: int, device, n_splits: Optional[int] = None):
+                 rows: int, device, n_splits: Optional[int] = None, big: Optional[bool] = None):
         self.group, self.rows = group, rows
         arr = (L.DwEntryT * len(entries))()
         items: List[int] = []
+        big_items: List[int] = []
+        use_big = (rows >= self.BIG_ROWS) if big is None else bool(big)
         for i, ent in enumerate(entries):
             dz, a, wk, bk = ent[:4]
             # optional 5th/6th items: (ptr, row stride, width) views for strided operands
@@ -456,28 +460,54 @@ class DwPlan:
             arr[i].a = a if isinstance(a, int) else a.data_ptr()
             arr[i].w_off, arr[i].b_off = group.offset(wk), group.offset(bk)
             arr[i].out, arr[i].in_ = out_f, in_f
+            if use_big and out_f % 128 == 0 and in_f % 64 == 0:
+                # token-matrix sized GEMMs (CDT projections): every 128x64 tile to osrl_mlp_backward_dw_big
+                for ot in range(out_f // 128):
+                    for it in range(in_f // 64):
+                        big_items += [i, ot, it, 0]
+                continue
             for ot in range((out_f + 63) // 64):
                 for it in range((in_f + 63) // 64):
                     items += [i, ot, it, 0]
         self.n_items = len(items) // 4
+        self.n_big = len(big_items) // 4
         raw = bytes(arr)
         self.d_entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.d_items = torch.tensor(items, dtype=torch.int32, device=device)
+        self.d_items = torch.tensor(items if items else [0, 0, 0, 0], dtype=torch.int32, device=device)
+        self.d_big = torch.tensor(big_items, dtype=torch.int32, device=device) if big_items else None
         self._keep = [e[0] for e in entries] + [e[1] for e in entries] + [e[6:] for e in entries if len(e) > 6]
         if n_splits is None:
             # one workgroup per (tile, split): aim at >= 4 rounds of the 512 resident workgroups (2 per CU at
             # 66 KB LDS) so the tail round is small, but keep >= 64 rows (4 k-steps) per wave; each split costs
             # one slab write here and one slab read in the Adam kernel
-            n_splits = max(1, min((2048 + self.n_items - 1) // self.n_items, max(rows // 256, 1), 32))
-        self.n_splits = n_splits
-        group.ensure_slabs(n_splits)
+            n_splits = max(1, min((2048 + max(self.n_items, 1) - 1) // max(self.n_items, 1), max(rows // 256, 1), 32))
+        self.n_splits_small = n_splits if self.n_items else 0
+        # big tiles: 4 waves (tiles) per workgroup, one workgroup per CU -> as many row splits as fill the 256 CUs once
+        self.n_splits_big = 0
+        if self.n_big:
+            wgs = (self.n_big + 3) // 4
+            best, best_eff = 1, 0.0
+            for S in range(1, min(32, max(rows // 512, 1)) + 1):  # fill whole rounds of the 256 CUs
+                eff = wgs * S / (256.0 * ((wgs * S + 255) // 256))
+                if eff > best_eff + 1e-9:
+                    best, best_eff = S, eff
+            self.n_splits_big = best
+        self.n_splits = max(self.n_splits_small, self.n_splits_big, 1)
+        group.ensure_slabs(self.n_splits)
 
     def launch(self) -> None:
+        """Both launches write disjoint parameter ranges; a range's slabs beyond its own split count are never written
+        and stay zero (FlatGroup.ensure_slabs allocates zeros), so the consumer may sum ``n_splits`` slabs of everything."""
         g = self.group
         g.cur_splits = self.n_splits
-        L.check(L.load().osrl_mlp_backward_dw(self.d_entries.data_ptr(), self.d_items.data_ptr(), self.n_items,
-                                              self.rows, self.n_splits, g.slabs.data_ptr(), g.n, cur_stream()),
-                "osrl_mlp_backward_dw")
+        if self.n_items:
+            L.check(L.load().osrl_mlp_backward_dw(self.d_entries.data_ptr(), self.d_items.data_ptr(), self.n_items,
+                                                  self.rows, self.n_splits_small, g.slabs.data_ptr(), g.n, cur_stream()),
+                    "osrl_mlp_backward_dw")
+        if self.n_big:
+            L.check(L.load().osrl_mlp_backward_dw_big(self.d_entries.data_ptr(), self.d_big.data_ptr(), self.n_big,
+                                                      self.rows, self.n_splits_big, g.slabs.data_ptr(), g.n,
+                                                      cur_stream()), "osrl_mlp_backward_dw_big")
 
 
 class Branches:

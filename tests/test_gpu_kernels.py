@@ -188,7 +188,8 @@ BIG_CASES = [
 
 @pytest.mark.parametrize("ci", range(len(BIG_CASES)))
 def test_mlp_fwd_big_rows(ci):
-    """The LDS-staged-weights forward kernel (mlp_fwd_big_kernel) (opt-in: tile_rows=-1) vs fp64 and vs the tile kernel (tile_rows=16); forward-only launches, as the N*B-row launches of CPQ / BCQ-Lag."""
+    """The 80-row one-workgroup-per-CU forward kernel (mlp_fwd_nb_kernel, tile_rows=80) vs fp64 and vs the tile kernels
+    (tile_rows = 32 / 16); forward-only launches, as the N*B-row launches of CPQ / BCQ-Lag."""
     from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
     E, dims, acts, oscale, rows, (d0, map0, div0) = BIG_CASES[ci]
     dev = _dev()
@@ -218,8 +219,8 @@ def test_mlp_fwd_big_rows(ci):
     src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
     src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
     outs = []
-    for tile_rows in (-1, 16, 80):  # 80: one 4-wave workgroup per CU (falls back to the default tile when the widest
-        # layer needs neither 4 nor 7 column blocks per wave)
+    for tile_rows in (32, 16, 80):  # 80: one 4-wave workgroup per CU (shapes the kernel does not take -- hidden layers
+        # of neither 13-16 nor 25-28 column blocks, wide last layer -- fall back to the default tile)
         desc = NetDesc(refs, acts, oscale)
         desc.c.tile_rows = tile_rows
         run = MlpRun(desc, rows, False, dev)
@@ -235,7 +236,7 @@ def test_mlp_fwd_big_rows(ci):
         for l, a in enumerate(acts):
             h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
         h = h * oscale
-        for nm, got in (("big", outs[0][e]), ("tile", outs[1][e]), ("tile80", outs[2][e])):
+        for nm, got in (("tile32", outs[0][e]), ("tile16", outs[1][e]), ("tile80", outs[2][e])):
             err = np.abs(got.reshape(h.shape) - h).max()
             assert err < 3e-5 * max(1.0, np.abs(h).max()), f"case {ci} {nm} kernel net {e}: max err {err}"
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
@@ -591,3 +592,31 @@ def test_dice_chi_step_kernel(B, n_chi, scale):
     g = (1 / (1 + np.exp(-0.4))) * (eps_ub - dkl)  # first Adam step: p -= lr * sign-like m/(sqrt(v)+eps)
     want = 0.4 - lr * g / (abs(g) + 1e-8)
     assert abs(leaves[0].item() - want) < 1e-5, (leaves[0].item(), want)
+
+
+@pytest.mark.parametrize("rows,out_f,in_f,force_big", [(8192 + 40, 256, 128, None), (3000, 128, 192, True),
+                                                       (16384, 384, 256, None), (8200, 128, 64, None)])
+def test_dw_big_rows_kernel(rows, out_f, in_f, force_big):
+    """osrl_mlp_backward_dw_big (one wave per 128x64 tile, one wave per SIMD; CDT's token-matrix dW) vs fp64, next to a
+    ragged layer of the same plan that stays with the 64x64-tile kernel; ragged row counts and several row splits."""
+    from osrl_amd.engine.core import DwPlan, FlatGroup
+    dev = _dev()
+    rs = np.random.RandomState(rows % 97)
+    grp = FlatGroup("t", dev)
+    for k, shp in (("a.w", (out_f, in_f)), ("a.b", (out_f,)), ("s.w", (40, 24)), ("s.b", (40,))):
+        grp.add(k, shp)
+    grp.finalize()
+    dz = torch.tensor(rs.randn(rows, out_f), dtype=torch.float32, device=dev)
+    a = torch.tensor(rs.randn(rows, in_f), dtype=torch.float32, device=dev)
+    dz2 = torch.tensor(rs.randn(rows, 40), dtype=torch.float32, device=dev)
+    a2 = torch.tensor(rs.randn(rows, 24), dtype=torch.float32, device=dev)
+    plan = DwPlan(grp, [(dz, a, "a.w", "a.b"), (dz2, a2, "s.w", "s.b")], rows, dev, big=force_big)
+    assert plan.n_big == (out_f // 128) * (in_f // 64) and plan.n_items > 0
+    plan.launch()
+    torch.cuda.synchronize()
+    for (z, x, wk, bk) in ((dz, a, "a.w", "a.b"), (dz2, a2, "s.w", "s.b")):
+        want = z.cpu().numpy().astype(np.float64).T @ x.cpu().numpy().astype(np.float64)
+        got = grp.grad_view(wk).cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (wk, np.abs(got - want).max())
+        wb = z.cpu().numpy().astype(np.float64).sum(0)
+        assert np.abs(grp.grad_view(bk).cpu().numpy() - wb).max() <= 2e-5 * max(1.0, np.abs(wb).max()), bk
