@@ -423,100 +423,136 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// Backward of the attention core.  Round 2: TWO workgroups per CU instead of one (108 -> 62 KB of LDS).  The kernel is
+// latency bound (about 600 MFMAs per (sample, head), 30 us per workgroup), so residency is what buys throughput:
+//   * one [S, S] tile instead of two: dP = dO V^T is an MFMA product that costs nothing to recompute, so pass 1 forms
+//     the dP blocks in registers only to get the row sums r_i = sum_j P'_ij dP'_ij (per-column-block partials in LDS,
+//     summed in a fixed order: deterministic), dV = P'^T dO is taken while the tile still holds P, and pass 2 recomputes
+//     the dP blocks and overwrites P with dS = P' dP' - P r in place;
+//   * two [S, d] operand tiles instead of four: (Q, K) for the probabilities, then (dO, V), then (Q, K) again for dQ / dK
+//     (the re-load is 20 KB from L2);
+//   * attention dropout: the keep mask of the tile is materialised once as bytes (regenerated from the counters exactly
+//     as the forward kernel draws it), because P' = P M / (1-p) and P are both needed.
+__device__ __forceinline__ float attn_keep_mult(const AttnArgs& a, const unsigned char* Mb, int Sp, int i, int j) {
+  return a.drop_thresh ? (Mb[i * Sp + j] ? a.drop_scale : 0.f) : 1.0f;
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = a.E / a.H, dp = (d + 15) & ~15, Sp = (a.S + 15) & ~15;
   const int ldq = dp + 8, ldp = Sp + 8;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float *Qs = sm, *Ks = Qs + Sp * ldq, *Vs = Ks + Sp * ldq, *dOs = Vs + Sp * ldq, *Ps = dOs + Sp * ldq,
-        *dS = Ps + Sp * ldp, *kvalid = dS + Sp * ldp;
+  const int nb = Sp >> 4, ncb = dp >> 4, ntri = nb * (nb + 1) / 2;
+  float *T0 = sm, *T1 = T0 + Sp * ldq, *Ps = T1 + Sp * ldq, *rpart = Ps + Sp * ldp, *kvalid = rpart + nb * Sp;
+  unsigned char* Mb = reinterpret_cast<unsigned char*>(kvalid + Sp);
   const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
-  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, Qs, ldq, nullptr, 0);
-  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, Ks, ldq, nullptr, 0);
-  attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, Vs, ldq, nullptr, 0);
-  attn_load_tile(a.dout + (size_t)b * a.S * a.E + h * d, a.E, a.S, d, Sp, dp, dOs, ldq, nullptr, 0);
+  const float* __restrict__ dob = a.dout + (size_t)b * a.S * a.E + h * d;
+  // ---- phase A: P = softmax(mask(Q K^T / sqrt(d)))  (T0 = Q, T1 = K)
+  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
+  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
   attn_key_valid(a, b, Sp, kvalid);
   __syncthreads();
-  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid, false, blockIdx.x);
-  const int nb = Sp >> 4, ncb = dp >> 4, ntri = nb * (nb + 1) / 2;
-  // dP = dO V^T on the lower-triangular blocks
-  for (int blk = wave; blk < ntri; blk += 4) {
-    int ib, jb;
-    tri_decode(blk, &ib, &jb);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < dp; kc += 16) mfma4(acc, frag_row(dOs, ldq, ib * 16, kc, lane), frag_row(Vs, ldq, jb * 16, kc, lane));
-    const int j = jb * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dS[(ib * 16 + 4 * (lane >> 4) + r) * ldp + j] = acc[r];
-  }
-  __syncthreads();
-  // dS = P * (dP - rowsum(dP * P)); zero outside the computed blocks
-  {
+  attn_probs_mfma(a, b, d, Sp, dp, T0, T1, ldq, Ps, ldp, kvalid, false, blockIdx.x);  // ends with a barrier
+  // ---- phase B: T0 = dO, T1 = V
+  attn_load_tile(dob, a.E, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
+  attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
+  if (a.drop_thresh) {  // keep mask of the whole tile, drawn in the forward kernel's row layout
     const int l16 = lane & 15, rsub = lane >> 4;
     for (int i0 = wave * 4; i0 < Sp; i0 += 16) {
       const int i = i0 + rsub;
-      const int jmax = ((i >> 4) + 1) << 4;
-      float pv[8], gv[8];
-      float r = 0.f;
+      float dm[8];
+      if (i < a.S) {
+        attn_drop_mult(a, blockIdx.x, i, l16, ((i >> 4) + 1), dm);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dm[k] = 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int j = l16 + 16 * k;
-        const bool in = j < jmax && j < Sp;
-        pv[k] = in ? Ps[i * ldp + j] : 0.f;
-        gv[k] = in ? dS[i * ldp + j] : 0.f;
-        r += pv[k] * gv[k];
-      }
-      if (a.drop_thresh && i < a.S) {
-        // with dropout gv is dP' (grad wrt the dropped probabilities P' = P*M'):  dS = P'*dP' - P*sum_j(P'*dP'),
-        // and dV below needs P' -> Ps is overwritten with it (each element is owned by exactly this lane)
-        float dm[8], pd[8];
-        attn_drop_mult(a, blockIdx.x, i, l16, jmax >> 4, dm);
-        r = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          pd[k] = pv[k] * dm[k];
-          r += pd[k] * gv[k];
-        }
-        r = row16_sum(r);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int j = l16 + 16 * k;
-          if (j < Sp) {
-            dS[i * ldp + j] = pd[k] * gv[k] - pv[k] * r;
-            if (j < jmax) Ps[i * ldp + j] = pd[k];
-          }
-        }
-        continue;
-      }
-      r = row16_sum(r);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int j = l16 + 16 * k;
-        if (j < Sp) dS[i * ldp + j] = pv[k] * (gv[k] - r);
+        if (j < Sp) Mb[i * Sp + j] = dm[k] != 0.f ? 1 : 0;
       }
     }
   }
   __syncthreads();
+  // dP block (ib, jb) = dO[ib] V[jb]^T in registers
+  auto dp_block = [&](int ib, int jb) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < dp; kc += 16) mfma4(acc, frag_row(T0, ldq, ib * 16, kc, lane), frag_row(T1, ldq, jb * 16, kc, lane));
+    return acc;
+  };
+  // pass 1: r-partials  rpart[jb][i] = sum_{j in block jb} P'_ij dP'_ij
+  for (int blk = wave; blk < ntri; blk += 4) {
+    int ib, jb;
+    tri_decode(blk, &ib, &jb);
+    const f32x4 g = dp_block(ib, jb);
+    const int j = jb * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ib * 16 + 4 * (lane >> 4) + r;
+      float t = Ps[i * ldp + j] * attn_keep_mult(a, Mb, Sp, i, j) * g[r];
+      t = row16_sum(t);
+      if ((lane & 15) == 0) rpart[jb * Sp + i] = t;
+    }
+  }
+  __syncthreads();
+  // dV[j][c] = sum_{i >= j} P'[i][j] dO[i][c]   (while Ps still holds P)
+  for (int blk = wave; blk < nb * ncb; blk += 4) {
+    const int rb = blk / ncb, cb = blk - rb * ncb;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ic = rb; ic < nb; ++ic) {
+      f32x4 pf = frag_col(Ps, ldp, ic * 16, rb * 16, lane);
+      if (a.drop_thresh) {
+        const int i0 = ic * 16 + 4 * (lane >> 4), j = rb * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pf[t] *= Mb[(i0 + t) * Sp + j] ? a.drop_scale : 0.f;
+      }
+      mfma4(acc, pf, frag_col(T0, ldq, ic * 16, cb * 16, lane));
+    }
+    const int c = cb * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = rb * 16 + 4 * (lane >> 4) + r;
+      if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + 2 * a.E + h * d + c] = acc[r];
+    }
+  }
+  __syncthreads();
+  // pass 2: dS = P' dP' - P r  in place over P (every element is read and written by the one lane that owns it)
+  for (int blk = wave; blk < ntri; blk += 4) {
+    int ib, jb;
+    tri_decode(blk, &ib, &jb);
+    const f32x4 g = dp_block(ib, jb);
+    const int j = jb * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ib * 16 + 4 * (lane >> 4) + r;
+      float ri = 0.f;
+      for (int q = 0; q <= ib; ++q) ri += rpart[q * Sp + i];
+      const float pv = Ps[i * ldp + j];
+      Ps[i * ldp + j] = pv * attn_keep_mult(a, Mb, Sp, i, j) * g[r] - pv * ri;
+    }
+  }
+  __syncthreads();
+  // ---- phase C: T0 = Q, T1 = K again; dQ, dK from dS
+  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
+  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
+  __syncthreads();
   const float scale = 1.0f / sqrtf((float)d);
-  // 3 * nb * ncb output blocks: dQ (ib, cb), dK (jb, cb), dV (jb, cb)
-  for (int blk = wave; blk < 3 * nb * ncb; blk += 4) {
+  for (int blk = wave; blk < 2 * nb * ncb; blk += 4) {
     const int which = blk / (nb * ncb), rem = blk - which * nb * ncb;
     const int rb = rem / ncb, cb = rem - rb * ncb;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (which == 0) {  // dQ[i][c] = sum_{j <= i} dS[i][j] K[j][c]
-      for (int jc = 0; jc <= rb; ++jc) mfma4(acc, frag_row(dS, ldp, rb * 16, jc * 16, lane), frag_col(Ks, ldq, jc * 16, cb * 16, lane));
-    } else if (which == 1) {  // dK[j][c] = sum_{i >= j} dS[i][j] Q[i][c]
-      for (int ic = rb; ic < nb; ++ic) mfma4(acc, frag_col(dS, ldp, ic * 16, rb * 16, lane), frag_col(Qs, ldq, ic * 16, cb * 16, lane));
-    } else {  // dV[j][c] = sum_{i >= j} P[i][j] dO[i][c]
-      for (int ic = rb; ic < nb; ++ic) mfma4(acc, frag_col(Ps, ldp, ic * 16, rb * 16, lane), frag_col(dOs, ldq, ic * 16, cb * 16, lane));
+      for (int jc = 0; jc <= rb; ++jc) mfma4(acc, frag_row(Ps, ldp, rb * 16, jc * 16, lane), frag_col(T1, ldq, jc * 16, cb * 16, lane));
+    } else {  // dK[j][c] = sum_{i >= j} dS[i][j] Q[i][c]
+      for (int ic = rb; ic < nb; ++ic) mfma4(acc, frag_col(Ps, ldp, ic * 16, rb * 16, lane), frag_col(T0, ldq, ic * 16, cb * 16, lane));
     }
     const int c = cb * 16 + (lane & 15);
-    const float sc = which == 2 ? 1.0f : scale;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = rb * 16 + 4 * (lane >> 4) + r;
-      if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + which * a.E + h * d + c] = acc[r] * sc;
+      if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + which * a.E + h * d + c] = acc[r] * scale;
     }
   }
 }
@@ -770,7 +806,9 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
 constexpr size_t kMaxLds = 160 * 1024;  // LDS per workgroup on gfx950
 static size_t attn_lds(int S_, int d, bool bwd) {
   const size_t Sp = (S_ + 15) & ~15, dp = (d + 15) & ~15, ldq = dp + 8, ldp = Sp + 8;
-  const size_t fl = bwd ? 4 * Sp * ldq + 2 * Sp * ldp + Sp : 2 * Sp * ldq + dp * ldp + Sp * ldp + Sp;
+  if (bwd)  // two operand tiles, one [S, S] tile, row-sum partials per column block, key mask, keep-mask bytes
+    return sizeof(float) * (2 * Sp * ldq + Sp * ldp + (Sp / 16) * Sp + Sp) + ((Sp * Sp + 15) & ~(size_t)15);
+  const size_t fl = 2 * Sp * ldq + dp * ldp + Sp * ldp + Sp;
   return sizeof(float) * fl;
 }
 
