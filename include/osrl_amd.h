@@ -321,12 +321,15 @@ int osrl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int osrl_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 /* CDTTrainer losses (cdt.py:357-394): head = (mu|log_std)[BT,2ad] (stochastic) or action prediction [BT,ad];
  * writes d head / d logits / d state_pred and stat[0..8] = nll, ent, ent_reg, all_loss, act_loss, cost_loss,
- * cost_acc, state_loss, train_lr; ent_out[0] = entropy (input of the temperature step). */
+ * cost_acc, state_loss, train_lr; ent_out[0] = entropy (input of the temperature step).
+ * ws (optional, >= 8 * ceil(B*T / 1024) floats) together with `counts`: one workgroup per 1024 tokens + an ordered
+ * sum of their partials instead of one workgroup for the whole batch. */
 int osrl_cdt_loss(const float* head, const float* logits, const float* state_pred, const float* actions,
                   const float* states, const float* mask, const float* costs, int32_t B, int32_t T, int32_t od,
                   int32_t ad, int32_t stochastic, int32_t no_entropy, const float* log_temperature, float cost_w,
                   float state_w, float lr, int32_t warmup, const osrl_step_state_t* st, const float* counts,
-                  int32_t world, float* dhead, float* dlogits, float* dsp, float* stat, float* ent_out, void* stream);
+                  int32_t world, float* dhead, float* dlogits, float* dsp, float* stat, float* ent_out, float* ws,
+                  void* stream);
 /* out = {#(mask > 0), sum(mask)}: the count-normalisers of cdt.py:358-359,386, to be all-reduced under data
  * parallelism and handed to osrl_cdt_loss as `counts` (with `world` = number of equal-sized ranks). */
 int osrl_cdt_mask_counts(const float* mask, int32_t BT, float* out, void* stream);

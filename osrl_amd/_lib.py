@@ -169,7 +169,7 @@ PROTOTYPES = {
     "osrl_dropout": [_fp, _fp, _i64, _P(DropoutT), _vp],
     "osrl_gelu_fwd": [_fp, _fp, _i64, _vp],
     "osrl_gelu_bwd": [_fp, _fp, _fp, _i64, _vp],
-    "osrl_cdt_loss": [_fp] * 7 + [_i32] * 6 + [_fp, _f32, _f32, _f32, _i32, _vp, _fp, _i32, _fp, _fp, _fp, _fp, _fp, _vp],
+    "osrl_cdt_loss": [_fp] * 7 + [_i32] * 6 + [_fp, _f32, _f32, _f32, _i32, _vp, _fp, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _vp],
     "osrl_cdt_mask_counts": [_fp, _i32, _fp, _vp],
     "osrl_cdt_timestep_scatter": [_fp, _vp, _i32, _i32, _fp, _vp],
     "osrl_clip_grad_scale": [_fp, _i64, _f32, _fp, _i32, _fp, _vp],

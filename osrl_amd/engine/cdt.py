@@ -91,6 +91,7 @@ class CDTEngine:
         self.clip_ws, self.clip_out = z(1024), z(4)
         self.temp_mv = z(2)
         self.counts = z(4)
+        self.loss_ws = z(8 * ((BT + 1023) // 1024) + 8)
         self._graph_failed = False
 
         # dW plans
@@ -254,10 +255,13 @@ class CDTEngine:
                               self.episode_cost, self.costs, st.ptr)
         self.forward(train=True)
         counts, world = None, 1
-        if self.dist is not None:  # count-normalisers over the GLOBAL batch
+        big = BT > 1024  # multi-workgroup loss: the normalisers are needed before the per-token gradients
+        if self.dist is not None or big:  # count-normalisers (over the GLOBAL batch)
             L.check(lib.osrl_cdt_mask_counts(self.mask.data_ptr(), BT, self.counts.data_ptr(), cur_stream()), "counts")
+            counts = self.counts.data_ptr()
+        if self.dist is not None:
             self.dist.all_reduce_(self.counts)
-            counts, world = self.counts.data_ptr(), self.dist.world
+            world = self.dist.world
         L.check(lib.osrl_cdt_loss(self.head.data_ptr(), self.logits.data_ptr(), self.sp.data_ptr(),
                                   self.actions.data_ptr(), self.states.data_ptr(), self.mask.data_ptr(),
                                   self.costs.data_ptr(), self.B, self.T, m.state_dim, m.action_dim,
@@ -265,7 +269,8 @@ class CDTEngine:
                                   m.log_temperature.data_ptr() if m.stochastic else None, cfg["loss_cost_weight"],
                                   cfg["loss_state_weight"], cfg["learning_rate"], cfg["lr_warmup_steps"], st.ptr,
                                   counts, world, self.dhead.data_ptr(), self.dlogits.data_ptr(), self.dsp.data_ptr(),
-                                  st.stats.data_ptr(), self.ent.data_ptr(), cur_stream()), "osrl_cdt_loss")
+                                  st.stats.data_ptr(), self.ent.data_ptr(), self.loss_ws.data_ptr() if big else None,
+                                  cur_stream()), "osrl_cdt_loss")
         # ---- backward: heads -> dout (only the state / action token rows are non-zero)
         self.dout.zero_()
         hk = "cdt.action_head.head.weight" if m.stochastic else "cdt.action_head.0.weight"
