@@ -27,9 +27,19 @@ namespace {
 constexpr int kMaxEPL = 8;  // features per lane: E <= 512
 constexpr float kLnEps = 1e-5f;
 
+// 64-lane sum, result in every lane: four DPP steps inside each 16-lane row (VALU, no LDS round trip), then two
+// cross-row exchanges -- instead of six ds_bpermute round trips (the LayerNorm kernels reduce twice per token row)
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));  // row_mirror
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ float block_sum1024(float v, float* sm) {
@@ -203,17 +213,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // dgamma -> slab[g_off + f], dbeta -> slab[b_off + f]  (fixed-order sum of the per-workgroup partials;
 // 64 columns per workgroup, the 4 waves split the partial rows, then a 4-way LDS reduction)
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, int E,
-                                                              float* __restrict__ slab, int64_t g_off, int64_t b_off) {
-  __shared__ float sm[4][64];
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, int E,
+                                                               float* __restrict__ slab, int64_t g_off, int64_t b_off) {
+  // 16 wave groups split the partial rows (8 independent loads in flight each; 4 groups x one dependent chain of 256
+  // loads took 62 us for the 1024 x 512 partials of one LayerNorm), fixed-order sums throughout
+  __shared__ float sm[16][64];
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + cl;
   float s = 0.f;
-  if (i < 2 * E)
-    for (int p = grp; p < nparts; p += 4) s += partial[(size_t)p * 2 * E + i];
+  if (i < 2 * E) {
+    int p = grp;
+    for (; p + 16 * 7 < nparts; p += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 16 * u) * 2 * E + i];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; p < nparts; p += 16) s += partial[(size_t)p * 2 * E + i];
+  }
   sm[grp][cl] = s;
   __syncthreads();
-  if (grp == 0 && i < 2 * E) slab[(i < E ? g_off + i : b_off + (i - E))] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+  if (grp == 0 && i < 2 * E) {
+    float t = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) t += sm[gq][cl];
+    slab[(i < E ? g_off + i : b_off + (i - E))] = t;
+  }
 }
 
 // ---------------- attention: one workgroup (4 waves) per (batch, head), fp32 MFMA 16x16x4 -------------
@@ -828,7 +853,7 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
     return -1;
   CLEAR();
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E);
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(256), 0, S, partial_ws, n_parts, E, slab,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
                      g_off, b_off);
   DONE();
 }
