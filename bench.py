@@ -250,7 +250,9 @@ def roofline(eng, flops_step: float, ms_per_step: float):
     # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows)
     dom = max(res, key=lambda k: res[k]["flops"])
     ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
-    mean_us, med_us = in_step_us(eng)
+    # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
+    # issue alone (this function runs on rank 0 only) -- N > 1 reports the isolated figure only
+    mean_us, med_us = in_step_us(eng) if eng.dist is None else (float("nan"), float("nan"))
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -261,8 +263,10 @@ def roofline(eng, flops_step: float, ms_per_step: float):
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
             "isolated_us": round(res[dom]["seconds"] * 1e6, 2),
-            "in_step_us": round(mean_us, 2), "in_step_us_median": round(med_us, 2),
-            "in_step_frac": round(res[dom]["flops"] / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
+            "in_step_us": None if mean_us != mean_us else round(mean_us, 2),
+            "in_step_us_median": None if med_us != med_us else round(med_us, 2),
+            "in_step_frac": None if mean_us != mean_us else
+            round(res[dom]["flops"] / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
             "step_frac": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
             "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2),
                             "wg_cap": int(cands[k][0].fwd_c.wg_cap)}
