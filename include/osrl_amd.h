@@ -233,6 +233,10 @@ int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_ol
  * (cpq.py:184,187); under data parallelism this rank's share, to be all-reduced(SUM). */
 int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl, const float* quantile,
                       int32_t n_samples, int32_t rows, int32_t rows_global, float* out, void* stream);
+/* osrl_quantile(kl, n_samples*rows, q) + osrl_cpq_ood_mean in ONE launch (cpq.py:183-184,187; single-GPU step):
+ * quant_out[0] = the quantile, out[0] = the OOD mean; same bits as the two calls.  n_samples*rows <= 32768 (-2). */
+int osrl_cpq_ood_stat(const float* qc_sampled, int32_t n_qc_old, const float* kl, float q, int32_t n_samples,
+                      int32_t rows, int32_t rows_global, float* quant_out, float* out, void* stream);
 /* CPQ cost-critic loss (cpq.py:161,186-199): backup = c + gamma*min qc_old; dq = 2(qc-backup)/B;
  * log_alpha (device scalar) ascends with the GLOBAL ood_mean (device scalar) and is clamped to +-5;
  * stat[0] = loss, stat[1] = exp(log_alpha) after the update.  stat_share = 1/world_size scales the

@@ -148,6 +148,7 @@ PROTOTYPES = {
     "osrl_quantile": [_fp, _i64, _f32, _fp, _vp],
     "osrl_cpq_critic_loss": [_fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
     "osrl_cpq_ood_mean": [_fp, _i32, _fp, _fp, _i32, _i32, _i32, _fp, _vp],
+    "osrl_cpq_ood_stat": [_fp, _i32, _fp, _f32, _i32, _i32, _i32, _fp, _fp, _vp],
     "osrl_cpq_cost_loss": [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _f32, _i32, _f32, _fp, _fp, _fp, _vp],
     "osrl_cpq_alpha_step": [_fp, _f32, _f32, _f32, _fp, _fp, _vp],
     "osrl_cpq_cost_loss_ood": [_fp, _i32, _fp, _fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _f32, _fp, _fp,

@@ -261,44 +261,105 @@ __device__ uint32_t radix_select(const float* __restrict__ x, const uint32_t (&k
   return prefix;
 }
 
+// k-th smallest (0-based) of REGISTER-resident keys (element j*blockDim + tid in kreg[j]; slots past n hold
+// 0xffffffff): the answer is built from the top bit down, one block-wide count of "key < candidate" per bit -- 32
+// rounds of REG compares, a wave reduction, one 16-entry LDS exchange and ONE barrier (the exchange is double
+// buffered).  No atomics: the histogram form spends its time in same-address LDS atomics because KL values of one
+// batch share their high bytes (27 us at n = 20480; this form: see profiles/r2_kbench.txt).
+// cnt: 32 uints of LDS.  *n_le = number of keys <= the selected one.
+template <int REG>
+__device__ uint32_t bit_select(const uint32_t (&kreg)[REG], int64_t n, int64_t k, uint32_t* cnt, uint32_t* n_le) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int nw = (int)(blockDim.x >> 6);
+  const int jmax = (int)((n + blockDim.x - 1) / blockDim.x);  // uniform: registers past it hold padding only
+  auto count_below = [&](uint32_t t, bool le, int buf) -> uint32_t {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < REG; ++j)
+      if (j < jmax) c += le ? (kreg[j] <= t ? 1u : 0u) : (kreg[j] < t ? 1u : 0u);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    uint32_t* b = cnt + buf * 16;
+    if (l == 0) b[w] = c;
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int i = 0; i < nw; ++i) tot += b[i];
+    return tot;
+  };
+  uint32_t prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t t = prefix | (1u << bit);
+    if ((int64_t)count_below(t, false, bit & 1) <= k) prefix = t;  // largest v with #(keys < v) <= k
+  }
+  __syncthreads();  // the last round's readers are done with buffer 0 before it is rewritten
+  *n_le = count_below(prefix, true, 0);
+  return prefix;
+}
+
+// torch.quantile(x, q) ('linear') of n <= 32 * blockDim values, keys in registers; valid in every thread.
+// cnt: 32 uints, s_min: 17 uints of LDS.
+__device__ float quantile_regs(const float* __restrict__ x, int64_t n, float q, uint32_t* cnt, uint32_t* s_min) {
+  constexpr int kReg = 32;
+  const double pos = (double)q * (double)(n - 1);
+  const int64_t lo = (int64_t)floor(pos);
+  const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
+  const float w = (float)(pos - (double)lo);
+  uint32_t kreg[kReg];
+#pragma unroll
+  for (int j = 0; j < kReg; ++j) {  // all loads in flight at once
+    const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
+    kreg[j] = i < n ? f2key(x[i]) : 0xffffffffu;
+  }
+  uint32_t n_le;
+  const uint32_t klo = bit_select<kReg>(kreg, n, lo, cnt, &n_le);
+  uint32_t khi = klo;
+  if (hi != lo && (int64_t)n_le < hi + 1) {  // the next order statistic is the smallest key strictly above klo
+    uint32_t mn = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < kReg; ++j) {
+      const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
+      if (i < n && kreg[j] > klo && kreg[j] < mn) mn = kreg[j];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint32_t other = __shfl_xor(mn, o);
+      mn = other < mn ? other : mn;
+    }
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    uint32_t t = s_min[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = s_min[i] < t ? s_min[i] : t;
+    khi = t;
+  }
+  const float vlo = key2f(klo), vhi = key2f(khi);
+  return vlo + (vhi - vlo) * w;
+}
+
 __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict__ x, int64_t n, float q,
                                                         float* __restrict__ out) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t bc[4];
-  __shared__ uint32_t s_min[16];
+  __shared__ uint32_t s_min[17];
+  if (n <= (int64_t)32 * blockDim.x) {  // register-resident keys, bitwise select
+    const float v = quantile_regs(x, n, q, hist, s_min);
+    if (threadIdx.x == 0) out[0] = v;
+    return;
+  }
   // torch.quantile 'linear': pos = q*(n-1); lo=floor(pos); result = x_lo + (x_hi-x_lo)*(pos-lo)
   const double pos = (double)q * (double)(n - 1);
   const int64_t lo = (int64_t)floor(pos);
   const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
   const float w = (float)(pos - (double)lo);
-  constexpr int kReg = 32;  // register-resident keys for n <= 32 * 1024
-  const bool in_regs = n <= (int64_t)kReg * blockDim.x;
-  uint32_t kreg[kReg];
-  if (in_regs) {
-#pragma unroll
-    for (int j = 0; j < kReg; ++j) {  // all loads in flight at once
-      const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
-      kreg[j] = i < n ? f2key(x[i]) : 0u;
-    }
-  }
   const uint32_t none[1] = {0u};
-  const uint32_t klo = in_regs ? radix_select<kReg>(x, kreg, n, lo, hist, bc) : radix_select<0>(x, none, n, lo, hist, bc);
+  const uint32_t klo = radix_select<0>(x, none, n, lo, hist, bc);
   const int64_t n_le = bc[2];
   uint32_t khi = klo;
   if (hi != lo && n_le < hi + 1) {
     // the (lo+1)-th order statistic is the smallest key strictly above klo: one min-reduction pass
     uint32_t mn = 0xffffffffu;
-    if (in_regs) {
-#pragma unroll
-      for (int j = 0; j < kReg; ++j) {
-        const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
-        if (i < n && kreg[j] > klo && kreg[j] < mn) mn = kreg[j];
-      }
-    } else {
-      for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t key = f2key(x[i]);
-        if (key > klo && key < mn) mn = key;
-      }
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t key = f2key(x[i]);
+      if (key > klo && key < mn) mn = key;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -355,10 +416,9 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
 
 // mean over the (global) batch of qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184,187
 __device__ __forceinline__ float cpq_ood_mean_block(const float* __restrict__ qc_sampled, int n_qc_old,
-                                                    const float* __restrict__ kl, const float* __restrict__ quantile,
+                                                    const float* __restrict__ kl, const float quant,
                                                     int n_samples, int rows, float inv_rows, float* sm) {
   float ood = 0.f;
-  const float quant = quantile[0];
   const int nr = n_samples * rows;
   for (int b = threadIdx.x; b < rows; b += kRed) {
     float s = 0.f;
@@ -379,8 +439,25 @@ __global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restr
                                                             const float* __restrict__ quantile, int n_samples,
                                                             int rows, float inv_rows, float* __restrict__ out) {
   __shared__ float sm[20];
-  const float ood = cpq_ood_mean_block(qc_sampled, n_qc_old, kl, quantile, n_samples, rows, inv_rows, sm);
+  const float ood = cpq_ood_mean_block(qc_sampled, n_qc_old, kl, quantile[0], n_samples, rows, inv_rows, sm);
   if (threadIdx.x == 0) out[0] = ood;
+}
+
+// quantile + OOD mean in one launch (single-GPU step, n_samples * rows <= 32 * 1024): the KL rows are read once into
+// registers for the select, the masked mean re-reads them from L2 in the order of cpq_ood_mean_kernel (same bits)
+__global__ __launch_bounds__(kRed) void cpq_ood_stat_kernel(const float* __restrict__ qc_sampled, int n_qc_old,
+                                                            const float* __restrict__ kl, float q, int n_samples,
+                                                            int rows, float inv_rows, float* __restrict__ quant_out,
+                                                            float* __restrict__ out) {
+  __shared__ uint32_t cnt[32];
+  __shared__ uint32_t s_min[17];
+  __shared__ float sm[20];
+  const float quant = quantile_regs(kl, (int64_t)n_samples * rows, q, cnt, s_min);
+  const float ood = cpq_ood_mean_block(qc_sampled, n_qc_old, kl, quant, n_samples, rows, inv_rows, sm);
+  if (threadIdx.x == 0) {
+    quant_out[0] = quant;
+    out[0] = ood;
+  }
 }
 
 struct OodArgs {  // non-NULL qc_sampled: compute the OOD mean here (single-GPU step: one launch less)
@@ -399,7 +476,7 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
   __shared__ float sm[20];
   float ood_here = 0.f;
   if (oa.qc_sampled)
-    ood_here = cpq_ood_mean_block(oa.qc_sampled, oa.n_qc_old, oa.kl, oa.quantile, oa.n_samples, rows, inv_rows, sm);
+    ood_here = cpq_ood_mean_block(oa.qc_sampled, oa.n_qc_old, oa.kl, oa.quantile[0], oa.n_samples, rows, inv_rows, sm);
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
     const float backup = cost[b] + gamma * min_over(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
@@ -710,6 +787,16 @@ int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cpq_ood_mean_kernel, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, quantile, n_samples,
                      rows, 1.0f / (float)(rows_global > 0 ? rows_global : rows), out);
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_ood_stat(const float* qc_sampled, int32_t n_qc_old, const float* kl, float q, int32_t n_samples,
+                      int32_t rows, int32_t rows_global, float* quant_out, float* out, void* stream) {
+  if (!qc_sampled || !kl || !quant_out || !out || rows < 1 || n_samples < 1 || q < 0.f || q > 1.f) return -1;
+  if ((int64_t)n_samples * rows > (int64_t)32 * kRed) return -2;  // keys must fit the workgroup's registers
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(cpq_ood_stat_kernel, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, q, n_samples, rows,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), quant_out, out);
   LAUNCH_CHECK();
 }
 

@@ -7,7 +7,7 @@ import torch
 
 from ..common.net import net_desc_seq
 from . import glue as G
-from .core import DwPlan, MlpRun, StepState
+from .core import DwPlan, MlpRun, StepState, load_into
 
 STAT_KEYS = ["loss/actor_loss"]
 
@@ -70,8 +70,7 @@ class BCEngine:
     def step(self, observations, actions, use_graph: bool = True) -> None:
         if self.replay is not None:
             raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
-        self.obs.copy_(torch.as_tensor(observations).reshape(self.obs.shape), non_blocking=True)
-        self.act.copy_(torch.as_tensor(actions).reshape(self.act.shape), non_blocking=True)
+        load_into(((self.obs, observations), (self.act, actions)))
         if use_graph and self.dist is None:
             if self.graph is None:
                 self._capture()

@@ -15,7 +15,7 @@ import torch
 from .. import _lib as L
 from ..common.net import net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, randn_fill
+from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, randn_fill
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/qc_penalty",
              "loss/lagrangian"]
@@ -201,10 +201,8 @@ class BCQLEngine:
             ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
-        for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
-                         (self.rew, rewards), (self.cost, costs), (self.done, done)):
-            if src is not dst:
-                dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+        load_into(((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
+                   (self.rew, rewards), (self.cost, costs), (self.done, done)))
 
     def _snapshot(self):
         m = self.model

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _lib as L
-from .core import DwPlan, FlatGroup, StepState, cur_stream
+from .core import DwPlan, FlatGroup, StepState, cur_stream, load_into
 
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
 
@@ -331,14 +331,8 @@ class CDTEngine:
             self.dist.all_reduce_(st.stats)
 
     def load_batch(self, states, actions, returns, costs_return, time_steps, mask, costs) -> None:
-        cp = lambda d, s: d.copy_(torch.as_tensor(s).reshape(d.shape), non_blocking=True)  # noqa: E731
-        cp(self.states, states)
-        cp(self.actions, actions)
-        cp(self.returns, returns)
-        cp(self.ctg, costs_return)
-        cp(self.time_steps, time_steps)
-        cp(self.mask, mask)
-        cp(self.costs, costs)
+        load_into(((self.states, states), (self.actions, actions), (self.returns, returns), (self.ctg, costs_return),
+                   (self.time_steps, time_steps), (self.mask, mask), (self.costs, costs)))
 
     def attach_store(self, store) -> None:
         if store is not None and self.dist is not None:

@@ -19,7 +19,7 @@ import torch
 
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq
-from .core import DwPlan, MlpRun, StepState, cur_stream, randn_fill
+from .core import DwPlan, MlpRun, StepState, cur_stream, load_into, randn_fill
 
 STAT_KEYS = ["loss/chi_loss", "loss/tau_loss", "loss/D_kl", "loss/Df", "loss/td_error", "loss/nu_loss",
              "loss/lmbda_loss", "loss/actor_loss", "loss/tau", "loss/lmbda"]
@@ -144,9 +144,8 @@ class COptiDICEEngine:
         self._adam("actor", self.p_actor, extra=(st.stats,) if dp is not None else ())
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done, is_init) -> None:
-        for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
-                         (self.rew, rewards), (self.cost, costs), (self.done, done), (self.init, is_init)):
-            dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+        load_into(((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
+                   (self.rew, rewards), (self.cost, costs), (self.done, done), (self.init, is_init)))
 
     def _snapshot(self):
         m = self.model

@@ -595,3 +595,24 @@ class StepState:
 def randn_fill(out: torch.Tensor, seed: int, stream_id: int, st_ptr: Optional[int]) -> None:
     L.check(L.load().osrl_randn_fill(out.data_ptr(), out.numel(), seed, stream_id, st_ptr, cur_stream()),
             "osrl_randn_fill")
+
+
+def load_into(pairs) -> None:
+    """Copy caller tensors into the engine's static batch buffers (the addresses the captured graph reads).  Device
+    fp32 sources of the right size go through ONE multi-tensor copy launch instead of one launch per tensor -- this is
+    the per-call cost ``trainer.train_one_step(tensors)`` adds on top of the replayed graph; anything else (host
+    arrays, other dtypes) takes the per-tensor ``copy_``."""
+    fast_d, fast_s = [], []
+    for dst, src in pairs:
+        if src is dst:
+            continue
+        if isinstance(src, torch.Tensor) and src.device == dst.device and src.dtype == dst.dtype \
+                and src.numel() == dst.numel() and src.is_contiguous():
+            fast_d.append(dst)
+            fast_s.append(src.view(dst.shape))
+        else:
+            dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+    if len(fast_d) == 1:
+        fast_d[0].copy_(fast_s[0], non_blocking=True)
+    elif fast_d:
+        torch._foreach_copy_(fast_d, fast_s, non_blocking=True)

@@ -20,7 +20,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, randn_fill
+from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, randn_fill
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
@@ -261,8 +261,11 @@ class CPQEngine:
             if self._probe is not None:
                 self._probe[1].record()
             G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
-            G.quantile(self.kl, N * B, 0.75, self.quant)
-            G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            if N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
+                G.cpq_ood_stat(qc_s, nqc, self.kl, 0.75, N, B, rg, self.quant, self.ood_mean)
+            else:
+                G.quantile(self.kl, N * B, 0.75, self.quant)
+                G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
 
         # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch) and cost critic (here)
         par.wait(ev_critic)
@@ -410,10 +413,8 @@ class CPQEngine:
 
     # ------------------------------------------------------------------ #
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
-        for dst, src in ((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
-                         (self.rew, rewards), (self.cost, costs), (self.done, done)):
-            if src is not dst:
-                dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+        load_into(((self.obs, observations), (self.nobs, next_observations), (self.act, actions),
+                   (self.rew, rewards), (self.cost, costs), (self.done, done)))
 
     def load_noise(self, noise: Dict[str, torch.Tensor]) -> None:
         for k in NOISE_KEYS:

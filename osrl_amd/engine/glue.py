@@ -68,6 +68,11 @@ def cpq_ood_mean(qc_sampled, n_qc_old, kl, quant, n_samples, rows, rows_global, 
                                        _p(out), cur_stream()), "osrl_cpq_ood_mean")
 
 
+def cpq_ood_stat(qc_sampled, n_qc_old, kl, q, n_samples, rows, rows_global, quant_out, out):
+    L.check(L.load().osrl_cpq_ood_stat(_p(qc_sampled), n_qc_old, _p(kl), q, n_samples, rows, rows_global,
+                                       _p(quant_out), _p(out), cur_stream()), "osrl_cpq_ood_stat")
+
+
 def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows, gamma, qc_thres, alpha_lr, rows_global,
                   stat_share, log_alpha, dq, stat):
     L.check(L.load().osrl_cpq_cost_loss(_p(qc_old_next), n_qc_old, _p(qc), n_qc, _p(ood_mean), _p(cost), rows, gamma,
