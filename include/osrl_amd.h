@@ -101,7 +101,7 @@ typedef struct {
   float bc1;        /* 1 - beta1^t */
   float bc2_sqrt;   /* sqrt(1 - beta2^t) */
   float lr_scale;   /* LambdaLR factor min(t/warmup,1) (cdt.py:327-330); 1 when warmup == 0 */
-  float pad_;
+  uint32_t arrive_; /* workgroup arrival counter of osrl_step_begin (0 between launches) */
 } osrl_step_state_t;
 
 /* One dropout site (HOST struct, read at launch): probability, site id (unique per nn.Dropout call site and
@@ -150,6 +150,15 @@ int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const int32_t* d_
  * the host can read logged values lazily instead of .item()-syncing every step. */
 int osrl_step_tick(osrl_step_state_t* st, float beta1, float beta2, int32_t warmup, const float* stats_cur,
                    float* ring, int32_t n_stats, int32_t ring_len, void* stream);
+/* The whole step prologue in ONE launch: osrl_step_tick + osrl_randn_fill (if noise != NULL) + osrl_replay_gather (if
+ * n_fields > 0), with exactly their results -- the draws use step t+1, the value the tick is about to store; the last
+ * workgroup to have read the old step performs the tick.  Replaces three dependent launches (and their launch gaps)
+ * at the head of every train step. */
+int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, int32_t warmup, const float* stats_cur,
+                    float* ring, int32_t n_stats, int32_t ring_len, float* noise, int64_t noise_n,
+                    uint64_t noise_seed, uint32_t noise_stream, int32_t n_fields, const float* const* src,
+                    float* const* dst, const int32_t* width, const float* scale, int64_t n_rows, int32_t batch,
+                    uint64_t gather_seed, uint32_t gather_stream, void* stream);
 /* g = sum_s slabs[s][i] (* *gscale if gscale != NULL); AdamW decay if weight_decay != 0;
  * then tgt = tau*p + (1-tau)*tgt if tgt != NULL.  n and slab_stride must be multiples of 4. */
 int osrl_adam_step(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,

@@ -85,7 +85,7 @@ POLICY_MAX_ROWS = 4
 
 class StepStateT(C.Structure):
     _fields_ = [("step", C.c_int64), ("bc1", C.c_float), ("bc2_sqrt", C.c_float),
-                ("lr_scale", C.c_float), ("pad_", C.c_float)]
+                ("lr_scale", C.c_float), ("arrive_", C.c_uint32)]
 
 
 _i32, _i64, _f32, _u32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64, C.c_void_p
@@ -129,6 +129,8 @@ PROTOTYPES = {
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_mlp_backward_dw_big": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
+    "osrl_step_begin": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _fp, _i64, _u64, _u32, _i32, _P(_fp), _P(_fp),
+                        _P(_i32), _P(_f32), _i64, _i32, _u64, _u32, _vp],
     "osrl_adam_step": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,
                        _vp, _vp],
     "osrl_adam_step_packed": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,

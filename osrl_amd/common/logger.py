@@ -139,8 +139,11 @@ def store_stats(logger, st, mode: str, tab=None, keys=None) -> None:
         # materialise before the device ring wraps (amortised: one sync per ring_len/2 steps).  The trigger is the
         # AGE of the oldest pending step, not the entry count: with a `keys` subset the count grows slower than the ring
         if step - pend[0]._step >= st.ring_len // 2:
-            for v in pend:
-                v.materialize()
+            todo = [v for v in pend if v._val is None]
+            rows = st.read_stats_many({v._step for v in todo})  # ONE device->host copy for the whole backlog
+            for v in todo:
+                v._val = float(rows[v._step][st.index[v._key]])
+                v._st = None
             pend.clear()
         logger.store(**kw, **vals)
     elif mode != "none":

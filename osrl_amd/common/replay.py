@@ -87,6 +87,21 @@ class ReplayStore:
                                             st_ptr, cur_stream()), "osrl_replay_gather")
 
 
+    def gather_args(self, dst: Sequence[torch.Tensor], fields: Optional[Sequence[int]] = None, stream_id: int = 1):
+        """The arguments of ``gather`` / ``gather_fields`` as the tuple ``StepState.begin(gather=...)`` takes (the
+        fused step prologue draws the same rows: the indices are a function of (seed, step, row) only)."""
+        if fields is None:
+            fields = range(self.n_fields)
+        fields = list(fields)
+        if len(dst) != len(fields):
+            raise ValueError(f"{len(fields)} tables selected, {len(dst)} destination buffers were given")
+        n = len(fields)
+        src = (C.c_void_p * n)(*[self.tables[i].data_ptr() for i in fields])
+        d = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
+        w = (C.c_int32 * n)(*[self.widths[i] for i in fields])
+        sc = (C.c_float * n)(*[self.scales[i] for i in fields])
+        return (n, src, d, w, sc, self.n_rows, dst[0].shape[0], self.seed, stream_id, list(dst))
+
     def gather_fields(self, fields: Sequence[int], dst: Sequence[torch.Tensor], st_ptr: Optional[int],
                       stream_id: int = 1) -> None:
         """The same draw as ``gather`` (the row indices are a function of (seed, step, row) only) restricted to some

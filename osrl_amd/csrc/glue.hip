@@ -262,61 +262,59 @@ __device__ uint32_t radix_select(const float* __restrict__ x, const uint32_t (&k
 }
 
 // k-th smallest (0-based) of REGISTER-resident keys (element j*blockDim + tid in kreg[j]; slots past n hold
-// 0xffffffff): the answer is built from the top bit down, one block-wide count of "key < candidate" per bit -- 32
-// rounds of REG compares, a wave reduction, one 16-entry LDS exchange and ONE barrier (the exchange is double
-// buffered).  No atomics: the histogram form spends its time in same-address LDS atomics because KL values of one
-// batch share their high bytes (27 us at n = 20480; this form: see profiles/r2_kbench.txt).
-// cnt: 32 uints of LDS.  *n_le = number of keys <= the selected one.
-template <int REG>
-__device__ uint32_t bit_select(const uint32_t (&kreg)[REG], int64_t n, int64_t k, uint32_t* cnt, uint32_t* n_le) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int nw = (int)(blockDim.x >> 6);
-  const int jmax = (int)((n + blockDim.x - 1) / blockDim.x);  // uniform: registers past it hold padding only
-  auto count_below = [&](uint32_t t, bool le, int buf) -> uint32_t {
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < REG; ++j)
-      if (j < jmax) c += le ? (kreg[j] <= t ? 1u : 0u) : (kreg[j] < t ? 1u : 0u);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-    uint32_t* b = cnt + buf * 16;
-    if (l == 0) b[w] = c;
-    __syncthreads();
-    uint32_t tot = 0;
-    for (int i = 0; i < nw; ++i) tot += b[i];
-    return tot;
-  };
+// 0xffffffff): the answer is built from the top bit down, one block-wide count of "key < candidate" per bit.  A
+// round is ROWS compares whose lane masks are counted on the scalar unit (v_cmp -> s_bcnt1: no cross-lane traffic),
+// one LDS atomic per wave into that round's own counter, ONE barrier, one broadcast read.  The histogram form spends
+// its time in same-address LDS atomics because the KL values of one batch share their high bytes (27 us at
+// n = 20480; this form: profiles/r2_kbench.txt).
+// cnt: 34 uints of LDS, zeroed, with a barrier between the zeroing and this call.  *n_le = #keys <= the result.
+template <int ROWS>
+__device__ __forceinline__ uint32_t bit_select(const uint32_t (&kreg)[ROWS], int64_t k, uint32_t* cnt,
+                                               uint32_t* n_le) {
+  const bool lead = (threadIdx.x & 63) == 0;
   uint32_t prefix = 0;
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t t = prefix | (1u << bit);
-    if ((int64_t)count_below(t, false, bit & 1) <= k) prefix = t;  // largest v with #(keys < v) <= k
+    uint32_t c = 0;  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) c += (uint32_t)__popcll(__ballot(kreg[j] < t));
+    if (lead) atomicAdd(&cnt[bit], c);
+    __syncthreads();
+    if ((int64_t)cnt[bit] <= k) prefix = t;  // largest v with #(keys < v) <= k  ==  the k-th smallest key
   }
-  __syncthreads();  // the last round's readers are done with buffer 0 before it is rewritten
-  *n_le = count_below(prefix, true, 0);
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) c += (uint32_t)__popcll(__ballot(kreg[j] <= prefix));
+  if (lead) atomicAdd(&cnt[32], c);
+  __syncthreads();
+  *n_le = cnt[32];
   return prefix;
 }
 
-// torch.quantile(x, q) ('linear') of n <= 32 * blockDim values, keys in registers; valid in every thread.
-// cnt: 32 uints, s_min: 17 uints of LDS.
-__device__ float quantile_regs(const float* __restrict__ x, int64_t n, float q, uint32_t* cnt, uint32_t* s_min) {
-  constexpr int kReg = 32;
+// torch.quantile(x, q) ('linear') of n <= ROWS * blockDim values, keys in registers; valid in every thread.
+// cnt: 34 uints, s_min: 17 uints of LDS.
+template <int ROWS>
+__device__ __forceinline__ float quantile_rows(const float* __restrict__ x, int64_t n, float q, uint32_t* cnt,
+                                               uint32_t* s_min) {
   const double pos = (double)q * (double)(n - 1);
   const int64_t lo = (int64_t)floor(pos);
   const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
   const float w = (float)(pos - (double)lo);
-  uint32_t kreg[kReg];
+  if (threadIdx.x < 34) cnt[threadIdx.x] = 0;
+  uint32_t kreg[ROWS];
 #pragma unroll
-  for (int j = 0; j < kReg; ++j) {  // all loads in flight at once
+  for (int j = 0; j < ROWS; ++j) {  // all loads in flight at once
     const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
     kreg[j] = i < n ? f2key(x[i]) : 0xffffffffu;
   }
+  __syncthreads();
   uint32_t n_le;
-  const uint32_t klo = bit_select<kReg>(kreg, n, lo, cnt, &n_le);
+  const uint32_t klo = bit_select<ROWS>(kreg, lo, cnt, &n_le);
   uint32_t khi = klo;
   if (hi != lo && (int64_t)n_le < hi + 1) {  // the next order statistic is the smallest key strictly above klo
     uint32_t mn = 0xffffffffu;
 #pragma unroll
-    for (int j = 0; j < kReg; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
       const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
       if (i < n && kreg[j] > klo && kreg[j] < mn) mn = kreg[j];
     }
@@ -333,6 +331,15 @@ __device__ float quantile_regs(const float* __restrict__ x, int64_t n, float q, 
   }
   const float vlo = key2f(klo), vhi = key2f(khi);
   return vlo + (vhi - vlo) * w;
+}
+constexpr int kQuantRegRows = 32;
+__device__ __forceinline__ float quantile_regs(const float* __restrict__ x, int64_t n, float q, uint32_t* cnt,
+                                               uint32_t* s_min) {
+  const int rows = (int)((n + blockDim.x - 1) / blockDim.x);  // uniform
+  if (rows <= 4) return quantile_rows<4>(x, n, q, cnt, s_min);
+  if (rows <= 12) return quantile_rows<12>(x, n, q, cnt, s_min);
+  if (rows <= 20) return quantile_rows<20>(x, n, q, cnt, s_min);
+  return quantile_rows<kQuantRegRows>(x, n, q, cnt, s_min);
 }
 
 __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict__ x, int64_t n, float q,
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(kRed) void cpq_ood_stat_kernel(const float* __restr
                                                             const float* __restrict__ kl, float q, int n_samples,
                                                             int rows, float inv_rows, float* __restrict__ quant_out,
                                                             float* __restrict__ out) {
-  __shared__ uint32_t cnt[32];
+  __shared__ uint32_t cnt[34];
   __shared__ uint32_t s_min[17];
   __shared__ float sm[20];
   const float quant = quantile_regs(kl, (int64_t)n_samples * rows, q, cnt, s_min);

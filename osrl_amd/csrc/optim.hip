@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/osrl_amd.h"
+#include "step.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -23,19 +24,9 @@ __global__ void step_tick_kernel(osrl_step_state_t* st, float beta1, float beta2
                                  const float* __restrict__ stats_cur, float* __restrict__ ring, int n_stats,
                                  int ring_len) {
   const int64_t t_old = st->step;
-  if (stats_cur && ring && t_old >= 1) {
-    const int slot = (int)((t_old - 1) % ring_len);
-    for (int i = threadIdx.x; i < n_stats; i += blockDim.x) ring[(size_t)slot * n_stats + i] = stats_cur[i];
-  }
+  osrl_step::commit_stats(t_old, stats_cur, ring, n_stats, ring_len);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int64_t t = t_old + 1;
-    st->step = t;
-    st->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
-    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)t));
-    // LambdaLR(min((s+1)/warmup, 1)) with s = number of scheduler steps taken = t-1 (cdt.py:327-330,409)
-    st->lr_scale = warmup > 0 ? (float)fmin((double)t / (double)warmup, 1.0) : 1.0f;
-  }
+  if (threadIdx.x == 0) osrl_step::advance(st, t_old, beta1, beta2, warmup);
 }
 
 // sum_s slabs[s][i] in slab order; 8 loads are issued before the first add so their latencies overlap

@@ -15,16 +15,16 @@
 
 #include "../../include/osrl_amd.h"
 #include "philox.h"
+#include "step.h"
 
 namespace {
 
 using namespace osrl_rng;
 
-__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
-                                                    uint32_t stream_id, const osrl_step_state_t* __restrict__ st) {
-  const uint32_t step = st ? (uint32_t)st->step : 0u;
+__device__ __forceinline__ void randn_body(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
+                                           uint32_t stream_id, uint32_t step, int64_t block, int64_t n_blocks) {
   const int64_t n4 = (n + 3) >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = block * blockDim.x + threadIdx.x; i < n4; i += n_blocks * blockDim.x) {
     const U4 r = philox4x32_10(U4{(uint32_t)i, (uint32_t)(i >> 32), step, stream_id}, k0, k1);
     const float r0 = sqrtf(-2.0f * __logf(u01(r.x))), r1 = sqrtf(-2.0f * __logf(u01(r.z)));
     float s0, c0, s1, c1;
@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int
   }
 }
 
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
+                                                    uint32_t stream_id, const osrl_step_state_t* __restrict__ st) {
+  randn_body(out, n, k0, k1, stream_id, st ? (uint32_t)st->step : 0u, blockIdx.x, gridDim.x);
+}
+
 #define OSRL_MAX_FIELDS 8
 struct GatherArgs {
   const float* src[OSRL_MAX_FIELDS];
@@ -55,11 +60,10 @@ struct GatherArgs {
 };
 
 // one wave per sampled row; lanes stride over the row's columns (coalesced both sides)
-__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+__device__ __forceinline__ void gather_body(const GatherArgs& a, uint32_t step, int block) {
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = block * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.batch) return;
-  const uint32_t step = a.st ? (uint32_t)a.st->step : 0u;
   const U4 r = philox4x32_10(U4{(uint32_t)b, 0x5eedu, step, a.stream_id}, a.k0, a.k1);
   // 64-bit multiply-shift maps a 64-bit uniform onto [0, n_rows) (bias < 2^-40 for n_rows < 2^24)
   const uint64_t u = ((uint64_t)r.x << 32) | r.y;
@@ -71,6 +75,56 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
     float* __restrict__ d = a.dst[f] + (size_t)b * w;
     const float sc = a.scale[f];
     for (int c = lane; c < w; c += 64) d[c] = s[c] * sc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+  gather_body(a, a.st ? (uint32_t)a.st->step : 0u, blockIdx.x);
+}
+
+// 1024-thread workgroups: every workgroup signs in with one atomic on ONE address (those serialise at ~20 ns each:
+// 600 four-row workgroups made this kernel 17 us long), so few, fat workgroups
+constexpr int kBeginThreads = 1024;
+// The step prologue in one launch (osrl_step_begin): workgroups [0, g_blocks) gather, [g_blocks, g_blocks + r_blocks)
+// fill the noise, every one of them with step = t_old + 1; the LAST workgroup to have read t_old ticks the state.
+struct BeginArgs {
+  osrl_step_state_t* st;
+  float beta1, beta2;
+  int32_t warmup, n_stats, ring_len;
+  const float* stats_cur;
+  float* ring;
+  float* noise;
+  int64_t noise_n;
+  uint32_t nk0, nk1, noise_stream;
+  int32_t g_blocks, r_blocks;
+};
+
+__global__ __launch_bounds__(kBeginThreads) void step_begin_kernel(const BeginArgs b, const GatherArgs a) {
+  __shared__ int64_t s_t;
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_t = __atomic_load_n(&b.st->step, __ATOMIC_RELAXED);
+  __syncthreads();
+  const int64_t t_old = s_t;
+  if (threadIdx.x == 0) {
+    // the old step has been READ by this workgroup (its value went through LDS): count the arrival
+    __threadfence();
+    const uint32_t seen = atomicAdd(&b.st->arrive_, 1u);
+    s_last = seen == gridDim.x - 1;
+  }
+  const uint32_t step = (uint32_t)(t_old + 1);
+  const int blk = blockIdx.x;
+  if (blk < b.g_blocks) {
+    gather_body(a, step, blk);
+  } else if (b.noise) {
+    randn_body(b.noise, b.noise_n, b.nk0, b.nk1, b.noise_stream, step, blk - b.g_blocks, b.r_blocks);
+  }
+  __syncthreads();
+  if (s_last) {  // every workgroup holds t_old in registers by now: the state may move
+    osrl_step::commit_stats(t_old, b.stats_cur, b.ring, b.n_stats, b.ring_len);
+    if (threadIdx.x == 0) {
+      osrl_step::advance(b.st, t_old, b.beta1, b.beta2, b.warmup);
+      b.st->arrive_ = 0;
+    }
   }
 }
 
@@ -215,5 +269,52 @@ extern "C" int osrl_replay_gather(int32_t n_fields, const float* const* src, flo
   a.st = st;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(gather_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, int32_t warmup, const float* stats_cur,
+                               float* ring, int32_t n_stats, int32_t ring_len, float* noise, int64_t noise_n,
+                               uint64_t noise_seed, uint32_t noise_stream, int32_t n_fields, const float* const* src,
+                               float* const* dst, const int32_t* width, const float* scale, int64_t n_rows,
+                               int32_t batch, uint64_t gather_seed, uint32_t gather_stream, void* stream) {
+  if (!st || n_fields < 0 || n_fields > OSRL_MAX_FIELDS || (noise && noise_n < 1)) return -1;
+  if (n_fields > 0 && (!src || !dst || !width || n_rows < 1 || batch < 1)) return -1;
+  GatherArgs a;
+  for (int f = 0; f < OSRL_MAX_FIELDS; ++f) {
+    a.src[f] = f < n_fields ? src[f] : nullptr;
+    a.dst[f] = f < n_fields ? dst[f] : nullptr;
+    a.width[f] = f < n_fields ? width[f] : 0;
+    a.scale[f] = (f < n_fields && scale) ? scale[f] : 1.0f;
+    if (f < n_fields && (!a.src[f] || !a.dst[f] || a.width[f] < 1)) return -1;
+  }
+  a.n_fields = n_fields;
+  a.batch = n_fields > 0 ? batch : 0;
+  a.n_rows = n_rows;
+  a.idx_out = nullptr;
+  a.k0 = (uint32_t)gather_seed;
+  a.k1 = (uint32_t)(gather_seed >> 32);
+  a.stream_id = gather_stream;
+  a.st = st;
+  BeginArgs b;
+  b.st = st;
+  b.beta1 = beta1;
+  b.beta2 = beta2;
+  b.warmup = warmup;
+  b.n_stats = n_stats;
+  b.ring_len = ring_len > 0 ? ring_len : 1;
+  b.stats_cur = stats_cur;
+  b.ring = ring;
+  b.noise = noise;
+  b.noise_n = noise_n;
+  b.nk0 = (uint32_t)noise_seed;
+  b.nk1 = (uint32_t)(noise_seed >> 32);
+  b.noise_stream = noise_stream;
+  constexpr int kWaves = kBeginThreads / 64;
+  b.g_blocks = n_fields > 0 ? (batch + kWaves - 1) / kWaves : 0;
+  int64_t rb = noise ? ((noise_n + 3) / 4 + kBeginThreads - 1) / kBeginThreads : 0;
+  b.r_blocks = (int32_t)(rb > 256 ? 256 : rb);
+  const int grid = b.g_blocks + b.r_blocks > 0 ? b.g_blocks + b.r_blocks : 1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(step_begin_kernel, dim3(grid), dim3(kBeginThreads), 0, (hipStream_t)stream, b, a);
   return (int)hipGetLastError();
 }

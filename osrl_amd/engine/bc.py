@@ -52,9 +52,7 @@ class BCEngine:
 
     def body(self) -> None:
         m, B, ad = self.model, self.B, self.model.action_dim
-        self.st.tick()
-        if self.replay is not None:
-            self.replay.gather_fields((0, 2), (self.obs, self.act), self.st.ptr)
+        self.st.prologue(self.replay, (self.obs, self.act), None, 0, False, fields=(0, 2))
         pred = self.r_pi.forward(self.obs)[0]
         ng = (self.rows_global or B) * ad
         G.mse_loss(pred, self.act, B * ad, ng, self.du, self.st.stat_ptr("loss/actor_loss"))

@@ -133,11 +133,7 @@ class BCQLEngine:
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
-        st.tick()
-        if self.replay is not None:
-            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-        if device_noise:
-            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat, self.seed, device_noise)
         for k in ("z_c", "z_cc", "z_actor"):  # net.py:334-335 clamps the latent draw
             G.clamp_(nz[k], -0.5, 0.5)
 

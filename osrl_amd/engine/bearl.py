@@ -123,11 +123,7 @@ class BEARLEngine:
         m, st, nz, B, lib = self.model, self.st, self.noise, self.B, L.load()
         od, ad, Lz, N, M = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num, m.num_samples_mmd_match
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
-        st.tick()
-        if self.replay is not None:
-            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-        if device_noise:
-            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat, self.seed, device_noise)
         G.clamp_(nz["z_mmd"], -0.5, 0.5)  # decode_multiple clamps its latent draw (net.py:343-346)
 
         head = self.r_enc.forward(self.obs, self.act)[0]

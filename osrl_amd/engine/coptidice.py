@@ -91,11 +91,7 @@ class COptiDICEEngine:
         s = cur_stream
         dp, rg = self.dist, self.rows_global
         share = 1.0 if dp is None else 1.0 / dp.world
-        st.tick()
-        if self.replay is not None:  # TransitionDataset(state_init=True) + DataLoader + H2D, folded into the step
-            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done, self.init), st.ptr)
-        if device_noise:
-            randn_fill(self.noise_flat, self.seed, 0, st.ptr)
+        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done, self.init), self.noise_flat, self.seed, device_noise)
         leaves = m.scalar_leaves
 
         nu2 = self.r_nu.forward(self.x2)

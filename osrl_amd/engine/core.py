@@ -12,6 +12,7 @@ PyTorch is used for device memory and streams only; all arithmetic is in libosrl
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -545,6 +546,9 @@ class Branches:
             torch.cuda.current_stream().wait_event(ev)
 
 
+FUSED_BEGIN = os.environ.get("OSRL_FUSED_BEGIN", "1") == "1"
+
+
 class StepState:
     """Device-resident step counter / bias corrections / statistics ring (csrc/optim.hip)."""
 
@@ -572,6 +576,38 @@ class StepState:
                 "osrl_step_tick")
         self.host_step += 1
 
+    def begin(self, noise: Optional[torch.Tensor] = None, noise_seed: int = 0, noise_stream: int = 0,
+              gather=None) -> None:
+        """The step prologue in ONE launch (csrc/rng.hip ``step_begin_kernel``): this tick + the Philox fill of
+        ``noise`` (flat fp32 buffer, the draws of ``randn_fill(noise, noise_seed, noise_stream, st)``) + the minibatch
+        gather described by ``gather`` = ``store.gather_args(dst)``.  Same results as the three separate launches."""
+        n_f, src, dst, w, sc, n_rows, B, g_seed, g_stream, _keep = gather if gather is not None else \
+            (0, None, None, None, None, 0, 0, 0, 0, None)
+        L.check(L.load().osrl_step_begin(
+            self.ptr, self.betas[0], self.betas[1], self.warmup, self.stats.data_ptr(), self.ring.data_ptr(),
+            self.n_stats, self.ring_len, None if noise is None else noise.data_ptr(),
+            0 if noise is None else noise.numel(), noise_seed, noise_stream, n_f, src, dst, w, sc, n_rows, B, g_seed,
+            g_stream, cur_stream()), "osrl_step_begin")
+        self.host_step += 1
+
+    def prologue(self, replay, dst, noise: Optional[torch.Tensor], seed: int, device_noise: bool,
+                 fields: Optional[Sequence[int]] = None) -> None:
+        """tick [+ minibatch gather from ``replay`` into ``dst``] [+ noise fill]: one fused launch when there is
+        anything beside the tick (OSRL_FUSED_BEGIN=0: the separate launches, for A/B measurements)."""
+        want_noise = device_noise and noise is not None
+        if FUSED_BEGIN and (replay is not None or want_noise):
+            self.begin(noise if want_noise else None, seed, 0,
+                       None if replay is None else replay.gather_args(dst, fields))
+            return
+        self.tick()
+        if replay is not None:
+            if fields is None:
+                replay.gather(dst, self.ptr)
+            else:
+                replay.gather_fields(fields, dst, self.ptr)
+        if want_noise:
+            randn_fill(noise, seed, 0, self.ptr)
+
     def set_step(self, step: int) -> None:
         """Continue counting from ``step`` completed train steps (engine rebuild, checkpoint resume): the next
         tick makes it step+1 and recomputes the bias corrections / warm-up scale from that."""
@@ -590,6 +626,26 @@ class StepState:
                 raise RuntimeError("statistics of that step were already overwritten in the ring")
             v = self.ring[(step - 1) % self.ring_len].tolist()
         return dict(zip(self.keys, v))
+
+    def read_stats_many(self, steps) -> Dict[int, List[float]]:
+        """Statistics rows of several past steps through ONE device->host copy of the ring (the lazy logger's flush:
+        per-row reads cost one synchronising copy each, ~95 us per train step amortised at 5 keys)."""
+        steps = list(steps)
+        if not steps:
+            return {}
+        if min(steps) < 1 or self.host_step - min(steps) >= self.ring_len:
+            raise RuntimeError("statistics of that step were already overwritten in the ring")
+        both = torch.cat([self.ring.reshape(-1), self.stats]).tolist()  # one kernel, one synchronising copy
+        n = self.n_stats
+        cur = both[self.ring_len * n:]
+        out = {}
+        for s_ in steps:
+            if s_ == self.host_step:
+                out[s_] = cur
+            else:
+                r = (s_ - 1) % self.ring_len
+                out[s_] = both[r * n:(r + 1) * n]
+        return out
 
 
 def randn_fill(out: torch.Tensor, seed: int, stream_id: int, st_ptr: Optional[int]) -> None:

@@ -131,6 +131,7 @@ class CPQEngine:
         self._graph_failed = False
         self._probe = None
         self.ood_first = os.environ.get("OSRL_OOD_FIRST", "1") == "1"
+        self.cost_fwd_side = os.environ.get("OSRL_COST_FWD_SIDE", "0") == "1"
         self.n_branches = int(os.environ.get("OSRL_BRANCHES", "1"))  # 2 = the N*B-row launches on a branch of their own
 
     # ------------------------------------------------------------------ #
@@ -169,24 +170,9 @@ class CPQEngine:
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         par = par or Branches(False)
-        st.tick()
-        if par.enabled and device_noise and self.replay is not None:
-            # prologue: the noise fill (side stream) and the minibatch gather are independent -- +1 % step
-            par.fork(0)
-            with par.on(0):
-                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
-                ev_r = par.mark(0)
-            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-            ev_g = torch.cuda.Event()
-            ev_g.record()
-            par.wait(ev_r)
-            par.side[0].wait_event(ev_g)
-        else:
-            if self.replay is not None:
-                self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-            if device_noise:
-                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
-            par.fork(0)
+        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat,
+                    self.seed, device_noise)
+        par.fork(0)
         # ---- main: vae_loss  (cpq.py:125-135)
         head = self.r_enc.forward(self.obs, self.act)[0]
         G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
@@ -213,6 +199,12 @@ class CPQEngine:
             hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
             head_next, head_obs = hn[0], ho[0]
             G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+            if self.cost_fwd_side:
+                # the cost-critic phase's forward pair (cpq.py:159-161,188) needs nothing of the VAE phase: it runs
+                # here, beside it; the main branch picks up at the loss.  Balances the two chains (main was ~65 us
+                # longer once the quantile launch shrank)
+                qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
+                                                                   (self.obs, self.act))
             ev_next2 = par.mark(0)
             G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
@@ -242,7 +234,9 @@ class CPQEngine:
 
         # ---- main: cost_critic_loss (cpq.py:155-201), the part with a gradient: Bellman MSE of the online cost critics
         par.wait(ev_next2)
-        qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost, (self.obs, self.act))
+        if not self.cost_fwd_side:
+            qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
+                                                               (self.obs, self.act))
         G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0, None,
                         self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
@@ -292,24 +286,9 @@ class CPQEngine:
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         par = par or Branches(False)
-        st.tick()
-        if par.enabled and device_noise and self.replay is not None:
-            # prologue: the noise fill (side stream) and the minibatch gather are independent -- +1 % step
-            par.fork(0)
-            with par.on(0):
-                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
-                ev_r = par.mark(0)
-            self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-            ev_g = torch.cuda.Event()
-            ev_g.record()
-            par.wait(ev_r)
-            par.side[0].wait_event(ev_g)
-        else:
-            if self.replay is not None:
-                self.replay.gather((self.obs, self.nobs, self.act, self.rew, self.cost, self.done), st.ptr)
-            if device_noise:
-                randn_fill(self.noise_flat, self.seed, 0, st.ptr)
-            par.fork(0)
+        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat,
+                    self.seed, device_noise)
+        par.fork(0)
         # the side stream may start here; its launches are issued after the VAE phase's so the
         # graph executor (which dispatches nodes in creation order) starts both branches at once
         # ---- main: vae_loss  (cpq.py:125-135)

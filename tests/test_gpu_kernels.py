@@ -387,6 +387,45 @@ def test_quantile_exact(n):
         assert abs(out[0].item() - ref) <= 1e-6 * max(1, abs(ref)), (n, q, out[0].item(), ref)
 
 
+@pytest.mark.parametrize("n", [64, 1025, 20480, 32768, 32769])
+def test_quantile_clustered_values_both_select_paths(n):
+    """KL-like inputs (positive, sharing their high bytes, many exact ties) on both sides of the register / streaming
+    switch at n = 32 * 1024; the two order statistics are exact, the interpolation is within one ulp."""
+    from osrl_amd.engine import glue as G
+    dev = _dev()
+    rs = np.random.RandomState(n)
+    x = (0.5 + 1e-3 * rs.rand(n)).astype(np.float32)
+    x[rs.randint(0, n, n // 3)] = x[0]
+    xt = torch.tensor(x, device=dev)
+    out = torch.zeros(4, device=dev)
+    xs = np.sort(x)
+    for q in (0.75, 0.25, 0.999, 0.0, 1.0):
+        G.quantile(xt, n, q, out)
+        pos = np.float64(np.float32(q)) * (n - 1)
+        lo = int(np.floor(pos))
+        hi = min(lo + 1, n - 1)
+        ref = np.float32(xs[lo] + (xs[hi] - xs[lo]) * np.float32(pos - lo))
+        assert abs(out[0].item() - ref) <= np.spacing(ref), (n, q, out[0].item(), ref)  # fma vs mul+add
+
+
+@pytest.mark.parametrize("N,B,nqc", [(10, 2048, 2), (10, 256, 1), (3, 1000, 2)])
+def test_cpq_ood_stat_equals_quantile_then_mean(N, B, nqc):
+    """The fused single-GPU launch (quantile + masked OOD mean) returns the bits of the two separate launches."""
+    from osrl_amd.engine import glue as G
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(N * B)
+    kl = (0.3 + 0.01 * torch.rand(N * B, generator=g)).to(dev)
+    qc = torch.randn(nqc, N * B, generator=g).to(dev)
+    q0, m0, q1, m1 = (torch.zeros(4, device=dev) for _ in range(4))
+    G.quantile(kl, N * B, 0.75, q0)
+    G.cpq_ood_mean(qc, nqc, kl, q0, N, B, B, m0)
+    G.cpq_ood_stat(qc, nqc, kl, 0.75, N, B, B, q1, m1)
+    assert q0[0].item() == q1[0].item() and m0[0].item() == m1[0].item()
+    keep = (kl >= q0[0]).view(N, B)
+    ref = (keep * qc.min(0).values.view(N, B)).mean(0).mean().item()
+    assert abs(m1[0].item() - ref) <= 1e-5 * max(1.0, abs(ref))
+
+
 def test_randn_and_gather():
     from osrl_amd import _lib as L
     from osrl_amd.engine.core import StepState, cur_stream, randn_fill
@@ -422,6 +461,38 @@ def test_randn_and_gather():
     assert torch.equal(outs[0], tabs[0][ii]) and torch.equal(outs[1], tabs[1][ii])
     assert torch.equal(outs[2], tabs[2][ii] * 0.5)
     assert abs(ii.float().mean().item() / n_rows - 0.5) < 0.03
+
+
+@pytest.mark.parametrize("with_noise,with_gather", [(True, True), (True, False), (False, True)])
+def test_fused_step_prologue_equals_tick_randn_gather(with_noise, with_gather):
+    """osrl_step_begin (one launch) == osrl_step_tick -> osrl_randn_fill -> osrl_replay_gather over several steps:
+    same step state bytes, same statistics ring, same noise, same gathered rows; the arrival counter is back at 0."""
+    from osrl_amd.common.replay import ReplayStore, synthetic_transitions
+    from osrl_amd.engine.core import StepState, randn_fill
+    dev = _dev()
+    B, od, ad = 1000, 11, 3
+    store = ReplayStore(synthetic_transitions(5000, od, ad), dev, reward_scale=0.5, seed=7)
+    mk = lambda: [torch.zeros(B, w, device=dev) for w in (od, od, ad, 1, 1, 1)]  # noqa: E731
+    sa, sb = StepState(dev, ["x", "y"], ring_len=4), StepState(dev, ["x", "y"], ring_len=4)
+    na, nb = torch.zeros(12346, device=dev), torch.zeros(12346, device=dev)
+    da, db = mk(), mk()
+    for step in range(7):
+        for s_ in (sa, sb):
+            s_.stats.copy_(torch.tensor([step + 0.5, -step], device=dev))
+        sa.tick()
+        if with_noise:
+            randn_fill(na, 4321, 0, sa.ptr)
+        if with_gather:
+            store.gather(da, sa.ptr)
+        sb.begin(nb if with_noise else None, 4321, 0, store.gather_args(db) if with_gather else None)
+        torch.cuda.synchronize()
+        assert torch.equal(sa.state, sb.state), step
+        assert int(sb.state[20:24].view(torch.int32).item()) == 0
+        assert torch.equal(sa.ring, sb.ring) and sa.host_step == sb.host_step == step + 1
+        assert torch.equal(na, nb)
+        for x, y in zip(da, db):
+            assert torch.equal(x, y)
+    assert sb.device_step() == 7 and (not with_noise or na.abs().sum() > 0)
 
 
 def test_autograd_function_matches_torch():

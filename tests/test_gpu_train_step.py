@@ -195,6 +195,24 @@ def test_graph_replay_is_deterministic_and_trains(name):
     assert moved == len(p0)
 
 
+def test_lazy_statistics_over_several_ring_lengths_equal_the_synchronous_ones():
+    """300 graph-replayed steps (ring = 256 rows): the values the lazy logger materialises in bulk flushes are, step
+    for step, the ones a synchronising ``stats_mode="sync"`` run logs."""
+    c = CASES["cpq_small"]
+    logs = {}
+    for mode in ("sync", "lazy"):
+        m, tr, lg = build_gpu(c, stats_mode=mode, use_graph=True)
+        lg.max_keep = 10 ** 6
+        b = gpu_batch(c)
+        for s in range(300):
+            gpu_step(tr, c, b, s, with_noise=False)
+        torch.cuda.synchronize()
+        logs[mode] = {k: [float(x) for x in v] for k, v in lg.data.items()}
+    assert set(logs["sync"]) == set(logs["lazy"])
+    for k in logs["sync"]:
+        assert len(logs["lazy"][k]) == 300 and logs["lazy"][k] == logs["sync"][k], k
+
+
 @pytest.mark.parametrize("name", ["cpq_small", "cpq_wide", "bcql_small", "bc_small", "cpq_c2_full", "cpq_c4_full", "bearl_small",
                                   "bearl_wide", "coptidice_small", "coptidice_wide"])
 def test_graph_with_parallel_branches_equals_eager_sequential(name):

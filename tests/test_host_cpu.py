@@ -97,6 +97,37 @@ def test_lazy_stat_and_logger():
     assert lg.get_mean("a") == 3.5 and float(lg.data["a"][0]) == 6.0
 
 
+def test_lazy_stats_flush_reads_the_ring_once_and_keeps_every_step():
+    """store_stats(mode="lazy") over several ring lengths: each flush is ONE read_stats_many call covering the whole
+    backlog (keys subset included), every handed-out LazyStat ends with its own step's value, none is lost to a wrap."""
+    from osrl_amd.common.logger import DummyLogger, store_stats
+
+    class FakeSt:
+        keys = ["a", "b", "c"]
+        index = {"a": 0, "b": 1, "c": 2}
+        ring_len = 16
+
+        def __init__(self):
+            self.host_step, self.calls = 0, 0
+
+        def read_stats_many(self, steps):
+            self.calls += 1
+            assert all(self.host_step - s < self.ring_len for s in steps)
+            return {s: [1.0 * s, 2.0 * s, 3.0 * s] for s in steps}
+
+        def read_stats(self, step=None):
+            raise AssertionError("per-row read on the flush path")
+
+    st, lg = FakeSt(), DummyLogger(max_keep=10 ** 6)
+    for _ in range(100):
+        st.host_step += 1
+        store_stats(lg, st, "lazy", keys=["a", "c"])
+    assert 100 // 8 - 1 <= st.calls <= 100 // 8 + 1
+    done = [v for v in lg.data["c"] if getattr(v, "_val", v) is not None]
+    assert len(lg.data["a"]) == 100 and len(done) >= 100 - 8
+    assert [float(v) for v in lg.data["c"][:len(done)]] == [3.0 * (i + 1) for i in range(len(done))]
+
+
 def test_header_is_plain_c():
     """include/osrl_amd.h is the drop-in boundary: it must compile as C99 (no C++ constructs, no torch types) and a
     C translation unit must be able to take the address of every entry point it declares."""

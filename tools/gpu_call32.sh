@@ -1,16 +1,7 @@
-#!/bin/bash
-cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_cdt.py -m gpu -q --timeout=600 2>&1 | tail -4
-for nb in 1; do
-OSRL_LINEAR_NB=$nb timeout 200 python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-roofline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('linear_nb=$nb c5 steps/s', d['value'], d['ms_per_step'], d['last_stats']['all_loss'])"
-done
-cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cdt -o cdt -- python $GRAFT_REPO_ROOT/tools/prof_one.py cdt 5 > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
-S=$(find gpurun_out/prof_cdt -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/c32_cdt_kernel_stats.csv; find gpurun_out/prof_cdt -name "*trace.csv" -delete
-python - <<'PY'
-import csv
-rows=list(csv.DictReader(open('gpurun_out/c32_cdt_kernel_stats.csv')))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-for r in rows[:8]:
-    print(f"{r['Name'][:60]:60s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:9.1f} us  {float(r['TotalDurationNs'])/tot*100:5.1f}%")
-PY
+cd "$GRAFT_REPO_ROOT"; O=$GRAFT_REPO_ROOT/gpurun_out/c32; mkdir -p $O; export TMPDIR=/tmp
+cd /tmp && rocprofv3 --kernel-trace -f csv -d $O/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --no-roofline --steps 200 > $O/bench_profiled.json 2> $O/prof.err
+cd $GRAFT_REPO_ROOT
+T=$(find $O/prof -name "*kernel_trace.csv" | head -1)
+python tools/timeline.py $T > $O/timeline.txt 2>&1
+rm -rf $O/prof
+cat $O/timeline.txt
