@@ -134,3 +134,29 @@ def test_bearl_oracle_mmd_gradient_by_finite_differences(kernel):
         ym[b, j, k] -= h
         fd = (mmd_and_grad(x, yp, 1.7, kernel)[0][b] - mmd_and_grad(x, ym, 1.7, kernel)[0][b]) / (2 * h)
         assert abs(fd - g[b, j, k]) < 1e-6 * max(1.0, abs(fd)), (kernel, b, j, k, fd, g[b, j, k])
+
+
+def test_torch_cpu_baseline_matches_numpy_oracle():
+    """oracle/torch_cpq_cpu.py (bench.py's torch-on-CPU baseline, autograd + torch.optim.Adam) against the numpy
+    oracle (hand-derived backward, pinned to the reference's golden vectors above): same parameters after 3 steps,
+    same logged losses -- so the thing bench.py times as "the reference's CPU path" computes the reference's step."""
+    import torch
+    from cases import CASES, hyper, make_batch, make_noise, make_params
+    from oracle.torch_cpq_cpu import TorchCPQ
+    from oracle_util import build_oracle, oracle_step
+    c = CASES["cpq_small"]
+    hp = hyper(c)
+    o = build_oracle(c)
+    t = TorchCPQ(make_params(c), max_action=c.max_action, sample_action_num=c.N, gamma=hp["gamma"], tau=hp["tau"],
+                 beta=hp["beta"], qc_scalar=hp["qc_scalar"], cost_limit=c.cost_limit, episode_len=c.episode_len,
+                 actor_lr=hp["actor_lr"], critic_lr=hp["critic_lr"], alpha_lr=hp["alpha_lr"], vae_lr=hp["vae_lr"])
+    b = make_batch(c)
+    for step in range(3):
+        so = oracle_step(o, c, step)
+        st = t.train_one_step(b["observations"], b["next_observations"], b["actions"], b["rewards"], b["costs"],
+                              b["done"], make_noise(c, step))
+        for k in so:
+            assert abs(so[k] - st[k]) <= 2e-5 * max(1.0, abs(so[k])), (step, k, so[k], st[k])
+    for k, v in o.p.items():
+        d = float(np.abs(v - t.p[k].detach().numpy()).max())
+        assert d <= 2e-5 * max(1.0, float(np.abs(v).max())), (k, d)
