@@ -419,31 +419,134 @@ __device__ __forceinline__ void attn_key_valid(const AttnArgs& a, int b, int Sp,
     kvalid[j] = (j < a.S && a.mask[(size_t)b * (a.S / a.rep) + j / a.rep] > 0.f) ? 1.f : 0.f;
 }
 
+// one [16, 4-column] fragment of a row-major global matrix in frag_row layout: X[row0 + (lane & 15)][k0 + 4*(lane>>4) ..+3],
+// zero outside [0, rows) x [0, cols)
+__device__ __forceinline__ f32x4 gfrag_row(const float* __restrict__ base, size_t ld, int row0, int rows, int k0,
+                                           int cols, int lane) {
+  const int r = row0 + (lane & 15), c = k0 + 4 * (lane >> 4);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (r < rows) {
+    const float* p = base + (size_t)r * ld + c;
+    if (c + 3 < cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+      v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (c + t < cols) v[t] = p[t];
+    }
+  }
+  return v;
+}
+
+// Forward of the attention core, one workgroup per (sample, head).  Round 2, second version: the probabilities never
+// touch LDS.  A wave owns whole 16-query row blocks and forms the TRANSPOSED score blocks S^T = K Q^T, whose
+// accumulator layout (lane: query i = lane & 15, keys 4*(lane>>4) .. +3 of the block) IS the A-operand fragment layout
+// of P in O = P V -- so mask, softmax (row reductions = in-register over the blocks + two cross-row-group shuffles),
+// dropout and the second product all run from registers.  LDS holds only K and V^T (24 KB at S = 80, d = 32, against
+// 65 KB with the Q and [S, S] tiles): six workgroups per CU instead of two, one barrier instead of four, no idle waves
+// behind a serial softmax.  Q fragments come straight from global.  Row blocks are dealt to the four waves largest
+// first (block ib costs ib + 1 key blocks under the causal mask).
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = a.E / a.H, dp = (d + 15) & ~15, Sp = (a.S + 15) & ~15;
   const int ldq = dp + 8, ldp = Sp + 8;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float *Qs = sm, *Ks = Qs + Sp * ldq, *Vt = Ks + Sp * ldq, *Ps = Vt + dp * ldp, *kvalid = Ps + Sp * ldp;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float *Ks = sm, *Vt = Ks + Sp * ldq, *kvalid = Vt + dp * ldp;
   const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
-  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, Qs, ldq, nullptr, 0);
   attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, Ks, ldq, nullptr, 0);
   attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, nullptr, 0, Vt, ldp);
   attn_key_valid(a, b, Sp, kvalid);
-  __syncthreads();
-  attn_probs_mfma(a, b, d, Sp, dp, Qs, Ks, ldq, Ps, ldp, kvalid, true, blockIdx.x);
-  // O = P V : blocks (ib, cb); A = row fragments of P, B = row fragments of V^T
   const int nb = Sp >> 4, ncb = dp >> 4;
-  for (int blk = wave; blk < nb * ncb; blk += 4) {
-    const int ib = blk / ncb, cb = blk - ib * ncb;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int jc = 0; jc <= ib; ++jc) mfma4(acc, frag_row(Ps, ldp, ib * 16, jc * 16, lane), frag_row(Vt, ldp, cb * 16, jc * 16, lane));
-    const int c = cb * 16 + (lane & 15);
+  // deal the row blocks, largest first, each to the least loaded wave (every wave computes the same deal)
+  unsigned mine = 0;
+  {
+    int load[4] = {0, 0, 0, 0};
+    for (int ib = nb - 1; ib >= 0; --ib) {
+      int w = 0;
+      for (int k = 1; k < 4; ++k)
+        if (load[k] < load[w]) w = k;
+      load[w] += ib + 1;
+      if (w == wave) mine |= 1u << ib;
+    }
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)d);
+  const int q4 = 4 * (lane >> 4), m = lane & 15;
+  for (int ib = nb - 1; ib >= 0; --ib) {
+    if (!((mine >> ib) & 1u)) continue;
+    f32x4 qf[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ib * 16 + 4 * (lane >> 4) + r;
-      if (i < a.S && c < d) a.o[((size_t)b * a.S + i) * a.E + h * d + c] = acc[r];
+    for (int c = 0; c < 4; ++c) {
+      qf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < ncb) qf[c] = gfrag_row(base, 3 * (size_t)a.E, ib * 16, a.S, c * 16, d, lane);
+    }
+    const int i = ib * 16 + m;  // the query row this lane normalises
+    f32x4 s[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+      s[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (jb <= ib) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < ncb) mfma4(s[jb], frag_row(Ks, ldq, jb * 16, c * 16, lane), qf[c]);
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kvalid + jb * 16 + q4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = jb * 16 + q4 + r;
+          s[jb][r] = (j <= i && kv[r] > 0.f) ? s[jb][r] * scale : -INFINITY;
+          mx = fmaxf(mx, s[jb][r]);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const bool live = i < a.S && mx > -INFINITY;
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+      if (jb <= ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (live && s[jb][r] > -INFINITY) ? expf(s[jb][r] - mx) : 0.f;
+          s[jb][r] = e;
+          sum += e;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = live ? 1.0f / sum : 0.f;
+    if (a.drop_thresh && i < a.S) {  // P' = P M / (1-p): the mask of lane (i, l16 = q4 + r), block k = jb
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float dm[8];
+        attn_drop_mult(a, blockIdx.x, i, q4 + r, ib + 1, dm);
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb)
+          if (jb <= ib) s[jb][r] *= dm[jb];
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+      if (jb <= ib) s[jb] *= inv;
+    // O[ib] = P[ib] V : A = the probability fragments in registers, B = row fragments of V^T
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      if (cb < ncb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb)
+          if (jb <= ib) mfma4(acc, s[jb], frag_row(Vt, ldp, cb * 16, jb * 16, lane));
+        const int c = cb * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int io = ib * 16 + q4 + r;
+          if (io < a.S && c < d) a.o[((size_t)b * a.S + io) * a.E + h * d + c] = acc[r];
+        }
+      }
     }
   }
 }
@@ -863,7 +966,7 @@ static size_t attn_lds(int S_, int d, bool bwd) {
   const size_t Sp = (S_ + 15) & ~15, dp = (d + 15) & ~15, ldq = dp + 8, ldp = Sp + 8;
   if (bwd)  // two operand tiles, one [S, S] tile, row-sum partials per column block, key mask, keep-mask bytes
     return sizeof(float) * (2 * Sp * ldq + Sp * ldp + (Sp / 16) * Sp + Sp) + ((Sp * Sp + 15) & ~(size_t)15);
-  const size_t fl = 2 * Sp * ldq + dp * ldp + Sp * ldp + Sp;
+  const size_t fl = Sp * ldq + dp * ldp + Sp;  // forward: K, V^T, key mask (scores stay in registers)
   return sizeof(float) * fl;
 }
 
