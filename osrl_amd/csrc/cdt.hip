@@ -446,6 +446,7 @@ __device__ __forceinline__ f32x4 gfrag_row(const float* __restrict__ base, size_
 // 65 KB with the Q and [S, S] tiles): six workgroups per CU instead of two, one barrier instead of four, no idle waves
 // behind a serial softmax.  Q fragments come straight from global.  Row blocks are dealt to the four waves largest
 // first (block ib costs ib + 1 key blocks under the causal mask).
+template <int NBMAX>  // S <= 16 * NBMAX (5: CDT's 4 x 20 tokens; 8: the 128-token limit) -- sizes the register tiles
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = a.E / a.H, dp = (d + 15) & ~15, Sp = (a.S + 15) & ~15;
@@ -483,10 +484,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       if (c < ncb) qf[c] = gfrag_row(base, 3 * (size_t)a.E, ib * 16, a.S, c * 16, d, lane);
     }
     const int i = ib * 16 + m;  // the query row this lane normalises
-    f32x4 s[8];
+    f32x4 s[NBMAX];
     float mx = -INFINITY;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
+    for (int jb = 0; jb < NBMAX; ++jb) {
       s[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (jb <= ib) {
 #pragma unroll
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const bool live = i < a.S && mx > -INFINITY;
     float sum = 0.f;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
+    for (int jb = 0; jb < NBMAX; ++jb) {
       if (jb <= ib) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -525,12 +526,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         float dm[8];
         attn_drop_mult(a, blockIdx.x, i, q4 + r, ib + 1, dm);
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb)
+        for (int jb = 0; jb < NBMAX; ++jb)
           if (jb <= ib) s[jb][r] *= dm[jb];
       }
     }
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+    for (int jb = 0; jb < NBMAX; ++jb)
       if (jb <= ib) s[jb] *= inv;
     // O[ib] = P[ib] V : A = the probability fragments in registers, B = row fragments of V^T
 #pragma unroll
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       if (cb < ncb) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb)
+        for (int jb = 0; jb < NBMAX; ++jb)
           if (jb <= ib) mfma4(acc, s[jb], frag_row(Vt, ldp, cb * 16, jb * 16, lane));
         const int c = cb * 16 + m;
 #pragma unroll
@@ -551,137 +552,228 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
-// Backward of the attention core.  Round 2: TWO workgroups per CU instead of one (108 -> 62 KB of LDS).  The kernel is
-// latency bound (about 600 MFMAs per (sample, head), 30 us per workgroup), so residency is what buys throughput:
-//   * one [S, S] tile instead of two: dP = dO V^T is an MFMA product that costs nothing to recompute, so pass 1 forms
-//     the dP blocks in registers only to get the row sums r_i = sum_j P'_ij dP'_ij (per-column-block partials in LDS,
-//     summed in a fixed order: deterministic), dV = P'^T dO is taken while the tile still holds P, and pass 2 recomputes
-//     the dP blocks and overwrites P with dS = P' dP' - P r in place;
-//   * two [S, d] operand tiles instead of four: (Q, K) for the probabilities, then (dO, V), then (Q, K) again for dQ / dK
-//     (the re-load is 20 KB from L2);
-//   * attention dropout: the keep mask of the tile is materialised once as bytes (regenerated from the counters exactly
-//     as the forward kernel draws it), because P' = P M / (1-p) and P are both needed.
-__device__ __forceinline__ float attn_keep_mult(const AttnArgs& a, const unsigned char* Mb, int Sp, int i, int j) {
-  return a.drop_thresh ? (Mb[i * Sp + j] ? a.drop_scale : 0.f) : 1.0f;
+// deal blocks 0..nb-1 with costs cost(blk) to 4 waves, most expensive first, each to the least loaded wave
+__device__ __forceinline__ unsigned attn_deal(int nb, int wave, bool rows) {
+  unsigned mine = 0;
+  int load[4] = {0, 0, 0, 0};
+  for (int t = 0; t < nb; ++t) {
+    const int blk = rows ? nb - 1 - t : t;  // row block ib costs ib + 1 key blocks, key block jb costs nb - jb row blocks
+    int w = 0;
+    for (int k = 1; k < 4; ++k)
+      if (load[k] < load[w]) w = k;
+    load[w] += rows ? blk + 1 : nb - blk;
+    if (w == wave) mine |= 1u << blk;
+  }
+  return mine;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
+// Backward of the attention core (net.py:395-417 under autograd), one workgroup per (sample, head), everything
+// [S, S]-shaped in registers (third version; round 1 kept two [S, S] tiles + four operand tiles in 108 KB of LDS, the
+// second version one tile + two operand tiles in 62 KB).  Two passes over the causal block triangle:
+//   A, by QUERY block (the wave that owns rows i): S^T = K Q^T and dP'^T = V dO^T in the transposed accumulator layout
+//      (lane: row i = lane & 15, keys 4*(lane>>4) ..+3), so softmax, r_i = sum_j P'_ij dP'_ij and
+//      dS = P' dP' - P r are lane-local plus two cross-row-group shuffles, and dS is already the A fragment of
+//      dQ = dS K.  Leaves per-row (max, 1/sum, r) and the keep-mask bytes of the tile in LDS.
+//   B, by KEY block (the wave that owns columns j): S = Q K^T and dP' = dO V^T in the standard layout (lane: rows
+//      4*(lane>>4) ..+3, key j = lane & 15), P rebuilt from the row statistics, and P'^T / dS^T are then the A fragments
+//      of dV = P'^T dO and dK = dS^T Q (the contraction runs over the query rows).
+// The MFMA products are recomputed (about 840 instead of 600 MFMAs per workgroup: nothing next to the latency they
+// replace); LDS holds two [S, d] tiles ((K, V) in pass A, (Q, dO) in pass B; the other two operands of each pass are
+// the owning wave's own rows, read straight from global as fragments), 33 KB at S = 80, d = 32: four workgroups per CU,
+// three barriers.
+template <int NBMAX>
+__global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = a.E / a.H, dp = (d + 15) & ~15, Sp = (a.S + 15) & ~15;
-  const int ldq = dp + 8, ldp = Sp + 8;
+  const int ldq = dp + 8;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nb = Sp >> 4, ncb = dp >> 4, ntri = nb * (nb + 1) / 2;
-  float *T0 = sm, *T1 = T0 + Sp * ldq, *Ps = T1 + Sp * ldq, *rpart = Ps + Sp * ldp, *kvalid = rpart + nb * Sp;
-  unsigned char* Mb = reinterpret_cast<unsigned char*>(kvalid + Sp);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nb = Sp >> 4, ncb = dp >> 4;
+  const int q4 = 4 * (lane >> 4), m = lane & 15;
+  float *T0 = sm, *T1 = T0 + Sp * ldq, *rmax = T1 + Sp * ldq, *rinv = rmax + Sp, *rdot = rinv + Sp, *kvalid = rdot + Sp;
+  unsigned char* Mb = reinterpret_cast<unsigned char*>(kvalid + Sp);  // [Sp][Sp] keep flags
+  const size_t ldg = 3 * (size_t)a.E;
   const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
   const float* __restrict__ dob = a.dout + (size_t)b * a.S * a.E + h * d;
-  // ---- phase A: P = softmax(mask(Q K^T / sqrt(d)))  (T0 = Q, T1 = K)
-  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
-  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
-  attn_key_valid(a, b, Sp, kvalid);
-  __syncthreads();
-  attn_probs_mfma(a, b, d, Sp, dp, T0, T1, ldq, Ps, ldp, kvalid, false, blockIdx.x);  // ends with a barrier
-  // ---- phase B: T0 = dO, T1 = V
-  attn_load_tile(dob, a.E, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
-  attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
-  if (a.drop_thresh) {  // keep mask of the whole tile, drawn in the forward kernel's row layout
-    const int l16 = lane & 15, rsub = lane >> 4;
-    for (int i0 = wave * 4; i0 < Sp; i0 += 16) {
-      const int i = i0 + rsub;
-      float dm[8];
-      if (i < a.S) {
-        attn_drop_mult(a, blockIdx.x, i, l16, ((i >> 4) + 1), dm);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dm[k] = 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int j = l16 + 16 * k;
-        if (j < Sp) Mb[i * Sp + j] = dm[k] != 0.f ? 1 : 0;
-      }
-    }
-  }
-  __syncthreads();
-  // dP block (ib, jb) = dO[ib] V[jb]^T in registers
-  auto dp_block = [&](int ib, int jb) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < dp; kc += 16) mfma4(acc, frag_row(T0, ldq, ib * 16, kc, lane), frag_row(T1, ldq, jb * 16, kc, lane));
-    return acc;
-  };
-  // pass 1: r-partials  rpart[jb][i] = sum_{j in block jb} P'_ij dP'_ij
-  for (int blk = wave; blk < ntri; blk += 4) {
-    int ib, jb;
-    tri_decode(blk, &ib, &jb);
-    const f32x4 g = dp_block(ib, jb);
-    const int j = jb * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ib * 16 + 4 * (lane >> 4) + r;
-      float t = Ps[i * ldp + j] * attn_keep_mult(a, Mb, Sp, i, j) * g[r];
-      t = row16_sum(t);
-      if ((lane & 15) == 0) rpart[jb * Sp + i] = t;
-    }
-  }
-  __syncthreads();
-  // dV[j][c] = sum_{i >= j} P'[i][j] dO[i][c]   (while Ps still holds P)
-  for (int blk = wave; blk < nb * ncb; blk += 4) {
-    const int rb = blk / ncb, cb = blk - rb * ncb;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ic = rb; ic < nb; ++ic) {
-      f32x4 pf = frag_col(Ps, ldp, ic * 16, rb * 16, lane);
-      if (a.drop_thresh) {
-        const int i0 = ic * 16 + 4 * (lane >> 4), j = rb * 16 + (lane & 15);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pf[t] *= Mb[(i0 + t) * Sp + j] ? a.drop_scale : 0.f;
-      }
-      mfma4(acc, pf, frag_col(T0, ldq, ic * 16, cb * 16, lane));
-    }
-    const int c = cb * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = rb * 16 + 4 * (lane >> 4) + r;
-      if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + 2 * a.E + h * d + c] = acc[r];
-    }
-  }
-  __syncthreads();
-  // pass 2: dS = P' dP' - P r  in place over P (every element is read and written by the one lane that owns it)
-  for (int blk = wave; blk < ntri; blk += 4) {
-    int ib, jb;
-    tri_decode(blk, &ib, &jb);
-    const f32x4 g = dp_block(ib, jb);
-    const int j = jb * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ib * 16 + 4 * (lane >> 4) + r;
-      float ri = 0.f;
-      for (int q = 0; q <= ib; ++q) ri += rpart[q * Sp + i];
-      const float pv = Ps[i * ldp + j];
-      Ps[i * ldp + j] = pv * attn_keep_mult(a, Mb, Sp, i, j) * g[r] - pv * ri;
-    }
-  }
-  __syncthreads();
-  // ---- phase C: T0 = Q, T1 = K again; dQ, dK from dS
-  attn_load_tile(base, 3 * a.E, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
-  attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
-  __syncthreads();
+  float* __restrict__ dq_out = a.dqkv + (size_t)b * a.S * 3 * a.E + h * d;
   const float scale = 1.0f / sqrtf((float)d);
-  for (int blk = wave; blk < 2 * nb * ncb; blk += 4) {
-    const int which = blk / (nb * ncb), rem = blk - which * nb * ncb;
-    const int rb = rem / ncb, cb = rem - rb * ncb;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (which == 0) {  // dQ[i][c] = sum_{j <= i} dS[i][j] K[j][c]
-      for (int jc = 0; jc <= rb; ++jc) mfma4(acc, frag_row(Ps, ldp, rb * 16, jc * 16, lane), frag_col(T1, ldq, jc * 16, cb * 16, lane));
-    } else {  // dK[j][c] = sum_{i >= j} dS[i][j] Q[i][c]
-      for (int ic = rb; ic < nb; ++ic) mfma4(acc, frag_col(Ps, ldp, ic * 16, rb * 16, lane), frag_col(T0, ldq, ic * 16, cb * 16, lane));
-    }
-    const int c = cb * 16 + (lane & 15);
+
+  // ---- pass A: T0 = K, T1 = V
+  attn_load_tile(base + a.E, ldg, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
+  attn_load_tile(base + 2 * a.E, ldg, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
+  attn_key_valid(a, b, Sp, kvalid);
+  const unsigned my_rows = attn_deal(nb, wave, true), my_cols = attn_deal(nb, wave, false);
+  __syncthreads();
+  for (int ib = nb - 1; ib >= 0; --ib) {
+    if (!((my_rows >> ib) & 1u)) continue;
+    f32x4 qf[4], dof[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = rb * 16 + 4 * (lane >> 4) + r;
-      if (i < a.S && c < d) a.dqkv[((size_t)b * a.S + i) * 3 * a.E + which * a.E + h * d + c] = acc[r] * scale;
+    for (int c = 0; c < 4; ++c) {
+      qf[c] = dof[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < ncb) {
+        qf[c] = gfrag_row(base, ldg, ib * 16, a.S, c * 16, d, lane);
+        dof[c] = gfrag_row(dob, (size_t)a.E, ib * 16, a.S, c * 16, d, lane);
+      }
     }
+    const int i = ib * 16 + m;
+    f32x4 s[NBMAX], g[NBMAX], pk[NBMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < NBMAX; ++jb) {
+      s[jb] = g[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (jb <= ib) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < ncb) {
+            mfma4(s[jb], frag_row(T0, ldq, jb * 16, c * 16, lane), qf[c]);
+            mfma4(g[jb], frag_row(T1, ldq, jb * 16, c * 16, lane), dof[c]);  // dP'[i][j] = sum_c dO[i][c] V[j][c]
+          }
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kvalid + jb * 16 + q4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = jb * 16 + q4 + r;
+          s[jb][r] = (j <= i && kv[r] > 0.f) ? s[jb][r] * scale : -INFINITY;
+          mx = fmaxf(mx, s[jb][r]);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const bool live = i < a.S && mx > -INFINITY;
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NBMAX; ++jb)
+      if (jb <= ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (live && s[jb][r] > -INFINITY) ? expf(s[jb][r] - mx) : 0.f;
+          s[jb][r] = e;
+          sum += e;
+        }
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = live ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NBMAX; ++jb)
+      if (jb <= ib) {
+        s[jb] *= inv;  // P
+        pk[jb] = s[jb];
+      }
+    if (a.drop_thresh) {  // P' = P M / (1-p); the keep flags of the tile go to LDS for pass B
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float dm[8];
+        if (i < a.S) {
+          attn_drop_mult(a, blockIdx.x, i, q4 + r, ib + 1, dm);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dm[k] = 0.f;
+        }
+#pragma unroll
+        for (int jb = 0; jb < NBMAX; ++jb)
+          if (jb <= ib) {
+            pk[jb][r] *= dm[jb];
+            Mb[i * Sp + jb * 16 + q4 + r] = dm[jb] != 0.f ? 1 : 0;
+          }
+      }
+    }
+    float rd = 0.f;  // r_i = sum_j P'_ij dP'_ij
+#pragma unroll
+    for (int jb = 0; jb < NBMAX; ++jb)
+      if (jb <= ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd += pk[jb][r] * g[jb][r];
+      }
+    rd += __shfl_xor(rd, 16);
+    rd += __shfl_xor(rd, 32);
+    if (q4 == 0) {
+      rmax[i] = live ? mx : 0.f;
+      rinv[i] = inv;
+      rdot[i] = rd;
+    }
+#pragma unroll
+    for (int jb = 0; jb < NBMAX; ++jb)
+      if (jb <= ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[jb][r] = pk[jb][r] * g[jb][r] - s[jb][r] * rd;  // dS
+      }
+    // dQ[ib] = scale * dS[ib] K : A = dS fragments (registers), B[k = j][n = c] = K[j][c]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      if (cb < ncb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < NBMAX; ++jb)
+          if (jb <= ib) mfma4(acc, g[jb], frag_col(T0, ldq, jb * 16, cb * 16, lane));
+        const int c = cb * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int io = ib * 16 + q4 + r;
+          if (io < a.S && c < d) dq_out[(size_t)io * ldg + c] = acc[r] * scale;
+        }
+      }
+  }
+  __syncthreads();  // K, V tiles are done with; row statistics and keep flags are complete
+
+  // ---- pass B: T0 = Q, T1 = dO
+  attn_load_tile(base, ldg, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
+  attn_load_tile(dob, (size_t)a.E, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
+  __syncthreads();
+  for (int jb = 0; jb < nb; ++jb) {
+    if (!((my_cols >> jb) & 1u)) continue;
+    f32x4 kf[4], vf[4], accK[4], accV[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kf[c] = vf[c] = accK[c] = accV[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < ncb) {
+        kf[c] = gfrag_row(base + a.E, ldg, jb * 16, a.S, c * 16, d, lane);
+        vf[c] = gfrag_row(base + 2 * a.E, ldg, jb * 16, a.S, c * 16, d, lane);
+      }
+    }
+    const int j = jb * 16 + m;
+    const bool jok = kvalid[j] > 0.f;
+    for (int ib = jb; ib < nb; ++ib) {
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f}, gp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < ncb) {
+          mfma4(sv, frag_row(T0, ldq, ib * 16, c * 16, lane), kf[c]);  // S[i][j]
+          mfma4(gp, frag_row(T1, ldq, ib * 16, c * 16, lane), vf[c]);  // dP'[i][j]
+        }
+      const f32x4 mxv = *reinterpret_cast<const f32x4*>(rmax + ib * 16 + q4);
+      const f32x4 ivv = *reinterpret_cast<const f32x4*>(rinv + ib * 16 + q4);
+      const f32x4 rdv = *reinterpret_cast<const f32x4*>(rdot + ib * 16 + q4);
+      f32x4 pp, dsv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib * 16 + q4 + r;
+        const float P = (jok && j <= i) ? expf(sv[r] * scale - mxv[r]) * ivv[r] : 0.f;
+        const float km = a.drop_thresh ? (Mb[i * Sp + j] ? a.drop_scale : 0.f) : 1.0f;
+        pp[r] = P * km;                        // P'
+        dsv[r] = pp[r] * gp[r] - P * rdv[r];   // dS
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        if (cb < ncb) {
+          mfma4(accV[cb], pp, frag_col(T1, ldq, ib * 16, cb * 16, lane));   // dV[j][c] += P'[i][j] dO[i][c]
+          mfma4(accK[cb], dsv, frag_col(T0, ldq, ib * 16, cb * 16, lane));  // dK[j][c] += dS[i][j] Q[i][c]
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      if (cb < ncb) {
+        const int c = cb * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jo = jb * 16 + q4 + r;
+          if (jo < a.S && c < d) {
+            dq_out[(size_t)jo * ldg + a.E + c] = accK[cb][r] * scale;
+            dq_out[(size_t)jo * ldg + 2 * a.E + c] = accV[cb][r];
+          }
+        }
+      }
   }
 }
 
@@ -964,8 +1056,8 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
 constexpr size_t kMaxLds = 160 * 1024;  // LDS per workgroup on gfx950
 static size_t attn_lds(int S_, int d, bool bwd) {
   const size_t Sp = (S_ + 15) & ~15, dp = (d + 15) & ~15, ldq = dp + 8, ldp = Sp + 8;
-  if (bwd)  // two operand tiles, one [S, S] tile, row-sum partials per column block, key mask, keep-mask bytes
-    return sizeof(float) * (2 * Sp * ldq + Sp * ldp + (Sp / 16) * Sp + Sp) + ((Sp * Sp + 15) & ~(size_t)15);
+  if (bwd)  // two [S, d] operand tiles, per-row (max, 1/sum, r), key mask, keep-flag bytes of the [S, S] tile
+    return sizeof(float) * (2 * Sp * ldq + 4 * Sp) + Sp * Sp;
   const size_t fl = Sp * ldq + dp * ldp + Sp;  // forward: K, V^T, key mask (scores stay in registers)
   return sizeof(float) * fl;
 }
@@ -1004,10 +1096,10 @@ int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S
   const size_t lds = attn_lds(S_, E / H, false);
   if (lds > kMaxLds) return -1;
   CLEAR();
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, S, a);
+  if (S_ <= 80)
+    hipLaunchKernelGGL(attn_fwd_kernel<5>, dim3(B * H), dim3(256), lds, S, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(B * H), dim3(256), lds, S, a);
   DONE();
 }
 
@@ -1017,12 +1109,12 @@ int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, i
   AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep};
   if (!attn_drop_args(drop, &a)) return -1;
   const size_t lds = attn_lds(S_, E / H, true);
-  if (lds > kMaxLds) return -1;  // e.g. S = 128 with head_dim 32 needs 221 KB: not supported
+  if (lds > 64 * 1024) return -1;
   CLEAR();
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, S, a);
+  if (S_ <= 80)
+    hipLaunchKernelGGL(attn_bwd_kernel<5>, dim3(B * H), dim3(256), lds, S, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel<8>, dim3(B * H), dim3(256), lds, S, a);
   DONE();
 }
 
