@@ -57,7 +57,9 @@ class OracleCDT:
                  target_entropy: Optional[float] = None, learning_rate: float = 1e-4, weight_decay: float = 1e-4,
                  betas=(0.9, 0.999), clip_grad: Optional[float] = 0.25, lr_warmup_steps: int = 500,
                  loss_cost_weight: float = 0.02, loss_state_weight: float = 0.0, no_entropy: bool = False,
-                 dtype=np.float32):
+                 time_emb: bool = True, use_rew: bool = True, use_cost: bool = True, add_cost_feat: bool = False,
+                 mul_cost_feat: bool = False, cat_cost_feat: bool = False, action_head_layers: int = 1,
+                 cost_prefix: bool = False, dtype=np.float32):
         self.p = {k: np.array(v, dtype=dtype) for k, v in params.items() if "causal_mask" not in k}
         self.dtype = dtype
         self.T, self.H, self.NL = seq_len, num_heads, num_layers
@@ -71,26 +73,51 @@ class OracleCDT:
         self.opt = Adam(list(self.p.keys()), learning_rate, betas[0], betas[1], 1e-8, weight_decay)  # AdamW :321-326
         self.opt_T = Adam(["log_temperature"], 1e-4, 0.9, 0.999)  # cdt.py:332-337
         self.steps = 0
+        # constructor variants (cdt.py:58-66,96-141): token set, cost features on the state feature, head depth, prefix
+        self.time_emb, self.use_rew, self.use_cost, self.prefix = time_emb, use_rew, use_cost, cost_prefix
+        self.R = 2 + int(use_rew) + int(use_cost)
+        self.add_cf, self.mul_cf, self.cat_cf = (add_cost_feat and use_cost, mul_cost_feat and use_cost,
+                                                 cat_cost_feat and use_cost)  # cdt.py:243-250 all require use_cost
+        self.head_layers = action_head_layers
+
+    # ---- action head (cdt.py:127-137): hidden Linear+GELU layers, then the output layer(s)
+    def _head_keys(self):
+        if self.stochastic:
+            hidden = ["action_head.0"] if self.head_layers >= 2 else []
+            pre = "action_head.2." if self.head_layers >= 2 else "action_head."
+            return hidden, [pre + "mu", pre + "log_std"]
+        n = self.head_layers
+        return [f"action_head.{2 * i}" for i in range(n - 1)], [f"action_head.{2 * (n - 1)}"]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, states, actions, returns, costs_to_go, time_steps, mask, drop=None):
+    def forward(self, states, actions, returns, costs_to_go, time_steps, mask, drop=None, episode_cost=None):
         drop = drop or {}
         one = self.dtype(1.0)
-        p, E, H = self.p, self.E, self.H
+        p, E, H, R = self.p, self.E, self.H, self.R
         B, T, _ = states.shape
-        S = 4 * T
+        S = R * T + int(self.prefix)
         c = {}
-        te = p["timestep_emb.weight"][time_steps]  # [B,T,E]
+        te = p["timestep_emb.weight"][time_steps] if self.time_emb else self.dtype(0.0)  # [B,T,E]  cdt.py:180-183
         ctg = (50.0 - costs_to_go) if self.cost_transform else costs_to_go  # cdt.py:78-81,187-188
         c["ctg"] = ctg
-        r_e = returns[..., None] * p["return_emb.weight"][:, 0] + p["return_emb.bias"] + te
-        c_e = ctg[..., None] * p["cost_emb.weight"][:, 0] + p["cost_emb.bias"] + te
         s_e = states @ p["state_emb.weight"].T + p["state_emb.bias"] + te
         a_e = actions @ p["action_emb.weight"].T + p["action_emb.bias"] + te
-        seq = np.stack([r_e, c_e, s_e, a_e], 2).reshape(B, S, E)  # (r,c,s,a) per timestep  cdt.py:185-200
+        toks = [s_e, a_e]
+        c_e = None
+        if self.use_cost:  # cdt.py:190-192: costs go in front of the state token ...
+            c_e = ctg[..., None] * p["cost_emb.weight"][:, 0] + p["cost_emb.bias"] + te
+            toks.insert(0, c_e)
+        if self.use_rew:  # cdt.py:193-195: ... and returns in front of those
+            toks.insert(0, returns[..., None] * p["return_emb.weight"][:, 0] + p["return_emb.bias"] + te)
+        c["c_e"] = c_e
+        seq = np.stack(toks, 2).reshape(B, R * T, E)  # (r,c,s,a) per timestep  cdt.py:185-200
+        key_pad = np.repeat(mask <= 0, R, axis=1)  # [B,S] True = ignore  cdt.py:202-205
+        if self.prefix:  # cdt.py:207-218: one token in front, from the episode's cost budget; masked like token 0
+            pe = np.asarray(episode_cost, self.dtype)[:, None, None] * p["prefix_emb.weight"][:, 0] + p["prefix_emb.bias"]
+            seq = np.concatenate([pe, seq], 1)
+            key_pad = np.concatenate([key_pad[:, :1], key_pad], 1)
         x, c["ln_emb"] = layer_norm(seq, p["emb_norm.weight"], p["emb_norm.bias"])
         x = x * drop.get("emb", one)  # emb_drop  cdt.py:222
-        key_pad = np.repeat(mask <= 0, 4, axis=1)  # [B,S] True = ignore  cdt.py:202-205
         causal = np.triu(np.ones((S, S), bool), 1)  # True = blocked  net.py:417-418
         blocked = causal[None, None] | key_pad[:, None, None, :]
         d = E // H
@@ -117,25 +144,41 @@ class OracleCDT:
             bc.update(n1=n1, q=q, k=k, v=v, P=P, Pd=Pd, o=o, n2=n2, hpre=hpre, h=h)
             c["blocks"].append(bc)
         out, c["ln_out"] = layer_norm(x, p["out_norm.weight"], p["out_norm.bias"])
-        out4 = out.reshape(B, T, 4, E)
-        sf, af = out4[:, :, 2], out4[:, :, 3]  # action head reads the STATE token  cdt.py:239-240
-        c.update(sf=sf, af=af)
+        if self.prefix:
+            out = out[:, 1:]  # cdt.py:229-231
+        out4 = out.reshape(B, T, R, E)
+        sf, af = out4[:, :, R - 2], out4[:, :, R - 1]  # action head reads the STATE token  cdt.py:239-240
+        feat = sf  # cdt.py:243-250: the (detached) cost embedding joins the state feature
+        if self.add_cf:
+            feat = feat + c_e
+        if self.mul_cf:
+            feat = feat * c_e
+        if self.cat_cf:
+            feat = np.concatenate([feat, c_e], -1)
+        hidden, outs = self._head_keys()
+        hcache, h = [], feat
+        for k in hidden:
+            pre_h = h @ p[k + ".weight"].T + p[k + ".bias"]
+            hcache.append((h, pre_h))
+            h = gelu(pre_h)
+        c.update(sf=sf, af=af, head_in=h, head_hidden=hcache)
         res = {}
         if self.stochastic:
-            res["mu"] = sf @ p["action_head.mu.weight"].T + p["action_head.mu.bias"]
-            res["ls"] = sf @ p["action_head.log_std.weight"].T + p["action_head.log_std.bias"]
+            res["mu"] = h @ p[outs[0] + ".weight"].T + p[outs[0] + ".bias"]
+            res["ls"] = h @ p[outs[1] + ".weight"].T + p[outs[1] + ".bias"]
         else:
-            res["act"] = sf @ p["action_head.0.weight"].T + p["action_head.0.bias"]
+            res["act"] = h @ p[outs[0] + ".weight"].T + p[outs[0] + ".bias"]
         logits = af @ p["cost_pred_head.weight"].T + p["cost_pred_head.bias"]
         z = logits - logits.max(-1, keepdims=True)
         res["cost_logp"] = z - np.log(np.exp(z).sum(-1, keepdims=True))
         res["state_pred"] = af @ p["state_pred_head.weight"].T + p["state_pred_head.bias"]
         return res, c
 
-    def act_mean(self, states, actions, returns, costs_to_go, time_steps, mask):
+    def act_mean(self, states, actions, returns, costs_to_go, time_steps, mask, episode_cost=None):
         """Deterministic action prediction (mean) for every timestep of the window."""
         res, _ = self.forward(*(np.asarray(a, self.dtype) if a.dtype.kind == "f" else a
-                                for a in (states, actions, returns, costs_to_go, time_steps, mask)))
+                                for a in (states, actions, returns, costs_to_go, time_steps, mask)),
+                              episode_cost=episode_cost)
         return res["mu"] if self.stochastic else res["act"]
 
     # ------------------------------------------------------------------ one train step
@@ -151,8 +194,9 @@ class OracleCDT:
         p, E, H = self.p, self.E, self.H
         B, T, od = states.shape
         ad = actions.shape[-1]
-        S, d = 4 * T, E // H
-        res, c = self.forward(states, actions, returns, costs_return, time_steps, mask, drop)
+        R = self.R
+        S, d = R * T + int(self.prefix), E // H
+        res, c = self.forward(states, actions, returns, costs_return, time_steps, mask, drop, episode_cost)
         valid = mask > 0
         nv = max(int(valid.sum()), 1) * ad
         stats = {}
@@ -191,25 +235,34 @@ class OracleCDT:
         # ---- heads backward
         sf, af = c["sf"], c["af"]
         f2 = lambda a: a.reshape(-1, a.shape[-1])  # noqa: E731
-        dsf = np.zeros_like(sf)
-        if self.stochastic:
-            for nm, dd in (("mu", dmu), ("log_std", dls)):
-                g[f"action_head.{nm}.weight"] = f2(dd).T @ f2(sf)
-                g[f"action_head.{nm}.bias"] = f2(dd).sum(0)
-                dsf = dsf + dd @ p[f"action_head.{nm}.weight"]
-        else:
-            g["action_head.0.weight"] = f2(dact).T @ f2(sf)
-            g["action_head.0.bias"] = f2(dact).sum(0)
-            dsf = dact @ p["action_head.0.weight"]
+        hidden, outs = self._head_keys()
+        hin = c["head_in"]
+        dh = np.zeros_like(hin)
+        for k, dd in zip(outs, (dmu, dls) if self.stochastic else (dact,)):
+            g[k + ".weight"] = f2(dd).T @ f2(hin)
+            g[k + ".bias"] = f2(dd).sum(0)
+            dh = dh + dd @ p[k + ".weight"]
+        for k, (h_in, pre_h) in zip(reversed(hidden), reversed(c["head_hidden"])):
+            dpre = dh * gelu_grad(pre_h)
+            g[k + ".weight"] = f2(dpre).T @ f2(h_in)
+            g[k + ".bias"] = f2(dpre).sum(0)
+            dh = dpre @ p[k + ".weight"]
+        dsf = dh  # gradient wrt the head's input feature -> wrt the state token (the cost embedding is detached)
+        if self.cat_cf:
+            dsf = dsf[..., :E]
+        if self.mul_cf:
+            dsf = dsf * c["c_e"]
         g["cost_pred_head.weight"] = f2(dlogits).T @ f2(af)
         g["cost_pred_head.bias"] = f2(dlogits).sum(0)
         g["state_pred_head.weight"] = f2(dsp).T @ f2(af)
         g["state_pred_head.bias"] = f2(dsp).sum(0)
         daf = dlogits @ p["cost_pred_head.weight"] + dsp @ p["state_pred_head.weight"]
-        dout = np.zeros((B, T, 4, E), dt)
-        dout[:, :, 2], dout[:, :, 3] = dsf, daf
-        dx, g["out_norm.weight"], g["out_norm.bias"] = layer_norm_bwd(dout.reshape(B, S, E), c["ln_out"],
-                                                                      p["out_norm.weight"])
+        dout = np.zeros((B, T, R, E), dt)
+        dout[:, :, R - 2], dout[:, :, R - 1] = dsf, daf
+        dout = dout.reshape(B, R * T, E)
+        if self.prefix:
+            dout = np.concatenate([np.zeros((B, 1, E), dt), dout], 1)
+        dx, g["out_norm.weight"], g["out_norm.bias"] = layer_norm_bwd(dout, c["ln_out"], p["out_norm.weight"])
         # ---- blocks backward
         for l in range(self.NL - 1, -1, -1):
             pre, bc = f"blocks.{l}.", c["blocks"][l]
@@ -242,19 +295,31 @@ class OracleCDT:
         # ---- embeddings backward
         dseq, g["emb_norm.weight"], g["emb_norm.bias"] = layer_norm_bwd(dx * drop.get("emb", one), c["ln_emb"],
                                                                         p["emb_norm.weight"])
-        d4 = dseq.reshape(B, T, 4, E)
-        dr, dc, ds, da = d4[:, :, 0], d4[:, :, 1], d4[:, :, 2], d4[:, :, 3]
-        g["return_emb.weight"] = (f2(dr) * returns.reshape(-1, 1)).sum(0)[:, None]
-        g["return_emb.bias"] = f2(dr).sum(0)
-        g["cost_emb.weight"] = (f2(dc) * c["ctg"].reshape(-1, 1)).sum(0)[:, None]
-        g["cost_emb.bias"] = f2(dc).sum(0)
+        if self.prefix:
+            dpe, dseq = dseq[:, 0], dseq[:, 1:]
+            g["prefix_emb.weight"] = (dpe * np.asarray(episode_cost, dt)[:, None]).sum(0)[:, None]
+            g["prefix_emb.bias"] = dpe.sum(0)
+        d4 = dseq.reshape(B, T, R, E)
+        slot = 0
+        if self.use_rew:
+            dr = d4[:, :, slot]
+            slot += 1
+            g["return_emb.weight"] = (f2(dr) * returns.reshape(-1, 1)).sum(0)[:, None]
+            g["return_emb.bias"] = f2(dr).sum(0)
+        if self.use_cost:
+            dc = d4[:, :, slot]
+            slot += 1
+            g["cost_emb.weight"] = (f2(dc) * c["ctg"].reshape(-1, 1)).sum(0)[:, None]
+            g["cost_emb.bias"] = f2(dc).sum(0)
+        ds, da = d4[:, :, R - 2], d4[:, :, R - 1]
         g["state_emb.weight"] = f2(ds).T @ f2(states)
         g["state_emb.bias"] = f2(ds).sum(0)
         g["action_emb.weight"] = f2(da).T @ f2(actions)
         g["action_emb.bias"] = f2(da).sum(0)
-        dte = np.zeros_like(p["timestep_emb.weight"])
-        np.add.at(dte, time_steps.reshape(-1), f2(dr + dc + ds + da))
-        g["timestep_emb.weight"] = dte
+        if self.time_emb:
+            dte = np.zeros_like(p["timestep_emb.weight"])
+            np.add.at(dte, time_steps.reshape(-1), f2(d4.sum(2)))
+            g["timestep_emb.weight"] = dte
 
         # ---- clip_grad_norm_ (cdt.py:398-399), AdamW with warm-up LR (cdt.py:321-330)
         if self.clip is not None:

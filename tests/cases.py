@@ -232,6 +232,23 @@ class CDTCase:
     seed: int = 0
     algo: str = "cdt"
     dropout: float = 0.0  # attention / residual / embedding dropout (cdt_configs.py:28-30 default 0.1)
+    # constructor variants of cdt.py:45-70 (all non-default in the reference's configs)
+    time_emb: bool = True
+    use_rew: bool = True
+    use_cost: bool = True
+    add_cost_feat: bool = False
+    mul_cost_feat: bool = False
+    cat_cost_feat: bool = False
+    head_layers: int = 1
+    cost_prefix: bool = False
+
+    @property
+    def R(self) -> int:  # tokens per timestep (cdt.py:96-105)
+        return 2 + int(self.use_rew) + int(self.use_cost)
+
+    @property
+    def S(self) -> int:  # sequence length the transformer sees (cdt.py:107-112)
+        return self.R * self.T + int(self.cost_prefix)
 
 
 CDT_CASES: Dict[str, CDTCase] = {c.name: c for c in [
@@ -241,6 +258,17 @@ CDT_CASES: Dict[str, CDTCase] = {c.name: c for c in [
     CDTCase("cdt_drop", od=5, ad=3, B=6, T=5, E=16, heads=2, layers=2, episode_len=20, steps=4, state_w=0.1,
             dropout=0.1, seed=3),
     CDTCase("cdt_mid", od=11, ad=3, B=16, T=10, E=128, heads=8, layers=3, episode_len=1000, steps=1, warmup=500),
+    # ---- constructor variants
+    CDTCase("cdt_v_norew", od=5, ad=3, B=6, T=4, E=16, heads=2, layers=2, episode_len=20, steps=4, state_w=0.1,
+            use_rew=False, add_cost_feat=True, head_layers=2, seed=11),
+    CDTCase("cdt_v_min", od=4, ad=2, B=5, T=3, E=16, heads=4, layers=1, episode_len=12, steps=3, stochastic=False,
+            cost_transform=False, clip=1e9, warmup=1, time_emb=False, use_rew=False, use_cost=False, head_layers=3,
+            seed=12),
+    CDTCase("cdt_v_prefix", od=5, ad=3, B=6, T=5, E=16, heads=2, layers=2, episode_len=20, steps=4, state_w=0.1,
+            cost_prefix=True, mul_cost_feat=True, cat_cost_feat=True, dropout=0.1, seed=13),
+    CDTCase("cdt_v_prefix_det", od=4, ad=2, B=5, T=4, E=32, heads=4, layers=1, episode_len=12, steps=3,
+            stochastic=False, cost_prefix=True, use_rew=False, cat_cost_feat=True, add_cost_feat=True, head_layers=2,
+            seed=14),
 ]}
 
 
@@ -262,12 +290,17 @@ def make_cdt_params(c: CDTCase) -> "OrderedDict[str, np.ndarray]":
 
     ln("emb_norm")
     ln("out_norm")
-    sd["timestep_emb.weight"] = (rs.randn(c.episode_len + c.T, E) * 0.02).astype(f)
+    if c.time_emb:
+        sd["timestep_emb.weight"] = (rs.randn(c.episode_len + c.T, E) * 0.02).astype(f)
     lin("state_emb", E, c.od)
     lin("action_emb", E, c.ad)
-    lin("cost_emb", E, 1)
-    lin("return_emb", E, 1)
-    S = 4 * c.T
+    if c.use_cost:
+        lin("cost_emb", E, 1)
+    if c.use_rew:
+        lin("return_emb", E, 1)
+    if c.cost_prefix:
+        lin("prefix_emb", E, 1)
+    S = c.S
     for l in range(c.layers):
         pre = f"blocks.{l}"
         sd[pre + ".causal_mask"] = ~np.tril(np.ones((S, S))).astype(bool)
@@ -278,11 +311,19 @@ def make_cdt_params(c: CDTCase) -> "OrderedDict[str, np.ndarray]":
         lin(pre + ".attention.out_proj", E, E)
         lin(pre + ".mlp.0", 4 * E, E)
         lin(pre + ".mlp.2", E, 4 * E)
-    if c.stochastic:
-        lin("action_head.mu", c.ad, E)
-        lin("action_head.log_std", c.ad, E)
-    else:
-        lin("action_head.0", c.ad, E)
+    Eh = 2 * E if c.cat_cost_feat else E  # cdt.py:125
+    if c.stochastic:  # cdt.py:127-133
+        if c.head_layers >= 2:
+            lin("action_head.0", Eh, Eh)
+            lin("action_head.2.mu", c.ad, Eh)
+            lin("action_head.2.log_std", c.ad, Eh)
+        else:
+            lin("action_head.mu", c.ad, Eh)
+            lin("action_head.log_std", c.ad, Eh)
+    else:  # cdt.py:134-137: mlp([Eh] * head_layers + [ad], GELU, Identity)
+        for i in range(c.head_layers - 1):
+            lin(f"action_head.{2 * i}", Eh, Eh)
+        lin(f"action_head.{2 * (c.head_layers - 1)}", c.ad, Eh)
     lin("state_pred_head", c.od, E)
     lin("cost_pred_head", 2, E)
     return sd
@@ -290,7 +331,7 @@ def make_cdt_params(c: CDTCase) -> "OrderedDict[str, np.ndarray]":
 
 def cdt_drop_sites(c: CDTCase):
     """(key, shape) of every nn.Dropout draw of one CDT forward, in the reference's call order."""
-    S = 4 * c.T
+    S = c.S
     out = [("emb", (c.B, S, c.E))]
     for l in range(c.layers):
         out += [(f"attn{l}", (c.B, c.heads, S, S)), (f"res1_{l}", (c.B, S, c.E)), (f"res2_{l}", (c.B, S, c.E))]

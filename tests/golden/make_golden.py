@@ -260,15 +260,18 @@ def main_cdt():
 
     torch.set_num_threads(4)
     dq = DropQueue(torch)
-    for c in sorted(CDT_CASES.values(), key=lambda c: c.dropout):  # patch the samplers only for the dropout cases
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--cdt-cases=")]
+    todo = [c for c in CDT_CASES.values() if not only or c.name in only[0]]
+    for c in sorted(todo, key=lambda c: c.dropout):  # patch the samplers only for the dropout cases
         if c.dropout > 0 and not dq.q and getattr(dq, "_on", None) is None:
             dq.install()
             dq._on = True
         m = algos.CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=c.episode_len, embedding_dim=c.E,
                       num_layers=c.layers, num_heads=c.heads, attention_dropout=c.dropout,
-                      residual_dropout=c.dropout, embedding_dropout=c.dropout, time_emb=True, use_rew=True, use_cost=True,
-                      cost_transform=c.cost_transform, action_head_layers=1, cost_prefix=False,
-                      stochastic=c.stochastic, init_temperature=0.1, target_entropy=-c.ad)
+                      residual_dropout=c.dropout, embedding_dropout=c.dropout, time_emb=c.time_emb, use_rew=c.use_rew,
+                      use_cost=c.use_cost, cost_transform=c.cost_transform, add_cost_feat=c.add_cost_feat,
+                      mul_cost_feat=c.mul_cost_feat, cat_cost_feat=c.cat_cost_feat, action_head_layers=c.head_layers,
+                      cost_prefix=c.cost_prefix, stochastic=c.stochastic, init_temperature=0.1, target_entropy=-c.ad)
         lg = Logger()
         tr = algos.CDTTrainer(m, None, lg, learning_rate=c.lr, weight_decay=c.wd, betas=(0.9, 0.999),
                               clip_grad=c.clip, lr_warmup_steps=c.warmup, reward_scale=0.1, cost_scale=1.0,
