@@ -300,14 +300,18 @@ int osrl_bcq_actor_loss(const float* q, int32_t nq1, int32_t nq2, const float* q
                         void* stream);
 
 /* ---- CDT (cdt.hip): the non-GEMM pieces of the Constrained Decision Transformer step ---- */
-/* Token embeddings + timestep embedding, (return, cost, state, action) interleave and emb LayerNorm
- * (cdt.py:178-222).  BT = batch*seq_len; outputs: seq[4BT,E] (pre-LN), x0[4BT,E], stats[4BT,2] = (mean, rstd),
- * ctg_t[BT] = the (optionally 50 - x transformed, cdt.py:78-81) cost-to-go fed to cost_emb. */
+/* Token embeddings + timestep embedding, interleave and emb LayerNorm (cdt.py:178-222).  Tokens per timestep, in
+ * order: [return if use_rew] [cost if use_cost] state action (R = 2..4); prefix != 0: one more token leads each
+ * sequence, Linear(1,E) of episode_cost[b] (cdt.py:207-218); timestep_emb == NULL: time_emb = False.  S = R*T + prefix.
+ * Outputs: seq[B*S,E] (pre-LN), x0[B*S,E], stats[B*S,2] = (mean, rstd), ctg_t[B*T] = the (optionally 50 - x
+ * transformed, cdt.py:78-81) cost-to-go fed to cost_emb.  Pointers of absent tokens may be NULL. */
 int osrl_cdt_embed_ln(const float* states, const float* actions, const float* returns, const float* costs_to_go,
-                      const int64_t* time_steps, const float* Ws, const float* bs, const float* Wa, const float* ba,
-                      const float* Wc, const float* bc, const float* Wr, const float* br, const float* timestep_emb,
-                      const float* ln_g, const float* ln_b, int32_t BT, int32_t od, int32_t ad, int32_t E,
-                      int32_t cost_transform, float* seq, float* x0, float* stats, float* ctg_t, void* stream);
+                      const float* episode_cost, const int64_t* time_steps, const float* Ws, const float* bs,
+                      const float* Wa, const float* ba, const float* Wc, const float* bc, const float* Wr,
+                      const float* br, const float* Wp, const float* bp, const float* timestep_emb, const float* ln_g,
+                      const float* ln_b, int32_t B, int32_t T, int32_t od, int32_t ad, int32_t E,
+                      int32_t cost_transform, int32_t use_rew, int32_t use_cost, int32_t prefix, float* seq, float* x0,
+                      float* stats, float* ctg_t, void* stream);
 /* nn.LayerNorm (eps 1e-5) of x (+ delta): y = LN(x + delta); xout = x + delta if non-NULL; stats = (mean, rstd). */
 int osrl_layernorm_fwd(const float* x, const float* delta, const float* gamma, const float* beta, float* xout,
                        float* y, float* stats, int32_t M, int32_t E, void* stream);
@@ -317,11 +321,12 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
                        float* dx, float* partial_ws, int32_t n_parts, int32_t M, int32_t E, float* slab,
                        int64_t g_off, int64_t b_off, void* stream);
 /* nn.MultiheadAttention core with the block's causal mask and key padding (net.py:417-435): qkv [B,S,3E] (q|k|v,
- * heads split the E axis contiguously), mask [B, S/rep] (1 = valid timestep, each repeated rep times along S). */
+ * heads split the E axis contiguously), mask [B, (S-prefix)/rep] (1 = valid timestep, each repeated rep times along S;
+ * prefix = 1: token 0 is the cost-prefix token, masked like timestep 0, cdt.py:216-218). */
 int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S, int32_t E, int32_t H, int32_t rep,
-                       const osrl_dropout_t* drop, float* o, void* stream);
+                       int32_t prefix, const osrl_dropout_t* drop, float* o, void* stream);
 int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S, int32_t E,
-                       int32_t H, int32_t rep, const osrl_dropout_t* drop, float* dqkv, void* stream);
+                       int32_t H, int32_t rep, int32_t prefix, const osrl_dropout_t* drop, float* dqkv, void* stream);
 /* nn.Dropout in training mode (cdt.py:87,222 embedding; net.py:404,439 residual; net.py:414 MLP tail):
  * y[i] = x[i] * keep_i / (1-p), may run in place.  keep_i is a pure function of (seed, st->step, site, i)
  * (Philox4x32-10), so calling it again on the incoming gradient IS the backward pass; nothing is stored.
@@ -346,9 +351,10 @@ int osrl_cdt_loss(const float* head, const float* logits, const float* state_pre
 /* out = {#(mask > 0), sum(mask)}: the count-normalisers of cdt.py:358-359,386, to be all-reduced under data
  * parallelism and handed to osrl_cdt_loss as `counts` (with `world` = number of equal-sized ranks). */
 int osrl_cdt_mask_counts(const float* mask, int32_t BT, float* out, void* stream);
-/* d timestep_emb[time_steps[bt]] += sum of the 4 token rows of dseq (atomic scatter) */
-int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t BT, int32_t E, float* dte,
-                              void* stream);
+/* d timestep_emb[time_steps[b,t]] += sum of the R token rows of timestep (b,t) in dseq [B, R*T + prefix, E] (atomic
+ * scatter) */
+int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t B, int32_t T, int32_t R,
+                              int32_t prefix, int32_t E, float* dte, void* stream);
 /* torch.nn.utils.clip_grad_norm_ (cdt.py:398-399): out[0] = min(1, clip/(||grad||+1e-6)), out[1] = ||grad|| */
 int osrl_clip_grad_scale(const float* grad, int64_t n, float clip, float* partial_ws, int32_t n_parts, float* out,
                          void* stream);

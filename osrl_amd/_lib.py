@@ -164,17 +164,17 @@ PROTOTYPES = {
     "osrl_bcq_actor_sums": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _fp, _vp],
     "osrl_bcq_actor_loss": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _fp, _f32, _fp, _fp,
                             _fp, _fp, _vp],
-    "osrl_cdt_embed_ln": [_fp, _fp, _fp, _fp, _vp] + [_fp] * 11 + [_i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _vp],
+    "osrl_cdt_embed_ln": [_fp, _fp, _fp, _fp, _fp, _vp] + [_fp] * 13 + [_i32] * 9 + [_fp, _fp, _fp, _fp, _vp],
     "osrl_layernorm_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _vp],
     "osrl_layernorm_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],
-    "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
-    "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
+    "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
+    "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
     "osrl_dropout": [_fp, _fp, _i64, _P(DropoutT), _vp],
     "osrl_gelu_fwd": [_fp, _fp, _i64, _vp],
     "osrl_gelu_bwd": [_fp, _fp, _fp, _i64, _vp],
     "osrl_cdt_loss": [_fp] * 7 + [_i32] * 6 + [_fp, _f32, _f32, _f32, _i32, _vp, _fp, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _vp],
     "osrl_cdt_mask_counts": [_fp, _i32, _fp, _vp],
-    "osrl_cdt_timestep_scatter": [_fp, _vp, _i32, _i32, _fp, _vp],
+    "osrl_cdt_timestep_scatter": [_fp, _vp, _i32, _i32, _i32, _i32, _i32, _fp, _vp],
     "osrl_clip_grad_scale": [_fp, _i64, _f32, _fp, _i32, _fp, _vp],
     "osrl_cdt_temperature_step": [_fp, _fp, _fp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
 }

@@ -3,8 +3,9 @@
 ``CDT`` keeps the constructor and ``state_dict`` layout of cdt.py:45-164 (the same torch container modules
 are created in the same order, so a seeded construction reproduces the reference's initial weights);
 ``CDTTrainer.train_one_step`` keeps the signature of cdt.py:343.  Supported configuration = the reference's
-training defaults (time/return/cost embeddings, optional cost transform, 1-layer stochastic or
-deterministic head, dropout); the deprecated cost-feature / cost-prefix variants raise.
+every constructor variant of cdt.py:45-141: any subset of the return / cost tokens, with or without the timestep
+embedding, the cost-prefix token, the add / mul / cat cost features on the state feature, deeper action heads,
+stochastic or deterministic, dropout.  Limits: <= 128 tokens per sequence, embedding_dim <= 256.
 """
 from __future__ import annotations
 
@@ -35,20 +36,18 @@ class CDT(nn.Module):
         unsupported = []
         if not all(0.0 <= p < 1.0 for p in (attention_dropout, residual_dropout, embedding_dropout)):
             raise ValueError("dropout probabilities must be in [0, 1)")
-        if not (time_emb and use_rew and use_cost):
-            unsupported.append("time_emb/use_rew/use_cost = False")
-        if add_cost_feat or mul_cost_feat or cat_cost_feat or cost_prefix:
-            unsupported.append("cost feature / cost prefix variants")
-        if action_head_layers != 1:
-            unsupported.append("action_head_layers != 1")
-        if embedding_dim % num_heads or embedding_dim > 512 or 4 * embedding_dim > 1024 or 4 * seq_len > 128:
-            unsupported.append("embedding_dim > 256 or 4*seq_len > 128")
-        else:  # the attention backward keeps Q, K, V, dO and two score tiles of one (batch, head) in LDS (160 KB)
+        if action_head_layers < 1:
+            raise ValueError("action_head_layers must be >= 1")
+        seq_repeat = 2 + int(bool(use_cost)) + int(bool(use_rew))  # cdt.py:96-105
+        S = seq_repeat * seq_len + int(bool(cost_prefix))           # cdt.py:107-112
+        if embedding_dim % num_heads or embedding_dim > 512 or 4 * embedding_dim > 1024 or S > 128:
+            unsupported.append("embedding_dim > 256 or more than 128 tokens per sequence")
+        else:  # the attention backward keeps two [S, head_dim] tiles, row statistics and the keep flags in LDS
             r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
-            sp, dp = r16(4 * seq_len), r16(embedding_dim // num_heads)
-            if 4 * (4 * sp * (dp + 8) + 2 * sp * (sp + 8) + sp) > 160 * 1024:
-                unsupported.append(f"4*seq_len = {4 * seq_len} tokens with head_dim {embedding_dim // num_heads} "
-                                   "(attention backward tile > 160 KB LDS)")
+            sp, dp = r16(S), r16(embedding_dim // num_heads)
+            if 4 * (2 * sp * (dp + 8) + 4 * sp) + sp * sp > 160 * 1024:
+                unsupported.append(f"{S} tokens with head_dim {embedding_dim // num_heads} "
+                                   "(attention backward tiles > 160 KB LDS)")
         if unsupported:
             raise NotImplementedError("osrl_amd CDT does not support: " + "; ".join(unsupported))
         self.seq_len, self.embedding_dim = seq_len, embedding_dim
@@ -57,12 +56,17 @@ class CDT(nn.Module):
         self.num_layers, self.num_heads = num_layers, num_heads
         self.cost_transform_on = bool(cost_transform)
         self.cost_transform = (lambda x: 50 - x) if cost_transform else None
-        self.add_cost_feat = self.mul_cost_feat = self.cat_cost_feat = False
+        # cdt.py:243-250: every cost-feature op also requires use_cost
+        self.add_cost_feat = bool(add_cost_feat and use_cost)
+        self.mul_cost_feat = bool(mul_cost_feat and use_cost)
+        self.cat_cost_feat = bool(cat_cost_feat and use_cost)
         self.stochastic = stochastic
         self.attention_dropout, self.residual_dropout = float(attention_dropout), float(residual_dropout)
         self.embedding_dropout = float(embedding_dropout)
-        self.time_emb, self.use_rew, self.use_cost, self.cost_prefix = True, True, True, False
-        self.seq_repeat = 4
+        self.time_emb, self.use_rew, self.use_cost = bool(time_emb), bool(use_rew), bool(use_cost)
+        self.cost_prefix = bool(cost_prefix)
+        self.seq_repeat = seq_repeat
+        self.action_head_layers = int(action_head_layers)
         self.device = str(device)
         dev = require_cuda(device)
 
@@ -70,17 +74,35 @@ class CDT(nn.Module):
         self.emb_drop = nn.Dropout(embedding_dropout)
         self.emb_norm = nn.LayerNorm(embedding_dim)
         self.out_norm = nn.LayerNorm(embedding_dim)
-        self.timestep_emb = nn.Embedding(episode_len + seq_len, embedding_dim)
+        if self.time_emb:
+            self.timestep_emb = nn.Embedding(episode_len + seq_len, embedding_dim)
         self.state_emb = nn.Linear(state_dim, embedding_dim)
         self.action_emb = nn.Linear(action_dim, embedding_dim)
-        self.cost_emb = nn.Linear(1, embedding_dim)
-        self.return_emb = nn.Linear(1, embedding_dim)
-        self.blocks = nn.ModuleList([TransformerBlock(4 * seq_len, embedding_dim, num_heads, attention_dropout,
+        if self.use_cost:
+            self.cost_emb = nn.Linear(1, embedding_dim)
+        if self.use_rew:
+            self.return_emb = nn.Linear(1, embedding_dim)
+        if self.cost_prefix:
+            self.prefix_emb = nn.Linear(1, embedding_dim)
+        self.blocks = nn.ModuleList([TransformerBlock(S, embedding_dim, num_heads, attention_dropout,
                                                       residual_dropout) for _ in range(num_layers)])
-        if stochastic:
-            self.action_head = DiagGaussianActor(embedding_dim, action_dim)
-        else:
-            self.action_head = mlp([embedding_dim, action_dim], activation=nn.GELU, output_activation=nn.Identity)
+        # cdt.py:125 tests the RAW constructor flag: the head is 2E wide whenever cat_cost_feat was asked for
+        Eh = self.head_in_dim = 2 * embedding_dim if cat_cost_feat else embedding_dim
+        if cat_cost_feat and not use_cost:
+            raise NotImplementedError("cat_cost_feat without use_cost builds a 2E-wide head the reference's forward "
+                                      "feeds E-wide features (cdt.py:125,247-250): it cannot run there either")
+        if stochastic:  # cdt.py:127-133
+            if action_head_layers >= 2:
+                self.action_head = nn.Sequential(nn.Linear(Eh, Eh), nn.GELU(), DiagGaussianActor(Eh, action_dim))
+                self.head_hidden_keys, self.head_out_key = ["cdt.action_head.0.weight"], "cdt.action_head.2.head.weight"
+            else:
+                self.action_head = DiagGaussianActor(Eh, action_dim)
+                self.head_hidden_keys, self.head_out_key = [], "cdt.action_head.head.weight"
+        else:  # cdt.py:134-137
+            self.action_head = mlp([Eh] * action_head_layers + [action_dim], activation=nn.GELU,
+                                   output_activation=nn.Identity)
+            self.head_hidden_keys = [f"cdt.action_head.{2 * i}.weight" for i in range(action_head_layers - 1)]
+            self.head_out_key = f"cdt.action_head.{2 * (action_head_layers - 1)}.weight"
         self.state_pred_head = nn.Linear(embedding_dim, state_dim)
         self.cost_pred_head = nn.Linear(embedding_dim, 2)
         self.apply(self._init_weights)
@@ -162,7 +184,11 @@ class CDT(nn.Module):
                 return out
             states, actions, returns_to_go, costs_to_go = pad(states), pad(actions), pad(returns_to_go), pad(costs_to_go)
             time_steps, mask = pad(time_steps), pad(mask)
-        e.load_batch(states, actions, returns_to_go, costs_to_go, time_steps, mask, torch.zeros_like(mask))
+        if self.cost_prefix and episode_cost is None:
+            raise ValueError("cost_prefix=True: pass episode_cost [B] (cdt.py:207-213)")
+        e.load_batch(states, actions, returns_to_go, costs_to_go, time_steps, mask, torch.zeros_like(mask),
+                     torch.as_tensor(episode_cost, dtype=torch.float32, device=states.device).reshape(B)
+                     if self.cost_prefix else None)
         self.repack()
         if self.training and max(self.attention_dropout, self.residual_dropout, self.embedding_dropout) > 0:
             e.st.tick()  # a model left in train() mode draws a fresh dropout mask per call, like nn.Dropout
@@ -199,9 +225,10 @@ class CDTTrainer:
                         loss_state_weight=loss_state_weight, no_entropy=no_entropy, seed=int(seed))
 
     def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs):
-        """cdt.py:343-418 (episode_cost only feeds the unsupported cost-prefix variant)."""
+        """cdt.py:343-418 (``episode_cost`` only feeds the cost-prefix variant)."""
         eng = self.model.engine(states.shape[0], self.cfg)
-        eng.step(states, actions, returns, costs_return, time_steps, mask, costs, use_graph=self.use_graph)
+        eng.step(states, actions, returns, costs_return, time_steps, mask, costs, use_graph=self.use_graph,
+                 episode_cost=episode_cost if self.model.cost_prefix else None)
         keys = None if self.stochastic else ["all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
         store_stats(self.logger, eng.st, self.stats_mode, tab="train", keys=keys)
 

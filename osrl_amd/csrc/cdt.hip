@@ -84,30 +84,44 @@ __device__ __forceinline__ void ln_row(const float (&v)[kMaxEPL], int E, int lan
 }
 
 struct EmbedArgs {
-  const float *states, *actions, *returns, *ctg;
+  const float *states, *actions, *returns, *ctg, *episode_cost;
   const int64_t* time_steps;
-  const float *Ws, *bs, *Wa, *ba, *Wc, *bc, *Wr, *br, *te, *g, *b;
+  const float *Ws, *bs, *Wa, *ba, *Wc, *bc, *Wr, *br, *Wp, *bp, *te, *g, *b;
   float *seq, *x0, *stats, *ctg_t;
-  int32_t BT, od, ad, E, cost_transform;
+  int32_t B, T, od, ad, E, cost_transform;
+  int32_t R, prefix, use_rew, use_cost;  // tokens per timestep (2..4), prefix token in front, which tokens exist
 };
 
-// one wave per token; token order per timestep (return, cost, state, action)  cdt.py:185-200
+// one wave per token.  Token order per timestep: [return] [cost] state action (cdt.py:185-200: costs are inserted in
+// front of the state token, returns in front of those); with a cost prefix one more token leads each sequence
+// (cdt.py:207-218: Linear(1, E) of the episode's cost budget, no timestep embedding).  te == NULL: time_emb = False.
 __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.BT * 4) return;
-  const int bt = row >> 2, which = row & 3;
-  const float* __restrict__ te = a.te + (size_t)a.time_steps[bt] * a.E;
+  const int S_ = a.R * a.T + a.prefix;
+  if (row >= a.B * S_) return;
+  const int b = row / S_, pos = row - b * S_;
+  const bool is_prefix = a.prefix && pos == 0;
+  const int tp = pos - a.prefix;
+  const int t = is_prefix ? 0 : tp / a.R, slot = is_prefix ? 0 : tp - t * a.R;
+  const int bt = b * a.T + t;
+  // slot -> token kind (0 return, 1 cost, 2 state, 3 action)
+  int which = slot + (4 - a.R);
+  if (a.R == 3 && a.use_rew) which = slot == 0 ? 0 : slot + 1;
+  const float* __restrict__ te = (a.te && !is_prefix) ? a.te + (size_t)a.time_steps[bt] * a.E : nullptr;
   float v[kMaxEPL];
-  const float ret = a.returns[bt];
-  const float ctg = a.cost_transform ? 50.0f - a.ctg[bt] : a.ctg[bt];  // cdt.py:78-81,187-188
-  if (which == 1 && lane == 0) a.ctg_t[bt] = ctg;
+  const float ret = a.use_rew ? a.returns[bt] : 0.f;
+  const float ctg = a.use_cost ? (a.cost_transform ? 50.0f - a.ctg[bt] : a.ctg[bt]) : 0.f;  // cdt.py:78-81,187-188
+  if (!is_prefix && which == 1 && lane == 0) a.ctg_t[bt] = ctg;
+  const float ec = is_prefix ? a.episode_cost[b] : 0.f;
 #pragma unroll
   for (int j = 0; j < kMaxEPL; ++j) {
     const int f = lane + 64 * j;
     float x = 0.f;
     if (f < a.E) {
-      if (which == 0) {
+      if (is_prefix) {
+        x = ec * a.Wp[f] + a.bp[f];
+      } else if (which == 0) {
         x = ret * a.Wr[f] + a.br[f];
       } else if (which == 1) {
         x = ctg * a.Wc[f] + a.bc[f];
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedArgs a) {
         x = a.ba[f];
         for (int i = 0; i < a.ad; ++i) x += a.actions[(size_t)bt * a.ad + i] * a.Wa[(size_t)f * a.ad + i];
       }
-      x += te[f];
+      if (te) x += te[f];
       a.seq[(size_t)row * a.E + f] = x;
     }
     v[j] = x;
@@ -255,6 +269,7 @@ struct AttnArgs {
   const float* dout;  // bwd in  [B, S, E]
   float* dqkv;        // bwd out [B, S, 3E]
   int32_t B, S, E, H, rep;
+  int32_t prefix;  // 1: token 0 of every sequence is the cost-prefix token (masked like timestep 0, cdt.py:216-218)
   // attention-probability dropout (net.py:406-409): drop_scale = 1/(1-p), 0 thresh = off
   uint32_t drop_thresh, drop_site, k0, k1;
   float drop_scale;
@@ -415,8 +430,11 @@ __device__ __forceinline__ void attn_probs_mfma(const AttnArgs& a, int b, int d,
 }
 
 __device__ __forceinline__ void attn_key_valid(const AttnArgs& a, int b, int Sp, float* kvalid) {
-  for (int j = threadIdx.x; j < Sp; j += blockDim.x)
-    kvalid[j] = (j < a.S && a.mask[(size_t)b * (a.S / a.rep) + j / a.rep] > 0.f) ? 1.f : 0.f;
+  const int T = (a.S - a.prefix) / a.rep;
+  for (int j = threadIdx.x; j < Sp; j += blockDim.x) {
+    const int t = j < a.prefix ? 0 : (j - a.prefix) / a.rep;
+    kvalid[j] = (j < a.S && a.mask[(size_t)b * T + t] > 0.f) ? 1.f : 0.f;
+  }
 }
 
 // one [16, 4-column] fragment of a row-major global matrix in frag_row layout: X[row0 + (lane & 15)][k0 + 4*(lane>>4) ..+3],
@@ -967,12 +985,20 @@ __global__ __launch_bounds__(1024) void mask_counts_kernel(const float* __restri
 
 // d timestep_emb[time[b,t]] += sum of the 4 token gradients of (b,t)   (scatter, fp32 atomics)
 __global__ void te_scatter_kernel(const float* __restrict__ dseq, const int64_t* __restrict__ time_steps, int BT, int E,
-                                  float* __restrict__ dte) {
+                                  int T, int R, int prefix, float* __restrict__ dte) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)BT * E) return;
   const int bt = (int)(i / E), f = (int)(i - (int64_t)bt * E);
-  const float* __restrict__ p = dseq + (size_t)bt * 4 * E + f;
-  atomicAdd(&dte[(size_t)time_steps[bt] * E + f], (p[0] + p[E]) + (p[2 * E] + p[3 * E]));
+  const int b = bt / T, t = bt - b * T;
+  const float* __restrict__ p = dseq + ((size_t)b * (R * T + prefix) + prefix + (size_t)t * R) * E + f;
+  float v;
+  if (R == 4) {
+    v = (p[0] + p[E]) + (p[2 * E] + p[3 * E]);
+  } else {
+    v = p[0] + p[E];
+    if (R == 3) v += p[2 * E];
+  }
+  atomicAdd(&dte[(size_t)time_steps[bt] * E + f], v);
 }
 
 // clip_grad_norm_: scale = min(1, clip / (||g||_2 + 1e-6))   two-stage deterministic reduction
@@ -1019,17 +1045,24 @@ __global__ void temperature_step_kernel(float* logT, float* mv, const float* ent
 extern "C" {
 
 int osrl_cdt_embed_ln(const float* states, const float* actions, const float* returns, const float* costs_to_go,
-                      const int64_t* time_steps, const float* Ws, const float* bs, const float* Wa, const float* ba,
-                      const float* Wc, const float* bc, const float* Wr, const float* br, const float* timestep_emb,
-                      const float* ln_g, const float* ln_b, int32_t BT, int32_t od, int32_t ad, int32_t E,
-                      int32_t cost_transform, float* seq, float* x0, float* stats, float* ctg_t, void* stream) {
-  if (!states || !actions || !returns || !costs_to_go || !time_steps || !seq || !x0 || !stats || !ctg_t || BT < 1 ||
-      E < 1 || E > 64 * kMaxEPL)
+                      const float* episode_cost, const int64_t* time_steps, const float* Ws, const float* bs,
+                      const float* Wa, const float* ba, const float* Wc, const float* bc, const float* Wr,
+                      const float* br, const float* Wp, const float* bp, const float* timestep_emb, const float* ln_g,
+                      const float* ln_b, int32_t B, int32_t T, int32_t od, int32_t ad, int32_t E,
+                      int32_t cost_transform, int32_t use_rew, int32_t use_cost, int32_t prefix, float* seq, float* x0,
+                      float* stats, float* ctg_t, void* stream) {
+  if (!states || !actions || !time_steps || !seq || !x0 || !stats || B < 1 || T < 1 || E < 1 || E > 64 * kMaxEPL)
     return -1;
-  EmbedArgs a{states, actions, returns, costs_to_go, time_steps, Ws, bs, Wa, ba, Wc, bc, Wr, br, timestep_emb,
-              ln_g, ln_b, seq, x0, stats, ctg_t, BT, od, ad, E, cost_transform};
+  if ((use_rew && (!returns || !Wr || !br)) || (use_cost && (!costs_to_go || !Wc || !bc || !ctg_t)) ||
+      (prefix && (!episode_cost || !Wp || !bp)))
+    return -1;
+  const int R = 2 + (use_rew ? 1 : 0) + (use_cost ? 1 : 0);
+  EmbedArgs a{states, actions, returns, costs_to_go, episode_cost, time_steps, Ws, bs, Wa, ba, Wc, bc, Wr, br, Wp, bp,
+              timestep_emb, ln_g, ln_b, seq, x0, stats, ctg_t, B, T, od, ad, E, cost_transform, R, prefix ? 1 : 0,
+              use_rew ? 1 : 0, use_cost ? 1 : 0};
+  const int rows = B * (R * T + (prefix ? 1 : 0));
   CLEAR();
-  hipLaunchKernelGGL(embed_ln_kernel, dim3(BT), dim3(256), 0, S, a);
+  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, S, a);
   DONE();
 }
 
@@ -1089,9 +1122,12 @@ int osrl_dropout(const float* x, float* y, int64_t n, const osrl_dropout_t* dr, 
 }
 
 int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S_, int32_t E, int32_t H, int32_t rep,
-                       const osrl_dropout_t* drop, float* o, void* stream) {
-  if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || S_ % rep) return -1;
-  AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep};
+                       int32_t prefix, const osrl_dropout_t* drop, float* o, void* stream) {
+  prefix = prefix ? 1 : 0;
+  if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || rep < 1 || (S_ - prefix) % rep ||
+      S_ - prefix < rep)
+    return -1;
+  AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep, prefix};
   if (!attn_drop_args(drop, &a)) return -1;
   const size_t lds = attn_lds(S_, E / H, false);
   if (lds > kMaxLds) return -1;
@@ -1104,12 +1140,19 @@ int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S
 }
 
 int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S_, int32_t E,
-                       int32_t H, int32_t rep, const osrl_dropout_t* drop, float* dqkv, void* stream) {
-  if (!qkv || !mask || !dout || !dqkv || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || S_ % rep) return -1;
-  AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep};
+                       int32_t H, int32_t rep, int32_t prefix, const osrl_dropout_t* drop, float* dqkv, void* stream) {
+  prefix = prefix ? 1 : 0;
+  if (!qkv || !mask || !dout || !dqkv || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || rep < 1 ||
+      (S_ - prefix) % rep || S_ - prefix < rep)
+    return -1;
+  AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep, prefix};
   if (!attn_drop_args(drop, &a)) return -1;
   const size_t lds = attn_lds(S_, E / H, true);
-  if (lds > 64 * 1024) return -1;
+  if (lds > kMaxLds) return -1;
+  if (lds > 64 * 1024) {  // opt in to a large dynamic allocation (S = 128 with head_dim 64)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   CLEAR();
   if (S_ <= 80)
     hipLaunchKernelGGL(attn_bwd_kernel<5>, dim3(B * H), dim3(256), lds, S, a);
@@ -1166,13 +1209,13 @@ int osrl_cdt_mask_counts(const float* mask, int32_t BT, float* out, void* stream
   DONE();
 }
 
-int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t BT, int32_t E, float* dte,
-                              void* stream) {
-  if (!dseq || !time_steps || !dte || BT < 1 || E < 1) return -1;
-  const int64_t n = (int64_t)BT * E;
+int osrl_cdt_timestep_scatter(const float* dseq, const int64_t* time_steps, int32_t B, int32_t T, int32_t R,
+                              int32_t prefix, int32_t E, float* dte, void* stream) {
+  if (!dseq || !time_steps || !dte || B < 1 || T < 1 || E < 1 || R < 2 || R > 4) return -1;
+  const int64_t n = (int64_t)B * T * E;
   CLEAR();
-  hipLaunchKernelGGL(te_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S, dseq, time_steps, BT, E,
-                     dte);
+  hipLaunchKernelGGL(te_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S, dseq, time_steps, B * T, E,
+                     T, R, prefix ? 1 : 0, dte);
   DONE();
 }
 

@@ -37,10 +37,17 @@ class CDTEngine:
         od, ad = m.state_dim, m.action_dim
         dev = torch.device(m.device)
         self.dev = dev
-        self.S = 4 * T
+        # token layout (cdt.py:96-112,185-218): R tokens per timestep = [return] [cost] state action, optional prefix token
+        R = self.R = m.seq_repeat
+        P = self.P = 1 if m.cost_prefix else 0
+        self.slot_rew = 0 if m.use_rew else None
+        self.slot_cost = (1 if m.use_rew else 0) if m.use_cost else None
+        self.S = R * T + P
         self.M = B * self.S
         self.BT = B * T
         M, BT = self.M, self.BT
+        self.feat_ops = bool(m.add_cost_feat or m.mul_cost_feat or m.cat_cost_feat)
+        Eh = self.Eh = m.head_in_dim  # 2E with cat_cost_feat (cdt.py:125)
         f = dict(dtype=torch.float32, device=dev)
         z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
         self.st = StepState(dev, STAT_KEYS, betas=tuple(trainer_cfg["betas"]), warmup=trainer_cfg["lr_warmup_steps"])
@@ -78,6 +85,24 @@ class CDTEngine:
         self.do = z(M, E)
         self.dqkv = [z(M, 3 * E) for _ in range(NL)]
         self.dseq = z(M, E)
+        # cost prefix: the heads and the embedding dW read the sequence WITHOUT the leading token as [B*T, R*E] rows;
+        # with the prefix the per-sample stride is not T*R*E any more, so compact copies carry that view
+        self.outc = z(B * T * R, E) if P else self.out
+        self.doutc = z(B * T * R, E) if P else self.dout
+        self.dseqc = z(B * T * R, E) if P else self.dseq
+        self.sf3 = torch.as_strided(self.outc, (B, T, E), (T * R * E, R * E, 1), (R - 2) * E)    # state-token features
+        self.dsf3 = torch.as_strided(self.doutc, (B, T, E), (T * R * E, R * E, 1), (R - 2) * E)
+        if self.feat_ops:  # cdt.py:243-250: the detached cost embedding (pre-LayerNorm, with its time embedding)
+            self.ce3 = torch.as_strided(self.seq, (B, T, E), (self.S * E, R * E, 1), (P + self.slot_cost) * E)
+            self.feat, self.dfeat = z(BT, Eh), z(BT, Eh)
+        # action head (cdt.py:127-137): hidden Linear + GELU layers in front of the output layer
+        self.head_hidden: List[str] = list(m.head_hidden_keys)
+        self.head_out: str = m.head_out_key
+        nhid = len(self.head_hidden)
+        self.hh_pre = [z(BT, Eh) for _ in range(nhid)]
+        self.hh = [z(BT, Eh) for _ in range(nhid)]
+        self.dhh = [z(BT, Eh) for _ in range(nhid)]
+        self.dhh_pre = [z(BT, Eh) for _ in range(nhid)]
         # dropout: probabilities, generator seed; gradients of the dropped branches need their own buffers
         # (the undropped gradient keeps flowing along the residual path)
         self.p_emb, self.p_attn, self.p_res = m.embedding_dropout, m.attention_dropout, m.residual_dropout
@@ -102,24 +127,43 @@ class CDTEngine:
                     (self.datt[l], self.o[l], p + "attention.out_proj.weight", p + "attention.out_proj.bias"),
                     (self.dhpre[l], self.n2[l], p + "mlp.0.weight", p + "mlp.0.bias"),
                     (self.dmo[l], self.h[l], p + "mlp.2.weight", p + "mlp.2.bias")]
-        sf_ptr, af_ptr = self.out.data_ptr() + 4 * 2 * E, self.out.data_ptr() + 4 * 3 * E
-        hk = "cdt.action_head.head" if m.stochastic else "cdt.action_head.0"
-        ds = self.dseq.data_ptr()
-        bt += [(self.dhead.data_ptr(), sf_ptr, hk + ".weight", hk + ".bias", 0, 4 * E),
-               (self.dlogits.data_ptr(), af_ptr, "cdt.cost_pred_head.weight", "cdt.cost_pred_head.bias", 0, 4 * E),
-               (self.dsp.data_ptr(), af_ptr, "cdt.state_pred_head.weight", "cdt.state_pred_head.bias", 0, 4 * E),
-               (ds + 4 * 0 * E, self.returns.data_ptr(), "cdt.return_emb.weight", "cdt.return_emb.bias", 4 * E, 0),
-               (ds + 4 * 1 * E, self.ctg_t.data_ptr(), "cdt.cost_emb.weight", "cdt.cost_emb.bias", 4 * E, 0),
-               (ds + 4 * 2 * E, self.states.data_ptr(), "cdt.state_emb.weight", "cdt.state_emb.bias", 4 * E, 0),
-               (ds + 4 * 3 * E, self.actions.data_ptr(), "cdt.action_emb.weight", "cdt.action_emb.bias", 4 * E, 0)]
+        sf_ptr, af_ptr = self.outc.data_ptr() + 4 * (R - 2) * E, self.outc.data_ptr() + 4 * (R - 1) * E
+        ds = self.dseqc.data_ptr()
+        wb = lambda wkey: (wkey, wkey[:-len("weight")] + "bias")  # noqa: E731
+        chain = self.head_hidden + [self.head_out]
+        for li, key in enumerate(chain):  # (dz, a, weight, bias, ldz, lda): 0 = dense
+            dz = self.dhead if li == len(chain) - 1 else self.dhh_pre[li]
+            if li > 0:
+                a_ptr, lda = self.hh[li - 1].data_ptr(), 0
+            elif self.feat_ops:
+                a_ptr, lda = self.feat.data_ptr(), 0
+            else:
+                a_ptr, lda = sf_ptr, R * E
+            bt.append((dz.data_ptr(), a_ptr) + wb(key) + (0, lda))
+        bt += [(self.dlogits.data_ptr(), af_ptr, "cdt.cost_pred_head.weight", "cdt.cost_pred_head.bias", 0, R * E),
+               (self.dsp.data_ptr(), af_ptr, "cdt.state_pred_head.weight", "cdt.state_pred_head.bias", 0, R * E),
+               (ds + 4 * (R - 2) * E, self.states.data_ptr(), "cdt.state_emb.weight", "cdt.state_emb.bias", R * E, 0),
+               (ds + 4 * (R - 1) * E, self.actions.data_ptr(), "cdt.action_emb.weight", "cdt.action_emb.bias", R * E, 0)]
+        if m.use_rew:
+            bt.append((ds + 4 * self.slot_rew * E, self.returns.data_ptr(), "cdt.return_emb.weight",
+                       "cdt.return_emb.bias", R * E, 0))
+        if m.use_cost:
+            bt.append((ds + 4 * self.slot_cost * E, self.ctg_t.data_ptr(), "cdt.cost_emb.weight", "cdt.cost_emb.bias",
+                       R * E, 0))
+        self._keep_bt = [self.dhead, self.dhh_pre, self.hh, self.dlogits, self.dsp, self.dseqc, self.outc]
         # an inference engine (CDT.forward, CDTBatchedRollout) never launches dW: no plans, no gradient slabs
         self.inference = bool(inference)
+        self.episode_cost = z(B)
+        self.p_pre = None
         if not self.inference:
             self.p_tok = DwPlan(g, tok, M, dev)
             self.p_bt = DwPlan(g, bt, BT, dev)
             self.n_splits = max(self.p_tok.n_splits, self.p_bt.n_splits)
+            if P:  # the prefix token's Linear(1, E): one row per sample (row 0 of each sequence in dseq)
+                self.p_pre = DwPlan(g, [(self.dseq.data_ptr(), self.episode_cost.data_ptr(), "cdt.prefix_emb.weight",
+                                         "cdt.prefix_emb.bias", self.S * E, 0)], B, dev)
+                self.n_splits = max(self.n_splits, self.p_pre.n_splits)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.episode_cost = z(B)
         self.store = None
         m.repack()
 
@@ -203,14 +247,18 @@ class CDTEngine:
         m, lib, E, M, BT = self.model, L.load(), self.E, self.M, self.BT
         v = self._v
         p_emb, p_attn, p_res = (self.p_emb, self.p_attn, self.p_res) if train else (0.0, 0.0, 0.0)
-        L.check(lib.osrl_cdt_embed_ln(self.states.data_ptr(), self.actions.data_ptr(), self.returns.data_ptr(),
-                                      self.ctg.data_ptr(), self.time_steps.data_ptr(), v("cdt.state_emb.weight"),
-                                      v("cdt.state_emb.bias"), v("cdt.action_emb.weight"), v("cdt.action_emb.bias"),
-                                      v("cdt.cost_emb.weight"), v("cdt.cost_emb.bias"), v("cdt.return_emb.weight"),
-                                      v("cdt.return_emb.bias"), v("cdt.timestep_emb.weight"), v("cdt.emb_norm.weight"),
-                                      v("cdt.emb_norm.bias"), BT, m.state_dim, m.action_dim, E,
-                                      1 if m.cost_transform_on else 0, self.seq.data_ptr(), self.x0.data_ptr(),
-                                      self.st_emb.data_ptr(), self.ctg_t.data_ptr(), cur_stream()), "osrl_cdt_embed_ln")
+        opt = lambda key, on: v(key) if on else None  # noqa: E731
+        L.check(lib.osrl_cdt_embed_ln(
+            self.states.data_ptr(), self.actions.data_ptr(), self.returns.data_ptr(), self.ctg.data_ptr(),
+            self.episode_cost.data_ptr(), self.time_steps.data_ptr(), v("cdt.state_emb.weight"),
+            v("cdt.state_emb.bias"), v("cdt.action_emb.weight"), v("cdt.action_emb.bias"),
+            opt("cdt.cost_emb.weight", m.use_cost), opt("cdt.cost_emb.bias", m.use_cost),
+            opt("cdt.return_emb.weight", m.use_rew), opt("cdt.return_emb.bias", m.use_rew),
+            opt("cdt.prefix_emb.weight", self.P), opt("cdt.prefix_emb.bias", self.P),
+            opt("cdt.timestep_emb.weight", m.time_emb), v("cdt.emb_norm.weight"), v("cdt.emb_norm.bias"), self.B, self.T,
+            m.state_dim, m.action_dim, E, 1 if m.cost_transform_on else 0, 1 if m.use_rew else 0,
+            1 if m.use_cost else 0, self.P, self.seq.data_ptr(), self.x0.data_ptr(), self.st_emb.data_ptr(),
+            self.ctg_t.data_ptr(), cur_stream()), "osrl_cdt_embed_ln")
         if p_emb > 0:
             self._drop(self.x0, self.x0, 0, p_emb)
         for l in range(self.NL):
@@ -219,8 +267,8 @@ class CDTEngine:
                 self._ln_fwd(self.xin[0], None, p + "norm1", None, self.n1[0], self.st1[0])
             self._lin(self.n1[l], E, M, p + "attention.in_proj_weight", self.qkv[l], 3 * E)
             da = self._site(1 + 3 * l, p_attn)
-            L.check(lib.osrl_attention_fwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.B, self.S, E, self.H, 4,
-                                           ctypes.byref(da) if p_attn > 0 else None, self.o[l].data_ptr(),
+            L.check(lib.osrl_attention_fwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.B, self.S, E, self.H,
+                                           self.R, self.P, ctypes.byref(da) if p_attn > 0 else None, self.o[l].data_ptr(),
                                            cur_stream()), "osrl_attention_fwd")
             self._lin(self.o[l], E, M, p + "attention.out_proj.weight", self.att, E)
             if p_res > 0:
@@ -236,11 +284,31 @@ class CDTEngine:
                              self.st1[l + 1])
             else:
                 self._ln_fwd(self.xmid[l], self.mo, "cdt.out_norm", self.xin[l + 1], self.out, self.st_out)
-        sf, af = self.out.data_ptr() + 4 * 2 * E, self.out.data_ptr() + 4 * 3 * E
-        hk = "cdt.action_head.head.weight" if m.stochastic else "cdt.action_head.0.weight"
-        self._lin(sf, 4 * E, BT, hk, self.head, self.head.shape[1])
-        self._lin(af, 4 * E, BT, "cdt.cost_pred_head.weight", self.logits, 2)
-        self._lin(af, 4 * E, BT, "cdt.state_pred_head.weight", self.sp, m.state_dim)
+        R, B, T, Eh = self.R, self.B, self.T, self.Eh
+        if self.P:  # out[:, 1:] (cdt.py:229-231) as a dense [B*T*R, E] matrix
+            self.outc.view(B, R * T, E).copy_(self.out.view(B, self.S, E)[:, 1:])
+        sf, af = self.outc.data_ptr() + 4 * (R - 2) * E, self.outc.data_ptr() + 4 * (R - 1) * E
+        hin, ldh = sf, R * E
+        if self.feat_ops:  # state feature (+ / * / cat) detached cost embedding, cdt.py:243-250
+            f3 = self.feat.view(B, T, Eh)[..., :E]
+            if m.add_cost_feat:
+                torch.add(self.sf3, self.ce3, out=f3)
+                if m.mul_cost_feat:
+                    f3.mul_(self.ce3)
+            elif m.mul_cost_feat:
+                torch.mul(self.sf3, self.ce3, out=f3)
+            else:
+                f3.copy_(self.sf3)
+            if m.cat_cost_feat:
+                self.feat.view(B, T, Eh)[..., E:].copy_(self.ce3)
+            hin, ldh = self.feat, Eh
+        for i, key in enumerate(self.head_hidden):
+            self._lin(hin, ldh, BT, key, self.hh_pre[i], Eh)
+            L.check(lib.osrl_gelu_fwd(self.hh_pre[i].data_ptr(), self.hh[i].data_ptr(), BT * Eh, cur_stream()), "gelu")
+            hin, ldh = self.hh[i], Eh
+        self._lin(hin, ldh, BT, self.head_out, self.head, self.head.shape[1])
+        self._lin(af, R * E, BT, "cdt.cost_pred_head.weight", self.logits, 2)
+        self._lin(af, R * E, BT, "cdt.state_pred_head.weight", self.sp, m.state_dim)
 
     # ---- one full train step -------------------------------------------------------------------
     def body(self) -> None:
@@ -272,12 +340,32 @@ class CDTEngine:
                                   st.stats.data_ptr(), self.ent.data_ptr(), self.loss_ws.data_ptr() if big else None,
                                   cur_stream()), "osrl_cdt_loss")
         # ---- backward: heads -> dout (only the state / action token rows are non-zero)
+        R, B, T, Eh = self.R, self.B, self.T, self.Eh
         self.dout.zero_()
-        hk = "cdt.action_head.head.weight" if m.stochastic else "cdt.action_head.0.weight"
-        d_sf, d_af = self.dout.data_ptr() + 4 * 2 * E, self.dout.data_ptr() + 4 * 3 * E
-        self._lin_dx(self.dhead, self.dhead.shape[1], BT, hk, d_sf, 4 * E)
-        self._lin_dx(self.dlogits, 2, BT, "cdt.cost_pred_head.weight", d_af, 4 * E)
-        self._lin_dx(self.dsp, m.state_dim, BT, "cdt.state_pred_head.weight", d_af, 4 * E, resid=d_af, ldr=4 * E)
+        if self.P:
+            self.doutc.zero_()
+        d_sf, d_af = self.doutc.data_ptr() + 4 * (R - 2) * E, self.doutc.data_ptr() + 4 * (R - 1) * E
+        chain = self.head_hidden + [self.head_out]
+        for li in range(len(chain) - 1, -1, -1):  # output layer first, then the hidden Linear + GELU layers
+            dz, n = (self.dhead, self.dhead.shape[1]) if li == len(chain) - 1 else (self.dhh_pre[li], Eh)
+            if li > 0:
+                self._lin_dx(dz, n, BT, chain[li], self.dhh[li - 1], Eh)
+                L.check(lib.osrl_gelu_bwd(self.dhh[li - 1].data_ptr(), self.hh_pre[li - 1].data_ptr(),
+                                          self.dhh_pre[li - 1].data_ptr(), BT * Eh, cur_stream()), "gelu_bwd")
+            elif self.feat_ops:
+                self._lin_dx(dz, n, BT, chain[li], self.dfeat, Eh)
+            else:
+                self._lin_dx(dz, n, BT, chain[li], d_sf, R * E)
+        if self.feat_ops:  # the cost embedding is detached: only the state-token path carries gradient
+            g3 = self.dfeat.view(B, T, Eh)[..., :E]
+            if m.mul_cost_feat:
+                torch.mul(g3, self.ce3, out=self.dsf3)
+            else:
+                self.dsf3.copy_(g3)
+        self._lin_dx(self.dlogits, 2, BT, "cdt.cost_pred_head.weight", d_af, R * E)
+        self._lin_dx(self.dsp, m.state_dim, BT, "cdt.state_pred_head.weight", d_af, R * E, resid=d_af, ldr=R * E)
+        if self.P:
+            self.dout.view(B, self.S, E)[:, 1:].copy_(self.doutc.view(B, R * T, E))
         self._ln_bwd(self.dout, self.xin[NL], self.st_out, "cdt.out_norm", None, self.dxo[NL])
         for l in range(NL - 1, -1, -1):
             p = f"cdt.blocks.{l}."
@@ -293,7 +381,8 @@ class CDTEngine:
             self._lin_dx(self.datt[l], E, M, p + "attention.out_proj.weight", self.do, E)
             da = self._site(1 + 3 * l, self.p_attn)
             L.check(lib.osrl_attention_bwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.do.data_ptr(), self.B,
-                                           self.S, E, self.H, 4, ctypes.byref(da) if self.p_attn > 0 else None,
+                                           self.S, E, self.H, self.R, self.P,
+                                           ctypes.byref(da) if self.p_attn > 0 else None,
                                            self.dqkv[l].data_ptr(), cur_stream()), "attn_bwd")
             self._lin_dx(self.dqkv[l], 3 * E, M, p + "attention.in_proj_weight", self.dn, E)
             self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l])
@@ -301,10 +390,15 @@ class CDTEngine:
             self._drop(self.dxo[0], self.dxo[0], 0, self.p_emb)
         self._ln_bwd(self.dxo[0], self.seq, self.st_emb, "cdt.emb_norm", None, self.dseq)
         # ---- parameter gradients
-        te_off, (te_rows, _) = g.layout["cdt.timestep_emb.weight"]
-        g.slabs[0, te_off:te_off + te_rows * E].zero_()
-        L.check(lib.osrl_cdt_timestep_scatter(self.dseq.data_ptr(), self.time_steps.data_ptr(), BT, E,
-                                              g.slabs.data_ptr() + 4 * te_off, cur_stream()), "te_scatter")
+        if m.time_emb:
+            te_off, (te_rows, _) = g.layout["cdt.timestep_emb.weight"]
+            g.slabs[0, te_off:te_off + te_rows * E].zero_()
+            L.check(lib.osrl_cdt_timestep_scatter(self.dseq.data_ptr(), self.time_steps.data_ptr(), self.B, self.T,
+                                                  self.R, self.P, E, g.slabs.data_ptr() + 4 * te_off, cur_stream()),
+                    "te_scatter")
+        if self.P:
+            self.dseqc.view(self.B, self.R * self.T, E).copy_(self.dseq.view(self.B, self.S, E)[:, 1:])
+            self.p_pre.launch()
         self.p_tok.launch()
         self.p_bt.launch()
         g.cur_splits = self.n_splits
@@ -330,9 +424,14 @@ class CDTEngine:
         if self.dist is not None:
             self.dist.all_reduce_(st.stats)
 
-    def load_batch(self, states, actions, returns, costs_return, time_steps, mask, costs) -> None:
-        load_into(((self.states, states), (self.actions, actions), (self.returns, returns), (self.ctg, costs_return),
-                   (self.time_steps, time_steps), (self.mask, mask), (self.costs, costs)))
+    def load_batch(self, states, actions, returns, costs_return, time_steps, mask, costs, episode_cost=None) -> None:
+        pairs = [(self.states, states), (self.actions, actions), (self.returns, returns), (self.ctg, costs_return),
+                 (self.time_steps, time_steps), (self.mask, mask), (self.costs, costs)]
+        if episode_cost is not None:  # only the cost-prefix variant reads it (cdt.py:207-213)
+            pairs.append((self.episode_cost, episode_cost))
+        elif self.P:
+            raise ValueError("cost_prefix=True: episode_cost is an input of the model")
+        load_into(pairs)
 
     def attach_store(self, store) -> None:
         if store is not None and self.dist is not None:
@@ -345,10 +444,11 @@ class CDTEngine:
         assert self.store is not None
         self._go(use_graph)
 
-    def step(self, states, actions, returns, costs_return, time_steps, mask, costs, use_graph: bool = True) -> None:
+    def step(self, states, actions, returns, costs_return, time_steps, mask, costs, use_graph: bool = True,
+             episode_cost=None) -> None:
         if self.store is not None:
             raise RuntimeError("a SequenceStore is attached: call step_store()")
-        self.load_batch(states, actions, returns, costs_return, time_steps, mask, costs)
+        self.load_batch(states, actions, returns, costs_return, time_steps, mask, costs, episode_cost)
         self._go(use_graph)
 
     def _go(self, use_graph: bool) -> None:
@@ -374,7 +474,8 @@ class CDTEngine:
     def _capture(self) -> None:
         m, g = self.model, self.g
         snap = (g.p.clone(), g.m.clone(), g.v.clone(), self.st.state.clone(), self.st.stats.clone(),
-                self.st.ring.clone(), self.st.host_step, m.log_temperature.clone(), self.temp_mv.clone())
+                self.st.ring.clone(), self.st.host_step, m.log_temperature.clone() if m.stochastic else None,
+                self.temp_mv.clone())
         try:  # warm-up + capture both run a real step: the snapshot goes back even when the capture is refused
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -389,6 +490,8 @@ class CDTEngine:
             g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])
             self.st.state.copy_(snap[3]); self.st.stats.copy_(snap[4]); self.st.ring.copy_(snap[5])
             self.st.host_step = snap[6]
-            m.log_temperature.copy_(snap[7]); self.temp_mv.copy_(snap[8])
+            if m.stochastic:
+                m.log_temperature.copy_(snap[7])
+            self.temp_mv.copy_(snap[8])
             m.repack()
         self.graph = gr

@@ -175,6 +175,7 @@ class CDTBatchedRollout:
         e.states[:, 0].copy_(self.obs)
         e.returns[:, 0] = float(target_return)
         e.ctg[:, 0] = float(target_cost)
+        e.episode_cost.fill_(float(target_cost))  # the cost-prefix token's input (cdt.py:459,481)
         e.mask[:, 0] = 1.0
         self.cursor.zero_()
 

@@ -107,10 +107,10 @@ def test_layernorm_gelu_attention_kernels():
         do = rs.randn(B, S, E).astype(np.float32)
         o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
         qt, mt = t(qkv), t(mask)
-        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, None, o.data_ptr(), cur_stream()),
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, 0, None, o.data_ptr(), cur_stream()),
                 "a")
         dot = t(do)
-        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, None,
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, 0, None,
                                        dqkv.data_ptr(), cur_stream()), "ab")
         q64 = qkv.astype(np.float64)
         q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
@@ -173,9 +173,9 @@ def test_dropout_kernels():
         o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
         qt, mt, dot = t(qkv), t(mk), t(do)
         dr = L.DropoutT(p, 7, 11, st.ptr)
-        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, C.byref(dr), o.data_ptr(),
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, 0, C.byref(dr), o.data_ptr(),
                                        cur_stream()), "a")
-        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, C.byref(dr),
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, 0, C.byref(dr),
                                        dqkv.data_ptr(), cur_stream()), "ab")
         raw = torch.empty(B * H, S, 16, 8, device=DEV)
         ones = torch.ones_like(raw)
@@ -205,7 +205,9 @@ def build_cdt_gpu(c, **kw):
     from osrl_amd.common.logger import DummyLogger
     m = CDT(c.od, c.ad, 1.0, seq_len=c.T, episode_len=c.episode_len, embedding_dim=c.E, num_layers=c.layers,
             num_heads=c.heads, attention_dropout=c.dropout, residual_dropout=c.dropout, embedding_dropout=c.dropout,
-            use_rew=True, use_cost=True, cost_transform=c.cost_transform, stochastic=c.stochastic,
+            time_emb=c.time_emb, use_rew=c.use_rew, use_cost=c.use_cost, cost_transform=c.cost_transform,
+            add_cost_feat=c.add_cost_feat, mul_cost_feat=c.mul_cost_feat, cat_cost_feat=c.cat_cost_feat,
+            action_head_layers=c.head_layers, cost_prefix=c.cost_prefix, stochastic=c.stochastic,
             init_temperature=0.1, target_entropy=-c.ad, device=DEV)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_cdt_params(c).items()})
     lg = DummyLogger()
@@ -259,7 +261,8 @@ C5_SLICE = CDTCase("cdt_c5_slice", od=11, ad=3, B=64, T=20, E=256, heads=8, laye
                    warmup=500, dropout=0.1, seed=5)
 
 
-@pytest.mark.parametrize("case,use_graph", [("cdt_drop", False), ("cdt_drop", True), ("cdt_c5_slice", False)])
+@pytest.mark.parametrize("case,use_graph", [("cdt_drop", False), ("cdt_drop", True), ("cdt_c5_slice", False),
+                                            ("cdt_v_prefix", False), ("cdt_v_prefix", True)])
 def test_cdt_dropout_train_step_matches_oracle(case, use_graph):
     """Dropout 0.1 at every site (the train-config default): the GPU step draws Philox masks; the oracle (pinned
     against the reference with injected masks, tests/golden/cdt_drop.npz) replays the same masks, exported from
@@ -292,7 +295,8 @@ def test_cdt_dropout_train_step_matches_oracle(case, use_graph):
     m.eval()
     ap, _, _ = m(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],
                  ~b["mask"].to(torch.bool), b["episode_cost"])
-    ref = o.act_mean(bn["states"], bn["actions"], bn["returns"], bn["costs_return"], bn["time_steps"], bn["mask"])
+    ref = o.act_mean(bn["states"], bn["actions"], bn["returns"], bn["costs_return"], bn["time_steps"], bn["mask"],
+                     bn["episode_cost"])
     assert np.abs(ap.mean.cpu().numpy() - ref).max() <= 1e-4
     m.train()
     a1 = m(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], ~b["mask"].to(torch.bool),
@@ -501,8 +505,8 @@ def test_linear_and_attention_random_shapes():
         do = rs.randn(B, S, E).astype(np.float32)
         o, dqkv = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
         qt, mt, dot = t(qkv), t(mask), t(do)
-        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, None, o.data_ptr(), cur_stream()), "a")
-        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, None,
+        L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, 4, 0, None, o.data_ptr(), cur_stream()), "a")
+        L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, 0, None,
                                        dqkv.data_ptr(), cur_stream()), "ab")
         q64 = qkv.astype(np.float64)
         q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))

@@ -66,11 +66,12 @@ def test_evaluate_matches_oracle_policy(name):
     assert ln == n0 and abs(ret - r0) < 1e-3 * max(1, abs(r0)) and abs(cost - c0) < 0.5, (ret, r0, cost, c0)
 
 
-def test_cdt_rollout_matches_oracle():
+@pytest.mark.parametrize("case", ["cdt_small", "cdt_v_prefix_det", "cdt_v_norew"])
+def test_cdt_rollout_matches_oracle(case):
     from osrl_amd.common.synthetic_env import SyntheticSafeEnv
     from test_gpu_cdt import build_cdt_gpu
     from test_oracle_cdt_golden import build_cdt_oracle
-    c = CDT_CASES["cdt_small"]
+    c = CDT_CASES[case]
     m, tr, lg = build_cdt_gpu(c)
     o = build_cdt_oracle(c)
     EL = 12
@@ -92,7 +93,7 @@ def test_cdt_rollout_matches_oracle():
         pad = lambda x: np.concatenate([x, np.zeros((T - n,) + x.shape[1:], x.dtype)])[None]  # noqa: E731
         mask = pad(np.ones(n, np.float32))
         acts = o.act_mean(pad(S[lo:step + 1]), pad(A[lo:step + 1]), pad(R[lo:step + 1]), pad(C[lo:step + 1]),
-                          pad(np.arange(lo, step + 1)), mask)
+                          pad(np.arange(lo, step + 1)), mask, np.array([5.0], np.float32))
         act = np.clip(acts[0, n - 1], -1, 1)
         obs, reward, term, trunc, info = env_o.step(act)
         A[step], S[step + 1] = act, obs
@@ -324,15 +325,15 @@ def test_ingest_large_matches_oracle_and_feeds_the_samplers():
     assert rstore.n_rows == int(safe["index"].shape[0])
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_cdt_batched_evaluate_matches_oracle_rollouts(use_graph):
+@pytest.mark.parametrize("use_graph,case", [(False, "cdt_small"), (True, "cdt_small"), (True, "cdt_v_prefix_det")])
+def test_cdt_batched_evaluate_matches_oracle_rollouts(use_graph, case):
     """CDTTrainer.evaluate on a VecSyntheticSafeEnv (window held in the engine's batch buffers, growing then sliding)
     == the numpy oracle re-slicing a full history per env step (cdt.py:436-518), episode by episode; the episode is
     longer than 2x seq_len and not a multiple of the graph chunk."""
     from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
     from test_gpu_cdt import build_cdt_gpu
     from test_oracle_cdt_golden import build_cdt_oracle
-    c = CDT_CASES["cdt_small"]
+    c = CDT_CASES[case]
     m, tr, lg = build_cdt_gpu(c, use_graph=use_graph)
     o = build_cdt_oracle(c)
     E, EL, T = 5, 2 * c.T + 3, c.T
@@ -355,7 +356,7 @@ def test_cdt_batched_evaluate_matches_oracle_rollouts(use_graph):
             n = step + 1 - lo
             pad = lambda x: np.concatenate([x, np.zeros((T - n,) + x.shape[1:], x.dtype)])[None]  # noqa: E731
             acts = o.act_mean(pad(S[lo:step + 1]), pad(A[lo:step + 1]), pad(R[lo:step + 1]), pad(C[lo:step + 1]),
-                              pad(np.arange(lo, step + 1)), pad(np.ones(n, np.float32)))
+                              pad(np.arange(lo, step + 1)), pad(np.ones(n, np.float32)), np.array([5.0], np.float32))
             act = np.clip(acts[0, n - 1], -1, 1)
             obs, reward, term, trunc, info = env.step(act)
             A[step], S[step + 1] = act, obs
