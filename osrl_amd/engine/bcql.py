@@ -66,8 +66,7 @@ class BCQLEngine:
 
         # target pipeline buffers (shared by the critic and the cost-critic phases)
         NB = N * B
-        import os
-        tr = int(os.environ.get("OSRL_BCQ_TILE", "0"))  # 80: the one-workgroup-per-CU forward (csrc/mlp.hip nb kernel)
+        tr = 0  # tile kernel picks its tile; the 80-row one-workgroup-per-CU forward measured no gain here
         self.r_dec_t = MlpRun(self.d_dec, NB, False, dev, tile_rows=tr)
         self.r_actor_old_t = MlpRun(self.d_actor_old, NB, False, dev, tile_rows=tr)
         self.a_t = z(NB, ad)
@@ -227,8 +226,7 @@ class BCQLEngine:
         with torch.cuda.stream(s):
             self.body(True)
         torch.cuda.current_stream().wait_stream(s)
-        import os
-        par = Branches(os.environ.get("OSRL_BCQ_SERIAL", "0") != "1", 1)
+        par = Branches(True, 1)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.body(True, par)

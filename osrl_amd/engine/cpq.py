@@ -130,9 +130,6 @@ class CPQEngine:
         self.parallel_branches = True
         self._graph_failed = False
         self._probe = None
-        self.ood_first = os.environ.get("OSRL_OOD_FIRST", "1") == "1"
-        self.cost_fwd_side = os.environ.get("OSRL_COST_FWD_SIDE", "0") == "1"
-        self.n_branches = int(os.environ.get("OSRL_BRANCHES", "1"))  # 2 = the N*B-row launches on a branch of their own
 
     # ------------------------------------------------------------------ #
     def _update(self, name: str, tau: float) -> None:
@@ -186,69 +183,40 @@ class CPQEngine:
         if ev_vae is not None:
             ev_vae.record()
 
-        # ---- side branch S: the actor forwards + heads, then the critic phase.  Branch O (three-branch plan only; else
-        # O = S): the N*B-row launches -- target cost critics (needs `sampled`), later the VAE encoder (needs the VAE's
-        # Adam), KL rows, quantile, OOD mean.
-        three = par.enabled and len(par.side) > 1
-        o_i = 1 if three else 0
-
-        def ood_targets():
-            return self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
-
+        # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
+        # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
             hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
             head_next, head_obs = hn[0], ho[0]
             G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
-            if self.cost_fwd_side:
-                # the cost-critic phase's forward pair (cpq.py:159-161,188) needs nothing of the VAE phase: it runs
-                # here, beside it; the main branch picks up at the loss.  Balances the two chains (main was ~65 us
-                # longer once the quantile launch shrank)
-                qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
-                                                                   (self.obs, self.act))
             ev_next2 = par.mark(0)
             G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
-            if three:
-                par.fork(1, after=0)
             # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
             G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
-            if not three and self.ood_first:
-                qc_s = ood_targets()
+            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
             # critic_loss (cpq.py:137-153)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
-            ev_tgt_s = par.mark(0)
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
             self._optim("critic", self.p_critic, m.tau)
-            ev_critic = par.mark(0)
-            if not three and not self.ood_first:  # beside the cost-critic phase instead of beside the VAE's dW
-                qc_s = ood_targets()
-            if not three:
-                ev_tgt_s = par.mark(0)  # the side branch's last reader of cost_critic_old is enqueued
-        ev_tgt_o = None
-        if three:
-            with par.on(1):
-                qc_s = ood_targets()
-                ev_tgt_o = par.mark(1)
+            ev_critic = par.mark(0)  # also: the side branch's last reader of cost_critic_old is enqueued
 
         # ---- main: cost_critic_loss (cpq.py:155-201), the part with a gradient: Bellman MSE of the online cost critics
         par.wait(ev_next2)
-        if not self.cost_fwd_side:
-            qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
-                                                               (self.obs, self.act))
+        qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost, (self.obs, self.act))
         G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0, None,
                         self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
         self.p_cost.launch()
-        par.wait(ev_tgt_s)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the branches
-        par.wait(ev_tgt_o)
+        par.wait(ev_critic)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the side branch
         self._update("cost_critic", m.tau)
 
-        # ---- branch O (or S), second half: the OOD statistic with the UPDATED vae
-        with par.on(o_i):
+        # ---- side branch, second half: the OOD statistic with the UPDATED vae
+        with par.on(0):
             if ev_vae is not None:
-                par.side[o_i].wait_event(ev_vae)
+                par.side[0].wait_event(ev_vae)
             if self._probe is not None:  # bench.py: HIP events around the dominant launch as it runs inside the step
                 self._probe[0].record()
             head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
@@ -271,8 +239,6 @@ class CPQEngine:
         self.r_actor_obs.backward_dz()
         self._optim("actor", self.p_actor, m.tau)
         par.join(0)
-        if three:
-            par.join(1)
         # dual step + the OOD term of the logged loss (cpq.py:186-195): after the join, so that the side branch has no
         # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains)
         G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
@@ -405,7 +371,7 @@ class CPQEngine:
         snap = self._snapshot()
         # data parallel: the side branch holds no collective (the critic group's all-reduce + Adam run on the
         # capture stream after the join), so every rank issues its RCCL calls in the same order on one stream
-        par = Branches(self.parallel_branches, self.n_branches if self.dist is None else 1)
+        par = Branches(self.parallel_branches, 1)
         try:  # the warm-up pass and the capture pass both advance the model: ALWAYS put the snapshot back, also
             # when the capture is refused and the caller falls back to eager launches
             s = torch.cuda.Stream()
