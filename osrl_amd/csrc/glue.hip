@@ -188,38 +188,25 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t bin, bool acti
   if (active && !same) atomicAdd(&hist[bin], 1u);
 }
 
-// k-th smallest (0-based) key among x[0..n); every thread returns it.  hist: 256 uints in LDS.
+// k-th smallest (0-based) key among x[0..n), STREAMED from global (any n; the register-resident form for
+// n <= 32 * 1024 is bit_select below); every thread returns it.  hist: 256 uints in LDS.
 // bc[2] returns the number of elements <= the selected key (for the interpolation partner).
-// REG > 0: the keys were loaded once into kreg[REG] (element j*blockDim + tid; n <= REG*blockDim) and all four
-// passes run from registers -- the streaming form re-reads x with one dependent load per element and pass
-// (31 us for n = 20480 on the CPQ step's critical path); REG = 0: stream from global (any n).
-template <int REG>
-__device__ uint32_t radix_select(const float* __restrict__ x, const uint32_t (&kreg)[REG > 0 ? REG : 1], int64_t n,
-                                 int64_t k, uint32_t* hist, uint32_t* bc /*4 uints*/) {
+__device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t k, uint32_t* hist,
+                                 uint32_t* bc /*4 uints*/) {
   uint32_t prefix = 0, mask = 0;
   int64_t below = 0;  // elements strictly below the current prefix range
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    if (REG > 0) {
-#pragma unroll
-      for (int j = 0; j < (REG > 0 ? REG : 1); ++j) {
-        const uint32_t key = kreg[j];
-        const bool act = (int64_t)j * blockDim.x + threadIdx.x < n && (key & mask) == prefix;
-        if (__builtin_amdgcn_readfirstlane((int)(((int64_t)j * blockDim.x + (threadIdx.x & ~63u)) < n)))
-          hist_add(hist, (key >> shift) & 255u, act);
+    const int nround = (int)((n + blockDim.x - 1) / blockDim.x * blockDim.x);
+    for (int i = threadIdx.x; i < nround; i += blockDim.x) {
+      uint32_t key = 0;
+      bool act = false;
+      if (i < n) {
+        key = f2key(x[i]);
+        act = (key & mask) == prefix;
       }
-    } else {
-      const int nround = (int)((n + blockDim.x - 1) / blockDim.x * blockDim.x);
-      for (int i = threadIdx.x; i < nround; i += blockDim.x) {
-        uint32_t key = 0;
-        bool act = false;
-        if (i < n) {
-          key = f2key(x[i]);
-          act = (key & mask) == prefix;
-        }
-        hist_add(hist, (key >> shift) & 255u, act);
-      }
+      hist_add(hist, (key >> shift) & 255u, act);
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -357,8 +344,7 @@ __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict_
   const int64_t lo = (int64_t)floor(pos);
   const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
   const float w = (float)(pos - (double)lo);
-  const uint32_t none[1] = {0u};
-  const uint32_t klo = radix_select<0>(x, none, n, lo, hist, bc);
+  const uint32_t klo = radix_select(x, n, lo, hist, bc);
   const int64_t n_le = bc[2];
   uint32_t khi = klo;
   if (hi != lo && n_le < hi + 1) {
