@@ -52,6 +52,7 @@ def main():
                                     env_steps_per_s=round(E * a.len / dt, 1), us_per_env_step_launch=round(dt / a.len * 1e6, 2),
                                     mean_return=round(r[0], 4), mean_cost=round(r[1], 4)))
         tr.env = env  # reference-shaped scalar loop on the same HIP ops
+        tr.evaluate(1)  # builds the resident policy descriptor (pinned I/O block): steady state is what is timed
         t0 = time.perf_counter()
         r = tr.evaluate(a.scalar_episodes)
         dt = time.perf_counter() - t0
