@@ -1403,49 +1403,51 @@ struct LinBigArgs {
   int32_t M, K, N, Np, col0;
 };
 
-__global__ __launch_bounds__(512, 2) void linear_big_kernel(const LinBigArgs a) {
-  constexpr int BM = 128, BN = 256;
-  __shared__ __attribute__((aligned(16))) float As[2][BM * 16];  // [row][16 k]
-  __shared__ __attribute__((aligned(16))) float Bs[2][16 * BN];  // [kq][col][4 k]
+// One 32*RB-row x 256-column output tile (RB = 16-row blocks per wave: 4 -> 128 rows, 1 -> 32 rows).
+template <int RB>
+__device__ __forceinline__ void lin_big_tile(const LinBigArgs& a, const int row0, const int gcol0, float (*As)[128 * 16],
+                                             float (*Bs)[16 * 256]) {
+  constexpr int BM = 32 * RB, BN = 256;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int row0 = blockIdx.x * BM, gcol0 = blockIdx.y * BN;
   const int M = a.M, nk = a.K >> 4;
-  // staging: A slice = 128 rows x 4 float4 -> one float4 per thread; B slab = 4 kq-rows x 256 cols float4 -> two
+  // staging: A slice = BM rows x 4 float4 -> one float4 per thread (the first 4*BM threads); B slab = 4 kq-rows x 256
+  // cols float4 -> two per thread
   const int ar = tid >> 2, ac = tid & 3;
+  const bool has_a = tid < 4 * BM;
   const int arow = row0 + ar < M ? row0 + ar : M - 1;
   const f32x4* __restrict__ Ag = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda_g) + ac;
   const int bq0 = tid >> 8, bcol = tid & 255;  // chunks (bq0, bcol) and (bq0 + 2, bcol)
   const f32x4* __restrict__ Bg = reinterpret_cast<const f32x4*>(a.P) + (size_t)a.col0 + gcol0 + bcol;
   const int Np = a.Np;
-  f32x4 sa, sb0, sb1;
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb0, sb1;
   auto g_load = [&](int ks) {
-    sa = Ag[ks * 4];
+    if (has_a) sa = Ag[ks * 4];
     sb0 = Bg[(size_t)(ks * 4 + bq0) * Np];
     sb1 = Bg[(size_t)(ks * 4 + bq0 + 2) * Np];
   };
   auto s_store = [&](int buf) {
-    reinterpret_cast<f32x4*>(As[buf])[tid] = sa;  // row ar, float4 ac  == linear index tid
+    if (has_a) reinterpret_cast<f32x4*>(As[buf])[tid] = sa;  // row ar, float4 ac  == linear index tid
     reinterpret_cast<f32x4*>(Bs[buf])[bq0 * BN + bcol] = sb0;
     reinterpret_cast<f32x4*>(Bs[buf])[(bq0 + 2) * BN + bcol] = sb1;
   };
-  f32x4 acc[4][4];
+  f32x4 acc[RB][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   g_load(0);
   s_store(0);
   if (nk > 1) g_load(1);
   __syncthreads();
-  const int a_off = ((wr * 64 + (lane & 15)) * 16 + 4 * (lane >> 4));       // floats inside As[buf]
-  const int b_off = ((lane >> 4) * BN + wc * 64 + (lane & 15)) * 4;         // floats inside Bs[buf]
+  const int a_off = ((wr * 16 * RB + (lane & 15)) * 16 + 4 * (lane >> 4));  // floats inside As[buf]
+  const int b_off = ((lane >> 4) * BN + wc * 64 + (lane & 15)) * 4;          // floats inside Bs[buf]
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
-    f32x4 af[4], bf[4];
+    f32x4 af[RB], bf[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) af[r] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + r * 16 * 16]);
+    for (int r = 0; r < RB; ++r) af[r] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + r * 16 * 16]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + c * 64]);
     if (ks + 1 < nk) {
@@ -1457,7 +1459,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const LinBigArgs a) 
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][t], bf[c][t], acc[r][c], 0, 0, 0);
+        for (int r = 0; r < RB; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][t], bf[c][t], acc[r][c], 0, 0, 0);
     __syncthreads();
   }
   // epilogue: + bias + residual, 16 lanes x 4 B contiguous per row
@@ -1466,10 +1468,10 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const LinBigArgs a) 
     const int col = gcol0 + wc * 64 + c * 16 + (lane & 15);
     const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RB; ++r) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int gr = row0 + wr * 64 + r * 16 + (lane >> 4) * 4 + i;
+        const int gr = row0 + wr * 16 * RB + r * 16 + (lane >> 4) * 4 + i;
         if (gr < M) {
           float v = acc[r][c][i] + bv;
           if (a.resid) v += a.resid[(size_t)gr * a.ldr + col];
@@ -1477,6 +1479,24 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const LinBigArgs a) 
         }
       }
     }
+  }
+}
+
+// TAIL = 0: one 128-row tile per workgroup.  TAIL = 1: 160 rows per workgroup as a 128-row tile followed by a 32-row
+// tile.  The host takes it when that turns a ragged last round of the 512 resident workgroups into whole rounds: at
+// M = 81920, N = 256 (five of the eight GEMMs of a CDT block) 128-row tiles are 640 workgroups = 1.25 rounds, i.e. the
+// launch pays two; 160 rows per workgroup are exactly 512.  (A single 160-row register tile needs 149 VGPRs: one
+// workgroup per CU instead of two.)
+template <int TAIL>
+__global__ __launch_bounds__(512, 4) void linear_big_kernel(const LinBigArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][128 * 16];  // [row][16 k]
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * 256];  // [kq][col][4 k]
+  constexpr int kRows = TAIL ? 160 : 128;
+  const int row0 = blockIdx.x * kRows, gcol0 = blockIdx.y * 256;
+  lin_big_tile<4>(a, row0, gcol0, As, Bs);
+  if (TAIL && row0 + 128 < a.M) {
+    // (the last k-step's barrier of the first tile already separates its LDS reads from the stores below)
+    lin_big_tile<1>(a, row0 + 128, gcol0, As, Bs);
   }
 }
 
@@ -1764,7 +1784,16 @@ extern "C" int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, co
     b.lda_g = lda; b.ldr = ldr; b.ldy = ldy;
     b.M = M; b.K = K; b.N = N; b.Np = Np; b.col0 = col0;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(linear_big_kernel, dim3((M + 127) / 128, N / 256, 1), dim3(512), 0, (hipStream_t)stream, b);
+    // rows per workgroup by whole rounds of the 512 resident workgroups (2 per CU).  The 128 + 32-row form costs 1.85
+    // tile times (measured: the 32-row pass pays the full per-k-step staging + barrier of a 128-row one for a quarter
+    // of the MFMAs), so it is taken only where it replaces two rounds by one: CDT's N = 256 GEMMs, 7.43 -> 7.05 ms/step
+    const long cols = N / 256;
+    const long t128 = (long)((M + 127) / 128) * cols, t160 = (long)((M + 159) / 160) * cols;
+    const double c128 = (double)((t128 + 511) / 512), c160 = 1.85 * (double)((t160 + 511) / 512);
+    if (c160 < c128 * 0.95)
+      hipLaunchKernelGGL(linear_big_kernel<1>, dim3((M + 159) / 160, N / 256, 1), dim3(512), 0, (hipStream_t)stream, b);
+    else
+      hipLaunchKernelGGL(linear_big_kernel<0>, dim3((M + 127) / 128, N / 256, 1), dim3(512), 0, (hipStream_t)stream, b);
     return (int)hipGetLastError();
   }
   LinArgs a;
