@@ -1404,63 +1404,77 @@ struct LinBigArgs {
 };
 
 // One 32*RB-row x 256-column output tile (RB = 16-row blocks per wave: 4 -> 128 rows, 1 -> 32 rows).
+// Both operands reach LDS by DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a THREE-slot
+// ring, two k-steps ahead of the MFMAs; the one barrier per k-step waits for this wave's DMA of the step about to be
+// read only (s_waitcnt vmcnt(n) with the newer batch left in flight -- __syncthreads() would carry a release fence =
+// vmcnt(0) and end the prefetch at every barrier).  LDS image of a slot: As = [row][16 k] as float4 number
+// row * 4 + k / 4 == the loading thread's id, Bs = [kq][col][4 k] as float4 number kq * 256 + col == thread id
+// (+ 512 for kq + 2): both are "wave base + lane * 16 B", which is what the DMA writes.
+constexpr int kLbSlots = 3;
+constexpr int kLbA = 128 * 16, kLbB = 16 * 256;                    // floats per slot
+constexpr size_t kLbLds = sizeof(float) * kLbSlots * (kLbA + kLbB);  // 72 KB: two workgroups per CU
+
+__device__ __forceinline__ void glds16(const void* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 template <int RB>
-__device__ __forceinline__ void lin_big_tile(const LinBigArgs& a, const int row0, const int gcol0, float (*As)[128 * 16],
-                                             float (*Bs)[16 * 256]) {
+__device__ __forceinline__ void lin_big_tile(const LinBigArgs& a, const int row0, const int gcol0, float* As, float* Bs) {
   constexpr int BM = 32 * RB, BN = 256;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int M = a.M, nk = a.K >> 4;
-  // staging: A slice = BM rows x 4 float4 -> one float4 per thread (the first 4*BM threads); B slab = 4 kq-rows x 256
-  // cols float4 -> two per thread
+  // DMA sources: A slice = BM rows x 4 float4 -> one per thread of the first 4*BM threads (whole waves: BM = 128 all
+  // eight, BM = 32 the first two); B slab = 4 kq-rows x 256 cols float4 -> two per thread
   const int ar = tid >> 2, ac = tid & 3;
-  const bool has_a = tid < 4 * BM;
+  const bool has_a = wave * 64 < 4 * BM;  // wave-uniform
   const int arow = row0 + ar < M ? row0 + ar : M - 1;
   const f32x4* __restrict__ Ag = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda_g) + ac;
   const int bq0 = tid >> 8, bcol = tid & 255;  // chunks (bq0, bcol) and (bq0 + 2, bcol)
   const f32x4* __restrict__ Bg = reinterpret_cast<const f32x4*>(a.P) + (size_t)a.col0 + gcol0 + bcol;
   const int Np = a.Np;
-  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb0, sb1;
-  auto g_load = [&](int ks) {
-    if (has_a) sa = Ag[ks * 4];
-    sb0 = Bg[(size_t)(ks * 4 + bq0) * Np];
-    sb1 = Bg[(size_t)(ks * 4 + bq0 + 2) * Np];
-  };
-  auto s_store = [&](int buf) {
-    if (has_a) reinterpret_cast<f32x4*>(As[buf])[tid] = sa;  // row ar, float4 ac  == linear index tid
-    reinterpret_cast<f32x4*>(Bs[buf])[bq0 * BN + bcol] = sb0;
-    reinterpret_cast<f32x4*>(Bs[buf])[(bq0 + 2) * BN + bcol] = sb1;
+  const int wbase = wave * 64 * 4;  // this wave's first float inside a slot image (float4 number = thread id)
+  auto dma = [&](int ks) {
+    float* as = As + (ks % kLbSlots) * kLbA;
+    float* bs = Bs + (ks % kLbSlots) * kLbB;
+    if (has_a) glds16(Ag + ks * 4, as + wbase);
+    glds16(Bg + (size_t)(ks * 4 + bq0) * Np, bs + wbase);
+    glds16(Bg + (size_t)(ks * 4 + bq0 + 2) * Np, bs + 512 * 4 + wbase);
   };
   f32x4 acc[RB][4];
 #pragma unroll
   for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  g_load(0);
-  s_store(0);
-  if (nk > 1) g_load(1);
-  __syncthreads();
-  const int a_off = ((wr * 16 * RB + (lane & 15)) * 16 + 4 * (lane >> 4));  // floats inside As[buf]
-  const int b_off = ((lane >> 4) * BN + wc * 64 + (lane & 15)) * 4;          // floats inside Bs[buf]
+  dma(0);
+  if (nk > 1) dma(1);
+  const int a_off = ((wr * 16 * RB + (lane & 15)) * 16 + 4 * (lane >> 4));  // floats inside an A slot
+  const int b_off = ((lane >> 4) * BN + wc * 64 + (lane & 15)) * 4;          // floats inside a B slot
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
+    // batch ks landed (this wave's part), batch ks + 1 may stay in flight; then everyone's part landed and everyone
+    // is done reading slot (ks + 2) % 3 (= the slot of step ks - 1)
+    if (ks + 1 < nk) {
+      if (has_a) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (ks + 2 < nk) dma(ks + 2);
+    const float* as = As + (ks % kLbSlots) * kLbA;
+    const float* bs = Bs + (ks % kLbSlots) * kLbB;
     f32x4 af[RB], bf[4];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) af[r] = *reinterpret_cast<const f32x4*>(&As[buf][a_off + r * 16 * 16]);
+    for (int r = 0; r < RB; ++r) af[r] = *reinterpret_cast<const f32x4*>(&as[a_off + r * 16 * 16]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_off + c * 64]);
-    if (ks + 1 < nk) {
-      s_store(buf ^ 1);  // the other buffer was last read in step ks - 1 (everyone passed that step's barrier)
-      if (ks + 2 < nk) g_load(ks + 2);
-    }
+    for (int c = 0; c < 4; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&bs[b_off + c * 64]);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][t], bf[c][t], acc[r][c], 0, 0, 0);
-    __syncthreads();
   }
   // epilogue: + bias + residual, 16 lanes x 4 B contiguous per row
 #pragma unroll
@@ -1489,13 +1503,14 @@ __device__ __forceinline__ void lin_big_tile(const LinBigArgs& a, const int row0
 // workgroup per CU instead of two.)
 template <int TAIL>
 __global__ __launch_bounds__(512, 4) void linear_big_kernel(const LinBigArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[2][128 * 16];  // [row][16 k]
-  __shared__ __attribute__((aligned(16))) float Bs[2][16 * 256];  // [kq][col][4 k]
+  extern __shared__ __attribute__((aligned(16))) float lb_lds[];
+  float* As = lb_lds;
+  float* Bs = lb_lds + kLbSlots * kLbA;
   constexpr int kRows = TAIL ? 160 : 128;
   const int row0 = blockIdx.x * kRows, gcol0 = blockIdx.y * 256;
   lin_big_tile<4>(a, row0, gcol0, As, Bs);
   if (TAIL && row0 + 128 < a.M) {
-    // (the last k-step's barrier of the first tile already separates its LDS reads from the stores below)
+    __syncthreads();  // every wave is done reading the first tile's last slots before the ring restarts
     lin_big_tile<1>(a, row0 + 128, gcol0, As, Bs);
   }
 }
@@ -1774,28 +1789,10 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
 }
 
 
-extern "C" int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, const float* P, int32_t Np, int32_t col0,
-                           int32_t N, const float* bias, const float* resid, int64_t ldr, float* Y, int64_t ldy,
-                           void* stream) {
-  if (!A || !P || !Y || M < 1 || K < 1 || K > 1024 || N < 1 || Np < 16) return -1;
-  if (M >= 4096 && (K & 15) == 0 && (N & 255) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
-    LinBigArgs b;
-    b.A = A; b.P = P; b.bias = bias; b.resid = resid; b.Y = Y;
-    b.lda_g = lda; b.ldr = ldr; b.ldy = ldy;
-    b.M = M; b.K = K; b.N = N; b.Np = Np; b.col0 = col0;
-    (void)hipGetLastError();
-    // rows per workgroup by whole rounds of the 512 resident workgroups (2 per CU).  The 128 + 32-row form costs 1.85
-    // tile times (measured: the 32-row pass pays the full per-k-step staging + barrier of a 128-row one for a quarter
-    // of the MFMAs), so it is taken only where it replaces two rounds by one: CDT's N = 256 GEMMs, 7.43 -> 7.05 ms/step
-    const long cols = N / 256;
-    const long t128 = (long)((M + 127) / 128) * cols, t160 = (long)((M + 159) / 160) * cols;
-    const double c128 = (double)((t128 + 511) / 512), c160 = 1.85 * (double)((t160 + 511) / 512);
-    if (c160 < c128 * 0.95)
-      hipLaunchKernelGGL(linear_big_kernel<1>, dim3((M + 159) / 160, N / 256, 1), dim3(512), 0, (hipStream_t)stream, b);
-    else
-      hipLaunchKernelGGL(linear_big_kernel<0>, dim3((M + 127) / 128, N / 256, 1), dim3(512), 0, (hipStream_t)stream, b);
-    return (int)hipGetLastError();
-  }
+// the register-streamed tile kernel (linear_kernel): any M, K <= 1024, any N
+static int launch_linear_tiles(const float* A, int64_t lda, int32_t M, int32_t K, const float* P, int32_t Np, int32_t col0,
+                               int32_t N, const float* bias, const float* resid, int64_t ldr, float* Y, int64_t ldy,
+                               void* stream) {
   LinArgs a;
   a.A = A; a.P = P; a.bias = bias; a.resid = resid; a.Y = Y;
   a.lda_g = lda; a.ldr = ldr; a.ldy = ldy;
@@ -1825,6 +1822,46 @@ extern "C" int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, co
   }
 #undef OSRL_LIN_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, const float* P, int32_t Np, int32_t col0,
+                           int32_t N, const float* bias, const float* resid, int64_t ldr, float* Y, int64_t ldy,
+                           void* stream) {
+  if (!A || !P || !Y || M < 1 || K < 1 || K > 1024 || N < 1 || Np < 16) return -1;
+  if (M >= 4096 && (K & 15) == 0 && (N & 255) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
+    LinBigArgs b;
+    b.A = A; b.P = P; b.bias = bias; b.resid = resid; b.Y = Y;
+    b.lda_g = lda; b.ldr = ldr; b.ldy = ldy;
+    b.M = M; b.K = K; b.N = N; b.Np = Np; b.col0 = col0;
+    (void)hipGetLastError();
+    // 128-row x 256-column tiles on the 512 resident workgroups (2 per CU): a ragged last round costs a whole one.
+    // At M = 81920, N = 256 (five of the eight GEMMs of a CDT block) that is 640 tiles = 1.25 rounds.
+    const long cols = N / 256, t128 = (long)((M + 127) / 128) * cols;
+    // the 128 + 32-row form costs 1.85 tile times (the 32-row pass pays the per-k-step staging + barrier of a 128-row
+    // one for a quarter of the MFMAs): only where it replaces two rounds by one.  (Sending the leftover rows to the
+    // register-streamed tile kernel in a second launch measured the same: 6.96 ms of projections per step either way,
+    // 7.43 ms with the ragged round.)
+    const long t160 = (long)((M + 159) / 160) * cols;
+    const double c128 = (double)((t128 + 511) / 512), c160 = 1.85 * (double)((t160 + 511) / 512);
+    static bool lds_set = false;
+    if (!lds_set) {  // 72 KB of dynamic LDS: opt in once per process
+      hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_big_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLbLds);
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_big_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLbLds);
+      if (e0 != hipSuccess || e1 != hipSuccess) return (int)(e0 != hipSuccess ? e0 : e1);
+      lds_set = true;
+      (void)hipGetLastError();
+    }
+    if (c160 < c128 * 0.95)
+      hipLaunchKernelGGL(linear_big_kernel<1>, dim3((M + 159) / 160, N / 256, 1), dim3(512), kLbLds,
+                         (hipStream_t)stream, b);
+    else
+      hipLaunchKernelGGL(linear_big_kernel<0>, dim3((M + 127) / 128, N / 256, 1), dim3(512), kLbLds,
+                         (hipStream_t)stream, b);
+    return (int)hipGetLastError();
+  }
+  return launch_linear_tiles(A, lda, M, K, P, Np, col0, N, bias, resid, ldr, Y, ldy, stream);
 }
 
 extern "C" int osrl_pack_weights(const float* src_flat, float* pf, float* pb, const osrl_pack_entry_t* d_entries,
