@@ -20,3 +20,4 @@ rm -rf $O/prof
 timeout 300 python tests/bench_eval.py > $O/eval_bench.json 2> $O/eval.err
 timeout 200 python tools/kbench.py > $O/kbench.txt 2>&1
 tail -4 $O/pytest.log; head -c 1500 $O/bench.json; echo; head -3 $O/bench_kernel_stats.csv | cut -c1-200
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
