@@ -276,24 +276,17 @@ struct AttnArgs {
   const osrl_step_state_t* st;
 };
 
-// keep-multipliers of the (up to 8) probabilities P[bh][i][l16 + 16k] one lane owns in the softmax / dS passes.
-// Logical mask layout [B*H, S, 16, 8]: element ((bh*S + i)*16 + l16)*8 + k, so k = 0..3 share one Philox call.
-__device__ __forceinline__ void attn_drop_mult(const AttnArgs& a, int bh, int i, int l16, int nk, float (&m)[8]) {
+// keep-multipliers of the four probabilities P[bh][i][j0 .. j0+3] (j0 a multiple of 4) one lane owns in the register
+// layout of the attention kernels.  Logical mask layout [B*H, S, Sp] (Sp = S rounded up to 16): element
+// (bh*S + i)*Sp + j, so one Philox call covers exactly the four keys of a lane's accumulator -- the earlier
+// [.., 16, 8] layout spent 8 calls per 16-query block and lane whatever the number of key blocks, and the regenerated
+// masks were most of the kernels' VALU time.
+__device__ __forceinline__ f32x4 attn_drop_mult4(const AttnArgs& a, int bh, int i, int j0, int Sp) {
   const uint32_t step = a.st ? (uint32_t)a.st->step : 0u;
-  const uint64_t e4 = (((uint64_t)bh * a.S + i) * 16 + l16) * 2;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half * 4 < nk) {
-      const osrl_rng::U4 w = osrl_rng::drop_words(e4 + half, step, a.drop_site, a.k0, a.k1);
-      m[half * 4 + 0] = w.x >= a.drop_thresh ? a.drop_scale : 0.f;
-      m[half * 4 + 1] = w.y >= a.drop_thresh ? a.drop_scale : 0.f;
-      m[half * 4 + 2] = w.z >= a.drop_thresh ? a.drop_scale : 0.f;
-      m[half * 4 + 3] = w.w >= a.drop_thresh ? a.drop_scale : 0.f;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[half * 4 + k] = 0.f;
-    }
-  }
+  const uint64_t e4 = (((uint64_t)bh * a.S + i) * Sp + j0) >> 2;
+  const osrl_rng::U4 w = osrl_rng::drop_words(e4, step, a.drop_site, a.k0, a.k1);
+  return f32x4{w.x >= a.drop_thresh ? a.drop_scale : 0.f, w.y >= a.drop_thresh ? a.drop_scale : 0.f,
+               w.z >= a.drop_thresh ? a.drop_scale : 0.f, w.w >= a.drop_thresh ? a.drop_scale : 0.f};
 }
 
 // 16-lane (one DPP row) butterfly reductions: 4 VALU DPP ops instead of 4-6 ds_bpermute round trips
@@ -334,13 +327,6 @@ __device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& a, const f32x4& b
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
 }
-__device__ __forceinline__ void tri_decode(int blk, int* ib, int* jb) {  // blk -> (ib, jb), jb <= ib
-  int i = 0;
-  while ((i + 1) * (i + 2) / 2 <= blk) ++i;
-  *ib = i;
-  *jb = blk - i * (i + 1) / 2;
-}
-
 // load one [S, d] slice of qkv / dout into a zero-padded row-major LDS tile (and optionally its transpose).
 // 8 independent global loads per thread are issued before the first LDS store so their latencies overlap
 // (one load per loop iteration serialises ~40 L2 round trips per workgroup: measured 3x slower kernels).
@@ -367,66 +353,6 @@ __device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, si
       }
     }
   }
-}
-
-// P = softmax(mask(Q K^T / sqrt(d))) into Ps (lower-triangular blocks; everything else = 0)
-// (apply_drop: the forward kernel stores the dropped probabilities P*M/(1-p); the backward kernel keeps P and
-// applies the regenerated mask in its dS pass)
-__device__ __forceinline__ void attn_probs_mfma(const AttnArgs& a, int b, int d, int Sp, int dp, const float* Qs,
-                                                const float* Ks, int ldq, float* Ps, int ldp, const float* kvalid,
-                                                bool apply_drop, int bh) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nb = Sp >> 4, ntri = nb * (nb + 1) / 2;
-  const float scale = 1.0f / sqrtf((float)d);
-  for (int blk = wave; blk < ntri; blk += 4) {
-    int ib, jb;
-    tri_decode(blk, &ib, &jb);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < dp; kc += 16) mfma4(acc, frag_row(Qs, ldq, ib * 16, kc, lane), frag_row(Ks, ldq, jb * 16, kc, lane));
-    const int j = jb * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ib * 16 + 4 * (lane >> 4) + r;
-      Ps[i * ldp + j] = (j <= i && kvalid[j] > 0.f) ? acc[r] * scale : -INFINITY;
-    }
-  }
-  __syncthreads();
-  // softmax rows: 16 lanes per row (4 rows per wave at a time), each lane owns columns l16 + 16k
-  const int l16 = lane & 15, rsub = lane >> 4;
-  for (int i0 = wave * 4; i0 < Sp; i0 += 16) {
-    const int i = i0 + rsub;
-    const int jmax = ((i >> 4) + 1) << 4;
-    float v[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int j = l16 + 16 * k;
-      v[k] = (j < jmax && j < Sp) ? Ps[i * ldp + j] : -INFINITY;
-      mx = fmaxf(mx, v[k]);
-    }
-    mx = row16_max(mx);
-    const bool live = i < a.S && mx > -INFINITY;
-    float sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      v[k] = (live && v[k] > -INFINITY) ? expf(v[k] - mx) : 0.f;
-      sum += v[k];
-    }
-    sum = row16_sum(sum);
-    const float inv = live ? 1.0f / sum : 0.f;
-    if (apply_drop && a.drop_thresh && i < a.S) {
-      float dm[8];
-      attn_drop_mult(a, bh, i, l16, jmax >> 4, dm);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= dm[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int j = l16 + 16 * k;
-      if (j < Sp) Ps[i * ldp + j] = v[k] * inv;
-    }
-  }
-  __syncthreads();
 }
 
 __device__ __forceinline__ void attn_key_valid(const AttnArgs& a, int b, int Sp, float* kvalid) {
@@ -538,15 +464,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = live ? 1.0f / sum : 0.f;
-    if (a.drop_thresh && i < a.S) {  // P' = P M / (1-p): the mask of lane (i, l16 = q4 + r), block k = jb
+    if (a.drop_thresh && i < a.S) {  // P' = P M / (1-p): one Philox call per key block and lane
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float dm[8];
-        attn_drop_mult(a, blockIdx.x, i, q4 + r, ib + 1, dm);
-#pragma unroll
-        for (int jb = 0; jb < NBMAX; ++jb)
-          if (jb <= ib) s[jb][r] *= dm[jb];
-      }
+      for (int jb = 0; jb < NBMAX; ++jb)
+        if (jb <= ib) s[jb] *= attn_drop_mult4(a, blockIdx.x, i, jb * 16 + q4, Sp);
     }
 #pragma unroll
     for (int jb = 0; jb < NBMAX; ++jb)
@@ -681,21 +602,14 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
       }
     if (a.drop_thresh) {  // P' = P M / (1-p); the keep flags of the tile go to LDS for pass B
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float dm[8];
-        if (i < a.S) {
-          attn_drop_mult(a, blockIdx.x, i, q4 + r, ib + 1, dm);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) dm[k] = 0.f;
+      for (int jb = 0; jb < NBMAX; ++jb)
+        if (jb <= ib) {
+          const f32x4 dm = i < a.S ? attn_drop_mult4(a, blockIdx.x, i, jb * 16 + q4, Sp) : f32x4{0.f, 0.f, 0.f, 0.f};
+          pk[jb] *= dm;
+          const uint32_t flags = (dm[0] != 0.f ? 1u : 0u) | (dm[1] != 0.f ? 0x100u : 0u) |
+                                 (dm[2] != 0.f ? 0x10000u : 0u) | (dm[3] != 0.f ? 0x1000000u : 0u);
+          *reinterpret_cast<uint32_t*>(Mb + i * Sp + jb * 16 + q4) = flags;  // 4 consecutive keys, 4-byte aligned
         }
-#pragma unroll
-        for (int jb = 0; jb < NBMAX; ++jb)
-          if (jb <= ib) {
-            pk[jb][r] *= dm[jb];
-            Mb[i * Sp + jb * 16 + q4 + r] = dm[jb] != 0.f ? 1 : 0;
-          }
-      }
     }
     float rd = 0.f;  // r_i = sum_j P'_ij dP'_ij
 #pragma unroll

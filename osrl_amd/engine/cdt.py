@@ -229,11 +229,11 @@ class CDTEngine:
             out["emb"] = out["emb"].view(B, S, E)
         for l in range(self.NL):
             if self.p_attn > 0:
-                o1 = torch.ones(B * H, S, 16, 8, device=self.dev)
+                Sp = _r16(S)  # the kernels' mask layout: [B*H, S, Sp], one Philox call per 4 consecutive keys
+                o1 = torch.ones(B * H, S, Sp, device=self.dev)
                 raw = torch.empty_like(o1)
                 self._drop(o1, raw, 1 + 3 * l, self.p_attn)
-                j = torch.arange(S, device=self.dev)
-                out[f"attn{l}"] = raw[:, :, j % 16, j // 16].reshape(B, H, S, S)
+                out[f"attn{l}"] = raw[:, :, :S].reshape(B, H, S, S)
             if self.p_res > 0:
                 for k, site in ((f"res1_{l}", 2 + 3 * l), (f"res2_{l}", 3 + 3 * l)):
                     t = torch.empty_like(ones)

@@ -177,11 +177,11 @@ def test_dropout_kernels():
                                        cur_stream()), "a")
         L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, 4, 0, C.byref(dr),
                                        dqkv.data_ptr(), cur_stream()), "ab")
-        raw = torch.empty(B * H, S, 16, 8, device=DEV)
+        Sp = (S + 15) // 16 * 16  # the attention kernels' mask layout: [B*H, S, Sp], 4 consecutive keys per draw
+        raw = torch.empty(B * H, S, Sp, device=DEV)
         ones = torch.ones_like(raw)
         L.check(lib.osrl_dropout(ones.data_ptr(), raw.data_ptr(), raw.numel(), C.byref(dr), cur_stream()), "m")
-        j = np.arange(S)
-        Mk = raw.cpu().numpy()[:, :, j % 16, j // 16].reshape(B, H, S, S).astype(np.float64)
+        Mk = raw.cpu().numpy()[:, :, :S].reshape(B, H, S, S).astype(np.float64)
         q64 = qkv.astype(np.float64)
         q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
         blocked = np.triu(np.ones((S, S), bool), 1)[None, None] | np.repeat(mk <= 0, 4, 1)[:, None, None, :]
