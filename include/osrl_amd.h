@@ -238,6 +238,12 @@ int osrl_quantile(const float* x, int64_t n, float q, float* out, void* stream);
 int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_old, int32_t n_qc_old,
                          const float* q, int32_t n_q, const float* rew, const float* done, int32_t rows,
                          float gamma, float q_thres, int32_t rows_global, float* dq, float* stat, void* stream);
+/* The same quantile for large n (the all-gathered KL rows of data-parallel CPQ: world * N * B values) as a grid: four
+ * multi-workgroup histogram passes + a successor search + a finish launch instead of one streaming workgroup (200 us
+ * at n = 163840).  ws: OSRL_QUANTILE_WS uint32 of device scratch, all zero before the first call; every call leaves it
+ * zeroed again.  Same result bits as osrl_quantile. */
+#define OSRL_QUANTILE_WS 1032
+int osrl_quantile_ws(const float* x, int64_t n, float q, uint32_t* ws, float* out, void* stream);
 /* out[0] = mean over the (global) batch of qc_ood = ((KL >= quantile) * min_e qc_sampled).mean(0)
  * (cpq.py:184,187); under data parallelism this rank's share, to be all-reduced(SUM). */
 int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl, const float* quantile,

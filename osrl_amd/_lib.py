@@ -148,6 +148,7 @@ PROTOTYPES = {
     "osrl_vae_latent_bwd": [_fp, _fp, _fp, _i32, _i32, _f32, _i32, _fp, _vp],
     "osrl_vae_kl_rows": [_fp, _i32, _i32, _fp, _vp],
     "osrl_quantile": [_fp, _i64, _f32, _fp, _vp],
+    "osrl_quantile_ws": [_fp, _i64, _f32, _vp, _fp, _vp],
     "osrl_cpq_critic_loss": [_fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
     "osrl_cpq_ood_mean": [_fp, _i32, _fp, _fp, _i32, _i32, _i32, _fp, _vp],
     "osrl_cpq_ood_stat": [_fp, _i32, _fp, _f32, _i32, _i32, _i32, _fp, _fp, _vp],
@@ -182,6 +183,7 @@ PROTOTYPES = {
 _LIB: Optional[C.CDLL] = None
 
 
+QUANTILE_WS = 1032  # uint32 elements of scratch for osrl_quantile_ws (include/osrl_amd.h OSRL_QUANTILE_WS)
 RESTYPES = {"osrl_ingest_ws_elems": C.c_int64}  # everything else returns int (0 = ok)
 
 

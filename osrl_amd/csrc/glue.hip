@@ -375,6 +375,126 @@ __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict_
   }
 }
 
+// ---------------- exact quantile of MANY values: multi-workgroup radix select ----------------
+// Data-parallel CPQ takes the 0.75-quantile over the all-gathered KL rows (world * N * B = 163840 values at 8 ranks);
+// the single-workgroup streaming select above needs 200 us for that, on the step's critical chain.  Here every pass
+// is a grid: workgroups histogram one key byte of their slice in LDS (wave-aggregated adds, then one global atomic per
+// non-empty bin -- integer adds, order-independent: deterministic), and the NEXT launch walks the global histograms of
+// the passes before it (256 bins each, redundantly per workgroup) to know its prefix.  Workspace (uint32): 4 x 256
+// histogram bins, then succ (atomicMin target) at [1024]; the last launch leaves it cleared for the next call.
+constexpr int kQselWs = 4 * 256 + 8;
+
+// digits of passes 0..npass-1 of the k-th smallest key, from the global histograms: prefix / rank inside the prefix /
+// number of keys below the prefix range / size of the last chosen bin.  One wave (64 threads) per call.
+struct QselWalk {
+  uint32_t prefix, k, below, cnt;
+};
+__device__ QselWalk qsel_walk(const uint32_t* __restrict__ ws, uint32_t k, int npass, uint32_t* sh /*>= 8 uints*/) {
+  // executed by threads 0..63 of the workgroup; result broadcast through sh[0..3]
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    uint32_t prefix = 0, below = 0, cnt = 0;
+    for (int p = 0; p < npass; ++p) {
+      const uint32_t* h = ws + p * 256;
+      const uint32_t c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
+      const uint32_t sl = c0 + c1 + c2 + c3;
+      uint32_t incl = sl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (l >= o) incl += t;
+      }
+      const uint32_t excl = incl - sl;
+      uint32_t d = 0, kk = 0, bd = 0, cd = 0;
+      const bool mine = k >= excl && k < incl;  // exactly one lane
+      if (mine) {
+        kk = k - excl; d = 4 * l; bd = excl; cd = c0;
+        if (kk >= c0) {
+          kk -= c0; bd += c0; d++; cd = c1;
+          if (kk >= c1) {
+            kk -= c1; bd += c1; d++; cd = c2;
+            if (kk >= c2) { kk -= c2; bd += c2; d++; cd = c3; }
+          }
+        }
+      }
+      const unsigned long long who = __ballot(mine);
+      const int src = __ffsll((long long)who) - 1;
+      d = __shfl(d, src); kk = __shfl(kk, src); bd = __shfl(bd, src); cd = __shfl(cd, src);
+      prefix |= d << (24 - 8 * p);
+      k = kk;
+      below += bd;
+      cnt = cd;
+    }
+    if (l == 0) { sh[0] = prefix; sh[1] = k; sh[2] = below; sh[3] = cnt; }
+  }
+  __syncthreads();
+  return QselWalk{sh[0], sh[1], sh[2], sh[3]};
+}
+
+__global__ __launch_bounds__(1024) void qsel_hist_kernel(const float* __restrict__ x, int64_t n, int64_t k, int pass,
+                                                         uint32_t* __restrict__ ws) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[8];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) ws[1024] = 0xffffffffu;  // successor search starts empty
+  const QselWalk w = qsel_walk(ws, (uint32_t)k, pass, sh);  // (its barrier also covers the zeroing above)
+  const int shift = 24 - 8 * pass;
+  const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nround = (n + stride - 1) / stride * stride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+    uint32_t key = 0;
+    bool act = false;
+    if (i < n) {
+      key = f2key(x[i]);
+      act = (key & mask) == w.prefix;
+    }
+    hist_add(hist, (key >> shift) & 255u, act);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x)
+    if (hist[i]) atomicAdd(&ws[pass * 256 + i], hist[i]);
+}
+
+// the (lo+1)-th order statistic when it is not a duplicate of the lo-th: the smallest key strictly above it
+__global__ __launch_bounds__(1024) void qsel_succ_kernel(const float* __restrict__ x, int64_t n, int64_t lo, int64_t hi,
+                                                         uint32_t* __restrict__ ws) {
+  __shared__ uint32_t sh[8];
+  const QselWalk w = qsel_walk(ws, (uint32_t)lo, 4, sh);
+  const int64_t n_le = (int64_t)w.below + w.cnt;  // keys <= the selected one
+  if (hi == lo || n_le >= hi + 1) return;         // the partner is the same key
+  uint32_t mn = 0xffffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t key = f2key(x[i]);
+    if (key > w.prefix && key < mn) mn = key;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t other = __shfl_xor(mn, o);
+    mn = other < mn ? other : mn;
+  }
+  if ((threadIdx.x & 63) == 0 && mn != 0xffffffffu) atomicMin(&ws[1024], mn);
+}
+
+__global__ __launch_bounds__(256) void qsel_finish_kernel(int64_t n, float q, uint32_t* __restrict__ ws,
+                                                          float* __restrict__ out) {
+  __shared__ uint32_t sh[8];
+  const double pos = (double)q * (double)(n - 1);
+  const int64_t lo = (int64_t)floor(pos);
+  const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
+  const float wgt = (float)(pos - (double)lo);
+  const QselWalk w = qsel_walk(ws, (uint32_t)lo, 4, sh);
+  const int64_t n_le = (int64_t)w.below + w.cnt;
+  const uint32_t klo = w.prefix;
+  const uint32_t khi = (hi == lo || n_le >= hi + 1) ? klo : ws[1024];
+  __syncthreads();  // everyone has read the histograms and the successor
+  if (threadIdx.x == 0) {
+    const float vlo = key2f(klo), vhi = key2f(khi);
+    out[0] = vlo + (vhi - vlo) * wgt;
+  }
+  for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) ws[i] = 0;  // ready for the next call
+}
+
 // ---------------- CPQ ----------------
 __device__ __forceinline__ float min_over(const float* __restrict__ q, int n, int stride, int i) {
   float v = q[i];
@@ -761,6 +881,20 @@ int osrl_quantile(const float* x, int64_t n, float q, float* out, void* stream) 
   if (!x || !out || n < 1 || q < 0.f || q > 1.f) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(quantile_kernel, dim3(1), dim3(kRed), 0, S, x, n, q, out);
+  LAUNCH_CHECK();
+}
+
+int osrl_quantile_ws(const float* x, int64_t n, float q, uint32_t* ws, float* out, void* stream) {
+  if (!x || !out || !ws || n < 1 || n > 0xffffffffll || q < 0.f || q > 1.f) return -1;
+  const double pos = (double)q * (double)(n - 1);
+  const int64_t lo = (int64_t)floor(pos), hi = lo + 1 < n ? lo + 1 : n - 1;
+  int64_t blocks = (n + 1023) / 1024;
+  blocks = blocks > 256 ? 256 : blocks;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  for (int pass = 0; pass < 4; ++pass)
+    hipLaunchKernelGGL(qsel_hist_kernel, dim3((unsigned)blocks), dim3(1024), 0, S, x, n, lo, pass, ws);
+  hipLaunchKernelGGL(qsel_succ_kernel, dim3((unsigned)blocks), dim3(1024), 0, S, x, n, lo, hi, ws);
+  hipLaunchKernelGGL(qsel_finish_kernel, dim3(1), dim3(256), 0, S, n, q, ws, out);
   LAUNCH_CHECK();
 }
 

@@ -56,6 +56,11 @@ def quantile(x, n, q, out):
     L.check(L.load().osrl_quantile(_p(x), n, q, _p(out), cur_stream()), "osrl_quantile")
 
 
+def quantile_ws(x, n, q, ws, out):
+    """Multi-workgroup select for large n; ``ws``: int32/uint32 tensor of L.QUANTILE_WS zeros (re-zeroed by the call)."""
+    L.check(L.load().osrl_quantile_ws(_p(x), n, q, ws.data_ptr(), _p(out), cur_stream()), "osrl_quantile_ws")
+
+
 def cpq_critic_loss(q_old, n_q_old, qc_old, n_qc_old, q, n_q, rew, done, rows, gamma, q_thres, rows_global, dq,
                     stat):
     L.check(L.load().osrl_cpq_critic_loss(_p(q_old), n_q_old, _p(qc_old), n_qc_old, _p(q), n_q, _p(rew), _p(done),

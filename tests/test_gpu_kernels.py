@@ -408,6 +408,28 @@ def test_quantile_clustered_values_both_select_paths(n):
         assert abs(out[0].item() - ref) <= np.spacing(ref), (n, q, out[0].item(), ref)  # fma vs mul+add
 
 
+@pytest.mark.parametrize("n", [1, 33, 40000, 163840, 200001])
+def test_quantile_grid_select_equals_single_workgroup(n):
+    """osrl_quantile_ws (multi-workgroup radix select: the data-parallel batch-global quantile) returns the bits of
+    osrl_quantile on clustered, tie-heavy and signed inputs; its workspace is left zeroed (two calls in a row)."""
+    from osrl_amd import _lib as L
+    from osrl_amd.engine import glue as G
+    dev = _dev()
+    rs = np.random.RandomState(n)
+    ws = torch.zeros(L.QUANTILE_WS, dtype=torch.int32, device=dev)
+    for kind in ("clustered", "normal"):
+        x = (0.5 + 1e-3 * rs.rand(n)).astype(np.float32) if kind == "clustered" else rs.randn(n).astype(np.float32)
+        if n > 10:
+            x[rs.randint(0, n, n // 3)] = x[0]
+        xt = torch.tensor(x, device=dev)
+        a, b = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+        for q in (0.75, 0.0, 1.0, 0.3333):
+            G.quantile(xt, n, q, a)
+            G.quantile_ws(xt, n, q, ws, b)
+            assert a[0].item() == b[0].item(), (n, kind, q, a[0].item(), b[0].item())
+            assert int(ws[:1024].abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("N,B,nqc", [(10, 2048, 2), (10, 256, 1), (3, 1000, 2)])
 def test_cpq_ood_stat_equals_quantile_then_mean(N, B, nqc):
     """The fused single-GPU launch (quantile + masked OOD mean) returns the bits of the two separate launches."""

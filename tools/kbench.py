@@ -87,6 +87,9 @@ def main():
     print(f"quantile n=20480: {timeit(lambda: G.quantile(x, 20480, 0.75, out)):.2f} us")
     x = torch.randn(163840, device=dev).abs()
     print(f"quantile n=163840: {timeit(lambda: G.quantile(x, 163840, 0.75, out)):.2f} us")
+    from osrl_amd import _lib as L_
+    ws = torch.zeros(L_.QUANTILE_WS, dtype=torch.int32, device=dev)
+    print(f"quantile_ws (grid select) n=163840: {timeit(lambda: G.quantile_ws(x, 163840, 0.75, ws, out)):.2f} us")
     st = StepState(dev, ["x"])
     st.tick()
     for n, S in ((388812, 15), (388812, 4), (172552, 8), (86532, 1)):
