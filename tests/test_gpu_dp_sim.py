@@ -181,13 +181,14 @@ def test_world2_sharded_step_equals_concatenated_batch(algo):
         assert torch.equal(v, reps[1][0].state_dict()[k]), f"{algo}: replicas diverged in {k}"
 
 
-def test_world2_cdt_sharded_step_equals_concatenated_batch():
+@pytest.mark.parametrize("case", ["cdt_small", "cdt_v_norew"])
+def test_world2_cdt_sharded_step_equals_concatenated_batch(case):
     """CDT: the count-normalised means ([mask > 0].mean(), accuracy) use GLOBAL counts (the two shards hold different
     numbers of valid tokens), the gradient is clipped by the norm of the REDUCED gradient, the temperature step
     sees the global entropy."""
     from cases import CDT_CASES, make_cdt_batch
     from test_gpu_cdt import build_cdt_gpu
-    c = CDT_CASES["cdt_small"]
+    c = CDT_CASES[case]  # the second one: 3 tokens per timestep, add-cost feature, 2-layer stochastic head
     W, B = 2, c.B
     Bl = B // W
     batch = make_cdt_batch(c)
