@@ -711,7 +711,109 @@ __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N,
   __syncthreads();
 }
 
-template <int NCB>
+// ---- 4q + 1 column blocks (400-wide layers: 25): every wave owns q blocks, the last block is SHARED by rows ----------
+// Dealing 25 blocks as 7 + 6 + 6 + 6 makes the 7-block wave the layer's pace: 12 % over the mean.  Here wave 0 takes
+// row blocks {0, 1} of the shared block, waves 1..3 one row block each: 32 / 31 / 31 / 31 register tiles.
+// NX = row blocks of the shared column this wave owns (2: wave 0, 1: the others), starting at rbx0.
+template <int CNT, int NX>
+__device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
+                                        int colx, int rbx0, f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX]) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* arow = lds + m * lda + 4 * kq;
+  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
+  const unsigned lane_offx = (unsigned)((kq * Np + colx + m) * 16);
+  const int rot = k_rot(nk);
+  const float* arowx = arow + rbx0 * 16 * lda;  // the shared column's row blocks (wave-uniform start)
+  f32x4 b[2][CNT + 1], a[2][kNbRb], ax[2][NX];
+  {
+    const int k0 = k_at(0, rot, nk, 0);
+    const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
+    b[0][CNT] = load_bp_s(Pk, lane_offx);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ax[0][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + k0 * 16);
+  }
+  auto step = [&](auto s_c, int kc) {
+    constexpr int s = decltype(s_c)::value;
+    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
+    const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
+    b[s ^ 1][CNT] = load_bp_s(Pk, lane_offx);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ax[s ^ 1][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + kn * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb)
+          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rb][t], b[s][c][t], acc[rb][c], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        xacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s][i][t], b[s][CNT][t], xacc[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, CNT + 1, 0);                    // VMEM reads of the next step first
+    __builtin_amdgcn_sched_group_barrier(0x100, kNbRb + NX, 0);                 // its DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * (kNbRb * CNT + NX), 0);     // then this step's MFMAs
+  };
+  using std::integral_constant;
+  int kc = 0;
+  for (; kc + 2 <= nk; kc += 2) {
+    step(integral_constant<int, 0>{}, kc);
+    step(integral_constant<int, 1>{}, kc + 1);
+  }
+  if (kc < nk) step(integral_constant<int, 0>{}, kc);
+}
+
+template <int CNT, int NX>
+__device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int N, const float* __restrict__ P,
+                                                const float* __restrict__ bias, int act, int cb0, int cbx, int rbx0,
+                                                int lane) {
+  f32x4 acc[kNbRb][CNT], xacc[NX];
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) {
+    const int col = (cb0 + c) * 16 + (lane & 15);
+    const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) acc[rb][c] = f32x4{bv, bv, bv, bv};
+  }
+  const int colx = cbx * 16 + (lane & 15);
+  const bool livex = colx < N;
+  {
+    const float bv = livex ? bias[colx] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xacc[i] = f32x4{bv, bv, bv, bv};
+  }
+  nb_mm_x<CNT, NX>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, acc, xacc);
+  __syncthreads();  // every wave finished reading the previous activations
+  if (act == OSRL_ACT_RELU)
+    nb_epilogue<CNT, OSRL_ACT_RELU>(lds, lda, acc, cb0, N, lane);
+  else if (act == OSRL_ACT_TANH)
+    nb_epilogue<CNT, OSRL_ACT_TANH>(lds, lda, acc, cb0, N, lane);
+  else
+    nb_epilogue<CNT, OSRL_ACT_ID>(lds, lda, acc, cb0, N, lane);
+  float* dst = lds + ((lane >> 4) * 4) * lda + colx;
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = act_fwd(act, xacc[i][r]);
+      dst[((rbx0 + i) * 16 + r) * lda] = livex ? v : 0.f;
+    }
+  __syncthreads();
+}
+
+// SHARED: every wide layer has 4 (NCB - 1) + 1 column blocks (the 400-wide VAE encoder / decoder): NCB - 1 blocks per
+// wave + the row-shared last block (nb_wide_layer_x); a separate instantiation, so that neither form carries the
+// other's register footprint
+template <int NCB, bool SHARED = false>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * kNbRb;
@@ -759,12 +861,22 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
   PHASE_STAMP(1);
   for (int l = 0; l + 1 < L; ++l) {  // wide layers
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
-    int cb0, cnt;
-    wave_blocks<4>((N + 15) >> 4, wave, &cb0, &cnt);
-    if (cnt == NCB)
-      nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
-    else
-      nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+    const int nblk = (N + 15) >> 4;
+    if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
+      const int q = nblk >> 2;
+      if (wave == 0)
+        nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane);
+      else
+        nb_wide_layer_x<NCB - 1, 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, 4 * q,
+                                    wave + 1, lane);
+    } else {
+      int cb0, cnt;
+      wave_blocks<4>(nblk, wave, &cb0, &cnt);
+      if (cnt == NCB)
+        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+      else
+        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+    }
     PHASE_STAMP(2 + 4 * l);
     PHASE_STAMP(3 + 4 * l);
     PHASE_STAMP(4 + 4 * l);
@@ -1638,13 +1750,13 @@ constexpr int kNotBig = -12345;
 constexpr size_t kLdsMax = 160 * 1024;
 
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
-template <int NCB>
+template <int NCB, bool SHARED = false>
 static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   (void)hipGetLastError();
-  hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1675,6 +1787,9 @@ static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osr
   for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
   a.lda = lda;
   const int tiles = (in->rows + 79) / 80;
+  bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
+  for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;
+  if (shared) return launch_nb<7, true>(a, tiles, nets, lds_bytes, stream);
   return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
 }
 
