@@ -625,6 +625,9 @@ struct NbArgs {
   int32_t lda;
 };
 
+#ifndef OSRL_NB_INTERLEAVE
+#define OSRL_NB_INTERLEAVE 1
+#endif
 constexpr int kNbRb = 5;  // row blocks per tile (80 rows)
 
 template <int CNT>
@@ -659,9 +662,27 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
           acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rb][t], b[s][c][t], acc[rb][c], 0, 0, 0);
+#if OSRL_NB_INTERLEAVE
+    // next step's loads one at a time, each followed by a few of THIS step's MFMAs: with one wave per SIMD nothing else
+    // can fill the MFMA pipe while the ~35 address / load instructions of a step issue (540 cycles per 16-deep k-step
+    // with all of them in front of the MFMAs)
+    constexpr int kPer = (4 * kNbRb * CNT) / (CNT + kNbRb + 1);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kNbRb; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT - kPer * (CNT + kNbRb), 0);
+#else
     __builtin_amdgcn_sched_group_barrier(0x020, CNT, 0);                // VMEM reads of the next step first
     __builtin_amdgcn_sched_group_barrier(0x100, kNbRb, 0);              // its DS reads
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT, 0);    // then this step's MFMAs
+#endif
   };
   using std::integral_constant;
   int kc = 0;
@@ -759,9 +780,24 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
       for (int i = 0; i < NX; ++i)
         xacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s][i][t], b[s][CNT][t], xacc[i], 0, 0, 0);
     }
+#if OSRL_NB_INTERLEAVE
+    constexpr int kTot = 4 * (kNbRb * CNT + NX), kPer = kTot / (CNT + 1 + kNbRb + NX + 1);
+#pragma unroll
+    for (int i = 0; i < CNT + 1; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kNbRb + NX; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, kTot - kPer * (CNT + 1 + kNbRb + NX), 0);
+#else
     __builtin_amdgcn_sched_group_barrier(0x020, CNT + 1, 0);                    // VMEM reads of the next step first
     __builtin_amdgcn_sched_group_barrier(0x100, kNbRb + NX, 0);                 // its DS reads
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * (kNbRb * CNT + NX), 0);     // then this step's MFMAs
+#endif
   };
   using std::integral_constant;
   int kc = 0;
