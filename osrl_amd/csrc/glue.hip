@@ -71,6 +71,12 @@ __global__ void gauss_head_kernel(const float* __restrict__ head, const float* _
   if (logp) logp[r] = lp;
 }
 
+// A loaded value that is only consumed under a condition gets its load SUNK into that branch by the compiler (and a
+// select on it turned into such a branch), where it waits alone: s_waitcnt vmcnt(0) per load, one memory round trip
+// after the other.  pin() makes the value unconditionally live at the point of the call, so a group of loads issued
+// back to back in front of a group of pin()s stays in flight together.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
 __global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
                                       const float* __restrict__ tanh_u, const float* __restrict__ da_nets,
                                       int n_nets, int rows, int ad, float max_a, float* __restrict__ dhead) {
@@ -78,15 +84,29 @@ __global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const floa
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * ad) return;
   const int r = i / ad, j = i - r * ad;
+  float t = tanh_u[i];
+  float lsr = head[(size_t)r * 2 * ad + ad + j];
+  float ev = eps[i];
   float da = 0.f;
-  for (int e = 0; e < n_nets; ++e) da += da_nets[(size_t)e * rows * ad + i];
-  const float t = tanh_u[i];
+  if (n_nets <= 4) {  // the usual ensemble sizes: every member requested at once (members past n_nets re-read member 0)
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = da_nets[(size_t)(e < n_nets ? e : 0) * rows * ad + i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pin(v[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) da += e < n_nets ? v[e] : 0.f;
+  } else {
+    for (int e = 0; e < n_nets; ++e) da += da_nets[(size_t)e * rows * ad + i];
+  }
+  pin(t);
+  pin(lsr);
+  pin(ev);
   const float du = da * max_a * (1.0f - t * t);
-  const float lsr = head[(size_t)r * 2 * ad + ad + j];
   const float ls = fminf(fmaxf(lsr, kLogStdMin), kLogStdMax);
   const bool inside = lsr >= kLogStdMin && lsr <= kLogStdMax;
   dhead[(size_t)r * 2 * ad + j] = du;
-  dhead[(size_t)r * 2 * ad + ad + j] = inside ? du * eps[i] * expf(ls) : 0.f;
+  dhead[(size_t)r * 2 * ad + ad + j] = inside ? du * ev * expf(ls) : 0.f;
 }
 
 __global__ void gauss_ood_kernel(const float* __restrict__ head, const float* __restrict__ eps, int n_samples,
@@ -127,14 +147,49 @@ __global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict_
   __shared__ float sm[20];
   float rec = 0.f, kl = 0.f;
   const float ia = inv_rows / (float)ad, il = inv_rows / (float)L;
-  for (int i = threadIdx.x; i < rows * ad; i += kRed) {
-    const float d = u[i] - act[i];
-    rec += d * d;
-    du[i] = 2.0f * d * ia;
+  // four strides of the workgroup per pass, their loads in flight together (one element per pass = one memory round
+  // trip per pass: 4 + 16 of them at C2's 2048 x (2 + 8)); per-thread accumulation order unchanged
+  const int n_rec = rows * ad, n_kl = rows * L;
+  for (int i0 = threadIdx.x; i0 < n_rec; i0 += 4 * kRed) {
+    float uv[4], av[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * kRed;
+      uv[k] = u[i < n_rec ? i : 0];
+      av[k] = act[i < n_rec ? i : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pin(uv[k]);
+      pin(av[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * kRed;
+      if (i < n_rec) {
+        const float d = uv[k] - av[k];
+        rec += d * d;
+        du[i] = 2.0f * d * ia;
+      }
+    }
   }
-  for (int i = threadIdx.x; i < rows * L; i += kRed) {
-    const int r = i / L, k = i - r * L;
-    kl += kl_elem(head[(size_t)r * 2 * L + k], head[(size_t)r * 2 * L + L + k]);
+  for (int i0 = threadIdx.x; i0 < n_kl; i0 += 4 * kRed) {
+    float mv[4], lv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * kRed < n_kl ? i0 + k * kRed : 0;
+      const int r = i / L, c = i - r * L;
+      mv[k] = head[(size_t)r * 2 * L + c];
+      lv[k] = head[(size_t)r * 2 * L + L + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pin(mv[k]);
+      pin(lv[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i0 + k * kRed < n_kl) kl += kl_elem(mv[k], lv[k]);
   }
   rec = block_sum(rec, sm);
   kl = block_sum(kl, sm);
@@ -150,19 +205,38 @@ __global__ void vae_latent_bwd_kernel(const float* __restrict__ head, const floa
   const int r = i / L, k = i - r * L;
   const float mean = head[(size_t)r * 2 * L + k];
   const float lsr = head[(size_t)r * 2 * L + L + k];
+  const float g = dz[i];
+  float ev = eps[i];
+  pin(ev);
   const float sd = expf(fminf(fmaxf(lsr, kVaeLsMin), kVaeLsMax));
   const float c = beta * inv_rows / (float)L;
-  const float g = dz[i];
   dhead[(size_t)r * 2 * L + k] = g + c * mean;
   const bool inside = lsr >= kVaeLsMin && lsr <= kVaeLsMax;
-  dhead[(size_t)r * 2 * L + L + k] = inside ? (g * eps[i] + c * (sd - 1.0f / sd)) * sd : 0.f;
+  dhead[(size_t)r * 2 * L + L + k] = inside ? (g * ev + c * (sd - 1.0f / sd)) * sd : 0.f;
 }
 
 __global__ void vae_kl_rows_kernel(const float* __restrict__ head, int rows, int L, float* __restrict__ kl) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float s = 0.f;
-  for (int k = 0; k < L; ++k) s += kl_elem(head[(size_t)r * 2 * L + k], head[(size_t)r * 2 * L + L + k]);
+  const float* __restrict__ hr = head + (size_t)r * 2 * L;
+  for (int k0 = 0; k0 < L; k0 += 4) {  // four latent dimensions per pass, their 8 loads in flight together
+    float mv[4], lv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u < L ? k0 + u : L - 1;
+      mv[u] = hr[k];
+      lv[u] = hr[L + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      pin(mv[u]);
+      pin(lv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < L) s += kl_elem(mv[u], lv[u]);
+  }
   kl[r] = s / (float)L;
 }
 
@@ -290,9 +364,13 @@ __device__ __forceinline__ float quantile_rows(const float* __restrict__ x, int6
   if (threadIdx.x < 34) cnt[threadIdx.x] = 0;
   uint32_t kreg[ROWS];
 #pragma unroll
-  for (int j = 0; j < ROWS; ++j) {  // all loads in flight at once
+  for (int j = 0; j < ROWS; ++j) {
+    // all loads in flight at once: clamped address + select.  ("i < n ? f2key(x[i]) : ~0u" compiles to an exec-masked
+    // load with its own s_waitcnt vmcnt(0) per row: ROWS serial round trips, most of this kernel's time.)
     const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
-    kreg[j] = i < n ? f2key(x[i]) : 0xffffffffu;
+    const bool ok = i < n;
+    const float xv = x[ok ? i : 0];
+    kreg[j] = f2key(xv) | (ok ? 0u : 0xffffffffu);  // (an OR, not a select: a select is turned back into a branch)
   }
   __syncthreads();
   uint32_t n_le;
@@ -496,12 +574,35 @@ __global__ __launch_bounds__(256) void qsel_finish_kernel(int64_t n, float q, ui
 }
 
 // ---------------- CPQ ----------------
+// Ensemble outputs are [n][stride].  SMALL (n <= kEns, host-checked: every reference config) requests all members of
+// an element together as straight-line code -- members past n re-read member 0 and are dropped by a select -- so the
+// loads of one batch row (targets, online nets, reward, done) overlap; the counted loops of the general form wait for
+// each member in turn (cpq_critic_loss: 8 serial round trips per row before).  Same fminf / accumulation order, same
+// bits.
+constexpr int kEns = 4;
+template <bool SMALL>
+__device__ __forceinline__ void load_members(const float* __restrict__ q, int n, int stride, int i, float (&v)[kEns]) {
+  static_assert(SMALL, "general form: counted loops at the call site");
+#pragma unroll
+  for (int e = 0; e < kEns; ++e) v[e] = q[(size_t)(e < n ? e : 0) * stride + i];
+}
+template <bool SMALL = false>
 __device__ __forceinline__ float min_over(const float* __restrict__ q, int n, int stride, int i) {
-  float v = q[i];
-  for (int e = 1; e < n; ++e) v = fminf(v, q[(size_t)e * stride + i]);
-  return v;
+  if constexpr (SMALL) {
+    float v[kEns];
+    load_members<true>(q, n, stride, i, v);
+    float m = v[0];
+#pragma unroll
+    for (int e = 1; e < kEns; ++e) m = e < n ? fminf(m, v[e]) : m;
+    return m;
+  } else {
+    float v = q[i];
+    for (int e = 1; e < n; ++e) v = fminf(v, q[(size_t)e * stride + i]);
+    return v;
+  }
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __restrict__ q_old, int n_q_old,
                                                                const float* __restrict__ qc_old, int n_qc_old,
                                                                const float* __restrict__ q, int n_q,
@@ -513,14 +614,27 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
   __shared__ float sm[20];
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
-    const float qt = min_over(q_old, n_q_old, rows, b);
-    const float qct = min_over(qc_old, n_qc_old, rows, b);
+    const float qt = min_over<SMALL>(q_old, n_q_old, rows, b);
+    const float qct = min_over<SMALL>(qc_old, n_qc_old, rows, b);
     // backup = r + gamma*(1-done)*(qc_targ<=q_thres)*q_targ      cpq.py:145-146
-    const float backup = rew[b] + gamma * (1.0f - done[b]) * (qct <= q_thres ? 1.0f : 0.0f) * qt;
-    for (int e = 0; e < n_q; ++e) {
-      const float d = q[(size_t)e * rows + b] - backup;
-      loss += d * d;
-      dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+    if constexpr (SMALL) {
+      float qv[kEns];
+      load_members<true>(q, n_q, rows, b, qv);
+      const float backup = rew[b] + gamma * (1.0f - done[b]) * (qct <= q_thres ? 1.0f : 0.0f) * qt;
+#pragma unroll
+      for (int e = 0; e < kEns; ++e)
+        if (e < n_q) {
+          const float d = qv[e] - backup;
+          loss += d * d;
+          dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+        }
+    } else {
+      const float backup = rew[b] + gamma * (1.0f - done[b]) * (qct <= q_thres ? 1.0f : 0.0f) * qt;
+      for (int e = 0; e < n_q; ++e) {
+        const float d = q[(size_t)e * rows + b] - backup;
+        loss += d * d;
+        dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+      }
     }
   }
   loss = block_sum(loss, sm);
@@ -528,6 +642,7 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
 }
 
 // mean over the (global) batch of qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184,187
+template <bool SMALL>
 __device__ __forceinline__ float cpq_ood_mean_block(const float* __restrict__ qc_sampled, int n_qc_old,
                                                     const float* __restrict__ kl, const float quant,
                                                     int n_samples, int rows, float inv_rows, float* sm) {
@@ -539,7 +654,7 @@ __device__ __forceinline__ float cpq_ood_mean_block(const float* __restrict__ qc
 #pragma unroll 5
     for (int j = 0; j < n_samples; ++j) {
       const int i = j * rows + b;
-      const float v = min_over(qc_sampled, n_qc_old, nr, i);
+      const float v = min_over<SMALL>(qc_sampled, n_qc_old, nr, i);
       s += kl[i] >= quant ? v : 0.f;
     }
     ood += s / (float)n_samples;
@@ -547,17 +662,19 @@ __device__ __forceinline__ float cpq_ood_mean_block(const float* __restrict__ qc
   return block_sum(ood, sm) * inv_rows;
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(kRed) void cpq_ood_mean_kernel(const float* __restrict__ qc_sampled, int n_qc_old,
                                                             const float* __restrict__ kl,
                                                             const float* __restrict__ quantile, int n_samples,
                                                             int rows, float inv_rows, float* __restrict__ out) {
   __shared__ float sm[20];
-  const float ood = cpq_ood_mean_block(qc_sampled, n_qc_old, kl, quantile[0], n_samples, rows, inv_rows, sm);
+  const float ood = cpq_ood_mean_block<SMALL>(qc_sampled, n_qc_old, kl, quantile[0], n_samples, rows, inv_rows, sm);
   if (threadIdx.x == 0) out[0] = ood;
 }
 
 // quantile + OOD mean in one launch (single-GPU step, n_samples * rows <= 32 * 1024): the KL rows are read once into
 // registers for the select, the masked mean re-reads them from L2 in the order of cpq_ood_mean_kernel (same bits)
+template <bool SMALL>
 __global__ __launch_bounds__(kRed) void cpq_ood_stat_kernel(const float* __restrict__ qc_sampled, int n_qc_old,
                                                             const float* __restrict__ kl, float q, int n_samples,
                                                             int rows, float inv_rows, float* __restrict__ quant_out,
@@ -566,7 +683,7 @@ __global__ __launch_bounds__(kRed) void cpq_ood_stat_kernel(const float* __restr
   __shared__ uint32_t s_min[17];
   __shared__ float sm[20];
   const float quant = quantile_regs(kl, (int64_t)n_samples * rows, q, cnt, s_min);
-  const float ood = cpq_ood_mean_block(qc_sampled, n_qc_old, kl, quant, n_samples, rows, inv_rows, sm);
+  const float ood = cpq_ood_mean_block<SMALL>(qc_sampled, n_qc_old, kl, quant, n_samples, rows, inv_rows, sm);
   if (threadIdx.x == 0) {
     quant_out[0] = quant;
     out[0] = ood;
@@ -580,6 +697,7 @@ struct OodArgs {  // non-NULL qc_sampled: compute the OOD mean here (single-GPU 
   int32_t n_qc_old, n_samples;
 };
 
+template <bool SMALL>
 __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
     const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
     float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
@@ -589,14 +707,28 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
   __shared__ float sm[20];
   float ood_here = 0.f;
   if (oa.qc_sampled)
-    ood_here = cpq_ood_mean_block(oa.qc_sampled, oa.n_qc_old, oa.kl, oa.quantile[0], oa.n_samples, rows, inv_rows, sm);
+    ood_here =
+        cpq_ood_mean_block<SMALL>(oa.qc_sampled, oa.n_qc_old, oa.kl, oa.quantile[0], oa.n_samples, rows, inv_rows, sm);
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
-    const float backup = cost[b] + gamma * min_over(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
-    for (int e = 0; e < n_qc; ++e) {
-      const float d = qc[(size_t)e * rows + b] - backup;
-      loss += d * d;
-      dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+    if constexpr (SMALL) {
+      float qv[kEns];
+      load_members<true>(qc, n_qc, rows, b, qv);
+      const float backup = cost[b] + gamma * min_over<true>(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
+#pragma unroll
+      for (int e = 0; e < kEns; ++e)
+        if (e < n_qc) {
+          const float d = qv[e] - backup;
+          loss += d * d;
+          dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+        }
+    } else {
+      const float backup = cost[b] + gamma * min_over(qc_old_next, n_qc_old, rows, b);  // cpq.py:161
+      for (int e = 0; e < n_qc; ++e) {
+        const float d = qc[(size_t)e * rows + b] - backup;
+        loss += d * d;
+        dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+      }
     }
   }
   loss = block_sum(loss, sm);
@@ -630,6 +762,7 @@ __global__ void cpq_alpha_step_kernel(const float* __restrict__ ood_mean, float 
   if (stat) stat[1] = stat_share * expf(la);
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(kRed) void cpq_actor_loss_kernel(const float* __restrict__ q, int n_q,
                                                               const float* __restrict__ qc, int n_qc, int rows,
                                                               float q_thres, float inv_rows,
@@ -639,12 +772,25 @@ __global__ __launch_bounds__(kRed) void cpq_actor_loss_kernel(const float* __res
   float loss = 0.f;
   for (int b = threadIdx.x; b < rows; b += kRed) {
     int am = 0;
-    float qm = q[b];
-    for (int e = 1; e < n_q; ++e) {
-      const float v = q[(size_t)e * rows + b];
-      if (v < qm) { qm = v; am = e; }
+    float qm;
+    if constexpr (SMALL) {
+      float qv[kEns];
+      load_members<true>(q, n_q, rows, b, qv);
+      qm = qv[0];
+#pragma unroll
+      for (int e = 1; e < kEns; ++e) {
+        const bool lt = e < n_q && qv[e] < qm;
+        qm = lt ? qv[e] : qm;
+        am = lt ? e : am;
+      }
+    } else {
+      qm = q[b];
+      for (int e = 1; e < n_q; ++e) {
+        const float v = q[(size_t)e * rows + b];
+        if (v < qm) { qm = v; am = e; }
+      }
     }
-    const float mask = min_over(qc, n_qc, rows, b) <= q_thres ? 1.0f : 0.0f;
+    const float mask = min_over<SMALL>(qc, n_qc, rows, b) <= q_thres ? 1.0f : 0.0f;
     loss -= mask * qm;
     for (int e = 0; e < n_q; ++e) dq[(size_t)e * rows + b] = e == am ? -mask * inv_rows : 0.f;
   }
@@ -903,8 +1049,13 @@ int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_ol
                          float gamma, float q_thres, int32_t rows_global, float* dq, float* stat, void* stream) {
   if (!q_old || !qc_old || !q || !rew || !done || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_critic_loss_kernel, dim3(1), dim3(kRed), 0, S, q_old, n_q_old, qc_old, n_qc_old, q, n_q,
-                     rew, done, rows, gamma, q_thres, 1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
+  const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
+  if (n_q_old <= kEns && n_qc_old <= kEns && n_q <= kEns)
+    hipLaunchKernelGGL(cpq_critic_loss_kernel<true>, dim3(1), dim3(kRed), 0, S, q_old, n_q_old, qc_old, n_qc_old, q, n_q,
+                       rew, done, rows, gamma, q_thres, inv, dq, stat);
+  else
+    hipLaunchKernelGGL(cpq_critic_loss_kernel<false>, dim3(1), dim3(kRed), 0, S, q_old, n_q_old, qc_old, n_qc_old, q,
+                       n_q, rew, done, rows, gamma, q_thres, inv, dq, stat);
   LAUNCH_CHECK();
 }
 
@@ -912,8 +1063,13 @@ int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl
                       int32_t n_samples, int32_t rows, int32_t rows_global, float* out, void* stream) {
   if (!qc_sampled || !kl || !quantile || !out || rows < 1 || n_samples < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_ood_mean_kernel, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, quantile, n_samples,
-                     rows, 1.0f / (float)(rows_global > 0 ? rows_global : rows), out);
+  const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
+  if (n_qc_old <= kEns)
+    hipLaunchKernelGGL(cpq_ood_mean_kernel<true>, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, quantile,
+                       n_samples, rows, inv, out);
+  else
+    hipLaunchKernelGGL(cpq_ood_mean_kernel<false>, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, quantile,
+                       n_samples, rows, inv, out);
   LAUNCH_CHECK();
 }
 
@@ -922,8 +1078,13 @@ int osrl_cpq_ood_stat(const float* qc_sampled, int32_t n_qc_old, const float* kl
   if (!qc_sampled || !kl || !quant_out || !out || rows < 1 || n_samples < 1 || q < 0.f || q > 1.f) return -1;
   if ((int64_t)n_samples * rows > (int64_t)32 * kRed) return -2;  // keys must fit the workgroup's registers
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_ood_stat_kernel, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, q, n_samples, rows,
-                     1.0f / (float)(rows_global > 0 ? rows_global : rows), quant_out, out);
+  const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
+  if (n_qc_old <= kEns)
+    hipLaunchKernelGGL(cpq_ood_stat_kernel<true>, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, q, n_samples, rows,
+                       inv, quant_out, out);
+  else
+    hipLaunchKernelGGL(cpq_ood_stat_kernel<false>, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, q, n_samples,
+                       rows, inv, quant_out, out);
   LAUNCH_CHECK();
 }
 
@@ -933,10 +1094,15 @@ int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* 
                        float* stat, void* stream) {
   if (!qc_old_next || !qc || !cost || (ood_mean && !log_alpha) || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
-                     const_cast<float*>(ood_mean), cost, rows, gamma, qc_thres, alpha_lr,
-                     1.0f / (float)(rows_global > 0 ? rows_global : rows), stat_share, log_alpha, dq, stat,
-                     OodArgs{nullptr, nullptr, nullptr, 0, 0});
+  const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
+  if (n_qc_old <= kEns && n_qc <= kEns)
+    hipLaunchKernelGGL(cpq_cost_loss_kernel<true>, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
+                       const_cast<float*>(ood_mean), cost, rows, gamma, qc_thres, alpha_lr, inv, stat_share, log_alpha,
+                       dq, stat, OodArgs{nullptr, nullptr, nullptr, 0, 0});
+  else
+    hipLaunchKernelGGL(cpq_cost_loss_kernel<false>, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
+                       const_cast<float*>(ood_mean), cost, rows, gamma, qc_thres, alpha_lr, inv, stat_share, log_alpha,
+                       dq, stat, OodArgs{nullptr, nullptr, nullptr, 0, 0});
   LAUNCH_CHECK();
 }
 
@@ -957,9 +1123,14 @@ int osrl_cpq_cost_loss_ood(const float* qc_sampled, int32_t n_qc_sampled, const 
       !log_alpha || !dq || rows < 1)
     return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_cost_loss_kernel, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc, ood_mean_out,
-                     cost, rows, gamma, qc_thres, alpha_lr, 1.0f / (float)rows, 1.0f, log_alpha, dq, stat,
-                     OodArgs{qc_sampled, kl, quantile, n_qc_sampled, n_samples});
+  if (n_qc_old <= kEns && n_qc <= kEns && n_qc_sampled <= kEns)
+    hipLaunchKernelGGL(cpq_cost_loss_kernel<true>, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
+                       ood_mean_out, cost, rows, gamma, qc_thres, alpha_lr, 1.0f / (float)rows, 1.0f, log_alpha, dq, stat,
+                       OodArgs{qc_sampled, kl, quantile, n_qc_sampled, n_samples});
+  else
+    hipLaunchKernelGGL(cpq_cost_loss_kernel<false>, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
+                       ood_mean_out, cost, rows, gamma, qc_thres, alpha_lr, 1.0f / (float)rows, 1.0f, log_alpha, dq, stat,
+                       OodArgs{qc_sampled, kl, quantile, n_qc_sampled, n_samples});
   LAUNCH_CHECK();
 }
 
@@ -967,8 +1138,13 @@ int osrl_cpq_actor_loss(const float* q, int32_t n_q, const float* qc, int32_t n_
                         int32_t rows_global, float* dq, float* stat, void* stream) {
   if (!q || !qc || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(cpq_actor_loss_kernel, dim3(1), dim3(kRed), 0, S, q, n_q, qc, n_qc, rows, q_thres,
-                     1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
+  const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
+  if (n_q <= kEns && n_qc <= kEns)
+    hipLaunchKernelGGL(cpq_actor_loss_kernel<true>, dim3(1), dim3(kRed), 0, S, q, n_q, qc, n_qc, rows, q_thres, inv, dq,
+                       stat);
+  else
+    hipLaunchKernelGGL(cpq_actor_loss_kernel<false>, dim3(1), dim3(kRed), 0, S, q, n_q, qc, n_qc, rows, q_thres, inv, dq,
+                       stat);
   LAUNCH_CHECK();
 }
 

@@ -76,8 +76,16 @@ __device__ long long g_wg_log[16384][4];
 
 namespace {
 
+// max(x, 0) as ONE v_max_f32: fmaxf() compiles to a canonicalising v_max x,x in front of the max (IEEE sNaN quieting),
+// and every VALU instruction of an epilogue is paid in MFMA issue slots (4 cycles per wave each).  Same value for
+// every non-NaN input.
+__device__ __forceinline__ float relu1(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
 __device__ __forceinline__ float act_fwd(int act, float x) {
-  if (act == OSRL_ACT_RELU) return fmaxf(x, 0.0f);
+  if (act == OSRL_ACT_RELU) return relu1(x);
   if (act == OSRL_ACT_TANH) return tanhf(x);
   return x;
 }
@@ -616,6 +624,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
 // once, each wide layer is  bias-initialised accumulators -> k-loop -> barrier -> activation into the LDS tile (in
 // place), the narrow head (<= 32 outputs, always the last layer) splits K over the 4 waves with ALL its weight
 // fragments preloaded before the previous layer's epilogue, partial tiles meet in LDS and go straight to global.
+// The wide layers compute the TRANSPOSED tile: the packed weight fragment is the MFMA's A operand and the activation
+// fragment its B operand (both are "16 lanes x 4 consecutive k", so loads and packing are those of the other kernels),
+// which leaves a lane with out[row = lane & 15][4 consecutive columns] -- exactly the row-major float4 the next
+// layer's fragment read wants.  The epilogue is then one ds_write_b128 per 16x16 tile in the (conflict-free) pattern
+// of the fragment reads, instead of four ds_write_b32 down a column: 4.85k -> see profiles (r2_mlp_phase_nb.txt) cycles
+// per 400-wide layer.  Same products, same accumulation order per output: same bits.
 // Eligibility (host): no saved activations, hidden layers of 13-16 (NCB = 4) or 25-28 (NCB = 7) column blocks, narrow
 // last layer with >= 4 k-steps; anything else takes mlp_fwd_kernel.
 struct NbArgs {
@@ -630,9 +644,39 @@ struct NbArgs {
 #endif
 constexpr int kNbRb = 5;  // row blocks per tile (80 rows)
 
+// Biases of a wave's column blocks, branch-free (clamped address + select): every load is in flight at once.  The
+// obvious "col < N ? bias[col] : 0.f" compiles to one exec-masked global_load + s_waitcnt vmcnt(0) PER BLOCK, i.e.
+// 7 serial L2 round trips in front of every wide layer: ~9k of the ~10k cycles a layer took beyond its MFMAs
+// (profiles/r2_mlp_phase_nb.txt: the same excess for the 5-step and the 25-step layer).
+// nb_bias only REQUESTS the values (columns past N read bias[0]); nb_bias_acc, called after the first weight /
+// activation fragments are requested and fenced from them by a scheduling barrier, turns them into the accumulators'
+// start values (acc = bias: no add in the epilogue), so the bias round trip and the first weight round trip overlap.
+// (Accumulator tiles are TRANSPOSED, see nb_mm: a lane holds columns 4 * (lane >> 4) + 0..3 of column block c.)
+template <int CNT>
+__device__ __forceinline__ void nb_bias(const float* __restrict__ bias, int col0, int N, int lane, f32x4 (&braw)[CNT]) {
+#pragma unroll
+  for (int c = 0; c < CNT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = col0 + c * 16 + 4 * (lane >> 4) + r;
+      braw[c][r] = bias[col < N ? col : 0];
+    }
+}
+template <int CNT, int R>
+__device__ __forceinline__ void nb_bias_acc(const f32x4 (&braw)[CNT], int col0, int N, int lane, f32x4 (&acc)[R][CNT]) {
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) {
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = col0 + c * 16 + 4 * (lane >> 4) + r < N ? braw[c][r] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) acc[rb][c] = bv;
+  }
+}
+
 template <int CNT>
 __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
-                                      f32x4 (&acc)[kNbRb][CNT]) {
+                                      int N, const f32x4 (&braw)[CNT], f32x4 (&acc)[kNbRb][CNT], int pl) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
@@ -647,6 +691,9 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
 #pragma unroll
     for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
+  if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
   auto step = [&](auto s_c, int kc) {
     constexpr int s = decltype(s_c)::value;
     const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
@@ -661,7 +708,7 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rb][t], b[s][c][t], acc[rb][c], 0, 0, 0);
+          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][c][t], a[s][rb][t], acc[rb][c], 0, 0, 0);
 #if OSRL_NB_INTERLEAVE
     // next step's loads one at a time, each followed by a few of THIS step's MFMAs: with one wave per SIMD nothing else
     // can fill the MFMA pipe while the ~35 address / load instructions of a step issue (540 cycles per 16-deep k-step
@@ -693,43 +740,57 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
   if (kc < nk) step(integral_constant<int, 0>{}, kc);
 }
 
-template <int CNT, int ACT>
-__device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&acc)[kNbRb][CNT], int cb0, int N, int lane) {
+// R row blocks of CNT column blocks.  RAGGED (N not a multiple of 16): columns past N are written as zeros, the k
+// padding of the next layer; otherwise the select is compiled out (the epilogue is VALU-bound: accumulator read +
+// activation + select per element was ~36 cycles x 124 elements per wave and layer).
+template <int CNT, int R, int ACT, bool RAGGED>
+__device__ __forceinline__ void nb_epilogue_core(float* lds, int lda, const f32x4 (&acc)[R][CNT], int cb0, int rb0, int N,
+                                                 int lane) {
 #pragma unroll
   for (int c = 0; c < CNT; ++c) {
-    const int col = (cb0 + c) * 16 + (lane & 15);
-    const bool live = col < N;
-    float* dst = lds + ((lane >> 4) * 4) * lda + col;
+    const int col = (cb0 + c) * 16 + 4 * (lane >> 4);
+    float* dst = lds + (rb0 * 16 + (lane & 15)) * lda + col;
 #pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb)
+    for (int rb = 0; rb < R; ++rb) {
+      f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = act_fwd(ACT, acc[rb][c][r]);
-        dst[(rb * 16 + r) * lda] = live ? v : 0.f;  // zero = k padding of the next layer
+        v[r] = act_fwd(ACT, acc[rb][c][r]);
+        if (RAGGED) v[r] = col + r < N ? v[r] : 0.f;
       }
+      *reinterpret_cast<f32x4*>(dst + rb * 16 * lda) = v;
+    }
+  }
+}
+template <int CNT, int R>
+__device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&acc)[R][CNT], int cb0, int rb0, int N,
+                                            int act, int lane) {
+  const bool ragged = (N & 15) != 0;
+  if (act == OSRL_ACT_RELU) {
+    if (ragged) nb_epilogue_core<CNT, R, OSRL_ACT_RELU, true>(lds, lda, acc, cb0, rb0, N, lane);
+    else nb_epilogue_core<CNT, R, OSRL_ACT_RELU, false>(lds, lda, acc, cb0, rb0, N, lane);
+  } else if (act == OSRL_ACT_TANH) {
+    nb_epilogue_core<CNT, R, OSRL_ACT_TANH, true>(lds, lda, acc, cb0, rb0, N, lane);
+  } else {
+    nb_epilogue_core<CNT, R, OSRL_ACT_ID, true>(lds, lda, acc, cb0, rb0, N, lane);
   }
 }
 
 template <int CNT>
 __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
-                                              const float* __restrict__ bias, int act, int cb0, int lane) {
+                                              const float* __restrict__ bias, int act, int cb0, int lane, int pl) {
+  (void)pl;  // layer number, for the debug build's phase stamps only
+  f32x4 braw[CNT];
+  nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
   f32x4 acc[kNbRb][CNT];
-#pragma unroll
-  for (int c = 0; c < CNT; ++c) {
-    const int col = (cb0 + c) * 16 + (lane & 15);
-    const float bv = col < N ? bias[col] : 0.f;
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) acc[rb][c] = f32x4{bv, bv, bv, bv};
-  }
-  nb_mm<CNT>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, acc);
+  nb_mm<CNT>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
+  PHASE_STAMP(2 + 4 * pl);
   __syncthreads();  // every wave finished reading the previous activations
-  if (act == OSRL_ACT_RELU)
-    nb_epilogue<CNT, OSRL_ACT_RELU>(lds, lda, acc, cb0, N, lane);
-  else if (act == OSRL_ACT_TANH)
-    nb_epilogue<CNT, OSRL_ACT_TANH>(lds, lda, acc, cb0, N, lane);
-  else
-    nb_epilogue<CNT, OSRL_ACT_ID>(lds, lda, acc, cb0, N, lane);
+  PHASE_STAMP(3 + 4 * pl);
+  nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
+  PHASE_STAMP(4 + 4 * pl);
   __syncthreads();
+  PHASE_STAMP(5 + 4 * pl);
 }
 
 // ---- 4q + 1 column blocks (400-wide layers: 25): every wave owns q blocks, the last block is SHARED by rows ----------
@@ -738,7 +799,8 @@ __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N,
 // NX = row blocks of the shared column this wave owns (2: wave 0, 1: the others), starting at rbx0.
 template <int CNT, int NX>
 __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
-                                        int colx, int rbx0, f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX]) {
+                                        int colx, int rbx0, int N, const f32x4 (&braw)[CNT], const f32x4 (&brawx)[1],
+                                        f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX], int pl) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
@@ -758,6 +820,15 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
 #pragma unroll
     for (int i = 0; i < NX; ++i) ax[0][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + k0 * 16);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
+  {
+    f32x4 xa[NX][1];
+    nb_bias_acc<1, NX>(brawx, colx, N, lane, xa);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xacc[i] = xa[i][0];
+  }
+  if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
   auto step = [&](auto s_c, int kc) {
     constexpr int s = decltype(s_c)::value;
     const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
@@ -775,10 +846,10 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rb][t], b[s][c][t], acc[rb][c], 0, 0, 0);
+          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][c][t], a[s][rb][t], acc[rb][c], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < NX; ++i)
-        xacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s][i][t], b[s][CNT][t], xacc[i], 0, 0, 0);
+        xacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][CNT][t], ax[s][i][t], xacc[i], 0, 0, 0);
     }
 #if OSRL_NB_INTERLEAVE
     constexpr int kTot = 4 * (kNbRb * CNT + NX), kPer = kTot / (CNT + 1 + kNbRb + NX + 1);
@@ -811,39 +882,26 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
 template <int CNT, int NX>
 __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int N, const float* __restrict__ P,
                                                 const float* __restrict__ bias, int act, int cb0, int cbx, int rbx0,
-                                                int lane) {
+                                                int lane, int pl) {
+  (void)pl;
   f32x4 acc[kNbRb][CNT], xacc[NX];
-#pragma unroll
-  for (int c = 0; c < CNT; ++c) {
-    const int col = (cb0 + c) * 16 + (lane & 15);
-    const float bv = col < N ? bias[col] : 0.f;
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) acc[rb][c] = f32x4{bv, bv, bv, bv};
-  }
-  const int colx = cbx * 16 + (lane & 15);
-  const bool livex = colx < N;
-  {
-    const float bv = livex ? bias[colx] : 0.f;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xacc[i] = f32x4{bv, bv, bv, bv};
-  }
-  nb_mm_x<CNT, NX>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, acc, xacc);
+  f32x4 braw[CNT], brawx[1];
+  nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
+  nb_bias<1>(bias, cbx * 16, N, lane, brawx);
+  nb_mm_x<CNT, NX>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl);
+  PHASE_STAMP(2 + 4 * pl);
   __syncthreads();  // every wave finished reading the previous activations
-  if (act == OSRL_ACT_RELU)
-    nb_epilogue<CNT, OSRL_ACT_RELU>(lds, lda, acc, cb0, N, lane);
-  else if (act == OSRL_ACT_TANH)
-    nb_epilogue<CNT, OSRL_ACT_TANH>(lds, lda, acc, cb0, N, lane);
-  else
-    nb_epilogue<CNT, OSRL_ACT_ID>(lds, lda, acc, cb0, N, lane);
-  float* dst = lds + ((lane >> 4) * 4) * lda + colx;
+  PHASE_STAMP(3 + 4 * pl);
+  nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
+  {
+    f32x4 xa[NX][1];
 #pragma unroll
-  for (int i = 0; i < NX; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = act_fwd(act, xacc[i][r]);
-      dst[((rbx0 + i) * 16 + r) * lda] = livex ? v : 0.f;
-    }
+    for (int i = 0; i < NX; ++i) xa[i][0] = xacc[i];
+    nb_epilogue<1, NX>(lds, lda, xa, cbx, rbx0, N, act, lane);
+  }
+  PHASE_STAMP(4 + 4 * pl);
   __syncthreads();
+  PHASE_STAMP(5 + 4 * pl);
 }
 
 // SHARED: every wide layer has 4 (NCB - 1) + 1 column blocks (the 400-wide VAE encoder / decoder): NCB - 1 blocks per
@@ -868,14 +926,31 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
     const float* __restrict__ s0 = a.in.src0;
     const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
     constexpr int kColChunks = 8;  // K0 <= 128 (host-checked)
+    // the row maps as straight-line code on values read ONCE: one unsigned division per (row, source) whose
+    // reciprocal set-up is common to the five passes, selects instead of the three-way branch of map_row().  (With
+    // map_row() inlined per pass the compiler re-read the descriptor from the kernel arguments in every branch arm:
+    // ~20 s_load + s_waitcnt lgkmcnt(0) round trips in front of the tile's loads.)
+    // The values are parked in VECTOR registers (the opaque asm makes them non-rematerialisable): there are plenty
+    // before the accumulators exist, while the scalar file is full of layer descriptors by now.
+    unsigned dv0 = a.in.map0 == OSRL_MAP_ID ? 1u : (unsigned)a.in.div0;
+    unsigned dv1 = a.in.map1 == OSRL_MAP_ID ? 1u : (unsigned)a.in.div1;
+    unsigned mod0 = a.in.map0 == OSRL_MAP_MOD, idn0 = a.in.map0 == OSRL_MAP_ID;
+    unsigned mod1 = a.in.map1 == OSRL_MAP_MOD, idn1 = a.in.map1 == OSRL_MAP_ID;
+    int d0v = d0, d1v = d1, rows_v = rows, K0v = K0;
+    asm volatile("" : "+v"(dv0), "+v"(dv1), "+v"(mod0), "+v"(idn0), "+v"(mod1), "+v"(idn1));
+    asm volatile("" : "+v"(d0v), "+v"(d1v), "+v"(rows_v), "+v"(K0v));
+    auto mapped = [](unsigned r, unsigned mod, unsigned idn, unsigned dv) -> unsigned {
+      const unsigned q = r / dv, rem = r - q * dv;  // dv == 1 for the identity map
+      return mod ? rem : (idn ? r : q);
+    };
     float v[kNbRb][kColChunks];
 #pragma unroll
     for (int p = 0; p < kNbRb; ++p) {
       const int gr = row0 + p * 16 + rl;
-      const bool rok = gr < rows;
-      const int grc = rok ? gr : rows - 1;
-      const float* p0 = s0 + (size_t)map_row(grc, a.in.map0, a.in.div0) * d0;
-      const float* p1 = s1 + (size_t)map_row(grc, a.in.map1, a.in.div1) * d1 - d0;
+      const bool rok = gr < rows_v;
+      const unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
+      const float* p0 = s0 + (size_t)mapped(grc, mod0, idn0, dv0) * d0v;
+      const float* p1 = s1 + (size_t)mapped(grc, mod1, idn1, dv1) * d1v - d0v;
 #pragma unroll
       for (int j = 0; j < kColChunks; ++j) {
         const int c = j * 16 + cl;
@@ -901,22 +976,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
     if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
       const int q = nblk >> 2;
       if (wave == 0)
-        nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane);
+        nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane, l);
       else
         nb_wide_layer_x<NCB - 1, 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, 4 * q,
-                                    wave + 1, lane);
+                                    wave + 1, lane, l);
     } else {
       int cb0, cnt;
       wave_blocks<4>(nblk, wave, &cb0, &cnt);
       if (cnt == NCB)
-        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
       else
-        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane);
+        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
     }
-    PHASE_STAMP(2 + 4 * l);
-    PHASE_STAMP(3 + 4 * l);
-    PHASE_STAMP(4 + 4 * l);
-    PHASE_STAMP(5 + 4 * l);
   }
   {  // ---- narrow head: K split over the 4 waves, every weight fragment of a wave's share loaded up front
     const int l = L - 1;
@@ -1034,15 +1105,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
     const float* __restrict__ dy = a.g.dy[e];
     const float* __restrict__ y = a.saved.h[e][L - 1];
     const int act = a.net.acts[L - 1];
+    const float* __restrict__ ysrc = act != OSRL_ACT_ID ? y : dy;
     for (int idx = tid; idx < BM * NLp; idx += 64 * NW) {
       const int r = idx / NLp, c = idx - r * NLp;
       const int gr = row0 + r;
-      float v = 0.f;
-      if (gr < rows && c < NL) {
-        v = dy[(size_t)gr * NL + c] * oscale;
-        if (act != OSRL_ACT_ID) v *= act_bwd(act, y[(size_t)gr * NL + c] * inv_oscale);
-      }
-      lds[r * lda + c] = v;
+      // branch-free (clamped address + select): dy and y are requested together; as "if (ok) { load dy; load y }"
+      // each load sat in its own exec-masked block with a full s_waitcnt behind it
+      const bool ok = gr < rows && c < NL;
+      const size_t off = ok ? (size_t)gr * NL + c : 0;
+      const float dyv = dy[off];
+      float yv = ysrc[off];  // (the identity activation re-reads dy: no branch between the two requests)
+      asm volatile("" : "+v"(yv));  // keeps the compiler from sinking this load into the activation branch below
+      float v = dyv * oscale;
+      if (act != OSRL_ACT_ID) v *= act_bwd(act, yv * inv_oscale);
+      lds[r * lda + c] = ok ? v : 0.f;
     }
     __syncthreads();
     if (a.g.dz[e][L - 1]) tile_to_global(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);

@@ -45,8 +45,54 @@ def mk(E, dims, acts, dev, tile_rows=0):
     return grp, d
 
 
+def glue_bench(dev):
+    """The single-workgroup / row-local kernels on the CPQ step's latency chain at C2 sizes (B=2048, N=10, ad=2, L=4)
+    plus the two N*B-row forwards and the 2048-row backward they wait for."""
+    B, N, ad, Lz = 2048, 10, 2, 4
+    r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    out, st = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    x = r(N * B).abs()
+    print(f"quantile n=20480: {timeit(lambda: G.quantile(x, N * B, 0.75, out)):.2f} us")
+    qcs, kl = r(2, N * B), r(N * B).abs()
+    print(f"cpq_ood_stat: {timeit(lambda: G.cpq_ood_stat(qcs, 2, kl, 0.75, N, B, B, out, out[1:])):.2f} us")
+    head, eps, u, act = r(B, 2 * Lz), r(B, Lz), r(B, ad), r(B, ad)
+    du, dh = torch.empty(B, ad, device=dev), torch.empty(B, 2 * Lz, device=dev)
+    print(f"vae_loss: {timeit(lambda: G.vae_loss(u, act, head, B, ad, Lz, 0.5, B, du, st)):.2f} us")
+    dzl = r(B, Lz)
+    print(f"vae_latent_bwd: {timeit(lambda: G.vae_latent_bwd(head, eps, dzl, B, Lz, 0.5, B, dh)):.2f} us")
+    hk, klr = r(N * B, 2 * Lz), torch.empty(N * B, device=dev)
+    print(f"vae_kl_rows: {timeit(lambda: G.vae_kl_rows(hk, N * B, Lz, klr)):.2f} us")
+    q2, qo, qco, rew, done = r(2, B), r(2, B), r(2, B), r(B), (torch.rand(B, device=dev) < 0.01).float()
+    dq = torch.empty(2, B, device=dev)
+    print(f"cpq_critic_loss: {timeit(lambda: G.cpq_critic_loss(qo, 2, qco, 2, q2, 2, rew, done, B, 0.99, 1.0, B, dq, st)):.2f} us")
+    la = torch.zeros(1, device=dev)
+    print(f"cpq_cost_loss: {timeit(lambda: G.cpq_cost_loss(qco, 2, q2, 2, None, rew, B, 0.99, 1.5, 1e-4, B, 1.0, la, dq, st)):.2f} us")
+    print(f"cpq_actor_loss: {timeit(lambda: G.cpq_actor_loss(q2, 2, qco, 2, B, 1.0, B, dq, st)):.2f} us")
+    hd, ea, tu, da = r(B, 2 * ad), r(B, ad), torch.tanh(r(B, ad)), r(2, B, ad)
+    dhd = torch.empty(B, 2 * ad, device=dev)
+    print(f"gauss_head_bwd: {timeit(lambda: G.gauss_head_bwd(hd, ea, tu, da, 2, B, ad, 1.0, dhd)):.2f} us")
+    lin = lambda d: sum(a * b for a, b in zip(d[:-1], d[1:]))  # noqa: E731
+    for name, E, dims, acts in (("enc", 1, [78, 400, 400, 8], ["relu", "relu", "id"]),
+                                ("q x2", 2, [78, 256, 256, 1], ["relu", "relu", "id"])):
+        grp, d = mk(E, dims, acts, dev, 80)
+        x0, x1 = r(N * B, 76), r(N * B, 2)
+        run = MlpRun(d, N * B, False, dev)
+        t = timeit(lambda: run.forward(x0, x1))
+        print(f"fwd {name} rows=20480 tile=80: {t:.2f} us  {2.0 * N * B * E * lin(dims) / t / 1e6:.2f} TF/s")
+    for name, E, dims, acts in (("dec", 1, [80, 400, 400, 2], ["relu", "relu", "tanh"]),
+                                ("q x2", 2, [78, 256, 256, 1], ["relu", "relu", "id"])):
+        grp, d = mk(E, dims, acts, dev, 16)
+        x0, x1 = r(B, 76), r(B, dims[0] - 76)
+        run = MlpRun(d, B, True, dev)
+        run.forward(x0, x1)
+        run.setup_backward(r(E, B, dims[-1]), need_dz=True, dx_cols=(76, dims[0] - 76))
+        print(f"fwd {name} rows=2048: {timeit(lambda: run.forward(x0, x1)):.2f} us | bwd_dz {timeit(run.backward_dz):.2f} us")
+
+
 def main():
     dev = torch.device("cuda:0")
+    if "--glue" in sys.argv:
+        return glue_bench(dev)
     lin = lambda d: sum(a * b for a, b in zip(d[:-1], d[1:]))  # noqa: E731
     cfgs = [("q x2", 2, [78, 256, 256, 1], ["relu", "relu", "id"], 76),
             ("q x4", 4, [78, 256, 256, 1], ["relu", "relu", "id"], 76),

@@ -80,6 +80,13 @@ int main(int argc, char** argv) {
       printf(" %s=%.0f", names[i], sacc);
     }
     printf("  total=%.0f\n", tot);
+    if (tile == 80) {  // mlp_fwd_nb_kernel stamps the start of layer 1's k-loop (slot 14)
+      double pro = 0;
+      for (int g = 0; g < nw; ++g)
+        for (int w = 0; w < 4; ++w) pro += (double)(pa[g][w][14] - pa[g][w][5]);
+      printf("  of L1 mm: %.0f cycles from the layer's start to the first k-step (pointers, bias + first fragments, acc init)\n",
+             pro / (4.0 * nw));
+    }
   }
   // workgroup residency: how many workgroups does a CU really hold at once?
   static long long wl[16384][4];
