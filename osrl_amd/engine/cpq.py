@@ -96,16 +96,15 @@ class CPQEngine:
         self.r_costold_next = MlpRun(self.d_cost_old, B, False, dev)
         self.r_actor_obs = MlpRun(self.d_actor, B, True, dev)  # also the actor forward of the actor phase
         self.sampled = z(N * B, ad)
-        # off the critical path (it runs beside the VAE phase): capped so that phase's 128-workgroup launches keep
-        # CU slots and MFMA issue (OSRL_OOD_WG_CAP overrides; 0 = uncapped)
-        ood_tile = int(os.environ.get("OSRL_OOD_TILE", "0"))
+        # Both N*B-row forwards (target cost critics beside the VAE phase, VAE encoder beside the cost-critic phase)
+        # take the 80-row one-workgroup-per-CU kernel (csrc/mlp.hip mlp_fwd_nb_kernel): 73 / 71 us alone vs 98 / 88 us
+        # for 32-row tiles.  Its 84 KB (256-wide) / 134 KB (400-wide) of LDS per workgroup leave the chain's launches
+        # room on every CU.  (Until the kernel's epilogue / bias / stage-in rework of round 2 the capped 32-row tile
+        # loop was the better neighbour for the VAE phase: 1968 vs 1876 steps/s; now 80-row tiles give 2095 vs 2020.
+        # OSRL_OOD_TILE=0 OSRL_OOD_WG_CAP=512 restores the old form.)
+        ood_tile = int(os.environ.get("OSRL_OOD_TILE", "80"))
         self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev,
-                                    wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "0" if ood_tile else "512")),
-                                    tile_rows=ood_tile)
-        # the VAE encoder on the N*B rows runs late on the side branch, beside the short cost-critic / actor launches:
-        # the 80-row one-workgroup-per-CU kernel (csrc/mlp.hip mlp_fwd_nb_kernel; 78.6 vs 87.8 us alone, 1968 vs 1941
-        # steps/s in the step); the target cost critics on the N*B rows run beside the VAE phase, where the capped
-        # 32-row tile loop disturbs the chain least (80-row tiles there: 1876 steps/s)
+                                    wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "0")), tile_rows=ood_tile)
         self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev, wg_cap=int(os.environ.get("OSRL_ENC_WG_CAP", "0")),
                                 tile_rows=int(os.environ.get("OSRL_ENC_TILE", str(ood_tile or 80))))
         self.kl = z(N * B)
