@@ -86,6 +86,25 @@ typedef struct {
   int32_t dx_col0, dx_cols;
 } osrl_mlp_grads_t;
 
+/* Optional row-local tail of a fused-MLP launch, applied by the workgroup that owns the rows while its last tile is
+ * still in LDS (one launch and one global round trip less on the step's latency chain).  HOST struct.
+ *   OSRL_TAIL_VAE_LATENT      forward of the VAE encoder (net 0, output [rows, 2L] = mean | log_std):
+ *                             out[rows, L] = mean + exp(clamp(log_std, -4, 15)) * eps        == osrl_vae_latent
+ *   OSRL_TAIL_VAE_LATENT_BWD  backward of the VAE decoder whose dX slice (dx[0], dx_cols == L) is dL/dz:
+ *                             out[rows, 2L] = d(recon + beta KL)/d(mean | log_std)          == osrl_vae_latent_bwd
+ *                             with head = the encoder output [rows, 2L]; beta, rows_global as in that call */
+enum { OSRL_TAIL_NONE = 0, OSRL_TAIL_VAE_LATENT = 1, OSRL_TAIL_VAE_LATENT_BWD = 2 };
+typedef struct {
+  int32_t kind;
+  int32_t L;
+  const float* eps;  /* [rows, L] */
+  const float* head; /* OSRL_TAIL_VAE_LATENT_BWD only */
+  float* out;
+  float beta;          /* OSRL_TAIL_VAE_LATENT_BWD only */
+  int32_t rows_global; /* OSRL_TAIL_VAE_LATENT_BWD only: the loss is a mean over this many rows (<= 0: rows) */
+  float inv_rows_;     /* filled in by the library */
+} osrl_mlp_tail_t;
+
 /* One weight-gradient GEMM  dW[out,in] = dz^T a,  db[out] = sum_rows dz  (autograd of addmm). */
 typedef struct {
   const float* dz; /* [rows, out] */
@@ -122,6 +141,13 @@ int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl
                       const osrl_mlp_t* net1, const osrl_rows_t* in1, const osrl_mlp_acts_t* out1, void* stream);
 int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                          const osrl_mlp_grads_t* g, void* stream);
+/* The same launches followed by a row-local tail (osrl_mlp_tail_t; NULL or kind NONE = the plain call): results are
+ * those of the plain call plus the named glue call (net.py:319-331 reparameterisation and its autograd, cpq.py:125-131),
+ * fused into the launch when its last tile is LDS-resident, two launches otherwise. */
+int osrl_mlp_forward_tail(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
+                          const osrl_mlp_tail_t* tail, void* stream);
+int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                              const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream);
 /* General linear layer on packed weights: Y[M,N] = A[M,K] * P (+ bias[N]) (+ resid[M,N]).  P is the forward
  * pack of W[N,K] (y = x W^T; Np = round16(N), col0 = 0) or the backward pack of W[N',K'] for dx = dy W
  * (then K = N', N = K' or a column slice starting at col0, Np = round16(K')+16).  K <= 1024; N is

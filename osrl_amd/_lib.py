@@ -48,6 +48,14 @@ class GradsT(C.Structure):
                 ("dx_col0", C.c_int32), ("dx_cols", C.c_int32)]
 
 
+class TailT(C.Structure):  # osrl_mlp_tail_t
+    _fields_ = [("kind", C.c_int32), ("L", C.c_int32), ("eps", _fp), ("head", _fp), ("out", _fp),
+                ("beta", C.c_float), ("rows_global", C.c_int32), ("inv_rows_", C.c_float)]
+
+
+TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD = 0, 1, 2
+
+
 class DwEntryT(C.Structure):
     _fields_ = [("dz", _fp), ("a", _fp), ("w_off", C.c_int64), ("b_off", C.c_int64),
                 ("out", C.c_int32), ("in_", C.c_int32), ("ldz", C.c_int32), ("lda", C.c_int32)]
@@ -124,6 +132,8 @@ PROTOTYPES = {
     "osrl_gather_rows": [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp],
     "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
+    "osrl_mlp_forward_tail": [_P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _vp],
+    "osrl_mlp_backward_dz_tail": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _P(TailT), _vp],
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
     "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],

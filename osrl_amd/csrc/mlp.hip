@@ -435,11 +435,54 @@ __device__ __forceinline__ void fwd_epilogue(float* lds, int lda, const f32x4 (&
     fwd_epilogue_core<NRB, NCB, ACT, true, true>(lds, lda, acc, cb0, cnt, N, oscale, lane);
 }
 
+// ---- row-local tails on the LDS-resident last tile (osrl_mlp_tail_t; the arithmetic of csrc/glue.hip's
+// vae_latent_kernel / vae_latent_bwd_kernel, expression for expression) ------------------------------------------
+constexpr float kTailLsMin = -4.0f, kTailLsMax = 15.0f;  // net.py:325 (== kVaeLsMin / kVaeLsMax of glue.hip)
+
+// tile = the encoder output [BM][2L] (mean | log_std): z = mean + exp(clamp(log_std)) * eps
+__device__ __forceinline__ void tail_vae_latent(const float* lds, int lda, int BM, int row0, int rows,
+                                                const osrl_mlp_tail_t& t) {
+  const int Lz = t.L;
+  for (int idx = threadIdx.x; idx < BM * Lz; idx += (int)blockDim.x) {
+    const int r = idx / Lz, k = idx - r * Lz;
+    const int gr = row0 + r;
+    if (gr < rows) {
+      const float mean = lds[r * lda + k];
+      const float ls = fminf(fmaxf(lds[r * lda + Lz + k], kTailLsMin), kTailLsMax);
+      const size_t i = (size_t)gr * Lz + k;
+      t.out[i] = mean + expf(ls) * t.eps[i];
+    }
+  }
+}
+
+// tile = dL/dz [BM][L] (the decoder's dX slice): d/d(mean | log_std) of recon + beta KL through z = mean + sd * eps
+__device__ __forceinline__ void tail_vae_latent_bwd(const float* lds, int lda, int BM, int row0, int rows,
+                                                    const osrl_mlp_tail_t& t) {
+  const int Lz = t.L;
+  for (int idx = threadIdx.x; idx < BM * Lz; idx += (int)blockDim.x) {
+    const int r = idx / Lz, k = idx - r * Lz;
+    const int gr = row0 + r;
+    if (gr < rows) {
+      const size_t i = (size_t)gr * Lz + k;
+      const float mean = t.head[(size_t)gr * 2 * Lz + k];
+      const float lsr = t.head[(size_t)gr * 2 * Lz + Lz + k];
+      const float ev = t.eps[i];
+      const float g = lds[r * lda + k];
+      const float sd = expf(fminf(fmaxf(lsr, kTailLsMin), kTailLsMax));
+      const float c = t.beta * t.inv_rows_ / (float)Lz;
+      t.out[(size_t)gr * 2 * Lz + k] = g + c * mean;
+      const bool inside = lsr >= kTailLsMin && lsr <= kTailLsMax;
+      t.out[(size_t)gr * 2 * Lz + Lz + k] = inside ? (g * ev + c * (sd - 1.0f / sd)) * sd : 0.f;
+    }
+  }
+}
+
 struct FwdArgs {
   osrl_mlp_t net;
   osrl_rows_t in;
   osrl_mlp_acts_t out;
   int32_t lda;
+  osrl_mlp_tail_t tail;
 };
 
 // waves per SIMD the register allocator must leave room for (512 VGPRs / waves): the accumulators need
@@ -576,7 +619,10 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e, cons
     float* save = a.out.h[e][l];
     if (save) tile_to_global(lds, lda, BM, N, save, row0, rows);
     PHASE_STAMP(5 + 4 * l);
-  }  WG_LOG(1);
+  }
+  // the net's output tile [BM][dims[L]] is still in LDS (nothing wrote it since the last barrier)
+  if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent(lds, lda, BM, row0, rows, a.tail);
+  WG_LOG(1);
 }
 
 template <int NRB, int NCB, int NW = 4>
@@ -1062,6 +1108,7 @@ struct BwdArgs {
   osrl_mlp_acts_t saved;
   osrl_mlp_grads_t g;
   int32_t rows, lda;
+  osrl_mlp_tail_t tail;
 };
 
 template <int NRB, int NCB, int NW = 4>
@@ -1202,6 +1249,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
     if (nblk <= 2 && nk >= 4 && lda >= 16 * NW) {
       narrow_layer_splitk<NRB, NCB, NW>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave, ring);
       tile_to_global(lds, lda, BM, nc, dx, row0, rows);
+      // (the host fuses the tail only when this branch is the one taken: bwd_tail_fusable)
+      if (a.tail.kind == OSRL_TAIL_VAE_LATENT_BWD && e == 0) tail_vae_latent_bwd(lds, lda, BM, row0, rows, a.tail);
     } else {
       int cb0, cnt;
       wave_blocks<NW>(nblk, wave, &cb0, &cnt);
@@ -1907,22 +1956,31 @@ static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osr
 
 }  // namespace
 
-extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
-                                void* stream) {
+static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
+                            const osrl_mlp_tail_t* tail, void* stream) {
   if (!valid_net(net) || net->out_scale == 0.f || !in || !out || in->rows < 1 || in->d0 + in->d1 != net->dims[0]) return -1;
   for (int e = 0; e < net->n_nets; ++e) {
     if (!out->h[e][net->n_layers - 1]) return -1;
     for (int l = 0; l < net->n_layers; ++l)
       if (!net->Wf[e][l] || !net->b[e][l]) return -1;
   }
+  const bool want_tail = tail && tail->kind != OSRL_TAIL_NONE;
+  if (want_tail && (tail->kind != OSRL_TAIL_VAE_LATENT || tail->L < 1 || 2 * tail->L != net->dims[net->n_layers] ||
+                    !tail->eps || !tail->out))
+    return -1;
   {
     const int rc = launch_fwd_nb(net, in, out, (hipStream_t)stream);
-    if (rc != kNotBig) return rc;
+    if (rc != kNotBig) {  // the 80-row kernel keeps no output tile in LDS: the tail is its own launch
+      if (rc != 0 || !want_tail) return rc;
+      return osrl_vae_latent(out->h[0][net->n_layers - 1], tail->eps, in->rows, tail->L, tail->out, stream);
+    }
   }
   FwdArgs a;
   a.net = *net;
   a.in = *in;
   a.out = *out;
+  a.tail = osrl_mlp_tail_t{};
+  if (want_tail) a.tail = *tail;
   const TileChoice t = choose_tile(net, in->rows, 0);
   a.lda = t.lda;
   if (net->wg_cap > 0 && t.nw == 4 && (t.ncb == 4 || t.ncb == 7) && t.nrb <= 2 &&
@@ -1937,6 +1995,16 @@ extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, co
     return launch_tiles(mlp_fwd_loop_kernel<1, 7>, a, R, E, 1, t.lda, st, 256, cap);
   }
   OSRL_DISPATCH_TILE(mlp_fwd_kernel, a, in->rows, net->n_nets, t, (hipStream_t)stream, 0);
+}
+
+extern "C" int osrl_mlp_forward(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
+                                void* stream) {
+  return mlp_forward_impl(net, in, out, nullptr, stream);
+}
+
+extern "C" int osrl_mlp_forward_tail(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
+                                     const osrl_mlp_tail_t* tail, void* stream) {
+  return mlp_forward_impl(net, in, out, tail, stream);
 }
 
 template <int NRB, int NCB, int NW>
@@ -1982,6 +2050,7 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
   FwdArgs a0, a1;
   a0.net = *net0; a0.in = *in0; a0.out = *out0;
   a1.net = *net1; a1.in = *in1; a1.out = *out1;
+  a0.tail = a1.tail = osrl_mlp_tail_t{};
   const int lda = t0.lda > t1.lda ? t0.lda : t1.lda;
   a0.lda = a1.lda = lda;
   const int n0 = net0->n_nets, n1 = net1->n_nets, r0 = in0->rows, r1 = in1->rows;
@@ -1994,8 +2063,8 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
   return launch_fwd2<1, 7, 4>(a0, a1, n0, n1, r0, r1, lda, st);
 }
 
-extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
-                                    const osrl_mlp_grads_t* g, void* stream) {
+static int mlp_backward_dz_impl(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                                const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream) {
   if (!valid_net(net) || !saved || !g || rows < 1) return -1;
   for (int e = 0; e < net->n_nets; ++e) {
     if (!g->dy[e]) return -1;
@@ -2005,14 +2074,42 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
       if (!saved->h[e][l] && (l < net->n_layers - 1 || net->acts[l] != OSRL_ACT_ID)) return -1;
     if (g->dx[e] && (g->dx_cols < 1 || g->dx_col0 < 0 || g->dx_col0 + g->dx_cols > net->dims[0])) return -1;
   }
+  const bool want_tail = tail && tail->kind != OSRL_TAIL_NONE;
+  if (want_tail && (tail->kind != OSRL_TAIL_VAE_LATENT_BWD || tail->L < 1 || !g->dx[0] || g->dx_cols != tail->L ||
+                    !tail->eps || !tail->head || !tail->out))
+    return -1;
   BwdArgs a;
   a.net = *net;
   a.saved = *saved;
   a.g = *g;
   a.rows = rows;
+  a.tail = osrl_mlp_tail_t{};
   const TileChoice t = choose_tile(net, rows, g->dx_cols);
   a.lda = t.lda;
+  // the kernel's dX step leaves the slice in LDS only in its split-K form (mlp_bwd_dz_kernel: nblk <= 2 && nk >= 4 &&
+  // lda >= 16 * NW); otherwise the tail is its own launch behind this one
+  const bool fused = want_tail && (g->dx_cols + 15) / 16 <= 2 && round16h(net->dims[1]) / 16 >= 4 && t.lda >= 16 * t.nw;
+  if (fused) {
+    a.tail = *tail;
+    a.tail.inv_rows_ = 1.0f / (float)(tail->rows_global > 0 ? tail->rows_global : rows);
+  }
+  if (want_tail && !fused) {
+    const int rc = mlp_backward_dz_impl(net, rows, saved, g, nullptr, stream);
+    if (rc != 0) return rc;
+    return osrl_vae_latent_bwd(tail->head, tail->eps, g->dx[0], rows, tail->L, tail->beta, tail->rows_global, tail->out,
+                               stream);
+  }
   OSRL_DISPATCH_TILE(mlp_bwd_dz_kernel, a, rows, net->n_nets, t, (hipStream_t)stream, 0);
+}
+
+extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                                    const osrl_mlp_grads_t* g, void* stream) {
+  return mlp_backward_dz_impl(net, rows, saved, g, nullptr, stream);
+}
+
+extern "C" int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                                         const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream) {
+  return mlp_backward_dz_impl(net, rows, saved, g, tail, stream);
 }
 
 

@@ -136,12 +136,10 @@ class BCQLEngine:
         for k in ("z_c", "z_cc", "z_actor"):  # net.py:334-335 clamps the latent draw
             G.clamp_(nz[k], -0.5, 0.5)
 
-        head = self.r_enc.forward(self.obs, self.act)[0]
-        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
         G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        self.r_dec.backward_dz()
-        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
 

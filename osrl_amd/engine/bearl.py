@@ -126,12 +126,10 @@ class BEARLEngine:
         st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat, self.seed, device_noise)
         G.clamp_(nz["z_mmd"], -0.5, 0.5)  # decode_multiple clamps its latent draw (net.py:343-346)
 
-        head = self.r_enc.forward(self.obs, self.act)[0]
-        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
         G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        self.r_dec.backward_dz()
-        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
 

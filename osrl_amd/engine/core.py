@@ -371,7 +371,8 @@ class MlpRun:
         return self.y, other.y
 
     def forward(self, src0: torch.Tensor, src1: Optional[torch.Tensor] = None, map0=L.MAP_ID, div0=1,
-                map1=L.MAP_ID, div1=1) -> torch.Tensor:
+                map1=L.MAP_ID, div1=1, tail: Optional["L.TailT"] = None) -> torch.Tensor:
+        """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's output tile (osrl_mlp_forward_tail)."""
         r = L.RowsT()
         r.rows = self.rows
         r.d0, r.map0, r.div0 = src0.shape[-1], map0, div0
@@ -382,6 +383,10 @@ class MlpRun:
         else:
             r.d1, r.map1, r.div1 = 0, L.MAP_ID, 1
         assert r.d0 + r.d1 == self.net.dims[0], (r.d0, r.d1, self.net.dims)
+        if tail is not None:
+            L.check(L.load().osrl_mlp_forward_tail(C.byref(self.fwd_c), C.byref(r), C.byref(self.acts_c), C.byref(tail),
+                                                   cur_stream()), "osrl_mlp_forward_tail")
+            return self.y
         L.check(L.load().osrl_mlp_forward(C.byref(self.fwd_c), C.byref(r), C.byref(self.acts_c), cur_stream()),
                 "osrl_mlp_forward")
         return self.y
@@ -419,7 +424,13 @@ class MlpRun:
             g.dx_col0, g.dx_cols = c0, nc
         self.grads_c, self.saved_c = g, sv
 
-    def backward_dz(self) -> None:
+    def backward_dz(self, tail: Optional["L.TailT"] = None) -> None:
+        """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's dX slice (osrl_mlp_backward_dz_tail)."""
+        if tail is not None:
+            L.check(L.load().osrl_mlp_backward_dz_tail(C.byref(self.bwd_net.c), self.rows, C.byref(self.saved_c),
+                                                       C.byref(self.grads_c), C.byref(tail), cur_stream()),
+                    "osrl_mlp_backward_dz_tail")
+            return
         L.check(L.load().osrl_mlp_backward_dz(C.byref(self.bwd_net.c), self.rows, C.byref(self.saved_c),
                                               C.byref(self.grads_c), cur_stream()), "osrl_mlp_backward_dz")
 

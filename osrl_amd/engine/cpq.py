@@ -170,12 +170,10 @@ class CPQEngine:
                     self.seed, device_noise)
         par.fork(0)
         # ---- main: vae_loss  (cpq.py:125-135)
-        head = self.r_enc.forward(self.obs, self.act)[0]
-        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
         G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        self.r_dec.backward_dz()
-        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
         ev_vae = torch.cuda.Event() if par.enabled else None
@@ -257,12 +255,10 @@ class CPQEngine:
         # the side stream may start here; its launches are issued after the VAE phase's so the
         # graph executor (which dispatches nodes in creation order) starts both branches at once
         # ---- main: vae_loss  (cpq.py:125-135)
-        head = self.r_enc.forward(self.obs, self.act)[0]
-        G.vae_latent(head, nz["eps_vae"], B, Lz, self.z)
+        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
         G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        self.r_dec.backward_dz()
-        G.vae_latent_bwd(head, nz["eps_vae"], self.r_dec.dx, B, Lz, m.beta, rg, self.dhead_enc)
+        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
 

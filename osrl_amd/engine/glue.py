@@ -5,6 +5,7 @@ asynchronous launch on the current stream.  No arithmetic happens in Python.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -36,6 +37,44 @@ def gauss_ood_sample(head, eps, n_samples, rows, ad, out):
 
 def vae_latent(head, eps, rows, Lz, z):
     L.check(L.load().osrl_vae_latent(_p(head), _p(eps), rows, Lz, _p(z), cur_stream()), "osrl_vae_latent")
+
+
+def vae_latent_tail(eps, Lz, z) -> "L.TailT":
+    """osrl_mlp_tail_t for MlpRun.forward(tail=...): vae_latent() fused behind the encoder's forward launch."""
+    t = L.TailT()
+    t.kind, t.L, t.eps, t.out = L.TAIL_VAE_LATENT, Lz, _p(eps), _p(z)
+    return t
+
+
+def vae_latent_bwd_tail(head, eps, Lz, beta, rows_global, dhead) -> "L.TailT":
+    """osrl_mlp_tail_t for MlpRun.backward_dz(tail=...): vae_latent_bwd() fused behind the decoder's backward launch."""
+    t = L.TailT()
+    t.kind, t.L, t.eps, t.head, t.out = L.TAIL_VAE_LATENT_BWD, Lz, _p(eps), _p(head), _p(dhead)
+    t.beta, t.rows_global = beta, rows_global
+    return t
+
+
+VAE_TAILS = os.environ.get("OSRL_VAE_TAILS", "1") == "1"  # 0: the reparameterisation and its backward as own launches
+
+
+def vae_encode(r_enc, obs, act, eps, Lz, z):
+    """head = encoder(obs, act); z = mean + exp(clamp(log_std)) * eps   (net.py:319-331) -- ONE launch: the latent is
+    produced by the encoder's forward launch from its LDS-resident output tile.  Returns head [rows, 2 Lz]."""
+    if VAE_TAILS:
+        return r_enc.forward(obs, act, tail=vae_latent_tail(eps, Lz, z))[0]
+    head = r_enc.forward(obs, act)[0]
+    vae_latent(head, eps, r_enc.rows, Lz, z)
+    return head
+
+
+def vae_decoder_backward(r_dec, head, eps, Lz, beta, rows_global, dhead):
+    """Backward of the decoder down to dL/dz (its dX slice) and on through the reparameterisation + the KL term to
+    dL/d(encoder head) -- ONE launch."""
+    if VAE_TAILS:
+        r_dec.backward_dz(tail=vae_latent_bwd_tail(head, eps, Lz, beta, rows_global, dhead))
+        return
+    r_dec.backward_dz()
+    vae_latent_bwd(head, eps, r_dec.dx, r_dec.rows, Lz, beta, rows_global, dhead)
 
 
 def vae_loss(u, act, head, rows, ad, Lz, beta, rows_global, du, stat):

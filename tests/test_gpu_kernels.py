@@ -296,6 +296,64 @@ def test_mlp_forward_pair_equals_two_launches():
                         assert close(a.h[e][l], b.h[e][l])
 
 
+@pytest.mark.parametrize("rows,od,ad,hid,tile", [(2048, 76, 2, 400, 0), (300, 17, 6, 256, 0), (37, 5, 3, 64, 0),
+                                                 (4096 + 5, 20, 4, 400, 0), (20480, 76, 2, 400, 80)])
+def test_vae_tails_fused_into_the_mlp_launches(rows, od, ad, hid, tile):
+    """osrl_mlp_forward_tail / osrl_mlp_backward_dz_tail (reparameterisation and its backward applied to the launch's
+    LDS-resident last tile) == the plain launch followed by osrl_vae_latent / osrl_vae_latent_bwd, bit for bit; also
+    where the library has to fall back to two launches (the 80-row forward, wide dX slices)."""
+    from osrl_amd.engine import glue as G
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
+    dev = _dev()
+    rs = np.random.RandomState(rows + ad)
+    Lz = 2 * ad
+
+    def mk(dims, acts, name):
+        grp = FlatGroup(name, dev)
+        for l in range(len(dims) - 1):
+            grp.add(f"{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{l}.w")
+            grp.add(f"{l}.b", (dims[l + 1],))
+        grp.finalize()
+        rr = []
+        for l in range(len(dims) - 1):
+            W, b = grp.view(f"{l}.w"), grp.view(f"{l}.b")
+            W.copy_(torch.tensor(rs.uniform(-0.2, 0.2, W.shape), dtype=torch.float32))
+            b.copy_(torch.tensor(rs.uniform(-0.2, 0.2, b.shape), dtype=torch.float32))
+            rr.append(LayerRef(W, b, grp, f"{l}.w", f"{l}.b"))
+        grp.repack()
+        return grp, NetDesc([rr], acts, 1.0)
+
+    _, enc = mk([od + ad, hid, hid, 2 * Lz], ["relu", "relu", "id"], "enc")
+    _, dec = mk([od + Lz, hid, hid, ad], ["relu", "relu", "tanh"], "dec")
+    obs, act = torch.randn(rows, od, device=dev), torch.rand(rows, ad, device=dev) * 2 - 1
+    eps = torch.randn(rows, Lz, device=dev)
+    # forward
+    r_a, r_b = MlpRun(enc, rows, tile == 0, dev, tile_rows=tile), MlpRun(enc, rows, tile == 0, dev, tile_rows=tile)
+    z_a, z_b = torch.full((rows, Lz), 7.0, device=dev), torch.full((rows, Lz), -7.0, device=dev)
+    head_a = r_a.forward(obs, act)[0]
+    G.vae_latent(head_a, eps, rows, Lz, z_a)
+    head_b = r_b.forward(obs, act, tail=G.vae_latent_tail(eps, Lz, z_b))[0]
+    torch.cuda.synchronize()
+    assert torch.equal(head_a, head_b) and torch.equal(z_a, z_b)
+    if tile:
+        return
+    # backward of the decoder through z
+    d_a, d_b = MlpRun(dec, rows, True, dev), MlpRun(dec, rows, True, dev)
+    du = torch.randn(1, rows, ad, device=dev)
+    for d in (d_a, d_b):
+        d.forward(obs, z_a)
+        d.setup_backward(du, need_dz=True, dx_cols=(od, Lz))
+    dh_a, dh_b = torch.full((rows, 2 * Lz), 3.0, device=dev), torch.full((rows, 2 * Lz), -3.0, device=dev)
+    d_a.backward_dz()
+    G.vae_latent_bwd(head_a, eps, d_a.dx, rows, Lz, 0.5, rows + 11, dh_a)
+    d_b.backward_dz(tail=G.vae_latent_bwd_tail(head_a, eps, Lz, 0.5, rows + 11, dh_b))
+    torch.cuda.synchronize()
+    assert torch.equal(d_a.dx, d_b.dx) and torch.equal(dh_a, dh_b)
+    for l in range(3):
+        assert torch.equal(d_a.dz[0][l], d_b.dz[0][l])
+
+
 def test_adam_polyak_matches_oracle():
     from oracle.osrl_oracle import Adam
     from osrl_amd.engine.core import FlatGroup, StepState
