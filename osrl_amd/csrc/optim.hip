@@ -31,10 +31,10 @@ __global__ void step_tick_kernel(osrl_step_state_t* st, float beta1, float beta2
 
 // sum_s slabs[s][i] in slab order; 8 loads are issued before the first add so their latencies overlap
 // (a one-load-per-iteration loop serialises up to 32 L2/HBM round trips: the Adam kernel sat at 12 us)
-__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ slabs, int n_splits, int64_t slab_stride,
-                                          int64_t i) {
-  f32x4 g = reinterpret_cast<const f32x4*>(slabs)[i];
-  int s = 1;
+// g + sum_{s >= s0} slabs[s][i], in slab order
+__device__ __forceinline__ f32x4 slab_sum_from(const float* __restrict__ slabs, int s0, int n_splits,
+                                               int64_t slab_stride, int64_t i, f32x4 g) {
+  int s = s0;
   for (; s + 8 <= n_splits; s += 8) {
     f32x4 t[8];
 #pragma unroll
@@ -55,6 +55,13 @@ __device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ slabs, int n
   }
   return g;
 }
+__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ slabs, int n_splits, int64_t slab_stride,
+                                          int64_t i) {
+  return slab_sum_from(slabs, 1, n_splits, slab_stride, i, reinterpret_cast<const f32x4*>(slabs)[i]);
+}
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pin4(f32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin4(i32x4& x) { asm volatile("" : "+v"(x)); }
 
 // packed-weight refresh fused into the optimizer step: map_f / map_b give, per flat parameter, its position in the
 // fragment-ordered forward / backward copies (-1 = not a packed weight); the zero padding of those copies is
@@ -79,11 +86,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   const float bc2s = st->bc2_sqrt;
   const float gs = gscale ? *gscale : 1.0f;
   const float decay = 1.0f - lr_t * wd;
+  // Everything an element needs is REQUESTED before anything is consumed: the first eight slabs (slabs past n_splits
+  // re-read slab 0), p, m, v, the target and the two pack maps (absent ones re-read p) -- one memory round trip instead
+  // of five dependent ones (slabs -> p/m/v -> target -> map_f -> map_b), which is what a group of <= 200k parameters
+  // (one element per thread, every wave resident at once) spends its 7-8 us on.  pin4() keeps the compiler from sinking
+  // a load into the branch that consumes it.
+  const f32x4* __restrict__ T4 = reinterpret_cast<const f32x4*>(tgt ? tgt : p);
+  const i32x4* __restrict__ MF4 = reinterpret_cast<const i32x4*>(pk.map_f ? (const void*)pk.map_f : (const void*)p);
+  const i32x4* __restrict__ MB4 = reinterpret_cast<const i32x4*>(pk.map_b ? (const void*)pk.map_b : (const void*)p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const f32x4 g = slab_sum(slabs, n_splits, slab_stride, i) * gs;
+    f32x4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      t[j] = reinterpret_cast<const f32x4*>(slabs + (size_t)(j < n_splits ? j : 0) * slab_stride)[i];
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    f32x4 tv0 = T4[i];
+    i32x4 mf = MF4[i], mb = MB4[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pin4(t[j]);
+    pin4(pv);
+    pin4(mv);
+    pin4(vv);
+    pin4(tv0);
+    pin4(mf);
+    pin4(mb);
+    f32x4 g = t[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+      if (j < n_splits) g += t[j];
+    if (n_splits > 8) g = slab_sum_from(slabs, 8, n_splits, slab_stride, i, g);
+    g *= gs;
     if (wd != 0.0f) pv *= decay;
     mv = b1 * mv + (1.0f - b1) * g;
     vv = b2 * vv + (1.0f - b2) * g * g;
@@ -94,13 +128,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     reinterpret_cast<f32x4*>(v)[i] = vv;
     f32x4 tv = pv;
     if (tgt) {
-      tv = reinterpret_cast<f32x4*>(tgt)[i];
-      tv = tau * pv + (1.0f - tau) * tv;
+      tv = tau * pv + (1.0f - tau) * tv0;
       reinterpret_cast<f32x4*>(tgt)[i] = tv;
     }
     if (pk.map_f) {
-      const int4 mf = reinterpret_cast<const int4*>(pk.map_f)[i];
-      const int mfa[4] = {mf.x, mf.y, mf.z, mf.w};
+      const int mfa[4] = {mf[0], mf[1], mf[2], mf[3]};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (mfa[k] >= 0) {
@@ -108,8 +140,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
           if (tgt && pk.tf) pk.tf[mfa[k]] = tv[k];
         }
       if (pk.map_b) {
-        const int4 mb = reinterpret_cast<const int4*>(pk.map_b)[i];
-        const int mba[4] = {mb.x, mb.y, mb.z, mb.w};
+        const int mba[4] = {mb[0], mb[1], mb[2], mb[3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (mba[k] >= 0) pk.pb[mba[k]] = pv[k];

@@ -71,6 +71,15 @@ def glue_bench(dev):
     hd, ea, tu, da = r(B, 2 * ad), r(B, ad), torch.tanh(r(B, ad)), r(2, B, ad)
     dhd = torch.empty(B, 2 * ad, device=dev)
     print(f"gauss_head_bwd: {timeit(lambda: G.gauss_head_bwd(hd, ea, tu, da, 2, B, ad, 1.0, dhd)):.2f} us")
+    stt = StepState(dev, ["x"])
+    stt.tick()
+    for n, S in ((388812, 4), (172552, 8), (86532, 4)):  # vae / cost critics / actor groups of C2
+        g = FlatGroup("a", dev, True)
+        g.add("w", (n,))
+        g.finalize()
+        g.ensure_slabs(S)
+        g.cur_splits = S
+        print(f"adam n={n} S={S}: {timeit(lambda: g.adam_step(1e-3, stt.ptr, tau=0.005)):.2f} us")
     lin = lambda d: sum(a * b for a, b in zip(d[:-1], d[1:]))  # noqa: E731
     for name, E, dims, acts in (("enc", 1, [78, 400, 400, 8], ["relu", "relu", "id"]),
                                 ("q x2", 2, [78, 256, 256, 1], ["relu", "relu", "id"])):
