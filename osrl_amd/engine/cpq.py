@@ -76,11 +76,12 @@ class CPQEngine:
         self.dhead_enc = z(1, B, 2 * Lz)
         self.r_dec.setup_backward(self.du, dx_cols=(od, Lz))
         self.r_enc.setup_backward(self.dhead_enc)
-        # 512 rows per split-K slab (the default policy gives 256): this dW runs beside the capped N*B-row launch of
-        # the side branch, where fewer, longer workgroups and half the slab traffic (here and in the Adam kernel that
-        # sums the slabs) win: 1819 vs 1779 steps/s, 3 runs each on one box; the other groups measure best at 256
+        # 1024 rows per split-K slab (the default policy gives 256): 140 tiles x 2 splits = 280 workgroups fit the 512
+        # resident slots in one round (x 4 splits = 560: a second, almost empty round), and the Adam kernel sums two
+        # slabs instead of four.  In the step: 2175 steps/s vs 2135 (4 splits), 2140 (3), 2015 (1); the other groups
+        # measure best at the default 256 rows (2175 vs 2110 at 512, 2010 at 1024)
         self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
-                            n_splits=max(1, B // 512))
+                            n_splits=int(os.environ.get("OSRL_VAE_DW_SPLITS", "0")) or max(1, B // 1024))
 
         # ---- critic phase
         self.r_actor_next = MlpRun(self.d_actor, B, False, dev)
@@ -226,8 +227,8 @@ class CPQEngine:
                 G.quantile(self.kl, N * B, 0.75, self.quant)
                 G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
 
-        # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch) and cost critic (here)
-        par.wait(ev_critic)
+        # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch: this stream waited for
+        # ev_critic above -- a second wait on it is one more graph edge, ~6 us on the chain) and cost critic (here)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
         G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
         self.r_pi_q.backward_dz()

@@ -9,5 +9,5 @@ cd /tmp && rocprofv3 --kernel-trace -f csv -d $O/prof -o bench -- python $GRAFT_
 cd $GRAFT_REPO_ROOT
 T=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python tools/timeline.py $T > $O/timeline.txt 2>&1
-rm -rf $O/prof
+cp $T $O/kernel_trace.csv; rm -rf $O/prof
 cat $O/timeline.txt
