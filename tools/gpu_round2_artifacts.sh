@@ -18,6 +18,7 @@ python tools/trace_summary.py $T > $O/trace_summary.txt 2>&1
 cp $S $O/bench_kernel_stats.csv
 rm -rf $O/prof
 timeout 300 python tests/bench_eval.py > $O/eval_bench.json 2> $O/eval.err
-timeout 200 python tools/kbench.py > $O/kbench.txt 2>&1
+timeout 120 python tools/kbench.py --glue > $O/kbench_chain.txt 2>&1
+for a in "20480 80 1 400 8" "20480 80 2 256 1"; do echo "# tools/mlp_phase.bin $a"; timeout 60 ./tools/mlp_phase.bin $a; done > $O/mlp_phase_nb.txt 2>&1
 tail -4 $O/pytest.log; head -c 1500 $O/bench.json; echo; head -3 $O/bench_kernel_stats.csv | cut -c1-200
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
