@@ -754,7 +754,7 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][c][t], a[s][rb][t], acc[rb][c], 0, 0, 0);
+          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
 #if OSRL_NB_INTERLEAVE
     // next step's loads one at a time, each followed by a few of THIS step's MFMAs: with one wave per SIMD nothing else
     // can fill the MFMA pipe while the ~35 address / load instructions of a step issue (540 cycles per 16-deep k-step
@@ -892,10 +892,10 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][c][t], a[s][rb][t], acc[rb][c], 0, 0, 0);
+          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
 #pragma unroll
       for (int i = 0; i < NX; ++i)
-        xacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][CNT][t], ax[s][i][t], xacc[i], 0, 0, 0);
+        xacc[i] = EXP_MFMA(b[s][CNT][t], ax[s][i][t], xacc[i]);
     }
 #if OSRL_NB_INTERLEAVE
     constexpr int kTot = 4 * (kNbRb * CNT + NX), kPer = kTot / (CNT + 1 + kNbRb + NX + 1);
