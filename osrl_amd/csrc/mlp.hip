@@ -668,14 +668,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
 // L2 latency with no second wave needed.
 // This kernel is that loop plus the least it needs around it: the input tile is staged with every load in flight at
 // once, each wide layer is  bias-initialised accumulators -> k-loop -> barrier -> activation into the LDS tile (in
-// place), the narrow head (<= 32 outputs, always the last layer) splits K over the 4 waves with ALL its weight
-// fragments preloaded before the previous layer's epilogue, partial tiles meet in LDS and go straight to global.
+// place), the narrow head (<= 32 outputs, always the last layer) splits K over the 4 waves with all of a wave's weight
+// fragments requested together in front of its k-steps, partial tiles meet in LDS and go straight to global.
 // The wide layers compute the TRANSPOSED tile: the packed weight fragment is the MFMA's A operand and the activation
 // fragment its B operand (both are "16 lanes x 4 consecutive k", so loads and packing are those of the other kernels),
 // which leaves a lane with out[row = lane & 15][4 consecutive columns] -- exactly the row-major float4 the next
 // layer's fragment read wants.  The epilogue is then one ds_write_b128 per 16x16 tile in the (conflict-free) pattern
-// of the fragment reads, instead of four ds_write_b32 down a column: 4.85k -> see profiles (r2_mlp_phase_nb.txt) cycles
-// per 400-wide layer.  Same products, same accumulation order per output: same bits.
+// of the fragment reads, instead of four ds_write_b32 down a column; with the one-instruction ReLU and no column select
+// for widths that are multiples of 16 the epilogue of a 400-wide layer went from 4.85k to 2.7k cycles
+// (profiles/r2_mlp_phase_nb.txt).  Same products, same accumulation order per output: same bits.
 // Eligibility (host): no saved activations, hidden layers of 13-16 (NCB = 4) or 25-28 (NCB = 7) column blocks, narrow
 // last layer with >= 4 k-steps; anything else takes mlp_fwd_kernel.
 struct NbArgs {
