@@ -183,6 +183,10 @@ BIG_CASES = [
     (2, [24, 96, 80, 40], ["tanh", "relu", "id"], 1.0, 33000, (20, 0, 1)),          # non-narrow last layer, odd widths
     (1, [76, 256, 256, 24], ["relu", "relu", "id"], 1.0, 30000, (76, 0, 1)),        # 2-block narrow head, no 2nd source
     (8, [12, 64, 64, 1], ["relu", "relu", "id"], 1.0, 6000, (8, 0, 1)),             # 8 small nets
+    # widths that are not multiples of 16 in the 80-row kernel: 13 / 16 column blocks (waves with 4 and with 3 blocks),
+    # tanh in a wide layer, zero-padded k of the next layer
+    (1, [78, 200, 250, 6], ["tanh", "relu", "id"], 1.0, 20480 + 3, (76, 1, 2048)),
+    (1, [40, 420, 440, 3], ["relu", "tanh", "id"], 2.0, 10240, (33, 0, 1)),         # 27 / 28 blocks: the 7-block form
 ]
 
 
