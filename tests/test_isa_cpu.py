@@ -1,0 +1,72 @@
+"""Compile-time guards for properties of the HIP kernels that no numeric test sees (CPU only: hipcc cross-compiles
+gfx950 assembly without a GPU).
+
+Round 2 found most single-workgroup kernels of the CPQ step paying one memory round trip per load: the compiler sinks a
+load into the branch that consumes it and turns ``c ? x[i] : 0`` back into such a branch ("last
+stretch").  The sources now request their loads together (clamped address + select / OR, ``pin()``); these tests hold
+the kernels to the resulting number of wait groups, and the N*B-row forward to its register / LDS-store shape, so that a
+compiler or source change that undoes it fails here."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+HIPCC = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+pytestmark = pytest.mark.skipif(HIPCC is None, reason="no hipcc")
+
+
+@pytest.fixture(scope="module")
+def listings(tmp_path_factory):
+    from osrl_amd.build import FLAGS
+    from isa_loads import scan
+    d = tmp_path_factory.mktemp("isa")
+    procs = {}
+    for name in ("glue", "optim", "mlp"):
+        out = str(d / f"{name}.s")
+        cmd = [HIPCC] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "osrl_amd", "csrc", f"{name}.hip"), "-o", out]
+        procs[name] = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), out)
+    res = {}
+    for name, (p, out) in procs.items():
+        assert p.wait() == 0, f"hipcc -S failed on {name}.hip"
+        res[name] = scan(out)
+    return res
+
+
+def _one(table, *needles):
+    hits = [k for k in table if all(n in k for n in needles)]
+    assert len(hits) == 1, (needles, hits)
+    return table[hits[0]]
+
+
+@pytest.mark.parametrize("needles,max_waits", [
+    (("quantile_kernel",), 16),                  # 73 loads; was one wait per load
+    (("cpq_ood_stat_kernel", "ILb1E"), 12),      # 98 loads; was 88 wait groups
+    (("cpq_critic_loss_kernel", "ILb1E"), 3),    # was 8 per batch row
+    (("cpq_cost_loss_kernel", "ILb1E"), 6),
+    (("cpq_actor_loss_kernel", "ILb1E"), 2),
+    (("vae_loss_kernel",), 3),
+    (("vae_latent_bwd_kernel",), 1),
+    (("vae_kl_rows_kernel",), 2),
+    (("gauss_head_bwd_kernel",), 3),
+])
+def test_chain_kernels_request_their_loads_together(listings, needles, max_waits):
+    r = _one(listings["glue"], *needles)
+    assert r["waits"] <= max_waits, (needles, r)
+    assert r["scratch"] == 0, (needles, r)
+
+
+def test_adam_requests_every_operand_up_front(listings):
+    r = _one(listings["optim"], "adam_kernel")
+    assert r["loads"] >= 14 and r["waits"] <= 4 and r["scratch"] == 0, r  # slabs, p, m, v, target, two maps: one group
+
+
+def test_nb_forward_kernel_shape(listings):
+    """mlp_fwd_nb_kernel: no scratch, one wave's registers within the file, float4 epilogue stores."""
+    for needles in (("mlp_fwd_nb_kernel", "ILi7ELb1E"), ("mlp_fwd_nb_kernel", "ILi4ELb0E"), ("mlp_fwd_nb_kernel", "ILi7ELb0E")):
+        r = _one(listings["mlp"], *needles)
+        assert r["scratch"] == 0 and 0 < r["vgprs"] <= 512, (needles, r)
+        assert r["b128_writes"] >= 60, (needles, r)  # the transposed-tile epilogue (ds_write_b32 per element before)
