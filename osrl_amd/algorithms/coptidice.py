@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..common.logger import DummyLogger, store_stats
+from ..common.logger import store_stats
 from ..common.net import EnsembleQCritic, SquashedGaussianMLPActor, bind_group, plan_group
 from ..engine.core import FlatGroup, require_cuda
 

@@ -14,7 +14,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..common.logger import DummyLogger
 from ..common.net import (VAE, EnsembleQCritic, SquashedGaussianMLPActor, bind_group, plan_group)
 from ..engine.core import FlatGroup, require_cuda
 

@@ -14,7 +14,7 @@ model yields the same initial weights as the reference under the same seed.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn as nn

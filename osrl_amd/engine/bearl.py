@@ -15,7 +15,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_dec_raw_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, cur_stream, load_into, randn_fill
+from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, cur_stream, load_into
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/mmd_loss",
              "loss/qc_penalty", "loss/lagrangian", "loss/alpha_value"]

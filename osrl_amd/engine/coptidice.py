@@ -19,7 +19,7 @@ import torch
 
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq
-from .core import DwPlan, MlpRun, StepState, cur_stream, load_into, randn_fill
+from .core import DwPlan, MlpRun, StepState, cur_stream, load_into
 
 STAT_KEYS = ["loss/chi_loss", "loss/tau_loss", "loss/D_kl", "loss/Df", "loss/td_error", "loss/nu_loss",
              "loss/lmbda_loss", "loss/actor_loss", "loss/tau", "loss/lmbda"]

@@ -20,7 +20,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, randn_fill
+from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, load_into
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]

@@ -8,10 +8,8 @@ from __future__ import annotations
 import os
 from typing import Optional
 
-import torch
-
 from .. import _lib as L
-from .core import _ptr, cur_stream
+from .core import cur_stream
 
 
 def _p(t) -> Optional[int]:
