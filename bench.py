@@ -234,8 +234,10 @@ def in_step_us(eng, iters=40):
     return float(np.mean(ts)), float(ts[len(ts) // 2])
 
 
-def roofline(eng, flops_step: float, ms_per_step: float):
-    """Dominant kernels of the CPQ step: the two N*B-row forward launches (69% of the step's FLOPs)."""
+def roofline(eng):
+    """Dominant kernels of the CPQ step: the two N*B-row forward launches (69% of the step's FLOPs).  Needs no trained
+    state (the in-step probe snapshots and restores the engine), so main() runs it BEFORE the timed region; ``step_frac``
+    is filled in afterwards."""
     from osrl_amd import _lib as L
     cands = {
         "mlp_fwd<vae-encoder, N*B rows>": (eng.r_enc_ood, lambda: eng.r_enc_ood.forward(
@@ -243,6 +245,13 @@ def roofline(eng, flops_step: float, ms_per_step: float):
         "mlp_fwd<cost_critic_old x2, N*B rows>": (eng.r_costold_ood, lambda: eng.r_costold_ood.forward(
             eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B)),
     }
+    # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
+    # issue alone (this function runs on rank 0 only) -- N > 1 reports the isolated figure only.  It goes first: its
+    # step bodies leave a sampled minibatch and the N*B sampled actions in the buffers the isolated launches read
+    mean_us, med_us = in_step_us(eng) if eng.dist is None else (float("nan"), float("nan"))
+    if eng.dist is not None:  # no step has run yet: time the launches on data, not on the zero-initialised buffers
+        eng.obs.normal_()
+        eng.sampled.normal_()
     res = {}
     for name, (run, fn) in cands.items():
         t = time_kernel(fn)
@@ -250,9 +259,6 @@ def roofline(eng, flops_step: float, ms_per_step: float):
     # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows)
     dom = max(res, key=lambda k: res[k]["flops"])
     ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
-    # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
-    # issue alone (this function runs on rank 0 only) -- N > 1 reports the isolated figure only
-    mean_us, med_us = in_step_us(eng) if eng.dist is None else (float("nan"), float("nan"))
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -267,7 +273,7 @@ def roofline(eng, flops_step: float, ms_per_step: float):
             "in_step_us_median": None if med_us != med_us else round(med_us, 2),
             "in_step_frac": None if mean_us != mean_us else
             round(res[dom]["flops"] / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
-            "step_frac": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+            "step_frac": None,  # main(): algorithmic GFLOP per step / measured ms per step / peak
             "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2),
                             "wg_cap": int(cands[k][0].fwd_c.wg_cap)}
                         for k, v in res.items()}}
@@ -406,6 +412,17 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    # The roofline probes go first: they need nothing from the timed steps, and the device leaves its idle clocks under
+    # them -- with a short timed region (the driver's K = 20 steps = 10 ms after W = 5) the steps otherwise run on
+    # ramping clocks (2059 vs 2155 steps/s at K = 20 vs K = 300 on one box, profiles/r2_bench_driver_cmd.json).  Rank 0
+    # only; the other ranks wait for it at the barrier that opens the timed region.
+    roof = None
+    if rank == 0 and not args.no_roofline and cfg["algo"] == "cpq":
+        try:
+            roof = roofline(eng)
+        except Exception as e:  # a failing probe must not take the headline line down
+            roof = {"error": repr(e)[:300]}
+            torch.cuda.synchronize()
     dt = timed_steps(wl.step, args.steps, args.warmup, barrier)
     if world > 1:
         import torch.distributed as dist
@@ -440,8 +457,9 @@ def main():
             "step_frac": round(fl / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
             "last_stats": {k: round(float(v), 5) for k, v in stats.items()},
         }
-        if not args.no_roofline and cfg["algo"] == "cpq":
-            out["roofline"] = roofline(eng, fl, ms)
+        if roof is not None:
+            roof["step_frac"] = out["step_frac"]
+            out["roofline"] = roof
         if world == 1 and not force_dp and not args.no_extras:
             out["api_path"] = api_path(wl)
             del wl, eng
@@ -454,7 +472,7 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp is not None:
         import torch.distributed as dist
-        barrier()  # rank 0 is still timing its roofline kernel: nobody tears the communicator down before it is done
+        barrier()  # nobody tears the communicator down before every rank is through
         dist.destroy_process_group()
 
 
