@@ -412,10 +412,11 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    # The roofline probes go first: they need nothing from the timed steps, and the device leaves its idle clocks under
-    # them -- with a short timed region (the driver's K = 20 steps = 10 ms after W = 5) the steps otherwise run on
-    # ramping clocks (2059 vs 2155 steps/s at K = 20 vs K = 300 on one box, profiles/r2_bench_driver_cmd.json).  Rank 0
-    # only; the other ranks wait for it at the barrier that opens the timed region.
+    # The roofline probes go first: they need nothing from the timed steps, and the device has then been busy for ~60 ms
+    # when the warm-up steps start -- a timed region as short as the driver's (K = 20 steps = 10 ms after W = 5) measured
+    # 4.5 % below a long one on the same box (2059 vs 2155 steps/s, profiles/r2_bench_driver_cmd.json vs r2_bench.json:
+    # idle clocks / first replays suspected).  Rank 0 only; the other ranks wait at the barrier that opens the timed
+    # region.
     roof = None
     if rank == 0 and not args.no_roofline and cfg["algo"] == "cpq":
         try:
