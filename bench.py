@@ -246,7 +246,7 @@ def roofline(eng):
             eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B)),
     }
     # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
-    # issue alone (this function runs on rank 0 only) -- N > 1 reports the isolated figure only.  It goes first: its
+    # issue out of step with its peers -- N > 1 reports the isolated figure only.  It goes first: its
     # step bodies leave a sampled minibatch and the N*B sampled actions in the buffers the isolated launches read
     mean_us, med_us = in_step_us(eng) if eng.dist is None else (float("nan"), float("nan"))
     if eng.dist is not None:  # no step has run yet: time the launches on data, not on the zero-initialised buffers
@@ -415,10 +415,10 @@ def main():
     # The roofline probes go first: they need nothing from the timed steps, and the device has then been busy for ~60 ms
     # when the warm-up steps start -- a timed region as short as the driver's (K = 20 steps = 10 ms after W = 5) measured
     # 4.5 % below a long one on the same box (2059 vs 2155 steps/s, profiles/r2_bench_driver_cmd.json vs r2_bench.json:
-    # idle clocks / first replays suspected).  Rank 0 only; the other ranks wait at the barrier that opens the timed
-    # region.
+    # idle clocks / first replays suspected).  Every rank runs them (no collectives inside: under data parallelism only
+    # the isolated launches are timed), rank 0 reports.
     roof = None
-    if rank == 0 and not args.no_roofline and cfg["algo"] == "cpq":
+    if not args.no_roofline and cfg["algo"] == "cpq":
         try:
             roof = roofline(eng)
         except Exception as e:  # a failing probe must not take the headline line down
