@@ -203,6 +203,22 @@ int osrl_adam_step_packed(float* p, float* m, float* v, float* tgt, const float*
 int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
                       void* stream);
 
+/* ---- device-resident argument blocks for the launches of a captured step (csrc/argmem.h) --------------------
+ * New (nothing in the reference to mirror: torch passes kernel arguments through the runtime).  The fused-MLP
+ * launches carry 1.2-2.4 KB descriptors by value; where the HIP runtime keeps kernel arguments in HOST memory (no
+ * large BAR, or HIP_FORCE_DEV_KERNARG=0) every wave fetches them over PCIe and a train step loses ~20 %.  A step
+ * engine's launches are static, so the caller may keep the descriptors in HBM instead:
+ *   1. osrl_args_begin(staging, NULL, cap, 0, 1)   record: run the step once (eagerly); every fused-MLP launch also
+ *      copies its descriptor into `staging` (host memory, identical blocks once);  osrl_args_end(&used, ...);
+ *   2. copy staging[0:used] to device memory `dev` (any hipMemcpy);
+ *   3. osrl_args_begin(staging, dev, cap, used, 2)  replay: run the step again (typically under hipGraph capture);
+ *      a launch whose descriptor is found in the staging buffer BY CONTENT starts the kernel variant that reads it
+ *      from `dev`; anything else is launched by value as always (counted in n_misses);  osrl_args_end(...).
+ * The context belongs to the calling thread; without it nothing changes.  `dev` must outlive the captured graph.
+ * Returns 0, -1 on bad arguments / no open context, -2 when a context is already open on this thread. */
+int osrl_args_begin(void* host_staging, const void* dev_copy, int64_t capacity, int64_t used, int32_t mode);
+int osrl_args_end(int64_t* used, int32_t* n_blocks, int32_t* n_hits, int32_t* n_misses);
+
 /* ---- RNG + replay (rng.hip): torch.randn / TransitionDataset sampling (dataset.py:832-847) ---- */
 /* out[i] ~ N(0,1): Philox4x32-10 keyed by seed, counter = (i/4, st->step, stream_id), Box-Muller. */
 int osrl_randn_fill(float* out, int64_t n, uint64_t seed, uint32_t stream_id, const osrl_step_state_t* st,

@@ -145,6 +145,9 @@ class CPQTrainer:
                  reward_scale: float = 1.0, cost_scale: float = 1.0, device="cuda",
                  stats_mode: str = "lazy", use_graph: bool = True) -> None:
         self.model = model
+        if logger is None:  # the reference default (a fresh one per trainer: no shared mutable default)
+            from ..common.logger import DummyLogger
+            logger = DummyLogger()
         self.logger = logger
         self.env = env
         self.reward_scale = reward_scale

@@ -29,7 +29,7 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, "..", "include", "osrl_amd.h"),
-                                                       os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h")]
+                                                       os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), os.path.join(CSRC, "argmem.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -63,7 +63,7 @@ def _build_locked(verbose: bool, force: bool = False) -> str:
     header is newer), then one link."""
     os.makedirs(OBJDIR, exist_ok=True)
     hip = _hipcc()
-    common = [os.path.join(PKG, "..", "include", "osrl_amd.h"), os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), __file__]
+    common = [os.path.join(PKG, "..", "include", "osrl_amd.h"), os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), os.path.join(CSRC, "argmem.h"), __file__]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))

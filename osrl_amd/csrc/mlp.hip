@@ -37,6 +37,7 @@
 #include <stdlib.h>
 
 #include "../../include/osrl_amd.h"
+#include "argmem.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -440,8 +441,8 @@ __device__ __forceinline__ void fwd_epilogue(float* lds, int lda, const f32x4 (&
 constexpr float kTailLsMin = -4.0f, kTailLsMax = 15.0f;  // net.py:325 (== kVaeLsMin / kVaeLsMax of glue.hip)
 
 // tile = the encoder output [BM][2L] (mean | log_std): z = mean + exp(clamp(log_std)) * eps
-__device__ __forceinline__ void tail_vae_latent(const float* lds, int lda, int BM, int row0, int rows,
-                                                const osrl_mlp_tail_t& t) {
+template <class TR>
+__device__ __forceinline__ void tail_vae_latent(const float* lds, int lda, int BM, int row0, int rows, TR t) {
   const int Lz = t.L;
   for (int idx = threadIdx.x; idx < BM * Lz; idx += (int)blockDim.x) {
     const int r = idx / Lz, k = idx - r * Lz;
@@ -456,8 +457,8 @@ __device__ __forceinline__ void tail_vae_latent(const float* lds, int lda, int B
 }
 
 // tile = dL/dz [BM][L] (the decoder's dX slice): d/d(mean | log_std) of recon + beta KL through z = mean + sd * eps
-__device__ __forceinline__ void tail_vae_latent_bwd(const float* lds, int lda, int BM, int row0, int rows,
-                                                    const osrl_mlp_tail_t& t) {
+template <class TR>
+__device__ __forceinline__ void tail_vae_latent_bwd(const float* lds, int lda, int BM, int row0, int rows, TR t) {
   const int Lz = t.L;
   for (int idx = threadIdx.x; idx < BM * Lz; idx += (int)blockDim.x) {
     const int r = idx / Lz, k = idx - r * Lz;
@@ -497,8 +498,10 @@ constexpr int waves_per_simd(int nrb, int ncb) {
 // the backward kernel also holds the prefetched activations of the epilogue: one wave less
 constexpr int waves_per_simd_bwd(int nrb, int ncb) { return nrb * ncb >= 7 ? 2 : 3; }
 
-template <int NRB, int NCB, int NW>
-__device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e, const int tile) {
+// AR = how the descriptor is reached: `const FwdArgs&` (the by-value kernel argument, i.e. the kernarg segment) or
+// `const OSRL_CAS FwdArgs&` (a device-resident block, argmem.h); same member accesses, same scalar loads
+template <int NRB, int NCB, int NW, class AR>
+__device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -621,13 +624,18 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs& a, const int e, cons
     PHASE_STAMP(5 + 4 * l);
   }
   // the net's output tile [BM][dims[L]] is still in LDS (nothing wrote it since the last barrier)
-  if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent(lds, lda, BM, row0, rows, a.tail);
+  if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
   WG_LOG(1);
 }
 
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd_kernel(const FwdArgs a) {
-  mlp_fwd_body<NRB, NCB, NW>(a, blockIdx.y, blockIdx.x);
+  mlp_fwd_body<NRB, NCB, NW, const FwdArgs&>(a, blockIdx.y, blockIdx.x);
+}
+// the same kernel with its descriptor in device memory (argmem.h)
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd_kernel_p(const void* p) {
+  mlp_fwd_body<NRB, NCB, NW, const OSRL_CAS FwdArgs&>(*(const OSRL_CAS FwdArgs*)p, blockIdx.y, blockIdx.x);
 }
 
 // gridDim.x capped below the tile count (osrl_mlp_t::wg_cap): a big launch that is NOT on the critical path then
@@ -637,7 +645,7 @@ template <int NRB, int NCB>
 __global__ __launch_bounds__(256, waves_per_simd(NRB, NCB)) void mlp_fwd_loop_kernel(const FwdArgs a) {
   const int n_tiles = (a.in.rows + 16 * NRB - 1) / (16 * NRB);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    mlp_fwd_body<NRB, NCB, 4>(a, blockIdx.y, tile);
+    mlp_fwd_body<NRB, NCB, 4, const FwdArgs&>(a, blockIdx.y, tile);
     __syncthreads();  // the LDS tile is reused
   }
 }
@@ -650,10 +658,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
     const FwdArgs a0, const FwdArgs a1, int nets0, int tiles0, int tiles1) {
   if ((int)blockIdx.y < nets0) {
     if ((int)blockIdx.x >= tiles0) return;  // whole workgroup leaves before any barrier
-    mlp_fwd_body<NRB, NCB, NW>(a0, blockIdx.y, blockIdx.x);
+    mlp_fwd_body<NRB, NCB, NW, const FwdArgs&>(a0, blockIdx.y, blockIdx.x);
   } else {
     if ((int)blockIdx.x >= tiles1) return;
-    mlp_fwd_body<NRB, NCB, NW>(a1, blockIdx.y - nets0, blockIdx.x);
+    mlp_fwd_body<NRB, NCB, NW, const FwdArgs&>(a1, blockIdx.y - nets0, blockIdx.x);
+  }
+}
+struct Fwd2Args {  // device-resident form of the pair launch (argmem.h)
+  FwdArgs a0, a1;
+  int32_t nets0, tiles0, tiles1, pad_;
+};
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd2_kernel_p(
+    const void* p) {
+  const OSRL_CAS Fwd2Args& f = *(const OSRL_CAS Fwd2Args*)p;
+  if ((int)blockIdx.y < f.nets0) {
+    if ((int)blockIdx.x >= f.tiles0) return;
+    mlp_fwd_body<NRB, NCB, NW, const OSRL_CAS FwdArgs&>(f.a0, blockIdx.y, blockIdx.x);
+  } else {
+    if ((int)blockIdx.x >= f.tiles1) return;
+    mlp_fwd_body<NRB, NCB, NW, const OSRL_CAS FwdArgs&>(f.a1, blockIdx.y - f.nets0, blockIdx.x);
   }
 }
 
@@ -954,8 +978,8 @@ __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int 
 // SHARED: every wide layer has 4 (NCB - 1) + 1 column blocks (the 400-wide VAE encoder / decoder): NCB - 1 blocks per
 // wave + the row-shared last block (nb_wide_layer_x); a separate instantiation, so that neither form carries the
 // other's register footprint
-template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
+template <int NCB, bool SHARED, class AR>
+__device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * kNbRb;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1103,6 +1127,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
   }
   WG_LOG(1);
 }
+template <int NCB, bool SHARED = false>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
+  mlp_fwd_nb_body<NCB, SHARED, const NbArgs&>(a);
+}
+template <int NCB, bool SHARED = false>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel_p(const void* p) {
+  mlp_fwd_nb_body<NCB, SHARED, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
+}
 
 struct BwdArgs {
   osrl_mlp_t net;
@@ -1112,8 +1144,8 @@ struct BwdArgs {
   osrl_mlp_tail_t tail;
 };
 
-template <int NRB, int NCB, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel(const BwdArgs a) {
+template <int NRB, int NCB, int NW, class AR>
+__device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1251,7 +1283,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
       narrow_layer_splitk<NRB, NCB, NW>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave, ring);
       tile_to_global(lds, lda, BM, nc, dx, row0, rows);
       // (the host fuses the tail only when this branch is the one taken: bwd_tail_fusable)
-      if (a.tail.kind == OSRL_TAIL_VAE_LATENT_BWD && e == 0) tail_vae_latent_bwd(lds, lda, BM, row0, rows, a.tail);
+      if (a.tail.kind == OSRL_TAIL_VAE_LATENT_BWD && e == 0) tail_vae_latent_bwd<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
     } else {
       int cb0, cnt;
       wave_blocks<NW>(nblk, wave, &cb0, &cnt);
@@ -1274,6 +1306,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
       }
     }
   }
+}
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel(const BwdArgs a) {
+  mlp_bwd_dz_body<NRB, NCB, NW, const BwdArgs&>(a);
+}
+template <int NRB, int NCB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel_p(const void* p) {
+  mlp_bwd_dz_body<NRB, NCB, NW, const OSRL_CAS BwdArgs&>(*(const OSRL_CAS BwdArgs*)p);
 }
 
 // ---- dW = dZ^T A, db = colsum(dZ) ---------------------------------------------------------------
@@ -1856,47 +1896,58 @@ inline TileChoice choose_tile(const osrl_mlp_t* net, int rows, int extra_width) 
   return t;
 }
 
+// kernel_p (may be nullptr): the variant that reads its descriptor from device memory; taken when the calling
+// thread's argument arena (argmem.h) holds an uploaded copy of `args`
 template <typename Args, typename K>
-int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int lda, hipStream_t stream,
-                 int threads = 256, int wg_cap = 0) {
+int launch_tiles(K kernel, void (*kernel_p)(const void*), const Args& args, int rows, int nets, int nrb, int lda,
+                 hipStream_t stream, int threads = 256, int wg_cap = 0) {
   const int BM = 16 * nrb;
   const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
   int tiles = (rows + BM - 1) / BM;
   if (wg_cap > 0 && tiles * nets > wg_cap) tiles = (wg_cap + nets - 1) / nets;  // forward kernel loops over tiles
   dim3 grid(tiles, nets, 1);
+  const void* dev_args = kernel_p ? osrl_argmem::slot(args) : nullptr;
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+    hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(kernel_p) : reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds_bytes, stream, args);
+  if (dev_args)
+    hipLaunchKernelGGL(kernel_p, grid, dim3(threads), lds_bytes, stream, dev_args);
+  else
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds_bytes, stream, args);
   return (int)hipGetLastError();
+}
+template <typename Args, typename K>
+int launch_tiles(K kernel, const Args& args, int rows, int nets, int nrb, int lda, hipStream_t stream,
+                 int threads = 256, int wg_cap = 0) {
+  return launch_tiles(kernel, (void (*)(const void*))nullptr, args, rows, nets, nrb, lda, stream, threads, wg_cap);
 }
 
 #define OSRL_DISPATCH_TILE(KERNEL, ARGS, ROWS, NETS, T, STREAM, CAP)                        \
   do {                                                                                  \
     if (T.nw == 8) {                                                                    \
-      if (T.ncb == 2) return launch_tiles(KERNEL<1, 2, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512, CAP); \
-      return launch_tiles(KERNEL<1, 4, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512, CAP);     \
+      if (T.ncb == 2) return launch_tiles(KERNEL<1, 2, 8>, KERNEL##_p<1, 2, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512, CAP); \
+      return launch_tiles(KERNEL<1, 4, 8>, KERNEL##_p<1, 4, 8>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 512, CAP);     \
     }                                                                                   \
     if (T.ncb == 1) {                                                                   \
-      if (T.nrb == 4) return launch_tiles(KERNEL<4, 1>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
-      if (T.nrb == 2) return launch_tiles(KERNEL<2, 1>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
-      return launch_tiles(KERNEL<1, 1>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 1>, KERNEL##_p<4, 1>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 1>, KERNEL##_p<2, 1>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+      return launch_tiles(KERNEL<1, 1>, KERNEL##_p<1, 1>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
     }                                                                                   \
     if (T.ncb == 2) {                                                                   \
-      if (T.nrb == 4) return launch_tiles(KERNEL<4, 2>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
-      if (T.nrb == 2) return launch_tiles(KERNEL<2, 2>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
-      return launch_tiles(KERNEL<1, 2>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 2>, KERNEL##_p<4, 2>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 2>, KERNEL##_p<2, 2>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+      return launch_tiles(KERNEL<1, 2>, KERNEL##_p<1, 2>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
     }                                                                                   \
     if (T.ncb == 4) {                                                                   \
-      if (T.nrb == 4) return launch_tiles(KERNEL<4, 4>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
-      if (T.nrb == 2) return launch_tiles(KERNEL<2, 4>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
-      return launch_tiles(KERNEL<1, 4>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
+      if (T.nrb == 4) return launch_tiles(KERNEL<4, 4>, KERNEL##_p<4, 4>, ARGS, ROWS, NETS, 4, T.lda, STREAM, 256, CAP); \
+      if (T.nrb == 2) return launch_tiles(KERNEL<2, 4>, KERNEL##_p<2, 4>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+      return launch_tiles(KERNEL<1, 4>, KERNEL##_p<1, 4>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);             \
     }                                                                                   \
-    if (T.nrb == 2) return launch_tiles(KERNEL<2, 7>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
-    return launch_tiles(KERNEL<1, 7>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);               \
+    if (T.nrb == 2) return launch_tiles(KERNEL<2, 7>, KERNEL##_p<2, 7>, ARGS, ROWS, NETS, 2, T.lda, STREAM, 256, CAP); \
+    return launch_tiles(KERNEL<1, 7>, KERNEL##_p<1, 7>, ARGS, ROWS, NETS, 1, T.lda, STREAM, 256, CAP);               \
   } while (0)
 
 bool valid_net(const osrl_mlp_t* n) {
@@ -1914,11 +1965,16 @@ constexpr size_t kLdsMax = 160 * 1024;
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
 template <int NCB, bool SHARED = false>
 static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED>),
+  const void* dev_args = osrl_argmem::slot(a);
+  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED>)
+                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   (void)hipGetLastError();
-  hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
+  if (dev_args)
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
+  else
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1943,7 +1999,7 @@ static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osr
   size_t lds_bytes = (size_t)80 * lda * sizeof(float);
   if (lds_bytes <= 80 * 1024) lds_bytes = 80 * 1024 + 256;  // more than half of the 160 KB: one workgroup per CU
   if (lds_bytes > kLdsMax) return kNotBig;
-  NbArgs a;
+  NbArgs a{};
   a.net = *net;
   a.in = *in;
   for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
@@ -1976,7 +2032,7 @@ static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const 
       return osrl_vae_latent(out->h[0][net->n_layers - 1], tail->eps, in->rows, tail->L, tail->out, stream);
     }
   }
-  FwdArgs a;
+  FwdArgs a{};
   a.net = *net;
   a.in = *in;
   a.out = *out;
@@ -2014,14 +2070,28 @@ static int launch_fwd2(const FwdArgs& a0, const FwdArgs& a1, int nets0, int nets
   const int BM = 16 * NRB;
   const int t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
   const size_t lds_bytes = (size_t)BM * lda * sizeof(float);
+  const void* dev_args = nullptr;
+  if (osrl_argmem::current()) {
+    Fwd2Args f{};
+    f.a0 = a0;
+    f.a1 = a1;
+    f.nets0 = nets0;
+    f.tiles0 = t0;
+    f.tiles1 = t1;
+    dev_args = osrl_argmem::slot(f);
+  }
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd2_kernel<NRB, NCB, NW>),
+    hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd2_kernel_p<NRB, NCB, NW>)
+                                                : reinterpret_cast<const void*>(mlp_fwd2_kernel<NRB, NCB, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();
-  hipLaunchKernelGGL((mlp_fwd2_kernel<NRB, NCB, NW>), dim3(t0 > t1 ? t0 : t1, nets0 + nets1, 1), dim3(64 * NW),
-                     lds_bytes, stream, a0, a1, nets0, t0, t1);
+  const dim3 grid(t0 > t1 ? t0 : t1, nets0 + nets1, 1);
+  if (dev_args)
+    hipLaunchKernelGGL((mlp_fwd2_kernel_p<NRB, NCB, NW>), grid, dim3(64 * NW), lds_bytes, stream, dev_args);
+  else
+    hipLaunchKernelGGL((mlp_fwd2_kernel<NRB, NCB, NW>), grid, dim3(64 * NW), lds_bytes, stream, a0, a1, nets0, t0, t1);
   return (int)hipGetLastError();
 }
 
@@ -2048,7 +2118,7 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
         if (!net->Wf[e][l] || !net->b[e][l]) return -1;
     }
   }
-  FwdArgs a0, a1;
+  FwdArgs a0{}, a1{};
   a0.net = *net0; a0.in = *in0; a0.out = *out0;
   a1.net = *net1; a1.in = *in1; a1.out = *out1;
   a0.tail = a1.tail = osrl_mlp_tail_t{};
@@ -2079,7 +2149,7 @@ static int mlp_backward_dz_impl(const osrl_mlp_t* net, int32_t rows, const osrl_
   if (want_tail && (tail->kind != OSRL_TAIL_VAE_LATENT_BWD || tail->L < 1 || !g->dx[0] || g->dx_cols != tail->L ||
                     !tail->eps || !tail->head || !tail->out))
     return -1;
-  BwdArgs a;
+  BwdArgs a{};
   a.net = *net;
   a.saved = *saved;
   a.g = *g;

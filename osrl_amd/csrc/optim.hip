@@ -210,3 +210,31 @@ extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_spli
                      n_splits, slab_stride, n / 4);
   return (int)hipGetLastError();
 }
+
+// ---- device-resident argument blocks (argmem.h): the calling thread's arena ------------------------------------
+#include "argmem.h"
+
+namespace osrl_argmem {
+static thread_local Arena g_arena = {nullptr, nullptr, 0, 0, kOff, 0, 0, 0};
+Arena* current() { return g_arena.mode == kOff ? nullptr : &g_arena; }
+}  // namespace osrl_argmem
+
+extern "C" int osrl_args_begin(void* host_staging, const void* dev_copy, int64_t capacity, int64_t used, int32_t mode) {
+  using namespace osrl_argmem;
+  if (!host_staging || capacity < 64 || used < 0 || used > capacity || (mode != kRecord && mode != kReplay)) return -1;
+  if (mode == kReplay && !dev_copy) return -1;
+  if (g_arena.mode != kOff) return -2;  // no nesting
+  g_arena = Arena{(char*)host_staging, (const char*)dev_copy, capacity, used, mode, 0, 0, 0};
+  return 0;
+}
+
+extern "C" int osrl_args_end(int64_t* used, int32_t* n_blocks, int32_t* n_hits, int32_t* n_misses) {
+  using namespace osrl_argmem;
+  if (g_arena.mode == kOff) return -1;
+  if (used) *used = g_arena.used;
+  if (n_blocks) *n_blocks = g_arena.n_blocks;
+  if (n_hits) *n_hits = g_arena.n_hits;
+  if (n_misses) *n_misses = g_arena.n_misses;
+  g_arena.mode = kOff;
+  return 0;
+}

@@ -7,7 +7,7 @@ import torch
 
 from ..common.net import net_desc_seq
 from . import glue as G
-from .core import DwPlan, MlpRun, StepState, load_into
+from .core import DwPlan, MlpRun, StepState, capture_step, load_into
 
 STAT_KEYS = ["loss/actor_loss"]
 
@@ -81,14 +81,7 @@ class BCEngine:
         g = self.model.groups["actor"]
         snap = (g.p.clone(), g.m.clone(), g.v.clone(), self.st.state.clone(), self.st.stats.clone(),
                 self.st.ring.clone(), self.st.host_step)
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.body()
-        torch.cuda.current_stream().wait_stream(s)
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            self.body()
+        gr, self._arena = capture_step(self.st.state.device, self.body, self.body)
         torch.cuda.synchronize()
         g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])
         self.st.state.copy_(snap[3]); self.st.stats.copy_(snap[4]); self.st.ring.copy_(snap[5])

@@ -15,7 +15,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_dec_raw_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, cur_stream, load_into
+from .core import Branches, DwPlan, MlpRun, StepState, capture_step, concat_nets, cur_stream, load_into
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/mmd_loss",
              "loss/qc_penalty", "loss/lagrangian", "loss/alpha_value"]
@@ -223,15 +223,8 @@ class BEARLEngine:
 
     def capture(self) -> None:
         snap = self._snapshot()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.body(True)
-        torch.cuda.current_stream().wait_stream(s)
         par = Branches(True, 1)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.body(True, par)
+        g, self._arena = capture_step(self.st.state.device, lambda: self.body(True), lambda: self.body(True, par))
         self._par = par  # keep the side stream alive with the graph
         torch.cuda.synchronize()
         self._restore(snap)

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _lib as L
-from .core import DwPlan, FlatGroup, StepState, cur_stream, load_into
+from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into
 
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
 
@@ -477,14 +477,7 @@ class CDTEngine:
                 self.st.ring.clone(), self.st.host_step, m.log_temperature.clone() if m.stochastic else None,
                 self.temp_mv.clone())
         try:  # warm-up + capture both run a real step: the snapshot goes back even when the capture is refused
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self.body()
-            torch.cuda.current_stream().wait_stream(s)
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                self.body()
+            gr, self._arena = capture_step(self.st.state.device, self.body, self.body)
         finally:
             torch.cuda.synchronize()
             g.p.copy_(snap[0]); g.m.copy_(snap[1]); g.v.copy_(snap[2])

@@ -19,7 +19,7 @@ import torch
 
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq
-from .core import DwPlan, MlpRun, StepState, cur_stream, load_into
+from .core import DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into
 
 STAT_KEYS = ["loss/chi_loss", "loss/tau_loss", "loss/D_kl", "loss/Df", "loss/td_error", "loss/nu_loss",
              "loss/lmbda_loss", "loss/actor_loss", "loss/tau", "loss/lmbda"]
@@ -163,14 +163,7 @@ class COptiDICEEngine:
 
     def capture(self) -> None:
         snap = self._snapshot()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.body(True)
-        torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.body(True)
+        g, self._arena = capture_step(self.st.state.device, lambda: self.body(True), lambda: self.body(True))
         torch.cuda.synchronize()
         self._restore(snap)
         self.graph = g

@@ -146,12 +146,19 @@ class FlatGroup:
         """Grow-only.  A hipGraph captured by an earlier engine on this group holds the RAW address of the slab
         tensor it was captured with (dW writes, slab reduction and Adam reads all use that one address, so the graph
         stays self-consistent); the replaced tensor is therefore kept alive for the group's lifetime instead of
-        going back to the caching allocator, where a replay would read and write freed memory."""
+        going back to the caching allocator, where a replay would read and write freed memory.
+
+        A retained tensor is ZEROED when another plan is attached to it: the dW kernels STORE rows [0, own splits) of
+        their own parameter ranges and the consumer sums ``cur_splits`` rows of everything, so a row that the new
+        plans never write must not keep what an earlier engine (bigger batch => more splits, or a different mix of
+        split counts inside one group: CDT's token / per-sample / prefix plans) left there."""
         if self.slabs is None or self.n_splits < n_splits:
             if self.slabs is not None:
                 self._retired_slabs.append(self.slabs)
             self.slabs = torch.zeros(n_splits, self.n, dtype=torch.float32, device=self.device)
             self.n_splits = n_splits
+        else:
+            self.slabs.zero_()
 
     def offset(self, key: str) -> int:
         return self.layout[key][0]
@@ -509,7 +516,8 @@ class DwPlan:
 
     def launch(self) -> None:
         """Both launches write disjoint parameter ranges; a range's slabs beyond its own split count are never written
-        and stay zero (FlatGroup.ensure_slabs allocates zeros), so the consumer may sum ``n_splits`` slabs of everything."""
+        by the plans of ONE engine and are zero (FlatGroup.ensure_slabs allocates zeros and re-zeroes a retained tensor
+        whenever a plan is attached), so the consumer may sum ``n_splits`` slabs of everything."""
         g = self.group
         g.cur_splits = self.n_splits
         if self.n_items:
@@ -555,6 +563,87 @@ class Branches:
     def wait(self, ev) -> None:
         if self.enabled and ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+
+
+class ArgArena:
+    """Device-resident argument blocks for the fused-MLP launches of a captured step (csrc/argmem.h, include/osrl_amd.h
+    ``osrl_args_begin``).  Usage around a graph capture::
+
+        arena = ArgArena(device)
+        with arena.record():      # the warm-up pass: descriptors are copied into the host staging buffer
+            body()
+        arena.upload()            # one host -> device copy, outside the capture
+        with torch.cuda.graph(g), arena.replay():
+            body()                # launches whose descriptor is in the arena read it from HBM
+        keep = arena              # the device copy must outlive the graph
+
+    Why: where the HIP runtime keeps kernel arguments in HOST memory (no large BAR, HIP_FORCE_DEV_KERNARG=0) every
+    wave fetches its 1-2 KB descriptor over PCIe -- the CPQ step measured 1690 instead of 2150 steps/s.
+    ``OSRL_ARG_ARENA=0`` disables it (A/B measurements)."""
+
+    ENABLED = os.environ.get("OSRL_ARG_ARENA", "1") == "1"
+
+    def __init__(self, device, capacity: int = 1 << 18):
+        self.device = torch.device(device)
+        self.host = torch.zeros(capacity, dtype=torch.uint8)
+        self.dev: Optional[torch.Tensor] = None
+        self.used = 0
+        self.blocks = self.hits = self.misses = 0
+
+    class _Ctx:
+        def __init__(self, arena: "ArgArena", mode: int):
+            self.a, self.mode, self.open = arena, mode, False
+
+        def __enter__(self):
+            a = self.a
+            if not ArgArena.ENABLED:
+                return a
+            dev = None if a.dev is None else a.dev.data_ptr()
+            L.check(L.load().osrl_args_begin(a.host.data_ptr(), dev, a.host.numel(), a.used, self.mode),
+                    "osrl_args_begin")
+            self.open = True
+            return a
+
+        def __exit__(self, *exc):
+            if self.open:
+                used, nb, nh, nm = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+                L.check(L.load().osrl_args_end(C.byref(used), C.byref(nb), C.byref(nh), C.byref(nm)), "osrl_args_end")
+                a = self.a
+                a.used = int(used.value)
+                if self.mode == 1:
+                    a.blocks += int(nb.value)
+                else:
+                    a.hits, a.misses = int(nh.value), int(nm.value)
+            return False
+
+    def record(self) -> "ArgArena._Ctx":
+        return ArgArena._Ctx(self, 1)
+
+    def upload(self) -> None:
+        if ArgArena.ENABLED and self.used:
+            self.dev = self.host[:self.used].to(self.device)  # synchronous copy from pageable memory
+
+    def replay(self) -> "ArgArena._Ctx":
+        if ArgArena.ENABLED and self.dev is None:
+            self.dev = torch.zeros(64, dtype=torch.uint8, device=self.device)  # nothing recorded: every lookup misses
+        return ArgArena._Ctx(self, 2)
+
+
+def capture_step(device, warm, captured):
+    """hipGraph capture of one step: ``warm()`` runs eagerly on a side stream (torch's warm-up requirement) while
+    the fused-MLP launches' argument blocks are recorded, the blocks go to HBM, then ``captured()`` is captured with
+    those launches reading their descriptors from there (ArgArena).  Returns (graph, arena); keep both alive."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    arena = ArgArena(device)
+    with torch.cuda.stream(s), arena.record():
+        warm()
+    torch.cuda.current_stream().wait_stream(s)
+    arena.upload()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), arena.replay():
+        captured()
+    return g, arena
 
 
 FUSED_BEGIN = os.environ.get("OSRL_FUSED_BEGIN", "1") == "1"

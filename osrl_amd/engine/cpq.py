@@ -20,7 +20,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, concat_nets, load_into
+from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
@@ -372,15 +372,18 @@ class CPQEngine:
             # when the capture is refused and the caller falls back to eager launches
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
+            arena = ArgArena(self.dev)  # the fused-MLP launches' descriptors live in HBM (core.ArgArena)
+            with torch.cuda.stream(s), arena.record():
                 self.body(True, par)
             torch.cuda.current_stream().wait_stream(s)
+            arena.upload()
             g = torch.cuda.CUDAGraph()
             # (capturing on a high-priority stream to favour the critical chain halves the throughput: measured 980
             # vs 1755 steps/s -- every kernel of the step ran ~2x slower)
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g), arena.replay():
                 self.body(True, par)
             self._par = par  # keep the side streams alive with the graph
+            self._arena = arena  # ... and the argument blocks its kernels read
         finally:
             torch.cuda.synchronize()
             self._restore(snap)

@@ -231,6 +231,13 @@ def test_graph_with_parallel_branches_equals_eager_sequential(name):
             gpu_step(tr, c, b, s, with_noise=False)
         torch.cuda.synchronize()
         assert (m._engine.graph is not None) == use_graph
+        if use_graph:
+            # the captured launches read their fused-MLP descriptors from HBM (core.ArgArena): every descriptor the
+            # capture pass looked up was one the warm-up pass had recorded -- so this comparison is also "kernels
+            # reading device-resident argument blocks == kernels taking them by value", bit for bit
+            ar = m._engine._arena
+            assert ar.ENABLED and ar.blocks > 0 and ar.hits >= ar.blocks and ar.misses == 0, \
+                (ar.blocks, ar.hits, ar.misses)
         res.append({k: v.clone() for k, v in m.state_dict().items()})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), f"{name}: {k} differs between eager and graph execution"
@@ -388,6 +395,45 @@ def test_checkpoint_resume_is_bit_identical(name, use_graph, tmp_path):
     for k, v in m_d.state_dict().items():
         assert torch.equal(v.cpu(), raw["model_state"][k]), k
     assert all(float(g.m.abs().max()) == 0.0 for g in m_d.groups.values())
+
+
+def test_engine_rebuild_at_a_smaller_batch_does_not_read_stale_gradient_slabs():
+    """ADVICE r2 (core.py DwPlan.launch): the dW kernels STORE rows [0, own splits) of the group's slab tensor and Adam
+    sums ``cur_splits`` rows.  An engine rebuilt at a smaller batch has fewer splits; rows beyond them still held the
+    previous engine's partial gradients in the retained (grow-only) tensor.  After the fix the rebuilt engine steps
+    exactly like a model that never saw the big batch."""
+    from cases import Case
+    c = Case("rebuild", "cpq", od=17, ad=6, B=2048, hidden=[64, 64], vae_hidden=96, N=4, steps=1, episode_len=1000)
+    small = 256
+    outs = []
+    for pre_steps in (2, 0):
+        m, tr, _ = build_gpu(c, stats_mode="none", use_graph=False)
+        b = gpu_batch(c)
+        for s in range(pre_steps):  # big batch first: several row splits per group, slabs filled
+            gpu_step(tr, c, b, s, with_noise=False)
+        if pre_steps:
+            assert max(g.n_splits for g in m.groups.values()) > 1
+            # bring parameters / moments / step count back to the fresh state, keep the (dirty) slab tensors
+            m2, _, _ = build_gpu(c, stats_mode="none", use_graph=False)
+            for n, g in m.groups.items():
+                g2 = m2.groups[n]
+                g.p.copy_(g2.p); g.m.zero_(); g.v.zero_()
+                if g.tgt is not None:
+                    g.tgt.copy_(g2.tgt)
+            m.log_alpha.copy_(m2.log_alpha)
+            m.repack()
+            m._engine.st.set_step(0)
+        bs = {k: v[:small].contiguous() for k, v in b.items()}
+        eng = m.engine(small)
+        if pre_steps:
+            eng.st.set_step(0)
+        for s in range(2):
+            eng.step(bs["observations"], bs["next_observations"], bs["actions"], bs["rewards"], bs["costs"], bs["done"],
+                     use_graph=False)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in m.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{k}: the rebuilt engine read stale slab rows"
 
 
 def test_engine_rebuild_keeps_the_step_count():

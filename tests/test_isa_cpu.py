@@ -66,7 +66,24 @@ def test_adam_requests_every_operand_up_front(listings):
 
 def test_nb_forward_kernel_shape(listings):
     """mlp_fwd_nb_kernel: no scratch, one wave's registers within the file, float4 epilogue stores."""
-    for needles in (("mlp_fwd_nb_kernel", "ILi7ELb1E"), ("mlp_fwd_nb_kernel", "ILi4ELb0E"), ("mlp_fwd_nb_kernel", "ILi7ELb0E")):
-        r = _one(listings["mlp"], *needles)
-        assert r["scratch"] == 0 and 0 < r["vgprs"] <= 512, (needles, r)
-        assert r["b128_writes"] >= 60, (needles, r)  # the transposed-tile epilogue (ds_write_b32 per element before)
+    for inst in ("ILi7ELb1E", "ILi4ELb0E", "ILi7ELb0E"):
+        shapes = []
+        # by-value kernel and its device-resident-descriptor twin (csrc/argmem.h): the same body behind one extra
+        # scalar load -- same registers, same stores
+        for needles in (("mlp_fwd_nb_kernelI", inst), ("mlp_fwd_nb_kernel_pI", inst)):
+            r = _one(listings["mlp"], *needles)
+            assert r["scratch"] == 0 and 0 < r["vgprs"] <= 512, (needles, r)
+            assert r["b128_writes"] >= 60, (needles, r)  # the transposed-tile epilogue (ds_write_b32 per element before)
+            shapes.append((r["vgprs"], r["b128_writes"]))
+        assert shapes[0] == shapes[1], (inst, shapes)
+
+
+def test_descriptor_pointer_kernels_read_their_arguments_with_scalar_loads(listings):
+    """The "_p" kernels (descriptor in device memory, reached through the constant address space) must not fall back
+    to per-lane loads of the descriptor: same VGPR count and no scratch as their by-value twins."""
+    for twin in (("mlp_fwd_kernelI", "mlp_fwd_kernel_pI"), ("mlp_fwd2_kernelI", "mlp_fwd2_kernel_pI"),
+                 ("mlp_bwd_dz_kernelI", "mlp_bwd_dz_kernel_pI")):
+        for inst in ("Li1ELi2ELi8E", "Li1ELi4ELi8E"):
+            a, b = _one(listings["mlp"], twin[0], inst), _one(listings["mlp"], twin[1], inst)
+            assert b["scratch"] == 0 and a["scratch"] == 0, (twin, inst, a, b)
+            assert abs(a["vgprs"] - b["vgprs"]) <= 4, (twin, inst, a["vgprs"], b["vgprs"])
