@@ -29,7 +29,8 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, "..", "include", "osrl_amd.h"),
-                                                       os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), os.path.join(CSRC, "argmem.h")]
+                                                       os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), os.path.join(CSRC, "argmem.h"),
+                                                       __file__]  # the compiler flags live here
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -54,7 +55,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          # SimplifyCFG's store sinking merges "ring[i] = load" of sibling branches into a store through a
          # pointer phi, after which the weight-ring arrays of mlp.hip can no longer be promoted to registers
          # (they end up in scratch with an s_waitcnt vmcnt(0) right after the prefetch loads)
-         "-mllvm", "-sink-common-insts=false", "-Wno-pass-failed"]
+         "-mllvm", "-sink-common-insts=false", "-Wno-pass-failed",
+         # kernarg preload (gfx940+): the command processor hands the first 16 dwords of a launch's arguments to every
+         # wave in SGPRs, instead of each wave issuing s_loads from the kernarg segment.  Where the runtime keeps
+         # kernel arguments in host memory those s_loads are PCIe round trips at the head of every wave: CPQ step
+         # 1884 -> 2092 steps/s there, 2176 -> 2190 with device-resident kernargs (profiles/r3_kernarg_ab.txt)
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 OBJDIR = os.path.join(LIBDIR, "obj")  # git-ignored (*.o); the objects are a build cache only
 
 
