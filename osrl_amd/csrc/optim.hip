@@ -15,6 +15,7 @@
 
 #include "../../include/osrl_amd.h"
 #include "step.h"
+#include "argmem.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -74,12 +75,14 @@ struct PackMap {
   float* tf;
 };
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
-                                                   float* __restrict__ v, float* __restrict__ tgt,
-                                                   const float* __restrict__ slabs, int n_splits,
-                                                   int64_t slab_stride, int64_t n4, float lr, float b1, float b2,
-                                                   float eps, float wd, float tau, const float* __restrict__ gscale,
-                                                   const osrl_step_state_t* __restrict__ st, const PackMap pk) {
+// i0 / stride: this thread's first float4 and the grid stride (the by-value kernel derives them from the launch
+// geometry, the device-resident-descriptor twin from its descriptor)
+__device__ __forceinline__ void adam_body(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                          float* __restrict__ tgt, const float* __restrict__ slabs, int n_splits,
+                                          int64_t slab_stride, int64_t n4, float lr, float b1, float b2, float eps,
+                                          float wd, float tau, const float* __restrict__ gscale,
+                                          const osrl_step_state_t* __restrict__ st, const PackMap pk, int64_t i0,
+                                          int64_t stride) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   const float lr_t = lr * st->lr_scale;
   const float step_size = lr_t / st->bc1;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   const f32x4* __restrict__ T4 = reinterpret_cast<const f32x4*>(tgt ? tgt : p);
   const i32x4* __restrict__ MF4 = reinterpret_cast<const i32x4*>(pk.map_f ? (const void*)pk.map_f : (const void*)p);
   const i32x4* __restrict__ MB4 = reinterpret_cast<const i32x4*>(pk.map_b ? (const void*)pk.map_b : (const void*)p);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = i0; i < n4; i += stride) {
     f32x4 t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -149,6 +152,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ tgt,
+                                                   const float* __restrict__ slabs, int n_splits,
+                                                   int64_t slab_stride, int64_t n4, float lr, float b1, float b2,
+                                                   float eps, float wd, float tau, const float* __restrict__ gscale,
+                                                   const osrl_step_state_t* __restrict__ st, const PackMap pk) {
+  adam_body(p, m, v, tgt, slabs, n_splits, slab_stride, n4, lr, b1, b2, eps, wd, tau, gscale, st, pk,
+            (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+// the same step with its 36 dwords of arguments in a device-resident block (argmem.h): no hidden launch-geometry
+// arguments either, so a wave's only kernarg traffic is the preloaded pointer
+struct AdamArgs {
+  float *p, *m, *v, *tgt;
+  const float* slabs;
+  int64_t slab_stride, n4, stride;
+  const float* gscale;
+  const osrl_step_state_t* st;
+  PackMap pk;
+  int32_t n_splits;
+  float lr, b1, b2, eps, wd, tau;
+};
+__global__ __launch_bounds__(256) void adam_kernel_p(const void* ptr) {
+  const OSRL_CAS AdamArgs& a = *(const OSRL_CAS AdamArgs*)ptr;
+  const PackMap pk{a.pk.map_f, a.pk.map_b, a.pk.pf, a.pk.pb, a.pk.tf};
+  adam_body(a.p, a.m, a.v, a.tgt, a.slabs, a.n_splits, a.slab_stride, a.n4, a.lr, a.b1, a.b2, a.eps, a.wd, a.tau,
+            a.gscale, a.st, pk, (int64_t)blockIdx.x * 256 + threadIdx.x, a.stride);
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ flat, const float* __restrict__ slabs,
                                                            int n_splits, int64_t slab_stride, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -179,8 +210,21 @@ static int adam_launch(float* p, float* m, float* v, float* tgt, const float* sl
                        const PackMap& pk, void* stream) {
   if (!p || !m || !v || !slabs || !st || n < 4 || (n & 3) || (slab_stride & 3) || n_splits < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, tgt, slabs,
-                     n_splits, slab_stride, n / 4, lr, beta1, beta2, eps, weight_decay, tau, gscale, st, pk);
+  const int grid = stream_grid(n / 4);
+  const void* dev_args = nullptr;
+  if (osrl_argmem::current()) {
+    AdamArgs a{};
+    a.p = p; a.m = m; a.v = v; a.tgt = tgt; a.slabs = slabs;
+    a.slab_stride = slab_stride; a.n4 = n / 4; a.stride = (int64_t)grid * 256;
+    a.gscale = gscale; a.st = st; a.pk = pk; a.n_splits = n_splits;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.tau = tau;
+    dev_args = osrl_argmem::slot(a);
+  }
+  if (dev_args)
+    hipLaunchKernelGGL(adam_kernel_p, dim3(grid), dim3(256), 0, (hipStream_t)stream, dev_args);
+  else
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, tgt, slabs,
+                       n_splits, slab_stride, n / 4, lr, beta1, beta2, eps, weight_decay, tau, gscale, st, pk);
   return (int)hipGetLastError();
 }
 
@@ -212,7 +256,6 @@ extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_spli
 }
 
 // ---- device-resident argument blocks (argmem.h): the calling thread's arena ------------------------------------
-#include "argmem.h"
 
 namespace osrl_argmem {
 static thread_local Arena g_arena = {nullptr, nullptr, 0, 0, kOff, 0, 0, 0};

@@ -16,6 +16,7 @@
 #include "../../include/osrl_amd.h"
 #include "philox.h"
 #include "step.h"
+#include "argmem.h"
 
 namespace {
 
@@ -60,7 +61,9 @@ struct GatherArgs {
 };
 
 // one wave per sampled row; lanes stride over the row's columns (coalesced both sides)
-__device__ __forceinline__ void gather_body(const GatherArgs& a, uint32_t step, int block) {
+// AR: `const GatherArgs&` (kernel argument by value) or `const OSRL_CAS GatherArgs&` (device-resident block, argmem.h)
+template <class AR>
+__device__ __forceinline__ void gather_body(AR a, uint32_t step, int block) {
   const int lane = threadIdx.x & 63;
   const int b = block * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.batch) return;
@@ -79,7 +82,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, uint32_t step, 
 }
 
 __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
-  gather_body(a, a.st ? (uint32_t)a.st->step : 0u, blockIdx.x);
+  gather_body<const GatherArgs&>(a, a.st ? (uint32_t)a.st->step : 0u, blockIdx.x);
 }
 
 // 1024-thread workgroups: every workgroup signs in with one atomic on ONE address (those serialise at ~20 ns each:
@@ -99,7 +102,8 @@ struct BeginArgs {
   int32_t g_blocks, r_blocks;
 };
 
-__global__ __launch_bounds__(kBeginThreads) void step_begin_kernel(const BeginArgs b, const GatherArgs a) {
+template <class BR, class AR>
+__device__ __forceinline__ void step_begin_body(BR b, AR a) {
   __shared__ int64_t s_t;
   __shared__ int s_last;
   if (threadIdx.x == 0) s_t = __atomic_load_n(&b.st->step, __ATOMIC_RELAXED);
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(kBeginThreads) void step_begin_kernel(const BeginAr
   const uint32_t step = (uint32_t)(t_old + 1);
   const int blk = blockIdx.x;
   if (blk < b.g_blocks) {
-    gather_body(a, step, blk);
+    gather_body<AR>(a, step, blk);
   } else if (b.noise) {
     randn_body(b.noise, b.noise_n, b.nk0, b.nk1, b.noise_stream, step, blk - b.g_blocks, b.r_blocks);
   }
@@ -126,6 +130,17 @@ __global__ __launch_bounds__(kBeginThreads) void step_begin_kernel(const BeginAr
       b.st->arrive_ = 0;
     }
   }
+}
+__global__ __launch_bounds__(kBeginThreads) void step_begin_kernel(const BeginArgs b, const GatherArgs a) {
+  step_begin_body<const BeginArgs&, const GatherArgs&>(b, a);
+}
+struct BeginPack {  // both descriptors as one device-resident block (argmem.h): the first launch of every step
+  BeginArgs b;
+  GatherArgs a;
+};
+__global__ __launch_bounds__(kBeginThreads) void step_begin_kernel_p(const void* p) {
+  const OSRL_CAS BeginPack& k = *(const OSRL_CAS BeginPack*)p;
+  step_begin_body<const OSRL_CAS BeginArgs&, const OSRL_CAS GatherArgs&>(k.b, k.a);
 }
 
 struct SeqArgs {
@@ -279,7 +294,9 @@ extern "C" int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, 
                                int32_t batch, uint64_t gather_seed, uint32_t gather_stream, void* stream) {
   if (!st || n_fields < 0 || n_fields > OSRL_MAX_FIELDS || (noise && noise_n < 1)) return -1;
   if (n_fields > 0 && (!src || !dst || !width || n_rows < 1 || batch < 1)) return -1;
-  GatherArgs a;
+  BeginPack k{};
+  GatherArgs& a = k.a;
+  BeginArgs& b = k.b;
   for (int f = 0; f < OSRL_MAX_FIELDS; ++f) {
     a.src[f] = f < n_fields ? src[f] : nullptr;
     a.dst[f] = f < n_fields ? dst[f] : nullptr;
@@ -295,7 +312,6 @@ extern "C" int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, 
   a.k1 = (uint32_t)(gather_seed >> 32);
   a.stream_id = gather_stream;
   a.st = st;
-  BeginArgs b;
   b.st = st;
   b.beta1 = beta1;
   b.beta2 = beta2;
@@ -315,6 +331,9 @@ extern "C" int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, 
   b.r_blocks = (int32_t)(rb > 256 ? 256 : rb);
   const int grid = b.g_blocks + b.r_blocks > 0 ? b.g_blocks + b.r_blocks : 1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(step_begin_kernel, dim3(grid), dim3(kBeginThreads), 0, (hipStream_t)stream, b, a);
+  if (const void* dev_args = osrl_argmem::slot(k))
+    hipLaunchKernelGGL(step_begin_kernel_p, dim3(grid), dim3(kBeginThreads), 0, (hipStream_t)stream, dev_args);
+  else
+    hipLaunchKernelGGL(step_begin_kernel, dim3(grid), dim3(kBeginThreads), 0, (hipStream_t)stream, b, a);
   return (int)hipGetLastError();
 }
