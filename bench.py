@@ -91,6 +91,72 @@ def flops_per_step(cfg) -> float:
     return 2.0 * per * Bsz
 
 
+def executed_flops_per_step(cfg) -> float:
+    """FLOPs this build actually ISSUES per step.  The reference's step (flops_per_step) contains work whose result
+    it discards or computes twice; the engine skips exactly that (same results):
+      * CPQ ``cost_critic_loss`` runs the whole VAE on the N*B sampled actions and keeps only the KL of the ENCODER
+        output (cpq.py:176-182: ``_, _, mean, std = self.vae(...)``): the decoder on N*B rows is never launched;
+      * the actor trunk on next_obs (cpq.py:141 and :159) and on obs (:164 and :209) is evaluated once each.
+    Other algorithms: nothing skipped."""
+    if cfg["algo"] != "cpq":
+        return flops_per_step(cfg)
+    od, ad, Bsz, H, V, N = cfg["od"], cfg["ad"], cfg["B"], HID, VAE_H, NS
+    actor = lin([od] + H) + 2 * H[-1] * ad
+    dec = lin([od + 2 * ad, V, V, ad])
+    return flops_per_step(cfg) - 2.0 * (N * dec + 2 * actor) * Bsz
+
+
+def lease_diagnostics(device) -> dict:
+    """Facts about the box this run got (the driver's fresh lease is not the build's): clocks, power, partition modes,
+    runtime / driver versions, the HIP/HSA environment, and where the HIP runtime keeps kernel arguments -- the one that
+    explained round 2's 1700-vs-2155 gap (host-resident kernargs, profiles/r3_kernarg_ab.txt)."""
+    import ctypes
+    import subprocess
+    d = {}
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        d["device"] = {"name": pr.name, "arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
+                       "hbm_gib": round(pr.total_memory / 2 ** 30, 1),
+                       "clock_mhz": round(getattr(pr, "clock_rate", 0) / 1e3)}
+    except Exception as e:
+        d["device"] = {"error": repr(e)[:120]}
+    d["versions"] = {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    try:
+        d["versions"]["rocm"] = open("/opt/rocm/.info/version").read().strip()
+    except Exception:
+        pass
+    d["env"] = {k: v for k, v in sorted(os.environ.items())
+                if k.split("_")[0] in ("HSA", "GPU", "HIP", "ROCR", "AMD", "NCCL", "RCCL", "OSRL", "DEBUG")}
+    try:  # device index as rocm-smi counts it: the first visible device
+        vis = (os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or "").split(",")[0]
+        idx = str(int(vis) + (device.index or 0)) if vis.isdigit() else str(device.index or 0)
+        out = subprocess.run(["rocm-smi", "-d", idx, "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
+                              "--showcomputepartition", "--showmemorypartition", "--showdriverversion", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        js = json.loads(out[out.index("{"):])
+        card = next((v for k, v in js.items() if k.startswith("card")), {})
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "partition", "performance level")):
+                keep[k] = v
+        keep.update({k: v for k, v in js.get("system", {}).items()})
+        d["smi"] = keep
+    except Exception as e:
+        d["smi"] = {"error": repr(e)[:120]}
+    try:
+        from osrl_amd import _lib as L
+        scratch = torch.zeros(2, dtype=torch.int64, device=device)
+        where, addr = ctypes.c_int32(-2), ctypes.c_uint64(0)
+        L.check(L.load().osrl_kernarg_probe(scratch.data_ptr(), ctypes.byref(where), ctypes.byref(addr),
+                                            torch.cuda.current_stream().cuda_stream), "osrl_kernarg_probe")
+        d["kernargs_in"] = {1: "device memory", 0: "HOST memory (every wave fetches launch arguments over PCIe)",
+                            -1: "unknown"}.get(where.value, "unknown")
+    except Exception as e:
+        d["kernargs_in"] = "probe failed: " + repr(e)[:120]
+    return d
+
+
 class Workload:
     """One BASELINE config as ``step()`` = one train step on a minibatch drawn on device from a HBM-resident store."""
 
@@ -211,27 +277,34 @@ def mlp_fwd_flops(run):
     return 2.0 * run.rows * run.net.E * lin(d)
 
 
+PROBE_SITES = ("enc_ood", "costold_ood", "vae_dw", "actor_phase_fwd", "critic_fwd")
+
+
 def in_step_us(eng, iters=40):
-    """Duration of the dominant launch AS IT RUNS INSIDE THE STEP: the step body is issued eagerly on the same two
-    streams the captured graph uses (main + side branch), with HIP events recorded on the main stream right around
-    the launch, so whatever the side branch runs beside it (the paired 2048-row critic forwards) runs beside it here
-    too.  The rocprofv3 --kernel-trace --stats summary of this command (profiles/) lists the same kernel's average
-    over graph replays."""
+    """Durations of the step's five heaviest launches AS THEY RUN INSIDE THE STEP: the step body is issued eagerly on
+    the same two streams the captured graph uses (main + side branch), with HIP events recorded on the launching stream
+    right around each of them, so whatever the other branch runs beside a launch runs beside it here too.  Returns
+    {site: (mean us, median us)}; "enc_ood" is the dominant one.  The rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/) lists the same kernels' averages over graph replays."""
     from osrl_amd.engine.core import Branches
     par = Branches(True, 1)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    mk = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))  # noqa: E731
+    evs = [{k: mk() for k in PROBE_SITES} for _ in range(iters)]
     snap = eng._snapshot()
     try:
         for i in range(3 + iters):
             eng._probe = evs[i - 3] if i >= 3 else None
             eng.body(True, par)
         torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        res = {}
+        for k in PROBE_SITES:
+            ts = sorted(e[k][0].elapsed_time(e[k][1]) * 1e3 for e in evs)
+            res[k] = (float(np.mean(ts)), float(ts[len(ts) // 2]))
     finally:
         eng._probe = None
         torch.cuda.synchronize()
         eng._restore(snap)
-    return float(np.mean(ts)), float(ts[len(ts) // 2])
+    return res
 
 
 def roofline(eng):
@@ -248,7 +321,8 @@ def roofline(eng):
     # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
     # issue out of step with its peers -- N > 1 reports the isolated figure only.  It goes first: its
     # step bodies leave a sampled minibatch and the N*B sampled actions in the buffers the isolated launches read
-    mean_us, med_us = in_step_us(eng) if eng.dist is None else (float("nan"), float("nan"))
+    sites = in_step_us(eng) if eng.dist is None else {}
+    mean_us, med_us = sites.get("enc_ood", (float("nan"), float("nan")))
     if eng.dist is not None:  # no step has run yet: time the launches on data, not on the zero-initialised buffers
         eng.obs.normal_()
         eng.sampled.normal_()
@@ -259,15 +333,22 @@ def roofline(eng):
     # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows)
     dom = max(res, key=lambda k: res[k]["flops"])
     ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
-    traffic = None
+    # HBM bytes per launch come from hardware counters, which cannot be read from inside this process: the figure is the
+    # one a separate `rocprofv3 --pmc FETCH_SIZE WRITE_SIZE` pass of tools/gpu_pmc.sh measured for this kernel
+    traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(dom)
+            traffic_src = "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of " \
+                          "tools/gpu_pmc.sh, not measured in this run)"
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+            "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": int(4 * (eng.r_enc_ood.rows * (eng.r_enc_ood.net.dims[0] + eng.r_enc_ood.net.dims[-1])
+                                          + lin(eng.r_enc_ood.net.dims) + sum(eng.r_enc_ood.net.dims[1:]))),
+            "in_step_sites_us": {k: round(v[0], 2) for k, v in sites.items()} or None,
             "isolated_us": round(res[dom]["seconds"] * 1e6, 2),
             "in_step_us": None if mean_us != mean_us else round(mean_us, 2),
             "in_step_us_median": None if med_us != med_us else round(med_us, 2),
@@ -417,6 +498,7 @@ def main():
     # 4.5 % below a long one on the same box (2059 vs 2155 steps/s, profiles/r2_bench_driver_cmd.json vs r2_bench.json:
     # idle clocks / first replays suspected).  Every rank runs them (no collectives inside: under data parallelism only
     # the isolated launches are timed), rank 0 reports.
+    lease = lease_diagnostics(device) if rank == 0 else None
     roof = None
     if not args.no_roofline and cfg["algo"] == "cpq":
         try:
@@ -435,9 +517,31 @@ def main():
     assert all(np.isfinite(v) for v in stats.values()), stats
     assert eng.st.device_step() == args.warmup + args.steps
 
+    # N > 1: BASELINE.json's multi-GPU config is C4 (CPQ at (17, 6), 2048 rows per GPU = global batch 16384 at 8 GPUs);
+    # every rank runs it (collectives inside), rank 0 reports it under other_configs
+    c4_dp = None
+    if world > 1 and args.config == "c2" and not args.no_extras:
+        try:
+            w4 = Workload("c4", device, rank, world, dp, n_store=1 << 18, use_graph=not args.eager)
+            dt4 = timed_steps(w4.step, 200, 20, barrier)
+            import torch.distributed as dist
+            t4 = torch.tensor([dt4], dtype=torch.float64, device=device)
+            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+            dt4 = float(t4.item())
+            f4, x4 = flops_per_step(w4.cfg), executed_flops_per_step(w4.cfg)
+            c4_dp = {"value": round(world * 200 / dt4, 2), "optimizer_steps_per_s": round(200 / dt4, 2),
+                     "ms_per_step": round(dt4 / 200 * 1e3, 4), "global_batch": w4.cfg["B"] * world,
+                     "parallelism": f"dp{world}", "gflop_per_step_per_gpu": round(f4 / 1e9, 2),
+                     "step_frac": round(f4 / (dt4 / 200) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                     "step_frac_executed": round(x4 / (dt4 / 200) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                     "graph": bool(getattr(w4.eng, "graph", None) is not None)}
+            del w4
+        except Exception as e:  # the headline line must survive a failing side measurement -- on every rank alike
+            c4_dp = {"error": repr(e)[:200]}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
-        fl = flops_per_step(cfg)
+        fl, fx = flops_per_step(cfg), executed_flops_per_step(cfg)
         B = cfg["B"]
         out = {
             "metric": "grad-steps/sec", "value": round(world * args.steps / dt, 2),
@@ -453,14 +557,24 @@ def main():
             "optimizer_steps_per_s": round(args.steps / dt, 2),
             "transitions_per_s": round(world * B * args.steps / dt, 1),
             "rccl_ranks": rccl_ranks,
+            # two accountings of the same step: the REFERENCE's work for it (SURVEY.md 8d formula; what a reference
+            # user gets per step) and the FLOPs this build actually issues (the reference's discarded VAE decoder on
+            # the N*B rows and its repeated actor forwards are not executed) -- hardware utilisation is the second
             "algorithmic_gflop_per_step": round(fl / 1e9, 2),
             "step_tflops": round(fl / (dt / args.steps) / 1e12, 3),
             "step_frac": round(fl / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
+            "step_frac_is": "reference_equivalent (FLOPs of the reference's step / time / fp32 peak)",
+            "executed_gflop_per_step": round(fx / 1e9, 2),
+            "step_frac_executed": round(fx / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
             "last_stats": {k: round(float(v), 5) for k, v in stats.items()},
         }
         if roof is not None:
             roof["step_frac"] = out["step_frac"]
+            roof["step_frac_executed"] = out["step_frac_executed"]
             out["roofline"] = roof
+        out["lease"] = lease
+        if c4_dp is not None:
+            out["other_configs"] = {"c4": c4_dp}
         if world == 1 and not force_dp and not args.no_extras:
             out["api_path"] = api_path(wl)
             del wl, eng
@@ -504,9 +618,12 @@ def other_configs(skip: str, device):
             w = Workload(name, device, 0, 1, None, n_store=1 << 18)
             dt = timed_steps(w.step, steps, warm)
             fl = flops_per_step(w.cfg)
+            fx = executed_flops_per_step(w.cfg)
             res[name] = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
                          "gflop_per_step": round(fl / 1e9, 2),
-                         "step_frac": round(fl / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4)}
+                         "step_frac": round(fl / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                         "executed_gflop_per_step": round(fx / 1e9, 2),
+                         "step_frac_executed": round(fx / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4)}
             del w
             torch.cuda.empty_cache()
         except Exception as e:  # a failing side measurement must not take the headline line down

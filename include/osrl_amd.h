@@ -596,6 +596,11 @@ int osrl_policy_io(void* handle, float** obs, float** noise, float** act, float*
 int osrl_policy_act(void* handle, int32_t rows, int32_t deterministic, int32_t host_noise, uint64_t seed, void* stream);
 int osrl_policy_destroy(void* handle);
 
+/* Diagnostics (diag.hip): where the HIP runtime of this process keeps kernel arguments -- *where = 1 device memory,
+ * 0 host memory (every wave then fetches its launch arguments over PCIe; see osrl_args_begin), -1 unknown.  dev_scratch:
+ * 8 bytes of device memory.  Synchronises `stream`; not for the hot path. */
+int osrl_kernarg_probe(uint64_t* dev_scratch, int32_t* where, uint64_t* address, void* stream);
+
 const char* osrl_version(void);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libosrl_amd.so")
-SOURCES = ["mlp.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip"]
+SOURCES = ["mlp.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "diag.hip"]
 
 
 def _hipcc() -> str:
@@ -84,7 +84,8 @@ def _build_locked(verbose: bool, force: bool = False) -> str:
         raise RuntimeError(f"hipcc failed on {failed}")
     tmp = LIB + f".tmp{os.getpid()}"
     cmd = [hip, "--offload-arch=gfx950", "-shared", "-fPIC"] + \
-        [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES] + ["-o", tmp]
+        [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES] + \
+        ["-L" + os.path.join(os.path.dirname(os.path.dirname(hip)), "lib"), "-lhsa-runtime64", "-o", tmp]  # diag.hip
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

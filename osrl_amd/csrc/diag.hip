@@ -1,0 +1,43 @@
+// diag.hip -- lease diagnostics (bench.py prints them beside the headline number).
+//
+// osrl_kernarg_probe: WHERE does this process's HIP runtime keep kernel arguments?  A one-lane kernel reports its own
+// kernarg segment address; ROCr's pointer database says which agent owns that allocation.  Host-resident kernargs
+// (no large BAR, or HIP_FORCE_DEV_KERNARG=0) cost the CPQ step 3-20 % depending on how many launches still read their
+// arguments themselves (profiles/r3_kernarg_ab.txt), so a slow lease can be attributed.
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <stdint.h>
+
+#include "../../include/osrl_amd.h"
+
+namespace {
+__global__ void kernarg_probe_kernel(uint64_t* out) {
+  if (threadIdx.x == 0) out[0] = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+}
+}  // namespace
+
+// where: 1 = device memory (a GPU agent owns the allocation), 0 = host memory, -1 = unknown to the pointer database.
+// dev_scratch: 8 bytes of device memory.  Synchronises the stream (diagnostic call, not for the hot path).
+extern "C" int osrl_kernarg_probe(uint64_t* dev_scratch, int32_t* where, uint64_t* address, void* stream) {
+  if (!dev_scratch || !where) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kernarg_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  uint64_t addr = 0;
+  e = hipMemcpy(&addr, dev_scratch, sizeof addr, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
+  if (address) *address = addr;
+  *where = -1;
+  hsa_amd_pointer_info_t info;
+  info.size = sizeof info;
+  if (hsa_amd_pointer_info((void*)(uintptr_t)addr, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return 0;
+  if (info.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return 0;
+  hsa_device_type_t dt;
+  if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS) return 0;
+  *where = dt == HSA_DEVICE_TYPE_GPU ? 1 : 0;
+  return 0;
+}

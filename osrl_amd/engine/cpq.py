@@ -141,11 +141,24 @@ class CPQEngine:
         grp.adam_step(m._lrs[name], self.st.ptr, tau=tau)
 
     def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
+        if name == "vae":
+            self._pr("vae_dw", 0)
         plan.launch()
+        if name == "vae":
+            self._pr("vae_dw", 1)
         self._update(name, tau)
 
+    def _pr(self, site: str, i: int) -> None:
+        """bench.py's in-step probe: HIP events (on the launching stream) around a named launch of the step body."""
+        if self._probe is not None and site in self._probe:
+            self._probe[site][i].record()
+
     def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
-        """One step.  Data parallel: ``body_dp`` (collectives pin the launch order).  Single GPU: the launch plan below.
+        """One step, single GPU or data parallel (``self.dist``): the launch plan below.  Data parallel adds four
+        collectives, ALL issued from the capture stream in the same order on every rank: the VAE gradient (before its
+        Adam), [critic | cost-critic gradients] (where the main branch waits for the side branch's critic dW anyway),
+        the all-gather of the N*B KL values for the batch-global quantile (the selection itself and the masked mean
+        return to the side branch), and [actor gradient | statistics | partial qc_ood mean] after the join.
 
         What the plan exploits (cpq.py:155-201): everything the OOD penalty is made of -- the N*B sampled actions, the
         target cost critics on them, the VAE encoder on them, the KL rows, their 0.75-quantile, ``qc_ood`` -- sits
@@ -161,8 +174,9 @@ class CPQEngine:
         The side branch joins at the END of the step.  Ordering constraints kept by events: the cost-critic Adam also
         Polyak-updates ``cost_critic_old``, so it waits for the side branch's last reader of the targets; the encoder on
         the N*B rows waits for the VAE's Adam; the actor phase waits for the critic's Adam."""
-        if self.dist is not None:
-            return self.body_dp(device_noise, par)
+        dp = self.dist
+        if dp is not None and os.environ.get("OSRL_DP_PLAN") == "r1":
+            return self.body_dp(device_noise, par)  # the round-1 plan (A/B measurements)
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
@@ -192,13 +206,22 @@ class CPQEngine:
             G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
             # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
             G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
+            self._pr("costold_ood", 0)
             qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+            self._pr("costold_ood", 1)
             # critic_loss (cpq.py:137-153)
+            self._pr("critic_fwd", 0)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
+            self._pr("critic_fwd", 1)
             G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
                               rg, self.dq, st.stat_ptr("loss/critic_loss"))
             self.r_critic.backward_dz()
-            self._optim("critic", self.p_critic, m.tau)
+            if dp is None:
+                self._optim("critic", self.p_critic, m.tau)
+            else:  # collectives stay on the capture stream (same order on every rank): reduced + stepped over there
+                self.p_critic.launch()
+                if os.environ.get("OSRL_DP_SIDE_REDUCE", "1") == "1":
+                    dp.reduce_local(m.groups["critic"])  # the per-rank slab sum is no collective: off the main chain
             ev_critic = par.mark(0)  # also: the side branch's last reader of cost_critic_old is enqueued
 
         # ---- main: cost_critic_loss (cpq.py:155-201), the part with a gradient: Bellman MSE of the online cost critics
@@ -209,19 +232,25 @@ class CPQEngine:
         self.r_cost.backward_dz()
         self.p_cost.launch()
         par.wait(ev_critic)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the side branch
-        self._update("cost_critic", m.tau)
+        if dp is None:
+            self._update("cost_critic", m.tau)
+        else:  # both critic groups' gradients in ONE collective (neither update reads the other's result)
+            gc, gcc = m.groups["critic"], m.groups["cost_critic"]
+            dp.all_reduce_many_([dp.reduce_local(gc), dp.reduce_local(gcc)])
+            gc.adam_step(m._lrs["critic"], st.ptr, tau=m.tau)
+            gcc.adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau)
 
         # ---- side branch, second half: the OOD statistic with the UPDATED vae
         with par.on(0):
             if ev_vae is not None:
                 par.side[0].wait_event(ev_vae)
-            if self._probe is not None:  # bench.py: HIP events around the dominant launch as it runs inside the step
-                self._probe[0].record()
+            self._pr("enc_ood", 0)  # bench.py: HIP events around the dominant launch as it runs inside the step
             head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
-            if self._probe is not None:
-                self._probe[1].record()
+            self._pr("enc_ood", 1)
             G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
-            if N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
+            if dp is not None:
+                ev_kl = par.mark(0)
+            elif N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
                 G.cpq_ood_stat(qc_s, nqc, self.kl, 0.75, N, B, rg, self.quant, self.ood_mean)
             else:
                 G.quantile(self.kl, N * B, 0.75, self.quant)
@@ -229,20 +258,49 @@ class CPQEngine:
 
         # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch: this stream waited for
         # ev_critic above -- a second wait on it is one more graph edge, ~6 us on the chain) and cost critic (here)
+        self._pr("actor_phase_fwd", 0)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
+        self._pr("actor_phase_fwd", 1)
+        if dp is not None:
+            # the batch-GLOBAL quantile (cpq.py:183 over all world * N * B values): the gather is a collective, so it
+            # is issued from the capture stream -- here, behind the actor phase's forward launch, which is about when
+            # the side branch has its KL rows (profiles/r2_timeline.txt: 397 us vs 405 us); the selection and the
+            # masked mean go back to the side branch and run beside the actor phase's backward
+            par.wait(ev_kl)
+            kl_all = dp.all_gather_concat(self.kl)
+            if os.environ.get("OSRL_DP_SIDE_QUANT", "1") == "1":
+                ev_g = torch.cuda.Event() if par.enabled else None
+                if ev_g is not None:
+                    ev_g.record()
+                with par.on(0):
+                    if ev_g is not None:
+                        par.side[0].wait_event(ev_g)
+                    dp.quantile_select(kl_all, 0.75, self.quant)
+                    G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            else:
+                dp.quantile_select(kl_all, 0.75, self.quant)
+                G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
         G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
         self.r_pi_q.backward_dz()
         G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
                          self.dhead_actor)
         self.r_actor_obs.backward_dz()
-        self._optim("actor", self.p_actor, m.tau)
-        par.join(0)
+        if dp is None:
+            self._optim("actor", self.p_actor, m.tau)
+            par.join(0)
+        else:  # actor gradient, the per-rank partial statistics and the partial qc_ood mean in one collective
+            self.p_actor.launch()
+            par.join(0)
+            ga = m.groups["actor"]
+            dp.all_reduce_many_([dp.reduce_local(ga), st.stats, self.ood_mean])
+            ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
         # dual step + the OOD term of the logged loss (cpq.py:186-195): after the join, so that the side branch has no
-        # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains)
+        # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains); under
+        # data parallelism the statistics are already the global ones here, so the global term is added once
         G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
 
     def body_dp(self, device_noise: bool, par: Optional[Branches] = None) -> None:
-        """One data-parallel step (also the single-GPU plan of round 1).  ``par`` (graph capture only) forks the independent parts onto side streams:
+        """The ROUND-1 data-parallel plan (OSRL_DP_PLAN=r1; ``body`` carries the data-parallel step since round 3).  ``par`` (graph capture only) forks the independent parts onto side streams:
         critic phase (cpq.py:137-153) and the cost-critic target pre-work (cpq.py:159-176) do not depend
         on the VAE update, so they run beside the VAE phase; the cost-critic update waits for the side branch's
         forwards (the readers of the targets it Polyak-updates), the actor phase for the whole branch."""
@@ -293,11 +351,9 @@ class CPQEngine:
 
         # ---- cost_critic_loss  (cpq.py:155-201): OOD scoring with the UPDATED vae
         par.wait(ev_sampled)
-        if self._probe is not None:  # bench.py: HIP events around the dominant launch as it runs inside the step
-            self._probe[0].record()
+        self._pr("enc_ood", 0)
         head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
-        if self._probe is not None:
-            self._probe[1].record()
+        self._pr("enc_ood", 1)
         G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
         if self.dist is not None:
             self.dist.quantile(self.kl, 0.75, self.quant)

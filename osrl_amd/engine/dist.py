@@ -53,7 +53,10 @@ class DataParallel:
         """all-reduce(SUM) of several tensors as ONE collective launch (ncclGroupStart/End coalescing): the step's
         messages are 4 B - 1.6 MB, i.e. latency-bound on xGMI, so the count of collectives is what costs."""
         ts = [t for t in ts if t is not None]
-        if len(ts) > 1 and ts[0].is_cuda and dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+        # (a subclass that supplies its own all_reduce_ -- the in-process stand-ins of tests/test_gpu_dp_sim.py -- must
+        # not be bypassed by the coalesced RCCL path just because some process group happens to be initialised)
+        own = type(self).all_reduce_ is DataParallel.all_reduce_
+        if own and len(ts) > 1 and ts[0].is_cuda and dist.is_initialized() and dist.get_backend(self.group) == "nccl":
             with dist._coalescing_manager(group=self.group, device=ts[0].device, async_ops=False):
                 for t in ts:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -114,8 +117,11 @@ class DataParallel:
         self.all_reduce_(self.reduce_local(grp))
 
     def quantile(self, local_vals: torch.Tensor, q: float, out: torch.Tensor) -> None:
+        self.quantile_select(self.all_gather_concat(local_vals), q, out)
+
+    def quantile_select(self, allv: torch.Tensor, q: float, out: torch.Tensor) -> None:
+        """The q-quantile of the gathered values (no collective inside: may run on a side stream)."""
         from . import glue as G
-        allv = self.all_gather_concat(local_vals)
         n = allv.numel()
         if n > 32768:  # past the register-resident single-workgroup select: the grid version (200 -> ~30 us at 8 ranks)
             ws = getattr(self, "_qws", None)

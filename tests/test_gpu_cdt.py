@@ -393,19 +393,14 @@ def test_cdt_graph_replay_matches_eager():
             assert (res[0][k] - res[1][k]).abs().max() < 1e-6, k
 
 
-def test_cdt_data_parallel_world1_matches_single():
+def test_cdt_data_parallel_world1_matches_single(nccl_world1):
     """CDT DP wiring (global count normalisers, flat-gradient all-reduce before the clip, entropy/stat reductions,
     hipGraph capture incl. RCCL) as a 1-rank NCCL job == the plain single-GPU step."""
     import os
     import torch.distributed as dist
     from osrl_amd.engine.dist import DataParallel
     c = CDT_CASES["cdt_small"]
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29300 + os.getpid() % 500))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
-        created = True
+    assert nccl_world1.is_initialized()  # the session's one 1-rank NCCL group (conftest.py)
     try:
         res = []
         for mode in ("single", "dp_eager", "dp_graph"):
@@ -425,8 +420,7 @@ def test_cdt_data_parallel_world1_matches_single():
             for k in res[0][1]:
                 assert np.allclose(res[0][1][k], other[1][k], rtol=1e-5, atol=1e-6), k
     finally:
-        if created:
-            dist.destroy_process_group()
+        pass
 
 
 def test_cdt_checkpoint_resume_is_bit_identical(tmp_path):

@@ -75,7 +75,13 @@ def test_train_step_matches_golden_and_oracle(name):
 
 
 GROUP_GATE = 2e-5  # Adam first moments (= gradients), relative to each tensor's scale
-LOOSE_GATES = {"cpq_c2_full": {"actor": 5e-3, "critic": 5e-4}}  # cancelling batch sums, see the test
+# C2's actor gradient at initialisation is tiny (|m| ~ 2e-6 .. 4e-6 at both seeds tried; the critic head's at one seed
+# 4e-4) while ONE row's contribution to it is ~(1 - beta1)/B * |dq/da| ~ 1e-6: a single ReLU unit of one row that sits
+# within an ulp of its kink and falls on the other side than in the fp64 oracle moves the sum by ~1e-8 -- with 2048 rows
+# x ~1000 units about one such unit is expected per step.  That is what is observed (9.9e-9 and 3.7e-8; the fp32 numpy
+# oracle happens to have none: 1.4e-12), so first moments are gated at 2e-5 of the tensor's scale OR this absolute
+# floor; every other group of every case (incl. the actor at the C4 shape) meets the relative gate with a 30x margin.
+KINK_FLOOR = 1e-7
 
 
 def _note(msg: str) -> None:
@@ -92,6 +98,9 @@ FULL_CASES = {
     # pinned oracle is the checker.  These are the only parity runs that reach the N*B-row launches (32-row tiles,
     # the capped tile-loop kernel), the paired launches and the 8-wave kernels at bench size.
     "cpq_c2_full": dict(algo="cpq", od=76, ad=2, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=21),
+    # a second seed of C2: the loose actor / critic-head gates of cpq_c2_full are claimed to be a property of THAT
+    # seed's gradient (a heavily cancelling batch sum), not of the kernels -- this one takes the tight gate everywhere
+    "cpq_c2_full_s2": dict(algo="cpq", od=76, ad=2, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=31),
     "bcql_c3_full": dict(algo="bcql", od=33, ad=8, B=4096, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=22),
     # BASELINE.json C4 per-GPU shape: CPQ on OfflineHalfCheetah dims (17, 6) -> latent 12, VAE inputs 23 / 29 wide,
     # q inputs 23 wide: other paddings / column-block splits than C2 (cpq_configs.py:359 task)
@@ -108,10 +117,12 @@ def test_full_size_train_step_matches_oracle(name):
     c = Case(name, episode_len=1000, **FULL_CASES[name])
     m, tr, lg = build_gpu(c)
     o = build_oracle(c, np.float64)  # fp64: the oracle's own round-off must not blur the comparison at this size
+    o32 = build_oracle(c, np.float32)  # the same restatement in fp32: what fp32 round-off alone does to each tensor
     b = gpu_batch(c)
     for s in range(c.steps):
         gpu_step(tr, c, b, s)
         ost = oracle_step(o, c, s)
+        oracle_step(o32, c, s)
         for k, r in ost.items():
             got = lg.last(k)
             assert abs(got - r) <= 1e-4 * max(1.0, abs(r)), f"{name} step {s} {k}: gpu {got} vs oracle {r}"
@@ -123,25 +134,30 @@ def test_full_size_train_step_matches_oracle(name):
     from cases import hyper
     hp = hyper(c)
     opts = {"actor": o.opt_actor, "critic": o.opt_critic, "cost_critic": o.opt_cost, "vae": o.opt_vae}
-    # Per-group gates on max|m_gpu - m_oracle| / max|m_oracle| per tensor.  Measured on MI355X (gpurun_out/
-    # parity_margins.txt, round 2): every group of every case agrees with the fp64 oracle to 3.4e-7 .. 6.4e-7 of its
-    # scale, EXCEPT two groups of cpq_c2_full whose gradients at this seed are heavily cancelling batch sums (actor:
-    # |g| ~ 1e-5 from terms ~1e-3 -> 2.8e-3; critic head weight: scale 3.9e-4 -> 1.5e-4).  So the gate is 2e-5
-    # everywhere -- a 1e-3 relative error in any kernel that first runs at this size (32-row tiles, the tile-loop
-    # kernel, the paired launches, the 8-wave variants) fails -- and the two cancellation cases carry their own.
-    gates = {g: GROUP_GATE for g in ("actor", "critic", "cost_critic", "vae")}
-    gates.update(LOOSE_GATES.get(name, {}))
-    worst = {}
+    opts32 = {"actor": o32.opt_actor, "critic": o32.opt_critic, "cost_critic": o32.opt_cost, "vae": o32.opt_vae}
+    # Per-tensor gate on max|m_gpu - m_oracle64|: 2e-5 of the tensor's scale -- a 1e-3 relative error in any kernel that
+    # first runs at this size (32-row tiles, the 80-row kernel, the paired launches, the 8-wave variants) fails -- or
+    # the absolute kink floor above.  Measured on MI355X (gpurun_out/parity_margins.txt): every group of every case
+    # sits at 3e-7 .. 7e-7 of its scale except C2's actor (both seeds) and the critic head of one seed.
+    worst, worst_ratio = {}, {}
     for gname, opt in opts.items():
         grp = m.groups[gname]
         for k, mo in opt.m.items():
             mg = grp._view(grp.m, k).cpu().numpy()
             scale = max(np.abs(mo).max(), 1e-12)
-            d = np.abs(mg - mo).max()
+            # a ReLU unit / min-routing decision within an ulp of its kink may fall on either side in fp32 and fp64: the
+            # GPU has to agree with ONE of the two restatements (seed 31: GPU == fp32 oracle to 1e-12 where both miss
+            # the fp64 oracle by 2.9e-7 on actor.mu_layer.weight)
+            d32 = np.abs(opts32[gname].m[k].astype(np.float64) - mo).max()
+            d = min(np.abs(mg - mo).max(), np.abs(mg - opts32[gname].m[k]).max())
             worst[gname] = max(worst.get(gname, 0.0), d / scale)
-            assert d <= gates[gname] * scale, \
-                f"{name} Adam first moment {k} ({gname}): max diff {d:.3e} vs scale {scale:.3e} (gate {gates[gname]:.0e})"
-    _note(f"{name} worst first-moment diff / scale per group: " + ", ".join(f"{g}={v:.2e}" for g, v in worst.items()))
+            if d > GROUP_GATE * scale:
+                worst_ratio[gname] = max(worst_ratio.get(gname, 0.0), d)
+            assert d <= max(GROUP_GATE * scale, KINK_FLOOR), \
+                f"{name} Adam first moment {k} ({gname}): max diff {d:.3e} vs scale {scale:.3e}, fp32 oracle misses by {d32:.3e}"
+    _note(f"{name} worst first-moment diff / scale per group: " + ", ".join(f"{g}={v:.2e}" for g, v in worst.items()) +
+          ("; beyond 2e-5 of scale (absolute error, gated by the kink floor 1e-7): " +
+           ", ".join(f"{g}={v:.2e}" for g, v in worst_ratio.items()) if worst_ratio else ""))
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     for k, v in o.p.items():
         lr = hp.get(k.split(".")[0].replace("cost_critic", "critic") + "_lr", max(x for n, x in hp.items() if n.endswith("_lr")))
@@ -243,7 +259,7 @@ def test_graph_with_parallel_branches_equals_eager_sequential(name):
         assert torch.equal(res[0][k], res[1][k]), f"{name}: {k} differs between eager and graph execution"
 
 
-def test_data_parallel_path_world1_nccl_matches_single():
+def test_data_parallel_path_world1_nccl_matches_single(nccl_world1):
     """The DP wiring (slab pre-reduction -> RCCL all-reduce -> Adam on the reduced gradient, all-gather
     quantile, scalar all-reduces) run as a 1-rank NCCL job must reproduce the plain single-GPU step
     bit-for-bit (all reductions are identities at world_size 1)."""
@@ -251,12 +267,7 @@ def test_data_parallel_path_world1_nccl_matches_single():
     import torch.distributed as dist
     from osrl_amd.engine.dist import DataParallel
     c = CASES["cpq_small"]
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-        created = True
+    assert nccl_world1.is_initialized()  # the session's one 1-rank NCCL group (conftest.py)
     try:
         res = []
         for use_dp in (False, True):
@@ -275,23 +286,17 @@ def test_data_parallel_path_world1_nccl_matches_single():
         for k in res[0][1]:
             assert [float(x) for x in res[0][1][k]] == [float(x) for x in res[1][1][k]], k
     finally:
-        if created:
-            dist.destroy_process_group()
+        pass
 
 
-def test_data_parallel_graph_capture_world1():
+def test_data_parallel_graph_capture_world1(nccl_world1):
     """hipGraph capture of the DP step including its RCCL collectives (1-rank job): must either capture
     and replay deterministically or fall back to eager with a warning -- never hang or corrupt state."""
     import os
     import torch.distributed as dist
     from osrl_amd.engine.dist import DataParallel
     c = CASES["cpq_small"]
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-        created = True
+    assert nccl_world1.is_initialized()  # the session's one 1-rank NCCL group (conftest.py)
     try:
         outs = []
         for rep in range(2):
@@ -308,24 +313,18 @@ def test_data_parallel_graph_capture_world1():
         for k in outs[0]:
             assert torch.equal(outs[0][k], outs[1][k]), k
     finally:
-        if created:
-            dist.destroy_process_group()
+        pass
 
 
 @pytest.mark.parametrize("name", ["bcql_pid", "bc_small", "bearl_lap"])
-def test_data_parallel_world1_other_algos(name):
+def test_data_parallel_world1_other_algos(name, nccl_world1):
     """BCQ-Lag / BEAR-Lag (global-mean pre-pass for the PID controller and the dual step) and BC under the DP hook as
     a 1-rank NCCL job == single GPU."""
     import os
     import torch.distributed as dist
     from osrl_amd.engine.dist import DataParallel
     c = ALL_CASES[name]
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29350 + os.getpid() % 500))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-        created = True
+    assert nccl_world1.is_initialized()  # the session's one 1-rank NCCL group (conftest.py)
     try:
         res = []
         for use_dp in (False, True):
@@ -342,8 +341,7 @@ def test_data_parallel_world1_other_algos(name):
         for k in res[0][1]:
             assert np.allclose(res[0][1][k], res[1][1][k], rtol=1e-6, atol=1e-7), k
     finally:
-        if created:
-            dist.destroy_process_group()
+        pass
 
 
 # --------------------------------------------------------------------------- #
