@@ -60,8 +60,9 @@ def test_chain_kernels_request_their_loads_together(listings, needles, max_waits
 
 
 def test_adam_requests_every_operand_up_front(listings):
-    r = _one(listings["optim"], "adam_kernel")
-    assert r["loads"] >= 14 and r["waits"] <= 4 and r["scratch"] == 0, r  # slabs, p, m, v, target, two maps: one group
+    for needle in ("adam_kernelE", "adam_kernel_pE"):  # by-value kernel and its device-resident-descriptor twin
+        r = _one(listings["optim"], needle)
+        assert r["loads"] >= 14 and r["waits"] <= 4 and r["scratch"] == 0, (needle, r)  # slabs, p, m, v, target, two maps: one group
 
 
 def test_nb_forward_kernel_shape(listings):
