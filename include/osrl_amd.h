@@ -92,8 +92,15 @@ typedef struct {
  *                             out[rows, L] = mean + exp(clamp(log_std, -4, 15)) * eps        == osrl_vae_latent
  *   OSRL_TAIL_VAE_LATENT_BWD  backward of the VAE decoder whose dX slice (dx[0], dx_cols == L) is dL/dz:
  *                             out[rows, 2L] = d(recon + beta KL)/d(mean | log_std)          == osrl_vae_latent_bwd
- *                             with head = the encoder output [rows, 2L]; beta, rows_global as in that call */
-enum { OSRL_TAIL_NONE = 0, OSRL_TAIL_VAE_LATENT = 1, OSRL_TAIL_VAE_LATENT_BWD = 2 };
+ *                             with head = the encoder output [rows, 2L]; beta, rows_global as in that call
+ *   OSRL_TAIL_GAUSS           forward of a squashed-Gaussian actor trunk (net 0, output [rows, 2L] = mu | log_std, L =
+ *                             action_dim; net.py:152-205): up to two action draws and the N pre-tanh OOD draws of
+ *                             cpq.py:164-176 from the LDS-resident head tile --
+ *                               out [rows, L]  = max_action * tanh(mu + exp(clamp(log_std, -20, 2)) * eps)    == osrl_gauss_head
+ *                               out2 [rows, L] = the same with eps2 (NULL = none), tanh2 [rows, L] = its tanh(u) (optional)
+ *                               out_ood [n_samples * rows, L], row j * rows + r = mu + sd * eps_ood[j, r, :]  == osrl_gauss_ood_sample
+ *                             (any of the three may be absent: eps / eps2 / eps_ood NULL) */
+enum { OSRL_TAIL_NONE = 0, OSRL_TAIL_VAE_LATENT = 1, OSRL_TAIL_VAE_LATENT_BWD = 2, OSRL_TAIL_GAUSS = 3 };
 typedef struct {
   int32_t kind;
   int32_t L;
@@ -103,6 +110,14 @@ typedef struct {
   float beta;          /* OSRL_TAIL_VAE_LATENT_BWD only */
   int32_t rows_global; /* OSRL_TAIL_VAE_LATENT_BWD only: the loss is a mean over this many rows (<= 0: rows) */
   float inv_rows_;     /* filled in by the library */
+  /* OSRL_TAIL_GAUSS only */
+  float max_action;
+  const float* eps2;
+  float* out2;
+  float* tanh2;
+  const float* eps_ood;
+  float* out_ood;
+  int32_t n_samples, pad_;
 } osrl_mlp_tail_t;
 
 /* One weight-gradient GEMM  dW[out,in] = dz^T a,  db[out] = sum_rows dz  (autograd of addmm). */
@@ -146,6 +161,11 @@ int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_act
  * fused into the launch when its last tile is LDS-resident, two launches otherwise. */
 int osrl_mlp_forward_tail(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
                           const osrl_mlp_tail_t* tail, void* stream);
+/* osrl_mlp_forward2 with a forward tail per problem (either may be NULL): e.g. the actor on next_obs and on obs with
+ * every action draw of the CPQ step (cpq.py:141,159,164-176,209) made by the same launch. */
+int osrl_mlp_forward2_tail(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
+                           const osrl_mlp_tail_t* tail0, const osrl_mlp_t* net1, const osrl_rows_t* in1,
+                           const osrl_mlp_acts_t* out1, const osrl_mlp_tail_t* tail1, void* stream);
 int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                               const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream);
 /* General linear layer on packed weights: Y[M,N] = A[M,K] * P (+ bias[N]) (+ resid[M,N]).  P is the forward
@@ -164,6 +184,12 @@ int osrl_pack_weights(const float* src_flat, float* pf, float* pb, const osrl_pa
  * 64x64 tiles; slabs = [n_splits][slab_stride] partial gradients (deterministic split-K over rows). */
 int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
                          int32_t rows, int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
+/* The same GEMMs on (16 * tile_blocks)^2 tiles (tile_blocks = 4 | 5) with a FLAT work list: d_work[4 i ..] =
+ * (entry, out tile, in tile, split | n_splits << 16); every (tile, split) pair is one workgroup and writes slab `split`.
+ * Lets the caller give tiles of unequal work unequal row splits and pick 80 x 80 tiles for 400-wide layers (25 column
+ * blocks = 5 x 5: no ragged tiles).  Same per-element arithmetic as osrl_mlp_backward_dw. */
+int osrl_mlp_backward_dw_tiles(const osrl_dw_entry_t* d_entries, const int32_t* d_work, int32_t n_work, int32_t rows,
+                               int32_t tile_blocks, float* slabs, int64_t slab_stride, void* stream);
 /* The same contract for items given in units of 128 (out) x 64 (in) tiles that lie fully inside their dW (only
  * full tiles may be listed): one wave per tile and row split, 128-register accumulator tiles, one wave per SIMD -- the big-row-count (token matrix) variant; db of an entry is written by its it == 0 tiles.
  * Splits beyond a plan's own n_splits are never written (the caller keeps them zero). */

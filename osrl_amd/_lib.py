@@ -50,10 +50,12 @@ class GradsT(C.Structure):
 
 class TailT(C.Structure):  # osrl_mlp_tail_t
     _fields_ = [("kind", C.c_int32), ("L", C.c_int32), ("eps", _fp), ("head", _fp), ("out", _fp),
-                ("beta", C.c_float), ("rows_global", C.c_int32), ("inv_rows_", C.c_float)]
+                ("beta", C.c_float), ("rows_global", C.c_int32), ("inv_rows_", C.c_float),
+                ("max_action", C.c_float), ("eps2", _fp), ("out2", _fp), ("tanh2", _fp), ("eps_ood", _fp),
+                ("out_ood", _fp), ("n_samples", C.c_int32), ("pad_", C.c_int32)]
 
 
-TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD = 0, 1, 2
+TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD, TAIL_GAUSS = 0, 1, 2, 3
 
 
 class DwEntryT(C.Structure):
@@ -133,10 +135,12 @@ PROTOTYPES = {
     "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
     "osrl_mlp_forward_tail": [_P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _vp],
+    "osrl_mlp_forward2_tail": [_P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _vp],
     "osrl_mlp_backward_dz_tail": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _P(TailT), _vp],
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
     "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
+    "osrl_mlp_backward_dw_tiles": [_vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp],
     "osrl_mlp_backward_dw_big": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
     "osrl_step_begin": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _fp, _i64, _u64, _u32, _i32, _P(_fp), _P(_fp),

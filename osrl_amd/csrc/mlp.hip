@@ -478,6 +478,56 @@ __device__ __forceinline__ void tail_vae_latent_bwd(const float* lds, int lda, i
   }
 }
 
+// tile = the actor trunk's output [BM][2 ad] (mu | log_std): the action draws of the squashed-Gaussian head
+// (glue.hip gauss_head_kernel / gauss_ood_kernel, expression for expression) while the tile is in LDS
+constexpr float kTailLogStdMin = -20.0f, kTailLogStdMax = 2.0f;  // net.py:148-149 (== kLogStdMin / kLogStdMax of glue.hip)
+template <class TR>
+__device__ __forceinline__ void tail_gauss(const float* lds, int lda, int BM, int row0, int rows, TR t) {
+  const int ad = t.L;
+  const float max_a = t.max_action;
+  const float* __restrict__ e1 = t.eps;
+  const float* __restrict__ e2 = t.eps2;
+  float* __restrict__ a1 = t.out;
+  float* __restrict__ a2 = t.out2;
+  float* __restrict__ th2 = t.tanh2;
+  for (int idx = threadIdx.x; idx < BM * ad; idx += (int)blockDim.x) {
+    const int r = idx / ad, j = idx - r * ad;
+    const int gr = row0 + r;
+    if (gr < rows) {
+      const float mu = lds[r * lda + j];
+      const float ls = fminf(fmaxf(lds[r * lda + ad + j], kTailLogStdMin), kTailLogStdMax);
+      const float sd = expf(ls);
+      const size_t i = (size_t)gr * ad + j;
+      if (e1) {
+        const float u = mu + sd * e1[i];
+        a1[i] = max_a * tanhf(u);
+      }
+      if (e2) {
+        const float u = mu + sd * e2[i];
+        const float th = tanhf(u);
+        a2[i] = max_a * th;
+        if (th2) th2[i] = th;
+      }
+    }
+  }
+  const float* __restrict__ eo = t.eps_ood;
+  if (eo) {
+    float* __restrict__ so = t.out_ood;
+    const int ns = t.n_samples;
+    for (int idx = threadIdx.x; idx < ns * BM * ad; idx += (int)blockDim.x) {
+      const int jr = idx / ad, k = idx - jr * ad;
+      const int smp = jr / BM, r = jr - smp * BM;
+      const int gr = row0 + r;
+      if (gr < rows) {
+        const float mu = lds[r * lda + k];
+        const float ls = fminf(fmaxf(lds[r * lda + ad + k], kTailLogStdMin), kTailLogStdMax);
+        const size_t i = ((size_t)smp * rows + gr) * ad + k;
+        so[i] = mu + expf(ls) * eo[i];
+      }
+    }
+  }
+}
+
 struct FwdArgs {
   osrl_mlp_t net;
   osrl_rows_t in;
@@ -625,6 +675,7 @@ __device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) 
   }
   // the net's output tile [BM][dims[L]] is still in LDS (nothing wrote it since the last barrier)
   if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
+  if (a.tail.kind == OSRL_TAIL_GAUSS && e == 0) tail_gauss<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
   WG_LOG(1);
 }
 
@@ -1454,6 +1505,203 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(const osrl_dw_entry_t* __re
 }
 
 
+// ---- dW on (16 T) x (16 T) tiles with a flat (tile, row split) work list ---------------------------------------
+// mlp_dw_kernel deals 64 x 64 tiles x a common split count.  For the 400-wide VAE (25 column blocks) that is 140 tiles,
+// 13 of every 49 ragged, x 2 splits = 280 workgroups on 256 CUs: the CUs that get two full tiles set the pace (49.6 us
+// for 1.59 GFLOP = 0.20 of the fp32 roof, profiles/r2_bench_trace_summary.txt).  25 = 5 x 5: with T = 5 (80 x 80
+// tiles, 25 accumulator tiles per wave) the VAE's six layers are 60 full tiles + 10 one-block-high strips, no ragged
+// edge anywhere; the work list gives a full tile 4 row splits (each wave 128 rows = 800 MFMAs) and a strip 1 (each wave
+// 512 rows = 640 MFMAs): 250 workgroups, one per CU, one round, even work.  Same arithmetic per output element as
+// mlp_dw_kernel (a wave's k-ordered MFMA chain over its rows, four partials summed in wave order, slabs summed in
+// split order by the consumer), so the sum order -- and the bits -- depend only on (rows per wave), as before.
+// items[4 i ..] = (entry, out tile, in tile, split | n_splits << 16).
+template <int T>
+struct DwFragT {
+  f32x4 a[T], b[T];
+};
+
+// One 16-row k-step of fragments, UNMASKED: the column offsets oa / ia are loop invariants, clamped once to stay in
+// bounds -- a lane of an invalid column reads element 0 of the row and pollutes only output rows o >= out / columns
+// i >= in, which are never stored (an MFMA's output element (o, i) depends on operand rows o and i alone).  With the
+// select-per-load form of mlp_dw_kernel every load is consumed by a v_cndmask right behind it, so the loads of step
+// k + 1 are waited for BEFORE the MFMAs of step k start and a k-step costs latency + MFMA time instead of the larger
+// of the two (tools/dw_bench.py: 54 us for the VAE group whatever the tiling).  Only rows are masked, and only in a
+// wave's last, partial k-step (dwt_load_tail).
+template <int T>
+__device__ __forceinline__ void dwt_load(DwFragT<T>& f, const float* __restrict__ pz, const float* __restrict__ pa,
+                                         size_t ldz, size_t lda_g, const unsigned (&oa)[T], const unsigned (&ia)[T],
+                                         int nob, int nib) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    // branch-free: blocks past nob / nib re-read column 0 (a guarded load gets its own wait)
+#pragma unroll
+    for (int ob = 0; ob < T; ++ob) f.a[ob][t] = pz[t * ldz + oa[ob]];
+#pragma unroll
+    for (int ib = 0; ib < T; ++ib) f.b[ib][t] = pa[t * lda_g + ia[ib]];
+  }
+}
+// the partial last k-step: rows >= r_end contribute zeros (A operand zeroed; B then does not matter)
+template <int T>
+__device__ __forceinline__ void dwt_load_tail(DwFragT<T>& f, const float* __restrict__ dz, const float* __restrict__ av,
+                                              size_t ldz, size_t lda_g, const unsigned (&oa)[T], const unsigned (&ia)[T],
+                                              int nob, int nib, int r0, int r_end, int kq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = r0 + 4 * kq + t;
+    const bool rok = r < r_end;
+    const size_t rc = (size_t)(rok ? r : r_end - 1);
+#pragma unroll
+    for (int ob = 0; ob < T; ++ob) {
+      const float v = dz[rc * ldz + oa[ob]];
+      f.a[ob][t] = rok ? v : 0.f;
+    }
+#pragma unroll
+    for (int ib = 0; ib < T; ++ib) f.b[ib][t] = av[rc * lda_g + ia[ib]];
+  }
+}
+
+// FULL: all T x T blocks of the tile exist -- straight-line MFMAs (a guard per block is a branch per block, and every
+// branch target gets a conservative s_waitcnt vmcnt(0): the next step's loads would be waited for before this step's
+// MFMAs start); ragged tiles and one-block strips take the guarded form
+// SHAPE 2 = 1 x T (the narrow heads' strips: one output block), also straight-line; SHAPE 0 = anything else, guarded
+template <int T, int SHAPE>
+__device__ __forceinline__ void dwt_mma(f32x4 (&acc)[T][T], float (&dbacc)[T], const DwFragT<T>& f, int nob, int nib,
+                                        bool want_db) {
+  constexpr bool FULL = SHAPE == 1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int ob = 0; ob < (SHAPE == 2 ? 1 : T); ++ob) {
+      if (SHAPE != 0 || ob < nob) {
+#pragma unroll
+        for (int ib = 0; ib < T; ++ib)
+          if (SHAPE != 0 || ib < nib) acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ob][t], f.b[ib][t], acc[ob][ib], 0, 0, 0);
+      }
+    }
+  }
+  (void)FULL;
+  if (want_db) {
+#pragma unroll
+    for (int ob = 0; ob < T; ++ob) dbacc[ob] += (f.a[ob][0] + f.a[ob][1]) + (f.a[ob][2] + f.a[ob][3]);
+  }
+}
+
+template <int T>
+constexpr size_t dwt_lds() { return sizeof(float) * (4 * (16 * T) * (16 * T + 1) + 4 * 16 * T); }
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* __restrict__ entries,
+                                                         const int32_t* __restrict__ items, int rows,
+                                                         float* __restrict__ slabs, int64_t slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][16T][16T+1] partials + [4][16T] bias partials
+  constexpr int TW = 16 * T, LD = TW + 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if OSRL_CHAIN_PRIO > 0
+  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
+  const int item = blockIdx.x;
+  const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2], sp = items[item * 4 + 3];
+  const int s = sp & 0xffff, nsp = sp >> 16;
+  // read through the constant address space: pointers loaded from there are known-global (global_load with a scalar
+  // base); loaded from a plain global struct they are generic and every fragment load becomes a flat_load with its own
+  // 64-bit address add, counted on BOTH vmcnt and lgkmcnt
+  const OSRL_CAS osrl_dw_entry_t& E = ((const OSRL_CAS osrl_dw_entry_t*)entries)[ei];
+  const int out = E.out, in = E.in;
+  const size_t ldz = E.ldz > 0 ? (size_t)E.ldz : (size_t)out, lda_g = E.lda > 0 ? (size_t)E.lda : (size_t)in;
+  const int o0 = ot * TW, i0 = it * TW;
+  int rps = (rows + nsp - 1) / nsp;
+  rps = (rps + 63) & ~63;  // 4 waves x whole 16-row k-steps
+  const int rpw = rps >> 2;
+  const int r_begin = s * rps + wave * rpw;
+  int r_end = r_begin + rpw;
+  r_end = r_end > rows ? rows : r_end;
+  const int m = lane & 15, kq = lane >> 4;
+  int nob = (out - o0 + 15) >> 4;
+  nob = nob > T ? T : nob;
+  int nib = (in - i0 + 15) >> 4;
+  nib = nib > T ? T : nib;
+  const bool want_db = it == 0;
+
+  f32x4 acc[T][T];
+  zero_acc<T, T>(acc);
+  float dbacc[T];
+#pragma unroll
+  for (int ob = 0; ob < T; ++ob) dbacc[ob] = 0.f;
+  const float* __restrict__ dz = E.dz;
+  const float* __restrict__ av = E.a;
+  unsigned oa[T], ia[T];  // this lane's column of each block, clamped into the row (see dwt_load)
+#pragma unroll
+  for (int b = 0; b < T; ++b) {
+    const int o = o0 + b * 16 + m, i = i0 + b * 16 + m;
+    oa[b] = (unsigned)(o < out ? o : 0);  // (also every block past nob / nib: o >= out, i >= in there)
+    ia[b] = (unsigned)(i < in ? i : 0);
+  }
+  if (r_begin < r_end) {
+    const int n_full = (r_end - r_begin) >> 4;  // whole 16-row k-steps
+    const float* __restrict__ pz = dz + (size_t)(r_begin + 4 * kq) * ldz;
+    const float* __restrict__ pa = av + (size_t)(r_begin + 4 * kq) * lda_g;
+    DwFragT<T> f0, f1;
+    // no control flow inside the pair loop (the reload past the end re-reads the last step): the compiler can then
+    // count the loads in flight (s_waitcnt vmcnt(n > 0)) and step k's MFMAs run under step k + 1's loads
+    auto run = [&](auto full_c) {
+      constexpr int FULL = decltype(full_c)::value;
+      if (n_full > 0) dwt_load<T>(f0, pz, pa, ldz, lda_g, oa, ia, nob, nib);
+      int k = 0;
+      for (; k + 1 < n_full; k += 2) {
+        dwt_load<T>(f1, pz + (size_t)(k + 1) * 16 * ldz, pa + (size_t)(k + 1) * 16 * lda_g, ldz, lda_g, oa, ia, nob, nib);
+        dwt_mma<T, FULL>(acc, dbacc, f0, nob, nib, want_db);
+        const int kn = k + 2 < n_full ? k + 2 : n_full - 1;
+        dwt_load<T>(f0, pz + (size_t)kn * 16 * ldz, pa + (size_t)kn * 16 * lda_g, ldz, lda_g, oa, ia, nob, nib);
+        dwt_mma<T, FULL>(acc, dbacc, f1, nob, nib, want_db);
+      }
+      if (k < n_full) dwt_mma<T, FULL>(acc, dbacc, f0, nob, nib, want_db);  // odd count: the last whole step is in f0
+      if (r_begin + 16 * n_full < r_end) {
+        dwt_load_tail<T>(f1, dz, av, ldz, lda_g, oa, ia, nob, nib, r_begin + 16 * n_full, r_end, kq);
+        dwt_mma<T, FULL>(acc, dbacc, f1, nob, nib, want_db);
+      }
+    };
+    if (nob == T && nib == T)
+      run(std::integral_constant<int, 1>{});
+    else if (nob == 1 && nib == T)
+      run(std::integral_constant<int, 2>{});
+    else
+      run(std::integral_constant<int, 0>{});
+  }
+  // ---- 4 partials -> LDS -> fixed-order sum -> one coalesced slab tile
+  float* mine = red + wave * TW * LD;
+#pragma unroll
+  for (int ob = 0; ob < T; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < T; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(ob * 16 + kq * 4 + r) * LD + ib * 16 + m] = acc[ob][ib][r];
+  if (want_db) {
+#pragma unroll
+    for (int ob = 0; ob < T; ++ob) {
+      float v = dbacc[ob];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0) red[4 * TW * LD + wave * TW + ob * 16 + m] = v;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+  for (int idx = tid; idx < TW * TW; idx += 256) {
+    const int ol = idx / TW, il = idx - ol * TW;
+    const int off = ol * LD + il;
+    const float v = ((red[off] + red[TW * LD + off]) + red[2 * TW * LD + off]) + red[3 * TW * LD + off];
+    const int o = o0 + ol, i = i0 + il;
+    if (o < out && i < in) slab[E.w_off + (size_t)o * in + i] = v;
+  }
+  if (want_db && tid < TW) {
+    const float* db = red + 4 * TW * LD;
+    const float v = ((db[tid] + db[TW + tid]) + db[2 * TW + tid]) + db[3 * TW + tid];
+    if (o0 + tid < out) slab[E.b_off + o0 + tid] = v;
+  }
+}
+
+
 
 // ---- dW for big row counts: one wave = one 128x128 tile, one wave per SIMD ------------------------------------
 // mlp_dw_kernel above is built for B = 2048-4096 rows (many small tiles, 4 waves splitting a few hundred rows).  At
@@ -2013,6 +2261,25 @@ static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osr
 
 }  // namespace
 
+// forward tails: argument check, and the same arithmetic as separate launches (the fallback when a launch keeps no
+// output tile in LDS)
+static bool fwd_tail_ok(const osrl_mlp_tail_t* t, const osrl_mlp_t* net) {
+  if (!t || t->kind == OSRL_TAIL_NONE) return true;
+  if (t->L < 1 || 2 * t->L != net->dims[net->n_layers]) return false;
+  if (t->kind == OSRL_TAIL_VAE_LATENT) return t->eps && t->out;
+  if (t->kind == OSRL_TAIL_GAUSS)
+    return (!t->eps || t->out) && (!t->eps2 || t->out2) && (!t->eps_ood || (t->out_ood && t->n_samples >= 1));
+  return false;
+}
+static int fwd_tail_as_launches(const osrl_mlp_tail_t* t, const float* head, int rows, void* stream) {
+  if (t->kind == OSRL_TAIL_VAE_LATENT) return osrl_vae_latent(head, t->eps, rows, t->L, t->out, stream);
+  int rc = 0;
+  if (t->eps) rc = osrl_gauss_head(head, t->eps, rows, t->L, t->max_action, t->out, nullptr, nullptr, stream);
+  if (rc == 0 && t->eps2) rc = osrl_gauss_head(head, t->eps2, rows, t->L, t->max_action, t->out2, t->tanh2, nullptr, stream);
+  if (rc == 0 && t->eps_ood) rc = osrl_gauss_ood_sample(head, t->eps_ood, t->n_samples, rows, t->L, t->out_ood, stream);
+  return rc;
+}
+
 static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out,
                             const osrl_mlp_tail_t* tail, void* stream) {
   if (!valid_net(net) || net->out_scale == 0.f || !in || !out || in->rows < 1 || in->d0 + in->d1 != net->dims[0]) return -1;
@@ -2022,14 +2289,12 @@ static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const 
       if (!net->Wf[e][l] || !net->b[e][l]) return -1;
   }
   const bool want_tail = tail && tail->kind != OSRL_TAIL_NONE;
-  if (want_tail && (tail->kind != OSRL_TAIL_VAE_LATENT || tail->L < 1 || 2 * tail->L != net->dims[net->n_layers] ||
-                    !tail->eps || !tail->out))
-    return -1;
+  if (want_tail && !fwd_tail_ok(tail, net)) return -1;
   {
     const int rc = launch_fwd_nb(net, in, out, (hipStream_t)stream);
     if (rc != kNotBig) {  // the 80-row kernel keeps no output tile in LDS: the tail is its own launch
       if (rc != 0 || !want_tail) return rc;
-      return osrl_vae_latent(out->h[0][net->n_layers - 1], tail->eps, in->rows, tail->L, tail->out, stream);
+      return fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
     }
   }
   FwdArgs a{};
@@ -2095,17 +2360,18 @@ static int launch_fwd2(const FwdArgs& a0, const FwdArgs& a1, int nets0, int nets
   return (int)hipGetLastError();
 }
 
-extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
-                                 const osrl_mlp_t* net1, const osrl_rows_t* in1, const osrl_mlp_acts_t* out1,
-                                 void* stream) {
+static int mlp_forward2_impl(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
+                             const osrl_mlp_tail_t* tail0, const osrl_mlp_t* net1, const osrl_rows_t* in1,
+                             const osrl_mlp_acts_t* out1, const osrl_mlp_tail_t* tail1, void* stream) {
   if (!valid_net(net0) || !valid_net(net1) || !in0 || !in1 || !out0 || !out1) return -1;
+  if (!fwd_tail_ok(tail0, net0) || !fwd_tail_ok(tail1, net1)) return -1;
   TileChoice t0 = choose_tile(net0, in0->rows, 0), t1 = choose_tile(net1, in1->rows, 0);
   // pair only 16-row-tile launches of equal tile shape; anything else runs as two launches
   const bool pair = t0.nrb == 1 && t1.nrb == 1 && t0.ncb == t1.ncb && t0.nw == t1.nw &&
                     ((t0.nw == 8 && (t0.ncb == 2 || t0.ncb == 4)) || (t0.nw == 4 && (t0.ncb == 4 || t0.ncb == 7)));
   if (!pair) {
-    const int rc = osrl_mlp_forward(net0, in0, out0, stream);
-    return rc != 0 ? rc : osrl_mlp_forward(net1, in1, out1, stream);
+    const int rc = mlp_forward_impl(net0, in0, out0, tail0, stream);
+    return rc != 0 ? rc : mlp_forward_impl(net1, in1, out1, tail1, stream);
   }
   for (int p = 0; p < 2; ++p) {
     const osrl_mlp_t* net = p ? net1 : net0;
@@ -2122,6 +2388,8 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
   a0.net = *net0; a0.in = *in0; a0.out = *out0;
   a1.net = *net1; a1.in = *in1; a1.out = *out1;
   a0.tail = a1.tail = osrl_mlp_tail_t{};
+  if (tail0) a0.tail = *tail0;
+  if (tail1) a1.tail = *tail1;
   const int lda = t0.lda > t1.lda ? t0.lda : t1.lda;
   a0.lda = a1.lda = lda;
   const int n0 = net0->n_nets, n1 = net1->n_nets, r0 = in0->rows, r1 = in1->rows;
@@ -2132,6 +2400,18 @@ extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0,
   }
   if (t0.ncb == 4) return launch_fwd2<1, 4, 4>(a0, a1, n0, n1, r0, r1, lda, st);
   return launch_fwd2<1, 7, 4>(a0, a1, n0, n1, r0, r1, lda, st);
+}
+
+extern "C" int osrl_mlp_forward2(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
+                                 const osrl_mlp_t* net1, const osrl_rows_t* in1, const osrl_mlp_acts_t* out1,
+                                 void* stream) {
+  return mlp_forward2_impl(net0, in0, out0, nullptr, net1, in1, out1, nullptr, stream);
+}
+
+extern "C" int osrl_mlp_forward2_tail(const osrl_mlp_t* net0, const osrl_rows_t* in0, const osrl_mlp_acts_t* out0,
+                                      const osrl_mlp_tail_t* tail0, const osrl_mlp_t* net1, const osrl_rows_t* in1,
+                                      const osrl_mlp_acts_t* out1, const osrl_mlp_tail_t* tail1, void* stream) {
+  return mlp_forward2_impl(net0, in0, out0, tail0, net1, in1, out1, tail1, stream);
 }
 
 static int mlp_backward_dz_impl(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
@@ -2283,6 +2563,28 @@ extern "C" int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const 
   hipLaunchKernelGGL(mlp_dw_big_kernel, dim3((n_items + 3) / 4, n_splits, 1), dim3(256), kLds, (hipStream_t)stream,
                      d_entries, d_items, n_items, rows, rps, slabs, slab_stride);
   return (int)hipGetLastError();
+}
+
+template <int T>
+static int launch_dwt(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_work, int32_t rows, float* slabs,
+                      int64_t slab_stride, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dwt_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dwt_lds<T>());
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(mlp_dwt_kernel<T>, dim3(n_work), dim3(256), dwt_lds<T>(), stream, d_entries, d_items, rows, slabs,
+                     slab_stride);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_mlp_backward_dw_tiles(const osrl_dw_entry_t* d_entries, const int32_t* d_work, int32_t n_work,
+                                          int32_t rows, int32_t tile_blocks, float* slabs, int64_t slab_stride,
+                                          void* stream) {
+  if (!d_entries || !d_work || n_work < 1 || rows < 1 || !slabs) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (tile_blocks == 5) return launch_dwt<5>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
+  if (tile_blocks == 4) return launch_dwt<4>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
+  return -1;
 }
 
 extern "C" int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,

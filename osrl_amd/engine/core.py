@@ -368,10 +368,18 @@ class MlpRun:
         assert r.d0 + r.d1 == self.net.dims[0], (r.d0, r.d1, self.net.dims)
         return r
 
-    def forward_with(self, args, other: "MlpRun", other_args) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_with(self, args, other: "MlpRun", other_args, tail: Optional["L.TailT"] = None,
+                     other_tail: Optional["L.TailT"] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """This forward and an independent one of ``other`` in ONE launch (osrl_mlp_forward2);
-        ``args`` / ``other_args`` are the positional arguments of the two ``forward`` calls."""
+        ``args`` / ``other_args`` are the positional arguments of the two ``forward`` calls; ``tail`` / ``other_tail``:
+        a forward tail (osrl_mlp_tail_t) per problem, applied to its net 0's output tile by the same launch."""
         r0, r1 = self._rows(*args), other._rows(*other_args)
+        if tail is not None or other_tail is not None:
+            L.check(L.load().osrl_mlp_forward2_tail(
+                C.byref(self.net.c), C.byref(r0), C.byref(self.acts_c), None if tail is None else C.byref(tail),
+                C.byref(other.net.c), C.byref(r1), C.byref(other.acts_c),
+                None if other_tail is None else C.byref(other_tail), cur_stream()), "osrl_mlp_forward2_tail")
+            return self.y, other.y
         L.check(L.load().osrl_mlp_forward2(C.byref(self.net.c), C.byref(r0), C.byref(self.acts_c),
                                            C.byref(other.net.c), C.byref(r1), C.byref(other.acts_c), cur_stream()),
                 "osrl_mlp_forward2")
@@ -457,14 +465,29 @@ class DwPlan:
     """Static work list for osrl_mlp_backward_dw over one optimizer group."""
 
     BIG_ROWS = 8192  # from this many rows on, fully 128x128-tiled layers take the one-wave-per-tile kernel
+    FLAT_DEFAULT = os.environ.get("OSRL_DW_FLAT", "1") == "1"
 
     def __init__(self, group: FlatGroup, entries: Sequence[Tuple[torch.Tensor, torch.Tensor, str, str]],
-                 rows: int, device, n_splits: Optional[int] = None, big: Optional[bool] = None):
+                 rows: int, device, n_splits: Optional[int] = None, big: Optional[bool] = None,
+                 tile_blocks: int = 0):
+        """``tile_blocks`` = 5: the flat (tile, row split) work list on 80 x 80 tiles (osrl_mlp_backward_dw_tiles) --
+        for groups of 400-wide layers (25 column blocks = 5 x 5: no ragged tiles); a tile gets row splits in
+        proportion to its blocks, so that every workgroup carries about the same number of MFMAs."""
         self.group, self.rows = group, rows
+        self.tile_blocks = int(tile_blocks)
+        use_big = (rows >= self.BIG_ROWS) if big is None else bool(big)
+        if not self.tile_blocks and self.FLAT_DEFAULT and not use_big:
+            # round 3: the training-row groups take the flat-list kernel too (64 x 64 tiles, the split policy of
+            # mlp_dw_kernel below): its unmasked, counted-wait k-loop runs a step's MFMAs under the next step's loads
+            self.tile_blocks = 4
+            if n_splits is None:
+                n_t = sum(((group.layout[e[2]][1][0] + 63) // 64) * ((group.layout[e[2]][1][1] + 63) // 64) for e in entries)
+                n_splits = max(1, min((2048 + max(n_t, 1) - 1) // max(n_t, 1), max(rows // 256, 1), 32))
         arr = (L.DwEntryT * len(entries))()
         items: List[int] = []
         big_items: List[int] = []
-        use_big = (rows >= self.BIG_ROWS) if big is None else bool(big)
+        work: List[int] = []
+        s_full = max(1, min(rows // 512, 8)) if n_splits is None else int(n_splits)  # row splits of a full tile
         for i, ent in enumerate(entries):
             dz, a, wk, bk = ent[:4]
             # optional 5th/6th items: (ptr, row stride, width) views for strided operands
@@ -479,6 +502,18 @@ class DwPlan:
             arr[i].a = a if isinstance(a, int) else a.data_ptr()
             arr[i].w_off, arr[i].b_off = group.offset(wk), group.offset(bk)
             arr[i].out, arr[i].in_ = out_f, in_f
+            if self.tile_blocks:
+                T = self.tile_blocks
+                ob_n, ib_n = (out_f + 15) // 16, (in_f + 15) // 16
+                for ot in range((ob_n + T - 1) // T):
+                    for it in range((ib_n + T - 1) // T):
+                        blocks = min(T, ob_n - T * ot) * min(T, ib_n - T * it)
+                        # a k-step costs max(load latency ~1.2 us, its MFMAs): a strip of few blocks is latency-bound,
+                        # so its time is its k-step COUNT -- it takes the full tiles' split count, not a share of it
+                        nsp = s_full
+                        for sp in range(nsp):
+                            work += [i, ot, it, sp | (nsp << 16)]
+                continue
             if use_big and out_f % 128 == 0 and in_f % 64 == 0:
                 # token-matrix sized GEMMs (CDT projections): every 128x64 tile to osrl_mlp_backward_dw_big
                 for ot in range(out_f // 128):
@@ -490,6 +525,8 @@ class DwPlan:
                     items += [i, ot, it, 0]
         self.n_items = len(items) // 4
         self.n_big = len(big_items) // 4
+        self.n_work = len(work) // 4
+        self.d_work = torch.tensor(work, dtype=torch.int32, device=device) if work else None
         raw = bytes(arr)
         self.d_entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.d_items = torch.tensor(items if items else [0, 0, 0, 0], dtype=torch.int32, device=device)
@@ -512,6 +549,8 @@ class DwPlan:
                     best, best_eff = S, eff
             self.n_splits_big = best
         self.n_splits = max(self.n_splits_small, self.n_splits_big, 1)
+        if self.n_work:
+            self.n_splits = max(w >> 16 for w in work[3::4])
         group.ensure_slabs(self.n_splits)
 
     def launch(self) -> None:
@@ -520,6 +559,11 @@ class DwPlan:
         whenever a plan is attached), so the consumer may sum ``n_splits`` slabs of everything."""
         g = self.group
         g.cur_splits = self.n_splits
+        if self.n_work:
+            L.check(L.load().osrl_mlp_backward_dw_tiles(self.d_entries.data_ptr(), self.d_work.data_ptr(), self.n_work,
+                                                        self.rows, self.tile_blocks, g.slabs.data_ptr(), g.n,
+                                                        cur_stream()), "osrl_mlp_backward_dw_tiles")
+            return
         if self.n_items:
             L.check(L.load().osrl_mlp_backward_dw(self.d_entries.data_ptr(), self.d_items.data_ptr(), self.n_items,
                                                   self.rows, self.n_splits_small, g.slabs.data_ptr(), g.n, cur_stream()),

@@ -22,6 +22,11 @@ from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_de
 from . import glue as G
 from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into
 
+# measured (round 3, one box, A/B pairs): 2042 vs 2180 steps/s with the fused draws -- bit-identical results, four launches
+# fewer, and SLOWER: the N*B cost-critic launch then starts 25 us earlier and runs beside the VAE backward instead of
+# its dW (the round-2 finding for a merged heads launch).  Off by default; the entry point and its
+# parity test stay (BCQ-Lag / BEAR-Lag / callers with another plan may want it).
+HEAD_TAILS = os.environ.get("OSRL_HEAD_TAILS", "0") == "1"
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -80,8 +85,16 @@ class CPQEngine:
         # resident slots in one round (x 4 splits = 560: a second, almost empty round), and the Adam kernel sums two
         # slabs instead of four.  In the step: 2175 steps/s vs 2135 (4 splits), 2140 (3), 2015 (1); the other groups
         # measure best at the default 256 rows (2175 vs 2110 at 512, 2010 at 1024)
-        self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
-                            n_splits=int(os.environ.get("OSRL_VAE_DW_SPLITS", "0")) or max(1, B // 1024))
+        # round 3: 400-wide layers are 25 = 5 x 5 column blocks -- on 80 x 80 tiles with a flat (tile, split) work list
+        # the VAE's dW is 250 even workgroups in one round (core.DwPlan tile_blocks; OSRL_VAE_DW_T5=0: the 64 x 64 form)
+        t5 = os.environ.get("OSRL_VAE_DW_T5", "1") == "1" and int(m.vae_hidden_sizes) % 80 == 0 and B >= 1024
+        if t5:
+            self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
+                                n_splits=int(os.environ.get("OSRL_VAE_DW_SPLITS", "0")) or max(1, (3 * B) // 2048),
+                                tile_blocks=5)  # 70 tiles x 3 splits = 210 workgroups: one round (tools/dw_bench.py)
+        else:
+            self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
+                                n_splits=int(os.environ.get("OSRL_VAE_DW_SPLITS", "0")) or max(1, B // 1024))
 
         # ---- critic phase
         self.r_actor_next = MlpRun(self.d_actor, B, False, dev)
@@ -198,14 +211,27 @@ class CPQEngine:
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
-            hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
-            head_next, head_obs = hn[0], ho[0]
-            G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
-            ev_next2 = par.mark(0)
-            G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
-            G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
-            # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
-            G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
+            if HEAD_TAILS:
+                # every action draw of the step (cpq.py:141 a_next, :159 a_next2, :164-176 the N OOD draws, :209 the
+                # actor-phase sample) by the actor trunks' own forward launch, from its LDS-resident head tiles: four
+                # single-purpose launches (30 us on this branch inside the step, profiles/r3_timeline_*.txt) fewer
+                hn, ho = self.r_actor_next.forward_with(
+                    (self.nobs,), self.r_actor_obs, (self.obs,),
+                    tail=G.gauss_tail(ad, m.max_action, eps=nz["eps_next_cc"], a=self.a_next2, eps2=nz["eps_next_c"],
+                                      a2=self.a_next),
+                    other_tail=G.gauss_tail(ad, m.max_action, eps2=nz["eps_actor"], a2=self.a_pi, tanh2=self.tanh_u,
+                                            eps_ood=nz["eps_ood"], n_samples=N, sampled=self.sampled))
+                head_next, head_obs = hn[0], ho[0]
+                ev_next2 = par.mark(0)
+            else:
+                hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
+                head_next, head_obs = hn[0], ho[0]
+                G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
+                ev_next2 = par.mark(0)
+                G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)
+                G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
+                # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
+                G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
             self._pr("costold_ood", 0)
             qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
             self._pr("costold_ood", 1)

@@ -55,6 +55,19 @@ def vae_latent_bwd_tail(head, eps, Lz, beta, rows_global, dhead) -> "L.TailT":
 VAE_TAILS = os.environ.get("OSRL_VAE_TAILS", "1") == "1"  # 0: the reparameterisation and its backward as own launches
 
 
+def gauss_tail(ad, max_action, eps=None, a=None, eps2=None, a2=None, tanh2=None, eps_ood=None, n_samples=0,
+               sampled=None):
+    """osrl_mlp_tail_t of kind GAUSS: the squashed-Gaussian head's action draws made by the actor trunk's own forward
+    launch (== gauss_head / gauss_ood_sample on its output)."""
+    t = L.TailT()
+    t.kind, t.L, t.max_action = L.TAIL_GAUSS, int(ad), float(max_action)
+    t.eps, t.out = _p(eps), _p(a)
+    t.eps2, t.out2, t.tanh2 = _p(eps2), _p(a2), _p(tanh2)
+    t.eps_ood, t.out_ood, t.n_samples = _p(eps_ood), _p(sampled), int(n_samples)
+    t._keep = (eps, a, eps2, a2, tanh2, eps_ood, sampled)
+    return t
+
+
 def vae_encode(r_enc, obs, act, eps, Lz, z):
     """head = encoder(obs, act); z = mean + exp(clamp(log_std)) * eps   (net.py:319-331) -- ONE launch: the latent is
     produced by the encoder's forward launch from its LDS-resident output tile.  Returns head [rows, 2 Lz]."""

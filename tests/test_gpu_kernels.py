@@ -172,6 +172,17 @@ def test_mlp_fwd_bwd(ci):
             got = run.dx[e].cpu().numpy()
             ref = g[:, c0:c0 + nc]
             assert np.abs(got - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), f"case {ci} dx net {e}"
+    # the same weight gradients through the flat (tile, split) work list on 80 x 80 and 64 x 64 tiles
+    # (osrl_mlp_backward_dw_tiles): tiles of unequal block counts get unequal row splits
+    ref_w = {k: grp.grad_view(k).cpu().numpy().astype(np.float64) for k in grp.layout}
+    for T in (5, 4):
+        plan_t = DwPlan(grp, run.dw_entries(), rows, dev, tile_blocks=T)
+        assert plan_t.n_work > 0
+        plan_t.launch()
+        torch.cuda.synchronize()
+        for k, ref in ref_w.items():
+            got = grp.grad_view(k).cpu().numpy()
+            assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f"case {ci} tiles {T}: {k}"
 
 
 BIG_CASES = [
@@ -356,6 +367,56 @@ def test_vae_tails_fused_into_the_mlp_launches(rows, od, ad, hid, tile):
     assert torch.equal(d_a.dx, d_b.dx) and torch.equal(dh_a, dh_b)
     for l in range(3):
         assert torch.equal(d_a.dz[0][l], d_b.dz[0][l])
+
+
+@pytest.mark.parametrize("rows,od,ad,hid,N", [(2048, 76, 2, 256, 10), (2048, 17, 6, 256, 10), (37, 5, 3, 64, 4),
+                                              (300, 20, 4, 96, 3)])
+def test_gauss_head_tails_fused_into_the_actor_forward_pair(rows, od, ad, hid, N):
+    """osrl_mlp_forward2_tail with OSRL_TAIL_GAUSS tails (the CPQ step's four action draws made by the actor trunks' own
+    paired forward launch) == osrl_mlp_forward2 followed by osrl_gauss_head x3 + osrl_gauss_ood_sample, bit for bit."""
+    from osrl_amd.engine import glue as G
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
+    dev = _dev()
+    rs = np.random.RandomState(rows + ad)
+    grp = FlatGroup("actor", dev)
+    dims, acts = [od, hid, hid, 2 * ad], ["relu", "relu", "id"]
+    for l in range(3):
+        grp.add(f"{l}.w", (dims[l + 1], dims[l]))
+        grp.mark_weight(f"{l}.w")
+        grp.add(f"{l}.b", (dims[l + 1],))
+    grp.finalize()
+    rr = []
+    for l in range(3):
+        W, b = grp.view(f"{l}.w"), grp.view(f"{l}.b")
+        W.copy_(torch.tensor(rs.uniform(-0.3, 0.3, W.shape), dtype=torch.float32))
+        b.copy_(torch.tensor(rs.uniform(-0.3, 0.3, b.shape), dtype=torch.float32))
+        rr.append(LayerRef(W, b, grp, f"{l}.w", f"{l}.b"))
+    grp.repack()
+    net = NetDesc([rr], acts, 1.0)
+    nobs, obs = torch.randn(rows, od, device=dev), torch.randn(rows, od, device=dev)
+    e_cc, e_c, e_pi = (torch.randn(rows, ad, device=dev) for _ in range(3))
+    e_ood = torch.randn(N, rows, ad, device=dev)
+    res = []
+    for fused in (False, True):
+        r_n, r_o = MlpRun(net, rows, False, dev), MlpRun(net, rows, True, dev)
+        fill = 5.0 if fused else -5.0
+        a2, a1, api, th = (torch.full((rows, ad), fill, device=dev) for _ in range(4))
+        smp = torch.full((N * rows, ad), fill, device=dev)
+        if fused:
+            hn, ho = r_n.forward_with((nobs,), r_o, (obs,),
+                                      tail=G.gauss_tail(ad, 1.5, eps=e_cc, a=a2, eps2=e_c, a2=a1),
+                                      other_tail=G.gauss_tail(ad, 1.5, eps2=e_pi, a2=api, tanh2=th, eps_ood=e_ood,
+                                                              n_samples=N, sampled=smp))
+        else:
+            hn, ho = r_n.forward_with((nobs,), r_o, (obs,))
+            G.gauss_head(hn[0], e_cc, rows, ad, 1.5, a=a2)
+            G.gauss_head(hn[0], e_c, rows, ad, 1.5, a=a1)
+            G.gauss_ood_sample(ho[0], e_ood, N, rows, ad, smp)
+            G.gauss_head(ho[0], e_pi, rows, ad, 1.5, a=api, tanh_u=th)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (hn[0], ho[0], a2, a1, api, th, smp)])
+    for x, y, name in zip(res[0], res[1], ("head_next", "head_obs", "a_next2", "a_next", "a_pi", "tanh_u", "sampled")):
+        assert torch.equal(x, y), name
 
 
 def test_adam_polyak_matches_oracle():
