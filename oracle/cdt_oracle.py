@@ -183,7 +183,11 @@ class OracleCDT:
 
     # ------------------------------------------------------------------ one train step
     def train_one_step(self, states, actions, returns, costs_return, time_steps, mask, episode_cost, costs,
-                       drop=None):
+                       drop=None, norm=None, grads_only=False):
+        """``norm`` (test aid for batches too big for one host pass): the batch-GLOBAL normalisers
+        ``dict(nv=valid tokens * action_dim, bt=B*T, state_n=B*(T-1)*state_dim, act_n=B*T*action_dim)`` to use instead
+        of this call's own -- the loss is a sum over samples once they are fixed, so the gradient of a big batch is the
+        sum of ``grads_only=True`` calls over its chunks (returns the unclipped gradient dict, no update)."""
         dt = self.dtype
         drop = {k: np.asarray(v, dt) for k, v in (drop or {}).items()}
         one = dt(1.0)
@@ -199,6 +203,9 @@ class OracleCDT:
         res, c = self.forward(states, actions, returns, costs_return, time_steps, mask, drop, episode_cost)
         valid = mask > 0
         nv = max(int(valid.sum()), 1) * ad
+        n_bt, n_state, n_act = B * T, None, None
+        if norm is not None:
+            nv, n_bt, n_state, n_act = norm["nv"], norm["bt"], norm["state_n"], norm["act_n"]
         stats = {}
         g: State = {}
         # ---- losses (cdt.py:357-394) and gradients wrt the head outputs
@@ -218,18 +225,18 @@ class OracleCDT:
         else:
             pred = res["act"]
             act_loss = (((pred - actions) ** 2) * mask[..., None]).mean()
-            dact = 2 * (pred - actions) * mask[..., None] / pred.size
+            dact = 2 * (pred - actions) * mask[..., None] / (pred.size if n_act is None else n_act)
         lp = res["cost_logp"]
         onehot = np.eye(2, dtype=dt)[costs_i]
         cost_loss = (-(lp * onehot).sum(-1) * mask).mean()  # mean over ALL B*T  cdt.py:378-380
-        dlogits = (np.exp(lp) - onehot) * mask[..., None] / (B * T) * self.cw
+        dlogits = (np.exp(lp) - onehot) * mask[..., None] / n_bt * self.cw
         pred_c = lp.argmax(-1)
         acc = ((pred_c == costs_i) * mask).sum() / mask.sum()
         sp = res["state_pred"]
         diff = sp[:, :-1] - states[:, 1:]
         state_loss = ((diff ** 2) * mask[:, :-1, None]).mean()
         dsp = np.zeros_like(sp)
-        dsp[:, :-1] = 2 * diff * mask[:, :-1, None] / diff.size * self.sw
+        dsp[:, :-1] = 2 * diff * mask[:, :-1, None] / (diff.size if n_state is None else n_state) * self.sw
         loss = act_loss + self.cw * cost_loss + self.sw * state_loss
 
         # ---- heads backward
@@ -321,6 +328,8 @@ class OracleCDT:
             np.add.at(dte, time_steps.reshape(-1), f2(d4.sum(2)))
             g["timestep_emb.weight"] = dte
 
+        if grads_only:
+            return g
         # ---- clip_grad_norm_ (cdt.py:398-399), AdamW with warm-up LR (cdt.py:321-330)
         if self.clip is not None:
             tot = math.sqrt(sum(float((np.asarray(v, np.float64) ** 2).sum()) for v in g.values()))

@@ -313,7 +313,11 @@ def test_cdt_c5_full_batch_forward_stats_and_graph():
     640-workgroup grids, the 81920-row dW launch and the 8192 attention workgroups under test.
     (a) step-1 logged statistics vs a forward-only fp64 pass of the pinned oracle with the GPU's own dropout masks
     replayed (the forward is per-sample independent, so the host evaluates it in 64-sample chunks);
-    (b) finite statistics; (c) captured graph == eager launches after 2 steps."""
+    (b) finite statistics; (c) captured graph == eager launches after 2 steps;
+    (d) (round 3) the full-batch GRADIENT: with the global normalisers fixed the loss is a sum over samples, so the fp64
+    oracle's backward runs in the same 64-sample chunks (``grads_only``, ``norm``) and the chunks' gradients add up to
+    the batch's; clipped by their global norm they must equal the GPU's Adam first moments / (1 - beta1) per tensor --
+    this is the parity run of the 81920-row dW launch, the 8192-workgroup attention backward and the clip."""
     import math
     from test_oracle_cdt_golden import build_cdt_oracle
     c = C5_FULL
@@ -330,10 +334,17 @@ def test_cdt_c5_full_batch_forward_stats_and_graph():
     f8 = lambda a: np.asarray(a, np.float64)  # noqa: E731
     acc = dict(ll=0.0, ent=0.0, nv=0.0, cl=0.0, hit=0.0, msum=0.0, sl=0.0)
     CH = 64
+    norm = dict(nv=max(int((bn["mask"] > 0).sum()), 1) * c.ad, bt=c.B * c.T, state_n=c.B * (c.T - 1) * c.od,
+                act_n=c.B * c.T * c.ad)
+    gsum = {}
     for i in range(0, c.B, CH):
         sl = slice(i, i + CH)
         drop = {k: v[sl].cpu().numpy().astype(np.float64) for k, v in masks.items()}
         st_, ac_, mk_ = f8(bn["states"][sl]), f8(bn["actions"][sl]), f8(bn["mask"][sl])
+        gch = o.train_one_step(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_,
+                               f8(bn["episode_cost"][sl]), bn["costs"][sl], drop=drop, norm=norm, grads_only=True)
+        for k, v in gch.items():
+            gsum[k] = gsum.get(k, 0.0) + np.asarray(v, np.float64)
         res, _ = o.forward(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_, drop)
         valid = (mk_ > 0)[..., None]
         zz = (ac_ - res["mu"]) / np.exp(res["ls"])
@@ -354,6 +365,24 @@ def test_cdt_c5_full_batch_forward_stats_and_graph():
     want["all_loss"] = want["act_loss"] + c.cost_w * want["cost_loss"] + c.state_w * want["state_loss"]
     for k, r in want.items():
         assert abs(got[k] - r) <= 1e-4 * max(1.0, abs(r)), f"C5 full batch {k}: gpu {got[k]} vs fp64 oracle forward {r}"
+    # (d) gradients: clip by the global norm (cdt.py:398-399), compare with Adam's first moments after this ONE step
+    tot = math.sqrt(sum(float((v ** 2).sum()) for v in gsum.values()))
+    coef = min(1.0, c.clip / (tot + 1e-6)) if getattr(c, "clip", None) is not None else 1.0
+    grp = m.groups["cdt"]
+    worst, n_cmp = 0.0, 0
+    for k, gv in gsum.items():
+        gk = "cdt." + k
+        if gk not in grp.layout or gk in grp.aliases:
+            continue
+        want_m = (1.0 - 0.9) * coef * gv
+        got_m = grp._view(grp.m, gk).cpu().numpy().astype(np.float64)
+        scale = max(np.abs(want_m).max(), 1e-12)
+        d = np.abs(got_m - want_m.reshape(got_m.shape)).max()
+        worst = max(worst, d / scale)
+        n_cmp += 1
+        assert d <= 2e-5 * scale + 1e-9, f"C5 full batch, Adam first moment {k}: max diff {d:.3e} vs scale {scale:.3e}"
+    assert n_cmp == len(gsum), (n_cmp, len(gsum), sorted(set(gsum) - {k[4:] for k in grp.layout}))
+    print(f"C5 full batch: {n_cmp} tensors, worst first-moment diff / scale {worst:.2e}, clip coefficient {coef:.4f}")
     del masks, m, tr
     torch.cuda.empty_cache()
     res = []
