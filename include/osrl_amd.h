@@ -362,6 +362,16 @@ int osrl_bcq_perturb_bwd(const float* dec, const float* t, const float* da_nets,
 int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_samples, const float* q_on,
                          int32_t n_on, const float* base, const float* done, int32_t rows, float gamma,
                          float lmbda, int32_t rows_global, float* dq, float* stat, void* stream);
+/* The two batch-sum losses on a grid of <= 64 workgroups (for batches beyond ~2048 rows, where one workgroup walking the
+ * batch alone costs 35-45 us): same values per row, the logged statistic is the sum of per-workgroup partials added in
+ * workgroup order by the last workgroup to arrive (deterministic; no floating-point atomics).  ws: OSRL_LOSS_WS floats
+ * of device memory, zeroed once before first use, private to one call site while a launch is in flight. */
+#define OSRL_LOSS_WS 132
+int osrl_bcq_critic_loss_ws(const float* q_t, int32_t n1, int32_t n2, int32_t n_samples, const float* q_on, int32_t n_on,
+                            const float* base, const float* done, int32_t rows, float gamma, float lmbda,
+                            int32_t rows_global, float* dq, float* stat, float* ws, void* stream);
+int osrl_vae_loss_ws(const float* u, const float* act, const float* head, int32_t rows, int32_t ad, int32_t L, float beta,
+                     int32_t rows_global, float* du, float* stat, float* ws, void* stream);
 /* BCQ-Lag actor loss (bcql.py:190-198 + PID net.py:376-387).  q/qc = [n1+n2][rows] (q1 nets then q2 nets).
  * pid = device {error_old, error_integral}; stat: [0]=loss [1]=qc_penalty [2]=multiplier.
  * Data parallel: global_means = all-reduced {mean q_pi, mean qc_pi} from osrl_bcq_actor_sums (NULL = compute

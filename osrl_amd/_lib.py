@@ -176,6 +176,8 @@ PROTOTYPES = {
     "osrl_bcq_perturb": [_fp, _fp, _i32, _i32, _f32, _f32, _fp, _vp],
     "osrl_bcq_perturb_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _fp, _vp],
     "osrl_bcq_critic_loss": [_fp, _i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
+    "osrl_bcq_critic_loss_ws": [_fp, _i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _fp, _vp],
+    "osrl_vae_loss_ws": [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _i32, _fp, _fp, _fp, _vp],
     "osrl_bcq_actor_sums": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _fp, _vp],
     "osrl_bcq_actor_loss": [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _fp, _f32, _fp, _fp,
                             _fp, _fp, _vp],
@@ -200,6 +202,7 @@ PROTOTYPES = {
 _LIB: Optional[C.CDLL] = None
 
 
+LOSS_WS = 132  # floats of scratch for the grid loss kernels (include/osrl_amd.h OSRL_LOSS_WS)
 QUANTILE_WS = 1032  # uint32 elements of scratch for osrl_quantile_ws (include/osrl_amd.h OSRL_QUANTILE_WS)
 RESTYPES = {"osrl_ingest_ws_elems": C.c_int64}  # everything else returns int (0 = ok)
 

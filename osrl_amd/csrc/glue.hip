@@ -866,6 +866,125 @@ __global__ __launch_bounds__(kRed) void bcq_critic_loss_kernel(const float* __re
   if (threadIdx.x == 0 && stat) stat[0] = loss * inv_rows;
 }
 
+// ---- batch-sum kernels on a GRID (round 3) --------------------------------------------------------------------
+// The single-workgroup loss kernels above are built for B = 2048 rows x a few columns; at BCQ-Lag's C3 shape (4096 rows,
+// 10 target samples x 4 target nets per row; VAE with 8 + 16 columns) one CU walks 0.65-1 MB alone: 44 us
+// (bcq_critic_loss, on BOTH branches of the step) and 34 us (vae_loss) of a 1.77 ms step.  Issuing more loads per
+// thread did not help (70 us / 33 us: the one CU's address path is the limit, not its latency).  Here <= 64
+// workgroups of 256 threads split the rows; every workgroup leaves its partial sum(s) in `ws`, signs in with one
+// atomic, and the LAST one to arrive adds the partials IN WORKGROUP ORDER (deterministic: no floating-point atomics)
+// and writes the statistic.  ws: >= OSRL_LOSS_WS floats, zero once before first use (the last arriver re-arms it).
+constexpr int kGridWg = 64, kGridThreads = 256;
+__device__ __forceinline__ float block_sum256(float v, float* sm /*>= 5 floats*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  return ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+// true in EVERY thread of the last workgroup to call it; partials must have been written by thread 0 before
+__device__ __forceinline__ bool grid_last_arriver(float* ws, int slot_counter) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned seen = atomicAdd(reinterpret_cast<unsigned*>(ws + slot_counter), 1u);
+    s_last = seen == gridDim.x - 1;
+    if (s_last) {
+      __threadfence();
+      reinterpret_cast<unsigned*>(ws + slot_counter)[0] = 0u;  // re-armed for the next launch
+    }
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+// the last workgroup's sum of n_sets x gridDim.x partials, in workgroup order: every partial is fetched by its own
+// thread (one round trip for all of them), thread 0 adds them from LDS; result in out[0 .. n_sets) of thread 0
+template <int NSETS>
+__device__ __forceinline__ void grid_ordered_sum(const float* ws, float (&out)[NSETS]) {
+  __shared__ float part[NSETS * kGridWg];
+  const int n = (int)gridDim.x;
+  for (int i = threadIdx.x; i < NSETS * kGridWg; i += kGridThreads) {
+    const int set = i / kGridWg, g = i - set * kGridWg;
+    part[i] = g < n ? reinterpret_cast<const volatile float*>(ws)[set * kGridWg + g] : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int set = 0; set < NSETS; ++set) {
+      float t = 0.f;
+      for (int g = 0; g < n; ++g) t += part[set * kGridWg + g];
+      out[set] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kGridThreads) void bcq_critic_loss_grid_kernel(
+    const float* __restrict__ q_t, int n1, int n2, int n_samples, const float* __restrict__ q_on, int n_on,
+    const float* __restrict__ base, const float* __restrict__ done, int rows, float gamma, float lmbda, float inv_rows,
+    float* __restrict__ dq, float* __restrict__ stat, float* __restrict__ ws) {
+  __shared__ float sm[8];
+  float loss = 0.f;
+  const int nr = rows * n_samples;
+  for (int b = blockIdx.x * kGridThreads + threadIdx.x; b < rows; b += gridDim.x * kGridThreads) {
+    float best = -INFINITY;
+    for (int j = 0; j < n_samples; ++j) {
+      const int i = b * n_samples + j;  // repeat_interleave order, bcql.py:138,146
+      const float q1 = min_over(q_t, n1, nr, i);
+      const float q2 = min_over(q_t + (size_t)n1 * nr, n2, nr, i);
+      const float v = lmbda * fminf(q1, q2) + (1.0f - lmbda) * fmaxf(q1, q2);
+      best = fmaxf(best, v);
+    }
+    const float nd = done ? (1.0f - done[b]) : 1.0f;
+    const float backup = base[b] + gamma * nd * best;
+    for (int e = 0; e < n_on; ++e) {
+      const float d = q_on[(size_t)e * rows + b] - backup;
+      loss += d * d;
+      dq[(size_t)e * rows + b] = 2.0f * d * inv_rows;
+    }
+  }
+  loss = block_sum256(loss, sm);
+  if (threadIdx.x == 0) ws[blockIdx.x] = loss;
+  if (grid_last_arriver(ws, 2 * kGridWg)) {
+    float t[1];
+    grid_ordered_sum<1>(ws, t);
+    if (threadIdx.x == 0 && stat) stat[0] = t[0] * inv_rows;
+  }
+}
+
+__global__ __launch_bounds__(kGridThreads) void vae_loss_grid_kernel(const float* __restrict__ u,
+                                                                     const float* __restrict__ act,
+                                                                     const float* __restrict__ head, int rows, int ad,
+                                                                     int L, float beta, float inv_rows,
+                                                                     float* __restrict__ du, float* __restrict__ stat,
+                                                                     float* __restrict__ ws) {
+  __shared__ float sm[8];
+  float rec = 0.f, kl = 0.f;
+  const float ia = inv_rows / (float)ad, il = inv_rows / (float)L;
+  const int n_rec = rows * ad, n_kl = rows * L;
+  const int stride = gridDim.x * kGridThreads;
+  for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < n_rec; i += stride) {
+    const float d = u[i] - act[i];
+    rec += d * d;
+    du[i] = 2.0f * d * ia;
+  }
+  for (int i = blockIdx.x * kGridThreads + threadIdx.x; i < n_kl; i += stride) {
+    const int r = i / L, c = i - r * L;
+    kl += kl_elem(head[(size_t)r * 2 * L + c], head[(size_t)r * 2 * L + L + c]);
+  }
+  rec = block_sum256(rec, sm);
+  kl = block_sum256(kl, sm);
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = rec;
+    ws[kGridWg + blockIdx.x] = kl;
+  }
+  if (grid_last_arriver(ws, 2 * kGridWg)) {
+    float t[2];
+    grid_ordered_sum<2>(ws, t);
+    if (threadIdx.x == 0 && stat) stat[0] = t[0] * ia + beta * (t[1] * il);
+  }
+}
+
 // min over the q1 group, min over the q2 group, then the binary min with torch's tie rule
 __device__ __forceinline__ float minmin(const float* __restrict__ q, int n1, int n2, int rows, int b, int* i1,
                                         int* i2, float* w1) {
@@ -1188,6 +1307,32 @@ int osrl_bcq_critic_loss(const float* q_t, int32_t n1, int32_t n2, int32_t n_sam
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(bcq_critic_loss_kernel, dim3(1), dim3(kRed), 0, S, q_t, n1, n2, n_samples, q_on, n_on, base,
                      done, rows, gamma, lmbda, 1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat);
+  LAUNCH_CHECK();
+}
+
+static int loss_grid(int64_t n_items) {
+  int64_t g = (n_items + kGridThreads - 1) / kGridThreads;
+  return (int)(g < 1 ? 1 : g > kGridWg ? kGridWg : g);
+}
+
+int osrl_bcq_critic_loss_ws(const float* q_t, int32_t n1, int32_t n2, int32_t n_samples, const float* q_on, int32_t n_on,
+                            const float* base, const float* done, int32_t rows, float gamma, float lmbda,
+                            int32_t rows_global, float* dq, float* stat, float* ws, void* stream) {
+  if (!q_t || !q_on || !base || !dq || !ws || rows < 1 || n1 < 1 || n2 < 1 || n_samples < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(bcq_critic_loss_grid_kernel, dim3(loss_grid(rows)), dim3(kGridThreads), 0, S, q_t, n1, n2,
+                     n_samples, q_on, n_on, base, done, rows, gamma, lmbda,
+                     1.0f / (float)(rows_global > 0 ? rows_global : rows), dq, stat, ws);
+  LAUNCH_CHECK();
+}
+
+int osrl_vae_loss_ws(const float* u, const float* act, const float* head, int32_t rows, int32_t ad, int32_t L, float beta,
+                     int32_t rows_global, float* du, float* stat, float* ws, void* stream) {
+  if (!u || !act || !head || !du || !ws || rows < 1) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  const int64_t n = (int64_t)rows * (ad > L ? ad : L);
+  hipLaunchKernelGGL(vae_loss_grid_kernel, dim3(loss_grid(n)), dim3(kGridThreads), 0, S, u, act, head, rows, ad, L,
+                     beta, 1.0f / (float)(rows_global > 0 ? rows_global : rows), du, stat, ws);
   LAUNCH_CHECK();
 }
 

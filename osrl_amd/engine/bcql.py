@@ -8,6 +8,8 @@ materialises the repeated observations: the MLP kernels read ``next_obs[r / N]``
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import torch
@@ -66,7 +68,7 @@ class BCQLEngine:
 
         # target pipeline buffers (shared by the critic and the cost-critic phases)
         NB = N * B
-        tr = 0  # tile kernel picks its tile; the 80-row one-workgroup-per-CU forward measured no gain here
+        tr = int(os.environ.get("OSRL_BCQ_TILE", "80"))  # 80: mlp_fwd_nb_kernel (round 3: 564 vs 554.5 steps/s at C3); 0: tile kernel
         self.r_dec_t = MlpRun(self.d_dec, NB, False, dev, tile_rows=tr)
         self.r_actor_old_t = MlpRun(self.d_actor_old, NB, False, dev, tile_rows=tr)
         self.a_t = z(NB, ad)
@@ -97,6 +99,9 @@ class BCQLEngine:
         self.pi_means = z(4)
         self.r_actor.setup_backward(self.dt)
         self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
+        # batch-sum losses on a grid beyond 2048 rows (one workgroup walking 4096 rows x 10 samples x 4 nets alone: 44 us)
+        big = B > 2048
+        self.ws_vae, self.ws_c, self.ws_cc = (G.loss_ws(dev) if big else None for _ in range(3))
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
 
@@ -138,33 +143,42 @@ class BCQLEngine:
 
         head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
-        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"), ws=self.ws_vae)
         G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
-
+        # round 3 (profiles/r3_bcql_timeline.txt): both branches are linear chains from here (a side branch forked BEFORE
+        # the VAE phase, to run the online forwards beside it, made the graph executor put both 950 us target pipelines
+        # on one queue: 1881 vs 1788 us).  The online critics' forwards (critic / cost critic on (obs, act),
+        # bcql.py:144,167: no dependency on anything the step computes) go out as ONE paired launch at the head of the
+        # side branch instead of two launches behind the pipelines; the head of actor_loss (bcql.py:183-187: needs the
+        # updated VAE and the not-yet-updated actor only) runs at the head of THIS branch instead of at the side
+        # branch's tail, which was the later one at the join.
+        # (creation order matters to the executor: THIS branch's first launches are created before the side branch's,
+        # so that it stays on the queue the VAE phase ran on and the side branch gets the second one)
         par.fork(0)
+        dec = self.r_dec_b.forward(self.obs, nz["z_actor"])[0]
+        t = self.r_actor.forward(self.obs, dec)[0]
+        G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
         q_t = self._targets("z_c", self.r_qold_t)
-        q = self.r_critic.forward(self.obs, self.act)
+
+        with par.on(0):
+            q, qc = self.r_critic.forward_with((self.obs, self.act), self.r_cost, (self.obs, self.act))
+            ev_on = par.mark(0)
+            qc_t = self._targets("z_cc", self.r_qcold_t, second=True)
+            G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
+                              st.stat_ptr("loss/cost_critic_loss"), ws=self.ws_cc)
+            self.r_cost.backward_dz()
+            self.p_cost.launch()
+
+        par.wait(ev_on)
         G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
-                          st.stat_ptr("loss/critic_loss"))
+                          st.stat_ptr("loss/critic_loss"), ws=self.ws_c)
         self.r_critic.backward_dz()
         if self.dist is None:
             self._optim("critic", self.p_critic, m.tau)
         else:  # reduced together with the cost critic's gradient after the join: one collective instead of two
             self.p_critic.launch()
-
-        with par.on(0):
-            qc_t = self._targets("z_cc", self.r_qcold_t, second=True)
-            qc = self.r_cost.forward(self.obs, self.act)
-            G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
-                              st.stat_ptr("loss/cost_critic_loss"))
-            self.r_cost.backward_dz()
-            self.p_cost.launch()
-            # head of actor_loss (bcql.py:183-187): needs the updated VAE and the not-yet-updated actor only
-            dec = self.r_dec_b.forward(self.obs, nz["z_actor"])[0]
-            t = self.r_actor.forward(self.obs, dec)[0]
-            G.bcq_perturb(dec, t, B, ad, m.phi, m.max_action, self.a_pi)
         par.join(0)
         if self.dist is None:
             self._update("cost_critic", m.tau)

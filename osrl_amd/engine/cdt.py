@@ -341,9 +341,9 @@ class CDTEngine:
                                   cur_stream()), "osrl_cdt_loss")
         # ---- backward: heads -> dout (only the state / action token rows are non-zero)
         R, B, T, Eh = self.R, self.B, self.T, self.Eh
-        self.dout.zero_()
-        if self.P:
-            self.doutc.zero_()
+        # dout / doutc: the rows of the return / cost (/ prefix) tokens carry no gradient from the heads and are never
+        # written by anything -- they keep the zeros they were allocated with; the state / action rows are fully
+        # rewritten below every step.  (Round 2 re-zeroed the 84 MB buffer per step: an aten fill launch, 0.3 ms at C5.)
         d_sf, d_af = self.doutc.data_ptr() + 4 * (R - 2) * E, self.doutc.data_ptr() + 4 * (R - 1) * E
         chain = self.head_hidden + [self.head_out]
         for li in range(len(chain) - 1, -1, -1):  # output layer first, then the hidden Linear + GELU layers

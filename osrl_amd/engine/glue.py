@@ -88,7 +88,18 @@ def vae_decoder_backward(r_dec, head, eps, Lz, beta, rows_global, dhead):
     vae_latent_bwd(head, eps, r_dec.dx, r_dec.rows, Lz, beta, rows_global, dhead)
 
 
-def vae_loss(u, act, head, rows, ad, Lz, beta, rows_global, du, stat):
+def loss_ws(device):
+    """Scratch of one call site of the grid loss kernels (osrl_vae_loss_ws / osrl_bcq_critic_loss_ws): zeroed once."""
+    import torch
+    return torch.zeros(L.LOSS_WS, dtype=torch.float32, device=device)
+
+
+def vae_loss(u, act, head, rows, ad, Lz, beta, rows_global, du, stat, ws=None):
+    """``ws`` (loss_ws()): the grid form -- for batches beyond ~2048 rows."""
+    if ws is not None:
+        L.check(L.load().osrl_vae_loss_ws(_p(u), _p(act), _p(head), rows, ad, Lz, beta, rows_global, _p(du), _p(stat),
+                                          _p(ws), cur_stream()), "osrl_vae_loss_ws")
+        return
     L.check(L.load().osrl_vae_loss(_p(u), _p(act), _p(head), rows, ad, Lz, beta, rows_global, _p(du), _p(stat),
                                    cur_stream()), "osrl_vae_loss")
 
@@ -168,7 +179,12 @@ def bcq_perturb_bwd(dec, t, da_nets, n_nets, rows, ad, phi, max_action, dt):
                                           cur_stream()), "osrl_bcq_perturb_bwd")
 
 
-def bcq_critic_loss(q_t, n1, n2, n_samples, q_on, n_on, base, done, rows, gamma, lmbda, rows_global, dq, stat):
+def bcq_critic_loss(q_t, n1, n2, n_samples, q_on, n_on, base, done, rows, gamma, lmbda, rows_global, dq, stat, ws=None):
+    if ws is not None:
+        L.check(L.load().osrl_bcq_critic_loss_ws(_p(q_t), n1, n2, n_samples, _p(q_on), n_on, _p(base), _p(done), rows,
+                                                 gamma, lmbda, rows_global, _p(dq), _p(stat), _p(ws), cur_stream()),
+                "osrl_bcq_critic_loss_ws")
+        return
     L.check(L.load().osrl_bcq_critic_loss(_p(q_t), n1, n2, n_samples, _p(q_on), n_on, _p(base), _p(done), rows,
                                           gamma, lmbda, rows_global, _p(dq), _p(stat), cur_stream()),
             "osrl_bcq_critic_loss")

@@ -419,6 +419,42 @@ def test_gauss_head_tails_fused_into_the_actor_forward_pair(rows, od, ad, hid, N
         assert torch.equal(x, y), name
 
 
+@pytest.mark.parametrize("rows,N,nq", [(4096, 10, 2), (4096 + 37, 7, 1), (300, 3, 2), (70000, 4, 2)])
+def test_grid_losses_match_the_single_workgroup_kernels(rows, N, nq):
+    """osrl_bcq_critic_loss_ws / osrl_vae_loss_ws (<= 64 workgroups, partials added in workgroup order by the last
+    arriver) == the single-workgroup kernels: per-row gradients bit for bit, the logged sums to fp32 summation-order
+    round-off; twice in a row on the same scratch (the arrival counter re-arms itself) and deterministic."""
+    from osrl_amd.engine import glue as G
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(rows + N)
+    r = lambda *s_: torch.randn(*s_, generator=g).to(dev)  # noqa: E731
+    q_t, q_on = r(2 * nq, rows * N, 1), r(2 * nq, rows, 1)
+    base, done = r(rows), (torch.rand(rows, generator=g) < 0.1).float().to(dev)
+    dq_a, dq_b = torch.zeros_like(q_on), torch.zeros_like(q_on)
+    st_a, st_b = torch.zeros(2, device=dev), torch.zeros(2, device=dev)
+    ws = G.loss_ws(dev)
+    G.bcq_critic_loss(q_t, nq, nq, N, q_on, 2 * nq, base, done, rows, 0.99, 0.75, rows + 5, dq_a, st_a)
+    vals = []
+    for _ in range(3):
+        G.bcq_critic_loss(q_t, nq, nq, N, q_on, 2 * nq, base, done, rows, 0.99, 0.75, rows + 5, dq_b, st_b, ws=ws)
+        torch.cuda.synchronize()
+        vals.append(float(st_b[0]))
+    assert torch.equal(dq_a, dq_b)
+    assert abs(vals[0] - float(st_a[0])) <= 2e-6 * max(1.0, abs(float(st_a[0]))) and vals[0] == vals[1] == vals[2]
+    ad, Lz = 3, 6
+    u, act, head = r(rows, ad), r(rows, ad), r(rows, 2 * Lz) * 0.3
+    du_a, du_b = torch.zeros(1, rows, ad, device=dev), torch.zeros(1, rows, ad, device=dev)
+    ws2 = G.loss_ws(dev)
+    G.vae_loss(u, act, head, rows, ad, Lz, 0.5, rows, du_a, st_a)
+    vals = []
+    for _ in range(3):
+        G.vae_loss(u, act, head, rows, ad, Lz, 0.5, rows, du_b, st_b, ws=ws2)
+        torch.cuda.synchronize()
+        vals.append(float(st_b[0]))
+    assert torch.equal(du_a, du_b)
+    assert abs(vals[0] - float(st_a[0])) <= 2e-6 * max(1.0, abs(float(st_a[0]))) and vals[0] == vals[1] == vals[2]
+
+
 def test_adam_polyak_matches_oracle():
     from oracle.osrl_oracle import Adam
     from osrl_amd.engine.core import FlatGroup, StepState
