@@ -4,9 +4,12 @@
 These modules hold parameters only -- as VIEWS into flat HBM optimizer groups
 (engine/core.py FlatGroup) -- plus thin ``forward`` methods that call the fused HIP
 MLP through ``osrl_amd.ops`` (a ``torch.autograd.Function`` over libosrl_amd.so).
-There is no CPU path, and no aten arithmetic on the train-step path; the one aten op in this file is the
-element-wise ``torch.minimum`` over an ensemble's outputs in ``predict()`` (an inference convenience the step plans
-never call: they take the minimum inside their loss kernels).
+There is no CPU path, and no aten arithmetic on the train-step path of BC / CPQ / BCQ-Lag / BEAR-Lag / COptiDICE / CDT's
+default configuration; the one aten op in this file is the element-wise ``torch.minimum`` over an ensemble's outputs in
+``predict()`` (an inference convenience the step plans never call: they take the minimum inside their loss kernels).
+Exception (engine/cdt.py): CDT's cost-feature (add / mul / cat) and cost-prefix constructor variants form the head's
+input feature and compact the prefix token's row with 3-6 small aten element-wise / copy launches inside the captured
+step (the maths, detach and mul-backward of cdt.py:243-250 included); the default training configuration has none.
 
 Construction mirrors the reference's module/parameter creation ORDER (nn.Linear default
 init draws from the global torch RNG), so ``torch.manual_seed(s)`` followed by building a

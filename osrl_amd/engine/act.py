@@ -75,10 +75,20 @@ class FastPolicy:
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
+    # The handle wraps a ctypes pointer to a pinned, device-mapped block: it cannot be copied or pickled.  A copied /
+    # unpickled model simply has no fast policy yet and builds its own on its first act() (the models test `_fast is None`).
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def act1(self, obs, deterministic: bool = True):
         """The hot call of the episode loop: ONE observation [obs_dim], no explicit noise.  Everything a call does on
         the host: one numpy copy into pinned memory, one C call, one or two copies out."""
-        self._obs1[:] = obs  # converts dtype, raises on a shape mismatch
+        if np.shape(obs) != self._obs1.shape:  # numpy would broadcast a scalar / length-1 observation silently
+            raise ValueError(f"expected one observation of shape {self._obs1.shape}, got {np.shape(obs)}")
+        self._obs1[:] = obs  # converts dtype
         st = self._raw_stream(self._dev_index) if self._raw_stream is not None else cur_stream()
         rc = self._fn(self._h, 1, 1 if deterministic else 0, 0, self.seed, st)
         if rc != 0:

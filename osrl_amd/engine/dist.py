@@ -75,7 +75,11 @@ class DataParallel:
     def all_agree(self, ok: bool, device) -> bool:
         """True iff EVERY rank passes ``ok`` (eager collective, outside any capture): used to settle graph replay vs
         eager launches for the whole group -- one rank replaying a graph with captured collectives while a peer
-        issues them eagerly would still match up on the wire, but a rank that fell back must not be the only one."""
+        issues them eagerly would still match up on the wire, but a rank that fell back must not be the only one.
+        Scope: this settles capture-time REFUSALS (the runtime raising while the step is being captured, after which
+        every rank arrives here).  A rank that raises from inside the warm-up pass BEFORE one of its collectives leaves
+        its peers blocked in that collective -- like any mid-step failure of a data-parallel job; the launcher's
+        timeout (torchrun / NCCL_TIMEOUT) is what ends it, not this vote."""
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=device)
         self.all_reduce_(t)
         return bool(float(t.item()) >= self.world - 0.5)
