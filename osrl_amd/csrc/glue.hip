@@ -14,12 +14,18 @@
 #include <stdint.h>
 
 #include "../../include/osrl_amd.h"
+#include "argmem.h"
 
 namespace {
 
 constexpr float kLogStdMin = -20.0f, kLogStdMax = 2.0f;  // net.py:148-149
 constexpr float kVaeLsMin = -4.0f, kVaeLsMax = 15.0f;    // net.py:325
 constexpr int kRed = 1024;
+// Launch geometry as compile-time constants (round 3): `blockDim` / `gridDim` are read from the hidden block behind a
+// kernel's explicit arguments, i.e. by an s_load from the kernarg segment in every wave -- a PCIe round trip at the head
+// of every wave where the runtime keeps kernel arguments in host memory, and beyond the 14 dwords that kernarg preload
+// hands over.  The element-wise kernels are always launched with kEw threads (GRID_1D), the batch-sum kernels with kRed.
+constexpr int kEw = 256;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -35,7 +41,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm /*>=17 floats*/) {
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+    for (int i = 0; i < (int)(kRed >> 6); ++i) t += sm[i];
     sm[16] = t;
   }
   __syncthreads();
@@ -45,14 +51,14 @@ __device__ __forceinline__ float softplus(float x) {  // log(1+exp(x)), F.softpl
   return x > 20.0f ? x : log1pf(expf(x));
 }
 
-#define GRID_1D(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+#define GRID_1D(n) dim3((unsigned)(((n) + kEw - 1) / kEw)), dim3(kEw)
 
 // ---------------- squashed Gaussian head ----------------
 __global__ void gauss_head_kernel(const float* __restrict__ head, const float* __restrict__ eps, int rows, int ad,
                                   float max_a, float* __restrict__ a, float* __restrict__ tanh_u,
                                   float* __restrict__ logp) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.x * kEw + threadIdx.x;
   if (r >= rows) return;
   float lp = 0.f;
   for (int j = 0; j < ad; ++j) {
@@ -81,7 +87,7 @@ __global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const floa
                                       const float* __restrict__ tanh_u, const float* __restrict__ da_nets,
                                       int n_nets, int rows, int ad, float max_a, float* __restrict__ dhead) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * kEw + threadIdx.x;
   if (i >= rows * ad) return;
   const int r = i / ad, j = i - r * ad;
   float t = tanh_u[i];
@@ -112,7 +118,7 @@ __global__ void gauss_head_bwd_kernel(const float* __restrict__ head, const floa
 __global__ void gauss_ood_kernel(const float* __restrict__ head, const float* __restrict__ eps, int n_samples,
                                  int rows, int ad, float* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kEw + threadIdx.x;
   const int64_t total = (int64_t)n_samples * rows * ad;
   if (i >= total) return;
   const int k = (int)(i % ad);
@@ -126,7 +132,7 @@ __global__ void gauss_ood_kernel(const float* __restrict__ head, const float* __
 __global__ void vae_latent_kernel(const float* __restrict__ head, const float* __restrict__ eps, int rows, int L,
                                   float* __restrict__ z) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * kEw + threadIdx.x;
   if (i >= rows * L) return;
   const int r = i / L, k = i - r * L;
   const float mean = head[(size_t)r * 2 * L + k];
@@ -139,10 +145,11 @@ __device__ __forceinline__ float kl_elem(float mean, float ls_raw) {
   return -0.5f * (1.0f + logf(sd * sd) - mean * mean - sd * sd);
 }
 
-__global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict__ u, const float* __restrict__ act,
-                                                        const float* __restrict__ head, int rows, int ad, int L,
-                                                        float beta, float inv_rows, float* __restrict__ du,
-                                                        float* __restrict__ stat) {
+// (body + two entry kernels: by value, and "_p" = arguments in a device-resident block, csrc/argmem.h -- the three
+// batch-sum kernels of the CPQ step whose 16-32 dwords of arguments exceed what kernarg preload hands a wave)
+__device__ __forceinline__ void vae_loss_body(const float* __restrict__ u, const float* __restrict__ act,
+                                              const float* __restrict__ head, int rows, int ad, int L, float beta,
+                                              float inv_rows, float* __restrict__ du, float* __restrict__ stat) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   __shared__ float sm[20];
   float rec = 0.f, kl = 0.f;
@@ -195,12 +202,28 @@ __global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict_
   kl = block_sum(kl, sm);
   if (threadIdx.x == 0 && stat) stat[0] = rec * ia + beta * (kl * il);
 }
+__global__ __launch_bounds__(kRed) void vae_loss_kernel(const float* __restrict__ u, const float* __restrict__ act,
+                                                        const float* __restrict__ head, int rows, int ad, int L,
+                                                        float beta, float inv_rows, float* __restrict__ du,
+                                                        float* __restrict__ stat) {
+  vae_loss_body(u, act, head, rows, ad, L, beta, inv_rows, du, stat);
+}
+struct VaeLossArgs {
+  const float *u, *act, *head;
+  float *du, *stat;
+  int32_t rows, ad, L;
+  float beta, inv_rows;
+};
+__global__ __launch_bounds__(kRed) void vae_loss_kernel_p(const void* p) {
+  const OSRL_CAS VaeLossArgs& a = *(const OSRL_CAS VaeLossArgs*)p;
+  vae_loss_body(a.u, a.act, a.head, a.rows, a.ad, a.L, a.beta, a.inv_rows, a.du, a.stat);
+}
 
 __global__ void vae_latent_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
                                       const float* __restrict__ dz, int rows, int L, float beta, float inv_rows,
                                       float* __restrict__ dhead) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * kEw + threadIdx.x;
   if (i >= rows * L) return;
   const int r = i / L, k = i - r * L;
   const float mean = head[(size_t)r * 2 * L + k];
@@ -216,7 +239,7 @@ __global__ void vae_latent_bwd_kernel(const float* __restrict__ head, const floa
 }
 
 __global__ void vae_kl_rows_kernel(const float* __restrict__ head, int rows, int L, float* __restrict__ kl) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.x * kEw + threadIdx.x;
   if (r >= rows) return;
   float s = 0.f;
   const float* __restrict__ hr = head + (size_t)r * 2 * L;
@@ -270,10 +293,10 @@ __device__ uint32_t radix_select(const float* __restrict__ x, int64_t n, int64_t
   uint32_t prefix = 0, mask = 0;
   int64_t below = 0;  // elements strictly below the current prefix range
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += kRed) hist[i] = 0;
     __syncthreads();
-    const int nround = (int)((n + blockDim.x - 1) / blockDim.x * blockDim.x);
-    for (int i = threadIdx.x; i < nround; i += blockDim.x) {
+    const int nround = (int)((n + kRed - 1) / kRed * kRed);
+    for (int i = threadIdx.x; i < nround; i += kRed) {
       uint32_t key = 0;
       bool act = false;
       if (i < n) {
@@ -367,7 +390,7 @@ __device__ __forceinline__ float quantile_rows(const float* __restrict__ x, int6
   for (int j = 0; j < ROWS; ++j) {
     // all loads in flight at once: clamped address + select.  ("i < n ? f2key(x[i]) : ~0u" compiles to an exec-masked
     // load with its own s_waitcnt vmcnt(0) per row: ROWS serial round trips, most of this kernel's time.)
-    const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)j * kRed + threadIdx.x;
     const bool ok = i < n;
     const float xv = x[ok ? i : 0];
     kreg[j] = f2key(xv) | (ok ? 0u : 0xffffffffu);  // (an OR, not a select: a select is turned back into a branch)
@@ -380,7 +403,7 @@ __device__ __forceinline__ float quantile_rows(const float* __restrict__ x, int6
     uint32_t mn = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-      const int64_t i = (int64_t)j * blockDim.x + threadIdx.x;
+      const int64_t i = (int64_t)j * kRed + threadIdx.x;
       if (i < n && kreg[j] > klo && kreg[j] < mn) mn = kreg[j];
     }
 #pragma unroll
@@ -391,7 +414,7 @@ __device__ __forceinline__ float quantile_rows(const float* __restrict__ x, int6
     if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mn;
     __syncthreads();
     uint32_t t = s_min[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = s_min[i] < t ? s_min[i] : t;
+    for (int i = 1; i < (int)(kRed >> 6); ++i) t = s_min[i] < t ? s_min[i] : t;
     khi = t;
   }
   const float vlo = key2f(klo), vhi = key2f(khi);
@@ -400,7 +423,7 @@ __device__ __forceinline__ float quantile_rows(const float* __restrict__ x, int6
 constexpr int kQuantRegRows = 32;
 __device__ __forceinline__ float quantile_regs(const float* __restrict__ x, int64_t n, float q, uint32_t* cnt,
                                                uint32_t* s_min) {
-  const int rows = (int)((n + blockDim.x - 1) / blockDim.x);  // uniform
+  const int rows = (int)((n + kRed - 1) / kRed);  // uniform
   if (rows <= 4) return quantile_rows<4>(x, n, q, cnt, s_min);
   if (rows <= 12) return quantile_rows<12>(x, n, q, cnt, s_min);
   if (rows <= 20) return quantile_rows<20>(x, n, q, cnt, s_min);
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict_
   __shared__ uint32_t hist[256];
   __shared__ uint32_t bc[4];
   __shared__ uint32_t s_min[17];
-  if (n <= (int64_t)32 * blockDim.x) {  // register-resident keys, bitwise select
+  if (n <= (int64_t)32 * kRed) {  // register-resident keys, bitwise select
     const float v = quantile_regs(x, n, q, hist, s_min);
     if (threadIdx.x == 0) out[0] = v;
     return;
@@ -428,7 +451,7 @@ __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict_
   if (hi != lo && n_le < hi + 1) {
     // the (lo+1)-th order statistic is the smallest key strictly above klo: one min-reduction pass
     uint32_t mn = 0xffffffffu;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int64_t i = threadIdx.x; i < n; i += kRed) {
       const uint32_t key = f2key(x[i]);
       if (key > klo && key < mn) mn = key;
     }
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(kRed) void quantile_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t t = s_min[0];
-      for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = s_min[i] < t ? s_min[i] : t;
+      for (int i = 1; i < (int)(kRed >> 6); ++i) t = s_min[i] < t ? s_min[i] : t;
       s_min[0] = t;
     }
     __syncthreads();
@@ -603,13 +626,12 @@ __device__ __forceinline__ float min_over(const float* __restrict__ q, int n, in
 }
 
 template <bool SMALL>
-__global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __restrict__ q_old, int n_q_old,
-                                                               const float* __restrict__ qc_old, int n_qc_old,
-                                                               const float* __restrict__ q, int n_q,
-                                                               const float* __restrict__ rew,
-                                                               const float* __restrict__ done, int rows,
-                                                               float gamma, float q_thres, float inv_rows,
-                                                               float* __restrict__ dq, float* __restrict__ stat) {
+__device__ __forceinline__ void cpq_critic_loss_body(const float* __restrict__ q_old, int n_q_old,
+                                                     const float* __restrict__ qc_old, int n_qc_old,
+                                                     const float* __restrict__ q, int n_q,
+                                                     const float* __restrict__ rew, const float* __restrict__ done,
+                                                     int rows, float gamma, float q_thres, float inv_rows,
+                                                     float* __restrict__ dq, float* __restrict__ stat) {
   __builtin_amdgcn_s_setprio(3);  // latency-chain kernel: outrank the N*B-row filler launches (csrc/mlp.hip)
   __shared__ float sm[20];
   float loss = 0.f;
@@ -639,6 +661,28 @@ __global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __re
   }
   loss = block_sum(loss, sm);
   if (threadIdx.x == 0 && stat) stat[0] = loss * inv_rows;
+}
+template <bool SMALL>
+__global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel(const float* __restrict__ q_old, int n_q_old,
+                                                               const float* __restrict__ qc_old, int n_qc_old,
+                                                               const float* __restrict__ q, int n_q,
+                                                               const float* __restrict__ rew,
+                                                               const float* __restrict__ done, int rows,
+                                                               float gamma, float q_thres, float inv_rows,
+                                                               float* __restrict__ dq, float* __restrict__ stat) {
+  cpq_critic_loss_body<SMALL>(q_old, n_q_old, qc_old, n_qc_old, q, n_q, rew, done, rows, gamma, q_thres, inv_rows, dq, stat);
+}
+struct CriticLossArgs {
+  const float *q_old, *qc_old, *q, *rew, *done;
+  float *dq, *stat;
+  int32_t n_q_old, n_qc_old, n_q, rows;
+  float gamma, q_thres, inv_rows;
+};
+template <bool SMALL>
+__global__ __launch_bounds__(kRed) void cpq_critic_loss_kernel_p(const void* p) {
+  const OSRL_CAS CriticLossArgs& a = *(const OSRL_CAS CriticLossArgs*)p;
+  cpq_critic_loss_body<SMALL>(a.q_old, a.n_q_old, a.qc_old, a.n_qc_old, a.q, a.n_q, a.rew, a.done, a.rows, a.gamma,
+                              a.q_thres, a.inv_rows, a.dq, a.stat);
 }
 
 // mean over the (global) batch of qc_ood = ((KL >= quantile) * qc_sampled).mean(0)   cpq.py:184,187
@@ -698,7 +742,7 @@ struct OodArgs {  // non-NULL qc_sampled: compute the OOD mean here (single-GPU 
 };
 
 template <bool SMALL>
-__global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
+__device__ __forceinline__ void cpq_cost_loss_body(
     const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
     float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
     float alpha_lr, float inv_rows, float stat_share, float* __restrict__ log_alpha, float* __restrict__ dq,
@@ -747,6 +791,29 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
     log_alpha[0] = la;
     if (stat) stat[1] = stat_share * expf(la);
   }
+}
+template <bool SMALL>
+__global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel(
+    const float* __restrict__ qc_old_next, int n_qc_old, const float* __restrict__ qc, int n_qc,
+    float* __restrict__ ood_mean_p, const float* __restrict__ cost, int rows, float gamma, float qc_thres,
+    float alpha_lr, float inv_rows, float stat_share, float* __restrict__ log_alpha, float* __restrict__ dq,
+    float* __restrict__ stat, const OodArgs oa) {
+  cpq_cost_loss_body<SMALL>(qc_old_next, n_qc_old, qc, n_qc, ood_mean_p, cost, rows, gamma, qc_thres, alpha_lr, inv_rows,
+                            stat_share, log_alpha, dq, stat, oa);
+}
+struct CostLossArgs {
+  const float *qc_old_next, *qc, *cost;
+  float *ood_mean_p, *log_alpha, *dq, *stat;
+  OodArgs oa;
+  int32_t n_qc_old, n_qc, rows;
+  float gamma, qc_thres, alpha_lr, inv_rows, stat_share;
+};
+template <bool SMALL>
+__global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel_p(const void* p) {
+  const OSRL_CAS CostLossArgs& a = *(const OSRL_CAS CostLossArgs*)p;
+  const OodArgs oa{a.oa.qc_sampled, a.oa.kl, a.oa.quantile, a.oa.n_qc_old, a.oa.n_samples};
+  cpq_cost_loss_body<SMALL>(a.qc_old_next, a.n_qc_old, a.qc, a.n_qc, a.ood_mean_p, a.cost, a.rows, a.gamma, a.qc_thres,
+                            a.alpha_lr, a.inv_rows, a.stat_share, a.log_alpha, a.dq, a.stat, oa);
 }
 
 // the dual step of cpq.py:186-195 on its own: stat[0] (the MSE part written by cpq_cost_loss_kernel) gets the
@@ -814,13 +881,13 @@ __global__ __launch_bounds__(kRed) void mse_loss_kernel(const float* __restrict_
 
 // ---------------- BCQ-Lag ----------------
 __global__ void clamp_kernel(float* __restrict__ x, int64_t n, float lo, float hi) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * kEw + threadIdx.x;
   if (i < n) x[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
 __global__ void bcq_perturb_kernel(const float* __restrict__ dec, const float* __restrict__ t, int n, float phi,
                                    float max_a, float* __restrict__ a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * kEw + threadIdx.x;
   if (i >= n) return;
   a[i] = fminf(fmaxf(dec[i] + phi * max_a * t[i], -max_a), max_a);  // net.py:61-62
 }
@@ -828,7 +895,7 @@ __global__ void bcq_perturb_kernel(const float* __restrict__ dec, const float* _
 __global__ void bcq_perturb_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ t,
                                        const float* __restrict__ da_nets, int n_nets, int n, float phi, float max_a,
                                        float* __restrict__ dt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * kEw + threadIdx.x;
   if (i >= n) return;
   float da = 0.f;
   for (int e = 0; e < n_nets; ++e) da += da_nets[(size_t)e * n + i];
@@ -1121,8 +1188,18 @@ int osrl_vae_loss(const float* u, const float* act, const float* head, int32_t r
                   float beta, int32_t rows_global, float* du, float* stat, void* stream) {
   if (!u || !act || !head || !du || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(kRed), 0, S, u, act, head, rows, ad, L, beta,
-                     1.0f / (float)(rows_global > 0 ? rows_global : rows), du, stat);
+  const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
+  const void* dev_args = nullptr;
+  if (osrl_argmem::current()) {
+    VaeLossArgs a{};
+    a.u = u; a.act = act; a.head = head; a.du = du; a.stat = stat;
+    a.rows = rows; a.ad = ad; a.L = L; a.beta = beta; a.inv_rows = inv;
+    dev_args = osrl_argmem::slot(a);
+  }
+  if (dev_args)
+    hipLaunchKernelGGL(vae_loss_kernel_p, dim3(1), dim3(kRed), 0, S, dev_args);
+  else
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(kRed), 0, S, u, act, head, rows, ad, L, beta, inv, du, stat);
   LAUNCH_CHECK();
 }
 
@@ -1169,7 +1246,21 @@ int osrl_cpq_critic_loss(const float* q_old, int32_t n_q_old, const float* qc_ol
   if (!q_old || !qc_old || !q || !rew || !done || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
-  if (n_q_old <= kEns && n_qc_old <= kEns && n_q <= kEns)
+  const bool small = n_q_old <= kEns && n_qc_old <= kEns && n_q <= kEns;
+  if (osrl_argmem::current()) {
+    CriticLossArgs a{};
+    a.q_old = q_old; a.qc_old = qc_old; a.q = q; a.rew = rew; a.done = done; a.dq = dq; a.stat = stat;
+    a.n_q_old = n_q_old; a.n_qc_old = n_qc_old; a.n_q = n_q; a.rows = rows;
+    a.gamma = gamma; a.q_thres = q_thres; a.inv_rows = inv;
+    if (const void* dev_args = osrl_argmem::slot(a)) {
+      if (small)
+        hipLaunchKernelGGL(cpq_critic_loss_kernel_p<true>, dim3(1), dim3(kRed), 0, S, dev_args);
+      else
+        hipLaunchKernelGGL(cpq_critic_loss_kernel_p<false>, dim3(1), dim3(kRed), 0, S, dev_args);
+      LAUNCH_CHECK();
+    }
+  }
+  if (small)
     hipLaunchKernelGGL(cpq_critic_loss_kernel<true>, dim3(1), dim3(kRed), 0, S, q_old, n_q_old, qc_old, n_qc_old, q, n_q,
                        rew, done, rows, gamma, q_thres, inv, dq, stat);
   else
@@ -1214,7 +1305,22 @@ int osrl_cpq_cost_loss(const float* qc_old_next, int32_t n_qc_old, const float* 
   if (!qc_old_next || !qc || !cost || (ood_mean && !log_alpha) || !dq || rows < 1) return -1;
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   const float inv = 1.0f / (float)(rows_global > 0 ? rows_global : rows);
-  if (n_qc_old <= kEns && n_qc <= kEns)
+  const bool small = n_qc_old <= kEns && n_qc <= kEns;
+  if (osrl_argmem::current()) {
+    CostLossArgs a{};
+    a.qc_old_next = qc_old_next; a.qc = qc; a.cost = cost; a.ood_mean_p = const_cast<float*>(ood_mean);
+    a.log_alpha = log_alpha; a.dq = dq; a.stat = stat; a.oa = OodArgs{nullptr, nullptr, nullptr, 0, 0};
+    a.n_qc_old = n_qc_old; a.n_qc = n_qc; a.rows = rows; a.gamma = gamma; a.qc_thres = qc_thres;
+    a.alpha_lr = alpha_lr; a.inv_rows = inv; a.stat_share = stat_share;
+    if (const void* dev_args = osrl_argmem::slot(a)) {
+      if (small)
+        hipLaunchKernelGGL(cpq_cost_loss_kernel_p<true>, dim3(1), dim3(kRed), 0, S, dev_args);
+      else
+        hipLaunchKernelGGL(cpq_cost_loss_kernel_p<false>, dim3(1), dim3(kRed), 0, S, dev_args);
+      LAUNCH_CHECK();
+    }
+  }
+  if (small)
     hipLaunchKernelGGL(cpq_cost_loss_kernel<true>, dim3(1), dim3(kRed), 0, S, qc_old_next, n_qc_old, qc, n_qc,
                        const_cast<float*>(ood_mean), cost, rows, gamma, qc_thres, alpha_lr, inv, stat_share, log_alpha,
                        dq, stat, OodArgs{nullptr, nullptr, nullptr, 0, 0});

@@ -381,20 +381,23 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRB][NCB]) {
     for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// copy the LDS tile [BM][N] (stride lda) to global dst[(row0+r)*N + c]
+// copy the LDS tile [BM][N] (stride lda) to global dst[(row0+r)*N + c].  NT = the workgroup's thread count when the
+// caller knows it at compile time: `blockDim` is an s_load from the hidden block of the kernarg segment in every wave
+// (a PCIe round trip where the runtime keeps kernel arguments in host memory); 0 = read it
+template <int NT = 0>
 __device__ __forceinline__ void tile_to_global(const float* lds, int lda, int BM, int N, float* __restrict__ dst,
                                                int row0, int rows) {
   const int tid = threadIdx.x;
   if ((N & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
     const int n4 = N >> 2;
-    for (int idx = tid; idx < BM * n4; idx += (int)blockDim.x) {
+    for (int idx = tid; idx < BM * n4; idx += (NT ? NT : (int)blockDim.x)) {
       const int r = idx / n4, c4 = idx - r * n4;
       if (row0 + r < rows)
         *reinterpret_cast<f32x4*>(dst + (size_t)(row0 + r) * N + 4 * c4) =
             *reinterpret_cast<const f32x4*>(lds + r * lda + 4 * c4);
     }
   } else {
-    for (int idx = tid; idx < BM * N; idx += (int)blockDim.x) {
+    for (int idx = tid; idx < BM * N; idx += (NT ? NT : (int)blockDim.x)) {
       const int r = idx / N, c = idx - r * N;
       if (row0 + r < rows) dst[(size_t)(row0 + r) * N + c] = lds[r * lda + c];
     }
@@ -441,10 +444,10 @@ __device__ __forceinline__ void fwd_epilogue(float* lds, int lda, const f32x4 (&
 constexpr float kTailLsMin = -4.0f, kTailLsMax = 15.0f;  // net.py:325 (== kVaeLsMin / kVaeLsMax of glue.hip)
 
 // tile = the encoder output [BM][2L] (mean | log_std): z = mean + exp(clamp(log_std)) * eps
-template <class TR>
+template <class TR, int NT = 0>
 __device__ __forceinline__ void tail_vae_latent(const float* lds, int lda, int BM, int row0, int rows, TR t) {
   const int Lz = t.L;
-  for (int idx = threadIdx.x; idx < BM * Lz; idx += (int)blockDim.x) {
+  for (int idx = threadIdx.x; idx < BM * Lz; idx += (NT ? NT : (int)blockDim.x)) {
     const int r = idx / Lz, k = idx - r * Lz;
     const int gr = row0 + r;
     if (gr < rows) {
@@ -457,10 +460,10 @@ __device__ __forceinline__ void tail_vae_latent(const float* lds, int lda, int B
 }
 
 // tile = dL/dz [BM][L] (the decoder's dX slice): d/d(mean | log_std) of recon + beta KL through z = mean + sd * eps
-template <class TR>
+template <class TR, int NT = 0>
 __device__ __forceinline__ void tail_vae_latent_bwd(const float* lds, int lda, int BM, int row0, int rows, TR t) {
   const int Lz = t.L;
-  for (int idx = threadIdx.x; idx < BM * Lz; idx += (int)blockDim.x) {
+  for (int idx = threadIdx.x; idx < BM * Lz; idx += (NT ? NT : (int)blockDim.x)) {
     const int r = idx / Lz, k = idx - r * Lz;
     const int gr = row0 + r;
     if (gr < rows) {
@@ -481,7 +484,7 @@ __device__ __forceinline__ void tail_vae_latent_bwd(const float* lds, int lda, i
 // tile = the actor trunk's output [BM][2 ad] (mu | log_std): the action draws of the squashed-Gaussian head
 // (glue.hip gauss_head_kernel / gauss_ood_kernel, expression for expression) while the tile is in LDS
 constexpr float kTailLogStdMin = -20.0f, kTailLogStdMax = 2.0f;  // net.py:148-149 (== kLogStdMin / kLogStdMax of glue.hip)
-template <class TR>
+template <class TR, int NT = 0>
 __device__ __forceinline__ void tail_gauss(const float* lds, int lda, int BM, int row0, int rows, TR t) {
   const int ad = t.L;
   const float max_a = t.max_action;
@@ -490,7 +493,7 @@ __device__ __forceinline__ void tail_gauss(const float* lds, int lda, int BM, in
   float* __restrict__ a1 = t.out;
   float* __restrict__ a2 = t.out2;
   float* __restrict__ th2 = t.tanh2;
-  for (int idx = threadIdx.x; idx < BM * ad; idx += (int)blockDim.x) {
+  for (int idx = threadIdx.x; idx < BM * ad; idx += (NT ? NT : (int)blockDim.x)) {
     const int r = idx / ad, j = idx - r * ad;
     const int gr = row0 + r;
     if (gr < rows) {
@@ -514,7 +517,7 @@ __device__ __forceinline__ void tail_gauss(const float* lds, int lda, int BM, in
   if (eo) {
     float* __restrict__ so = t.out_ood;
     const int ns = t.n_samples;
-    for (int idx = threadIdx.x; idx < ns * BM * ad; idx += (int)blockDim.x) {
+    for (int idx = threadIdx.x; idx < ns * BM * ad; idx += (NT ? NT : (int)blockDim.x)) {
       const int jr = idx / ad, k = idx - jr * ad;
       const int smp = jr / BM, r = jr - smp * BM;
       const int gr = row0 + r;
@@ -613,7 +616,7 @@ __device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) 
       }
     }
     __syncthreads();
-    if (e == 0 && a.out.x) tile_to_global(lds, lda, BM, K0, a.out.x, row0, rows);
+    if (e == 0 && a.out.x) tile_to_global<64 * NW>(lds, lda, BM, K0, a.out.x, row0, rows);
   }
   PHASE_STAMP(1);
 
@@ -670,12 +673,12 @@ __device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) 
     PHASE_STAMP(4 + 4 * l);
     __syncthreads();
     float* save = a.out.h[e][l];
-    if (save) tile_to_global(lds, lda, BM, N, save, row0, rows);
+    if (save) tile_to_global<64 * NW>(lds, lda, BM, N, save, row0, rows);
     PHASE_STAMP(5 + 4 * l);
   }
   // the net's output tile [BM][dims[L]] is still in LDS (nothing wrote it since the last barrier)
-  if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
-  if (a.tail.kind == OSRL_TAIL_GAUSS && e == 0) tail_gauss<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
+  if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent<decltype((a.tail)), 64 * NW>(lds, lda, BM, row0, rows, a.tail);
+  if (a.tail.kind == OSRL_TAIL_GAUSS && e == 0) tail_gauss<decltype((a.tail)), 64 * NW>(lds, lda, BM, row0, rows, a.tail);
   WG_LOG(1);
 }
 
@@ -1252,7 +1255,7 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
       lds[r * lda + c] = ok ? v : 0.f;
     }
     __syncthreads();
-    if (a.g.dz[e][L - 1]) tile_to_global(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);
+    if (a.g.dz[e][L - 1]) tile_to_global<64 * NW>(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);
   }
 
   for (int l = L - 1; l >= 1; --l) {
@@ -1320,7 +1323,7 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
     else
       epilogue(std::integral_constant<int, OSRL_ACT_ID>{});
     __syncthreads();
-    if (a.g.dz[e][l - 1]) tile_to_global(lds, lda, BM, N, a.g.dz[e][l - 1], row0, rows);
+    if (a.g.dz[e][l - 1]) tile_to_global<64 * NW>(lds, lda, BM, N, a.g.dz[e][l - 1], row0, rows);
   }
 
   if (a.g.dx[e]) {
@@ -1332,9 +1335,9 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
     float* __restrict__ dx = a.g.dx[e];
     if (nblk <= 2 && nk >= 4 && lda >= 16 * NW) {
       narrow_layer_splitk<NRB, NCB, NW>(lds, lda, nk, a.net.Wb[e][0], Npb, a.g.dx_col0, nblk, wave, ring);
-      tile_to_global(lds, lda, BM, nc, dx, row0, rows);
+      tile_to_global<64 * NW>(lds, lda, BM, nc, dx, row0, rows);
       // (the host fuses the tail only when this branch is the one taken: bwd_tail_fusable)
-      if (a.tail.kind == OSRL_TAIL_VAE_LATENT_BWD && e == 0) tail_vae_latent_bwd<decltype((a.tail))>(lds, lda, BM, row0, rows, a.tail);
+      if (a.tail.kind == OSRL_TAIL_VAE_LATENT_BWD && e == 0) tail_vae_latent_bwd<decltype((a.tail)), 64 * NW>(lds, lda, BM, row0, rows, a.tail);
     } else {
       int cb0, cnt;
       wave_blocks<NW>(nblk, wave, &cb0, &cnt);

@@ -22,10 +22,14 @@ namespace {
 
 using namespace osrl_rng;
 
+// NT: the workgroup size when it is a compile-time constant (0: read blockDim -- an s_load from the hidden kernarg block)
+template <int NT = 0>
 __device__ __forceinline__ void randn_body(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
                                            uint32_t stream_id, uint32_t step, int64_t block, int64_t n_blocks) {
   const int64_t n4 = (n + 3) >> 2;
-  for (int64_t i = block * blockDim.x + threadIdx.x; i < n4; i += n_blocks * blockDim.x) {
+  constexpr bool kConst = NT != 0;
+  const int64_t nt = kConst ? NT : (int64_t)blockDim.x;
+  for (int64_t i = block * nt + threadIdx.x; i < n4; i += n_blocks * nt) {
     const U4 r = philox4x32_10(U4{(uint32_t)i, (uint32_t)(i >> 32), step, stream_id}, k0, k1);
     const float r0 = sqrtf(-2.0f * __logf(u01(r.x))), r1 = sqrtf(-2.0f * __logf(u01(r.z)));
     float s0, c0, s1, c1;
@@ -62,10 +66,10 @@ struct GatherArgs {
 
 // one wave per sampled row; lanes stride over the row's columns (coalesced both sides)
 // AR: `const GatherArgs&` (kernel argument by value) or `const OSRL_CAS GatherArgs&` (device-resident block, argmem.h)
-template <class AR>
+template <class AR, int NT = 0>
 __device__ __forceinline__ void gather_body(AR a, uint32_t step, int block) {
   const int lane = threadIdx.x & 63;
-  const int b = block * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b = block * (NT ? NT / 64 : (int)(blockDim.x >> 6)) + (threadIdx.x >> 6);
   if (b >= a.batch) return;
   const U4 r = philox4x32_10(U4{(uint32_t)b, 0x5eedu, step, a.stream_id}, a.k0, a.k1);
   // 64-bit multiply-shift maps a 64-bit uniform onto [0, n_rows) (bias < 2^-40 for n_rows < 2^24)
@@ -113,18 +117,19 @@ __device__ __forceinline__ void step_begin_body(BR b, AR a) {
     // the old step has been READ by this workgroup (its value went through LDS): count the arrival
     __threadfence();
     const uint32_t seen = atomicAdd(&b.st->arrive_, 1u);
-    s_last = seen == gridDim.x - 1;
+    const int nb = b.g_blocks + b.r_blocks;  // the launch's grid (host: max(g_blocks + r_blocks, 1))
+    s_last = seen == (unsigned)(nb > 0 ? nb : 1) - 1;
   }
   const uint32_t step = (uint32_t)(t_old + 1);
   const int blk = blockIdx.x;
   if (blk < b.g_blocks) {
-    gather_body<AR>(a, step, blk);
+    gather_body<AR, kBeginThreads>(a, step, blk);
   } else if (b.noise) {
-    randn_body(b.noise, b.noise_n, b.nk0, b.nk1, b.noise_stream, step, blk - b.g_blocks, b.r_blocks);
+    randn_body<kBeginThreads>(b.noise, b.noise_n, b.nk0, b.nk1, b.noise_stream, step, blk - b.g_blocks, b.r_blocks);
   }
   __syncthreads();
   if (s_last) {  // every workgroup holds t_old in registers by now: the state may move
-    osrl_step::commit_stats(t_old, b.stats_cur, b.ring, b.n_stats, b.ring_len);
+    osrl_step::commit_stats<kBeginThreads>(t_old, b.stats_cur, b.ring, b.n_stats, b.ring_len);
     if (threadIdx.x == 0) {
       osrl_step::advance(b.st, t_old, b.beta1, b.beta2, b.warmup);
       b.st->arrive_ = 0;

@@ -8,12 +8,14 @@
 
 namespace osrl_step {
 
-// commit the previous step's statistics into the ring (all threads of the calling workgroup)
+// commit the previous step's statistics into the ring (all threads of the calling workgroup; NT = its size when known
+// at compile time: `blockDim` is a load from the hidden kernarg block)
+template <int NT = 0>
 __device__ __forceinline__ void commit_stats(int64_t t_old, const float* __restrict__ stats_cur,
                                              float* __restrict__ ring, int n_stats, int ring_len) {
   if (stats_cur && ring && t_old >= 1) {
     const int slot = (int)((t_old - 1) % ring_len);
-    for (int i = threadIdx.x; i < n_stats; i += blockDim.x) ring[(size_t)slot * n_stats + i] = stats_cur[i];
+    for (int i = threadIdx.x; i < n_stats; i += (NT ? NT : (int)blockDim.x)) ring[(size_t)slot * n_stats + i] = stats_cur[i];
   }
 }
 
