@@ -64,7 +64,12 @@ class BCQLEngine:
         self.z, self.du, self.dhead_enc = z(B, Lz), z(1, B, ad), z(1, B, 2 * Lz)
         self.r_dec.setup_backward(self.du, dx_cols=(od, Lz))
         self.r_enc.setup_backward(self.dhead_enc)
-        self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev)
+        if int(m.vae_hidden_sizes) % 80 == 0 and B >= 1024 and os.environ.get("OSRL_VAE_DW_T5", "1") == "1":
+            # 400-wide layers = 5 x 5 column blocks: 80 x 80 tiles, 3 row splits per 2048 rows (engine/cpq.py)
+            self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
+                                n_splits=max(1, (3 * B) // 2048), tile_blocks=5)
+        else:
+            self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev)
 
         # target pipeline buffers (shared by the critic and the cost-critic phases)
         NB = N * B
