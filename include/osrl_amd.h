@@ -404,6 +404,16 @@ int osrl_layernorm_fwd(const float* x, const float* delta, const float* gamma, c
 int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
                        float* dx, float* partial_ws, int32_t n_parts, int32_t M, int32_t E, float* slab,
                        int64_t g_off, int64_t b_off, void* stream);
+/* The same two calls with the nn.Dropout of the residual branch folded in (net.py:414,439; round 3): forward applies
+ * the keep-multiplier of `drop` to `delta` on the way in (== osrl_dropout(delta) then osrl_layernorm_fwd, bit for bit;
+ * drop NULL or p <= 0: the plain call); backward also writes dx_dropped = dx * keep-multiplier of `drop` (the gradient
+ * that enters the residual branch whose output fed this LayerNorm's input: == osrl_dropout on dx). */
+int osrl_layernorm_fwd_drop(const float* x, const float* delta, const osrl_dropout_t* drop, const float* gamma,
+                            const float* beta, float* xout, float* y, float* stats, int32_t M, int32_t E,
+                            void* stream);
+int osrl_layernorm_bwd_drop(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
+                            float* dx, float* dx_dropped, const osrl_dropout_t* drop, float* partial_ws, int32_t n_parts,
+                            int32_t M, int32_t E, float* slab, int64_t g_off, int64_t b_off, void* stream);
 /* nn.MultiheadAttention core with the block's causal mask and key padding (net.py:417-435): qkv [B,S,3E] (q|k|v,
  * heads split the E axis contiguously), mask [B, (S-prefix)/rep] (1 = valid timestep, each repeated rep times along S;
  * prefix = 1: token 0 is the cost-prefix token, masked like timestep 0, cdt.py:216-218). */

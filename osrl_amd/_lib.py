@@ -184,6 +184,8 @@ PROTOTYPES = {
     "osrl_cdt_embed_ln": [_fp, _fp, _fp, _fp, _fp, _vp] + [_fp] * 13 + [_i32] * 9 + [_fp, _fp, _fp, _fp, _vp],
     "osrl_layernorm_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _vp],
     "osrl_layernorm_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],
+    "osrl_layernorm_fwd_drop": [_fp, _fp, _P(DropoutT), _fp, _fp, _fp, _fp, _fp, _i32, _i32, _vp],
+    "osrl_layernorm_bwd_drop": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _P(DropoutT), _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],
     "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
     "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
     "osrl_dropout": [_fp, _fp, _i64, _P(DropoutT), _vp],

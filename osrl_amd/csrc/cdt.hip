@@ -145,14 +145,33 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedArgs a) {
   }
 }
 
-// y = LN(x + delta); xout = x + delta (optional)
+// the dropout keep-multiplier of flat element i at a site (the mask of dropout_kernel: one Philox call per 4 consecutive
+// elements, word i & 3) -- for kernels whose lanes do not own 4 consecutive elements
+struct DropSite {
+  uint32_t thresh, site, k0, k1;
+  float scale;
+  const osrl_step_state_t* st;
+};
+__device__ __forceinline__ float drop_keep(const DropSite& d, uint32_t step, uint64_t i) {
+  const osrl_rng::U4 w = osrl_rng::drop_words(i >> 2, step, d.site, d.k0, d.k1);
+  const uint32_t r = (i & 3) == 0 ? w.x : (i & 3) == 1 ? w.y : (i & 3) == 2 ? w.z : w.w;
+  return r >= d.thresh ? d.scale : 0.f;
+}
+
+// y = LN(x + delta); xout = x + delta (optional).  DROP (round 3): delta is the residual branch BEFORE its nn.Dropout
+// (net.py:414,439): the keep-multiplier is applied on the way in -- x + (delta * m), product rounded before the add,
+// i.e. the bits of osrl_dropout followed by the plain kernel -- and one read + one write pass over [M, E] and a launch
+// per residual branch disappear (0.36 ms of the 15 ms C5 step)
+template <bool DROP>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ delta,
                                                      const float* __restrict__ g, const float* __restrict__ b,
                                                      float* __restrict__ xout, float* __restrict__ y,
-                                                     float* __restrict__ stats, int M, int E) {
+                                                     float* __restrict__ stats, int M, int E, const DropSite ds) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  uint32_t step = 0;
+  if constexpr (DROP) step = ds.st ? (uint32_t)ds.st->step : 0u;
   float v[kMaxEPL];
 #pragma unroll
   for (int j = 0; j < kMaxEPL; ++j) {
@@ -160,7 +179,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     float t = 0.f;
     if (f < E) {
       t = x[(size_t)row * E + f];
-      if (delta) t += delta[(size_t)row * E + f];
+      if (delta) {
+        float d = delta[(size_t)row * E + f];
+        if constexpr (DROP) d = __fmul_rn(d, drop_keep(ds, step, (uint64_t)row * E + f));
+        t = __fadd_rn(t, d);
+      }
       if (xout) xout[(size_t)row * E + f] = t;
     }
     v[j] = t;
@@ -174,11 +197,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)) (+ dres); per-workgroup partial dgamma/dbeta
+// DROP (round 3): also dxd = dx * keep-multiplier of a dropout site -- the gradient entering the residual branch
+// behind the dropout that follows this LayerNorm's input (what a separate osrl_dropout pass over dx produced)
+template <bool DROP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ g,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
-                                                     float* __restrict__ partial, int M, int E) {
+                                                     float* __restrict__ partial, int M, int E,
+                                                     float* __restrict__ dxd, const DropSite ds) {
   __shared__ float sm[4][2 * 64 * kMaxEPL];
+  uint32_t step = 0;
+  if constexpr (DROP) step = ds.st ? (uint32_t)ds.st->step : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[kMaxEPL], db[kMaxEPL];
 #pragma unroll
@@ -210,6 +239,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float v = rstd * (dxh[j] - s1 - xh[j] * s2);
         if (dres) v += dres[(size_t)row * E + f];
         dx[(size_t)row * E + f] = v;
+        if constexpr (DROP) dxd[(size_t)row * E + f] = __fmul_rn(v, drop_keep(ds, step, (uint64_t)row * E + f));
       }
     }
   }
@@ -984,7 +1014,27 @@ int osrl_layernorm_fwd(const float* x, const float* delta, const float* gamma, c
                        float* y, float* stats, int32_t M, int32_t E, void* stream) {
   if (!x || !gamma || !beta || !y || !stats || M < 1 || E < 1 || E > 64 * kMaxEPL) return -1;
   CLEAR();
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M, E);
+  hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M,
+                     E, DropSite{});
+  DONE();
+}
+
+static bool drop_site(const osrl_dropout_t* dr, DropSite* d) {
+  if (!dr || !(dr->p > 0.f) || !(dr->p < 1.0f)) return false;
+  *d = DropSite{osrl_rng::drop_thresh(dr->p), dr->site, (uint32_t)dr->seed, (uint32_t)(dr->seed >> 32),
+                1.0f / (1.0f - dr->p), dr->st};
+  return true;
+}
+
+int osrl_layernorm_fwd_drop(const float* x, const float* delta, const osrl_dropout_t* drop, const float* gamma,
+                            const float* beta, float* xout, float* y, float* stats, int32_t M, int32_t E,
+                            void* stream) {
+  if (!x || !delta || !gamma || !beta || !y || !stats || M < 1 || E < 1 || E > 64 * kMaxEPL) return -1;
+  DropSite d{};
+  if (!drop_site(drop, &d)) return osrl_layernorm_fwd(x, delta, gamma, beta, xout, y, stats, M, E, stream);
+  CLEAR();
+  hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M, E,
+                     d);
   DONE();
 }
 
@@ -994,7 +1044,24 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
   if (!dy || !x || !stats || !gamma || !dx || !partial_ws || !slab || n_parts < 1 || M < 1 || E > 64 * kMaxEPL)
     return -1;
   CLEAR();
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E);
+  hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M,
+                     E, nullptr, DropSite{});
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
+                     g_off, b_off);
+  DONE();
+}
+
+int osrl_layernorm_bwd_drop(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
+                            float* dx, float* dx_dropped, const osrl_dropout_t* drop, float* partial_ws, int32_t n_parts,
+                            int32_t M, int32_t E, float* slab, int64_t g_off, int64_t b_off, void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !dx_dropped || !partial_ws || !slab || n_parts < 1 || M < 1 ||
+      E > 64 * kMaxEPL)
+    return -1;
+  DropSite d{};
+  if (!drop_site(drop, &d)) return -1;
+  CLEAR();
+  hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E,
+                     dx_dropped, d);
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
                      g_off, b_off);
   DONE();

@@ -13,6 +13,7 @@ the backward kernels regenerate them, nothing is stored; with p = 0 no extra ker
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -20,6 +21,7 @@ import torch
 from .. import _lib as L
 from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into
 
+FUSE_DROP = os.environ.get("OSRL_CDT_FUSE_DROP", "1") == "1"  # residual-branch dropout inside the LayerNorm launches
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
 
 
@@ -194,19 +196,43 @@ class CDTEngine:
         L.check(L.load().osrl_linear(a, ldd, Mrows, N, self._P(key, True), _r16(K) + 16, 0, K, None, r, ldr, y, ldy,
                                      cur_stream()), "osrl_linear(dx)")
 
-    def _ln_fwd(self, x, delta, key, xout, y, stats):
+    def _ln_fwd(self, x, delta, key, xout, y, stats, drop=None):
+        """``drop`` = (site, p): ``delta`` is a residual branch BEFORE its nn.Dropout -- the keep-multiplier is applied
+        by this launch (osrl_layernorm_fwd_drop: same bits as osrl_dropout + the plain call, two HBM passes fewer)."""
+        if drop is not None and drop[1] > 0 and FUSE_DROP:
+            d = self._site(*drop)
+            L.check(L.load().osrl_layernorm_fwd_drop(x.data_ptr(), delta.data_ptr(), ctypes.byref(d),
+                                                     self._v(key + ".weight"), self._v(key + ".bias"),
+                                                     None if xout is None else xout.data_ptr(), y.data_ptr(),
+                                                     stats.data_ptr(), self.M, self.E, cur_stream()),
+                    "osrl_layernorm_fwd_drop")
+            return
+        if drop is not None and drop[1] > 0:
+            self._drop(delta, delta, drop[0], drop[1])
         L.check(L.load().osrl_layernorm_fwd(x.data_ptr(), None if delta is None else delta.data_ptr(),
                                             self._v(key + ".weight"), self._v(key + ".bias"),
                                             None if xout is None else xout.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                             self.M, self.E, cur_stream()), "osrl_layernorm_fwd")
 
-    def _ln_bwd(self, dy, x, stats, key, dres, dx):
+    def _ln_bwd(self, dy, x, stats, key, dres, dx, drop=None, dx_dropped=None):
+        """``drop`` = (site, p), ``dx_dropped``: also write dx * keep-multiplier of that site (the gradient entering the
+        residual branch whose dropout output fed this LayerNorm's input)."""
         g = self.g
+        if drop is not None and drop[1] > 0 and FUSE_DROP:
+            d = self._site(*drop)
+            L.check(L.load().osrl_layernorm_bwd_drop(
+                dy.data_ptr(), x.data_ptr(), stats.data_ptr(), self._v(key + ".weight"),
+                None if dres is None else dres.data_ptr(), dx.data_ptr(), dx_dropped.data_ptr(), ctypes.byref(d),
+                self.ln_ws.data_ptr(), self.n_parts, self.M, self.E, g.slabs.data_ptr(), g.offset(key + ".weight"),
+                g.offset(key + ".bias"), cur_stream()), "osrl_layernorm_bwd_drop")
+            return
         L.check(L.load().osrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), self._v(key + ".weight"),
                                             None if dres is None else dres.data_ptr(), dx.data_ptr(),
                                             self.ln_ws.data_ptr(), self.n_parts, self.M, self.E, g.slabs.data_ptr(),
                                             g.offset(key + ".weight"), g.offset(key + ".bias"), cur_stream()),
                 "osrl_layernorm_bwd")
+        if drop is not None and drop[1] > 0:
+            self._drop(dx, dx_dropped, drop[0], drop[1])
 
     # ---- dropout sites: 0 = embedding; layer l: 1+3l attention probabilities, 2+3l / 3+3l the two residual branches
     def _site(self, site: int, p: float):
@@ -271,19 +297,17 @@ class CDTEngine:
                                            self.R, self.P, ctypes.byref(da) if p_attn > 0 else None, self.o[l].data_ptr(),
                                            cur_stream()), "osrl_attention_fwd")
             self._lin(self.o[l], E, M, p + "attention.out_proj.weight", self.att, E)
-            if p_res > 0:
-                self._drop(self.att, self.att, 2 + 3 * l, p_res)
-            self._ln_fwd(self.xin[l], self.att, p + "norm2", self.xmid[l], self.n2[l], self.st2[l])
+            self._ln_fwd(self.xin[l], self.att, p + "norm2", self.xmid[l], self.n2[l], self.st2[l],
+                         drop=(2 + 3 * l, p_res))
             self._lin(self.n2[l], E, M, p + "mlp.0.weight", self.hpre[l], 4 * E)
             L.check(lib.osrl_gelu_fwd(self.hpre[l].data_ptr(), self.h[l].data_ptr(), M * 4 * E, cur_stream()), "gelu")
             self._lin(self.h[l], 4 * E, M, p + "mlp.2.weight", self.mo, E)
-            if p_res > 0:
-                self._drop(self.mo, self.mo, 3 + 3 * l, p_res)
             if l + 1 < self.NL:
                 self._ln_fwd(self.xmid[l], self.mo, f"cdt.blocks.{l + 1}.norm1", self.xin[l + 1], self.n1[l + 1],
-                             self.st1[l + 1])
+                             self.st1[l + 1], drop=(3 + 3 * l, p_res))
             else:
-                self._ln_fwd(self.xmid[l], self.mo, "cdt.out_norm", self.xin[l + 1], self.out, self.st_out)
+                self._ln_fwd(self.xmid[l], self.mo, "cdt.out_norm", self.xin[l + 1], self.out, self.st_out,
+                             drop=(3 + 3 * l, p_res))
         R, B, T, Eh = self.R, self.B, self.T, self.Eh
         if self.P:  # out[:, 1:] (cdt.py:229-231) as a dense [B*T*R, E] matrix
             self.outc.view(B, R * T, E).copy_(self.out.view(B, self.S, E)[:, 1:])
@@ -366,18 +390,18 @@ class CDTEngine:
         self._lin_dx(self.dsp, m.state_dim, BT, "cdt.state_pred_head.weight", d_af, R * E, resid=d_af, ldr=R * E)
         if self.P:
             self.dout.view(B, self.S, E)[:, 1:].copy_(self.doutc.view(B, R * T, E))
-        self._ln_bwd(self.dout, self.xin[NL], self.st_out, "cdt.out_norm", None, self.dxo[NL])
+        # (each LayerNorm backward also leaves dx * keep-mask of the residual branch that fed its input: the gradient the
+        # branch's last Linear needs -- osrl_layernorm_bwd_drop)
+        self._ln_bwd(self.dout, self.xin[NL], self.st_out, "cdt.out_norm", None, self.dxo[NL],
+                     drop=(3 + 3 * (NL - 1), self.p_res), dx_dropped=self.dmo[NL - 1])
         for l in range(NL - 1, -1, -1):
             p = f"cdt.blocks.{l}."
-            if self.p_res > 0:
-                self._drop(self.dxo[l + 1], self.dmo[l], 3 + 3 * l, self.p_res)
             self._lin_dx(self.dmo[l], E, M, p + "mlp.2.weight", self.dh, 4 * E)
             L.check(lib.osrl_gelu_bwd(self.dh.data_ptr(), self.hpre[l].data_ptr(), self.dhpre[l].data_ptr(),
                                       M * 4 * E, cur_stream()), "gelu_bwd")
             self._lin_dx(self.dhpre[l], 4 * E, M, p + "mlp.0.weight", self.dn, E)
-            self._ln_bwd(self.dn, self.xmid[l], self.st2[l], p + "norm2", self.dxo[l + 1], self.dxm[l])
-            if self.p_res > 0:
-                self._drop(self.dxm[l], self.datt[l], 2 + 3 * l, self.p_res)
+            self._ln_bwd(self.dn, self.xmid[l], self.st2[l], p + "norm2", self.dxo[l + 1], self.dxm[l],
+                         drop=(2 + 3 * l, self.p_res), dx_dropped=self.datt[l])
             self._lin_dx(self.datt[l], E, M, p + "attention.out_proj.weight", self.do, E)
             da = self._site(1 + 3 * l, self.p_attn)
             L.check(lib.osrl_attention_bwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.do.data_ptr(), self.B,
@@ -385,7 +409,11 @@ class CDTEngine:
                                            ctypes.byref(da) if self.p_attn > 0 else None,
                                            self.dqkv[l].data_ptr(), cur_stream()), "attn_bwd")
             self._lin_dx(self.dqkv[l], 3 * E, M, p + "attention.in_proj_weight", self.dn, E)
-            self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l])
+            if l > 0:
+                self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l],
+                             drop=(3 + 3 * (l - 1), self.p_res), dx_dropped=self.dmo[l - 1])
+            else:
+                self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l])
         if self.p_emb > 0:
             self._drop(self.dxo[0], self.dxo[0], 0, self.p_emb)
         self._ln_bwd(self.dxo[0], self.seq, self.st_emb, "cdt.emb_norm", None, self.dseq)

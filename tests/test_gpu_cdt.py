@@ -404,6 +404,29 @@ def test_cdt_c5_full_batch_forward_stats_and_graph():
             assert (res[0][k] - res[1][k]).abs().max() < 1e-6, k
 
 
+@pytest.mark.parametrize("case", ["cdt_drop", "cdt_v_prefix"])
+def test_cdt_dropout_folded_into_layernorm_equals_separate_passes(case, monkeypatch):
+    """osrl_layernorm_fwd_drop / osrl_layernorm_bwd_drop (the residual branches' nn.Dropout applied by the LayerNorm
+    launches) == separate osrl_dropout passes over 3 train steps (parameters and moments; same products and sums)."""
+    import osrl_amd.engine.cdt as ce
+    c = CDT_CASES[case]
+    b = {k: t(v) for k, v in make_cdt_batch(c).items()}
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ce, "FUSE_DROP", fuse)
+        m, tr, lg = build_cdt_gpu(c, use_graph=False, seed=99)
+        for s_ in range(3):
+            tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                              b["episode_cost"], b["costs"])
+        torch.cuda.synchronize()
+        g = m.groups["cdt"]
+        res.append((g.p.clone(), g.m.clone(), g.v.clone()))
+    # (not torch.equal: the timestep-embedding scatter accumulates with fp32 atomics, whose order -- and through the clip
+    # norm every update's last bits -- varies from run to run; the same bound as graph == eager)
+    for x, y, name in zip(res[0], res[1], ("p", "m", "v")):
+        assert (x - y).abs().max() < 1e-6, name
+
+
 def test_cdt_graph_replay_matches_eager():
     c = CDT_CASES["cdt_small"]
     res = []
