@@ -520,11 +520,11 @@ def main():
     # N > 1: BASELINE.json's multi-GPU config is C4 (CPQ at (17, 6), 2048 rows per GPU = global batch 16384 at 8 GPUs);
     # every rank runs it (collectives inside), rank 0 reports it under other_configs
     c4_dp = None
-    if world > 1 and args.config == "c2" and not args.no_extras:
+    if (world > 1 or force_dp) and args.config == "c2" and not args.no_extras:  # (force_dp: the same code on one rank)
         try:
             w4 = Workload("c4", device, rank, world, dp, n_store=1 << 18, use_graph=not args.eager)
             dt4 = timed_steps(w4.step, 200, 20, barrier)
-            import torch.distributed as dist
+            import torch.distributed as dist  # noqa: F811
             t4 = torch.tensor([dt4], dtype=torch.float64, device=device)
             dist.all_reduce(t4, op=dist.ReduceOp.MAX)
             dt4 = float(t4.item())
