@@ -168,6 +168,66 @@ int osrl_mlp_forward2_tail(const osrl_mlp_t* net0, const osrl_rows_t* in0, const
                            const osrl_mlp_acts_t* out1, const osrl_mlp_tail_t* tail1, void* stream);
 int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                               const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream);
+/* ---- one supervised regression step of one MLP in ONE launch (mlp.hip mlp_step_kernel) -------------------------
+ * BCTrainer.train_one_step (osrl/algorithms/bc.py:45-55,103-109 with the minibatch of examples/train/train_bc.py:105-121):
+ *   [sample + gather the minibatch] -> forward -> F.mse_loss -> backward -> dW / db -> Adam (+ refresh of the packed
+ *   weight copies) -> step tick (+ the previous step's statistics into the ring)
+ * i.e. exactly osrl_step_begin + osrl_mlp_forward + osrl_mse_loss + osrl_mlp_backward_dz + osrl_mlp_backward_dw_tiles +
+ * osrl_adam_step_packed on the same arguments, with the same parameter bits (same MFMA chains, same summation orders,
+ * same element-wise update); the loss statistic is summed per 16-row tile and then in tile order (deterministic, not
+ * the single-workgroup order of osrl_mse_loss).  At B = 256 those six launches are ~53 us of mostly launch gaps; here
+ * the row tiles (16 rows, 8 waves) run gather / forward / loss / backward back to back out of LDS, signal an
+ * arrival counter, and the dW tile workgroups -- which cover ALL rows, so there are no gradient slabs -- apply Adam to
+ * their tile from LDS.  One grid-wide dependency instead of five launch boundaries.
+ * Requirements (else OSRL_E_UNSUPPORTED and nothing is launched; callers keep the six-launch plan): one net; widest
+ * layer 129..448 (the 8-wave 16-row tile of the fused MLP kernels); rows <= 16 * OSRL_STEP_MAX_WG; a dW work list in
+ * osrl_mlp_backward_dw_tiles' format with ONE row split per tile and <= OSRL_STEP_MAX_WG items; weight decay 0; no
+ * target copy.  ws: OSRL_STEP_WS floats of device scratch, zero before the first call, owned by this step (the kernel
+ * re-arms its counters; ws[OSRL_STEP_MAX_WG + 2] != 0 afterwards = a workgroup gave up waiting, results invalid).
+ * All workgroups of the launch must be resident at once (<= OSRL_STEP_MAX_WG of 256 CUs: they are). HOST struct. */
+#define OSRL_STEP_MAX_WG 128
+#define OSRL_STEP_WS (OSRL_STEP_MAX_WG + 8)
+#define OSRL_E_UNSUPPORTED (-2)
+typedef struct {
+  /* osrl_step_begin's state arguments */
+  osrl_step_state_t* st;
+  float beta1, beta2;
+  int32_t warmup, n_stats, ring_len;
+  /* osrl_replay_gather's arguments; n_fields = 0: the minibatch is already in `in` / `target` */
+  int32_t n_fields;
+  const float* stats_cur;
+  float* ring;
+  const float* src[8];
+  float* dst[8];
+  int32_t width[8];
+  float scale[8];
+  int64_t n_rows;
+  uint64_t gather_seed;
+  uint32_t gather_stream, pad0_;
+  /* osrl_mlp_forward / osrl_mlp_backward_dz's arguments (grads.dy[0] = the loss gradient buffer, written here) */
+  osrl_mlp_t net;
+  osrl_rows_t in;
+  osrl_mlp_acts_t acts;
+  osrl_mlp_grads_t grads;
+  /* osrl_mse_loss's arguments */
+  const float* target; /* [rows, dims[L]] */
+  int64_t n_global;    /* elements the mean runs over (<= 0: rows * dims[L]) */
+  float* stat;         /* optional */
+  /* osrl_mlp_backward_dw_tiles's arguments; tile_blocks = 4 (64 x 64 tiles) or 2 (32 x 32: four times the
+   * workgroups on a quarter of the MFMA work each -- what a 256-row batch wants; same bits, the sum order of an
+   * output element depends on its rows-per-wave only) */
+  const osrl_dw_entry_t* entries;
+  const int32_t* work;
+  int32_t n_work, tile_blocks;
+  /* osrl_adam_step_packed's arguments (n_splits = 1, no target, weight decay 0) */
+  float *p, *m, *v;
+  const int32_t *map_f, *map_b;
+  float *pf, *pb;
+  float lr, eps;
+  float* ws;
+} osrl_mlp_step_t;
+int osrl_mlp_regress_step(const osrl_mlp_step_t* s, void* stream);
+
 /* General linear layer on packed weights: Y[M,N] = A[M,K] * P (+ bias[N]) (+ resid[M,N]).  P is the forward
  * pack of W[N,K] (y = x W^T; Np = round16(N), col0 = 0) or the backward pack of W[N',K'] for dx = dy W
  * (then K = N', N = K' or a column slice starting at col0, Np = round16(K')+16).  K <= 1024; N is

@@ -63,6 +63,24 @@ class DwEntryT(C.Structure):
                 ("out", C.c_int32), ("in_", C.c_int32), ("ldz", C.c_int32), ("lda", C.c_int32)]
 
 
+STEP_MAX_WG = 128
+STEP_WS = STEP_MAX_WG + 8  # floats of scratch of osrl_mlp_regress_step (include/osrl_amd.h OSRL_STEP_WS)
+E_UNSUPPORTED = -2
+
+
+class MlpStepT(C.Structure):  # osrl_mlp_step_t
+    _fields_ = [("st", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("warmup", C.c_int32),
+                ("n_stats", C.c_int32), ("ring_len", C.c_int32), ("n_fields", C.c_int32),
+                ("stats_cur", _fp), ("ring", _fp), ("src", _fp * 8), ("dst", _fp * 8), ("width", C.c_int32 * 8),
+                ("scale", C.c_float * 8), ("n_rows", C.c_int64), ("gather_seed", C.c_uint64),
+                ("gather_stream", C.c_uint32), ("pad0_", C.c_uint32),
+                ("net", MlpT), ("in_", RowsT), ("acts", ActsT), ("grads", GradsT),
+                ("target", _fp), ("n_global", C.c_int64), ("stat", _fp),
+                ("entries", C.c_void_p), ("work", C.c_void_p), ("n_work", C.c_int32), ("tile_blocks", C.c_int32),
+                ("p", _fp), ("m", _fp), ("v", _fp), ("map_f", C.c_void_p), ("map_b", C.c_void_p), ("pf", _fp),
+                ("pb", _fp), ("lr", C.c_float), ("eps", C.c_float), ("ws", _fp)]
+
+
 class PackEntryT(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("f_off", C.c_int64), ("b_off", C.c_int64),
                 ("out", C.c_int32), ("in_", C.c_int32)]
@@ -197,6 +215,7 @@ PROTOTYPES = {
     "osrl_clip_grad_scale": [_fp, _i64, _f32, _fp, _i32, _fp, _vp],
     "osrl_cdt_temperature_step": [_fp, _fp, _fp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     "osrl_kernarg_probe": [_vp, _P(_i32), _P(_u64), _vp],
+    "osrl_mlp_regress_step": [_P(MlpStepT), _vp],
     "osrl_args_begin": [_vp, _vp, _i64, _i64, _i32],
     "osrl_args_end": [_P(_i64), _P(_i32), _P(_i32), _P(_i32)],
 }

@@ -24,13 +24,19 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (needed to build libosrl_amd.so for gfx950)")
 
 
+HEADERS = ["philox.h", "step.h", "argmem.h", "adam.h", "gather.h"]  # csrc headers shared between translation units
+
+
+def _common_deps():
+    """What every object depends on: the public header, the shared csrc headers, this file (the compiler flags)."""
+    return [os.path.join(PKG, "..", "include", "osrl_amd.h")] + [os.path.join(CSRC, h) for h in HEADERS] + [__file__]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, "..", "include", "osrl_amd.h"),
-                                                       os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), os.path.join(CSRC, "argmem.h"),
-                                                       __file__]  # the compiler flags live here
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _common_deps()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -69,7 +75,7 @@ def _build_locked(verbose: bool, force: bool = False) -> str:
     header is newer), then one link."""
     os.makedirs(OBJDIR, exist_ok=True)
     hip = _hipcc()
-    common = [os.path.join(PKG, "..", "include", "osrl_amd.h"), os.path.join(CSRC, "philox.h"), os.path.join(CSRC, "step.h"), os.path.join(CSRC, "argmem.h"), __file__]
+    common = _common_deps()
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))

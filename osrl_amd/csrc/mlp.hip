@@ -33,11 +33,15 @@
 //     in a fixed order (deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include "../../include/osrl_amd.h"
 #include "argmem.h"
+#include "adam.h"
+#include "gather.h"
+#include "step.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -133,7 +137,50 @@ __device__ __forceinline__ f32x4 load_bp_s(const float* __restrict__ Pk /*unifor
 //   mm_run       runs the k-loop assuming exactly that.
 // Measured (tools/mlp_phase.hip, all workgroups): without this a wave spent 22k cycles in the 5-k-step first
 // layer (5k cycles of MFMA work) and 13k cycles staging its input with nothing else in flight.
-constexpr int kRing = 3;  // ring slots (STAGES <= kRing)
+constexpr int kRing = 3;  // ring slots (STAGES <= ring depth) of the many-workgroups-per-CU kernels
+// Ring depth of the 8-wave kernels (NW = 8: launches of at most ~2 workgroups per CU -- the 2048-row training launches,
+// BC's 256 rows), an EXPERIMENT knob: nothing else on the CU hides a weight load's latency there, so a deeper ring
+// (OSRL_RING_DEEP = 4 / 6: 3 / 5 k-steps of weights in flight) looked like the remedy for their 13k-cycle 16-k-step
+// layers (8k of MFMA time).  Measured (tools/mlp_phase.hip variants, profiles/r3_phase_ring_warm.txt): depth 4 changes
+// a layer by -4 % .. +2 %, depth 6 is 20-30 % SLOWER (registers: the ring is live across staging and epilogues), and
+// it makes no difference whether the weights were just re-written from another XCD (COLD=1) or are L2-hot -- these
+// layers are chains of ~700-cycle round trips (weights, LDS, barriers) of which the weight ring is only one.  Default 3.
+#ifndef OSRL_RING_DEEP
+#define OSRL_RING_DEEP 3
+#endif
+constexpr int kRingDeep = OSRL_RING_DEEP;
+template <int NW>
+constexpr int ring_depth() { return NW == 8 ? kRingDeep : kRing; }
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// L2 warm-up for the 8-wave kernels, the second EXPERIMENT of the same measurement (OSRL_L2_WARM=1): each thread
+// touches kWarmLines 128-byte lines of the next layers' weights while the current layer computes.  It costs 10-25 %
+// (the first layer's k-loop waits behind the touches: loads return in order) and buys nothing -- see above, the
+// layers are not bound by where the weights come from.  Off; kept for the A/B build of tools/build_phase_variants.sh.
+constexpr int kWarmLines = 4;  // x 512 threads x 128 B = 256 KB per layer (a 256 x 256 layer)
+#ifndef OSRL_L2_WARM
+#define OSRL_L2_WARM 0
+#endif
+template <int NT>
+__device__ __forceinline__ void l2_warm(const float* __restrict__ P, int n_floats, float (&d)[kWarmLines]) {
+  const int n_lines = n_floats >> 5;
+#pragma unroll
+  for (int j = 0; j < kWarmLines; ++j) {
+    int i = (int)threadIdx.x + j * NT;
+    i = i < n_lines ? i : n_lines - 1;  // (past the end: touch the last line again -- no branch around a load)
+    d[j] = P[(size_t)i * 32];
+  }
+}
+__device__ __forceinline__ void l2_warm_done(float (&d)[kWarmLines]) {
+#pragma unroll
+  for (int j = 0; j < kWarmLines; ++j) asm volatile("" ::"v"(d[j]));
+}
 #ifndef OSRL_PIN_ROWS
 #define OSRL_PIN_ROWS 5
 #endif
@@ -168,10 +215,10 @@ __device__ __forceinline__ f32x4 EXP_MFMA(float a, float b, f32x4 c) {
 #define EXP_AREAD(p) (*reinterpret_cast<const f32x4*>(p))
 #endif
 
-template <int RW, int CNT, int STAGES>
-__device__ __forceinline__ void mm_prefetch(f32x4 (&b)[kRing][RW], int nk, const float* __restrict__ P, int Np, int col0,
+template <int RW, int CNT, int STAGES, int RD>
+__device__ __forceinline__ void mm_prefetch(f32x4 (&b)[RD][RW], int nk, const float* __restrict__ P, int Np, int col0,
                                             int kc0 = 0) {
-  static_assert(CNT <= RW && STAGES <= kRing, "ring too small");
+  static_assert(CNT <= RW && STAGES <= RD, "ring too small");
   const int lane = threadIdx.x & 63;
   const unsigned lane_off = (unsigned)(((lane >> 4) * Np + col0 + (lane & 15)) * 16);  // bytes
   const int rot = k_rot(nk);
@@ -186,10 +233,10 @@ __device__ __forceinline__ void mm_prefetch(f32x4 (&b)[kRing][RW], int nk, const
 
 // Only the first CNT (<= AW) column blocks of acc are touched, so a wave with fewer blocks runs a dense loop
 // on the same accumulator array.
-template <int NRB, int AW, int RW, int CNT, int STAGES>
+template <int NRB, int AW, int RW, int CNT, int STAGES, int RD>
 __device__ __forceinline__ void mm_run(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
-                                       f32x4 (&acc)[NRB][AW], f32x4 (&b)[kRing][RW], int kc0 = 0) {
-  static_assert(CNT <= AW && CNT <= RW && STAGES <= kRing, "tile shapes");
+                                       f32x4 (&acc)[NRB][AW], f32x4 (&b)[RD][RW], int kc0 = 0) {
+  static_assert(CNT <= AW && CNT <= RW && STAGES <= RD, "tile shapes");
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
@@ -231,9 +278,19 @@ __device__ __forceinline__ void mm_run(const float* lds, int lda, int nk, const 
   // Main loop: groups of U = 2*STAGES steps with NO per-step control flow (every taken branch costs the wave an
   // instruction-buffer refill: with a conditional per unrolled step a lone wave reached 74% MFMA issue in a
   // load-free loop, tools/mlp_phase.hip); the < U leftover steps run in a branchy tail.
-  constexpr int U = 2 * STAGES;
   using std::integral_constant;
   int kc = 0;
+  if constexpr (STAGES > 3) {
+    // deep ring: groups of STAGES steps (even: the A double buffer alternates with the step index), then the
+    // < STAGES leftover steps with one uniform branch each
+    static_assert(STAGES % 2 == 0, "the A double buffer needs an even group");
+    for (; kc + STAGES <= nk; kc += STAGES) static_for<STAGES>([&](auto s_c) { step(s_c, kc + decltype(s_c)::value); });
+    static_for<STAGES - 1>([&](auto s_c) {
+      if (kc + decltype(s_c)::value < nk) step(s_c, kc + decltype(s_c)::value);
+    });
+    return;
+  }
+  constexpr int U = 2 * STAGES;
   for (; kc + U <= nk; kc += U) {
     step(integral_constant<int, 0>{}, kc);
     step(integral_constant<int, 1>{}, kc + 1);
@@ -261,14 +318,16 @@ __device__ __forceinline__ void mm_run(const float* lds, int lda, int nk, const 
   }
 }
 
-template <int NRB, int NCB>
-constexpr int mm_stages() { return (NRB * NCB >= 16 || NCB >= 7) ? 2 : 3; }  // short k-steps need a deeper load ring
+template <int NRB, int NCB, int RD = kRing>
+constexpr int mm_stages() {  // short k-steps need a deeper load ring
+  return RD > 3 ? RD : (NRB * NCB >= 16 || NCB >= 7) ? 2 : 3;
+}
 
 // cnt (<= NCB) column blocks starting at column col0 (= first block * 16 [+ dx_col0]); 0 = idle wave
-template <int NRB, int NCB>
-__device__ __forceinline__ void layer_prefetch(f32x4 (&ring)[kRing][NCB], int nk, const float* __restrict__ P, int Np,
+template <int NRB, int NCB, int RD>
+__device__ __forceinline__ void layer_prefetch(f32x4 (&ring)[RD][NCB], int nk, const float* __restrict__ P, int Np,
                                                int col0, int cnt) {
-  constexpr int ST = mm_stages<NRB, NCB>();
+  constexpr int ST = mm_stages<NRB, NCB, RD>();
   if (cnt == NCB) {
     mm_prefetch<NCB, NCB, ST>(ring, nk, P, Np, col0);
   } else if (NCB > 2 && cnt == NCB - 1) {
@@ -279,10 +338,10 @@ __device__ __forceinline__ void layer_prefetch(f32x4 (&ring)[kRing][NCB], int nk
 }
 
 // requires layer_prefetch(ring, same arguments) to have been issued by this wave
-template <int NRB, int NCB>
+template <int NRB, int NCB, int RD>
 __device__ __forceinline__ void layer_run(const float* lds, int lda, int nk, const float* __restrict__ P, int Np,
-                                          int col0, int cnt, f32x4 (&acc)[NRB][NCB], f32x4 (&ring)[kRing][NCB]) {
-  constexpr int ST = mm_stages<NRB, NCB>();
+                                          int col0, int cnt, f32x4 (&acc)[NRB][NCB], f32x4 (&ring)[RD][NCB]) {
+  constexpr int ST = mm_stages<NRB, NCB, RD>();
   if (cnt == NCB) {
     mm_run<NRB, NCB, NCB, NCB, ST>(lds, lda, nk, P, Np, col0, acc, ring);
   } else if (NCB > 2 && cnt == NCB - 1) {
@@ -324,16 +383,16 @@ __device__ __forceinline__ NarrowPart narrow_part(int nk, int col_off, int nblk,
   const int k_lo = (nk * part) / parts, k_hi = (nk * (part + 1)) / parts;
   return NarrowPart{col_off + blk * 16, k_lo, k_hi - k_lo};
 }
-template <int NCB, int NW = 4>
-__device__ __forceinline__ void narrow_prefetch(f32x4 (&ring)[kRing][NCB], int nk, const float* __restrict__ P, int Np,
+template <int NCB, int NW = 4, int RD = kRing>
+__device__ __forceinline__ void narrow_prefetch(f32x4 (&ring)[RD][NCB], int nk, const float* __restrict__ P, int Np,
                                                 int col_off, int nblk, int wave) {
   const NarrowPart np = narrow_part<NW>(nk, col_off, nblk, wave);
   if (np.k_n > 0) mm_prefetch<NCB, 1, 3>(ring, np.k_n, P, Np, np.col, np.k_lo);
 }
 // requires narrow_prefetch(ring, same arguments)
-template <int NRB, int NCB, int NW = 4>
+template <int NRB, int NCB, int NW = 4, int RD = kRing>
 __device__ __forceinline__ void narrow_layer_splitk(float* lds, int lda, int nk, const float* __restrict__ P, int Np,
-                                                    int col_off, int nblk, int wave, f32x4 (&ring)[kRing][NCB]) {
+                                                    int col_off, int nblk, int wave, f32x4 (&ring)[RD][NCB]) {
   const int lane = threadIdx.x & 63;
   const int parts = NW / nblk;
   const NarrowPart np = narrow_part<NW>(nk, col_off, nblk, wave);
@@ -570,7 +629,7 @@ __device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) 
   WG_LOG(0);
   PHASE_STAMP(0);
   // first weight loads of layer l (issued before the previous layer's epilogue / before the input is staged)
-  f32x4 ring[kRing][NCB];
+  f32x4 ring[ring_depth<NW>()][NCB];
   auto begin_layer = [&](int l) {
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
     const int nblk = (N + 15) >> 4, nk = round16(K) >> 4;
@@ -619,6 +678,12 @@ __device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) 
     if (e == 0 && a.out.x) tile_to_global<64 * NW>(lds, lda, BM, K0, a.out.x, row0, rows);
   }
   PHASE_STAMP(1);
+  constexpr bool kWarm = OSRL_L2_WARM && NW == 8;
+  float warm[OSRL_MAX_LAYERS - 1][kWarmLines];
+  if (kWarm) {
+    for (int l = 1; l < L; ++l)
+      l2_warm<64 * NW>(a.net.Wf[e][l], round16(a.net.dims[l]) * round16(a.net.dims[l + 1]), warm[l - 1]);
+  }
 
   for (int l = 0; l < L; ++l) {
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
@@ -675,6 +740,9 @@ __device__ __forceinline__ void mlp_fwd_body(AR a, const int e, const int tile) 
     float* save = a.out.h[e][l];
     if (save) tile_to_global<64 * NW>(lds, lda, BM, N, save, row0, rows);
     PHASE_STAMP(5 + 4 * l);
+    if (kWarm && l == 0) {
+      for (int w = 1; w < L; ++w) l2_warm_done(warm[w - 1]);
+    }
   }
   // the net's output tile [BM][dims[L]] is still in LDS (nothing wrote it since the last barrier)
   if (a.tail.kind == OSRL_TAIL_VAE_LATENT && e == 0) tail_vae_latent<decltype((a.tail)), 64 * NW>(lds, lda, BM, row0, rows, a.tail);
@@ -1199,13 +1267,12 @@ struct BwdArgs {
 };
 
 template <int NRB, int NCB, int NW, class AR>
-__device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
+__device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int tile) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * NRB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int e = blockIdx.y;
-  const int row0 = blockIdx.x * BM;
+  const int row0 = tile * BM;
   const int rows = a.rows, lda = a.lda;
   const int L = a.net.n_layers;
 #if OSRL_CHAIN_PRIO > 0
@@ -1213,7 +1280,7 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
 #endif
 
   // steps: l = L-1 .. 1 (dH_{l-1} = dZ_l W_l), then step 0 = the dX slice; begin_step issues a step's first weight loads
-  f32x4 ring[kRing][NCB];
+  f32x4 ring[ring_depth<NW>()][NCB];
   auto begin_step = [&](int l) {
     if (l >= 1) {
       const int K = a.net.dims[l + 1], N = a.net.dims[l];
@@ -1256,6 +1323,12 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
     }
     __syncthreads();
     if (a.g.dz[e][L - 1]) tile_to_global<64 * NW>(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);
+  }
+  constexpr bool kWarm = OSRL_L2_WARM && NW == 8;
+  float warm[OSRL_MAX_LAYERS - 1][kWarmLines];
+  if (kWarm) {  // the later steps' W^T packs (step L-1's first loads are already in flight)
+    for (int l = L - 2; l >= (a.g.dx[e] ? 0 : 1); --l)
+      l2_warm<64 * NW>(a.net.Wb[e][l], round16(a.net.dims[l + 1]) * (round16(a.net.dims[l]) + 16), warm[l]);
   }
 
   for (int l = L - 1; l >= 1; --l) {
@@ -1324,6 +1397,9 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
       epilogue(std::integral_constant<int, OSRL_ACT_ID>{});
     __syncthreads();
     if (a.g.dz[e][l - 1]) tile_to_global<64 * NW>(lds, lda, BM, N, a.g.dz[e][l - 1], row0, rows);
+    if (kWarm && l == L - 1) {
+      for (int w = L - 2; w >= (a.g.dx[e] ? 0 : 1); --w) l2_warm_done(warm[w]);
+    }
   }
 
   if (a.g.dx[e]) {
@@ -1363,11 +1439,11 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a) {
 }
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel(const BwdArgs a) {
-  mlp_bwd_dz_body<NRB, NCB, NW, const BwdArgs&>(a);
+  mlp_bwd_dz_body<NRB, NCB, NW, const BwdArgs&>(a, blockIdx.y, blockIdx.x);
 }
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel_p(const void* p) {
-  mlp_bwd_dz_body<NRB, NCB, NW, const OSRL_CAS BwdArgs&>(*(const OSRL_CAS BwdArgs*)p);
+  mlp_bwd_dz_body<NRB, NCB, NW, const OSRL_CAS BwdArgs&>(*(const OSRL_CAS BwdArgs*)p, blockIdx.y, blockIdx.x);
 }
 
 // ---- dW = dZ^T A, db = colsum(dZ) ---------------------------------------------------------------
@@ -1592,18 +1668,20 @@ __device__ __forceinline__ void dwt_mma(f32x4 (&acc)[T][T], float (&dbacc)[T], c
 template <int T>
 constexpr size_t dwt_lds() { return sizeof(float) * (4 * (16 * T) * (16 * T + 1) + 4 * 16 * T); }
 
-template <int T>
-__global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* __restrict__ entries,
-                                                         const int32_t* __restrict__ items, int rows,
-                                                         float* __restrict__ slabs, int64_t slab_stride) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][16T][16T+1] partials + [4][16T] bias partials
+// One work item: the four waves' partials of a tile go to LDS (red: [4][16T][16T+1] + [4][16T] bias partials), then
+// epi(E, o0, i0, split, want_db) consumes them after a barrier: the slab store of mlp_dwt_kernel, or the optimizer
+// step itself when the item covers all rows (mlp_step_kernel).  Waves beyond the first four (a wider workgroup) only
+// take part in the barrier and the epilogue.
+// WARM (experiment, off: every lane first touches the 128-byte lines of its wave's row range -- measured 7.5 -> 9.7 us
+// for the one-launch step's dW phase, tools/step_stamps.py).
+// DEEP (the one-launch step at <= 64 rows per wave): the four k-steps' fragments are all requested before the first
+// MFMA -- one round trip to operands that other XCDs wrote moments ago instead of three (same MFMA order, same bits).
+template <int T, bool WARM = false, bool DEEP = false, class EPI>
+__device__ __forceinline__ void dwt_tile(const osrl_dw_entry_t* __restrict__ entries, const int32_t* __restrict__ items,
+                                         const int item, const int rows, float* __restrict__ red, EPI epi) {
   constexpr int TW = 16 * T, LD = TW + 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if OSRL_CHAIN_PRIO > 0
-  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
-  const int item = blockIdx.x;
   const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2], sp = items[item * 4 + 3];
   const int s = sp & 0xffff, nsp = sp >> 16;
   // read through the constant address space: pointers loaded from there are known-global (global_load with a scalar
@@ -1626,6 +1704,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
   nib = nib > T ? T : nib;
   const bool want_db = it == 0;
 
+  if (wave < 4) {
   f32x4 acc[T][T];
   zero_acc<T, T>(acc);
   float dbacc[T];
@@ -1644,11 +1723,40 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
     const int n_full = (r_end - r_begin) >> 4;  // whole 16-row k-steps
     const float* __restrict__ pz = dz + (size_t)(r_begin + 4 * kq) * ldz;
     const float* __restrict__ pa = av + (size_t)(r_begin + 4 * kq) * lda_g;
+    float wt[WARM ? 4 * ((TW + 31) / 32) : 1];
+    if constexpr (WARM) {
+      constexpr int NL = (TW + 31) / 32;  // lines per row of a panel
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        int r = r_begin + pass * 64 + lane;
+        r = r < r_end ? r : r_end - 1;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          const int oc = o0 + 32 * j < out ? o0 + 32 * j : out - 1, ic = i0 + 32 * j < in ? i0 + 32 * j : in - 1;
+          wt[(pass * 2 + 0) * NL + j] = dz[(size_t)r * ldz + oc];
+          wt[(pass * 2 + 1) * NL + j] = av[(size_t)r * lda_g + ic];
+        }
+      }
+    }
     DwFragT<T> f0, f1;
     // no control flow inside the pair loop (the reload past the end re-reads the last step): the compiler can then
     // count the loads in flight (s_waitcnt vmcnt(n > 0)) and step k's MFMAs run under step k + 1's loads
     auto run = [&](auto full_c) {
       constexpr int FULL = decltype(full_c)::value;
+      if constexpr (DEEP) {
+        if (n_full == 4 && r_begin + 64 == r_end) {
+          DwFragT<T> f2, f3;
+          dwt_load<T>(f0, pz, pa, ldz, lda_g, oa, ia, nob, nib);
+          dwt_load<T>(f1, pz + (size_t)16 * ldz, pa + (size_t)16 * lda_g, ldz, lda_g, oa, ia, nob, nib);
+          dwt_load<T>(f2, pz + (size_t)32 * ldz, pa + (size_t)32 * lda_g, ldz, lda_g, oa, ia, nob, nib);
+          dwt_load<T>(f3, pz + (size_t)48 * ldz, pa + (size_t)48 * lda_g, ldz, lda_g, oa, ia, nob, nib);
+          dwt_mma<T, FULL>(acc, dbacc, f0, nob, nib, want_db);
+          dwt_mma<T, FULL>(acc, dbacc, f1, nob, nib, want_db);
+          dwt_mma<T, FULL>(acc, dbacc, f2, nob, nib, want_db);
+          dwt_mma<T, FULL>(acc, dbacc, f3, nob, nib, want_db);
+          return;
+        }
+      }
       if (n_full > 0) dwt_load<T>(f0, pz, pa, ldz, lda_g, oa, ia, nob, nib);
       int k = 0;
       for (; k + 1 < n_full; k += 2) {
@@ -1670,6 +1778,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
       run(std::integral_constant<int, 2>{});
     else
       run(std::integral_constant<int, 0>{});
+    if constexpr (WARM) {
+#pragma unroll
+      for (int j = 0; j < 4 * ((TW + 31) / 32); ++j) asm volatile("" ::"v"(wt[j]));
+    }
   }
   // ---- 4 partials -> LDS -> fixed-order sum -> one coalesced slab tile
   float* mine = red + wave * TW * LD;
@@ -1688,21 +1800,40 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
       if (kq == 0) red[4 * TW * LD + wave * TW + ob * 16 + m] = v;
     }
   }
+  }  // wave < 4
   __syncthreads();
-  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
-  for (int idx = tid; idx < TW * TW; idx += 256) {
-    const int ol = idx / TW, il = idx - ol * TW;
-    const int off = ol * LD + il;
-    const float v = ((red[off] + red[TW * LD + off]) + red[2 * TW * LD + off]) + red[3 * TW * LD + off];
-    const int o = o0 + ol, i = i0 + il;
-    if (o < out && i < in) slab[E.w_off + (size_t)o * in + i] = v;
-  }
-  if (want_db && tid < TW) {
-    const float* db = red + 4 * TW * LD;
-    const float v = ((db[tid] + db[TW + tid]) + db[2 * TW + tid]) + db[3 * TW + tid];
-    if (o0 + tid < out) slab[E.b_off + o0 + tid] = v;
-  }
+  epi(E, o0, i0, s, want_db);
 }
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* __restrict__ entries,
+                                                         const int32_t* __restrict__ items, int rows,
+                                                         float* __restrict__ slabs, int64_t slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][16T][16T+1] partials + [4][16T] bias partials
+  constexpr int TW = 16 * T, LD = TW + 1;
+  const int tid = threadIdx.x;
+#if OSRL_CHAIN_PRIO > 0
+  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
+  dwt_tile<T>(entries, items, blockIdx.x, rows, red,
+              [&](const OSRL_CAS osrl_dw_entry_t& E, const int o0, const int i0, const int s, const bool want_db) {
+    const int out = E.out, in = E.in;
+    float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+    for (int idx = tid; idx < TW * TW; idx += 256) {
+      const int ol = idx / TW, il = idx - ol * TW;
+      const int off = ol * LD + il;
+      const float v = ((red[off] + red[TW * LD + off]) + red[2 * TW * LD + off]) + red[3 * TW * LD + off];
+      const int o = o0 + ol, i = i0 + il;
+      if (o < out && i < in) slab[E.w_off + (size_t)o * in + i] = v;
+    }
+    if (want_db && tid < TW) {
+      const float* db = red + 4 * TW * LD;
+      const float v = ((db[tid] + db[TW + tid]) + db[2 * TW + tid]) + db[3 * TW + tid];
+      if (o0 + tid < out) slab[E.b_off + o0 + tid] = v;
+    }
+  });
+}
+
 
 
 
@@ -2262,6 +2393,272 @@ static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osr
   return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
 }
 
+
+// ---- one supervised regression step of one MLP in ONE launch (osrl_mlp_regress_step) ---------------------------
+// BC at B = 256 (bc.py:45-55,103-109) is six dependent launches of 2-8 us of work each: the step is its launch gaps.
+// Here workgroup w < n_tiles owns rows [16 w, 16 w + 16): it draws and gathers them (the replay sampler's indices are a
+// pure function of (seed, step, row): gather.h), runs the forward, the MSE gradient and the backward chain through the
+// same bodies as the separate launches (mlp_fwd_body / mlp_bwd_dz_body, 8 waves), and signs in at an arrival counter.
+// Workgroup w < n_work owns item w of the 64 x 64 dW work list; every item covers ALL rows (one row split), so once
+// the counter shows every row tile, the tile's gradient is complete in LDS (dwt_tile) and the workgroup applies Adam
+// to it right there -- no gradient slab, no optimizer launch.  The last workgroup to finish ticks the step state and
+// re-arms the counters.  One grid-wide dependency (the counter) instead of five launch boundaries.
+// All <= OSRL_STEP_MAX_WG workgroups are resident at once (one per CU, 256 CUs), so the wait cannot starve; it is
+// bounded anyway (kStepSpinMax polls, then the error word is set and the workgroup leaves).
+constexpr int kStepThreads = 512;
+#ifndef OSRL_STEP_FENCE_ALL
+#define OSRL_STEP_FENCE_ALL 0  // 1: every wave executes the release fence (3.4 us vs 1.8 us, tools/step_stamps.py)
+#endif
+#ifdef OSRL_STEP_STAMPS  // tools/step_stamps.py: 100 MHz wall-clock stamps of thread 0 of every workgroup (debug builds only)
+__device__ long long g_step_stamp[OSRL_STEP_MAX_WG][16];
+#define STEP_STAMP(i) \
+  if (threadIdx.x == 0) g_step_stamp[blockIdx.x][i] = wall_clock64();
+#else
+#define STEP_STAMP(i)
+#endif
+constexpr int kStepSpinMax = 1 << 22;  // x ~130 ns per poll: ~0.5 s
+struct StepArgs {
+  FwdArgs fwd;
+  BwdArgs bwd;
+  osrl_gather::GatherArgs gather;
+  osrl_step_state_t* st;
+  const float* stats_cur;
+  float* ring;
+  const float* target;
+  float* du;
+  float* stat;
+  const osrl_dw_entry_t* entries;
+  const int32_t* work;
+  float *p, *m, *v;
+  const int32_t *map_f, *map_b;
+  float *pf, *pb;
+  float* ws;  // [OSRL_STEP_MAX_WG] loss partials | [0] tiles arrived  [1] workgroups done  [2] error
+  float beta1, beta2, lr, eps, inv_n;
+  int32_t warmup, n_stats, ring_len, n_tiles, n_work, n_wg, rows, tile_blocks;
+};
+
+template <int NCB, class AR>
+__device__ __forceinline__ void mlp_step_body(AR a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int64_t s_t;
+  __shared__ int s_flag;
+  __shared__ float s_red[kStepThreads / 64];
+  __shared__ float s_part[OSRL_STEP_MAX_WG];
+  __shared__ float s_tick[3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  unsigned* __restrict__ ctr = reinterpret_cast<unsigned*>(a.ws + OSRL_STEP_MAX_WG);
+  STEP_STAMP(0);
+  if (tid == 0) s_t = __atomic_load_n(&a.st->step, __ATOMIC_RELAXED);
+  __syncthreads();
+  STEP_STAMP(1);
+  const int64_t t_old = s_t;
+  const uint32_t step = (uint32_t)(t_old + 1);
+  // the previous step's statistics go to the ring before anything of this step can overwrite them (the loss is stored
+  // by the last row tile to arrive, and workgroup 0 is a row tile: it arrives after this)
+  if (wg == 0) osrl_step::commit_stats<kStepThreads>(t_old, a.stats_cur, a.ring, a.n_stats, a.ring_len);
+
+  if (wg < a.n_tiles) {
+    const int rows = a.rows, row0 = wg * 16;
+    if (a.gather.n_fields > 0) {  // half a wave per row: this tile's 16 rows in one pass
+      osrl_gather::gather_tile16<decltype((a.gather))>(a.gather, step, wg);
+      __syncthreads();  // (workgroup scope: the rows were written through this CU's L1)
+    }
+    STEP_STAMP(2);
+    mlp_fwd_body<1, NCB, 8, decltype((a.fwd))>(a.fwd, 0, wg);
+    __syncthreads();
+    STEP_STAMP(3);
+    {  // F.mse_loss (bc.py:46-47) on this tile: du = 2 (u - target) / n, partial sum of squares
+      const int L = a.fwd.net.n_layers, ad = a.fwd.net.dims[L];
+      const float* __restrict__ u = a.fwd.out.h[0][L - 1];
+      const float* __restrict__ tg = a.target;
+      float* __restrict__ du = a.du;
+      const float inv_n = a.inv_n;
+      float loss = 0.f;
+      int n_here = (rows - row0) * ad;
+      n_here = n_here > 16 * ad ? 16 * ad : n_here;
+      for (int idx = tid; idx < n_here; idx += kStepThreads) {
+        const size_t i = (size_t)row0 * ad + idx;
+        const float d = u[i] - tg[i];
+        loss += d * d;
+        du[i] = 2.0f * d * inv_n;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) loss += __shfl_xor(loss, o);
+      if (lane == 0) s_red[wave] = loss;
+      __syncthreads();
+      if (tid == 0)
+        a.ws[wg] = (((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
+    }
+    STEP_STAMP(4);
+    mlp_bwd_dz_body<1, NCB, 8, decltype((a.bwd))>(a.bwd, 0, wg);
+    STEP_STAMP(5);
+    // release: what this tile wrote (activations, dZ, the loss partial) leaves this XCD's L2 before the arrival is
+    // counted.  A barrier does not wait for global stores (the compiler emits lgkmcnt only), so every wave first waits
+    // for ITS stores to be acknowledged by the L2; then one write-back of the L2 covers them all.
+#if OSRL_STEP_FENCE_ALL
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+#endif
+      const unsigned seen = atomicAdd(ctr, 1u);
+      s_flag = seen == (unsigned)a.n_tiles - 1;
+      if (s_flag) __threadfence();
+    }
+    __syncthreads();
+    STEP_STAMP(6);
+    if (s_flag) {  // last row tile: the loss, summed in tile order (every partial fetched by its own lane)
+      if (tid < OSRL_STEP_MAX_WG) s_part[tid] = tid < a.n_tiles ? reinterpret_cast<const volatile float*>(a.ws)[tid] : 0.f;
+      __syncthreads();
+      if (tid == 0 && a.stat) {
+        float t = 0.f;
+        for (int g = 0; g < a.n_tiles; ++g) t += s_part[g];
+        a.stat[0] = t * a.inv_n;
+      }
+    }
+  }
+
+  STEP_STAMP(7);
+  if (wg < a.n_work) {
+    auto phase_b = [&](auto t_c) {
+      constexpr int T = decltype(t_c)::value, TW = 16 * T, LD = TW + 1;
+      constexpr int PER = (TW * TW + kStepThreads - 1) / kStepThreads;  // elements of the tile per lane (8 / 2)
+      // The optimizer state of this workgroup's tile does not depend on the row tiles: p / m / v and the pack maps of
+      // this lane's elements are requested BEFORE the wait and are in registers when the gradient is.
+      const int ei = a.work[wg * 4 + 0], ot = a.work[wg * 4 + 1], it = a.work[wg * 4 + 2];
+      const OSRL_CAS osrl_dw_entry_t& E0 = ((const OSRL_CAS osrl_dw_entry_t*)a.entries)[ei];
+      const int out = E0.out, in = E0.in, o0 = ot * TW, i0 = it * TW;
+      float* __restrict__ P = a.p;
+      float* __restrict__ M = a.m;
+      float* __restrict__ V = a.v;
+      const int32_t* __restrict__ MF = a.map_f;
+      const int32_t* __restrict__ MB = a.map_b;
+      float pv[PER], mv[PER], vv[PER];
+      int mf[PER], mb[PER];
+      unsigned w[PER];
+      bool ok[PER];
+      const bool has_b = it == 0 && tid < TW && o0 + tid < out;
+      const unsigned wb = (unsigned)(E0.b_off + (has_b ? o0 + tid : 0));
+      float pb_, mb_, vb_;
+      auto load_state = [&]() {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const int idx = tid + j * kStepThreads;
+          const int ol = idx / TW, il = idx - ol * TW;
+          const int o = o0 + ol, i = i0 + il;
+          ok[j] = idx < TW * TW && o < out && i < in;
+          w[j] = ok[j] ? (unsigned)(E0.w_off + (int64_t)o * in + i) : (unsigned)E0.w_off;  // (groups are < 2^32 floats)
+          pv[j] = P[w[j]];
+          mv[j] = M[w[j]];
+          vv[j] = V[w[j]];
+          mf[j] = MF ? MF[w[j]] : -1;
+          mb[j] = MB ? MB[w[j]] : -1;
+        }
+        pb_ = P[wb];
+        mb_ = M[wb];
+        vb_ = V[wb];
+      };
+      // (64 x 64 tiles: 8 elements per lane = 48 registers on top of the tile's 64 accumulators and 64 fragment
+      // registers -- they would spill; there the state is read when the gradient is ready, as the optimizer launch does)
+      constexpr bool PRE = T == 2;
+      if constexpr (PRE) load_state();
+      if (tid == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.n_tiles) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++polls > kStepSpinMax) {
+            ctr[2] = 1u;
+            break;
+          }
+        }
+        // acquire: drop this CU's L1 / this XCD's L2 copies of what the row tiles wrote.  A cache operation of the
+        // CU, not of the wave: the other waves' loads come after the barrier behind it.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      STEP_STAMP(8);
+      __syncthreads();
+      STEP_STAMP(9);
+      if (wave == 7 && lane < 3) {
+        // this step's bias corrections (osrl_step::tick_values: two double-precision pow, ~2 us on one lane) on a wave
+        // that idles while waves 0-3 run the tile's MFMAs; lanes 0 / 1 take beta1 / beta2 in lockstep
+        const double t = (double)(t_old + 1);
+        const double pw = pow((double)(lane == 0 ? a.beta1 : a.beta2), t);
+        const float lrs = a.warmup > 0 ? (float)fmin(t / (double)a.warmup, 1.0) : 1.0f;
+        s_tick[lane] = lane == 0 ? (float)(1.0 - pw) : lane == 1 ? (float)sqrt(1.0 - pw) : lrs;
+      }
+      dwt_tile<T, false, T == 2>(a.entries, a.work, wg, a.rows, lds,
+                                 [&](const OSRL_CAS osrl_dw_entry_t&, const int, const int, const int /*split*/, const bool) {
+        STEP_STAMP(10);
+        if constexpr (!PRE) load_state();
+        const float lr_t = a.lr * s_tick[2];
+        const osrl_adam::Coef c{a.beta1, a.beta2, a.eps, lr_t / s_tick[0], s_tick[1]};
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const int idx = tid + j * kStepThreads;
+          const int ol = idx / TW, il = idx - ol * TW;
+          const int off = ok[j] ? ol * LD + il : 0;
+          const float g = ((lds[off] + lds[TW * LD + off]) + lds[2 * TW * LD + off]) + lds[3 * TW * LD + off];
+          if (ok[j]) {
+            osrl_adam::update1(pv[j], mv[j], vv[j], g, c);
+            P[w[j]] = pv[j];
+            M[w[j]] = mv[j];
+            V[w[j]] = vv[j];
+            if (mf[j] >= 0) a.pf[mf[j]] = pv[j];
+            if (mb[j] >= 0) a.pb[mb[j]] = pv[j];
+          }
+        }
+        if (has_b) {
+          const float* db = lds + 4 * TW * LD;
+          const float gb = ((db[tid] + db[TW + tid]) + db[2 * TW + tid]) + db[3 * TW + tid];
+          osrl_adam::update1(pb_, mb_, vb_, gb, c);
+          P[wb] = pb_;
+          M[wb] = mb_;
+          V[wb] = vb_;
+        }
+      });
+    };
+    if (a.tile_blocks == 2)
+      phase_b(std::integral_constant<int, 2>{});
+    else
+      phase_b(std::integral_constant<int, 4>{});
+  }
+
+  STEP_STAMP(11);
+  __syncthreads();
+  if (tid == 0) {
+    // (no fence: the count orders nothing but the tick below, and every workgroup read t_old before its first barrier)
+    const unsigned done = atomicAdd(ctr + 1, 1u);
+    if (done == (unsigned)a.n_wg - 1) {  // every workgroup read t_old long ago and is past the counter: tick, re-arm
+      if (wg < a.n_work) {  // (wave 7 of a dW workgroup computed exactly osrl_step::tick_values(t_old + 1) already)
+        a.st->step = t_old + 1;
+        a.st->bc1 = s_tick[0];
+        a.st->bc2_sqrt = s_tick[1];
+        a.st->lr_scale = s_tick[2];
+      } else {
+        osrl_step::advance(a.st, t_old, a.beta1, a.beta2, a.warmup);
+      }
+      ctr[0] = 0u;
+      ctr[1] = 0u;
+    }
+  }
+  STEP_STAMP(12);
+}
+
+template <int NCB>
+__global__ __launch_bounds__(kStepThreads, 2) void mlp_step_kernel(const StepArgs a) {
+  mlp_step_body<NCB, const StepArgs&>(a);
+}
+template <int NCB>
+__global__ __launch_bounds__(kStepThreads, 2) void mlp_step_kernel_p(const void* p) {
+  mlp_step_body<NCB, const OSRL_CAS StepArgs&>(*(const OSRL_CAS StepArgs*)p);
+}
+
 }  // namespace
 
 // forward tails: argument check, and the same arithmetic as separate launches (the fallback when a launch keeps no
@@ -2466,6 +2863,100 @@ extern "C" int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, co
   return mlp_backward_dz_impl(net, rows, saved, g, tail, stream);
 }
 
+
+
+// ---- host side of mlp_step_kernel ---------------------------------------------------------------------------------
+template <int NCB>
+static int launch_step(const StepArgs& k, size_t lds_bytes, hipStream_t stream) {
+  const void* dev_args = osrl_argmem::slot(k);
+  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_step_kernel_p<NCB>)
+                                              : reinterpret_cast<const void*>(mlp_step_kernel<NCB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  if (dev_args)
+    hipLaunchKernelGGL(mlp_step_kernel_p<NCB>, dim3(k.n_wg), dim3(kStepThreads), lds_bytes, stream, dev_args);
+  else
+    hipLaunchKernelGGL(mlp_step_kernel<NCB>, dim3(k.n_wg), dim3(kStepThreads), lds_bytes, stream, k);
+  return (int)hipGetLastError();
+}
+
+#ifdef OSRL_STEP_STAMPS
+extern "C" int osrl_debug_step_stamps(long long* host_out /* [OSRL_STEP_MAX_WG][16] */) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_stamp), sizeof(long long) * OSRL_STEP_MAX_WG * 16);
+}
+#endif
+
+extern "C" int osrl_mlp_regress_step(const osrl_mlp_step_t* s, void* stream) {
+  if (!s || !s->st || !valid_net(&s->net) || !s->target || !s->entries || !s->work || !s->p || !s->m || !s->v || !s->ws)
+    return -1;
+  const osrl_mlp_t* net = &s->net;
+  const int L = net->n_layers, rows = s->in.rows;
+  if (rows < 1 || s->in.d0 + s->in.d1 != net->dims[0] || !s->in.src0 || (s->in.d1 > 0 && !s->in.src1) || s->n_work < 1)
+    return -1;
+  if (!s->acts.x || !s->grads.dy[0] || s->grads.dx[0] || (s->tile_blocks != 2 && s->tile_blocks != 4)) return -1;
+  for (int l = 0; l < L; ++l)
+    if (!s->acts.h[0][l] || !s->grads.dz[0][l] || !net->Wf[0][l] || !net->b[0][l] || (l > 0 && !net->Wb[0][l])) return -1;
+  if ((s->map_f && !s->pf) || (s->map_b && !s->pb)) return -1;
+  osrl_gather::GatherArgs ga{};
+  if (s->n_fields < 0 || s->n_fields > OSRL_MAX_FIELDS ||
+      !osrl_gather::fill(ga, s->n_fields, s->src, s->dst, s->width, s->scale, s->n_rows, rows, s->gather_seed, s->gather_stream,
+                         s->st) ||
+      (s->n_fields > 0 && s->n_rows < 1))
+    return -1;
+  // the shapes the fused launch is built for: everything else keeps the separate launches
+  const TileChoice t = choose_tile(net, rows, 0);
+  const int n_tiles = (rows + 15) / 16;
+  if (net->n_nets != 1 || t.nw != 8 || t.nrb != 1 || n_tiles > OSRL_STEP_MAX_WG || s->n_work > OSRL_STEP_MAX_WG)
+    return OSRL_E_UNSUPPORTED;
+  StepArgs k{};
+  k.fwd.net = *net;
+  k.fwd.in = s->in;
+  k.fwd.out = s->acts;
+  k.fwd.lda = t.lda;
+  k.fwd.tail = osrl_mlp_tail_t{};
+  k.bwd.net = *net;
+  k.bwd.saved = s->acts;
+  k.bwd.g = s->grads;
+  k.bwd.rows = rows;
+  k.bwd.lda = t.lda;
+  k.bwd.tail = osrl_mlp_tail_t{};
+  k.gather = ga;
+  k.st = s->st;
+  k.stats_cur = s->stats_cur;
+  k.ring = s->ring;
+  k.target = s->target;
+  k.du = const_cast<float*>(s->grads.dy[0]);
+  k.stat = s->stat;
+  k.entries = s->entries;
+  k.work = s->work;
+  k.p = s->p;
+  k.m = s->m;
+  k.v = s->v;
+  k.map_f = s->map_f;
+  k.map_b = s->map_b;
+  k.pf = s->pf;
+  k.pb = s->pb;
+  k.ws = s->ws;
+  k.beta1 = s->beta1;
+  k.beta2 = s->beta2;
+  k.lr = s->lr;
+  k.eps = s->eps;
+  const int64_t n = s->n_global > 0 ? s->n_global : (int64_t)rows * net->dims[L];
+  k.inv_n = 1.0f / (float)n;
+  k.warmup = s->warmup;
+  k.n_stats = s->n_stats;
+  k.ring_len = s->ring_len > 0 ? s->ring_len : 1;
+  k.n_tiles = n_tiles;
+  k.n_work = s->n_work;
+  k.n_wg = n_tiles > s->n_work ? n_tiles : s->n_work;
+  k.rows = rows;
+  k.tile_blocks = s->tile_blocks == 2 ? 2 : 4;
+  const size_t lds_rows = (size_t)16 * t.lda * sizeof(float);
+  const size_t lds_bytes = lds_rows > dwt_lds<4>() ? lds_rows : dwt_lds<4>();
+  if (t.ncb == 2) return launch_step<2>(k, lds_bytes, (hipStream_t)stream);
+  return launch_step<4>(k, lds_bytes, (hipStream_t)stream);
+}
 
 // the register-streamed tile kernel (linear_kernel): any M, K <= 1024, any N
 static int launch_linear_tiles(const float* A, int64_t lda, int32_t M, int32_t K, const float* P, int32_t Np, int32_t col0,

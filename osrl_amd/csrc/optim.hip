@@ -16,6 +16,7 @@
 #include "../../include/osrl_amd.h"
 #include "step.h"
 #include "argmem.h"
+#include "adam.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -122,10 +123,7 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, float* __restri
     if (n_splits > 8) g = slab_sum_from(slabs, 8, n_splits, slab_stride, i, g);
     g *= gs;
     if (wd != 0.0f) pv *= decay;
-    mv = b1 * mv + (1.0f - b1) * g;
-    vv = b2 * vv + (1.0f - b2) * g * g;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) / bc2s + eps));
+    osrl_adam::update4(pv, mv, vv, g, osrl_adam::Coef{b1, b2, eps, step_size, bc2s});
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;

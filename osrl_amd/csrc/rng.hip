@@ -15,6 +15,7 @@
 
 #include "../../include/osrl_amd.h"
 #include "philox.h"
+#include "gather.h"
 #include "step.h"
 #include "argmem.h"
 
@@ -51,39 +52,8 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int
   randn_body(out, n, k0, k1, stream_id, st ? (uint32_t)st->step : 0u, blockIdx.x, gridDim.x);
 }
 
-#define OSRL_MAX_FIELDS 8
-struct GatherArgs {
-  const float* src[OSRL_MAX_FIELDS];
-  float* dst[OSRL_MAX_FIELDS];
-  int32_t width[OSRL_MAX_FIELDS];
-  float scale[OSRL_MAX_FIELDS];
-  int32_t n_fields, batch;
-  int64_t n_rows;
-  int32_t* idx_out;
-  uint32_t k0, k1, stream_id;
-  const osrl_step_state_t* st;
-};
-
-// one wave per sampled row; lanes stride over the row's columns (coalesced both sides)
-// AR: `const GatherArgs&` (kernel argument by value) or `const OSRL_CAS GatherArgs&` (device-resident block, argmem.h)
-template <class AR, int NT = 0>
-__device__ __forceinline__ void gather_body(AR a, uint32_t step, int block) {
-  const int lane = threadIdx.x & 63;
-  const int b = block * (NT ? NT / 64 : (int)(blockDim.x >> 6)) + (threadIdx.x >> 6);
-  if (b >= a.batch) return;
-  const U4 r = philox4x32_10(U4{(uint32_t)b, 0x5eedu, step, a.stream_id}, a.k0, a.k1);
-  // 64-bit multiply-shift maps a 64-bit uniform onto [0, n_rows) (bias < 2^-40 for n_rows < 2^24)
-  const uint64_t u = ((uint64_t)r.x << 32) | r.y;
-  const int64_t idx = (int64_t)__umul64hi(u, (uint64_t)a.n_rows);
-  if (lane == 0 && a.idx_out) a.idx_out[b] = (int32_t)idx;
-  for (int f = 0; f < a.n_fields; ++f) {
-    const int w = a.width[f];
-    const float* __restrict__ s = a.src[f] + (size_t)idx * w;
-    float* __restrict__ d = a.dst[f] + (size_t)b * w;
-    const float sc = a.scale[f];
-    for (int c = lane; c < w; c += 64) d[c] = s[c] * sc;
-  }
-}
+using osrl_gather::GatherArgs;
+using osrl_gather::gather_body;
 
 __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
   gather_body<const GatherArgs&>(a, a.st ? (uint32_t)a.st->step : 0u, blockIdx.x);

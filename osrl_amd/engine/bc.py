@@ -1,13 +1,17 @@
-"""The BC train step as a static launch plan (osrl/algorithms/bc.py:45-52,103-109)."""
+"""The BC train step (osrl/algorithms/bc.py:45-52,103-109): ONE launch (csrc/mlp.hip ``mlp_step_kernel``) where the
+shape allows it, otherwise the static plan of six launches; either way replayed as a hipGraph."""
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Optional
 
 import torch
 
+from .. import _lib as L
 from ..common.net import net_desc_seq
 from . import glue as G
-from .core import DwPlan, MlpRun, StepState, capture_step, load_into
+from .core import DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into
 
 STAT_KEYS = ["loss/actor_loss"]
 
@@ -30,6 +34,61 @@ class BCEngine:
         self.plan = DwPlan(m.groups["actor"], self.r_pi.dw_entries(), B, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
+        # gather -> forward -> MSE -> backward -> dW -> Adam -> tick as one launch (include/osrl_amd.h
+        # osrl_mlp_regress_step): single device, one row split per dW tile (no gradient slabs to sum), a work list and
+        # a row-tile count that fit the resident grid; the library has the last word (OSRL_E_UNSUPPORTED -> the plan)
+        self.one_launch = (os.environ.get("OSRL_BC_ONE_LAUNCH", "1") == "1" and dist is None and self.plan.tile_blocks == 4
+                           and self.plan.n_splits == 1 and 0 < self.plan.n_work <= L.STEP_MAX_WG
+                           and B <= 16 * L.STEP_MAX_WG)
+        self.step_ws = torch.zeros(L.STEP_WS, **f) if self.one_launch else None
+        self._step_c = None
+        # the one-launch step's own dW work list: 32 x 32 tiles when they fit the resident grid (a 256-row batch gives a
+        # 64 x 64 tile 3.4 us of MFMA work on ONE CU; a quarter of that on four CUs), else the plan's 64 x 64 list
+        self._step_work, self._step_T = self.plan.d_work, 4
+        if self.one_launch:
+            work = []
+            for i, (_dz, _a, wk, _bk) in enumerate(self.r_pi.dw_entries()):
+                out_f, in_f = m.groups["actor"].layout[wk][1]
+                work += [v for ot in range((out_f + 31) // 32) for it in range((in_f + 31) // 32)
+                         for v in (i, ot, it, 0 | (1 << 16))]
+            if len(work) // 4 <= L.STEP_MAX_WG and os.environ.get("OSRL_BC_STEP_T", "2") == "2":
+                self._step_work, self._step_T = torch.tensor(work, dtype=torch.int32, device=dev), 2
+
+    def _one_launch_args(self) -> "L.MlpStepT":
+        """The descriptor of osrl_mlp_regress_step for the current replay store (static: built once per attachment)."""
+        if self._step_c is not None:
+            return self._step_c
+        m, st, grp, r = self.model, self.st, self.model.groups["actor"], self.r_pi
+        k = L.MlpStepT()
+        k.st, k.beta1, k.beta2, k.warmup = st.ptr, st.betas[0], st.betas[1], st.warmup
+        k.n_stats, k.ring_len = st.n_stats, st.ring_len
+        k.stats_cur, k.ring = st.stats.data_ptr(), st.ring.data_ptr()
+        if self.replay is not None:
+            n_f, src, dst, w, sc, n_rows, _B, g_seed, g_stream, keep = self.replay.gather_args((self.obs, self.act), (0, 2))
+            k.n_fields, k.n_rows, k.gather_seed, k.gather_stream = n_f, n_rows, g_seed, g_stream
+            for i in range(n_f):
+                k.src[i], k.dst[i], k.width[i], k.scale[i] = src[i], dst[i], w[i], sc[i]
+            self._step_keep = keep
+        k.net = r.fwd_c
+        k.in_ = r._rows(self.obs)
+        k.acts = r.acts_c
+        k.grads = r.grads_c
+        k.target = self.act.data_ptr()
+        k.n_global = (self.rows_global or self.B) * m.action_dim
+        k.stat = st.stat_ptr("loss/actor_loss")
+        k.entries, k.work = self.plan.d_entries.data_ptr(), self._step_work.data_ptr()
+        k.n_work, k.tile_blocks = self._step_work.numel() // 4, self._step_T
+        k.p, k.m, k.v = grp.p.data_ptr(), grp.m.data_ptr(), grp.v.data_ptr()
+        k.map_f, k.map_b, k.pf, k.pb = grp._map_f.data_ptr(), grp._map_b.data_ptr(), grp.pf.data_ptr(), grp.pb.data_ptr()
+        k.lr, k.eps = m._lrs["actor"], 1e-8
+        k.ws = self.step_ws.data_ptr()
+        self._step_c = k
+        return k
+
+    def one_launch_failed(self) -> bool:
+        """True when a workgroup of the one-launch step gave up waiting for the row tiles (synchronises; never seen:
+        all its workgroups are resident at once).  The parameters are invalid after that."""
+        return bool(self.one_launch and self.step_ws[L.STEP_MAX_WG + 2].item() != 0)
 
     def attach_replay(self, store) -> None:
         """Sample (observations, actions) minibatches on device from ``store`` (common/replay.py) inside the step:
@@ -39,6 +98,7 @@ class BCEngine:
                              f"{self.obs.shape[1]} (bc_mode='multi-task' appends the cost return: process_bc_dataset)")
         self.replay = store
         self.graph = None
+        self._step_c = None
 
     def step_replay(self, use_graph: bool = True) -> None:
         assert self.replay is not None
@@ -52,6 +112,14 @@ class BCEngine:
 
     def body(self) -> None:
         m, B, ad = self.model, self.B, self.model.action_dim
+        if self.one_launch:
+            rc = L.load().osrl_mlp_regress_step(C.byref(self._one_launch_args()), cur_stream())
+            if rc == L.E_UNSUPPORTED:
+                self.one_launch = False  # (a shape outside the fused launch's: the plan below, from now on)
+            else:
+                L.check(rc, "osrl_mlp_regress_step")
+                self.st.host_step += 1
+                return
         self.st.prologue(self.replay, (self.obs, self.act), None, 0, False, fields=(0, 2))
         pred = self.r_pi.forward(self.obs)[0]
         ng = (self.rows_global or B) * ad

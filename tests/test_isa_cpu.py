@@ -91,3 +91,17 @@ def test_descriptor_pointer_kernels_read_their_arguments_with_scalar_loads(listi
             a, b = _one(listings["mlp"], twin[0], inst), _one(listings["mlp"], twin[1], inst)
             assert b["scratch"] == 0 and a["scratch"] == 0, (twin, inst, a, b)
             assert abs(a["vgprs"] - b["vgprs"]) <= 4, (twin, inst, a["vgprs"], b["vgprs"])
+
+
+def test_one_launch_step_kernel_fits_its_registers(listings):
+    """mlp_step_kernel (the BC step as one launch): 8 waves per workgroup = 2 per SIMD = 256 registers per lane for the
+    forward / backward bodies, the 64 x 64 (or 32 x 32 with all four k-steps in flight) dW tile and the preloaded
+    optimizer state together -- no scratch in the captured ("_p") instances, and both twins the same shape."""
+    for inst in ("ILi2E", "ILi4E"):
+        a, b = _one(listings["mlp"], "mlp_step_kernelI", inst), _one(listings["mlp"], "mlp_step_kernel_pI", inst)
+        # (the by-value twin -- eager mode and the capture's warm-up pass -- indexes the gather descriptor's small arrays
+        # dynamically out of the kernarg segment, which the compiler stages through <= 64 bytes of scratch)
+        assert b["scratch"] == 0 and a["scratch"] <= 64, (inst, a, b)
+        for r in (a, b):
+            assert 0 < r["vgprs"] <= 256, (inst, r)
+        assert abs(a["vgprs"] - b["vgprs"]) <= 16, (inst, a["vgprs"], b["vgprs"])
