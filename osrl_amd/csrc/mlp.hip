@@ -3078,6 +3078,10 @@ extern "C" int osrl_mlp_backward_dw_tiles(const osrl_dw_entry_t* d_entries, cons
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (tile_blocks == 5) return launch_dwt<5>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
   if (tile_blocks == 4) return launch_dwt<4>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
+  // 48 x 48 / 32 x 32 tiles: 38 / 17 KB of LDS and < 100 registers per lane, i.e. workgroups that fit on a CU beside an
+  // 80-row forward workgroup (which leaves a 64 x 64 tile's 68 KB no room)
+  if (tile_blocks == 3) return launch_dwt<3>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
+  if (tile_blocks == 2) return launch_dwt<2>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
   return -1;
 }
 

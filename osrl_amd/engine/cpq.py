@@ -103,7 +103,9 @@ class CPQEngine:
         self.r_critic = MlpRun(self.d_critic, B, True, dev)
         self.dq = z(nq, B, 1)
         self.r_critic.setup_backward(self.dq)
-        self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev)
+        self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev,
+                               tile_blocks=int(os.environ.get("OSRL_DW_T_CRITIC", "0")),
+                               n_splits=(int(os.environ["OSRL_DW_S_CRITIC"]) if "OSRL_DW_S_CRITIC" in os.environ else None))
 
         # ---- cost-critic phase
         self.a_next2 = z(B, ad)
@@ -127,7 +129,9 @@ class CPQEngine:
         self.r_cost = MlpRun(self.d_cost, B, True, dev)
         self.dqc = z(nqc, B, 1)
         self.r_cost.setup_backward(self.dqc)
-        self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev)
+        self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev,
+                             tile_blocks=int(os.environ.get("OSRL_DW_T_COST", "0")),
+                             n_splits=(int(os.environ["OSRL_DW_S_COST"]) if "OSRL_DW_S_COST" in os.environ else None))
 
         # ---- actor phase
         self.a_pi, self.tanh_u = z(B, ad), z(B, ad)
