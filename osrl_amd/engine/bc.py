@@ -11,7 +11,7 @@ import torch
 from .. import _lib as L
 from ..common.net import net_desc_seq
 from . import glue as G
-from .core import DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into
+from .core import ArgArena, DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into
 
 STAT_KEYS = ["loss/actor_loss"]
 
@@ -42,6 +42,12 @@ class BCEngine:
                            and B <= 16 * L.STEP_MAX_WG)
         self.step_ws = torch.zeros(L.STEP_WS, **f) if self.one_launch else None
         self._step_c = None
+        # A one-kernel step is launched directly: replaying a one-node hipGraph costs 42.4 us per step where the
+        # launch itself costs 39.2 (tools/bc_eager_vs_graph.py).  Its descriptor still lives in HBM (ArgArena:
+        # recorded by the first step, looked up by the later ones), so a box that keeps kernel arguments in host
+        # memory does not fetch 3 KB per wave over PCIe.  OSRL_BC_DIRECT=0: capture it like every other step.
+        self.direct = os.environ.get("OSRL_BC_DIRECT", "1") == "1"
+        self._arena_direct: Optional[ArgArena] = None
         # the one-launch step's own dW work list: 32 x 32 tiles when they fit the resident grid (a 256-row batch gives a
         # 64 x 64 tile 3.4 us of MFMA work on ONE CU; a quarter of that on four CUs), else the plan's 64 x 64 list
         self._step_work, self._step_T = self.plan.d_work, 4
@@ -99,9 +105,22 @@ class BCEngine:
         self.replay = store
         self.graph = None
         self._step_c = None
+        self._arena_direct = None
 
-    def step_replay(self, use_graph: bool = True) -> None:
-        assert self.replay is not None
+    def _run(self, use_graph: bool) -> None:
+        if use_graph and self.dist is None and self.one_launch and self.direct:
+            if self._arena_direct is None:  # this step records the launch's descriptor; the later ones read it from HBM
+                arena = ArgArena(self.st.state.device, capacity=1 << 14)
+                with arena.record():
+                    self.body()
+                arena.upload()
+                # (if the library refused the shape, body() ran the six launches and cleared one_launch: this step is
+                # done either way, and the next one takes the captured plan below)
+                self._arena_direct = arena if self.one_launch else None
+            else:
+                with self._arena_direct.replay():
+                    self.body()
+            return
         if use_graph and self.dist is None:
             if self.graph is None:
                 self._capture()
@@ -109,6 +128,10 @@ class BCEngine:
             self.st.host_step += 1
         else:
             self.body()
+
+    def step_replay(self, use_graph: bool = True) -> None:
+        assert self.replay is not None
+        self._run(use_graph)
 
     def body(self) -> None:
         m, B, ad = self.model, self.B, self.model.action_dim
@@ -137,13 +160,7 @@ class BCEngine:
         if self.replay is not None:
             raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         load_into(((self.obs, observations), (self.act, actions)))
-        if use_graph and self.dist is None:
-            if self.graph is None:
-                self._capture()
-            self.graph.replay()
-            self.st.host_step += 1
-        else:
-            self.body()
+        self._run(use_graph)
 
     def _capture(self) -> None:
         g = self.model.groups["actor"]

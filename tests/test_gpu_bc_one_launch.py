@@ -45,8 +45,8 @@ def _same_state(ea, eb, what):
 
 
 @pytest.mark.parametrize("B,hidden,od,ad,graph", [
-    (256, [256, 256], 8, 2, False),    # BASELINE.json configs[0] (the by-value kernel)
-    (256, [256, 256], 8, 2, True),     # ... captured: the descriptor lives in the argument arena
+    (256, [256, 256], 8, 2, False),    # BASELINE.json configs[0] (use_graph=False: the by-value kernel)
+    (256, [256, 256], 8, 2, True),     # ... the default: direct launches, the descriptor lives in the argument arena
     (250, [256, 256], 17, 6, True),    # ragged last row tile, wider in / out layers
     (48, [400, 300], 11, 3, True),     # 25 / 19 column blocks: the <1, 4, 8> tile, ragged dW tiles
     (500, [256, 256, 256], 8, 2, True),  # three hidden layers, 32 row tiles vs 44 dW tiles
@@ -64,9 +64,10 @@ def test_one_launch_equals_the_six_launch_plan_with_replay(B, hidden, od, ad, gr
         eb.step_replay(use_graph=graph)
         torch.cuda.synchronize()
         _same_state(ea, eb, f"step {s + 1}")
-    assert ea.one_launch and (ea.graph is not None) == graph
-    if graph:
-        assert ea._arena.misses == 0 and ea._arena.hits >= 1  # the captured launch reads its descriptor from HBM
+    assert ea.one_launch and ea.graph is None  # (a one-kernel step is launched directly, never captured)
+    assert (eb.graph is not None) == graph
+    if graph:  # ... with its descriptor in HBM: recorded by the first step, found by every later one
+        assert ea._arena_direct.misses == 0 and ea._arena_direct.hits >= 1
     # statistics ring: every earlier step's loss was committed by the NEXT launch
     ra, rb = ea.st.read_stats_many(range(1, 8)), eb.st.read_stats_many(range(1, 8))
     for s in range(1, 8):
@@ -123,3 +124,21 @@ def test_the_c_abi_refuses_bad_descriptors():
     k = L.MlpStepT()
     assert L.load().osrl_mlp_regress_step(C.byref(k), None) == -1
     assert L.load().osrl_mlp_regress_step(None, None) == -1
+
+
+def test_one_launch_captured_in_a_graph_too(monkeypatch):
+    """OSRL_BC_DIRECT=0: the one-kernel step inside a hipGraph (what an outer capture of several steps would do)."""
+    monkeypatch.setenv("OSRL_BC_DIRECT", "0")
+    ma, mb = _pair(8, 2, [256, 256])
+    ea, eb = ma.engine(256), mb.engine(256)
+    assert ea.one_launch and not ea.direct
+    eb.one_launch = False
+    store = _store(8, 2)
+    ea.attach_replay(store)
+    eb.attach_replay(store)
+    for s in range(4):
+        ea.step_replay()
+        eb.step_replay()
+        torch.cuda.synchronize()
+        _same_state(ea, eb, f"step {s + 1}")
+    assert ea.graph is not None and ea._arena.misses == 0 and ea._arena.hits >= 1
