@@ -258,6 +258,34 @@ def timed_steps(step, steps: int, warmup: int, barrier=None):
     return time.perf_counter() - t0
 
 
+def preroll(device, ms: float = 40.0) -> float:
+    """Dense fp32 GEMM work queued right in front of the warm-up steps, nothing synchronising in between.
+
+    After ANY idle gap (20 ms is enough: tools/step_series.py, profiles/r3_step_series.txt) the device runs the first
+    ~25 replays of the CPQ step at 470-485 us and only then settles at 455 us -- a power-state ramp, not a property of the
+    step: behind 40 GEMMs the very first replays run at 450.  The driver's command times steps 6..25 of the process
+    (W = 5, K = 20 = 9 ms), i.e. exactly that ramp: 2105-2152 steps/s where the same 20 steps after 200 warm-up steps
+    give 2208-2233 and 200 steps give 2202-2207 (profiles/r3_warmup_ab.txt).  The pre-roll is untimed, touches no engine
+    state and issues no step; it makes the K timed steps measure the rate a training job runs at from its 30th millisecond
+    on.  ``--preroll-ms 0`` turns it off.  Returns the milliseconds queued."""
+    if ms <= 0:
+        return 0.0
+    x = torch.randn(4096, 4096, device=device)
+    y = torch.empty_like(x)
+    torch.mm(x, x, out=y)  # (first call: library setup)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.mm(x, x, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1), 0.05)
+    n = max(1, int(ms / one + 0.5))
+    for _ in range(n):
+        torch.mm(x, x, out=y)
+    return n * one
+
+
 def time_kernel(fn, iters=30):
     """Average duration (s) of ``fn`` (one kernel launch on the current stream) by HIP events."""
     for _ in range(3):
@@ -450,6 +478,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--preroll-ms", type=float, default=40.0,
+                    help="untimed dense GEMM work queued in front of the warm-up steps (power-state ramp; 0 = none)")
     ap.add_argument("--no-extras", action="store_true", help="skip api_path / other_configs (N=1 extras)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     args = ap.parse_args()
@@ -506,6 +536,7 @@ def main():
         except Exception as e:  # a failing probe must not take the headline line down
             roof = {"error": repr(e)[:300]}
             torch.cuda.synchronize()
+    pre_ms = preroll(device, args.preroll_ms)
     dt = timed_steps(wl.step, args.steps, args.warmup, barrier)
     if world > 1:
         import torch.distributed as dist
@@ -555,6 +586,7 @@ def main():
                        "name": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
                        "graph": bool(getattr(eng, "graph", None) is not None)},
             "optimizer_steps_per_s": round(args.steps / dt, 2),
+            "preroll_ms": round(pre_ms, 1),  # untimed GEMM work queued before the W warm-up steps (see preroll())
             "transitions_per_s": round(world * B * args.steps / dt, 1),
             "rccl_ranks": rccl_ranks,
             # two accountings of the same step: the REFERENCE's work for it (SURVEY.md 8d formula; what a reference
