@@ -20,6 +20,10 @@ per-GPU batch, one optimizer step per iteration, gradient all-reduce over RCCL),
 = per-GPU-batch gradient steps per second over the whole job ("scaling": "weak"); ``optimizer_steps_per_s`` and
 ``transitions_per_s`` are printed beside it.
 
+Timing: [probes, then ``--preroll-ms`` (40) of untimed GEMM work -- the device's power state needs ~25 ms of load
+after any idle gap, see preroll()] -> W warm-up steps -> barrier + synchronize -> EXACTLY K steps -> barrier +
+synchronize; max over ranks.
+
 Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` and ``cpu_baseline``.
 Nothing here reads /root/reference.
 """
