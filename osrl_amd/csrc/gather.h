@@ -24,6 +24,45 @@ struct GatherArgs {
   const osrl_step_state_t* st;
 };
 
+// One row of every table, index `idx` -> batch row `b`, by L lanes (lane id l): ALL fields' loads are requested before
+// the first store.  (As a loop "for each field: load, scale, store" the fields were one dependent round trip each --
+// six for the CPQ tables -- and the step prologue, which nothing overlaps, took 10.8 us: profiles/r3_timeline.txt.)
+// Columns beyond 2 L of a wide table take the plain loop.
+template <int L, class AR>
+__device__ __forceinline__ void gather_row(AR a, int64_t idx, int b, int l) {
+  float v[OSRL_MAX_FIELDS][2];
+  const int nf = a.n_fields;
+#pragma unroll
+  for (int f = 0; f < OSRL_MAX_FIELDS; ++f) {
+    const bool on = f < nf;
+    const int w = on ? a.width[f] : 0;
+    const float* __restrict__ s = (on ? a.src[f] : a.src[0]) + (on ? (size_t)idx * w : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = l + j * L;
+      const float x = s[c < w ? c : 0];  // (clamped address + select: no branch around the load)
+      v[f][j] = c < w ? x : 0.f;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < OSRL_MAX_FIELDS; ++f) {
+    if (f < nf) {
+      const int w = a.width[f];
+      const float sc = a.scale[f];
+      float* __restrict__ d = a.dst[f] + (size_t)b * w;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = l + j * L;
+        if (c < w) d[c] = v[f][j] * sc;
+      }
+      if (w > 2 * L) {
+        const float* __restrict__ s = a.src[f] + (size_t)idx * w;
+        for (int c = l + 2 * L; c < w; c += L) d[c] = s[c] * sc;
+      }
+    }
+  }
+}
+
 // one wave per sampled row; lanes stride over the row's columns (coalesced both sides)
 // AR: `const GatherArgs&` (kernel argument by value) or `const OSRL_CAS GatherArgs&` (device-resident block, argmem.h)
 // NT: the workgroup size when it is a compile-time constant (0: read blockDim -- an s_load from the hidden kernarg block)
@@ -38,13 +77,7 @@ __device__ __forceinline__ void gather_body(AR a, uint32_t step, int block) {
   const uint64_t u = ((uint64_t)r.x << 32) | r.y;
   const int64_t idx = (int64_t)__umul64hi(u, (uint64_t)a.n_rows);
   if (lane == 0 && a.idx_out) a.idx_out[b] = (int32_t)idx;
-  for (int f = 0; f < a.n_fields; ++f) {
-    const int w = a.width[f];
-    const float* __restrict__ s = a.src[f] + (size_t)idx * w;
-    float* __restrict__ d = a.dst[f] + (size_t)b * w;
-    const float sc = a.scale[f];
-    for (int c = lane; c < w; c += 64) d[c] = s[c] * sc;
-  }
+  gather_row<64, AR>(a, idx, b, lane);
 }
 
 // rows [16 tile, 16 tile + 16) by one 8-wave workgroup in ONE pass: half a wave per row (the same draws, the same rows
@@ -59,13 +92,7 @@ __device__ __forceinline__ void gather_tile16(AR a, uint32_t step, int tile) {
   const uint64_t u = ((uint64_t)r.x << 32) | r.y;
   const int64_t idx = (int64_t)__umul64hi(u, (uint64_t)a.n_rows);
   if (l == 0 && a.idx_out) a.idx_out[b] = (int32_t)idx;
-  for (int f = 0; f < a.n_fields; ++f) {
-    const int w = a.width[f];
-    const float* __restrict__ s = a.src[f] + (size_t)idx * w;
-    float* __restrict__ d = a.dst[f] + (size_t)b * w;
-    const float sc = a.scale[f];
-    for (int c = l; c < w; c += 32) d[c] = s[c] * sc;
-  }
+  gather_row<32, AR>(a, idx, b, l);
 }
 
 // host: the descriptor of osrl_replay_gather's arguments (false: invalid)
