@@ -80,9 +80,21 @@ template <class BR, class AR>
 __device__ __forceinline__ void step_begin_body(BR b, AR a) {
   __shared__ int64_t s_t;
   __shared__ int s_last;
+  __shared__ float s_tick[3];
   if (threadIdx.x == 0) s_t = __atomic_load_n(&b.st->step, __ATOMIC_RELAXED);
   __syncthreads();
   const int64_t t_old = s_t;
+  // The tick's bias corrections (osrl_step::tick_values: two double-precision pow, ~2 us on one lane) used to run in the
+  // last workgroup AFTER everything else -- serial time at the head of every step.  Every workgroup now computes them
+  // up front on three lanes of its last wave (lanes 0 / 1 take beta1 / beta2 in lockstep), beside its gather / noise work;
+  // whoever turns out to be last only stores them.  Same expressions, same bits.
+  if (threadIdx.x >= kBeginThreads - 64 && threadIdx.x < kBeginThreads - 61) {
+    const int l = threadIdx.x - (kBeginThreads - 64);
+    const double t = (double)(t_old + 1);
+    const double pw = pow((double)(l == 0 ? b.beta1 : b.beta2), t);
+    const float lrs = b.warmup > 0 ? (float)fmin(t / (double)b.warmup, 1.0) : 1.0f;
+    s_tick[l] = l == 0 ? (float)(1.0 - pw) : l == 1 ? (float)sqrt(1.0 - pw) : lrs;
+  }
   if (threadIdx.x == 0) {
     // the old step has been READ by this workgroup (its value went through LDS): count the arrival
     __threadfence();
@@ -101,7 +113,10 @@ __device__ __forceinline__ void step_begin_body(BR b, AR a) {
   if (s_last) {  // every workgroup holds t_old in registers by now: the state may move
     osrl_step::commit_stats<kBeginThreads>(t_old, b.stats_cur, b.ring, b.n_stats, b.ring_len);
     if (threadIdx.x == 0) {
-      osrl_step::advance(b.st, t_old, b.beta1, b.beta2, b.warmup);
+      b.st->step = t_old + 1;
+      b.st->bc1 = s_tick[0];
+      b.st->bc2_sqrt = s_tick[1];
+      b.st->lr_scale = s_tick[2];
       b.st->arrive_ = 0;
     }
   }
