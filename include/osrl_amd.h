@@ -250,6 +250,28 @@ int osrl_mlp_backward_dw(const osrl_dw_entry_t* d_entries, const int32_t* d_item
  * blocks = 5 x 5: no ragged tiles).  Same per-element arithmetic as osrl_mlp_backward_dw. */
 int osrl_mlp_backward_dw_tiles(const osrl_dw_entry_t* d_entries, const int32_t* d_work, int32_t n_work, int32_t rows,
                                int32_t tile_blocks, float* slabs, int64_t slab_stride, void* stream);
+/* osrl_mlp_backward_dw_tiles AND the optimizer step of the group the gradients belong to, in ONE launch (new: the
+ * reference runs loss.backward() and optimizer.step() as separate passes, cpq.py:131-133,149-151,196-198,218-220):
+ * every (tile, split) workgroup stores its slab tile as above and signs in at its tile's arrival counter
+ * (d_counters[d_tile_ids[i]], uint32, ZERO before the first launch; the last split to arrive re-arms it); that last
+ * workgroup sums the tile's n_splits slabs in slab order and applies osrl_adam_step_packed's update (weight decay 0,
+ * no gradient scale) to the tile's parameters: p, m, v, the Polyak target (tgt, may be NULL) and the packed copies
+ * through map_f / map_b (may be NULL).  Same bits as the two launches it replaces.  Nobody waits inside the kernel (a
+ * workgroup either is the last of its tile or leaves), so there is no residency requirement.  The work list must
+ * cover every parameter of the group that has a gradient exactly once per split; d_tile_ids[i] is the same for the
+ * n_splits items of a tile and different between tiles.  NOT for data-parallel steps (the all-reduce sits between dW
+ * and the update there).  HOST struct. */
+typedef struct {
+  float *p, *m, *v, *tgt;            /* flat group buffers (tgt may be NULL) */
+  const int32_t *map_f, *map_b;      /* osrl_adam_step_packed's maps (may be NULL) */
+  float *pf, *pb, *tf;               /* packed copies (tf: packed Polyak target, may be NULL) */
+  const osrl_step_state_t* st;       /* bias corrections / warm-up factor of the current step */
+  float lr, beta1, beta2, eps, tau;
+  int32_t pad_;
+} osrl_dw_adam_t;
+int osrl_mlp_backward_dw_tiles_adam(const osrl_dw_entry_t* d_entries, const int32_t* d_work, const int32_t* d_tile_ids,
+                                    uint32_t* d_counters, int32_t n_work, int32_t rows, int32_t tile_blocks,
+                                    float* slabs, int64_t slab_stride, const osrl_dw_adam_t* opt, void* stream);
 /* The same contract for items given in units of 128 (out) x 64 (in) tiles that lie fully inside their dW (only
  * full tiles may be listed): one wave per tile and row split, 128-register accumulator tiles, one wave per SIMD -- the big-row-count (token matrix) variant; db of an entry is written by its it == 0 tiles.
  * Splits beyond a plan's own n_splits are never written (the caller keeps them zero). */

@@ -63,6 +63,12 @@ class DwEntryT(C.Structure):
                 ("out", C.c_int32), ("in_", C.c_int32), ("ldz", C.c_int32), ("lda", C.c_int32)]
 
 
+class DwAdamT(C.Structure):  # osrl_dw_adam_t
+    _fields_ = [("p", _fp), ("m", _fp), ("v", _fp), ("tgt", _fp), ("map_f", C.c_void_p), ("map_b", C.c_void_p),
+                ("pf", _fp), ("pb", _fp), ("tf", _fp), ("st", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("tau", C.c_float), ("pad_", C.c_int32)]
+
+
 STEP_MAX_WG = 128
 STEP_WS = STEP_MAX_WG + 8  # floats of scratch of osrl_mlp_regress_step (include/osrl_amd.h OSRL_STEP_WS)
 E_UNSUPPORTED = -2
@@ -160,6 +166,7 @@ PROTOTYPES = {
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_mlp_backward_dw_tiles": [_vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp],
     "osrl_mlp_backward_dw_big": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
+    "osrl_mlp_backward_dw_tiles_adam": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _P(DwAdamT), _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
     "osrl_step_begin": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _fp, _i64, _u64, _u32, _i32, _P(_fp), _P(_fp),
                         _P(_i32), _P(_f32), _i64, _i32, _u64, _u32, _vp],

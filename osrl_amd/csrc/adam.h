@@ -26,6 +26,12 @@ __device__ __forceinline__ void update1(float& pv, float& mv, float& vv, const f
   pv = __fmaf_rn(-c.step_size, mv / d, pv);
 }
 
+// Polyak target  t <- tau p + (1 - tau) t   (cpq.py:107-113 _soft_update), the rounding spelled out for the same reason:
+// one product rounded, then one fused multiply-add -- in the streaming kernel and in the dW launch's optimizer epilogue
+__device__ __forceinline__ float polyak1(const float tau, const float pv, const float tv) {
+  return __fmaf_rn(tau, pv, __fmul_rn(1.0f - tau, tv));
+}
+
 __device__ __forceinline__ void update4(f32x4& pv, f32x4& mv, f32x4& vv, const f32x4 g, const Coef c) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

@@ -31,189 +31,13 @@
 //   * backward-dz walks the same structure with the transposed weight access; backward-dw is a
 //     split-K (over rows) MFMA GEMM dW = dZ^T A writing per-split slabs that the Adam kernel sums
 //     in a fixed order (deterministic, no atomics).
-#include <hip/hip_runtime.h>
-#include <type_traits>
-#include <utility>
-#include <stdint.h>
-#include <stdlib.h>
-
-#include "../../include/osrl_amd.h"
-#include "argmem.h"
+#include "mlp_common.h"
 #include "adam.h"
 #include "gather.h"
 #include "step.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#ifdef OSRL_PHASE_TIMING  // tools/mlp_phase.hip: per-phase cycle stamps of workgroup 0 (debug builds only)
-__device__ long long g_phase_t[4][64];
-__device__ long long g_phase_all[8192][4][16];  // every workgroup (first 8192), for phase averages
-#define PHASE_STAMP(i)                                                                                  \
-  if ((threadIdx.x & 63) == 0) {                                                                        \
-    const long long t_ = __builtin_readcyclecounter();                                                  \
-    const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                                \
-    if (wg_ < 8192 && (i) < 16 && threadIdx.x < 256) g_phase_all[wg_][threadIdx.x >> 6][i] = t_;                             \
-    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x < 256) g_phase_t[threadIdx.x >> 6][i] = t_;           \
-  }
-// residency log: (start, end) in 100 MHz ticks, HW_ID, XCC_ID of every workgroup
-__device__ long long g_wg_log[16384][4];
-#define WG_LOG(slot)                                                                                  \
-  if (threadIdx.x == 0) {                                                                             \
-    const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                              \
-    if (wg_ < 16384) {                                                                                \
-      g_wg_log[wg_][slot] = wall_clock64();                                                           \
-      g_wg_log[wg_][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   \
-      g_wg_log[wg_][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
-    }                                                                                                 \
-  }
-#else
-#define PHASE_STAMP(i)
-#define WG_LOG(slot)
-#endif
-
-// Wave priority (s_setprio 0..3, default 0): launches on at most OSRL_CHAIN_PRIO rows -- the 2048-row latency chain of a
-// train step: forwards with saved activations, backward-dz, dW -- raise theirs to 3, so that on a CU they share with
-// the N*B-row inference launches (the step's filler work, priority 0) the instruction arbiter serves the chain first.
-// Measured on the CPQ step: +1.3 % (1945 -> 1970 steps/s); 0 disables.
-#ifndef OSRL_CHAIN_PRIO
-#define OSRL_CHAIN_PRIO 4096
-#endif
-
 namespace {
 
-// max(x, 0) as ONE v_max_f32: fmaxf() compiles to a canonicalising v_max x,x in front of the max (IEEE sNaN quieting),
-// and every VALU instruction of an epilogue is paid in MFMA issue slots (4 cycles per wave each).  Same value for
-// every non-NaN input.
-__device__ __forceinline__ float relu1(float x) {
-  float y;
-  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-  return y;
-}
-__device__ __forceinline__ float act_fwd(int act, float x) {
-  if (act == OSRL_ACT_RELU) return relu1(x);
-  if (act == OSRL_ACT_TANH) return tanhf(x);
-  return x;
-}
-// derivative expressed with the activation OUTPUT y (relu: threshold_backward on the output)
-__device__ __forceinline__ float act_bwd(int act, float y) {
-  if (act == OSRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
-  if (act == OSRL_ACT_TANH) return 1.0f - y * y;
-  return 1.0f;
-}
-__device__ __forceinline__ int map_row(int r, int map, int div) {
-  if (map == OSRL_MAP_MOD) return r % div;
-  if (map == OSRL_MAP_DIV) return r / div;
-  return r;
-}
-__device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
-// balanced split of nblk column blocks over the NW waves: the first (nblk % NW) waves take one extra block
-template <int NW = 4>
-__device__ __forceinline__ void wave_blocks(int nblk, int wave, int* cb0, int* cnt) {
-  const int base = nblk / NW, rem = nblk % NW;
-  *cnt = base + (wave < rem ? 1 : 0);
-  *cb0 = wave * base + (wave < rem ? wave : rem);
-}
-
-// B fragment (4 consecutive k of column n) from the packed layout P[q = k/4][n][4], Np columns, with the k-step
-// part of the address kept scalar: P + kc*16*Np is wave-uniform (SGPR pair), the lane part (kq*Np + n)*16 bytes is a
-// 32-bit VGPR offset computed once per layer -> global_load_dwordx4 saddr+voffset
-__device__ __forceinline__ f32x4 load_bp_s(const float* __restrict__ Pk /*uniform*/, unsigned lane_off_bytes) {
-#ifdef OSRL_EXP_NO_BLOAD
-  const float v = (float)lane_off_bytes * 1e-6f;
-  return f32x4{v, v + 1.f, v + 2.f, v + 3.f};
-#else
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Pk) + lane_off_bytes);
-#endif
-}
-
-// ---- the MFMA core -------------------------------------------------------------------------------------
-// acc[rb][c] += A(lds tile rows rb*16.., k) * B(k, cols n0 + c*16..)   over nk 16-deep k steps.
-// Software pipeline: a ring of STAGES B-fragment sets keeps STAGES-1 k-steps of weight loads in flight
-// (global -> VGPR, straight from L2) while the MFMAs of the current step run; the A fragments
-// (ds_read_b128 from the LDS activation tile) are prefetched one step ahead.
-// The pipeline is split in two calls so that a layer's FIRST weight loads can be issued long before its
-// k-loop starts -- before the previous layer's barrier + epilogue, or before the input tile is staged:
-//   mm_prefetch  issues the loads of the first STAGES-1 k-steps into the ring (no waits);
-//   mm_run       runs the k-loop assuming exactly that.
-// Measured (tools/mlp_phase.hip, all workgroups): without this a wave spent 22k cycles in the 5-k-step first
-// layer (5k cycles of MFMA work) and 13k cycles staging its input with nothing else in flight.
-constexpr int kRing = 3;  // ring slots (STAGES <= ring depth) of the many-workgroups-per-CU kernels
-// Ring depth of the 8-wave kernels (NW = 8: launches of at most ~2 workgroups per CU -- the 2048-row training launches,
-// BC's 256 rows), an EXPERIMENT knob: nothing else on the CU hides a weight load's latency there, so a deeper ring
-// (OSRL_RING_DEEP = 4 / 6: 3 / 5 k-steps of weights in flight) looked like the remedy for their 13k-cycle 16-k-step
-// layers (8k of MFMA time).  Measured (tools/mlp_phase.hip variants, profiles/r3_phase_ring_warm.txt): depth 4 changes
-// a layer by -4 % .. +2 %, depth 6 is 20-30 % SLOWER (registers: the ring is live across staging and epilogues), and
-// it makes no difference whether the weights were just re-written from another XCD (COLD=1) or are L2-hot -- these
-// layers are chains of ~700-cycle round trips (weights, LDS, barriers) of which the weight ring is only one.  Default 3.
-#ifndef OSRL_RING_DEEP
-#define OSRL_RING_DEEP 3
-#endif
-constexpr int kRingDeep = OSRL_RING_DEEP;
-template <int NW>
-constexpr int ring_depth() { return NW == 8 ? kRingDeep : kRing; }
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-// L2 warm-up for the 8-wave kernels, the second EXPERIMENT of the same measurement (OSRL_L2_WARM=1): each thread
-// touches kWarmLines 128-byte lines of the next layers' weights while the current layer computes.  It costs 10-25 %
-// (the first layer's k-loop waits behind the touches: loads return in order) and buys nothing -- see above, the
-// layers are not bound by where the weights come from.  Off; kept for the A/B build of tools/build_phase_variants.sh.
-constexpr int kWarmLines = 4;  // x 512 threads x 128 B = 256 KB per layer (a 256 x 256 layer)
-#ifndef OSRL_L2_WARM
-#define OSRL_L2_WARM 0
-#endif
-template <int NT>
-__device__ __forceinline__ void l2_warm(const float* __restrict__ P, int n_floats, float (&d)[kWarmLines]) {
-  const int n_lines = n_floats >> 5;
-#pragma unroll
-  for (int j = 0; j < kWarmLines; ++j) {
-    int i = (int)threadIdx.x + j * NT;
-    i = i < n_lines ? i : n_lines - 1;  // (past the end: touch the last line again -- no branch around a load)
-    d[j] = P[(size_t)i * 32];
-  }
-}
-__device__ __forceinline__ void l2_warm_done(float (&d)[kWarmLines]) {
-#pragma unroll
-  for (int j = 0; j < kWarmLines; ++j) asm volatile("" ::"v"(d[j]));
-}
-#ifndef OSRL_PIN_ROWS
-#define OSRL_PIN_ROWS 5
-#endif
-constexpr int kPinRows = OSRL_PIN_ROWS;  // row blocks per tile from which mm_run pins its in-step instruction order
-
-// Every workgroup needs the SAME weight lines; each starts its k-walk at a different step so the
-// request streams are decorrelated (fp32 sum order changes per workgroup; fixed per (grid, tile)).
-// (wave index through readfirstlane: rot, every k index and the weight base address stay in SGPRs; a per-lane
-// k costs two 64-bit VALU multiply-adds per weight load, and VALU issue time adds to -- does not hide behind --
-// the MFMA time of the other waves on the SIMD: measured 2.7 VALU instructions per MFMA before this)
-__device__ __forceinline__ int k_rot(int nk) {
-  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  return (int)((blockIdx.x * 5u + blockIdx.y * 3u + w) % (unsigned)nk);
-}
-__device__ __forceinline__ int k_at(int kc, int rot, int nk, int kc0) {  // nk steps starting at kc0 (split-K sub-range)
-  const int k = kc + rot;
-  return kc0 + (k >= nk ? k - nk : k);
-}
-
-// experiment switches of tools/mlp_phase.hip (never defined in the product build)
-#ifdef OSRL_EXP_NO_MFMA
-__device__ __forceinline__ f32x4 EXP_MFMA(float a, float b, f32x4 c) {
-  c[0] += a * b;  // one VALU FMA keeps the operands alive; no matrix instruction
-  return c;
-}
-#else
-#define EXP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
-#endif
-#ifdef OSRL_EXP_NO_AREAD
-#define EXP_AREAD(p) (f32x4{(float)(size_t)(p), 1.f, 2.f, 3.f})
-#else
-#define EXP_AREAD(p) (*reinterpret_cast<const f32x4*>(p))
-#endif
 
 template <int RW, int CNT, int STAGES, int RD>
 __device__ __forceinline__ void mm_prefetch(f32x4 (&b)[RD][RW], int nk, const float* __restrict__ P, int Np, int col0,
@@ -803,461 +627,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
   }
 }
 
-// ---- N*B-row forward: 80-row tiles, ONE 4-wave workgroup per CU ------------------------------------------
-// The inference-only launches of a step (CPQ: target cost critics and the VAE encoder on the N*B = 20480 sampled
-// rows; BCQ-Lag / BEAR-Lag: decoder, actor, target critics on N*B rows) carry 69 % of the step's FLOPs.  With the tile
-// kernel above, 2-3 workgroups share a CU and the k-loop sits at 53-58 % of the fp32 MFMA roof; tools/loop_probe2.hip
-// shows why a different shape wins: ONE wave per SIMD with an 80-row x (64 | 112)-column register tile (80-140
-// accumulator registers out of the wave's 512) runs the same loop at 93-96 % -- 5 ds_read_b128 + 4-7
-// global_load_dwordx4 feed 80-140 MFMAs per k-step, weight traffic per FLOP is 2.5-5x lower than with 16/32-row tiles,
-// and with the in-step order pinned (loads of the next step first) one k-step of MFMAs (2560-4480 cycles) covers the
-// L2 latency with no second wave needed.
-// This kernel is that loop plus the least it needs around it: the input tile is staged with every load in flight at
-// once, each wide layer is  bias-initialised accumulators -> k-loop -> barrier -> activation into the LDS tile (in
-// place), the narrow head (<= 32 outputs, always the last layer) splits K over the 4 waves with all of a wave's weight
-// fragments requested together in front of its k-steps, partial tiles meet in LDS and go straight to global.
-// The wide layers compute the TRANSPOSED tile: the packed weight fragment is the MFMA's A operand and the activation
-// fragment its B operand (both are "16 lanes x 4 consecutive k", so loads and packing are those of the other kernels),
-// which leaves a lane with out[row = lane & 15][4 consecutive columns] -- exactly the row-major float4 the next
-// layer's fragment read wants.  The epilogue is then one ds_write_b128 per 16x16 tile in the (conflict-free) pattern
-// of the fragment reads, instead of four ds_write_b32 down a column; with the one-instruction ReLU and no column select
-// for widths that are multiples of 16 the epilogue of a 400-wide layer went from 4.85k to 2.7k cycles
-// (profiles/r2_mlp_phase_nb.txt).  Same products, same accumulation order per output: same bits.
-// Eligibility (host): no saved activations, hidden layers of 13-16 (NCB = 4) or 25-28 (NCB = 7) column blocks, narrow
-// last layer with >= 4 k-steps; anything else takes mlp_fwd_kernel.
-struct NbArgs {
-  osrl_mlp_t net;
-  osrl_rows_t in;
-  float* y[OSRL_MAX_NETS];
-  int32_t lda;
-};
-
-#ifndef OSRL_NB_INTERLEAVE
-#define OSRL_NB_INTERLEAVE 1
-#endif
-constexpr int kNbRb = 5;  // row blocks per tile (80 rows)
-
-// Biases of a wave's column blocks, branch-free (clamped address + select): every load is in flight at once.  The
-// obvious "col < N ? bias[col] : 0.f" compiles to one exec-masked global_load + s_waitcnt vmcnt(0) PER BLOCK, i.e.
-// 7 serial L2 round trips in front of every wide layer: ~9k of the ~10k cycles a layer took beyond its MFMAs
-// (profiles/r2_mlp_phase_nb.txt: the same excess for the 5-step and the 25-step layer).
-// nb_bias only REQUESTS the values (columns past N read bias[0]); nb_bias_acc, called after the first weight /
-// activation fragments are requested and fenced from them by a scheduling barrier, turns them into the accumulators'
-// start values (acc = bias: no add in the epilogue), so the bias round trip and the first weight round trip overlap.
-// (Accumulator tiles are TRANSPOSED, see nb_mm: a lane holds columns 4 * (lane >> 4) + 0..3 of column block c.)
-template <int CNT>
-__device__ __forceinline__ void nb_bias(const float* __restrict__ bias, int col0, int N, int lane, f32x4 (&braw)[CNT]) {
-#pragma unroll
-  for (int c = 0; c < CNT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col = col0 + c * 16 + 4 * (lane >> 4) + r;
-      braw[c][r] = bias[col < N ? col : 0];
-    }
-}
-template <int CNT, int R>
-__device__ __forceinline__ void nb_bias_acc(const f32x4 (&braw)[CNT], int col0, int N, int lane, f32x4 (&acc)[R][CNT]) {
-#pragma unroll
-  for (int c = 0; c < CNT; ++c) {
-    f32x4 bv;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = col0 + c * 16 + 4 * (lane >> 4) + r < N ? braw[c][r] : 0.f;
-#pragma unroll
-    for (int rb = 0; rb < R; ++rb) acc[rb][c] = bv;
-  }
-}
-
-template <int CNT>
-__device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
-                                      int N, const f32x4 (&braw)[CNT], f32x4 (&acc)[kNbRb][CNT], int pl) {
-  const int lane = threadIdx.x & 63;
-  const int m = lane & 15, kq = lane >> 4;
-  const float* arow = lds + m * lda + 4 * kq;
-  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
-  const int rot = k_rot(nk);
-  f32x4 b[2][CNT], a[2][kNbRb];
-  {
-    const int k0 = k_at(0, rot, nk, 0);
-    const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
-#pragma unroll
-    for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
-  if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
-  auto step = [&](auto s_c, int kc) {
-    constexpr int s = decltype(s_c)::value;
-    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
-    const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
-#pragma unroll
-    for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int c = 0; c < CNT; ++c)
-#pragma unroll
-        for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
-#if OSRL_NB_INTERLEAVE
-    // next step's loads one at a time, each followed by a few of THIS step's MFMAs: with one wave per SIMD nothing else
-    // can fill the MFMA pipe while the ~35 address / load instructions of a step issue (540 cycles per 16-deep k-step
-    // with all of them in front of the MFMAs)
-    constexpr int kPer = (4 * kNbRb * CNT) / (CNT + kNbRb + 1);
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < kNbRb; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT - kPer * (CNT + kNbRb), 0);
-#else
-    __builtin_amdgcn_sched_group_barrier(0x020, CNT, 0);                // VMEM reads of the next step first
-    __builtin_amdgcn_sched_group_barrier(0x100, kNbRb, 0);              // its DS reads
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT, 0);    // then this step's MFMAs
-#endif
-  };
-  using std::integral_constant;
-  int kc = 0;
-  for (; kc + 2 <= nk; kc += 2) {
-    step(integral_constant<int, 0>{}, kc);
-    step(integral_constant<int, 1>{}, kc + 1);
-  }
-  if (kc < nk) step(integral_constant<int, 0>{}, kc);
-}
-
-// R row blocks of CNT column blocks.  RAGGED (N not a multiple of 16): columns past N are written as zeros, the k
-// padding of the next layer; otherwise the select is compiled out (the epilogue is VALU-bound: accumulator read +
-// activation + select per element was ~36 cycles x 124 elements per wave and layer).
-template <int CNT, int R, int ACT, bool RAGGED>
-__device__ __forceinline__ void nb_epilogue_core(float* lds, int lda, const f32x4 (&acc)[R][CNT], int cb0, int rb0, int N,
-                                                 int lane) {
-#pragma unroll
-  for (int c = 0; c < CNT; ++c) {
-    const int col = (cb0 + c) * 16 + 4 * (lane >> 4);
-    float* dst = lds + (rb0 * 16 + (lane & 15)) * lda + col;
-#pragma unroll
-    for (int rb = 0; rb < R; ++rb) {
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = act_fwd(ACT, acc[rb][c][r]);
-        if (RAGGED) v[r] = col + r < N ? v[r] : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(dst + rb * 16 * lda) = v;
-    }
-  }
-}
-template <int CNT, int R>
-__device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&acc)[R][CNT], int cb0, int rb0, int N,
-                                            int act, int lane) {
-  const bool ragged = (N & 15) != 0;
-  if (act == OSRL_ACT_RELU) {
-    if (ragged) nb_epilogue_core<CNT, R, OSRL_ACT_RELU, true>(lds, lda, acc, cb0, rb0, N, lane);
-    else nb_epilogue_core<CNT, R, OSRL_ACT_RELU, false>(lds, lda, acc, cb0, rb0, N, lane);
-  } else if (act == OSRL_ACT_TANH) {
-    nb_epilogue_core<CNT, R, OSRL_ACT_TANH, true>(lds, lda, acc, cb0, rb0, N, lane);
-  } else {
-    nb_epilogue_core<CNT, R, OSRL_ACT_ID, true>(lds, lda, acc, cb0, rb0, N, lane);
-  }
-}
-
-template <int CNT>
-__device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
-                                              const float* __restrict__ bias, int act, int cb0, int lane, int pl) {
-  (void)pl;  // layer number, for the debug build's phase stamps only
-  f32x4 braw[CNT];
-  nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
-  f32x4 acc[kNbRb][CNT];
-  nb_mm<CNT>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
-  PHASE_STAMP(2 + 4 * pl);
-  __syncthreads();  // every wave finished reading the previous activations
-  PHASE_STAMP(3 + 4 * pl);
-  nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
-  PHASE_STAMP(4 + 4 * pl);
-  __syncthreads();
-  PHASE_STAMP(5 + 4 * pl);
-}
-
-// ---- 4q + 1 column blocks (400-wide layers: 25): every wave owns q blocks, the last block is SHARED by rows ----------
-// Dealing 25 blocks as 7 + 6 + 6 + 6 makes the 7-block wave the layer's pace: 12 % over the mean.  Here wave 0 takes
-// row blocks {0, 1} of the shared block, waves 1..3 one row block each: 32 / 31 / 31 / 31 register tiles.
-// NX = row blocks of the shared column this wave owns (2: wave 0, 1: the others), starting at rbx0.
-template <int CNT, int NX>
-__device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
-                                        int colx, int rbx0, int N, const f32x4 (&braw)[CNT], const f32x4 (&brawx)[1],
-                                        f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX], int pl) {
-  const int lane = threadIdx.x & 63;
-  const int m = lane & 15, kq = lane >> 4;
-  const float* arow = lds + m * lda + 4 * kq;
-  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
-  const unsigned lane_offx = (unsigned)((kq * Np + colx + m) * 16);
-  const int rot = k_rot(nk);
-  const float* arowx = arow + rbx0 * 16 * lda;  // the shared column's row blocks (wave-uniform start)
-  f32x4 b[2][CNT + 1], a[2][kNbRb], ax[2][NX];
-  {
-    const int k0 = k_at(0, rot, nk, 0);
-    const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
-#pragma unroll
-    for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
-    b[0][CNT] = load_bp_s(Pk, lane_offx);
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) ax[0][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + k0 * 16);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
-  {
-    f32x4 xa[NX][1];
-    nb_bias_acc<1, NX>(brawx, colx, N, lane, xa);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xacc[i] = xa[i][0];
-  }
-  if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
-  auto step = [&](auto s_c, int kc) {
-    constexpr int s = decltype(s_c)::value;
-    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
-    const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
-#pragma unroll
-    for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
-    b[s ^ 1][CNT] = load_bp_s(Pk, lane_offx);
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) ax[s ^ 1][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + kn * 16);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int c = 0; c < CNT; ++c)
-#pragma unroll
-        for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
-#pragma unroll
-      for (int i = 0; i < NX; ++i)
-        xacc[i] = EXP_MFMA(b[s][CNT][t], ax[s][i][t], xacc[i]);
-    }
-#if OSRL_NB_INTERLEAVE
-    constexpr int kTot = 4 * (kNbRb * CNT + NX), kPer = kTot / (CNT + 1 + kNbRb + NX + 1);
-#pragma unroll
-    for (int i = 0; i < CNT + 1; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < kNbRb + NX; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, kTot - kPer * (CNT + 1 + kNbRb + NX), 0);
-#else
-    __builtin_amdgcn_sched_group_barrier(0x020, CNT + 1, 0);                    // VMEM reads of the next step first
-    __builtin_amdgcn_sched_group_barrier(0x100, kNbRb + NX, 0);                 // its DS reads
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * (kNbRb * CNT + NX), 0);     // then this step's MFMAs
-#endif
-  };
-  using std::integral_constant;
-  int kc = 0;
-  for (; kc + 2 <= nk; kc += 2) {
-    step(integral_constant<int, 0>{}, kc);
-    step(integral_constant<int, 1>{}, kc + 1);
-  }
-  if (kc < nk) step(integral_constant<int, 0>{}, kc);
-}
-
-template <int CNT, int NX>
-__device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int N, const float* __restrict__ P,
-                                                const float* __restrict__ bias, int act, int cb0, int cbx, int rbx0,
-                                                int lane, int pl) {
-  (void)pl;
-  f32x4 acc[kNbRb][CNT], xacc[NX];
-  f32x4 braw[CNT], brawx[1];
-  nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
-  nb_bias<1>(bias, cbx * 16, N, lane, brawx);
-  nb_mm_x<CNT, NX>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl);
-  PHASE_STAMP(2 + 4 * pl);
-  __syncthreads();  // every wave finished reading the previous activations
-  PHASE_STAMP(3 + 4 * pl);
-  nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
-  {
-    f32x4 xa[NX][1];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xa[i][0] = xacc[i];
-    nb_epilogue<1, NX>(lds, lda, xa, cbx, rbx0, N, act, lane);
-  }
-  PHASE_STAMP(4 + 4 * pl);
-  __syncthreads();
-  PHASE_STAMP(5 + 4 * pl);
-}
-
-// SHARED: every wide layer has 4 (NCB - 1) + 1 column blocks (the 400-wide VAE encoder / decoder): NCB - 1 blocks per
-// wave + the row-shared last block (nb_wide_layer_x); a separate instantiation, so that neither form carries the
-// other's register footprint
-template <int NCB, bool SHARED, class AR>
-__device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int BM = 16 * kNbRb;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int e = blockIdx.y, row0 = blockIdx.x * BM;
-  const int rows = a.in.rows, lda = a.lda, L = a.net.n_layers;
-  WG_LOG(0);
-  PHASE_STAMP(0);
-  {  // ---- stage cat(src0[map0(r)], src1[map1(r)]) zero padded to a multiple of 16 columns: every load of the tile
-     // is issued before the first LDS store.  16 lanes walk one row (64-byte segments), 16 rows per pass, 5 passes;
-     // no per-element division (80 x K0p / 256 of them cost 23k cycles in the first version of this kernel).
-    const int K0 = a.net.dims[0], K0p = round16(K0);
-    const int d0 = a.in.d0, d1 = a.in.d1;
-    const int cl = tid & 15, rl = tid >> 4;
-    const float* __restrict__ s0 = a.in.src0;
-    const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
-    constexpr int kColChunks = 8;  // K0 <= 128 (host-checked)
-    // the row maps as straight-line code on values read ONCE: one unsigned division per (row, source) whose
-    // reciprocal set-up is common to the five passes, selects instead of the three-way branch of map_row().  (With
-    // map_row() inlined per pass the compiler re-read the descriptor from the kernel arguments in every branch arm:
-    // ~20 s_load + s_waitcnt lgkmcnt(0) round trips in front of the tile's loads.)
-    // The values are parked in VECTOR registers (the opaque asm makes them non-rematerialisable): there are plenty
-    // before the accumulators exist, while the scalar file is full of layer descriptors by now.
-    unsigned dv0 = a.in.map0 == OSRL_MAP_ID ? 1u : (unsigned)a.in.div0;
-    unsigned dv1 = a.in.map1 == OSRL_MAP_ID ? 1u : (unsigned)a.in.div1;
-    unsigned mod0 = a.in.map0 == OSRL_MAP_MOD, idn0 = a.in.map0 == OSRL_MAP_ID;
-    unsigned mod1 = a.in.map1 == OSRL_MAP_MOD, idn1 = a.in.map1 == OSRL_MAP_ID;
-    int d0v = d0, d1v = d1, rows_v = rows, K0v = K0;
-    asm volatile("" : "+v"(dv0), "+v"(dv1), "+v"(mod0), "+v"(idn0), "+v"(mod1), "+v"(idn1));
-    asm volatile("" : "+v"(d0v), "+v"(d1v), "+v"(rows_v), "+v"(K0v));
-    auto mapped = [](unsigned r, unsigned mod, unsigned idn, unsigned dv) -> unsigned {
-      const unsigned q = r / dv, rem = r - q * dv;  // dv == 1 for the identity map
-      return mod ? rem : (idn ? r : q);
-    };
-    float v[kNbRb][kColChunks];
-#pragma unroll
-    for (int p = 0; p < kNbRb; ++p) {
-      const int gr = row0 + p * 16 + rl;
-      const bool rok = gr < rows_v;
-      const unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
-      const float* p0 = s0 + (size_t)mapped(grc, mod0, idn0, dv0) * d0v;
-      const float* p1 = s1 + (size_t)mapped(grc, mod1, idn1, dv1) * d1v - d0v;
-#pragma unroll
-      for (int j = 0; j < kColChunks; ++j) {
-        const int c = j * 16 + cl;
-        const bool ok = rok && c < K0;
-        const float* q = c < d0 ? p0 + c : p1 + c;
-        v[p][j] = *(ok ? q : s0);
-        v[p][j] = ok ? v[p][j] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < kNbRb; ++p)
-#pragma unroll
-      for (int j = 0; j < kColChunks; ++j) {
-        const int c = j * 16 + cl;
-        if (c < K0p) lds[(p * 16 + rl) * lda + c] = v[p][j];
-      }
-    __syncthreads();
-  }
-  PHASE_STAMP(1);
-  for (int l = 0; l + 1 < L; ++l) {  // wide layers
-    const int K = a.net.dims[l], N = a.net.dims[l + 1];
-    const int nblk = (N + 15) >> 4;
-    if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
-      const int q = nblk >> 2;
-      if (wave == 0)
-        nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane, l);
-      else
-        nb_wide_layer_x<NCB - 1, 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, 4 * q,
-                                    wave + 1, lane, l);
-    } else {
-      int cb0, cnt;
-      wave_blocks<4>(nblk, wave, &cb0, &cnt);
-      if (cnt == NCB)
-        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
-      else
-        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
-    }
-  }
-  {  // ---- narrow head: K split over the 4 waves, every weight fragment of a wave's share loaded up front
-    const int l = L - 1;
-    const int K = a.net.dims[l], N = a.net.dims[l + 1];
-    const int Np = round16(N), nblk = Np >> 4, nk = round16(K) >> 4;
-    const int k_lo = (nk * wave) / 4, k_hi = (nk * (wave + 1)) / 4;
-    constexpr int kMaxSteps = 8;  // nk <= 32 (widths <= 448 -> nk <= 28 -> <= 7 steps per wave)
-    const float* __restrict__ P = a.net.Wf[e][l];
-    const int m = lane & 15, kq = lane >> 4;
-    f32x4 t[kNbRb][2];
-#pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) t[rb][0] = t[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bw[kMaxSteps][2];
-#pragma unroll
-    for (int sI = 0; sI < kMaxSteps; ++sI) {
-      const int ks = k_lo + sI < k_hi ? k_lo + sI : k_hi - 1;
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-        bw[sI][c] = (c < nblk) ? *reinterpret_cast<const f32x4*>(P + ((size_t)(ks * 4 + kq) * Np + c * 16 + m) * 4)
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float* arow = lds + m * lda + 4 * kq;
-#pragma unroll
-    for (int sI = 0; sI < kMaxSteps; ++sI) {
-      if (k_lo + sI < k_hi) {
-        const int ks = k_lo + sI;
-        f32x4 af[kNbRb];
-#pragma unroll
-        for (int rb = 0; rb < kNbRb; ++rb) af[rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ks * 16);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int rb = 0; rb < kNbRb; ++rb) {
-            t[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rb][tt], bw[sI][0][tt], t[rb][0], 0, 0, 0);
-            if (nblk > 1) t[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rb][tt], bw[sI][1][tt], t[rb][1], 0, 0, 0);
-          }
-      }
-    }
-    PHASE_STAMP(2 + 4 * l);
-    __syncthreads();  // all reads of the activations are done: the tile's first 4 * Np columns take the partials
-    PHASE_STAMP(3 + 4 * l);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-      if (c < nblk) {
-#pragma unroll
-        for (int rb = 0; rb < kNbRb; ++rb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            lds[(rb * 16 + kq * 4 + r) * lda + wave * Np + c * 16 + m] = t[rb][c][r];
-      }
-    __syncthreads();
-    PHASE_STAMP(4 + 4 * l);
-    const float* __restrict__ bias = a.net.b[e][l];
-    const int act = a.net.acts[l];
-    const float oscale = a.net.out_scale;
-    float* __restrict__ y = a.y[e];
-    for (int idx = tid; idx < BM * N; idx += 256) {
-      const int r = idx / N, c = idx - r * N;
-      if (row0 + r < rows) {
-        const float* p = lds + r * lda + c;
-        const float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
-        y[(size_t)(row0 + r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
-      }
-    }
-    PHASE_STAMP(5 + 4 * l);
-  }
-  WG_LOG(1);
-}
-template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
-  mlp_fwd_nb_body<NCB, SHARED, const NbArgs&>(a);
-}
-template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel_p(const void* p) {
-  mlp_fwd_nb_body<NCB, SHARED, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
-}
-
 struct BwdArgs {
   osrl_mlp_t net;
   osrl_mlp_acts_t saved;
@@ -1669,7 +1038,7 @@ template <int T>
 constexpr size_t dwt_lds() { return sizeof(float) * (4 * (16 * T) * (16 * T + 1) + 4 * 16 * T); }
 
 // One work item: the four waves' partials of a tile go to LDS (red: [4][16T][16T+1] + [4][16T] bias partials), then
-// epi(E, o0, i0, split, want_db) consumes them after a barrier: the slab store of mlp_dwt_kernel, or the optimizer
+// epi(E, o0, i0, split | n_splits << 16, want_db) consumes them after a barrier: the slab store of mlp_dwt_kernel, or the optimizer
 // step itself when the item covers all rows (mlp_step_kernel).  Waves beyond the first four (a wider workgroup) only
 // take part in the barrier and the epilogue.
 // WARM (experiment, off: every lane first touches the 128-byte lines of its wave's row range -- measured 7.5 -> 9.7 us
@@ -1802,7 +1171,7 @@ __device__ __forceinline__ void dwt_tile(const osrl_dw_entry_t* __restrict__ ent
   }
   }  // wave < 4
   __syncthreads();
-  epi(E, o0, i0, s, want_db);
+  epi(E, o0, i0, sp, want_db);
 }
 
 template <int T>
@@ -1816,9 +1185,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
   if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
 #endif
   dwt_tile<T>(entries, items, blockIdx.x, rows, red,
-              [&](const OSRL_CAS osrl_dw_entry_t& E, const int o0, const int i0, const int s, const bool want_db) {
+              [&](const OSRL_CAS osrl_dw_entry_t& E, const int o0, const int i0, const int sp, const bool want_db) {
     const int out = E.out, in = E.in;
-    float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+    float* __restrict__ slab = slabs + (size_t)(sp & 0xffff) * slab_stride;
     for (int idx = tid; idx < TW * TW; idx += 256) {
       const int ol = idx / TW, il = idx - ol * TW;
       const int off = ol * LD + il;
@@ -1835,6 +1204,206 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
 }
 
 
+
+
+// ---- dW + the optimizer step of its group in ONE launch (osrl_mlp_backward_dw_tiles_adam) ------------------------
+// The (tile, row split) workgroups of mlp_dwt_kernel, and the LAST split of a tile to finish applies Adam (+ Polyak +
+// the packed-copy refresh) to that tile's parameters right there: every split stores its slab tile (device-coherent
+// stores), waits for their acknowledgement and signs in at the tile's arrival counter; the workgroup that finds all
+// other splits signed in reads the tile's slabs back (device-coherent loads), sums them IN SLAB ORDER -- the order
+// of optim.hip's adam_body -- and runs osrl_adam::update1 on the sum, i.e. parameters, moments, targets and packed
+// copies get the same bits as from osrl_mlp_backward_dw_tiles + osrl_adam_step_packed.  What it removes from a train
+// step: one launch per optimizer group (four on the CPQ step's chains, 6.6-10 us each plus what they lose beside an
+// N*B-row launch), the slab re-read by a second grid, and the full-group pass over padding.  A tile with ONE split
+// needs no counter and no slab: its gradient is complete in LDS (the BC one-launch step's epilogue).
+// The wait-free form matters: nobody spins -- a workgroup either is the last one or leaves -- so the launch makes no
+// assumption about co-residency or dispatch order (cf. mlp_step_kernel's bounded poll).
+struct DwAdamArgs {
+  const osrl_dw_entry_t* entries;
+  const int32_t* items;
+  const int32_t* tile_ids;  // [n_work] arrival counter of each item's tile
+  uint32_t* counters;       // [n_tiles] zero before the first launch; the last arriver of a tile re-arms it
+  float* slabs;
+  int64_t slab_stride;
+  float *p, *m, *v, *tgt;
+  const int32_t *map_f, *map_b;
+  float *pf, *pb, *tf;
+  const osrl_step_state_t* st;
+  float lr, b1, b2, eps, tau;
+  int32_t rows, pad_;
+};
+
+// device-coherent slab words (see the exchange in mlp_dwt_adam_body)
+__device__ __forceinline__ void slab_put(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float slab_get(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int T, class AR>
+__device__ __forceinline__ void mlp_dwt_adam_body(AR a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][16T][16T+1] partials + [4][16T] bias partials
+  __shared__ int s_last;
+  constexpr int TW = 16 * T, LD = TW + 1;
+  constexpr int PER = (TW * TW + 255) / 256;  // elements of the tile per lane (T = 5: 25, 4: 16, 3: 9, 2: 4)
+  const int tid = threadIdx.x;
+  const int rows = a.rows;
+#if OSRL_CHAIN_PRIO > 0
+  if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
+  const int item = blockIdx.x;
+  dwt_tile<T>(a.entries, a.items, item, rows, red,
+              [&](const OSRL_CAS osrl_dw_entry_t& E, const int o0, const int i0, const int sp, const bool want_db) {
+    const int out = E.out, in = E.in;
+    const int s = sp & 0xffff, nsp = sp >> 16;
+    float* __restrict__ slabs = a.slabs;
+    const int64_t stride = a.slab_stride;
+    const int64_t w_off = E.w_off, b_off = E.b_off;
+    float* __restrict__ P = a.p;
+    float* __restrict__ M = a.m;
+    float* __restrict__ V = a.v;
+    float* TG = a.tgt;
+    const int32_t* MF = a.map_f;
+    const int32_t* MB = a.map_b;
+    const float* TGr = TG ? TG : P;  // absent target / maps re-read p: no branch around a load
+    const int32_t* MFr = MF ? MF : reinterpret_cast<const int32_t*>(P);
+    const int32_t* MBr = MB ? MB : reinterpret_cast<const int32_t*>(P);
+    // ---- (every split) the optimizer state of this tile's elements is REQUESTED before the slab tile is stored and the
+    // arrival is counted: it does not depend on the other splits, and its round trip then runs under the store + release
+    // + atomic sequence instead of behind the acquire, where only the slabs remain to be fetched.  (The splits that turn
+    // out not to be the last one waste these loads: 24 B per element and split, L2 hits after the first.)
+    unsigned w[PER];
+    bool ok[PER];
+    int offl[PER];
+    float pv[PER], mv[PER], vv[PER], tv0[PER];
+    int mf[PER], mb[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int idx = tid + j * 256;
+      const int ol = idx / TW, il = idx - ol * TW;
+      const int o = o0 + ol, i = i0 + il;
+      ok[j] = idx < TW * TW && o < out && i < in;
+      w[j] = (unsigned)(ok[j] ? w_off + (int64_t)o * in + i : w_off);  // (groups are < 2^32 floats)
+      offl[j] = ok[j] ? ol * LD + il : 0;
+      pv[j] = P[w[j]];
+      mv[j] = M[w[j]];
+      vv[j] = V[w[j]];
+      tv0[j] = TGr[w[j]];
+      mf[j] = MFr[w[j]];
+      mb[j] = MBr[w[j]];
+    }
+    const bool has_b = want_db && tid < TW && o0 + tid < out;
+    const unsigned wb = (unsigned)(b_off + (has_b ? o0 + tid : 0));
+    float pb_ = P[wb], mb_ = M[wb], vb_ = V[wb], tb_ = TGr[wb];
+    if (nsp > 1) {
+      float* __restrict__ slab = slabs + (size_t)s * stride;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int off = offl[j];
+        const float v = ((red[off] + red[TW * LD + off]) + red[2 * TW * LD + off]) + red[3 * TW * LD + off];
+        if (ok[j]) slab_put(slab + w[j], v);
+      }
+      if (has_b) {
+        const float* db = red + 4 * TW * LD;
+        slab_put(slab + wb, ((db[tid] + db[TW + tid]) + db[2 * TW + tid]) + db[3 * TW + tid]);
+      }
+      // The slab tile is exchanged between workgroups on different XCDs (each with its own L2) INSIDE the launch.  The
+      // textbook form -- release fence (write back the whole L2), count, acquire fence (invalidate the whole L2) -- cost
+      // this launch 15-30 us (224-448 workgroups each writing back an L2 that the others are still filling, the last
+      // arrivers' invalidates evicting everybody's operand lines).  Instead the slab words themselves are device-coherent
+      // accesses (relaxed agent-scope atomics = sc1 stores / loads: written through to, and read from, the level all
+      // XCDs share), the arrival is counted once every wave's stores are acknowledged, and no cache is touched.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        unsigned* c = a.counters + a.tile_ids[item];
+        const unsigned seen = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = seen == (unsigned)nsp - 1;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every split signed in: re-arm
+        s_last = last;
+      }
+      __syncthreads();
+      if (!s_last) return;
+    }
+    // ---- the optimizer step on this tile (optim.hip adam_body, element for element)
+    const osrl_step_state_t* __restrict__ st = a.st;
+    const float lr_t = a.lr * st->lr_scale;
+    const osrl_adam::Coef c{a.b1, a.b2, a.eps, lr_t / st->bc1, st->bc2_sqrt};
+    const float tau = a.tau;
+    auto apply = [&](const unsigned wi, const float g, float p_, float m_, float v_, const float t0, const int mfi,
+                     const int mbi) {
+      osrl_adam::update1(p_, m_, v_, g, c);
+      P[wi] = p_;
+      M[wi] = m_;
+      V[wi] = v_;
+      float tv = p_;
+      if (TG) {
+        tv = osrl_adam::polyak1(tau, p_, t0);
+        TG[wi] = tv;
+      }
+      if (MF && mfi >= 0) {
+        a.pf[mfi] = p_;
+        if (TG && a.tf) a.tf[mfi] = tv;
+      }
+      if (MF && MB && mbi >= 0) a.pb[mbi] = p_;
+    };
+    float g[PER], gb = 0.f;
+    if (nsp > 1) {
+      // every slab value of the tile requested at once (KS slabs per element in flight, slabs past nsp re-read slab 0 and
+      // are dropped by a select): ONE round trip behind the acquire; summed in slab order like adam_body
+      auto gather = [&](auto ks_c) {
+        constexpr int KS = decltype(ks_c)::value;
+        float sl[PER][KS], sb[KS];
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+          for (int q = 0; q < KS; ++q) sl[j][q] = slab_get(slabs + (size_t)(q < nsp ? q : 0) * stride + w[j]);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) sb[q] = slab_get(slabs + (size_t)(q < nsp ? q : 0) * stride + wb);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          g[j] = sl[j][0];
+#pragma unroll
+          for (int q = 1; q < KS; ++q)
+            if (q < nsp) g[j] += sl[j][q];
+          for (int q = KS; q < nsp; ++q) g[j] += slab_get(slabs + (size_t)q * stride + w[j]);
+        }
+        gb = sb[0];
+#pragma unroll
+        for (int q = 1; q < KS; ++q)
+          if (q < nsp) gb += sb[q];
+        for (int q = KS; q < nsp; ++q) gb += slab_get(slabs + (size_t)q * stride + wb);
+      };
+      // (80 x 80 tiles carry 25 elements per lane: 8 slabs each in flight on top of their state would spill)
+      if (nsp <= 4 || PER > 16)
+        gather(std::integral_constant<int, 4>{});
+      else
+        gather(std::integral_constant<int, 8>{});
+    } else {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int off = offl[j];
+        g[j] = ((red[off] + red[TW * LD + off]) + red[2 * TW * LD + off]) + red[3 * TW * LD + off];
+      }
+      const float* db = red + 4 * TW * LD;
+      const int tb = has_b ? tid : 0;
+      gb = ((db[tb] + db[TW + tb]) + db[2 * TW + tb]) + db[3 * TW + tb];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (ok[j]) apply(w[j], g[j], pv[j], mv[j], vv[j], tv0[j], mf[j], mb[j]);
+    if (has_b) apply(wb, gb, pb_, mb_, vb_, tb_, -1, -1);
+  });
+}
+template <int T>
+__global__ __launch_bounds__(256, 1) void mlp_dwt_adam_kernel(const DwAdamArgs a) {
+  mlp_dwt_adam_body<T, const DwAdamArgs&>(a);
+}
+template <int T>
+__global__ __launch_bounds__(256, 1) void mlp_dwt_adam_kernel_p(const void* p) {
+  mlp_dwt_adam_body<T, const OSRL_CAS DwAdamArgs&>(*(const OSRL_CAS DwAdamArgs*)p);
+}
 
 
 // ---- dW for big row counts: one wave = one 128x128 tile, one wave per SIMD ------------------------------------
@@ -2341,59 +1910,6 @@ bool valid_net(const osrl_mlp_t* n) {
 }
 
 
-constexpr int kNotBig = -12345;
-constexpr size_t kLdsMax = 160 * 1024;
-
-// ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
-template <int NCB, bool SHARED = false>
-static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
-  const void* dev_args = osrl_argmem::slot(a);
-  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED>)
-                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return (int)e;
-  (void)hipGetLastError();
-  if (dev_args)
-    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
-  else
-    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
-  return (int)hipGetLastError();
-}
-
-static int launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream) {
-  const int L = net->n_layers, nets = net->n_nets;
-  if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNotBig;
-  for (int e = 0; e < nets; ++e)
-    for (int l = 0; l + 1 < L; ++l)
-      if (out->h[e][l]) return kNotBig;  // training launches keep hidden activations: mlp_fwd_kernel
-  int ncb = 0, wmax = net->dims[0];
-  for (int l = 0; l + 1 < L; ++l) {  // wide layers: every wave owns NCB or NCB - 1 column blocks
-    const int N = net->dims[l + 1], nblk = (N + 15) / 16;
-    const int need = nblk >= 13 && nblk <= 16 ? 4 : nblk >= 25 && nblk <= 28 ? 7 : 0;
-    if (!need || (ncb && need != ncb)) return kNotBig;
-    ncb = need;
-    wmax = N > wmax ? N : wmax;
-  }
-  const int NL = net->dims[L], nkl = (((net->dims[L - 1] + 15) & ~15) >> 4);
-  if (NL > 32 || nkl < 4 || nkl > 32) return kNotBig;  // narrow head, K split over 4 waves (<= 8 steps each)
-  const int lda = ((wmax + 15) & ~15) + 8;
-  if (lda < 4 * ((NL + 15) & ~15)) return kNotBig;  // the head's 4 partial tiles live in the activation tile
-  size_t lds_bytes = (size_t)80 * lda * sizeof(float);
-  if (lds_bytes <= 80 * 1024) lds_bytes = 80 * 1024 + 256;  // more than half of the 160 KB: one workgroup per CU
-  if (lds_bytes > kLdsMax) return kNotBig;
-  NbArgs a{};
-  a.net = *net;
-  a.in = *in;
-  for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
-  a.lda = lda;
-  const int tiles = (in->rows + 79) / 80;
-  bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
-  for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;
-  if (shared) return launch_nb<7, true>(a, tiles, nets, lds_bytes, stream);
-  return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
-}
-
-
 // ---- one supervised regression step of one MLP in ONE launch (osrl_mlp_regress_step) ---------------------------
 // BC at B = 256 (bc.py:45-55,103-109) is six dependent launches of 2-8 us of work each: the step is its launch gaps.
 // Here workgroup w < n_tiles owns rows [16 w, 16 w + 16): it draws and gathers them (the replay sampler's indices are a
@@ -2691,8 +2207,8 @@ static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const 
   const bool want_tail = tail && tail->kind != OSRL_TAIL_NONE;
   if (want_tail && !fwd_tail_ok(tail, net)) return -1;
   {
-    const int rc = launch_fwd_nb(net, in, out, (hipStream_t)stream);
-    if (rc != kNotBig) {  // the 80-row kernel keeps no output tile in LDS: the tail is its own launch
+    const int rc = osrl_launch_fwd_nb(net, in, out, (hipStream_t)stream);
+    if (rc != kNbNotTaken) {  // the 80-row kernel keeps no output tile in LDS: the tail is its own launch
       if (rc != 0 || !want_tail) return rc;
       return fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
     }
@@ -3082,6 +2598,49 @@ extern "C" int osrl_mlp_backward_dw_tiles(const osrl_dw_entry_t* d_entries, cons
   // 80-row forward workgroup (which leaves a 64 x 64 tile's 68 KB no room)
   if (tile_blocks == 3) return launch_dwt<3>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
   if (tile_blocks == 2) return launch_dwt<2>(d_entries, d_work, n_work, rows, slabs, slab_stride, (hipStream_t)stream);
+  return -1;
+}
+
+template <int T>
+static int launch_dwt_adam(const DwAdamArgs& a, int32_t n_work, hipStream_t stream) {
+  const void* dev_args = osrl_argmem::slot(a);
+  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_dwt_adam_kernel_p<T>)
+                                              : reinterpret_cast<const void*>(mlp_dwt_adam_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dwt_lds<T>());
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  if (dev_args)
+    hipLaunchKernelGGL(mlp_dwt_adam_kernel_p<T>, dim3(n_work), dim3(256), dwt_lds<T>(), stream, dev_args);
+  else
+    hipLaunchKernelGGL(mlp_dwt_adam_kernel<T>, dim3(n_work), dim3(256), dwt_lds<T>(), stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_mlp_backward_dw_tiles_adam(const osrl_dw_entry_t* d_entries, const int32_t* d_work,
+                                               const int32_t* d_tile_ids, uint32_t* d_counters, int32_t n_work,
+                                               int32_t rows, int32_t tile_blocks, float* slabs, int64_t slab_stride,
+                                               const osrl_dw_adam_t* o, void* stream) {
+  if (!d_entries || !d_work || !d_tile_ids || !d_counters || n_work < 1 || rows < 1 || !slabs || !o) return -1;
+  if (!o->p || !o->m || !o->v || !o->st || (o->map_f && !o->pf) || (o->map_b && (!o->pb || !o->map_f))) return -1;
+  DwAdamArgs a{};
+  a.entries = d_entries;
+  a.items = d_work;
+  a.tile_ids = d_tile_ids;
+  a.counters = d_counters;
+  a.slabs = slabs;
+  a.slab_stride = slab_stride;
+  a.p = o->p; a.m = o->m; a.v = o->v; a.tgt = o->tgt;
+  a.map_f = o->map_f; a.map_b = o->map_b;
+  a.pf = o->pf; a.pb = o->pb; a.tf = o->tgt ? o->tf : nullptr;
+  a.st = o->st;
+  a.lr = o->lr; a.b1 = o->beta1; a.b2 = o->beta2; a.eps = o->eps; a.tau = o->tau;
+  a.rows = rows;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipStream_t st = (hipStream_t)stream;
+  if (tile_blocks == 5) return launch_dwt_adam<5>(a, n_work, st);
+  if (tile_blocks == 4) return launch_dwt_adam<4>(a, n_work, st);
+  if (tile_blocks == 3) return launch_dwt_adam<3>(a, n_work, st);
+  if (tile_blocks == 2) return launch_dwt_adam<2>(a, n_work, st);
   return -1;
 }
 

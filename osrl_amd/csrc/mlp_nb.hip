@@ -1,0 +1,512 @@
+// mlp_nb.hip -- the N*B-row forward of the fused MLP (80-row tiles, one workgroup per CU) for gfx950.
+// Split from mlp.hip (round 4) so that the two units compile side by side; design notes at the kernel below and in
+// mlp.hip's header.
+#include "mlp_common.h"
+
+namespace {
+
+// ---- N*B-row forward: 80-row tiles, ONE 4-wave workgroup per CU ------------------------------------------
+// The inference-only launches of a step (CPQ: target cost critics and the VAE encoder on the N*B = 20480 sampled
+// rows; BCQ-Lag / BEAR-Lag: decoder, actor, target critics on N*B rows) carry 69 % of the step's FLOPs.  With the tile
+// kernel above, 2-3 workgroups share a CU and the k-loop sits at 53-58 % of the fp32 MFMA roof; tools/loop_probe2.hip
+// shows why a different shape wins: ONE wave per SIMD with an 80-row x (64 | 112)-column register tile (80-140
+// accumulator registers out of the wave's 512) runs the same loop at 93-96 % -- 5 ds_read_b128 + 4-7
+// global_load_dwordx4 feed 80-140 MFMAs per k-step, weight traffic per FLOP is 2.5-5x lower than with 16/32-row tiles,
+// and with the in-step order pinned (loads of the next step first) one k-step of MFMAs (2560-4480 cycles) covers the
+// L2 latency with no second wave needed.
+// This kernel is that loop plus the least it needs around it: the input tile is staged with every load in flight at
+// once, each wide layer is  bias-initialised accumulators -> k-loop -> barrier -> activation into the LDS tile (in
+// place), the narrow head (<= 32 outputs, always the last layer) splits K over the 4 waves with all of a wave's weight
+// fragments requested together in front of its k-steps, partial tiles meet in LDS and go straight to global.
+// The wide layers compute the TRANSPOSED tile: the packed weight fragment is the MFMA's A operand and the activation
+// fragment its B operand (both are "16 lanes x 4 consecutive k", so loads and packing are those of the other kernels),
+// which leaves a lane with out[row = lane & 15][4 consecutive columns] -- exactly the row-major float4 the next
+// layer's fragment read wants.  The epilogue is then one ds_write_b128 per 16x16 tile in the (conflict-free) pattern
+// of the fragment reads, instead of four ds_write_b32 down a column; with the one-instruction ReLU and no column select
+// for widths that are multiples of 16 the epilogue of a 400-wide layer went from 4.85k to 2.7k cycles
+// (profiles/r2_mlp_phase_nb.txt).  Same products, same accumulation order per output: same bits.
+// Eligibility (host): no saved activations, hidden layers of 13-16 (NCB = 4) or 25-28 (NCB = 7) column blocks, narrow
+// last layer with >= 4 k-steps; anything else takes mlp_fwd_kernel.
+struct NbArgs {
+  osrl_mlp_t net;
+  osrl_rows_t in;
+  float* y[OSRL_MAX_NETS];
+  int32_t lda;
+};
+
+#ifndef OSRL_NB_INTERLEAVE
+#define OSRL_NB_INTERLEAVE 1
+#endif
+constexpr int kNbRb = 5;  // row blocks per tile (80 rows)
+
+// Biases of a wave's column blocks, branch-free (clamped address + select): every load is in flight at once.  The
+// obvious "col < N ? bias[col] : 0.f" compiles to one exec-masked global_load + s_waitcnt vmcnt(0) PER BLOCK, i.e.
+// 7 serial L2 round trips in front of every wide layer: ~9k of the ~10k cycles a layer took beyond its MFMAs
+// (profiles/r2_mlp_phase_nb.txt: the same excess for the 5-step and the 25-step layer).
+// nb_bias only REQUESTS the values (columns past N read bias[0]); nb_bias_acc, called after the first weight /
+// activation fragments are requested and fenced from them by a scheduling barrier, turns them into the accumulators'
+// start values (acc = bias: no add in the epilogue), so the bias round trip and the first weight round trip overlap.
+// (Accumulator tiles are TRANSPOSED, see nb_mm: a lane holds columns 4 * (lane >> 4) + 0..3 of column block c.)
+template <int CNT>
+__device__ __forceinline__ void nb_bias(const float* __restrict__ bias, int col0, int N, int lane, f32x4 (&braw)[CNT]) {
+#pragma unroll
+  for (int c = 0; c < CNT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = col0 + c * 16 + 4 * (lane >> 4) + r;
+      braw[c][r] = bias[col < N ? col : 0];
+    }
+}
+template <int CNT, int R>
+__device__ __forceinline__ void nb_bias_acc(const f32x4 (&braw)[CNT], int col0, int N, int lane, f32x4 (&acc)[R][CNT]) {
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) {
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = col0 + c * 16 + 4 * (lane >> 4) + r < N ? braw[c][r] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) acc[rb][c] = bv;
+  }
+}
+
+template <int CNT>
+__device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
+                                      int N, const f32x4 (&braw)[CNT], f32x4 (&acc)[kNbRb][CNT], int pl) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* arow = lds + m * lda + 4 * kq;
+  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
+  const int rot = k_rot(nk);
+  f32x4 b[2][CNT], a[2][kNbRb];
+  {
+    const int k0 = k_at(0, rot, nk, 0);
+    const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
+  if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
+  auto step = [&](auto s_c, int kc) {
+    constexpr int s = decltype(s_c)::value;
+    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
+    const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb)
+          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
+#if OSRL_NB_INTERLEAVE
+    // next step's loads one at a time, each followed by a few of THIS step's MFMAs: with one wave per SIMD nothing else
+    // can fill the MFMA pipe while the ~35 address / load instructions of a step issue (540 cycles per 16-deep k-step
+    // with all of them in front of the MFMAs)
+    constexpr int kPer = (4 * kNbRb * CNT) / (CNT + kNbRb + 1);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kNbRb; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT - kPer * (CNT + kNbRb), 0);
+#else
+    __builtin_amdgcn_sched_group_barrier(0x020, CNT, 0);                // VMEM reads of the next step first
+    __builtin_amdgcn_sched_group_barrier(0x100, kNbRb, 0);              // its DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT, 0);    // then this step's MFMAs
+#endif
+  };
+  using std::integral_constant;
+  int kc = 0;
+  for (; kc + 2 <= nk; kc += 2) {
+    step(integral_constant<int, 0>{}, kc);
+    step(integral_constant<int, 1>{}, kc + 1);
+  }
+  if (kc < nk) step(integral_constant<int, 0>{}, kc);
+}
+
+// R row blocks of CNT column blocks.  RAGGED (N not a multiple of 16): columns past N are written as zeros, the k
+// padding of the next layer; otherwise the select is compiled out (the epilogue is VALU-bound: accumulator read +
+// activation + select per element was ~36 cycles x 124 elements per wave and layer).
+template <int CNT, int R, int ACT, bool RAGGED>
+__device__ __forceinline__ void nb_epilogue_core(float* lds, int lda, const f32x4 (&acc)[R][CNT], int cb0, int rb0, int N,
+                                                 int lane) {
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) {
+    const int col = (cb0 + c) * 16 + 4 * (lane >> 4);
+    float* dst = lds + (rb0 * 16 + (lane & 15)) * lda + col;
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = act_fwd(ACT, acc[rb][c][r]);
+        if (RAGGED) v[r] = col + r < N ? v[r] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dst + rb * 16 * lda) = v;
+    }
+  }
+}
+template <int CNT, int R>
+__device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&acc)[R][CNT], int cb0, int rb0, int N,
+                                            int act, int lane) {
+  const bool ragged = (N & 15) != 0;
+  if (act == OSRL_ACT_RELU) {
+    if (ragged) nb_epilogue_core<CNT, R, OSRL_ACT_RELU, true>(lds, lda, acc, cb0, rb0, N, lane);
+    else nb_epilogue_core<CNT, R, OSRL_ACT_RELU, false>(lds, lda, acc, cb0, rb0, N, lane);
+  } else if (act == OSRL_ACT_TANH) {
+    nb_epilogue_core<CNT, R, OSRL_ACT_TANH, true>(lds, lda, acc, cb0, rb0, N, lane);
+  } else {
+    nb_epilogue_core<CNT, R, OSRL_ACT_ID, true>(lds, lda, acc, cb0, rb0, N, lane);
+  }
+}
+
+template <int CNT>
+__device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
+                                              const float* __restrict__ bias, int act, int cb0, int lane, int pl) {
+  (void)pl;  // layer number, for the debug build's phase stamps only
+  f32x4 braw[CNT];
+  nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
+  f32x4 acc[kNbRb][CNT];
+  nb_mm<CNT>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
+  PHASE_STAMP(2 + 4 * pl);
+  __syncthreads();  // every wave finished reading the previous activations
+  PHASE_STAMP(3 + 4 * pl);
+  nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
+  PHASE_STAMP(4 + 4 * pl);
+  __syncthreads();
+  PHASE_STAMP(5 + 4 * pl);
+}
+
+// ---- 4q + 1 column blocks (400-wide layers: 25): every wave owns q blocks, the last block is SHARED by rows ----------
+// Dealing 25 blocks as 7 + 6 + 6 + 6 makes the 7-block wave the layer's pace: 12 % over the mean.  Here wave 0 takes
+// row blocks {0, 1} of the shared block, waves 1..3 one row block each: 32 / 31 / 31 / 31 register tiles.
+// NX = row blocks of the shared column this wave owns (2: wave 0, 1: the others), starting at rbx0.
+template <int CNT, int NX>
+__device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
+                                        int colx, int rbx0, int N, const f32x4 (&braw)[CNT], const f32x4 (&brawx)[1],
+                                        f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX], int pl) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* arow = lds + m * lda + 4 * kq;
+  const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
+  const unsigned lane_offx = (unsigned)((kq * Np + colx + m) * 16);
+  const int rot = k_rot(nk);
+  const float* arowx = arow + rbx0 * 16 * lda;  // the shared column's row blocks (wave-uniform start)
+  f32x4 b[2][CNT + 1], a[2][kNbRb], ax[2][NX];
+  {
+    const int k0 = k_at(0, rot, nk, 0);
+    const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
+    b[0][CNT] = load_bp_s(Pk, lane_offx);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ax[0][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + k0 * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
+  {
+    f32x4 xa[NX][1];
+    nb_bias_acc<1, NX>(brawx, colx, N, lane, xa);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xacc[i] = xa[i][0];
+  }
+  if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
+  auto step = [&](auto s_c, int kc) {
+    constexpr int s = decltype(s_c)::value;
+    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
+    const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
+    b[s ^ 1][CNT] = load_bp_s(Pk, lane_offx);
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ax[s ^ 1][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + kn * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb)
+          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        xacc[i] = EXP_MFMA(b[s][CNT][t], ax[s][i][t], xacc[i]);
+    }
+#if OSRL_NB_INTERLEAVE
+    constexpr int kTot = 4 * (kNbRb * CNT + NX), kPer = kTot / (CNT + 1 + kNbRb + NX + 1);
+#pragma unroll
+    for (int i = 0; i < CNT + 1; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kNbRb + NX; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, kTot - kPer * (CNT + 1 + kNbRb + NX), 0);
+#else
+    __builtin_amdgcn_sched_group_barrier(0x020, CNT + 1, 0);                    // VMEM reads of the next step first
+    __builtin_amdgcn_sched_group_barrier(0x100, kNbRb + NX, 0);                 // its DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * (kNbRb * CNT + NX), 0);     // then this step's MFMAs
+#endif
+  };
+  using std::integral_constant;
+  int kc = 0;
+  for (; kc + 2 <= nk; kc += 2) {
+    step(integral_constant<int, 0>{}, kc);
+    step(integral_constant<int, 1>{}, kc + 1);
+  }
+  if (kc < nk) step(integral_constant<int, 0>{}, kc);
+}
+
+template <int CNT, int NX>
+__device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int N, const float* __restrict__ P,
+                                                const float* __restrict__ bias, int act, int cb0, int cbx, int rbx0,
+                                                int lane, int pl) {
+  (void)pl;
+  f32x4 acc[kNbRb][CNT], xacc[NX];
+  f32x4 braw[CNT], brawx[1];
+  nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
+  nb_bias<1>(bias, cbx * 16, N, lane, brawx);
+  nb_mm_x<CNT, NX>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl);
+  PHASE_STAMP(2 + 4 * pl);
+  __syncthreads();  // every wave finished reading the previous activations
+  PHASE_STAMP(3 + 4 * pl);
+  nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
+  {
+    f32x4 xa[NX][1];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xa[i][0] = xacc[i];
+    nb_epilogue<1, NX>(lds, lda, xa, cbx, rbx0, N, act, lane);
+  }
+  PHASE_STAMP(4 + 4 * pl);
+  __syncthreads();
+  PHASE_STAMP(5 + 4 * pl);
+}
+
+// SHARED: every wide layer has 4 (NCB - 1) + 1 column blocks (the 400-wide VAE encoder / decoder): NCB - 1 blocks per
+// wave + the row-shared last block (nb_wide_layer_x); a separate instantiation, so that neither form carries the
+// other's register footprint
+template <int NCB, bool SHARED, class AR>
+__device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 16 * kNbRb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e = blockIdx.y, row0 = blockIdx.x * BM;
+  const int rows = a.in.rows, lda = a.lda, L = a.net.n_layers;
+  WG_LOG(0);
+  PHASE_STAMP(0);
+  {  // ---- stage cat(src0[map0(r)], src1[map1(r)]) zero padded to a multiple of 16 columns: every load of the tile
+     // is issued before the first LDS store.  16 lanes walk one row (64-byte segments), 16 rows per pass, 5 passes;
+     // no per-element division (80 x K0p / 256 of them cost 23k cycles in the first version of this kernel).
+    const int K0 = a.net.dims[0], K0p = round16(K0);
+    const int d0 = a.in.d0, d1 = a.in.d1;
+    const int cl = tid & 15, rl = tid >> 4;
+    const float* __restrict__ s0 = a.in.src0;
+    const float* __restrict__ s1 = a.in.src1 ? a.in.src1 : a.in.src0;
+    constexpr int kColChunks = 8;  // K0 <= 128 (host-checked)
+    // the row maps as straight-line code on values read ONCE: one unsigned division per (row, source) whose
+    // reciprocal set-up is common to the five passes, selects instead of the three-way branch of map_row().  (With
+    // map_row() inlined per pass the compiler re-read the descriptor from the kernel arguments in every branch arm:
+    // ~20 s_load + s_waitcnt lgkmcnt(0) round trips in front of the tile's loads.)
+    // The values are parked in VECTOR registers (the opaque asm makes them non-rematerialisable): there are plenty
+    // before the accumulators exist, while the scalar file is full of layer descriptors by now.
+    unsigned dv0 = a.in.map0 == OSRL_MAP_ID ? 1u : (unsigned)a.in.div0;
+    unsigned dv1 = a.in.map1 == OSRL_MAP_ID ? 1u : (unsigned)a.in.div1;
+    unsigned mod0 = a.in.map0 == OSRL_MAP_MOD, idn0 = a.in.map0 == OSRL_MAP_ID;
+    unsigned mod1 = a.in.map1 == OSRL_MAP_MOD, idn1 = a.in.map1 == OSRL_MAP_ID;
+    int d0v = d0, d1v = d1, rows_v = rows, K0v = K0;
+    asm volatile("" : "+v"(dv0), "+v"(dv1), "+v"(mod0), "+v"(idn0), "+v"(mod1), "+v"(idn1));
+    asm volatile("" : "+v"(d0v), "+v"(d1v), "+v"(rows_v), "+v"(K0v));
+    auto mapped = [](unsigned r, unsigned mod, unsigned idn, unsigned dv) -> unsigned {
+      const unsigned q = r / dv, rem = r - q * dv;  // dv == 1 for the identity map
+      return mod ? rem : (idn ? r : q);
+    };
+    float v[kNbRb][kColChunks];
+#pragma unroll
+    for (int p = 0; p < kNbRb; ++p) {
+      const int gr = row0 + p * 16 + rl;
+      const bool rok = gr < rows_v;
+      const unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
+      const float* p0 = s0 + (size_t)mapped(grc, mod0, idn0, dv0) * d0v;
+      const float* p1 = s1 + (size_t)mapped(grc, mod1, idn1, dv1) * d1v - d0v;
+#pragma unroll
+      for (int j = 0; j < kColChunks; ++j) {
+        const int c = j * 16 + cl;
+        const bool ok = rok && c < K0;
+        const float* q = c < d0 ? p0 + c : p1 + c;
+        v[p][j] = *(ok ? q : s0);
+        v[p][j] = ok ? v[p][j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kNbRb; ++p)
+#pragma unroll
+      for (int j = 0; j < kColChunks; ++j) {
+        const int c = j * 16 + cl;
+        if (c < K0p) lds[(p * 16 + rl) * lda + c] = v[p][j];
+      }
+    __syncthreads();
+  }
+  PHASE_STAMP(1);
+  for (int l = 0; l + 1 < L; ++l) {  // wide layers
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    const int nblk = (N + 15) >> 4;
+    if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
+      const int q = nblk >> 2;
+      if (wave == 0)
+        nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane, l);
+      else
+        nb_wide_layer_x<NCB - 1, 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, 4 * q,
+                                    wave + 1, lane, l);
+    } else {
+      int cb0, cnt;
+      wave_blocks<4>(nblk, wave, &cb0, &cnt);
+      if (cnt == NCB)
+        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
+      else
+        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
+    }
+  }
+  {  // ---- narrow head: K split over the 4 waves, every weight fragment of a wave's share loaded up front
+    const int l = L - 1;
+    const int K = a.net.dims[l], N = a.net.dims[l + 1];
+    const int Np = round16(N), nblk = Np >> 4, nk = round16(K) >> 4;
+    const int k_lo = (nk * wave) / 4, k_hi = (nk * (wave + 1)) / 4;
+    constexpr int kMaxSteps = 8;  // nk <= 32 (widths <= 448 -> nk <= 28 -> <= 7 steps per wave)
+    const float* __restrict__ P = a.net.Wf[e][l];
+    const int m = lane & 15, kq = lane >> 4;
+    f32x4 t[kNbRb][2];
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb) t[rb][0] = t[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bw[kMaxSteps][2];
+#pragma unroll
+    for (int sI = 0; sI < kMaxSteps; ++sI) {
+      const int ks = k_lo + sI < k_hi ? k_lo + sI : k_hi - 1;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        bw[sI][c] = (c < nblk) ? *reinterpret_cast<const f32x4*>(P + ((size_t)(ks * 4 + kq) * Np + c * 16 + m) * 4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* arow = lds + m * lda + 4 * kq;
+#pragma unroll
+    for (int sI = 0; sI < kMaxSteps; ++sI) {
+      if (k_lo + sI < k_hi) {
+        const int ks = k_lo + sI;
+        f32x4 af[kNbRb];
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb) af[rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + ks * 16);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int rb = 0; rb < kNbRb; ++rb) {
+            t[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rb][tt], bw[sI][0][tt], t[rb][0], 0, 0, 0);
+            if (nblk > 1) t[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rb][tt], bw[sI][1][tt], t[rb][1], 0, 0, 0);
+          }
+      }
+    }
+    PHASE_STAMP(2 + 4 * l);
+    __syncthreads();  // all reads of the activations are done: the tile's first 4 * Np columns take the partials
+    PHASE_STAMP(3 + 4 * l);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (c < nblk) {
+#pragma unroll
+        for (int rb = 0; rb < kNbRb; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            lds[(rb * 16 + kq * 4 + r) * lda + wave * Np + c * 16 + m] = t[rb][c][r];
+      }
+    __syncthreads();
+    PHASE_STAMP(4 + 4 * l);
+    const float* __restrict__ bias = a.net.b[e][l];
+    const int act = a.net.acts[l];
+    const float oscale = a.net.out_scale;
+    float* __restrict__ y = a.y[e];
+    for (int idx = tid; idx < BM * N; idx += 256) {
+      const int r = idx / N, c = idx - r * N;
+      if (row0 + r < rows) {
+        const float* p = lds + r * lda + c;
+        const float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
+        y[(size_t)(row0 + r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
+      }
+    }
+    PHASE_STAMP(5 + 4 * l);
+  }
+  WG_LOG(1);
+}
+template <int NCB, bool SHARED = false>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
+  mlp_fwd_nb_body<NCB, SHARED, const NbArgs&>(a);
+}
+template <int NCB, bool SHARED = false>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel_p(const void* p) {
+  mlp_fwd_nb_body<NCB, SHARED, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
+}
+
+// ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
+template <int NCB, bool SHARED = false>
+static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
+  const void* dev_args = osrl_argmem::slot(a);
+  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED>)
+                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  if (dev_args)
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
+  else
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream) {
+  const int L = net->n_layers, nets = net->n_nets;
+  if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNbNotTaken;
+  for (int e = 0; e < nets; ++e)
+    for (int l = 0; l + 1 < L; ++l)
+      if (out->h[e][l]) return kNbNotTaken;  // training launches keep hidden activations: mlp_fwd_kernel
+  int ncb = 0, wmax = net->dims[0];
+  for (int l = 0; l + 1 < L; ++l) {  // wide layers: every wave owns NCB or NCB - 1 column blocks
+    const int N = net->dims[l + 1], nblk = (N + 15) / 16;
+    const int need = nblk >= 13 && nblk <= 16 ? 4 : nblk >= 25 && nblk <= 28 ? 7 : 0;
+    if (!need || (ncb && need != ncb)) return kNbNotTaken;
+    ncb = need;
+    wmax = N > wmax ? N : wmax;
+  }
+  const int NL = net->dims[L], nkl = (((net->dims[L - 1] + 15) & ~15) >> 4);
+  if (NL > 32 || nkl < 4 || nkl > 32) return kNbNotTaken;  // narrow head, K split over 4 waves (<= 8 steps each)
+  const int lda = ((wmax + 15) & ~15) + 8;
+  if (lda < 4 * ((NL + 15) & ~15)) return kNbNotTaken;  // the head's 4 partial tiles live in the activation tile
+  size_t lds_bytes = (size_t)80 * lda * sizeof(float);
+  if (lds_bytes <= 80 * 1024) lds_bytes = 80 * 1024 + 256;  // more than half of the 160 KB: one workgroup per CU
+  if (lds_bytes > kLdsMax) return kNbNotTaken;
+  NbArgs a{};
+  a.net = *net;
+  a.in = *in;
+  for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
+  a.lda = lda;
+  const int tiles = (in->rows + 79) / 80;
+  bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
+  for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;
+  if (shared) return launch_nb<7, true>(a, tiles, nets, lds_bytes, stream);
+  return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
+}

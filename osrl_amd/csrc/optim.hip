@@ -129,7 +129,8 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, float* __restri
     reinterpret_cast<f32x4*>(v)[i] = vv;
     f32x4 tv = pv;
     if (tgt) {
-      tv = tau * pv + (1.0f - tau) * tv0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tv[k] = osrl_adam::polyak1(tau, pv[k], tv0[k]);
       reinterpret_cast<f32x4*>(tgt)[i] = tv;
     }
     if (pk.map_f) {

@@ -461,6 +461,16 @@ class MlpRun:
         return out
 
 
+# dW + the group's optimizer step in one launch (osrl_mlp_backward_dw_tiles_adam; single device, weight decay 0, no clip
+# scale).  Measured on the CPQ step (round 4, gpurun_out/r4a, DESIGN_LOG.md): with row splits the tile's slabs are
+# exchanged between workgroups INSIDE the launch -- store, acknowledge, count, read back: four dependent device-coherent
+# round trips, 9-14 us behind the dW k-loop against the 6.4-10 us of the separate optimizer launch (actor group 23.0 vs
+# 11.5 + 6.6 us isolated, critic 41.9 vs 20.5 + 8.0; C2 1935 vs 2230 steps/s) -- so "auto" fuses only plans whose tiles
+# have ONE split (the gradient is then complete in LDS: no slab, no exchange; small batches).  "1" forces it for every
+# flat plan (the bit-equality test, A/B runs), "0" never fuses.
+FUSE_DW_ADAM = os.environ.get("OSRL_FUSE_DW_ADAM", "auto")
+
+
 class DwPlan:
     """Static work list for osrl_mlp_backward_dw over one optimizer group."""
 
@@ -527,6 +537,16 @@ class DwPlan:
         self.n_big = len(big_items) // 4
         self.n_work = len(work) // 4
         self.d_work = torch.tensor(work, dtype=torch.int32, device=device) if work else None
+        # arrival counters of the fused dW + optimizer launch (launch_adam): one per tile, shared by its row splits
+        self.d_tile_ids = self.d_counters = None
+        if work:
+            ids, seen = [], {}
+            for j in range(self.n_work):
+                key = tuple(work[4 * j:4 * j + 3])
+                ids.append(seen.setdefault(key, len(seen)))
+            self.d_tile_ids = torch.tensor(ids, dtype=torch.int32, device=device)
+            self.d_counters = torch.zeros(max(len(seen), 1), dtype=torch.int32, device=device)
+        self._adam_c = None
         raw = bytes(arr)
         self.d_entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.d_items = torch.tensor(items if items else [0, 0, 0, 0], dtype=torch.int32, device=device)
@@ -552,6 +572,38 @@ class DwPlan:
         if self.n_work:
             self.n_splits = max(w >> 16 for w in work[3::4])
         group.ensure_slabs(self.n_splits)
+
+    def can_fuse_adam(self) -> bool:
+        """The fused dW + optimizer launch covers a group whose whole plan is the flat (tile, split) work list."""
+        flat = bool(self.n_work) and not self.n_items and not self.n_big
+        if FUSE_DW_ADAM == "auto":
+            return flat and self.n_splits == 1
+        return flat and FUSE_DW_ADAM == "1"
+
+    def launch_adam(self, lr: float, st_ptr: int, tau: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                    polyak: bool = True) -> None:
+        """dW and the group's Adam (+ Polyak + packed-copy refresh) step in ONE launch
+        (osrl_mlp_backward_dw_tiles_adam): same bits as ``launch()`` + ``group.adam_step(lr, st_ptr, tau)``.
+        Single-device steps only -- a data-parallel step all-reduces the gradient in between."""
+        g = self.group
+        g.cur_splits = self.n_splits
+        key = (float(lr), int(st_ptr), float(tau), tuple(betas), float(eps), bool(polyak))
+        if self._adam_c is None or self._adam_c[0] != key:
+            o = L.DwAdamT()
+            o.p, o.m, o.v = g.p.data_ptr(), g.m.data_ptr(), g.v.data_ptr()
+            o.tgt = _ptr(g.tgt) if (polyak and g.tgt is not None) else None
+            if g.weights:
+                o.map_f, o.map_b = g._map_f.data_ptr(), g._map_b.data_ptr()
+                o.pf, o.pb = g.pf.data_ptr(), g.pb.data_ptr()
+                o.tf = _ptr(g.tf) if o.tgt else None
+            o.st = st_ptr
+            o.lr, o.beta1, o.beta2, o.eps, o.tau = lr, betas[0], betas[1], eps, tau
+            self._adam_c = (key, o)
+        o = self._adam_c[1]
+        L.check(L.load().osrl_mlp_backward_dw_tiles_adam(
+            self.d_entries.data_ptr(), self.d_work.data_ptr(), self.d_tile_ids.data_ptr(), self.d_counters.data_ptr(),
+            self.n_work, self.rows, self.tile_blocks, g.slabs.data_ptr(), g.n, C.byref(o), cur_stream()),
+            "osrl_mlp_backward_dw_tiles_adam")
 
     def launch(self) -> None:
         """Both launches write disjoint parameter ranges; a range's slabs beyond its own split count are never written

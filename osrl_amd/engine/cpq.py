@@ -160,6 +160,11 @@ class CPQEngine:
     def _optim(self, name: str, plan: DwPlan, tau: float) -> None:
         if name == "vae":
             self._pr("vae_dw", 0)
+        if self.dist is None and plan.can_fuse_adam():  # dW and the optimizer step in one launch (same bits)
+            plan.launch_adam(self.model._lrs[name], self.st.ptr, tau=tau)
+            if name == "vae":
+                self._pr("vae_dw", 1)
+            return
         plan.launch()
         if name == "vae":
             self._pr("vae_dw", 1)
@@ -260,9 +265,13 @@ class CPQEngine:
         G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0, None,
                         self.dqc, st.stat_ptr("loss/cost_critic_loss"))
         self.r_cost.backward_dz()
-        self.p_cost.launch()
+        fuse_cost = dp is None and self.p_cost.can_fuse_adam()
+        if not fuse_cost:
+            self.p_cost.launch()
         par.wait(ev_critic)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the side branch
-        if dp is None:
+        if fuse_cost:
+            self.p_cost.launch_adam(m._lrs["cost_critic"], st.ptr, tau=m.tau)
+        elif dp is None:
             self._update("cost_critic", m.tau)
         else:  # both critic groups' gradients in ONE collective (neither update reads the other's result)
             gc, gcc = m.groups["critic"], m.groups["cost_critic"]

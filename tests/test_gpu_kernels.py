@@ -872,3 +872,65 @@ def test_dw_big_rows_kernel(rows, out_f, in_f, force_big):
         assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (wk, np.abs(got - want).max())
         wb = z.cpu().numpy().astype(np.float64).sum(0)
         assert np.abs(grp.grad_view(bk).cpu().numpy() - wb).max() <= 2e-5 * max(1.0, np.abs(wb).max()), bk
+
+
+@pytest.mark.parametrize("rows,T,splits,target", [(2048, 5, 3, True), (2048, 4, None, True), (300, 4, 1, False),
+                                                  (1000, 2, 4, True), (2048 + 37, 3, 2, False), (4096, 4, 12, True)])
+def test_dw_tiles_adam_one_launch_equals_dw_then_adam(rows, T, splits, target):
+    """osrl_mlp_backward_dw_tiles_adam (the last split of a tile to arrive applies the optimizer step to it) vs
+    osrl_mlp_backward_dw_tiles + osrl_adam_step_packed on a twin group: parameters, moments, Polyak targets and all
+    three packed copies BIT-equal after every one of four steps (the arrival counters re-arm themselves); one split
+    (no slab, gradient straight from LDS), several, and more than the eight the epilogue keeps in flight; ragged
+    tiles, a packed two-head alias, biases."""
+    from osrl_amd.engine.core import DwPlan, FlatGroup, StepState
+    dev = _dev()
+    rs = np.random.RandomState(rows + T)
+    shapes = [("a", 400, 78), ("b", 400, 400), ("h", 6, 400)] if T == 5 else [("a", 256, 41), ("b", 100, 256), ("h", 6, 100)]
+    groups = []
+    for _ in range(2):
+        grp = FlatGroup("g", dev, with_target=target)
+        for k, o, i in shapes:
+            if k == "h":  # two adjacent [3, in] heads packed as one [6, in] weight
+                grp.add("mu.w", (3, i), align=True)
+                grp.add("ls.w", (3, i), align=False)
+                grp.alias("h.w", "mu.w", (6, i))
+                grp.add("mu.b", (3,), align=True)
+                grp.add("ls.b", (3,), align=False)
+                grp.alias("h.b", "mu.b", (6,))
+            else:
+                grp.add(k + ".w", (o, i))
+                grp.add(k + ".b", (o,))
+            grp.mark_weight(k + ".w")
+        grp.finalize()
+        groups.append(grp)
+    live = np.zeros(groups[0].n, np.float32)  # alignment padding stays zero, as in every engine: the streaming Adam
+    for key, (off, shape) in groups[0].layout.items():  # kernel walks (and Polyak-averages) the padding floats too
+        live[off:off + int(np.prod(shape))] = 1.0
+    p0 = torch.tensor(rs.randn(groups[0].n).astype(np.float32) * live, device=dev)
+    t0 = torch.tensor(rs.randn(groups[0].n).astype(np.float32) * live, device=dev)
+    for grp in groups:
+        grp.p.copy_(p0)
+        if target:
+            grp.tgt.copy_(t0)
+        grp.repack()
+    acts = [(torch.zeros(rows, o, device=dev), torch.zeros(rows, i, device=dev)) for _, o, i in shapes]
+    ents = [(dz, a, k + ".w", k + ".b") for (dz, a), (k, _, _) in zip(acts, shapes)]
+    plans = [DwPlan(grp, ents, rows, dev, n_splits=splits, tile_blocks=T) for grp in groups]
+    assert plans[0].n_work > 0 and not plans[0].n_items and not plans[0].n_big  # the whole plan is the flat work list
+    st = StepState(dev, ["x"])
+    ga, gb = groups
+    for step in range(4):
+        for dz, a in acts:
+            dz.copy_(torch.tensor(rs.randn(*dz.shape), dtype=torch.float32))
+            a.copy_(torch.tensor(rs.randn(*a.shape), dtype=torch.float32))
+        st.tick()
+        plans[0].launch()
+        ga.adam_step(3e-3, st.ptr, tau=0.25)
+        plans[1].launch_adam(3e-3, st.ptr, tau=0.25)
+        torch.cuda.synchronize()
+        assert int(plans[1].d_counters.abs().sum().item()) == 0, "arrival counters not re-armed"
+        names = ["p", "m", "v", "pf", "pb"] + (["tgt", "tf"] if target else [])
+        for n in names:
+            x, y = getattr(ga, n), getattr(gb, n)
+            assert torch.equal(x, y), (step, n, float((x - y).abs().max()))
+    assert float((ga.p - p0).abs().max()) > 1e-3  # the steps moved the parameters

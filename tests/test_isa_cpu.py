@@ -25,7 +25,7 @@ def listings(tmp_path_factory):
     from isa_loads import scan
     d = tmp_path_factory.mktemp("isa")
     procs = {}
-    for name in ("glue", "optim", "mlp"):
+    for name in ("glue", "optim", "mlp", "mlp_nb"):
         out = str(d / f"{name}.s")
         cmd = [HIPCC] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "osrl_amd", "csrc", f"{name}.hip"), "-o", out]
         procs[name] = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), out)
@@ -75,7 +75,7 @@ def test_nb_forward_kernel_shape(listings):
         # by-value kernel and its device-resident-descriptor twin (csrc/argmem.h): the same body behind one extra
         # scalar load -- same registers, same stores
         for needles in (("mlp_fwd_nb_kernelI", inst), ("mlp_fwd_nb_kernel_pI", inst)):
-            r = _one(listings["mlp"], *needles)
+            r = _one(listings["mlp_nb"], *needles)
             assert r["scratch"] == 0 and 0 < r["vgprs"] <= 512, (needles, r)
             assert r["b128_writes"] >= 60, (needles, r)  # the transposed-tile epilogue (ds_write_b32 per element before)
             shapes.append((r["vgprs"], r["b128_writes"]))

@@ -1,6 +1,7 @@
 // Per-phase cycle breakdown of mlp_fwd_kernel for one workgroup (debug build of csrc/mlp.hip).
 #define OSRL_PHASE_TIMING 1
 #include "../osrl_amd/csrc/mlp.hip"
+#include "../osrl_amd/csrc/mlp_nb.hip"
 // (mlp.hip's unfused tail fall-backs call into glue.hip, which this stand-alone build does not link)
 extern "C" int osrl_vae_latent(const float*, const float*, int32_t, int32_t, float*, void*) { return -1; }
 extern "C" int osrl_vae_latent_bwd(const float*, const float*, const float*, int32_t, int32_t, float, int32_t, float*,
