@@ -34,6 +34,9 @@ struct NbArgs {
   int32_t lda;
 };
 
+#ifndef OSRL_NB8_ADB
+#define OSRL_NB8_ADB false  // 8-wave form: activation fragments single buffered (see nb_mm)
+#endif
 #ifndef OSRL_NB_INTERLEAVE
 #define OSRL_NB_INTERLEAVE 1
 #endif
@@ -69,7 +72,10 @@ __device__ __forceinline__ void nb_bias_acc(const f32x4 (&braw)[CNT], int col0, 
   }
 }
 
-template <int CNT>
+// ADB: the activation fragments are double buffered (next step's ds_reads issued under this step's MFMAs: one wave per
+// SIMD has nothing else to hide them behind).  The 8-wave form reads them single buffered at the end of a step -- the
+// SIMD's other wave covers the LDS round trip -- which is what brings it under 160 registers per lane.
+template <int CNT, bool ADB = true>
 __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
                                       int N, const f32x4 (&braw)[CNT], f32x4 (&acc)[kNbRb][CNT], int pl) {
   const int lane = threadIdx.x & 63;
@@ -77,7 +83,7 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
   const float* arow = lds + m * lda + 4 * kq;
   const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
   const int rot = k_rot(nk);
-  f32x4 b[2][CNT], a[2][kNbRb];
+  f32x4 b[2][CNT], a[ADB ? 2 : 1][kNbRb];
   {
     const int k0 = k_at(0, rot, nk, 0);
     const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
@@ -91,19 +97,35 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
   if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
   auto step = [&](auto s_c, int kc) {
     constexpr int s = decltype(s_c)::value;
+    constexpr int sa = ADB ? s : 0, sn = ADB ? (s ^ 1) : 0;
     const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
     const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
+    if constexpr (ADB) {
 #pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+      for (int rb = 0; rb < kNbRb; ++rb) a[sn][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
+          acc[rb][c] = EXP_MFMA(b[s][c][t], a[sa][rb][t], acc[rb][c]);
+    if constexpr (!ADB) {
+#pragma unroll
+      for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+      constexpr int kPerB = (4 * kNbRb * CNT) / (CNT + 1);
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, kPerB, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kNbRb * CNT - kPerB * CNT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, kNbRb, 0);
+      return;
+    }
 #if OSRL_NB_INTERLEAVE
     // next step's loads one at a time, each followed by a few of THIS step's MFMAs: with one wave per SIMD nothing else
     // can fill the MFMA pipe while the ~35 address / load instructions of a step issue (540 cycles per 16-deep k-step
@@ -171,14 +193,14 @@ __device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&a
   }
 }
 
-template <int CNT>
+template <int CNT, bool ADB = true>
 __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
                                               const float* __restrict__ bias, int act, int cb0, int lane, int pl) {
   (void)pl;  // layer number, for the debug build's phase stamps only
   f32x4 braw[CNT];
   nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
   f32x4 acc[kNbRb][CNT];
-  nb_mm<CNT>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
+  nb_mm<CNT, ADB>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
   PHASE_STAMP(2 + 4 * pl);
   __syncthreads();  // every wave finished reading the previous activations
   PHASE_STAMP(3 + 4 * pl);
@@ -192,7 +214,7 @@ __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N,
 // Dealing 25 blocks as 7 + 6 + 6 + 6 makes the 7-block wave the layer's pace: 12 % over the mean.  Here wave 0 takes
 // row blocks {0, 1} of the shared block, waves 1..3 one row block each: 32 / 31 / 31 / 31 register tiles.
 // NX = row blocks of the shared column this wave owns (2: wave 0, 1: the others), starting at rbx0.
-template <int CNT, int NX>
+template <int CNT, int NX, bool ADB = true>
 __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
                                         int colx, int rbx0, int N, const f32x4 (&braw)[CNT], const f32x4 (&brawx)[1],
                                         f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX], int pl) {
@@ -203,7 +225,7 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
   const unsigned lane_offx = (unsigned)((kq * Np + colx + m) * 16);
   const int rot = k_rot(nk);
   const float* arowx = arow + rbx0 * 16 * lda;  // the shared column's row blocks (wave-uniform start)
-  f32x4 b[2][CNT + 1], a[2][kNbRb], ax[2][NX];
+  f32x4 b[2][CNT + 1], a[ADB ? 2 : 1][kNbRb], ax[ADB ? 2 : 1][NX];
   {
     const int k0 = k_at(0, rot, nk, 0);
     const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
@@ -226,25 +248,43 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
   if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
   auto step = [&](auto s_c, int kc) {
     constexpr int s = decltype(s_c)::value;
+    constexpr int sa = ADB ? s : 0, sn = ADB ? (s ^ 1) : 0;
     const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
     const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
     b[s ^ 1][CNT] = load_bp_s(Pk, lane_offx);
+    if constexpr (ADB) {
 #pragma unroll
-    for (int rb = 0; rb < kNbRb; ++rb) a[s ^ 1][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+      for (int rb = 0; rb < kNbRb; ++rb) a[sn][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) ax[s ^ 1][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + kn * 16);
+      for (int i = 0; i < NX; ++i) ax[sn][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + kn * 16);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int rb = 0; rb < kNbRb; ++rb)
-          acc[rb][c] = EXP_MFMA(b[s][c][t], a[s][rb][t], acc[rb][c]);
+          acc[rb][c] = EXP_MFMA(b[s][c][t], a[sa][rb][t], acc[rb][c]);
 #pragma unroll
       for (int i = 0; i < NX; ++i)
-        xacc[i] = EXP_MFMA(b[s][CNT][t], ax[s][i][t], xacc[i]);
+        xacc[i] = EXP_MFMA(b[s][CNT][t], ax[sa][i][t], xacc[i]);
+    }
+    if constexpr (!ADB) {
+#pragma unroll
+      for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + kn * 16);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ax[0][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + kn * 16);
+      constexpr int kTotB = 4 * (kNbRb * CNT + NX), kPerB = kTotB / (CNT + 2);
+#pragma unroll
+      for (int i = 0; i < CNT + 1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, kPerB, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, kTotB - kPerB * (CNT + 1), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, kNbRb + NX, 0);
+      return;
     }
 #if OSRL_NB_INTERLEAVE
     constexpr int kTot = 4 * (kNbRb * CNT + NX), kPer = kTot / (CNT + 1 + kNbRb + NX + 1);
@@ -274,7 +314,7 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
   if (kc < nk) step(integral_constant<int, 0>{}, kc);
 }
 
-template <int CNT, int NX>
+template <int CNT, int NX, bool ADB = true>
 __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int N, const float* __restrict__ P,
                                                 const float* __restrict__ bias, int act, int cb0, int cbx, int rbx0,
                                                 int lane, int pl) {
@@ -283,7 +323,7 @@ __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int 
   f32x4 braw[CNT], brawx[1];
   nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
   nb_bias<1>(bias, cbx * 16, N, lane, brawx);
-  nb_mm_x<CNT, NX>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl);
+  nb_mm_x<CNT, NX, ADB>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl);
   PHASE_STAMP(2 + 4 * pl);
   __syncthreads();  // every wave finished reading the previous activations
   PHASE_STAMP(3 + 4 * pl);
@@ -302,7 +342,11 @@ __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int 
 // SHARED: every wide layer has 4 (NCB - 1) + 1 column blocks (the 400-wide VAE encoder / decoder): NCB - 1 blocks per
 // wave + the row-shared last block (nb_wide_layer_x); a separate instantiation, so that neither form carries the
 // other's register footprint
-template <int NCB, bool SHARED, class AR>
+// NW = waves per workgroup: 4 (one wave per SIMD, the shapes above) or 8 (two per SIMD, 400-wide layers only: every wave
+// owns 3 column blocks, the 25th is shared by rows over waves 0..4 -- 16 / 15 register tiles per wave instead of 32 / 31,
+// i.e. <= 160 registers per lane instead of 339: the chain's 8-wave workgroups (2 x 96 registers per SIMD) then fit on
+// the CU beside this one, which at one 339-register wave per SIMD they do not; DESIGN.md section 3 "round 4")
+template <int NCB, bool SHARED, int NW, class AR>
 __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * kNbRb;
@@ -338,11 +382,12 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
       const unsigned q = r / dv, rem = r - q * dv;  // dv == 1 for the identity map
       return mod ? rem : (idn ? r : q);
     };
-    float v[kNbRb][kColChunks];
+    constexpr int kRowsPass = 4 * NW, kPasses = (BM + kRowsPass - 1) / kRowsPass;  // 16 rows x 5 passes | 32 x 3 (the last half empty)
+    float v[kPasses][kColChunks];
 #pragma unroll
-    for (int p = 0; p < kNbRb; ++p) {
-      const int gr = row0 + p * 16 + rl;
-      const bool rok = gr < rows_v;
+    for (int p = 0; p < kPasses; ++p) {
+      const int gr = row0 + p * kRowsPass + rl;
+      const bool rok = gr < rows_v && (BM % kRowsPass == 0 || p * kRowsPass + rl < BM);
       const unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
       const float* p0 = s0 + (size_t)mapped(grc, mod0, idn0, dv0) * d0v;
       const float* p1 = s1 + (size_t)mapped(grc, mod1, idn1, dv1) * d1v - d0v;
@@ -356,11 +401,11 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
       }
     }
 #pragma unroll
-    for (int p = 0; p < kNbRb; ++p)
+    for (int p = 0; p < kPasses; ++p)
 #pragma unroll
       for (int j = 0; j < kColChunks; ++j) {
         const int c = j * 16 + cl;
-        if (c < K0p) lds[(p * 16 + rl) * lda + c] = v[p][j];
+        if (c < K0p && (BM % kRowsPass == 0 || p * kRowsPass + rl < BM)) lds[(p * kRowsPass + rl) * lda + c] = v[p][j];
       }
     __syncthreads();
   }
@@ -368,7 +413,14 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   for (int l = 0; l + 1 < L; ++l) {  // wide layers
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
     const int nblk = (N + 15) >> 4;
-    if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
+    if constexpr (SHARED && NW == 8) {  // 8q + 1 blocks (25): q = 3 each, the last one shared by rows over waves 0..4
+      const int q = nblk >> 3;
+      if (wave < kNbRb)
+        nb_wide_layer_x<NCB - 1, 1, OSRL_NB8_ADB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q,
+                                                  8 * q, wave, lane, l);
+      else
+        nb_wide_layer<NCB - 1, OSRL_NB8_ADB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, lane, l);
+    } else if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
       const int q = nblk >> 2;
       if (wave == 0)
         nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane, l);
@@ -377,7 +429,7 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
                                     wave + 1, lane, l);
     } else {
       int cb0, cnt;
-      wave_blocks<4>(nblk, wave, &cb0, &cnt);
+      wave_blocks<NW>(nblk, wave, &cb0, &cnt);
       if (cnt == NCB)
         nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
       else
@@ -388,8 +440,8 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     const int l = L - 1;
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
     const int Np = round16(N), nblk = Np >> 4, nk = round16(K) >> 4;
-    const int k_lo = (nk * wave) / 4, k_hi = (nk * (wave + 1)) / 4;
-    constexpr int kMaxSteps = 8;  // nk <= 32 (widths <= 448 -> nk <= 28 -> <= 7 steps per wave)
+    const int k_lo = (nk * wave) / NW, k_hi = (nk * (wave + 1)) / NW;
+    constexpr int kMaxSteps = 32 / NW;  // nk <= 32 (widths <= 448 -> nk <= 28 -> <= 7 | 4 steps per wave)
     const float* __restrict__ P = a.net.Wf[e][l];
     const int m = lane & 15, kq = lane >> 4;
     f32x4 t[kNbRb][2];
@@ -439,11 +491,12 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     const int act = a.net.acts[l];
     const float oscale = a.net.out_scale;
     float* __restrict__ y = a.y[e];
-    for (int idx = tid; idx < BM * N; idx += 256) {
+    for (int idx = tid; idx < BM * N; idx += 64 * NW) {
       const int r = idx / N, c = idx - r * N;
       if (row0 + r < rows) {
         const float* p = lds + r * lda + c;
-        const float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
+        float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
+        if constexpr (NW == 8) sacc = (((sacc + p[4 * Np]) + p[5 * Np]) + p[6 * Np]) + p[7 * Np];
         y[(size_t)(row0 + r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
       }
     }
@@ -453,11 +506,22 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
 }
 template <int NCB, bool SHARED = false>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
-  mlp_fwd_nb_body<NCB, SHARED, const NbArgs&>(a);
+  mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&>(a);
 }
 template <int NCB, bool SHARED = false>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel_p(const void* p) {
-  mlp_fwd_nb_body<NCB, SHARED, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
+  mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
+}
+// the 8-wave form (25-block layers): NCB - 1 = 3 column blocks per wave
+#ifndef OSRL_NB8_WPE
+#define OSRL_NB8_WPE 2
+#endif
+#define OSRL_NB8_ATTR
+__global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_kernel(const NbArgs a) {
+  mlp_fwd_nb_body<4, true, 8, const NbArgs&>(a);
+}
+__global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_kernel_p(const void* p) {
+  mlp_fwd_nb_body<4, true, 8, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
 }
 
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
@@ -507,6 +571,23 @@ __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* n
   const int tiles = (in->rows + 79) / 80;
   bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
   for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;
+  // 8 waves for the 25-block layers (OSRL_NB_WAVES=4: the one-wave-per-SIMD form, for A/B runs); the head's 8 partial
+  // tiles need 8 * round16(NL) columns of the activation tile
+  const char* nb_env = getenv("OSRL_NB_WAVES");  // (read per launch: a test flips it between calls)
+  const bool nb8 = !(nb_env && atoi(nb_env) == 4);
+  if (shared && nb8 && lda >= 8 * ((NL + 15) & ~15)) {
+    const void* dev_args = osrl_argmem::slot(a);
+    hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb8_kernel_p)
+                                                : reinterpret_cast<const void*>(mlp_fwd_nb8_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    (void)hipGetLastError();
+    if (dev_args)
+      hipLaunchKernelGGL(mlp_fwd_nb8_kernel_p, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, dev_args);
+    else
+      hipLaunchKernelGGL(mlp_fwd_nb8_kernel, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
+    return (int)hipGetLastError();
+  }
   if (shared) return launch_nb<7, true>(a, tiles, nets, lds_bytes, stream);
   return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
 }

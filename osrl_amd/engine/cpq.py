@@ -103,9 +103,15 @@ class CPQEngine:
         self.r_critic = MlpRun(self.d_critic, B, True, dev)
         self.dq = z(nq, B, 1)
         self.r_critic.setup_backward(self.dq)
+        # round 4: the two critic groups' dW on 32 x 32 tiles x 2 row splits (17 KB of LDS, 154 registers per lane): such
+        # workgroups fit on a CU beside the 8-wave N*B-row encoder launch (130 KB, 2 x 152 registers per SIMD), which a
+        # 64 x 64 tile's 68 KB / 304 registers do not -- the cost critics' dW runs beside that launch on the main branch
+        # (84 -> 65 us there; C2 2245 -> 2260-2267 steps/s with both groups, gpurun_out/r4c)
+        small_dw = B >= 1024
+        t_def, s_def = ("2", 2) if small_dw else ("0", None)
         self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev,
-                               tile_blocks=int(os.environ.get("OSRL_DW_T_CRITIC", "0")),
-                               n_splits=(int(os.environ["OSRL_DW_S_CRITIC"]) if "OSRL_DW_S_CRITIC" in os.environ else None))
+                               tile_blocks=int(os.environ.get("OSRL_DW_T_CRITIC", t_def)),
+                               n_splits=(int(os.environ["OSRL_DW_S_CRITIC"]) if "OSRL_DW_S_CRITIC" in os.environ else s_def))
 
         # ---- cost-critic phase
         self.a_next2 = z(B, ad)
@@ -130,8 +136,8 @@ class CPQEngine:
         self.dqc = z(nqc, B, 1)
         self.r_cost.setup_backward(self.dqc)
         self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev,
-                             tile_blocks=int(os.environ.get("OSRL_DW_T_COST", "0")),
-                             n_splits=(int(os.environ["OSRL_DW_S_COST"]) if "OSRL_DW_S_COST" in os.environ else None))
+                             tile_blocks=int(os.environ.get("OSRL_DW_T_COST", t_def)),
+                             n_splits=(int(os.environ["OSRL_DW_S_COST"]) if "OSRL_DW_S_COST" in os.environ else s_def))
 
         # ---- actor phase
         self.a_pi, self.tanh_u = z(B, ad), z(B, ad)

@@ -1,6 +1,7 @@
 """GPU unit parity of the individual HIP kernels (through the C ABI via ctypes) against fp64
 numpy/torch-CPU references of the same op.  Tolerances: fp32 round-off (1e-5 relative-ish)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -234,12 +235,18 @@ def test_mlp_fwd_big_rows(ci):
     src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
     src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
     outs = []
-    for tile_rows in (32, 16, 80):  # 80: one 4-wave workgroup per CU (shapes the kernel does not take -- hidden layers
-        # of neither 13-16 nor 25-28 column blocks, wide last layer -- fall back to the default tile)
+    for tile_rows, waves in ((32, 0), (16, 0), (80, 0), (80, 4)):  # 80: one workgroup per CU (shapes the kernel does
+        # not take -- hidden layers of neither 13-16 nor 25-28 column blocks, wide last layer -- fall back to the default
+        # tile); 25-block layers take its 8-wave form unless OSRL_NB_WAVES=4 asks for one wave per SIMD
         desc = NetDesc(refs, acts, oscale)
         desc.c.tile_rows = tile_rows
         run = MlpRun(desc, rows, False, dev)
-        y = run.forward(src0, src1, map0=map0, div0=div0)
+        if waves:
+            os.environ["OSRL_NB_WAVES"] = str(waves)
+        try:
+            y = run.forward(src0, src1, map0=map0, div0=div0)
+        finally:
+            os.environ.pop("OSRL_NB_WAVES", None)
         torch.cuda.synchronize()
         outs.append(torch.stack([t.clone() for t in y]).cpu().numpy() if isinstance(y, (list, tuple)) else y.clone().cpu().numpy())
     idx0 = {0: np.arange(rows), 1: np.arange(rows) % div0, 2: np.arange(rows) // div0}[map0]
@@ -251,7 +258,7 @@ def test_mlp_fwd_big_rows(ci):
         for l, a in enumerate(acts):
             h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
         h = h * oscale
-        for nm, got in (("tile32", outs[0][e]), ("tile16", outs[1][e]), ("tile80", outs[2][e])):
+        for nm, got in (("tile32", outs[0][e]), ("tile16", outs[1][e]), ("tile80", outs[2][e]), ("tile80w4", outs[3][e])):
             err = np.abs(got.reshape(h.shape) - h).max()
             assert err < 3e-5 * max(1.0, np.abs(h).max()), f"case {ci} {nm} kernel net {e}: max err {err}"
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
