@@ -168,6 +168,46 @@ int osrl_mlp_forward2_tail(const osrl_mlp_t* net0, const osrl_rows_t* in0, const
                            const osrl_mlp_acts_t* out1, const osrl_mlp_tail_t* tail1, void* stream);
 int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                               const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream);
+/* The backward launch COMPUTES the gradient it starts from (new; the reference's autograd starts from a loss scalar,
+ * cpq.py:133,151,198,220): the loss kernels between a forward and a backward launch (osrl_vae_loss,
+ * osrl_cpq_critic_loss, osrl_cpq_cost_loss, osrl_cpq_actor_loss, osrl_gauss_head_bwd) only turn forward outputs of the
+ * SAME ROWS into dL/d(output) plus one logged batch sum -- here every row tile evaluates that expression for its rows
+ * while it stages dY (g->dy is ignored and may be NULL), and the statistic is the fixed-order sum of per-tile partials
+ * taken by the last workgroup to finish (wait-free: partials are device-coherent words, one arrival atomic per
+ * workgroup at its very end).  dL/d(output) has the bits of the named loss kernel; the statistic is the same sum in a
+ * different (fixed) order.  Kinds, with y_e = output of net e of this launch and inv = 1 / rows_global (<= 0: rows):
+ *   OSRL_SEED_MSE        dy = 2 (y - x0[r, c]) scale;   stat = sum (y - x0)^2 * stat_scale
+ *                        [+ kl_beta * stat_scale2 * sum_{r, k < kl_L} KL(kl_head[r, k], kl_head[r, kl_L + k]) if kl_head]
+ *                        (VAE: x0 = actions, scale = stat_scale = inv / ad, stat_scale2 = inv / L; == osrl_vae_loss)
+ *   OSRL_SEED_CPQ_CRITIC backup = x0[r] + gamma (1 - x1[r]) 1[min_e b_e[r] <= thres] min_e a_e[r];  dy_e = 2 (y_e - backup) inv
+ *                        (a = target critics [n_a, rows], b = target cost critics, x0 = rewards, x1 = done; == osrl_cpq_critic_loss)
+ *   OSRL_SEED_CPQ_COST   backup = x0[r] + gamma min_e a_e[r];  dy_e = 2 (y_e - backup) inv       (== osrl_cpq_cost_loss, MSE part)
+ *   OSRL_SEED_CPQ_ACTOR  dy_e = -1[min b_e[r] <= thres] inv if e == argmin_e a_e[r] else 0; stat = -sum mask min_e a_e * inv
+ *                        (a = the critics' outputs [n_a, rows] = this launch's nets, b = the cost critics'; == osrl_cpq_actor_loss)
+ *   OSRL_SEED_GAUSS_HEAD dy[r, :] = d/d(mu | log_std) of a = max_action tanh(mu + sd eps) given dL/da = sum_e a_e[r, :]
+ *                        (a = [n_a, rows, ad] input gradients, tanh_u / eps [rows, ad]; no statistic; == osrl_gauss_head_bwd)
+ * partials: >= 2 * n_nets * ceil(rows / 16) floats of scratch; counter: one uint32, ZERO before the first launch
+ * (re-armed by the launch).  HOST struct. */
+enum { OSRL_SEED_NONE = 0, OSRL_SEED_MSE = 1, OSRL_SEED_CPQ_CRITIC = 2, OSRL_SEED_CPQ_COST = 3, OSRL_SEED_CPQ_ACTOR = 4,
+       OSRL_SEED_GAUSS_HEAD = 5 };
+typedef struct {
+  int32_t kind;
+  int32_t n_a, n_b;
+  int32_t rows_global;
+  const float *a, *b;
+  const float *x0, *x1;
+  const float *eps, *tanh_u;
+  const float* kl_head;
+  int32_t kl_L, pad_;
+  float gamma, thres, scale, max_action;
+  float stat_scale, stat_scale2, kl_beta, pad2_;
+  float* partials;
+  uint32_t* counter;
+  float* stat;
+} osrl_mlp_seed_t;
+int osrl_mlp_backward_dz_seed(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                              const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, const osrl_mlp_seed_t* seed,
+                              void* stream);
 /* ---- one supervised regression step of one MLP in ONE launch (mlp.hip mlp_step_kernel) -------------------------
  * BCTrainer.train_one_step (osrl/algorithms/bc.py:45-55,103-109 with the minibatch of examples/train/train_bc.py:105-121):
  *   [sample + gather the minibatch] -> forward -> F.mse_loss -> backward -> dW / db -> Adam (+ refresh of the packed

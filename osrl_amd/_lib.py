@@ -58,6 +58,18 @@ class TailT(C.Structure):  # osrl_mlp_tail_t
 TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD, TAIL_GAUSS = 0, 1, 2, 3
 
 
+class SeedT(C.Structure):  # osrl_mlp_seed_t
+    _fields_ = [("kind", C.c_int32), ("n_a", C.c_int32), ("n_b", C.c_int32), ("rows_global", C.c_int32),
+                ("a", _fp), ("b", _fp), ("x0", _fp), ("x1", _fp), ("eps", _fp), ("tanh_u", _fp), ("kl_head", _fp),
+                ("kl_L", C.c_int32), ("pad_", C.c_int32), ("gamma", C.c_float), ("thres", C.c_float),
+                ("scale", C.c_float), ("max_action", C.c_float), ("stat_scale", C.c_float),
+                ("stat_scale2", C.c_float), ("kl_beta", C.c_float), ("pad2_", C.c_float), ("partials", _fp),
+                ("counter", C.c_void_p), ("stat", _fp)]
+
+
+SEED_NONE, SEED_MSE, SEED_CPQ_CRITIC, SEED_CPQ_COST, SEED_CPQ_ACTOR, SEED_GAUSS_HEAD = 0, 1, 2, 3, 4, 5
+
+
 class DwEntryT(C.Structure):
     _fields_ = [("dz", _fp), ("a", _fp), ("w_off", C.c_int64), ("b_off", C.c_int64),
                 ("out", C.c_int32), ("in_", C.c_int32), ("ldz", C.c_int32), ("lda", C.c_int32)]
@@ -161,6 +173,7 @@ PROTOTYPES = {
     "osrl_mlp_forward_tail": [_P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _vp],
     "osrl_mlp_forward2_tail": [_P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _vp],
     "osrl_mlp_backward_dz_tail": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _P(TailT), _vp],
+    "osrl_mlp_backward_dz_seed": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _P(TailT), _P(SeedT), _vp],
     "osrl_linear": [_fp, _i64, _i32, _i32, _fp, _i32, _i32, _i32, _fp, _fp, _i64, _fp, _i64, _vp],
     "osrl_pack_weights": [_fp, _fp, _fp, _vp, _i32, _i32, _vp],
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],

@@ -633,7 +633,94 @@ struct BwdArgs {
   osrl_mlp_grads_t g;
   int32_t rows, lda;
   osrl_mlp_tail_t tail;
+  osrl_mlp_seed_t seed;
 };
+
+// ---- loss seeds (osrl_mlp_seed_t): dL/d(output) of the rows a tile stages, from forward outputs of the same rows --
+// the expressions of csrc/glue.hip's loss kernels, term for term (vae_loss_body, cpq_critic_loss_body,
+// cpq_cost_loss_body, cpq_actor_loss_kernel, gauss_head_bwd_kernel), so that the gradient has their bits.
+constexpr float kSeedLogStdMin = -20.0f, kSeedLogStdMax = 2.0f;  // net.py:148-149 (== kLogStdMin / kLogStdMax of glue.hip)
+constexpr int kSeedEns = 4;                                       // == kEns of glue.hip (host-checked)
+__device__ __forceinline__ void seed_members(const float* __restrict__ q, int n, int stride, int i, float (&v)[kSeedEns]) {
+#pragma unroll
+  for (int e = 0; e < kSeedEns; ++e) v[e] = q[(size_t)(e < n ? e : 0) * stride + i];  // members past n re-read member 0
+}
+__device__ __forceinline__ float seed_min(const float* __restrict__ q, int n, int stride, int i) {
+  float v[kSeedEns];
+  seed_members(q, n, stride, i, v);
+  float m = v[0];
+#pragma unroll
+  for (int e = 1; e < kSeedEns; ++e) m = e < n ? fminf(m, v[e]) : m;
+  return m;
+}
+__device__ __forceinline__ float seed_kl_elem(float mean, float ls_raw) {
+  const float sd = expf(fminf(fmaxf(ls_raw, kTailLsMin), kTailLsMax));
+  return -0.5f * (1.0f + logf(sd * sd) - mean * mean - sd * sd);
+}
+// element (r, c) of net e's dY; yv = that element of the net's output, yrow = the output row; l0 collects the
+// statistic's terms of valid elements
+template <class SR>
+__device__ __forceinline__ float seed_dy(SR s, const int e, const int r, const int c, const int NL, const int rows,
+                                         const float yv, const float* __restrict__ yrow, const bool ok, float& l0) {
+  const int kind = s.kind;
+  if (kind == OSRL_SEED_MSE) {
+    const float d = yv - s.x0[(size_t)r * NL + c];
+    if (ok) l0 += d * d;
+    return 2.0f * d * s.scale;
+  }
+  if (kind == OSRL_SEED_CPQ_CRITIC) {
+    const float qt = seed_min(s.a, s.n_a, rows, r);
+    const float qct = seed_min(s.b, s.n_b, rows, r);
+    const float backup = s.x0[r] + s.gamma * (1.0f - s.x1[r]) * (qct <= s.thres ? 1.0f : 0.0f) * qt;  // cpq.py:145-146
+    const float d = yv - backup;
+    if (ok) l0 += d * d;
+    return 2.0f * d * s.scale;
+  }
+  if (kind == OSRL_SEED_CPQ_COST) {
+    const float backup = s.x0[r] + s.gamma * seed_min(s.a, s.n_a, rows, r);  // cpq.py:161
+    const float d = yv - backup;
+    if (ok) l0 += d * d;
+    return 2.0f * d * s.scale;
+  }
+  if (kind == OSRL_SEED_CPQ_ACTOR) {
+    float qv[kSeedEns];
+    seed_members(s.a, s.n_a, rows, r, qv);
+    float qm = qv[0];
+    int am = 0;
+#pragma unroll
+    for (int k = 1; k < kSeedEns; ++k) {
+      const bool lt = k < s.n_a && qv[k] < qm;
+      qm = lt ? qv[k] : qm;
+      am = lt ? k : am;
+    }
+    const float mask = seed_min(s.b, s.n_b, rows, r) <= s.thres ? 1.0f : 0.0f;
+    if (ok && e == 0) l0 -= mask * qm;
+    return e == am ? -mask * s.scale : 0.f;
+  }
+  // OSRL_SEED_GAUSS_HEAD: yrow = (mu | log_std) of the row, NL = 2 ad
+  const int ad = NL >> 1;
+  const int j = c < ad ? c : c - ad;
+  const float t = s.tanh_u[(size_t)r * ad + j];
+  const float lsr = yrow[ad + j];
+  const float ev = s.eps[(size_t)r * ad + j];
+  float dv[kSeedEns];
+#pragma unroll
+  for (int k = 0; k < kSeedEns; ++k) dv[k] = s.a[((size_t)(k < s.n_a ? k : 0) * rows + r) * ad + j];
+  float da = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSeedEns; ++k) da += k < s.n_a ? dv[k] : 0.f;
+  const float du = da * s.max_action * (1.0f - t * t);
+  const float ls = fminf(fmaxf(lsr, kSeedLogStdMin), kSeedLogStdMax);
+  const bool inside = lsr >= kSeedLogStdMin && lsr <= kSeedLogStdMax;
+  return c < ad ? du : (inside ? du * ev * expf(ls) : 0.f);
+}
+// device-coherent words for the statistic's partials (workgroups on different XCDs exchange them inside the launch)
+__device__ __forceinline__ void coh_put(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float coh_get(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int NRB, int NCB, int NW, class AR>
 __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int tile) {
@@ -644,6 +731,8 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
   const int row0 = tile * BM;
   const int rows = a.rows, lda = a.lda;
   const int L = a.net.n_layers;
+  __shared__ float s_seed[2][8];  // per-wave partials of a seeded launch's statistic
+  __shared__ int s_seed_last;
 #if OSRL_CHAIN_PRIO > 0
   if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -676,6 +765,44 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
     const float* __restrict__ y = a.saved.h[e][L - 1];
     const int act = a.net.acts[L - 1];
     const float* __restrict__ ysrc = act != OSRL_ACT_ID ? y : dy;
+    if (a.seed.kind != OSRL_SEED_NONE) {
+      // the launch computes its own dY (osrl_mlp_seed_t) + this tile's partial of the logged statistic
+      float l0 = 0.f, l1 = 0.f;
+      for (int idx = tid; idx < BM * NLp; idx += 64 * NW) {
+        const int r = idx / NLp, c = idx - r * NLp;
+        const int gr = row0 + r;
+        const bool ok = gr < rows && c < NL;
+        const int grc = gr < rows ? gr : rows - 1, cc = c < NL ? c : 0;
+        const float* __restrict__ yrow = y + (size_t)grc * NL;
+        const float yv = yrow[cc];
+        const float dyv = seed_dy<decltype((a.seed))>(a.seed, e, grc, cc, NL, rows, yv, yrow, ok, l0);
+        float v = dyv * oscale;
+        if (act != OSRL_ACT_ID) v *= act_bwd(act, yv * inv_oscale);
+        lds[r * lda + c] = ok ? v : 0.f;
+      }
+      if (a.seed.kl_head && e == 0) {  // the KL term of the VAE statistic (vae_loss_body) over this tile's rows
+        const int Lz = a.seed.kl_L;
+        const float* __restrict__ hd = a.seed.kl_head;
+        for (int idx = tid; idx < BM * Lz; idx += 64 * NW) {
+          const int r = idx / Lz, k = idx - r * Lz;
+          const int gr = row0 + r;
+          const int grc = gr < rows ? gr : rows - 1;
+          const float kv = seed_kl_elem(hd[(size_t)grc * 2 * Lz + k], hd[(size_t)grc * 2 * Lz + Lz + k]);
+          l1 += gr < rows ? kv : 0.f;
+        }
+      }
+      if (a.seed.partials) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          l0 += __shfl_xor(l0, o);
+          l1 += __shfl_xor(l1, o);
+        }
+        if (lane == 0) {
+          s_seed[0][wave] = l0;
+          s_seed[1][wave] = l1;
+        }
+      }
+    } else
     for (int idx = tid; idx < BM * NLp; idx += 64 * NW) {
       const int r = idx / NLp, c = idx - r * NLp;
       const int gr = row0 + r;
@@ -691,6 +818,16 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
       lds[r * lda + c] = ok ? v : 0.f;
     }
     __syncthreads();
+    if (a.seed.kind != OSRL_SEED_NONE && a.seed.partials && tid == 0) {  // this tile's partials, waves in order
+      float t0 = 0.f, t1 = 0.f;
+      for (int w = 0; w < NW; ++w) {
+        t0 += s_seed[0][w];
+        t1 += s_seed[1][w];
+      }
+      float* pp = a.seed.partials + 2 * ((size_t)e * ((rows + BM - 1) / BM) + tile);
+      coh_put(pp, t0);
+      coh_put(pp + 1, t1);
+    }
     if (a.g.dz[e][L - 1]) tile_to_global<64 * NW>(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);
   }
   constexpr bool kWarm = OSRL_L2_WARM && NW == 8;
@@ -802,6 +939,46 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
             }
           }
         }
+      }
+    }
+  }
+  if (a.seed.kind != OSRL_SEED_NONE && a.seed.partials) {
+    // the logged statistic: the last workgroup to get here sums every tile's partials in a fixed order (each lane a
+    // contiguous chunk, lanes by the butterfly, waves in order).  Wait-free: a workgroup is the last one or leaves.
+    const int n_part = a.net.n_nets * ((rows + BM - 1) / BM);
+    if (tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's partials are acknowledged
+      const unsigned seen = __hip_atomic_fetch_add(a.seed.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = seen == (unsigned)n_part - 1;
+      if (last) __hip_atomic_store(a.seed.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_seed_last = last;
+    }
+    __syncthreads();
+    if (s_seed_last) {
+      const int per = (n_part + 64 * NW - 1) / (64 * NW);
+      float t0 = 0.f, t1 = 0.f;
+      const float* pp = a.seed.partials;
+      for (int i = tid * per; i < (tid + 1) * per && i < n_part; ++i) {
+        t0 += coh_get(pp + 2 * i);
+        t1 += coh_get(pp + 2 * i + 1);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        t0 += __shfl_xor(t0, o);
+        t1 += __shfl_xor(t1, o);
+      }
+      if (lane == 0) {
+        s_seed[0][wave] = t0;
+        s_seed[1][wave] = t1;
+      }
+      __syncthreads();
+      if (tid == 0 && a.seed.stat) {
+        float u0 = 0.f, u1 = 0.f;
+        for (int w = 0; w < NW; ++w) {
+          u0 += s_seed[0][w];
+          u1 += s_seed[1][w];
+        }
+        a.seed.stat[0] = u0 * a.seed.stat_scale + a.seed.kl_beta * (u1 * a.seed.stat_scale2);
       }
     }
   }
@@ -2330,11 +2507,33 @@ extern "C" int osrl_mlp_forward2_tail(const osrl_mlp_t* net0, const osrl_rows_t*
   return mlp_forward2_impl(net0, in0, out0, tail0, net1, in1, out1, tail1, stream);
 }
 
+static bool seed_ok(const osrl_mlp_seed_t* s, const osrl_mlp_t* net, const osrl_mlp_acts_t* saved) {
+  if (!s || s->kind == OSRL_SEED_NONE) return true;
+  const int L = net->n_layers, NL = net->dims[L];
+  for (int e = 0; e < net->n_nets; ++e)
+    if (!saved->h[e][L - 1]) return false;  // the seeds read the nets' outputs
+  if ((s->partials != nullptr) != (s->counter != nullptr)) return false;
+  switch (s->kind) {
+    case OSRL_SEED_MSE: return s->x0 && (!s->kl_head || s->kl_L >= 1);
+    case OSRL_SEED_CPQ_CRITIC:
+      return NL == 1 && s->a && s->b && s->x0 && s->x1 && s->n_a >= 1 && s->n_a <= kSeedEns && s->n_b >= 1 && s->n_b <= kSeedEns;
+    case OSRL_SEED_CPQ_COST: return NL == 1 && s->a && s->x0 && s->n_a >= 1 && s->n_a <= kSeedEns;
+    case OSRL_SEED_CPQ_ACTOR:
+      return NL == 1 && s->a && s->b && s->n_a >= 1 && s->n_a <= kSeedEns && s->n_b >= 1 && s->n_b <= kSeedEns;
+    case OSRL_SEED_GAUSS_HEAD:
+      return (NL & 1) == 0 && net->n_nets == 1 && s->a && s->eps && s->tanh_u && s->n_a >= 1 && s->n_a <= kSeedEns && !s->partials;
+    default: return false;
+  }
+}
+
 static int mlp_backward_dz_impl(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
-                                const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream) {
+                                const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream,
+                                const osrl_mlp_seed_t* seed = nullptr) {
   if (!valid_net(net) || !saved || !g || rows < 1) return -1;
+  const bool seeded = seed && seed->kind != OSRL_SEED_NONE;
+  if (seeded && !seed_ok(seed, net, saved)) return -1;
   for (int e = 0; e < net->n_nets; ++e) {
-    if (!g->dy[e]) return -1;
+    if (!g->dy[e] && !seeded) return -1;
     for (int l = g->dx[e] ? 0 : 1; l < net->n_layers; ++l)
       if (!net->Wb[e][l]) return -1;
     for (int l = 0; l < net->n_layers; ++l)
@@ -2351,6 +2550,8 @@ static int mlp_backward_dz_impl(const osrl_mlp_t* net, int32_t rows, const osrl_
   a.g = *g;
   a.rows = rows;
   a.tail = osrl_mlp_tail_t{};
+  a.seed = osrl_mlp_seed_t{};
+  if (seeded) a.seed = *seed;
   const TileChoice t = choose_tile(net, rows, g->dx_cols);
   a.lda = t.lda;
   // the kernel's dX step leaves the slice in LDS only in its split-K form (mlp_bwd_dz_kernel: nblk <= 2 && nk >= 4 &&
@@ -2361,7 +2562,7 @@ static int mlp_backward_dz_impl(const osrl_mlp_t* net, int32_t rows, const osrl_
     a.tail.inv_rows_ = 1.0f / (float)(tail->rows_global > 0 ? tail->rows_global : rows);
   }
   if (want_tail && !fused) {
-    const int rc = mlp_backward_dz_impl(net, rows, saved, g, nullptr, stream);
+    const int rc = mlp_backward_dz_impl(net, rows, saved, g, nullptr, stream, seed);
     if (rc != 0) return rc;
     return osrl_vae_latent_bwd(tail->head, tail->eps, g->dx[0], rows, tail->L, tail->beta, tail->rows_global, tail->out,
                                stream);
@@ -2377,6 +2578,12 @@ extern "C" int osrl_mlp_backward_dz(const osrl_mlp_t* net, int32_t rows, const o
 extern "C" int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
                                          const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail, void* stream) {
   return mlp_backward_dz_impl(net, rows, saved, g, tail, stream);
+}
+
+extern "C" int osrl_mlp_backward_dz_seed(const osrl_mlp_t* net, int32_t rows, const osrl_mlp_acts_t* saved,
+                                         const osrl_mlp_grads_t* g, const osrl_mlp_tail_t* tail,
+                                         const osrl_mlp_seed_t* seed, void* stream) {
+  return mlp_backward_dz_impl(net, rows, saved, g, tail, stream, seed);
 }
 
 
@@ -2437,6 +2644,7 @@ extern "C" int osrl_mlp_regress_step(const osrl_mlp_step_t* s, void* stream) {
   k.bwd.rows = rows;
   k.bwd.lda = t.lda;
   k.bwd.tail = osrl_mlp_tail_t{};
+  k.bwd.seed = osrl_mlp_seed_t{};
   k.gather = ga;
   k.st = s->st;
   k.stats_cur = s->stats_cur;

@@ -439,8 +439,14 @@ class MlpRun:
             g.dx_col0, g.dx_cols = c0, nc
         self.grads_c, self.saved_c = g, sv
 
-    def backward_dz(self, tail: Optional["L.TailT"] = None) -> None:
-        """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's dX slice (osrl_mlp_backward_dz_tail)."""
+    def backward_dz(self, tail: Optional["L.TailT"] = None, seed: Optional["L.SeedT"] = None) -> None:
+        """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's dX slice (osrl_mlp_backward_dz_tail);
+        ``seed``: an osrl_mlp_seed_t -- the launch computes dL/d(output) itself (osrl_mlp_backward_dz_seed)."""
+        if seed is not None:
+            L.check(L.load().osrl_mlp_backward_dz_seed(C.byref(self.bwd_net.c), self.rows, C.byref(self.saved_c),
+                                                       C.byref(self.grads_c), None if tail is None else C.byref(tail),
+                                                       C.byref(seed), cur_stream()), "osrl_mlp_backward_dz_seed")
+            return
         if tail is not None:
             L.check(L.load().osrl_mlp_backward_dz_tail(C.byref(self.bwd_net.c), self.rows, C.byref(self.saved_c),
                                                        C.byref(self.grads_c), C.byref(tail), cur_stream()),

@@ -148,6 +148,25 @@ class CPQEngine:
         self.r_actor_obs.setup_backward(self.dhead_actor)
         self.p_actor = DwPlan(g["actor"], self.r_actor_obs.dw_entries(), B, dev)
 
+        # ---- loss seeds (round 4): each backward launch computes the gradient it starts from (glue.seed_*,
+        # osrl_mlp_backward_dz_seed) -- the five loss launches between a forward and a backward leave the chains
+        rg = self.rows_global
+        st = self.st
+        self.seeds = None
+        if G.SEEDS and G.VAE_TAILS and max(nq, nqc) <= 4:
+            y_old, y_pi = self.r_old_next.y, self.r_pi_q.y
+            self.seeds = {
+                "vae": G.seed_vae(self.act, self.r_enc.y[0], B, ad, Lz, m.beta, rg, G.SeedStat(dev, 1, B),
+                                  st.stat_ptr("loss/loss_vae")),
+                "critic": G.seed_cpq_critic(y_old[:nq], nq, y_old[nq:], nqc, self.rew, self.done, B, m.gamma, m.q_thres,
+                                            rg, G.SeedStat(dev, nq, B), st.stat_ptr("loss/critic_loss")),
+                "cost": G.seed_cpq_cost(self.r_costold_next.y, nqc, self.cost, B, m.gamma, rg, G.SeedStat(dev, nqc, B),
+                                        st.stat_ptr("loss/cost_critic_loss")),
+                "actor": G.seed_cpq_actor(y_pi[:nq], nq, y_pi[nq:], nqc, B, m.q_thres, rg, G.SeedStat(dev, nq, B),
+                                          st.stat_ptr("loss/actor_loss")),
+                "head": G.seed_gauss_head(self.noise["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, m.max_action),
+            }
+
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
         self.parallel_branches = True
@@ -215,8 +234,13 @@ class CPQEngine:
         # ---- main: vae_loss  (cpq.py:125-135)
         head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
-        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
+        sd = self.seeds
+        if sd is not None:  # reconstruction gradient + the logged loss by the decoder's backward launch itself
+            self.r_dec.backward_dz(tail=G.vae_latent_bwd_tail(head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc),
+                                   seed=sd["vae"])
+        else:
+            G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+            G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
         ev_vae = torch.cuda.Event() if par.enabled else None
@@ -254,9 +278,12 @@ class CPQEngine:
             self._pr("critic_fwd", 0)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
             self._pr("critic_fwd", 1)
-            G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
-                              rg, self.dq, st.stat_ptr("loss/critic_loss"))
-            self.r_critic.backward_dz()
+            if sd is not None:
+                self.r_critic.backward_dz(seed=sd["critic"])
+            else:
+                G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
+                                  rg, self.dq, st.stat_ptr("loss/critic_loss"))
+                self.r_critic.backward_dz()
             if dp is None:
                 self._optim("critic", self.p_critic, m.tau)
             else:  # collectives stay on the capture stream (same order on every rank): reduced + stepped over there
@@ -268,9 +295,12 @@ class CPQEngine:
         # ---- main: cost_critic_loss (cpq.py:155-201), the part with a gradient: Bellman MSE of the online cost critics
         par.wait(ev_next2)
         qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost, (self.obs, self.act))
-        G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0, None,
-                        self.dqc, st.stat_ptr("loss/cost_critic_loss"))
-        self.r_cost.backward_dz()
+        if sd is not None:
+            self.r_cost.backward_dz(seed=sd["cost"])
+        else:
+            G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0,
+                            None, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
+            self.r_cost.backward_dz()
         fuse_cost = dp is None and self.p_cost.can_fuse_adam()
         if not fuse_cost:
             self.p_cost.launch()
@@ -325,11 +355,15 @@ class CPQEngine:
             else:
                 dp.quantile_select(kl_all, 0.75, self.quant)
                 G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
-        G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
-        self.r_pi_q.backward_dz()
-        G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
-                         self.dhead_actor)
-        self.r_actor_obs.backward_dz()
+        if sd is not None:
+            self.r_pi_q.backward_dz(seed=sd["actor"])
+            self.r_actor_obs.backward_dz(seed=sd["head"])
+        else:
+            G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
+            self.r_pi_q.backward_dz()
+            G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
+                             self.dhead_actor)
+            self.r_actor_obs.backward_dz()
         if dp is None:
             self._optim("actor", self.p_actor, m.tau)
             par.join(0)

@@ -204,3 +204,81 @@ def bcq_actor_loss(q, nq1, nq2, qc, nc1, nc2, rows, qc_thres, KP, KI, KD, rows_g
 
 def clamp_(x, lo, hi):
     L.check(L.load().osrl_clamp(_p(x), x.numel(), lo, hi, cur_stream()), "osrl_clamp")
+
+
+# ---- loss seeds (osrl_mlp_seed_t): the backward launch computes dL/d(output) itself --------------------------------
+SEEDS = os.environ.get("OSRL_SEEDS", "1") == "1"  # 0: the loss kernels as launches of their own (A/B, bit-equality tests)
+
+
+class SeedStat:
+    """Scratch of one seeded call site: the per-tile partials of its logged statistic + the arrival counter."""
+
+    def __init__(self, device, n_nets: int, rows: int):
+        import torch
+        self.partials = torch.zeros(2 * max(n_nets, 1) * ((rows + 15) // 16), dtype=torch.float32, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def _seed(kind, rows, rows_global, ws: Optional[SeedStat], stat) -> "L.SeedT":
+    s = L.SeedT()
+    s.kind, s.rows_global = kind, int(rows_global)
+    if ws is not None:
+        s.partials, s.counter, s.stat = ws.partials.data_ptr(), ws.counter.data_ptr(), _p(stat)
+    s._keep = [ws]
+    return s
+
+
+def _inv(rows, rows_global):
+    import numpy as np
+    return np.float32(1.0) / np.float32(rows_global if rows_global > 0 else rows)
+
+
+def seed_vae(act, head, rows, ad, Lz, beta, rows_global, ws, stat) -> "L.SeedT":
+    """== vae_loss(u, act, head, ...): du = 2 (u - act) inv / ad; stat = rec inv / ad + beta * KL inv / L."""
+    import numpy as np
+    s = _seed(L.SEED_MSE, rows, rows_global, ws, stat)
+    inv = _inv(rows, rows_global)
+    s.x0, s.kl_head, s.kl_L = _p(act), _p(head), int(Lz)
+    s.scale = s.stat_scale = float(inv / np.float32(ad))
+    s.stat_scale2, s.kl_beta = float(inv / np.float32(Lz)), float(beta)
+    s._keep += [act, head]
+    return s
+
+
+def seed_cpq_critic(q_old, n_q_old, qc_old, n_qc_old, rew, done, rows, gamma, q_thres, rows_global, ws, stat):
+    """== cpq_critic_loss(...) for the online critics of the launch."""
+    s = _seed(L.SEED_CPQ_CRITIC, rows, rows_global, ws, stat)
+    s.a, s.n_a, s.b, s.n_b, s.x0, s.x1 = _p(q_old), n_q_old, _p(qc_old), n_qc_old, _p(rew), _p(done)
+    s.gamma, s.thres = float(gamma), float(q_thres)
+    s.scale = s.stat_scale = float(_inv(rows, rows_global))
+    s._keep += [q_old, qc_old, rew, done]
+    return s
+
+
+def seed_cpq_cost(qc_old_next, n_qc_old, cost, rows, gamma, rows_global, ws, stat):
+    """== the MSE part of cpq_cost_loss(...) (the dual step stays with cpq_alpha_step)."""
+    s = _seed(L.SEED_CPQ_COST, rows, rows_global, ws, stat)
+    s.a, s.n_a, s.x0 = _p(qc_old_next), n_qc_old, _p(cost)
+    s.gamma = float(gamma)
+    s.scale = s.stat_scale = float(_inv(rows, rows_global))
+    s._keep += [qc_old_next, cost]
+    return s
+
+
+def seed_cpq_actor(q, n_q, qc, n_qc, rows, q_thres, rows_global, ws, stat):
+    """== cpq_actor_loss(...): the launch's nets are the n_q critics whose outputs are ``q``."""
+    s = _seed(L.SEED_CPQ_ACTOR, rows, rows_global, ws, stat)
+    s.a, s.n_a, s.b, s.n_b = _p(q), n_q, _p(qc), n_qc
+    s.thres = float(q_thres)
+    s.scale = s.stat_scale = float(_inv(rows, rows_global))
+    s._keep += [q, qc]
+    return s
+
+
+def seed_gauss_head(eps, tanh_u, da_nets, n_nets, rows, max_action):
+    """== gauss_head_bwd(head, eps, tanh_u, da_nets, ...): head is the launch's own saved output."""
+    s = _seed(L.SEED_GAUSS_HEAD, rows, 0, None, None)
+    s.eps, s.tanh_u, s.a, s.n_a = _p(eps), _p(tanh_u), _p(da_nets), n_nets
+    s.max_action = float(max_action)
+    s._keep += [eps, tanh_u, da_nets]
+    return s

@@ -443,3 +443,43 @@ def test_engine_rebuild_keeps_the_step_count():
         tr.train_one_step(b["observations"], b["actions"])
     tr.train_one_step(b["observations"][:16], b["actions"][:16])
     assert m._engine.B == 16 and m._engine.st.device_step() == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cpq_small", "cpq_odd", "cpq_wide", "cpq_c2_full", "cpq_c4_full"])
+def test_seeded_backward_launches_equal_the_loss_launches(name):
+    """Round 4: the CPQ step's backward launches compute the gradient they start from (osrl_mlp_backward_dz_seed) instead
+    of reading it from five loss launches (vae_loss, cpq_critic_loss, cpq_cost_loss, cpq_actor_loss, gauss_head_bwd).
+    Same expressions per row => every parameter, target and Adam moment BIT-equal to the plan with the loss launches
+    after each of three steps; the logged statistics are the same sums in another fixed order (<= 2e-6 relative)."""
+    from cases import Case
+    from osrl_amd.engine import glue as G
+    c = Case(name, episode_len=1000, **FULL_CASES[name]) if name in FULL_CASES else ALL_CASES[name]
+    b = gpu_batch(c)
+    runs = []
+    for seeds in (False, True):
+        old = G.SEEDS
+        G.SEEDS = seeds
+        try:
+            m, tr, lg = build_gpu(c)
+            stats = []
+            for s in range(3):
+                gpu_step(tr, c, b, s)
+                stats.append({k: float(lg.last(k)) for k in ("loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss",
+                                                             "loss/actor_loss", "loss/alpha_value")})
+            assert (m._engine.seeds is not None) == seeds
+            torch.cuda.synchronize()
+            runs.append((m, stats))
+        finally:
+            G.SEEDS = old
+    (ma, sa), (mb, sb) = runs
+    for gname in ma.groups:
+        ga, gb = ma.groups[gname], mb.groups[gname]
+        for buf in ("p", "m", "v", "tgt"):
+            x, y = getattr(ga, buf), getattr(gb, buf)
+            if x is not None:
+                assert torch.equal(x, y), (gname, buf, float((x - y).abs().max()))
+    assert torch.equal(ma.log_alpha, mb.log_alpha)
+    for s, (x, y) in enumerate(zip(sa, sb)):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 2e-6 * max(1.0, abs(x[k])), (s, k, x[k], y[k])

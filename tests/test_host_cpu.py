@@ -164,7 +164,7 @@ def test_ctypes_struct_layouts_match_the_compiled_header():
         pytest.skip("no gcc")
     pairs = [("osrl_mlp_t", L.MlpT), ("osrl_pack_entry_t", L.PackEntryT), ("osrl_rows_t", L.RowsT),
              ("osrl_mlp_acts_t", L.ActsT), ("osrl_mlp_grads_t", L.GradsT), ("osrl_mlp_tail_t", L.TailT),
-             ("osrl_dw_entry_t", L.DwEntryT), ("osrl_dw_adam_t", L.DwAdamT), ("osrl_mlp_step_t", L.MlpStepT),
+             ("osrl_mlp_seed_t", L.SeedT), ("osrl_dw_entry_t", L.DwEntryT), ("osrl_dw_adam_t", L.DwAdamT), ("osrl_mlp_step_t", L.MlpStepT),
              ("osrl_step_state_t", L.StepStateT), ("osrl_dropout_t", L.DropoutT), ("osrl_env_t", L.EnvT)]
     hdr_dir = os.path.join(ROOT, "include")
     with tempfile.TemporaryDirectory() as d:
