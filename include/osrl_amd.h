@@ -100,7 +100,10 @@ typedef struct {
  *                               out2 [rows, L] = the same with eps2 (NULL = none), tanh2 [rows, L] = its tanh(u) (optional)
  *                               out_ood [n_samples * rows, L], row j * rows + r = mu + sd * eps_ood[j, r, :]  == osrl_gauss_ood_sample
  *                             (any of the three may be absent: eps / eps2 / eps_ood NULL) */
-enum { OSRL_TAIL_NONE = 0, OSRL_TAIL_VAE_LATENT = 1, OSRL_TAIL_VAE_LATENT_BWD = 2, OSRL_TAIL_GAUSS = 3 };
+/*   OSRL_TAIL_VAE_KL          forward of the VAE encoder (net 0, output [rows, 2L]): out[rows] = mean_k KL(N(mean_k, sd_k) || N(0, 1)),
+ *                             the per-row statistic of cpq.py:178-182                                      == osrl_vae_kl_rows
+ *                             (fused into the 80-row N*B-row kernel's output pass; a launch of its own behind any other) */
+enum { OSRL_TAIL_NONE = 0, OSRL_TAIL_VAE_LATENT = 1, OSRL_TAIL_VAE_LATENT_BWD = 2, OSRL_TAIL_GAUSS = 3, OSRL_TAIL_VAE_KL = 4 };
 typedef struct {
   int32_t kind;
   int32_t L;

@@ -55,7 +55,7 @@ class TailT(C.Structure):  # osrl_mlp_tail_t
                 ("out_ood", _fp), ("n_samples", C.c_int32), ("pad_", C.c_int32)]
 
 
-TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD, TAIL_GAUSS = 0, 1, 2, 3
+TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD, TAIL_GAUSS, TAIL_VAE_KL = 0, 1, 2, 3, 4
 
 
 class SeedT(C.Structure):  # osrl_mlp_seed_t

@@ -2360,12 +2360,14 @@ static bool fwd_tail_ok(const osrl_mlp_tail_t* t, const osrl_mlp_t* net) {
   if (!t || t->kind == OSRL_TAIL_NONE) return true;
   if (t->L < 1 || 2 * t->L != net->dims[net->n_layers]) return false;
   if (t->kind == OSRL_TAIL_VAE_LATENT) return t->eps && t->out;
+  if (t->kind == OSRL_TAIL_VAE_KL) return t->out != nullptr;
   if (t->kind == OSRL_TAIL_GAUSS)
     return (!t->eps || t->out) && (!t->eps2 || t->out2) && (!t->eps_ood || (t->out_ood && t->n_samples >= 1));
   return false;
 }
 static int fwd_tail_as_launches(const osrl_mlp_tail_t* t, const float* head, int rows, void* stream) {
   if (t->kind == OSRL_TAIL_VAE_LATENT) return osrl_vae_latent(head, t->eps, rows, t->L, t->out, stream);
+  if (t->kind == OSRL_TAIL_VAE_KL) return osrl_vae_kl_rows(head, rows, t->L, t->out, stream);
   int rc = 0;
   if (t->eps) rc = osrl_gauss_head(head, t->eps, rows, t->L, t->max_action, t->out, nullptr, nullptr, stream);
   if (rc == 0 && t->eps2) rc = osrl_gauss_head(head, t->eps2, rows, t->L, t->max_action, t->out2, t->tanh2, nullptr, stream);
@@ -2384,11 +2386,16 @@ static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const 
   const bool want_tail = tail && tail->kind != OSRL_TAIL_NONE;
   if (want_tail && !fwd_tail_ok(tail, net)) return -1;
   {
-    const int rc = osrl_launch_fwd_nb(net, in, out, (hipStream_t)stream);
-    if (rc != kNbNotTaken) {  // the 80-row kernel keeps no output tile in LDS: the tail is its own launch
-      if (rc != 0 || !want_tail) return rc;
+    const bool kl_tail = want_tail && tail->kind == OSRL_TAIL_VAE_KL;  // the one tail the 80-row kernel runs itself
+    const int rc = osrl_launch_fwd_nb(net, in, out, (hipStream_t)stream, kl_tail ? tail->out : nullptr, kl_tail ? tail->L : 0);
+    if (rc != kNbNotTaken) {  // the 80-row kernel keeps no output tile in LDS: any other tail is its own launch
+      if (rc != 0 || !want_tail || kl_tail) return rc;
       return fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
     }
+  }
+  if (want_tail && tail->kind == OSRL_TAIL_VAE_KL) {  // tile kernels: the plain forward, then the rows kernel
+    const int rc = mlp_forward_impl(net, in, out, nullptr, stream);
+    return rc != 0 ? rc : fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
   }
   FwdArgs a{};
   a.net = *net;

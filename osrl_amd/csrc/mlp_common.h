@@ -188,4 +188,6 @@ __device__ __forceinline__ f32x4 EXP_MFMA(float a, float b, f32x4 c) {
 constexpr int kNbNotTaken = -12345;
 constexpr size_t kLdsMax = 160 * 1024;
 }  // namespace
-__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream);
+// kl / kl_L: the OSRL_TAIL_VAE_KL tail (per-row KL of net 0's (mean | log_std) output), NULL = none
+__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream,
+                                                             float* kl = nullptr, int kl_L = 0);

@@ -31,8 +31,10 @@ struct NbArgs {
   osrl_mlp_t net;
   osrl_rows_t in;
   float* y[OSRL_MAX_NETS];
-  int32_t lda;
+  int32_t lda, kl_L;
+  float* kl;  // OSRL_TAIL_VAE_KL: [rows] per-row KL of net 0's (mean | log_std) output, or NULL
 };
+constexpr float kNbLsMin = -4.0f, kNbLsMax = 15.0f;  // net.py:325 (== kVaeLsMin / kVaeLsMax of glue.hip)
 
 #ifndef OSRL_NB8_ADB
 #define OSRL_NB8_ADB false  // 8-wave form: activation fragments single buffered (see nb_mm)
@@ -500,6 +502,28 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
         y[(size_t)(row0 + r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
       }
     }
+    if (a.kl && e == 0) {
+      // the KL rows of cpq.py:178-182 (glue.hip vae_kl_rows_kernel, term for term) from the partial tiles still in LDS:
+      // one launch and one read of the head off the side chain's tail
+      const int Lz = a.kl_L;
+      for (int r = tid; r < BM; r += 64 * NW) {
+        if (row0 + r < rows) {
+          auto outv = [&](int c) {
+            const float* p = lds + r * lda + c;
+            float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
+            if constexpr (NW == 8) sacc = (((sacc + p[4 * Np]) + p[5 * Np]) + p[6 * Np]) + p[7 * Np];
+            return act_fwd(act, sacc + bias[c]) * oscale;
+          };
+          float s_ = 0.f;
+          for (int k = 0; k < Lz; ++k) {
+            const float mean = outv(k);
+            const float sd = expf(fminf(fmaxf(outv(Lz + k), kNbLsMin), kNbLsMax));
+            s_ += -0.5f * (1.0f + logf(sd * sd) - mean * mean - sd * sd);
+          }
+          a.kl[row0 + r] = s_ / (float)Lz;
+        }
+      }
+    }
     PHASE_STAMP(5 + 4 * l);
   }
   WG_LOG(1);
@@ -542,7 +566,8 @@ static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hip
 
 }  // namespace
 
-__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream) {
+__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream,
+                                                             float* kl, int kl_L) {
   const int L = net->n_layers, nets = net->n_nets;
   if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNbNotTaken;
   for (int e = 0; e < nets; ++e)
@@ -568,6 +593,8 @@ __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* n
   a.in = *in;
   for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
   a.lda = lda;
+  a.kl = kl;
+  a.kl_L = kl_L;
   const int tiles = (in->rows + 79) / 80;
   bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
   for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;

@@ -22,11 +22,12 @@ from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_de
 from . import glue as G
 from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into
 
-# measured (round 3, one box, A/B pairs): 2042 vs 2180 steps/s with the fused draws -- bit-identical results, four launches
-# fewer, and SLOWER: the N*B cost-critic launch then starts 25 us earlier and runs beside the VAE backward instead of
-# its dW (the round-2 finding for a merged heads launch).  Off by default; the entry point and its
-# parity test stay (BCQ-Lag / BEAR-Lag / callers with another plan may want it).
-HEAD_TAILS = os.environ.get("OSRL_HEAD_TAILS", "0") == "1"
+# Every action draw of the step by the actor trunks' own forward launch (osrl_mlp_forward2_tail; bit-identical to the four
+# gauss_head / gauss_ood launches).  Round 3 measured it SLOWER (2042 vs 2180 steps/s: the N*B cost-critic launch then
+# started 25 us earlier, beside the VAE backward instead of its dW); with round 4's plan (seeded backward launches, the
+# 8-wave encoder launch, small dW tiles) the same switch is +4.9 % at C2 (2135-2138 -> 2237-2245 steps/s, two A/B pairs
+# on one box, gpurun_out/r4e) and -1.7 % at C4's (17, 6): on by default.
+HEAD_TAILS = os.environ.get("OSRL_HEAD_TAILS", "1") == "1"
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -320,9 +321,9 @@ class CPQEngine:
             if ev_vae is not None:
                 par.side[0].wait_event(ev_vae)
             self._pr("enc_ood", 0)  # bench.py: HIP events around the dominant launch as it runs inside the step
-            head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
+            # (the KL rows of cpq.py:178-182 by the encoder launch itself: OSRL_TAIL_VAE_KL)
+            self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl))
             self._pr("enc_ood", 1)
-            G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
             if dp is not None:
                 ev_kl = par.mark(0)
             elif N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)

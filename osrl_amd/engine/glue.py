@@ -52,6 +52,15 @@ def vae_latent_bwd_tail(head, eps, Lz, beta, rows_global, dhead) -> "L.TailT":
     return t
 
 
+def vae_kl_tail(Lz, kl) -> "L.TailT":
+    """osrl_mlp_tail_t for MlpRun.forward(tail=...): vae_kl_rows() on the encoder's output, by the forward launch itself
+    (the 80-row N*B-row kernel) or as a launch behind it (any other kernel)."""
+    t = L.TailT()
+    t.kind, t.L, t.out = L.TAIL_VAE_KL, int(Lz), _p(kl)
+    t._keep = kl
+    return t
+
+
 VAE_TAILS = os.environ.get("OSRL_VAE_TAILS", "1") == "1"  # 0: the reparameterisation and its backward as own launches
 
 
