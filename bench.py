@@ -20,9 +20,9 @@ per-GPU batch, one optimizer step per iteration, gradient all-reduce over RCCL),
 = per-GPU-batch gradient steps per second over the whole job ("scaling": "weak"); ``optimizer_steps_per_s`` and
 ``transitions_per_s`` are printed beside it.
 
-Timing: [probes, then ``--preroll-ms`` (40) of untimed GEMM work -- the device's power state needs ~25 ms of load
-after any idle gap, see preroll()] -> W warm-up steps -> barrier + synchronize -> EXACTLY K steps -> barrier +
-synchronize; max over ranks.
+Timing: probes -> [W warm-up steps -> barrier + synchronize -> EXACTLY K steps -> barrier + synchronize] reported as
+``no_preroll`` -> ``--preroll-ms`` (40) of untimed GEMM work (the device's power state needs ~25 ms of load after any idle
+gap, see preroll()) -> the same W + K sequence again = ``value``; max over ranks.  Both protocols are in every line.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` and ``cpu_baseline``.
 Nothing here reads /root/reference.
@@ -339,6 +339,36 @@ def in_step_us(eng, iters=40):
     return res
 
 
+def collectives_in_step(eng, dp, iters=30):
+    """Every collective of the data-parallel step AS IT RUNS INSIDE THE STEP: the step body is issued eagerly on the
+    graph's two streams (as in_step_us does) with the DataParallel hook recording HIP events around each collective on
+    its stream.  Every rank runs this (the bodies hold the collectives); returns [{what, bytes, us, us_median}] in issue
+    order -- 4 entries for CPQ: VAE gradient, [critic | cost-critic] gradients, KL all-gather, [actor | statistics |
+    qc_ood] -- whose sum against ms_per_step is the step's exposed communication."""
+    from osrl_amd.engine.core import Branches
+    par = Branches(True, 1)
+    snap = eng._snapshot()
+    recs = []
+    try:
+        for i in range(3 + iters):
+            dp._probe = [] if i >= 3 else None
+            eng.body(True, par)
+            if i >= 3:
+                recs.append(dp._probe)
+        torch.cuda.synchronize()
+        n = min(len(r) for r in recs)
+        out = []
+        for j in range(n):
+            ts = sorted(r[j][2].elapsed_time(r[j][3]) * 1e3 for r in recs)
+            out.append({"what": recs[0][j][0], "bytes": recs[0][j][1], "us": round(float(np.mean(ts)), 2),
+                        "us_median": round(float(ts[len(ts) // 2]), 2)})
+    finally:
+        dp._probe = None
+        torch.cuda.synchronize()
+        eng._restore(snap)
+    return out
+
+
 def roofline(eng):
     """Dominant kernels of the CPQ step: the two N*B-row forward launches (69% of the step's FLOPs).  Needs no trained
     state (the in-step probe snapshots and restores the engine), so main() runs it BEFORE the timed region; ``step_frac``
@@ -376,8 +406,17 @@ def roofline(eng):
                           "tools/gpu_pmc.sh, not measured in this run)"
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+    # headline `frac` / `achieved` = the launch AS IT RUNS INSIDE THE STEP (HIP events around it in the eagerly issued
+    # two-stream step body; the rocprofv3 average of the same kernel over graph replays is the cross-check under
+    # profiles/); `isolated_*` = the same launch alone on the device.  (Under data parallelism the in-step probe is not
+    # run -- its step bodies hold collectives -- and the isolated figure is reported, labelled.)
+    in_run = mean_us == mean_us
+    ach_run = res[dom]["flops"] / (mean_us * 1e-6) / 1e12 if in_run else ach
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach_run, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_run / PEAK_FP32_TFLOPS, 4),
+            "frac_is": "in-run (inside the step, beside the other branch's launches)" if in_run else "isolated (N > 1: no in-step probe)",
+            "isolated_achieved": round(ach, 3), "isolated_frac": round(ach / PEAK_FP32_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": int(4 * (eng.r_enc_ood.rows * (eng.r_enc_ood.net.dims[0] + eng.r_enc_ood.net.dims[-1])
                                           + lin(eng.r_enc_ood.net.dims) + sum(eng.r_enc_ood.net.dims[1:]))),
             "in_step_sites_us": {k: round(v[0], 2) for k, v in sites.items()} or None,
@@ -468,6 +507,87 @@ def cpu_baseline(budget_s=24.0):
                       f"{rate(probe[('torch', min(cands))]):.2f} steps/s"}
 
 
+def cpu_baseline_others(which=("c1", "c3", "c5")):
+    """CPU figures for the other BASELINE configs (SURVEY.md 8d's timing plan): the numpy oracle of each algorithm on the
+    config's shapes, at 4 BLAS threads (the reference's default, *_configs.py `threads`) and at the host's full pool.
+    Bounded samples: c1 ~1.5 s per setting; c3 >= 3 steps; c5 on a 128-sample slice of the 1024-sample batch (the loss is a
+    sum over samples; the figure is divided by 8) -- a reported baseline beside the GPU numbers, not a target."""
+    import dataclasses
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import Case, make_batch, make_cdt_batch, make_noise
+    from oracle_util import build_oracle
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    ncpu = os.cpu_count() or 1
+    wide = min(ncpu, 64)
+
+    def at(nthreads, fn):
+        ctx = threadpool_limits(limits=nthreads, user_api="blas") if threadpool_limits else None
+        try:
+            return fn()
+        finally:
+            if ctx is not None:
+                ctx.unregister() if hasattr(ctx, "unregister") else ctx.__exit__(None, None, None)
+
+    def rate(step, min_steps, budget):
+        step()
+        t0, n = time.perf_counter(), 0
+        while n < min_steps or time.perf_counter() - t0 < budget:
+            step()
+            n += 1
+            if n >= 2000:
+                break
+        return n, time.perf_counter() - t0
+
+    # the first seconds of BLAS work in a process run 10-50x slow on some hosts (thread-pool spin-up / cpu quota ramp:
+    # 16 vs 970 BC steps/s measured back to back in this container): 3 s of matmuls first
+    wa = np.random.RandomState(0).randn(512, 512).astype(np.float32)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 3.0:
+        wa @ wa
+    out = {}
+    for name in which:
+        try:
+            cfg = CONFIGS[name]
+            if cfg["algo"] == "cdt":
+                from test_gpu_cdt import C5_FULL
+                from test_oracle_cdt_golden import build_cdt_oracle
+                c = dataclasses.replace(C5_FULL, B=128, dropout=0.0)
+                o = build_cdt_oracle(c, np.float32)
+                b = make_cdt_batch(c)
+                a = (b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                     b["episode_cost"], b["costs"])
+                step, scale, mins, budget = (lambda: o.train_one_step(*a)), 128.0 / cfg["B"], 2, 0.0
+                what = f"CDT oracle (oracle/cdt_oracle.py, fp32) on a 128-sample slice of the {cfg['B']}-sample batch, x 1/8"
+            else:
+                c = Case("bench_" + name, cfg["algo"], od=cfg["od"], ad=cfg["ad"], B=cfg["B"], hidden=HID, vae_hidden=VAE_H,
+                         N=NS, steps=1, episode_len=cfg["episode_len"])
+                o = build_oracle(c)
+                b = make_batch(c)
+                if cfg["algo"] == "bc":
+                    step, mins, budget = (lambda: o.train_one_step(b["observations"], b["actions"])), 20, 1.5
+                else:
+                    nz = make_noise(c, 0)
+                    step = lambda: o.train_one_step(b["observations"], b["next_observations"], b["actions"],  # noqa: E731
+                                                    b["rewards"], b["costs"], b["done"], nz)
+                    mins, budget = 3, 0.0
+                scale = 1.0
+                what = f"numpy oracle (oracle/osrl_oracle.py) of {cfg['algo']} at ({cfg['od']}, {cfg['ad']}) B={cfg['B']}"
+            n4, d4 = at(min(4, ncpu), lambda: rate(step, mins, budget))
+            nw, dw = at(wide, lambda: rate(step, mins, budget)) if wide > 4 else (n4, d4)
+            r4, rw = n4 / d4 * scale, nw / dw * scale
+            best_threads = wide if rw >= r4 else min(4, ncpu)
+            out[name] = {"value": round(max(r4, rw), 4), "unit": "grad-steps/s", "cores": int(best_threads), "kind": "port",
+                         "at_4_threads": round(r4, 4), f"at_{wide}_threads": round(rw, 4),
+                         "sample": f"{what}: {n4} steps in {d4:.1f}s at 4 BLAS threads, {nw} in {dw:.1f}s at {wide} "
+                                   f"(host: {ncpu} cpus)"}
+        except Exception as e:  # a failing side measurement must not take the headline line down
+            out[name] = {"error": repr(e)[:200]}
+    return out
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -484,6 +604,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--preroll-ms", type=float, default=40.0,
                     help="untimed dense GEMM work queued in front of the warm-up steps (power-state ramp; 0 = none)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the first (no pre-roll) timed region")
     ap.add_argument("--no-extras", action="store_true", help="skip api_path / other_configs (N=1 extras)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     args = ap.parse_args()
@@ -540,17 +661,38 @@ def main():
         except Exception as e:  # a failing probe must not take the headline line down
             roof = {"error": repr(e)[:300]}
             torch.cuda.synchronize()
+    def max_over_ranks(x):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    # Both protocols are measured and reported: first W warm-up + K timed steps straight after the probes
+    # (`no_preroll`: what the same command measured in rounds 1-3's records), then the pre-roll + W + K again: `value`.
+    n_done = 0
+    dt_cold = None
+    if args.preroll_ms > 0 and not args.no_cold:
+        torch.cuda.synchronize()
+        dt_cold = max_over_ranks(timed_steps(wl.step, args.steps, args.warmup, barrier))
+        n_done += args.warmup + args.steps
     pre_ms = preroll(device, args.preroll_ms)
-    dt = timed_steps(wl.step, args.steps, args.warmup, barrier)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(timed_steps(wl.step, args.steps, args.warmup, barrier))
+    n_done += args.warmup + args.steps
 
     stats = eng.st.read_stats()
     assert all(np.isfinite(v) for v in stats.values()), stats
-    assert eng.st.device_step() == args.warmup + args.steps
+    assert eng.st.device_step() == n_done
+
+    # data parallel: how long each of the step's collectives takes inside the step (every rank runs the probe)
+    coll = None
+    if dp is not None and cfg["algo"] == "cpq":
+        try:
+            coll = collectives_in_step(eng, dp)
+        except Exception as e:
+            coll = {"error": repr(e)[:200]}
+            torch.cuda.synchronize()
 
     # N > 1: BASELINE.json's multi-GPU config is C4 (CPQ at (17, 6), 2048 rows per GPU = global batch 16384 at 8 GPUs);
     # every rank runs it (collectives inside), rank 0 reports it under other_configs
@@ -591,8 +733,15 @@ def main():
                        "graph": bool(getattr(eng, "graph", None) is not None)},
             "optimizer_steps_per_s": round(args.steps / dt, 2),
             "preroll_ms": round(pre_ms, 1),  # untimed GEMM work queued before the W warm-up steps (see preroll())
+            # the same W + K steps timed FIRST, without the pre-roll (rounds 1-3's protocol: the device's power state is
+            # still ramping during a 10 ms timed region) -- both protocols in every line
+            "no_preroll": None if dt_cold is None else {"value": round(world * args.steps / dt_cold, 2),
+                                                       "ms_per_step": round(dt_cold / args.steps * 1e3, 4)},
             "transitions_per_s": round(world * B * args.steps / dt, 1),
             "rccl_ranks": rccl_ranks,
+            # data parallel only: each collective of the step timed inside the eagerly issued step body (issue order);
+            # sum / (1e3 * ms_per_step) = the share of the step spent in exposed communication
+            "collectives_in_step": coll,
             # two accountings of the same step: the REFERENCE's work for it (SURVEY.md 8d formula; what a reference
             # user gets per step) and the FLOPs this build actually issues (the reference's discarded VAE decoder on
             # the N*B rows and its repeated actor forwards are not executed) -- hardware utilisation is the second
@@ -620,6 +769,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             if args.config == "c2":
                 out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if "other_configs" in out and not args.no_extras:  # the CPU figure beside each of the other configs' GPU numbers
+                for k, v in cpu_baseline_others().items():
+                    if k in out["other_configs"] and isinstance(out["other_configs"][k], dict):
+                        out["other_configs"][k]["cpu_baseline"] = v
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp is not None:
         import torch.distributed as dist

@@ -13,7 +13,13 @@
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), makes no
  *    host synchronisation and is hipGraph-capturable;
  *  - return value: 0 on success, otherwise a hipError_t (or -1 for a bad argument);
- *    nothing throws across the ABI; there is no global mutable state.
+ *    nothing throws across the ABI.  State: none that persists between calls, with ONE opt-in exception --
+ *    osrl_args_begin / osrl_args_end bracket a THREAD-LOCAL argument arena (csrc/argmem.h, a static thread_local in
+ *    csrc/optim.hip): between the two calls the fused-MLP / optimizer / prologue launches of the calling thread record
+ *    or look up their descriptors there; outside such a bracket (the default) every call is stateless and re-entrant
+ *    across streams, devices and threads.  A few entry points own caller-provided device scratch that must be zero
+ *    before the first call and is re-armed by the call itself (arrival counters: osrl_mlp_backward_dw_tiles_adam,
+ *    osrl_mlp_backward_dz_seed, osrl_mlp_regress_step, the *_ws loss / quantile calls).
  */
 #ifndef OSRL_AMD_H
 #define OSRL_AMD_H

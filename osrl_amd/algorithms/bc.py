@@ -98,6 +98,8 @@ class BCTrainer:
     def evaluate(self, eval_episodes):
         """bc.py:111-123.  A ``VecSyntheticSafeEnv`` as ``self.env`` runs the episodes as one batch on device."""
         from ..common.synthetic_env import VecSyntheticSafeEnv
+        if getattr(self.model, "_engine", None) is not None:
+            self.model._engine.check_health()  # never evaluate parameters a failed one-launch step left behind
         if isinstance(self.env, VecSyntheticSafeEnv):
             from ..engine.rollout import evaluate_batched
             extra = float(self.cost_limit) if self.bc_mode == "multi-task" else None

@@ -53,6 +53,9 @@ def train_step_count(model) -> int:
 
 def checkpoint_state(model, with_optimizer: bool = True) -> Dict[str, Any]:
     """The dict to hand to ``torch.save`` (host tensors only)."""
+    chk = getattr(getattr(model, "_engine", None), "check_health", None)
+    if chk is not None:
+        chk()  # never save parameters a failed one-launch step left behind (engine/bc.py)
     out: Dict[str, Any] = {"model_state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}
     if not with_optimizer:
         return out

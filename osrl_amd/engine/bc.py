@@ -41,6 +41,8 @@ class BCEngine:
                            and self.plan.n_splits == 1 and 0 < self.plan.n_work <= L.STEP_MAX_WG
                            and B <= 16 * L.STEP_MAX_WG)
         self.step_ws = torch.zeros(L.STEP_WS, **f) if self.one_launch else None
+        if self.one_launch:
+            self.st.health_checks.append(self.check_health)
         self._step_c = None
         # A one-kernel step is launched directly: replaying a one-node hipGraph costs 42.4 us per step where the
         # launch itself costs 39.2 (tools/bc_eager_vs_graph.py).  Its descriptor still lives in HBM (ArgArena:
@@ -95,6 +97,23 @@ class BCEngine:
         """True when a workgroup of the one-launch step gave up waiting for the row tiles (synchronises; never seen:
         all its workgroups are resident at once).  The parameters are invalid after that."""
         return bool(self.one_launch and self.step_ws[L.STEP_MAX_WG + 2].item() != 0)
+
+    def check_health(self) -> None:
+        """Runs wherever the host synchronises with the step anyway (StepState.health_checks: statistics flush,
+        device_step; BCTrainer.evaluate; checkpoint save).  The one-launch step's dW workgroups WAIT for the row tiles
+        with a bounded poll; on a device where they are not all resident at once (a partitioned or CU-masked GPU) the
+        poll can expire -- the kernel then flags it and goes on with an incomplete gradient.  That must not pass
+        silently: the flag is cleared, the engine falls back to the six-launch plan for good, and the caller is told
+        that the parameters since the last good checkpoint are invalid."""
+        if self.one_launch and self.step_ws[L.STEP_MAX_WG + 2].item() != 0:
+            self.one_launch = False
+            self._arena_direct = None
+            self.step_ws.zero_()
+            raise RuntimeError(
+                "osrl_amd: a workgroup of the one-launch BC step gave up waiting for the row tiles (not all of the "
+                "launch's workgroups were resident at once on this device); parameters updated since the last "
+                "statistics read are INVALID -- restore a checkpoint.  The engine now runs the six-launch plan "
+                "(OSRL_BC_ONE_LAUNCH=0 selects it from the start).")
 
     def attach_replay(self, store) -> None:
         """Sample (observations, actions) minibatches on device from ``store`` (common/replay.py) inside the step:

@@ -764,6 +764,14 @@ class StepState:
         self.stats = torch.zeros(self.n_stats, dtype=torch.float32, device=device)
         self.ring = torch.zeros(ring_len, self.n_stats, dtype=torch.float32, device=device)
         self.host_step = 0
+        # callables run at every point where the host synchronises with the step anyway (statistics reads, device_step):
+        # an engine whose launches can flag a failure on device (the one-launch BC step's bounded wait) registers its
+        # check here, so the flag cannot go unread for longer than one statistics flush
+        self.health_checks: list = []
+
+    def _health(self) -> None:
+        for f in self.health_checks:
+            f()
 
     @property
     def ptr(self) -> int:
@@ -817,10 +825,13 @@ class StepState:
         self.host_step = int(step)
 
     def device_step(self) -> int:
-        return int(self.state[:8].view(torch.int64).item())
+        v = int(self.state[:8].view(torch.int64).item())
+        self._health()
+        return v
 
     def read_stats(self, step: Optional[int] = None) -> Dict[str, float]:
         """Statistics of train step ``step`` (1-based; default = the latest).  Synchronises."""
+        self._health()
         if step is None or step == self.host_step:
             v = self.stats.tolist()
         else:
@@ -838,6 +849,7 @@ class StepState:
         if min(steps) < 1 or self.host_step - min(steps) >= self.ring_len:
             raise RuntimeError("statistics of that step were already overwritten in the ring")
         both = torch.cat([self.ring.reshape(-1), self.stats]).tolist()  # one kernel, one synchronising copy
+        self._health()
         n = self.n_stats
         cur = both[self.ring_len * n:]
         out = {}

@@ -223,8 +223,6 @@ class CPQEngine:
         Polyak-updates ``cost_critic_old``, so it waits for the side branch's last reader of the targets; the encoder on
         the N*B rows waits for the VAE's Adam; the actor phase waits for the critic's Adam."""
         dp = self.dist
-        if dp is not None and os.environ.get("OSRL_DP_PLAN") == "r1":
-            return self.body_dp(device_noise, par)  # the round-1 plan (A/B measurements)
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
@@ -378,115 +376,6 @@ class CPQEngine:
         # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains); under
         # data parallelism the statistics are already the global ones here, so the global term is added once
         G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
-
-    def body_dp(self, device_noise: bool, par: Optional[Branches] = None) -> None:
-        """The ROUND-1 data-parallel plan (OSRL_DP_PLAN=r1; ``body`` carries the data-parallel step since round 3).  ``par`` (graph capture only) forks the independent parts onto side streams:
-        critic phase (cpq.py:137-153) and the cost-critic target pre-work (cpq.py:159-176) do not depend
-        on the VAE update, so they run beside the VAE phase; the cost-critic update waits for the side branch's
-        forwards (the readers of the targets it Polyak-updates), the actor phase for the whole branch."""
-        m, st, nz, B = self.model, self.st, self.noise, self.B
-        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
-        nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
-        par = par or Branches(False)
-        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat,
-                    self.seed, device_noise)
-        par.fork(0)
-        # the side stream may start here; its launches are issued after the VAE phase's so the
-        # graph executor (which dispatches nodes in creation order) starts both branches at once
-        # ---- main: vae_loss  (cpq.py:125-135)
-        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
-        u = self.r_dec.forward(self.obs, self.z)[0]
-        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
-        self.r_enc.backward_dz()
-        self._optim("vae", self.p_vae, 0.0)
-
-        # ---- side branch (ONE side stream: the runtime runs two graph branches concurrently, see
-        # profiles/r1_timeline.txt): first everything of cost_critic_loss (cpq.py:155-176) that needs neither
-        # the new VAE nor a reduction -- so the N*B sampled actions exist early -- then critic_loss (cpq.py:137-153).
-        with par.on(0):
-            # independent 2048-row forwards are launched in pairs (osrl_mlp_forward2): each alone is at most one
-            # workgroup per CU running a serial latency chain
-            hn, ho = self.r_actor_next.forward_with((self.nobs,), self.r_actor_obs, (self.obs,))
-            head_next, head_obs = hn[0], ho[0]
-            G.gauss_head(head_next, nz["eps_next_cc"], B, ad, m.max_action, a=self.a_next2)
-            G.gauss_head(head_next, nz["eps_next_c"], B, ad, m.max_action, a=self.a_next)  # early: tiny launches
-            # issued while an N*B-row kernel holds the CU slots wait tens of microseconds for one
-            G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
-            ev_sampled = par.mark(0)
-            # the actor-phase sample (cpq.py:209) needs only this forward and its own noise: off the critical tail
-            G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
-            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
-            qc_old_next, qc = self.r_costold_next.forward_with((self.nobs, self.a_next2), self.r_cost,
-                                                               (self.obs, self.act))
-            y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
-            ev_fwd = par.mark(0)  # every forward of the side branch (all readers of cost_critic_old) is enqueued
-            G.cpq_critic_loss(y_old[:nq], nq, y_old[nq:], nqc, q, nq, self.rew, self.done, B, m.gamma, m.q_thres,
-                              rg, self.dq, st.stat_ptr("loss/critic_loss"))
-            self.r_critic.backward_dz()
-            if self.dist is None:
-                self._optim("critic", self.p_critic, m.tau)
-            else:  # collectives stay on the capture stream (same order on every rank): update after the join
-                self.p_critic.launch()
-
-        # ---- cost_critic_loss  (cpq.py:155-201): OOD scoring with the UPDATED vae
-        par.wait(ev_sampled)
-        self._pr("enc_ood", 0)
-        head_ood = self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)[0]
-        self._pr("enc_ood", 1)
-        G.vae_kl_rows(head_ood, N * B, Lz, self.kl)
-        if self.dist is not None:
-            self.dist.quantile(self.kl, 0.75, self.quant)
-        else:
-            G.quantile(self.kl, N * B, 0.75, self.quant)
-        # the cost-critic update needs the side branch's FORWARDS only (its products, and they are the last readers
-        # of cost_critic_old, which this phase's optimizer step Polyak-updates): it runs beside the critic's loss /
-        # backward / dW (/ Adam) chain instead of after it; the join moves to the actor phase -- or, under data
-        # parallelism, to the coalesced gradient all-reduce of the two critics (collectives stay on this stream)
-        par.wait(ev_fwd)
-        if self.dist is None and rg in (0, B):  # no batch-global reduction in between: one launch
-            G.cpq_cost_loss_ood(qc_s, nqc, self.kl, self.quant, N, qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost,
-                                B, m.gamma, m.qc_thres, m.alpha_lr, m.log_alpha, self.dqc,
-                                st.stat_ptr("loss/cost_critic_loss"))
-        elif self.dist is None:
-            G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
-            G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, self.ood_mean, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr,
-                            rg, 1.0, m.log_alpha, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
-        else:
-            # data parallel: the gradient does not depend on the global qc_ood mean (it only drives the dual step
-            # and the logged loss), so its reduction rides in the same collective as the two critics' gradients
-            G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
-            G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0,
-                            None, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
-        self.r_cost.backward_dz()
-        if self.dist is None:
-            self._optim("cost_critic", self.p_cost, m.tau)
-        else:
-            self.p_cost.launch()
-            par.join(0)  # the critic's dW (side branch) is complete
-            gc, gcc = m.groups["critic"], m.groups["cost_critic"]
-            self.dist.all_reduce_many_([self.dist.reduce_local(gc), self.dist.reduce_local(gcc), self.ood_mean])
-            gc.adam_step(m._lrs["critic"], st.ptr, tau=m.tau)
-            gcc.adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau)
-            G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0 / self.dist.world, m.log_alpha,
-                             st.stat_ptr("loss/cost_critic_loss"))
-
-        # ---- actor_loss  (cpq.py:203-222): needs the updated critic (side branch) and cost critic
-        if self.dist is None:
-            par.join(0)
-        y = self.r_pi_q.forward(self.obs, self.a_pi)
-        G.cpq_actor_loss(y[:nq], nq, y[nq:], nqc, B, m.q_thres, rg, self.dq_pi, st.stat_ptr("loss/actor_loss"))
-        self.r_pi_q.backward_dz()
-        G.gauss_head_bwd(head_obs, nz["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, ad, m.max_action,
-                         self.dhead_actor)
-        self.r_actor_obs.backward_dz()
-        if self.dist is None:
-            self._optim("actor", self.p_actor, m.tau)
-        else:  # actor gradient and the per-rank partial statistics in one collective
-            self.p_actor.launch()
-            ga = m.groups["actor"]
-            self.dist.all_reduce_many_([self.dist.reduce_local(ga), st.stats])
-            ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
 
     # ------------------------------------------------------------------ #
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:

@@ -38,6 +38,19 @@ class DataParallel:
         # broadcasts name their source by GLOBAL rank: rank 0 of a sub-group is not global rank 0
         self.src0 = dist.get_global_rank(group, 0) if group is not None else 0
         self._gather_buf = None
+        # bench.py's collective probe: a list makes every collective of the step bodies issued meanwhile record
+        # (label, bytes, start event, end event) on its stream -- how long each one takes INSIDE the step
+        self._probe: Optional[list] = None
+
+    def _timed(self, label: str, nbytes: int, fn):
+        if self._probe is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self._probe.append((label, int(nbytes), e0, e1))
+        return r
 
     def rank_seed(self, seed: int) -> int:
         """Philox key of this rank's noise / dropout / sampling streams: the ranks' rows are different samples of one
@@ -46,7 +59,8 @@ class DataParallel:
 
     # ---- collectives (plain torch.distributed; work on CPU tensors with gloo as well) ----
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._timed("all_reduce", t.numel() * t.element_size(),
+                    lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
         return t
 
     def all_reduce_many_(self, ts) -> None:
@@ -57,9 +71,11 @@ class DataParallel:
         # not be bypassed by the coalesced RCCL path just because some process group happens to be initialised)
         own = type(self).all_reduce_ is DataParallel.all_reduce_
         if own and len(ts) > 1 and ts[0].is_cuda and dist.is_initialized() and dist.get_backend(self.group) == "nccl":
-            with dist._coalescing_manager(group=self.group, device=ts[0].device, async_ops=False):
-                for t in ts:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            def coalesced():
+                with dist._coalescing_manager(group=self.group, device=ts[0].device, async_ops=False):
+                    for t in ts:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._timed(f"all_reduce x{len(ts)} coalesced", sum(t.numel() * t.element_size() for t in ts), coalesced)
         else:
             for t in ts:
                 self.all_reduce_(t)
@@ -69,7 +85,8 @@ class DataParallel:
         if self._gather_buf is None or self._gather_buf.numel() != n * self.world or \
                 self._gather_buf.device != t.device:
             self._gather_buf = torch.empty(n * self.world, dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(self._gather_buf, t.reshape(-1), group=self.group)
+        self._timed("all_gather", n * t.element_size() * self.world,
+                    lambda: dist.all_gather_into_tensor(self._gather_buf, t.reshape(-1), group=self.group))
         return self._gather_buf
 
     def all_agree(self, ok: bool, device) -> bool:

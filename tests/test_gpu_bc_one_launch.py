@@ -142,3 +142,28 @@ def test_one_launch_captured_in_a_graph_too(monkeypatch):
         torch.cuda.synchronize()
         _same_state(ea, eb, f"step {s + 1}")
     assert ea.graph is not None and ea._arena.misses == 0 and ea._arena.hits >= 1
+
+
+def test_a_flagged_one_launch_step_is_reported_at_the_next_synchronisation_and_the_engine_falls_back():
+    """the one-launch step's dW workgroups wait for the row tiles with a bounded poll; when it expires the
+    kernel sets an error word and continues.  The word is now read wherever the host synchronises anyway (statistics
+    read, device_step, evaluate, checkpoint): it raises once, clears the word, and the engine runs the six-launch plan
+    from then on."""
+    from osrl_amd import _lib as L
+    from osrl_amd.common.checkpoint import checkpoint_state
+    ma, _ = _pair(8, 2, [256, 256])
+    ea = ma.engine(256)
+    assert ea.one_launch
+    ea.attach_replay(_store(8, 2))
+    ea.step_replay()
+    ea.st.read_stats()  # healthy: no exception
+    ea.step_ws[L.STEP_MAX_WG + 2] = 1.0  # what the kernel writes when a workgroup gives up waiting
+    with pytest.raises(RuntimeError, match="one-launch BC step"):
+        ea.st.read_stats()
+    assert not ea.one_launch and float(ea.step_ws.abs().sum()) == 0.0
+    p0 = ma.groups["actor"].p.clone()
+    ea.step_replay()  # the six-launch plan
+    torch.cuda.synchronize()
+    assert not torch.equal(p0, ma.groups["actor"].p)
+    ea.st.read_stats()
+    checkpoint_state(ma)  # (also a check point; healthy now)
