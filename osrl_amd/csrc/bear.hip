@@ -16,6 +16,8 @@ namespace {
 
 constexpr float kLogStdMin = -20.0f, kLogStdMax = 2.0f;  // osrl/common/net.py:148-149
 constexpr int kRed = 1024;
+constexpr int kMmdWaves = 4;  // waves (= batch rows) per workgroup of bear_mmd_kernel; launch geometry as compile-time
+                              // constants: `blockDim` is a load from the hidden kernarg block in every wave
 constexpr int kMaxAd = 16;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -32,7 +34,7 @@ __device__ float block_sum(float v, float* sm /*>=17*/) {
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+    for (int i = 0; i < (kRed >> 6); ++i) t += sm[i];  // (always launched with kRed threads: no hidden-kernarg read)
     sm[16] = t;
   }
   __syncthreads();
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void bear_mmd_kernel(const float* __restrict__
                                                        float* __restrict__ a0) {
   extern __shared__ float lds[];  // per wave: x[M*ad], y[M*ad]
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int b = blockIdx.x * kMmdWaves + wv;
   float* xs = lds + (size_t)wv * 2 * M * ad;
   float* ys = xs + (size_t)M * ad;
   const bool row_ok = b < B;
@@ -234,7 +236,7 @@ __global__ void bear_head_bwd_kernel(const float* __restrict__ head, const float
                                      const float* __restrict__ tanh_u, const float* __restrict__ du_mmd,
                                      const float* __restrict__ coef, const float* __restrict__ da_nets, int n_nets,
                                      int B, int M, int ad, float* __restrict__ dhead) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (launched with 256 threads)
   if (i >= B * M * ad) return;
   const int r = i / ad, k = i - r * ad;
   const int b = r / M;
@@ -272,7 +274,7 @@ extern "C" int osrl_bear_mmd(const float* raw_vae, const float* head, const floa
       ad < 1 || ad > kMaxAd || !(sigma > 0.f) || (kernel != OSRL_MMD_GAUSSIAN && kernel != OSRL_MMD_LAPLACIAN))
     return -1;
   (void)hipGetLastError();
-  const int waves = 4;
+  const int waves = kMmdWaves;
   const size_t lds = (size_t)waves * 2 * n_samples * ad * sizeof(float);
   const dim3 grid((rows + waves - 1) / waves), block(64 * waves);
   if (kernel == OSRL_MMD_GAUSSIAN)

@@ -37,7 +37,7 @@ __device__ float block_red(float v, float* sm /*>=17*/) {
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = sm[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = MAX ? fmaxf(t, sm[i]) : t + sm[i];
+    for (int i = 1; i < (kRed >> 6); ++i) t = MAX ? fmaxf(t, sm[i]) : t + sm[i];  // (kRed-thread launches only)
     sm[16] = t;
   }
   __syncthreads();
@@ -93,7 +93,7 @@ __global__ void dice_w_kernel(const float* __restrict__ nu2, int n_nu, int B, co
                               const float* __restrict__ cost, const float* __restrict__ done,
                               const float* __restrict__ leaves, float* __restrict__ work, int use_saved, float alpha,
                               float gamma, int f_type, float* __restrict__ e_out, float* __restrict__ w_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x * 256 + threadIdx.x;
   const float lam = use_saved ? work[0] : softplus(leaves[3]);
   if (b == 0 && !use_saved) {
     work[0] = lam;
@@ -144,7 +144,7 @@ __device__ __forceinline__ float chi_ell(const ChiArgs& a, int b, int* i1, int* 
 
 // ell of this rank's rows (data parallel: all-gathered before dice_chi_kernel)
 __global__ void dice_chi_ell_kernel(ChiArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
   int i1, i2;
   a.ell[b] = chi_ell(a, b, &i1, &i2);
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kRed) void dice_nu_kernel(NuArgs a) {
 __global__ void dice_perturb_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                     const float* __restrict__ std, int rows, int d, float scale,
                                     float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * d) return;
   out[i] = x[i] + eps[i] * std[i % d] * scale;
 }

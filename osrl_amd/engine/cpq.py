@@ -315,6 +315,9 @@ class CPQEngine:
             gcc.adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau)
 
         # ---- side branch, second half: the OOD statistic with the UPDATED vae
+        # (round 4, measured and dropped: letting this launch wait for the cost critics' optimizer step instead -- so that it
+        # does not stretch the cost phase it runs beside -- is SLOWER, 2161-2165 vs 2242-2244 steps/s at C2, 2257 vs 2285 at
+        # C4: the step is throughput-bound, the N*B-row work has to start as early as its inputs allow)
         with par.on(0):
             if ev_vae is not None:
                 par.side[0].wait_event(ev_vae)
