@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libosrl_amd.so")
-SOURCES = ["mlp.hip", "mlp_nb.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "diag.hip"]
+SOURCES = ["mlp.hip", "mlp_nb.hip", "mlp_dw.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "diag.hip"]
 
 
 def _hipcc() -> str:
@@ -24,7 +24,7 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (needed to build libosrl_amd.so for gfx950)")
 
 
-HEADERS = ["philox.h", "step.h", "argmem.h", "adam.h", "gather.h", "mlp_common.h"]  # csrc headers shared between translation units
+HEADERS = ["philox.h", "step.h", "argmem.h", "adam.h", "gather.h", "mlp_common.h", "dwt.h"]  # csrc headers shared between translation units
 
 
 def _common_deps():

@@ -184,6 +184,14 @@ __device__ __forceinline__ f32x4 EXP_MFMA(float a, float b, f32x4 c) {
 #define EXP_AREAD(p) (*reinterpret_cast<const f32x4*>(p))
 #endif
 
+template <int NRB, int NCB>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRB][NCB]) {
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // the 80-row forward lives in mlp_nb.hip; mlp.hip's osrl_mlp_forward asks it first (kNbNotTaken: the shape is not its)
 constexpr int kNbNotTaken = -12345;
 constexpr size_t kLdsMax = 160 * 1024;
