@@ -1031,6 +1031,9 @@ int osrl_layernorm_fwd_drop(const float* x, const float* delta, const osrl_dropo
                             void* stream) {
   if (!x || !delta || !gamma || !beta || !y || !stats || M < 1 || E < 1 || E > 64 * kMaxEPL) return -1;
   DropSite d{};
+  // p = 0 (or no descriptor): the plain call.  p >= 1 would have to zero the branch (torch does) while the backward's
+  // twin rejects it: both reject it -- no reference config drops everything, the engine validates p < 1
+  if (drop && !(drop->p < 1.0f)) return -1;
   if (!drop_site(drop, &d)) return osrl_layernorm_fwd(x, delta, gamma, beta, xout, y, stats, M, E, stream);
   CLEAR();
   hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M, E,

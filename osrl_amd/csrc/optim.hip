@@ -171,7 +171,9 @@ struct AdamArgs {
   PackMap pk;
   int32_t n_splits;
   float lr, b1, b2, eps, wd, tau;
+  int32_t pad_;  // (explicit: the arena looks descriptors up by memcmp over the whole struct -- no implicit padding bytes)
 };
+static_assert(sizeof(AdamArgs) == 8 * 4 + 8 + 3 * 8 + 2 * 8 + sizeof(PackMap) + 8 * 4, "AdamArgs has implicit padding");
 __global__ __launch_bounds__(256) void adam_kernel_p(const void* ptr) {
   const OSRL_CAS AdamArgs& a = *(const OSRL_CAS AdamArgs*)ptr;
   const PackMap pk{a.pk.map_f, a.pk.map_b, a.pk.pf, a.pk.pb, a.pk.tf};

@@ -11,7 +11,7 @@ import torch
 from .. import _lib as L
 from ..common.net import net_desc_seq
 from . import glue as G
-from .core import ArgArena, DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into
+from .core import ArgArena, DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into, check_plans_current
 
 STAT_KEYS = ["loss/actor_loss"]
 
@@ -153,6 +153,7 @@ class BCEngine:
         self._run(use_graph)
 
     def body(self) -> None:
+        check_plans_current(self)
         m, B, ad = self.model, self.B, self.model.action_dim
         if self.one_launch:
             rc = L.load().osrl_mlp_regress_step(C.byref(self._one_launch_args()), cur_stream())
@@ -182,6 +183,7 @@ class BCEngine:
         self._run(use_graph)
 
     def _capture(self) -> None:
+        check_plans_current(self)
         g = self.model.groups["actor"]
         snap = (g.p.clone(), g.m.clone(), g.v.clone(), self.st.state.clone(), self.st.stats.clone(),
                 self.st.ring.clone(), self.st.host_step)

@@ -17,7 +17,7 @@ import torch
 from .. import _lib as L
 from ..common.net import net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, capture_step, concat_nets, load_into
+from .core import Branches, DwPlan, MlpRun, StepState, capture_step, concat_nets, load_into, check_plans_current
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/qc_penalty",
              "loss/lagrangian"]
@@ -252,6 +252,7 @@ class BCQLEngine:
 
     def step_replay(self, use_graph: bool = True) -> None:
         """One train step on a minibatch drawn on device from the attached replay store."""
+        check_plans_current(self)
         assert self.replay is not None
         if use_graph and self.dist is None:
             if self.graph is None:
@@ -263,6 +264,7 @@ class BCQLEngine:
 
     def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
              use_graph: bool = True) -> None:
+        check_plans_current(self)
         if self.replay is not None:
             raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done)

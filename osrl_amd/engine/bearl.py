@@ -15,7 +15,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_dec_raw_desc, vae_enc_desc
 from . import glue as G
-from .core import Branches, DwPlan, MlpRun, StepState, capture_step, concat_nets, cur_stream, load_into
+from .core import Branches, DwPlan, MlpRun, StepState, capture_step, concat_nets, cur_stream, load_into, check_plans_current
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/mmd_loss",
              "loss/qc_penalty", "loss/lagrangian", "loss/alpha_value"]
@@ -235,6 +235,7 @@ class BEARLEngine:
         self.graph = None
 
     def step_replay(self, use_graph: bool = True) -> None:
+        check_plans_current(self)
         assert self.replay is not None
         if use_graph and self.dist is None:
             if self.graph is None:
@@ -246,6 +247,7 @@ class BEARLEngine:
 
     def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
              use_graph: bool = True) -> None:
+        check_plans_current(self)
         if self.replay is not None:
             raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done)

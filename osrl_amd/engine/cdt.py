@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _lib as L
-from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into
+from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into, check_plans_current
 
 FUSE_DROP = os.environ.get("OSRL_CDT_FUSE_DROP", "1") == "1"  # residual-branch dropout inside the LayerNorm launches
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
@@ -108,6 +108,10 @@ class CDTEngine:
         # dropout: probabilities, generator seed; gradients of the dropped branches need their own buffers
         # (the undropped gradient keeps flowing along the residual path)
         self.p_emb, self.p_attn, self.p_res = m.embedding_dropout, m.attention_dropout, m.residual_dropout
+        for name, pv in (("embedding_dropout", self.p_emb), ("attention_dropout", self.p_attn),
+                         ("residual_dropout", self.p_res)):
+            if not (0.0 <= float(pv) < 1.0):  # p = 1 drops everything: the kernels' keep scale 1 / (1 - p) has no value
+                raise ValueError(f"CDT {name} = {pv}: the dropout kernels take 0 <= p < 1")
         self.seed = int(trainer_cfg.get("seed", 0))
         if dist is not None:  # independent dropout masks per rank
             self.seed = dist.rank_seed(self.seed)
@@ -469,11 +473,13 @@ class CDTEngine:
 
     def step_store(self, use_graph: bool = True) -> None:
         """One train step on windows sampled on device from the attached SequenceStore."""
+        check_plans_current(self)
         assert self.store is not None
         self._go(use_graph)
 
     def step(self, states, actions, returns, costs_return, time_steps, mask, costs, use_graph: bool = True,
              episode_cost=None) -> None:
+        check_plans_current(self)
         if self.store is not None:
             raise RuntimeError("a SequenceStore is attached: call step_store()")
         self.load_batch(states, actions, returns, costs_return, time_steps, mask, costs, episode_cost)

@@ -19,7 +19,7 @@ import torch
 
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq
-from .core import DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into
+from .core import DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into, check_plans_current
 
 STAT_KEYS = ["loss/chi_loss", "loss/tau_loss", "loss/D_kl", "loss/Df", "loss/td_error", "loss/nu_loss",
              "loss/lmbda_loss", "loss/actor_loss", "loss/tau", "loss/lmbda"]
@@ -176,6 +176,7 @@ class COptiDICEEngine:
         self.graph = None
 
     def step_replay(self, use_graph: bool = True) -> None:
+        check_plans_current(self)
         assert self.replay is not None
         if use_graph and self.dist is None:
             if self.graph is None:
@@ -187,6 +188,7 @@ class COptiDICEEngine:
 
     def step(self, observations, next_observations, actions, rewards, costs, done, is_init, noise=None,
              use_graph: bool = True) -> None:
+        check_plans_current(self)
         if self.replay is not None:
             raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done, is_init)

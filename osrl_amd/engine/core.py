@@ -74,6 +74,10 @@ class FlatGroup:
         self.b_off: Dict[str, int] = {}
         self.aliases: set = set()
         self._retired_slabs: list = []        # see ensure_slabs
+        # bumped whenever another plan is attached to slabs that an earlier engine's plans (and captured graphs) use: that
+        # engine's "rows beyond my split count stay zero" no longer holds once the newcomer writes there, so engines
+        # compare epochs before every replay and re-capture / refuse (stale_plans())
+        self.slab_epoch = 0
 
     def add(self, key: str, shape: Sequence[int], align: bool = True) -> int:
         assert self.p is None, "FlatGroup already finalized"
@@ -155,10 +159,12 @@ class FlatGroup:
         if self.slabs is None or self.n_splits < n_splits:
             if self.slabs is not None:
                 self._retired_slabs.append(self.slabs)
+                self.slab_epoch += 1
             self.slabs = torch.zeros(n_splits, self.n, dtype=torch.float32, device=self.device)
             self.n_splits = n_splits
         else:
             self.slabs.zero_()
+            self.slab_epoch += 1
 
     def offset(self, key: str) -> int:
         return self.layout[key][0]
@@ -230,6 +236,24 @@ class FlatGroup:
                                        self.slabs.data_ptr(), self.cur_splits, self.n, self.n, lr, betas[0],
                                        betas[1], eps, weight_decay, tau, _ptr(gscale), st_ptr, cur_stream()),
                     "osrl_adam_step")
+
+
+def slab_epochs(model) -> Tuple[int, ...]:
+    """The slab epochs of a model's optimizer groups, as an engine records them when its plans are built."""
+    return tuple(g.slab_epoch for g in model.groups.values())
+
+
+def check_plans_current(engine) -> None:
+    """Called by the step engines before a step: an engine built EARLIER on the same model whose groups have since had
+    another engine's plans attached must not run any more -- its dW plans' split counts no longer describe which slab
+    rows are written (FlatGroup.ensure_slabs) and a captured graph of it would sum rows the newcomer fills.
+    ``model.engine(...)`` always hands out the newest engine; holding on to an old one is the misuse this catches."""
+    cur = slab_epochs(engine.model)
+    if getattr(engine, "_slab_epochs", None) is None:
+        engine._slab_epochs = cur  # (first step of this engine: its own plans are the newest)
+    if cur != engine._slab_epochs:
+        raise RuntimeError("osrl_amd: this step engine is stale -- another engine was built on the same model after it "
+                           "(different batch size / plan); use the engine model.engine(...) returns now")
 
 
 class LayerRef:
@@ -716,6 +740,10 @@ class ArgArena:
                     a.blocks += int(nb.value)
                 else:
                     a.hits, a.misses = int(nh.value), int(nm.value)
+                    if a.misses:  # a launch whose descriptor the record pass did not store runs by value: correct, but its
+                        import warnings  # arguments then sit wherever the runtime keeps kernargs
+                        warnings.warn(f"osrl_amd: {a.misses} launch descriptor(s) of a captured step were not found in the "
+                                      f"argument arena ({a.hits} were); those launches take their arguments by value")
             return False
 
     def record(self) -> "ArgArena._Ctx":

@@ -20,7 +20,7 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
-from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into
+from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, check_plans_current
 
 # Every action draw of the step by the actor trunks' own forward launch (osrl_mlp_forward2_tail; bit-identical to the four
 # gauss_head / gauss_ood launches).  Round 3 measured it SLOWER (2042 vs 2180 steps/s: the N*B cost-critic launch then
@@ -472,11 +472,13 @@ class CPQEngine:
 
     def step_replay(self, use_graph: bool = True) -> None:
         """One train step on a minibatch drawn on device from the attached replay store."""
+        check_plans_current(self)
         assert self.replay is not None
         self._run(use_graph)
 
     def step(self, observations, next_observations, actions, rewards, costs, done, noise=None,
              use_graph: bool = True) -> None:
+        check_plans_current(self)
         if self.replay is not None:
             raise RuntimeError("a replay store is attached: call step_replay() (or attach_replay(None))")
         self.load_batch(observations, next_observations, actions, rewards, costs, done)

@@ -496,3 +496,21 @@ def test_seeded_backward_launches_equal_the_loss_launches(name):
     for s, (x, y) in enumerate(zip(sa, sb)):
         for k in x:
             assert abs(x[k] - y[k]) <= 2e-6 * max(1.0, abs(x[k])), (s, k, x[k], y[k])
+
+
+def test_an_engine_superseded_on_its_model_refuses_to_step():
+    """ADVICE r3 (core.py ensure_slabs): once another engine's dW plans are attached to a model's gradient slabs, an
+    engine built earlier -- its plans' split counts, its captured graph -- must not run any more; it raises instead of
+    summing slab rows the newcomer writes."""
+    c = ALL_CASES["cpq_small"]
+    m, tr, lg = build_gpu(c)
+    b = gpu_batch(c)
+    gpu_step(tr, c, b, 0)
+    old = m._engine
+    half = {k: v[: c.B // 2].contiguous() for k, v in b.items()}
+    tr.train_one_step(half["observations"], half["next_observations"], half["actions"], half["rewards"], half["costs"],
+                      half["done"])  # another batch size -> model.engine() builds a new engine on the same groups
+    assert m._engine is not old
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="stale"):
+        old.step(b["observations"], b["next_observations"], b["actions"], b["rewards"], b["costs"], b["done"])
