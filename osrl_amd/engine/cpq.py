@@ -26,8 +26,10 @@ from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, lo
 # gauss_head / gauss_ood launches).  Round 3 measured it SLOWER (2042 vs 2180 steps/s: the N*B cost-critic launch then
 # started 25 us earlier, beside the VAE backward instead of its dW); with round 4's plan (seeded backward launches, the
 # 8-wave encoder launch, small dW tiles) the same switch is +4.9 % at C2 (2135-2138 -> 2237-2245 steps/s, two A/B pairs
-# on one box, gpurun_out/r4e) and -1.7 % at C4's (17, 6): on by default.
-HEAD_TAILS = os.environ.get("OSRL_HEAD_TAILS", "1") == "1"
+# on one box, gpurun_out/r4e).
+# At C4's (17, 6) the tails cost 1 % instead (2295 vs 2319-2320; the OOD draws alone as a launch: 2272-2285): the tail of
+# the 128 actor tiles writes N x ad values per row, three times C2's.  "auto" (default) = tails while N * action_dim <= 32.
+HEAD_TAILS = os.environ.get("OSRL_HEAD_TAILS", "auto")
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -249,7 +251,7 @@ class CPQEngine:
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
-            if HEAD_TAILS:
+            if HEAD_TAILS == "1" or (HEAD_TAILS == "auto" and N * ad <= 32):
                 # every action draw of the step (cpq.py:141 a_next, :159 a_next2, :164-176 the N OOD draws, :209 the
                 # actor-phase sample) by the actor trunks' own forward launch, from its LDS-resident head tiles: four
                 # single-purpose launches (30 us on this branch inside the step, profiles/r3_timeline_*.txt) fewer
