@@ -605,6 +605,9 @@ def main():
     ap.add_argument("--preroll-ms", type=float, default=40.0,
                     help="untimed dense GEMM work queued in front of the warm-up steps (power-state ramp; 0 = none)")
     ap.add_argument("--no-cold", action="store_true", help="skip the first (no pre-roll) timed region")
+    ap.add_argument("--extras-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the side measurements behind the timed region may take before rank 0 prints the "
+                         "headline fields alone (0 = no watchdog)")
     ap.add_argument("--no-extras", action="store_true", help="skip api_path / other_configs (N=1 extras)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     args = ap.parse_args()
@@ -684,6 +687,32 @@ def main():
     stats = eng.st.read_stats()
     assert all(np.isfinite(v) for v in stats.values()), stats
     assert eng.st.device_step() == n_done
+
+    # ---- the headline measurement is done.  Everything below is side information; under data parallelism it holds
+    # collectives (the per-collective probe, the C4 line), i.e. a rank that fails or stalls there would hang its peers and
+    # the job would end without its line.  A watchdog guards the line: if the extras are not through after
+    # --extras-timeout seconds, rank 0 prints the headline fields alone (marked) and every rank leaves.
+    import threading
+    core = None
+    if rank == 0:
+        core = {"metric": "grad-steps/sec", "value": round(world * args.steps / dt, 2), "unit": "grad-steps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": cfg["desc"], "name": args.config, "global_batch": cfg["B"] * world,
+                           "parallelism": f"dp{world}", "graph": bool(getattr(eng, "graph", None) is not None)},
+                "rccl_ranks": rccl_ranks, "extras": f"timed out after {args.extras_timeout:.0f} s: headline fields only"}
+
+    def bail():
+        if core is not None:
+            os.write(json_fd, (json.dumps(core) + "\n").encode())
+        os._exit(0)
+
+    watchdog = None
+    if dp is not None and args.extras_timeout > 0:
+        watchdog = threading.Timer(args.extras_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
 
     # data parallel: how long each of the step's collectives takes inside the step (every rank runs the probe)
     coll = None
@@ -773,7 +802,11 @@ def main():
                 for k, v in cpu_baseline_others().items():
                     if k in out["other_configs"] and isinstance(out["other_configs"][k], dict):
                         out["other_configs"][k]["cpu_baseline"] = v
+        if watchdog is not None:
+            watchdog.cancel()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if watchdog is not None:
+        watchdog.cancel()
     if dp is not None:
         import torch.distributed as dist
         barrier()  # nobody tears the communicator down before every rank is through

@@ -195,10 +195,14 @@ int osrl_mlp_backward_dz_tail(const osrl_mlp_t* net, int32_t rows, const osrl_ml
  *                        (a = the critics' outputs [n_a, rows] = this launch's nets, b = the cost critics'; == osrl_cpq_actor_loss)
  *   OSRL_SEED_GAUSS_HEAD dy[r, :] = d/d(mu | log_std) of a = max_action tanh(mu + sd eps) given dL/da = sum_e a_e[r, :]
  *                        (a = [n_a, rows, ad] input gradients, tanh_u / eps [rows, ad]; no statistic; == osrl_gauss_head_bwd)
+ *   OSRL_SEED_BCQ_CRITIC backup = x0[r] + gamma (1 - x1[r]) max_j [ thres min(q1_j, q2_j) + (1 - thres) max(q1_j, q2_j) ] over the
+ *                        n_samples target samples j of row r (a = [n_a + n_b, rows * n_samples] target outputs, row-major by
+ *                        sample: r * n_samples + j; q1 = min over the first n_a, q2 over the last n_b; thres = lambda of
+ *                        bcql.py:144-146; x1 may be NULL: no (1 - done)); dy_e = 2 (y_e - backup) inv      (== osrl_bcq_critic_loss)
  * partials: >= 2 * n_nets * ceil(rows / 16) floats of scratch; counter: one uint32, ZERO before the first launch
  * (re-armed by the launch).  HOST struct. */
 enum { OSRL_SEED_NONE = 0, OSRL_SEED_MSE = 1, OSRL_SEED_CPQ_CRITIC = 2, OSRL_SEED_CPQ_COST = 3, OSRL_SEED_CPQ_ACTOR = 4,
-       OSRL_SEED_GAUSS_HEAD = 5 };
+       OSRL_SEED_GAUSS_HEAD = 5, OSRL_SEED_BCQ_CRITIC = 6 };
 typedef struct {
   int32_t kind;
   int32_t n_a, n_b;
@@ -207,7 +211,7 @@ typedef struct {
   const float *x0, *x1;
   const float *eps, *tanh_u;
   const float* kl_head;
-  int32_t kl_L, pad_;
+  int32_t kl_L, n_samples;
   float gamma, thres, scale, max_action;
   float stat_scale, stat_scale2, kl_beta, pad2_;
   float* partials;

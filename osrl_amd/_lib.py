@@ -61,13 +61,13 @@ TAIL_NONE, TAIL_VAE_LATENT, TAIL_VAE_LATENT_BWD, TAIL_GAUSS, TAIL_VAE_KL = 0, 1,
 class SeedT(C.Structure):  # osrl_mlp_seed_t
     _fields_ = [("kind", C.c_int32), ("n_a", C.c_int32), ("n_b", C.c_int32), ("rows_global", C.c_int32),
                 ("a", _fp), ("b", _fp), ("x0", _fp), ("x1", _fp), ("eps", _fp), ("tanh_u", _fp), ("kl_head", _fp),
-                ("kl_L", C.c_int32), ("pad_", C.c_int32), ("gamma", C.c_float), ("thres", C.c_float),
+                ("kl_L", C.c_int32), ("n_samples", C.c_int32), ("gamma", C.c_float), ("thres", C.c_float),
                 ("scale", C.c_float), ("max_action", C.c_float), ("stat_scale", C.c_float),
                 ("stat_scale2", C.c_float), ("kl_beta", C.c_float), ("pad2_", C.c_float), ("partials", _fp),
                 ("counter", C.c_void_p), ("stat", _fp)]
 
 
-SEED_NONE, SEED_MSE, SEED_CPQ_CRITIC, SEED_CPQ_COST, SEED_CPQ_ACTOR, SEED_GAUSS_HEAD = 0, 1, 2, 3, 4, 5
+SEED_NONE, SEED_MSE, SEED_CPQ_CRITIC, SEED_CPQ_COST, SEED_CPQ_ACTOR, SEED_GAUSS_HEAD, SEED_BCQ_CRITIC = 0, 1, 2, 3, 4, 5, 6
 
 
 class DwEntryT(C.Structure):

@@ -690,6 +690,26 @@ __device__ __forceinline__ float seed_dy(SR s, const int e, const int r, const i
     if (ok && e == 0) l0 -= mask * qm;
     return e == am ? -mask * s.scale : 0.f;
   }
+  if (kind == OSRL_SEED_BCQ_CRITIC) {  // glue.hip bcq_critic_loss_kernel, term for term (bcql.py:138-150)
+    const int ns = s.n_samples, nr = rows * ns;
+    const float lmbda = s.thres;
+    const float* __restrict__ q2p = s.a + (size_t)s.n_a * nr;
+    float best = -INFINITY;
+    for (int j = 0; j < ns; ++j) {
+      const int i = r * ns + j;
+      float q1 = s.a[i];
+      for (int k = 1; k < s.n_a; ++k) q1 = fminf(q1, s.a[(size_t)k * nr + i]);
+      float q2 = q2p[i];
+      for (int k = 1; k < s.n_b; ++k) q2 = fminf(q2, q2p[(size_t)k * nr + i]);
+      const float v = lmbda * fminf(q1, q2) + (1.0f - lmbda) * fmaxf(q1, q2);
+      best = fmaxf(best, v);
+    }
+    const float nd = s.x1 ? (1.0f - s.x1[r]) : 1.0f;
+    const float backup = s.x0[r] + s.gamma * nd * best;
+    const float d = yv - backup;
+    if (ok) l0 += d * d;
+    return 2.0f * d * s.scale;
+  }
   // OSRL_SEED_GAUSS_HEAD: yrow = (mu | log_std) of the row, NL = 2 ad
   const int ad = NL >> 1;
   const int j = c < ad ? c : c - ad;
@@ -1809,6 +1829,8 @@ static bool seed_ok(const osrl_mlp_seed_t* s, const osrl_mlp_t* net, const osrl_
     case OSRL_SEED_CPQ_COST: return NL == 1 && s->a && s->x0 && s->n_a >= 1 && s->n_a <= kSeedEns;
     case OSRL_SEED_CPQ_ACTOR:
       return NL == 1 && s->a && s->b && s->n_a >= 1 && s->n_a <= kSeedEns && s->n_b >= 1 && s->n_b <= kSeedEns;
+    case OSRL_SEED_BCQ_CRITIC:
+      return NL == 1 && s->a && s->x0 && s->n_a >= 1 && s->n_b >= 1 && s->n_samples >= 1;
     case OSRL_SEED_GAUSS_HEAD:
       return (NL & 1) == 0 && net->n_nets == 1 && s->a && s->eps && s->tanh_u && s->n_a >= 1 && s->n_a <= kSeedEns && !s->partials;
     default: return false;

@@ -107,6 +107,20 @@ class BCQLEngine:
         # batch-sum losses on a grid beyond 2048 rows (one workgroup walking 4096 rows x 10 samples x 4 nets alone: 44 us)
         big = B > 2048
         self.ws_vae, self.ws_c, self.ws_cc = (G.loss_ws(dev) if big else None for _ in range(3))
+        # loss seeds (round 4, as in engine/cpq.py): the VAE decoder's and the two online critic ensembles' backward
+        # launches compute the gradient they start from -- vae_loss and the two bcq_critic_loss launches leave the chains
+        self.seeds = None
+        if G.SEEDS and G.VAE_TAILS:
+            self.seeds = {
+                "vae": G.seed_vae(self.act, self.r_enc.y[0], B, ad, Lz, m.beta, self.rows_global, G.SeedStat(dev, 1, B),
+                                  self.st.stat_ptr("loss/loss_vae")),
+                "critic": G.seed_bcq_critic(self.r_qold_t.y, nq, nq, N, self.rew, self.done, B, m.gamma, m.lmbda,
+                                            self.rows_global, G.SeedStat(dev, 2 * nq, B),
+                                            self.st.stat_ptr("loss/critic_loss")),
+                "cost": G.seed_bcq_critic(self.r_qcold_t.y, nqc, nqc, N, self.cost, None, B, m.gamma, m.lmbda,
+                                          self.rows_global, G.SeedStat(dev, 2 * nqc, B),
+                                          self.st.stat_ptr("loss/cost_critic_loss")),
+            }
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
 
@@ -148,8 +162,13 @@ class BCQLEngine:
 
         head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
-        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"), ws=self.ws_vae)
-        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
+        sd = self.seeds
+        if sd is not None:
+            self.r_dec.backward_dz(tail=G.vae_latent_bwd_tail(head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc),
+                                   seed=sd["vae"])
+        else:
+            G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"), ws=self.ws_vae)
+            G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
         # round 3 (profiles/r3_bcql_timeline.txt): both branches are linear chains from here (a side branch forked BEFORE
@@ -171,15 +190,21 @@ class BCQLEngine:
             q, qc = self.r_critic.forward_with((self.obs, self.act), self.r_cost, (self.obs, self.act))
             ev_on = par.mark(0)
             qc_t = self._targets("z_cc", self.r_qcold_t, second=True)
-            G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
-                              st.stat_ptr("loss/cost_critic_loss"), ws=self.ws_cc)
-            self.r_cost.backward_dz()
+            if sd is not None:
+                self.r_cost.backward_dz(seed=sd["cost"])
+            else:
+                G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
+                                  st.stat_ptr("loss/cost_critic_loss"), ws=self.ws_cc)
+                self.r_cost.backward_dz()
             self.p_cost.launch()
 
         par.wait(ev_on)
-        G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
-                          st.stat_ptr("loss/critic_loss"), ws=self.ws_c)
-        self.r_critic.backward_dz()
+        if sd is not None:
+            self.r_critic.backward_dz(seed=sd["critic"])
+        else:
+            G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
+                              st.stat_ptr("loss/critic_loss"), ws=self.ws_c)
+            self.r_critic.backward_dz()
         if self.dist is None:
             self._optim("critic", self.p_critic, m.tau)
         else:  # reduced together with the cost critic's gradient after the join: one collective instead of two

@@ -115,6 +115,23 @@ class BEARLEngine:
         G.gauss_head(head, self.noise[eps_key], NB, m.action_dim, 1.0, a=self.a_t[which])
         return r_q.forward(self.nobs, self.a_t[which], map0=L.MAP_DIV, div0=N)
 
+    def _seeds(self):
+        """The loss seeds of this engine's backward launches (glue.seed_*), built once."""
+        if getattr(self, "_seed_cache", 0) == 0:
+            m, B, dev = self.model, self.B, self.obs.device
+            nq, nqc, N, rg = m.num_q, m.num_qc, m.sample_action_num, self.rows_global
+            self._seed_cache = None
+            if G.SEEDS and G.VAE_TAILS:
+                self._seed_cache = {
+                    "vae": G.seed_vae(self.act, self.r_enc.y[0], B, m.action_dim, m.latent_dim, m.beta, rg,
+                                      G.SeedStat(dev, 1, B), self.st.stat_ptr("loss/loss_vae")),
+                    "critic": G.seed_bcq_critic(self.r_qold_t.y, nq, nq, N, self.rew, self.done, B, m.gamma, m.lmbda, rg,
+                                                G.SeedStat(dev, 2 * nq, B), self.st.stat_ptr("loss/critic_loss")),
+                    "cost": G.seed_bcq_critic(self.r_qcold_t.y, nqc, nqc, N, self.cost, None, B, m.gamma, m.lmbda, rg,
+                                              G.SeedStat(dev, 2 * nqc, B), self.st.stat_ptr("loss/cost_critic_loss")),
+                }
+        return self._seed_cache
+
     def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
         """``par`` (graph capture): cost_critic_loss reads only actor_old and cost_critic_old -- nothing the critic
         phase writes -- so it runs on a side branch beside critic_loss, followed there by the head of actor_loss
@@ -128,17 +145,25 @@ class BEARLEngine:
 
         head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
         u = self.r_dec.forward(self.obs, self.z)[0]
-        G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
-        G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
+        sd = self._seeds()
+        if sd is not None:  # (round 4) the backward launches compute the gradient they start from, as in engine/cpq.py
+            self.r_dec.backward_dz(tail=G.vae_latent_bwd_tail(head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc),
+                                   seed=sd["vae"])
+        else:
+            G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
+            G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
 
         par.fork(0)
         q_t = self._targets("eps_c", self.r_qold_t, 0)
         q = self.r_critic.forward(self.obs, self.act)
-        G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
-                          st.stat_ptr("loss/critic_loss"))  # same lambda-mix / max-over-N backup as BCQ-L
-        self.r_critic.backward_dz()
+        if sd is not None:
+            self.r_critic.backward_dz(seed=sd["critic"])
+        else:
+            G.bcq_critic_loss(q_t, nq, nq, N, q, 2 * nq, self.rew, self.done, B, m.gamma, m.lmbda, rg, self.dq,
+                              st.stat_ptr("loss/critic_loss"))  # same lambda-mix / max-over-N backup as BCQ-L
+            self.r_critic.backward_dz()
         if self.dist is None:
             self._optim("critic", self.p_critic, m.tau)
         else:  # reduced together with the cost critic's gradient after the join: one collective instead of two
@@ -147,9 +172,12 @@ class BEARLEngine:
         with par.on(0):
             qc_t = self._targets("eps_cc", self.r_qcold_t, 1)
             qc = self.r_cost.forward(self.obs, self.act)
-            G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
-                              st.stat_ptr("loss/cost_critic_loss"))
-            self.r_cost.backward_dz()
+            if sd is not None:
+                self.r_cost.backward_dz(seed=sd["cost"])
+            else:
+                G.bcq_critic_loss(qc_t, nqc, nqc, N, qc, 2 * nqc, self.cost, None, B, m.gamma, m.lmbda, rg, self.dqc,
+                                  st.stat_ptr("loss/cost_critic_loss"))
+                self.r_cost.backward_dz()
             self.p_cost.launch()
             # head of actor_loss (bearl.py:219-232): needs the updated VAE and the not-yet-updated actor only
             raw = self.r_dec_raw.forward(self.obs, nz["z_mmd"], map0=L.MAP_DIV, div0=M)[0]

@@ -291,3 +291,13 @@ def seed_gauss_head(eps, tanh_u, da_nets, n_nets, rows, max_action):
     s.max_action = float(max_action)
     s._keep += [eps, tanh_u, da_nets]
     return s
+
+
+def seed_bcq_critic(q_t, n1, n2, n_samples, base, done, rows, gamma, lmbda, rows_global, ws, stat):
+    """== bcq_critic_loss(q_t, n1, n2, n_samples, q_on, ..., base, done, ...) for the online nets of the launch."""
+    s = _seed(L.SEED_BCQ_CRITIC, rows, rows_global, ws, stat)
+    s.a, s.n_a, s.n_b, s.n_samples, s.x0, s.x1 = _p(q_t), n1, n2, int(n_samples), _p(base), _p(done)
+    s.gamma, s.thres = float(gamma), float(lmbda)
+    s.scale = s.stat_scale = float(_inv(rows, rows_global))
+    s._keep += [q_t, base, done]
+    return s
