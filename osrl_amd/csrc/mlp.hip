@@ -1259,6 +1259,253 @@ __global__ __launch_bounds__(512, 4) void linear_big_kernel(const LinBigArgs a) 
   }
 }
 
+
+// ---- the persistent form of the same GEMM (round 4; tools/gemm_lab.hip is its bench, profiles/r4_gemm_lab.txt) -------
+// What linear_big_kernel loses at M = 81920 (0.61-0.69 of the fp32 MFMA roof by shape): every workgroup of the chip
+// reaches its epilogue at the same time -- 335 MB of stores in a burst at the chip's write rate with no MFMA running,
+// then a DMA prologue with neither (the same kernel with the stores removed: 0.75-0.80).  Here ONE 8-wave workgroup
+// per CU (256 registers per wave) walks a contiguous run of 128 x 128 tiles:
+//  * an S-slot DMA ring that keeps running across tile boundaries (no prologue per tile): slab g + 1 is landed at the
+//    top of k-step g and its fragments go to the OTHER fragment register set while the MFMAs of step g run;
+//  * the finished tile's accumulators move to a second register set and are stored ("dripped") 2 x 64 lanes per k-step
+//    during the first 16 k-steps of the next tile, the residual they need loaded one step earlier: the output leaves
+//    the chip beside the MFMAs;
+//  * A slot image XOR-swizzled (kq position = kq ^ perm[(row >> 2) & 3]) -> conflict-free ds_read_b128;
+//  * 16 k-steps unrolled, branch-free except for the point where a wave issues its memory instructions: after the
+//    first quarter of the step's MFMAs in waves 0-3, after the third in waves 4-7 (the two waves of a SIMD are w and
+//    w + 4: one feeds the matrix pipe while the other issues ds_read / DMA, ~100+ cycles each, in order).
+// Bit-identical to linear_big_kernel (same per-element k order).  Measured (M = 81920, us, old -> new):
+// K256 N1024 427 -> 344, K256 N768 336 -> 264, K1024 N256 +resid 434 -> 332, K256 N256 +resid 141 -> 107,
+// K768 N256 306 -> 245, K1024 N256 395 -> 319: 0.78-0.86 of the roof.
+// Requires M % 128 == 0, K % 256 == 0, N % 128 == 0 (host: osrl_linear); past the last tile the "next" tile is the
+// last one again (harmless reloads, drained before the kernel ends).
+// a load the compiler does not track: no conservative vmcnt(0) at its use (which would also wait for the DMA issued
+// since) -- the user waits with vm_wait<N>() naming the registers, N = vector memory operations issued after the load
+__device__ __forceinline__ float gload_untracked(const float* ubase, unsigned voff_bytes) {
+  float r;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff_bytes), "s"(ubase) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(float& r0, float& r1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N));
+}
+
+template <int RB, int CB, int S, bool RES>
+__global__ __launch_bounds__(512, 2) void linear_pers_kernel(const LinBigArgs a, const int row_tiles, const int col_groups,
+                                                          const int nwg) {
+  constexpr int BM = 32 * RB, BN = 64 * CB;
+  constexpr int kA = BM * 16, kB = 16 * BN;
+  constexpr int PB = 4 * BN / 512;    // B pieces per thread and slab
+  constexpr int NACC = RB * CB;       // accumulators (f32x4) per wave
+  constexpr int SPI = 4 * NACC / 16;  // dripped stores per k-step
+  constexpr int DMA_OPS = 1 + PB;
+  constexpr int L = S - 1;            // slabs in flight ahead of the one being multiplied
+  static_assert(BM == 128, "A slab = one float4 per thread");
+  extern __shared__ __attribute__((aligned(16))) float lds_p[];
+  float* As = lds_p;
+  float* Bs = lds_p + S * kA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int M = a.M, Np = a.Np;
+  const int ngrp = a.K >> 8;
+  const int tiles = row_tiles * col_groups;
+  const int wg = blockIdx.x;
+  const int t0 = (int)((long)tiles * wg / nwg), t1 = (int)((long)tiles * (wg + 1) / nwg);
+  if (t0 >= t1) return;
+  const int wbase = wave * 64 * 4;
+  // ---- issue side: this thread's float4 of the A slab (swizzled kq) and its PB float4 of the B slab ----
+  const int a_row = tid >> 2;
+  const int a_kq = (tid & 3) ^ ((0x78 >> (2 * ((tid >> 4) & 3))) & 3);
+  int bkq[PB], bcol[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int f = tid + 512 * p;
+    bkq[p] = f / BN;
+    bcol[p] = f % BN;
+  }
+  // running sources of the slab about to be issued: Ap = this thread's float4 of the A slab (per-thread pointer),
+  // Bp = first float4 of the B slab (wave-uniform: scalar registers) + voffB[p] = this thread's float4 inside the slab
+  // (never changes): loop-carried, so nothing about the 16 unrolled issues can be hoisted and spilled
+  const f32x4 *Ap, *Agn;
+  const f32x4 *Bp, *Bgn;
+  unsigned voffB[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) voffB[p] = (unsigned)(bkq[p] * Np + bcol[p]);
+  auto tile_ptrs = [&](int t, const f32x4*& ag, const f32x4*& bg) {
+    const int rt = t / col_groups, cg = t - rt * col_groups;
+    const int row = rt * BM + a_row;
+    ag = reinterpret_cast<const f32x4*>(a.A + (size_t)(row < M ? row : M - 1) * a.lda_g) + a_kq;
+    bg = reinterpret_cast<const f32x4*>(a.P) + (size_t)a.col0 + cg * BN;
+  };
+  tile_ptrs(t0, Ap, Bp);
+  tile_ptrs(t0 + 1 < t1 ? t0 + 1 : t0, Agn, Bgn);
+  int it_slot = 0;
+  const size_t b_step = (size_t)4 * Np;
+  auto dma = [&]() {  // the next slab of the tile being issued -> slot it_slot
+    float* as = As + it_slot * kA;
+    float* bs = Bs + it_slot * kB;
+    glds16(Ap, as + wbase);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) glds16(Bp + voffB[p], bs + p * 512 * 4 + wbase);
+    Ap += 4;
+    Bp += b_step;
+    it_slot = it_slot + 1 == S ? 0 : it_slot + 1;
+  };
+  // ---- consume side ----
+  const int a_off = (wr * 16 * RB + (lane & 15)) * 16 + 4 * ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3));
+  const int b_off = ((lane >> 4) * BN + wc * 16 * CB + (lane & 15)) * 4;
+  f32x4 acc[RB][CB], prev[RB][CB];
+  f32x4 af[2][RB], bf[2][CB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_slot = 0;  // slot of the slab being multiplied
+  auto rd = [&](int slot, f32x4* afb, f32x4* bfb) {
+    const float* as = As + slot * kA;
+    const float* bs = Bs + slot * kB;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) afb[r] = *reinterpret_cast<const f32x4*>(&as[a_off + r * 16 * 16]);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) bfb[c] = *reinterpret_cast<const f32x4*>(&bs[b_off + c * 64]);
+  };
+  auto mm = [&](const f32x4* afb, const f32x4* bfb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[r][t], bfb[c][t], acc[r][c], 0, 0, 0);
+  };
+  // element e (0 .. 4 NACC) of a wave tile = accumulator e / 4 = (r, c), row i = e % 4.  Its address is a wave-uniform
+  // base (scalar registers) + one per-lane 32-bit offset that never changes (saddr + voffset form).  The row stride is
+  // laundered through an empty asm so that the 64 offsets of a tile stay inside the k-loop (not hoisted and spilled).
+  const unsigned lane_row = (unsigned)(lane >> 4) * 4u;
+  const unsigned loff_y = lane_row * (unsigned)a.ldy + (unsigned)(lane & 15);
+  const unsigned loff_r = lane_row * (unsigned)a.ldr + (unsigned)(lane & 15);
+  const float* rbase = a.resid;
+  float* ybase = a.Y;
+  auto el_off = [&](int e, int ld_in) -> unsigned {
+    const int ai = e >> 2, i = e & 3, r = ai % RB;
+    const int c = ai / RB;
+    int ld = ld_in;
+    asm volatile("" : "+s"(ld));
+    return (unsigned)((r * 16 + i) * ld + c * 16);
+  };
+  float pbias[CB];
+
+  // prologue: slabs 0 .. L-1 of the first tile in flight; slab 0 landed for everyone, its fragments on the way to set 0
+#pragma unroll
+  for (int i = 0; i < L; ++i) dma();
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((L - 1) * DMA_OPS) : "memory");
+  rd(0, af[0], bf[0]);
+
+  // ONE instance of the 16 unrolled k-steps: whether the previous tile is dripped during them (first group of a tile
+  // that has a predecessor) and whether the slabs issued from step 16 - L on belong to the next tile (last group of a
+  // tile) are wave-uniform run-time flags
+  auto group = [&](auto drip_tag, const bool LAST) {
+    constexpr bool DRIP = decltype(drip_tag)::value;
+    // the residual of the elements stored at step j is loaded one step earlier (a full k-step of latency cover; the
+    // first set waits once per tile)
+    float rres[2][SPI];
+    auto res_load = [&](int j, float* dst) {
+#pragma unroll
+      for (int s = 0; s < SPI; ++s) {
+        dst[s] = gload_untracked(rbase + el_off(j * SPI + s, (int)a.ldr), loff_r * 4u);
+      }
+    };
+    if (DRIP && RES) res_load(0, rres[0]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // top of k-step g: slab g + 1 landed for everyone (slabs g + 2 .. g + S - 2 and the drips issued since may be in
+      // flight); everyone's MFMAs of step g - 1 are issued, i.e. the slot of slab g - 1 is free
+      constexpr int n_dma = (S - 3) * DMA_OPS;
+      if (j >= S - 2 && DRIP) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma + (S - 2) * SPI + (RES ? (S - 3) * SPI : 0)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma) : "memory");
+      c_slot = c_slot + 1 == S ? 0 : c_slot + 1;
+      if (DRIP && RES && j + 1 < 16) res_load(j + 1, rres[(j + 1) & 1]);
+      if (j + L == 16 && LAST) {  // the slabs issued from here on belong to the next tile
+        Ap = Agn;
+        Bp = Bgn;
+      }
+      // this step's fragments are in registers already: MFMAs first.  The reads of the next slab and the DMA issue
+      // (~100+ cycles each, in-order in this wave) go after the first quarter of the MFMAs in waves 0-3 and after the
+      // third quarter in waves 4-7 -- the two waves of a SIMD are w and w + 4, so one feeds the matrix pipe while the
+      // other issues memory instructions
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if ((t == 1 && wr == 0) || (t == 3 && wr == 1)) {
+          rd(c_slot, af[(j + 1) & 1], bf[(j + 1) & 1]);
+          dma();
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][r][t], bf[j & 1][c][t], acc[r][c], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (DRIP) {
+        if (RES) {
+          // issued after the loads of rres[j & 1]: this and the previous step's DMA, the previous step's stores and the
+          // next set's loads (before the loop for j = 0: the next set's loads and this step's DMA)
+          static_assert(SPI == 2, "vm_wait names two registers");
+          if (j == 0) vm_wait<SPI + DMA_OPS>(rres[0][0], rres[0][1]);
+          else if (j + 1 < 16) vm_wait<2 * DMA_OPS + 2 * SPI>(rres[j & 1][0], rres[j & 1][1]);
+          else vm_wait<2 * DMA_OPS + SPI>(rres[j & 1][0], rres[j & 1][1]);
+        }
+#pragma unroll
+        for (int s = 0; s < SPI; ++s) {
+          const int e = j * SPI + s;
+          float* yp = ybase + el_off(e, (int)a.ldy);
+          const int ai = e >> 2, r = ai % RB, c = ai / RB;
+          float pb = pbias[c];
+          asm volatile("" : "+v"(pb));
+          float v = prev[r][c][e & 3] + pb;
+          if (RES) v += rres[j & 1][s];
+          yp[loff_y] = v;
+        }
+      }
+    }
+  };
+
+  for (int t = t0; t < t1; ++t) {
+    for (int grp = 0; grp < ngrp; ++grp) {
+      if (grp == 0 && t > t0) group(std::true_type{}, grp == ngrp - 1);
+      else group(std::false_type{}, grp == ngrp - 1);
+    }
+    const int rt = t / col_groups, cg = t - rt * col_groups;
+    const int urow0 = rt * BM + wr * 16 * RB;
+    const int ucol0 = cg * BN + wc * 16 * CB;
+    ybase = a.Y + (size_t)urow0 * a.ldy + ucol0;
+    if (RES) rbase = a.resid + (size_t)urow0 * a.ldr + ucol0;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) pbias[c] = a.bias ? a.bias[ucol0 + c * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        prev[r][c] = acc[r][c];
+        acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    tile_ptrs(t + 2 < t1 ? t + 2 : t1 - 1, Agn, Bgn);
+  }
+  // the last tile's results (and the reloads issued past the end must have landed before the workgroup's LDS goes)
+#pragma unroll
+  for (int e = 0; e < 4 * NACC; ++e) {
+    float* yp = ybase + el_off(e, (int)a.ldy);
+    const int ai = e >> 2, r = ai % RB, c = ai / RB;
+    float v = prev[r][c][e & 3] + pbias[c];
+    if (RES) v += (rbase + el_off(e, (int)a.ldr))[loff_r];
+    yp[loff_y] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
 // forward pack  PF[q = k/4][n][k%4],  n < round16(N), q < round16(K)/4        (y = x W^T, W [N,K])
 // backward pack PB[q = o/4][i][o%4],  i < round16(K)+16, q < round16(N)/4     (dx = dz W)
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src_flat, float* __restrict__ pf,
@@ -2040,6 +2287,42 @@ extern "C" int osrl_linear(const float* A, int64_t lda, int32_t M, int32_t K, co
     (void)hipGetLastError();
     // 128-row x 256-column tiles on the 512 resident workgroups (2 per CU): a ragged last round costs a whole one.
     // At M = 81920, N = 256 (five of the eight GEMMs of a CDT block) that is 640 tiles = 1.25 rounds.
+    // the persistent 128 x 128-tile kernel where its shape conditions hold and the tiles spread evenly over the CUs
+    if ((M & 127) == 0 && (K & 255) == 0 && (N & 127) == 0) {
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+          n_cu = v;
+        else
+          n_cu = 256;
+        (void)hipGetLastError();
+      }
+      const int row_tiles = M / 128, col_groups = N / 128;
+      const long tiles = (long)row_tiles * col_groups;
+      if (tiles % n_cu == 0 || tiles >= 8L * n_cu) {
+        constexpr int kPersSlots = 4;
+        constexpr size_t kPersLds = sizeof(float) * kPersSlots * (128 * 16 + 16 * 128);
+        static bool pers_set = false;
+        if (!pers_set) {
+          hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_pers_kernel<4, 2, kPersSlots, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersLds);
+          hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_pers_kernel<4, 2, kPersSlots, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersLds);
+          if (e0 != hipSuccess || e1 != hipSuccess) return (int)(e0 != hipSuccess ? e0 : e1);
+          pers_set = true;
+          (void)hipGetLastError();
+        }
+        if (resid)
+          hipLaunchKernelGGL((linear_pers_kernel<4, 2, kPersSlots, true>), dim3(n_cu), dim3(512), kPersLds,
+                             (hipStream_t)stream, b, row_tiles, col_groups, n_cu);
+        else
+          hipLaunchKernelGGL((linear_pers_kernel<4, 2, kPersSlots, false>), dim3(n_cu), dim3(512), kPersLds,
+                             (hipStream_t)stream, b, row_tiles, col_groups, n_cu);
+        return (int)hipGetLastError();
+      }
+    }
     const long cols = N / 256, t128 = (long)((M + 127) / 128) * cols;
     // the 128 + 32-row form costs 1.85 tile times (the 32-row pass pays the per-k-step staging + barrier of a 128-row
     // one for a quarter of the MFMAs): only where it replaces two rounds by one.  (Sending the leftover rows to the

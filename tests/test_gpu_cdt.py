@@ -57,6 +57,55 @@ def test_linear_kernel_shapes():
         assert err < 3e-5 * max(1, np.abs(ref).max()), (M, K, N, "dx", err)
 
 
+def test_linear_persistent_kernel_equals_the_tile_kernel_bit_for_bit():
+    """The persistent 128 x 128-tile GEMM (M % 128 == 0, K % 256 == 0, N % 128 == 0, tiles spread evenly over the CUs)
+    against float64 and, bit for bit, against linear_big_kernel (the same call with 16 more rows takes that path):
+    residual / no residual, strided A / residual / Y, a column group of a wider pack (col0), several tiles per
+    workgroup (drip of the previous tile during the next one) and K = 256 .. 1024 (1 .. 4 groups of 16 k-steps)."""
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import FlatGroup, cur_stream
+    lib = L.load()
+    rs = np.random.RandomState(5)
+    r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for (M, K, N, Nw, col0, use_res, pad) in [(128 * ncu, 256, 128, 128, 0, True, 0),
+                                             (128 * ncu // 2, 256, 256, 256, 0, False, 0),
+                                             (64 * ncu, 1024, 256, 256, 0, True, 8),
+                                             (64 * ncu, 768, 256, 768, 256, False, 4),
+                                             (128 * ncu, 512, 384, 384, 0, True, 0),
+                                             (128 * ncu * 3, 256, 128, 256, 128, True, 12)]:
+        g = FlatGroup("t", DEV)
+        g.add("w", (Nw, K))
+        g.mark_weight("w")
+        g.add("b", (Nw,))
+        g.finalize()
+        W, b = rs.randn(Nw, K).astype(np.float32) * 0.1, rs.randn(Nw).astype(np.float32)
+        g.view("w").copy_(t(W))
+        g.view("b").copy_(t(b))
+        g.repack()
+        Mx = M + 16
+        lda, ldr, ldy = K + pad, N + pad, N + 2 * pad
+        A = np.zeros((Mx, lda), np.float32)
+        A[:, :K] = rs.randn(Mx, K)
+        R = np.zeros((Mx, ldr), np.float32)
+        R[:, :N] = rs.randn(Mx, N)
+        At, Rt = t(A), t(R)
+        bias = g.view("b")[col0:col0 + N].contiguous()
+        outs = []
+        for rows in (M, Mx):
+            Y = torch.full((Mx, ldy), 7.0, device=DEV)
+            L.check(lib.osrl_linear(At.data_ptr(), lda, rows, K, g.pf.data_ptr(), r16(Nw), col0, N, bias.data_ptr(),
+                                    Rt.data_ptr() if use_res else None, ldr, Y.data_ptr(), ldy, cur_stream()), "lin")
+            outs.append(Y.cpu().numpy())
+        y_pers, y_tile = outs
+        ref = A[:M, :K].astype(np.float64) @ W[col0:col0 + N].T.astype(np.float64) + b[col0:col0 + N]
+        if use_res:
+            ref = ref + R[:M, :N]
+        assert np.abs(y_pers[:M, :N] - ref).max() < 3e-5 * max(1, np.abs(ref).max()), (M, K, N)
+        assert np.array_equal(y_pers[:M, :N], y_tile[:M, :N]), (M, K, N)
+        assert np.all(y_pers[:M, N:] == 7.0) and np.all(y_pers[M:] == 7.0), "writes outside the [M, N] block"
+
+
 def test_layernorm_gelu_attention_kernels():
     from oracle.cdt_oracle import gelu, gelu_grad, layer_norm, layer_norm_bwd
     from osrl_amd import _lib as L

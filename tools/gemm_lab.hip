@@ -1,0 +1,745 @@
+// Lab bench for the CDT projection GEMM (linear_big_kernel of osrl_amd/csrc/mlp.hip): standalone, no torch.
+//   hipcc -O3 --offload-arch=gfx950 tools/gemm_lab.hip -o tools/_lab/gemm_lab && tools/_lab/gemm_lab
+// Variants of the k-loop / scheduling of the same 128 x 256 tile are timed on the CDT shapes (M = 81920) and checked
+// against variant 0 (bitwise where the summation order is the same) and a CPU dot product on sampled elements.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct LinBigArgs {
+  const float* A;
+  const float* P;
+  const float* bias;
+  const float* resid;
+  float* Y;
+  int64_t lda_g, ldr, ldy;
+  int32_t M, K, N, Np, col0;
+};
+
+constexpr int kLbSlots = 3;
+constexpr int kLbA = 128 * 16, kLbB = 16 * 256;
+constexpr size_t kLbLds = sizeof(float) * kLbSlots * (kLbA + kLbB);
+
+__device__ __forceinline__ void glds16(const void* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// VAR: 0 baseline | 1 baseline + s_setprio by workgroup slot parity | 2 half-k-step register pipeline (ds_read_b64 one
+// half ahead, barrier in the middle of the k-step) | 3 = 2 + setprio | 4 baseline without DMA / barriers (ceiling of
+// the MFMA + ds_read loop; garbage results) | 5 baseline without the epilogue stores | 6 = 2 with A-slot swizzle
+template <int RB, int VAR>
+__device__ __forceinline__ void lin_big_tile(const LinBigArgs& a, const int row0, const int gcol0, float* As, float* Bs) {
+  constexpr int BM = 32 * RB, BN = 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int M = a.M, nk = a.K >> 4;
+  const int ar = tid >> 2, ac = tid & 3;
+  const bool has_a = wave * 64 < 4 * BM;
+  const int arow = row0 + ar < M ? row0 + ar : M - 1;
+  const f32x4* __restrict__ Ag = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda_g) + ac;
+  const int bq0 = tid >> 8, bcol = tid & 255;
+  const f32x4* __restrict__ Bg = reinterpret_cast<const f32x4*>(a.P) + (size_t)a.col0 + gcol0 + bcol;
+  const int Np = a.Np;
+  const int wbase = wave * 64 * 4;
+  auto dma = [&](int ks) {
+    if (VAR == 4) return;
+    float* as = As + (ks % kLbSlots) * kLbA;
+    float* bs = Bs + (ks % kLbSlots) * kLbB;
+    if (has_a) glds16(Ag + ks * 4, as + wbase);
+    glds16(Bg + (size_t)(ks * 4 + bq0) * Np, bs + wbase);
+    glds16(Bg + (size_t)(ks * 4 + bq0 + 2) * Np, bs + 512 * 4 + wbase);
+  };
+  if (VAR == 1 || VAR == 3) {
+    // HW_REG_HW_ID (id 4): TG_ID = bits 19:16 -- the workgroup slot on this CU
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+    if (tg & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+  }
+  f32x4 acc[RB][4];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dma(0);
+  if (nk > 1) dma(1);
+  const int a_off = ((wr * 16 * RB + (lane & 15)) * 16 + 4 * (lane >> 4));
+  const int b_off = ((lane >> 4) * BN + wc * 64 + (lane & 15)) * 4;
+  if constexpr (VAR == 2 || VAR == 3) {
+    f32x2 af[2][RB], bf[2][4];
+    auto rd = [&](int ks, int h, auto& afb, auto& bfb) {
+      const float* as = As + (ks % kLbSlots) * kLbA;
+      const float* bs = Bs + (ks % kLbSlots) * kLbB;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) afb[r] = *reinterpret_cast<const f32x2*>(&as[a_off + r * 16 * 16 + 2 * h]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bfb[c] = *reinterpret_cast<const f32x2*>(&bs[b_off + c * 64 + 2 * h]);
+    };
+    auto mm = [&](auto& afb, auto& bfb) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[r][t], bfb[c][t], acc[r][c], 0, 0, 0);
+    };
+    // slot 0 landed for everyone
+    if (nk > 1) {
+      if (has_a) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    rd(0, 0, af[0], bf[0]);
+    for (int ks = 0; ks < nk; ++ks) {
+      rd(ks, 1, af[1], bf[1]);
+      mm(af[0], bf[0]);
+      if (ks + 1 < nk) {
+        // slot ks + 1 landed (issued one k-step ago, nothing newer in flight); everyone's MFMAs of step ks - 1 are
+        // issued, i.e. slot (ks + 2) % 3 is free
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ks + 2 < nk) dma(ks + 2);
+        rd(ks + 1, 0, af[0], bf[0]);
+      }
+      mm(af[1], bf[1]);
+    }
+  } else {
+    for (int ks = 0; ks < nk; ++ks) {
+      if (VAR != 4) {
+        if (ks + 1 < nk) {
+          if (has_a) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+      if (ks + 2 < nk) dma(ks + 2);
+      const float* as = As + (ks % kLbSlots) * kLbA;
+      const float* bs = Bs + (ks % kLbSlots) * kLbB;
+      f32x4 af[RB], bf[4];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) af[r] = *reinterpret_cast<const f32x4*>(&as[a_off + r * 16 * 16]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&bs[b_off + c * 64]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][t], bf[c][t], acc[r][c], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = gcol0 + wc * 64 + c * 16 + (lane & 15);
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gr = row0 + wr * 16 * RB + r * 16 + (lane >> 4) * 4 + i;
+        if (gr < M) {
+          float v = acc[r][c][i] + bv;
+          if (VAR == 5) {
+            if (v == 1.2345678e33f) a.Y[(size_t)gr * a.ldy + col] = v;
+            continue;
+          }
+          if (a.resid) v += a.resid[(size_t)gr * a.ldr + col];
+          a.Y[(size_t)gr * a.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TAIL, int VAR>
+__global__ __launch_bounds__(512, 4) void linear_big_kernel(const LinBigArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lb_lds[];
+  float* As = lb_lds;
+  float* Bs = lb_lds + kLbSlots * kLbA;
+  constexpr int kRows = TAIL ? 160 : 128;
+  const int row0 = blockIdx.x * kRows, gcol0 = blockIdx.y * 256;
+  lin_big_tile<4, VAR>(a, row0, gcol0, As, Bs);
+  if (TAIL && row0 + 128 < a.M) {
+    __syncthreads();
+    lin_big_tile<1, VAR>(a, row0 + 128, gcol0, As, Bs);
+  }
+}
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));    \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+
+// ---- variant 7: persistent, one 8-wave workgroup per CU (256 registers per wave) --------------------------------
+// * S-slot DMA ring that keeps running across tile boundaries (no prologue bubble per tile): slab g + 1 is landed at
+//   the top of k-step g and its fragments are read into the OTHER fragment register set while the MFMAs of step g run
+//   (nothing but the barrier itself between two MFMA blocks);
+// * the finished tile's accumulators move to a second register set and are stored ("dripped") 4 x 64 lanes per k-step
+//   during the first 16 k-steps of the next tile: the output leaves the chip beside the MFMAs instead of in a burst in
+//   which every workgroup of the chip stores at once and no MFMA runs;
+// * A slot image XOR-swizzled (kq position = kq ^ perm[(row >> 2) & 3]) -> conflict-free ds_read_b128;
+// * the k-loop body is branch-free: 16 k-steps unrolled, the slab issued L = S - 1 steps ahead comes from the current
+//   tile or (last group of a tile, j + L >= 16: known at compile time) from the next one; past the last tile the
+//   "next" tile is the current one again (harmless reloads, drained before the kernel ends).
+// Requires K % 256 == 0 (k-steps in groups of 16), N % (64 CB) == 0.
+// a load the compiler does not track: no conservative vmcnt(0) at its use (which would also wait for the DMA issued
+// since) -- the user waits with vm_wait<N>() naming the registers, N = vector memory operations issued after the load
+__device__ __forceinline__ float gload_untracked(const float* ubase, unsigned voff_bytes) {
+  float r;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff_bytes), "s"(ubase) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(float& r0, float& r1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N));
+}
+
+template <int RB, int CB, int S, bool RES>
+__global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, const int row_tiles, const int col_groups,
+                                                          const int nwg) {
+  constexpr int BM = 32 * RB, BN = 64 * CB;
+  constexpr int kA = BM * 16, kB = 16 * BN;
+  constexpr int PB = 4 * BN / 512;    // B pieces per thread and slab
+  constexpr int NACC = RB * CB;       // accumulators (f32x4) per wave
+  constexpr int SPI = 4 * NACC / 16;  // dripped stores per k-step
+  constexpr int DMA_OPS = 1 + PB;
+  constexpr int L = S - 1;            // slabs in flight ahead of the one being multiplied
+  static_assert(BM == 128, "A slab = one float4 per thread");
+  extern __shared__ __attribute__((aligned(16))) float lds_p[];
+  float* As = lds_p;
+  float* Bs = lds_p + S * kA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int M = a.M, Np = a.Np;
+  const int ngrp = a.K >> 8;
+  const int tiles = row_tiles * col_groups;
+  const int wg = blockIdx.x;
+  const int t0 = (int)((long)tiles * wg / nwg), t1 = (int)((long)tiles * (wg + 1) / nwg);
+  if (t0 >= t1) return;
+  const int wbase = wave * 64 * 4;
+  // ---- issue side: this thread's float4 of the A slab (swizzled kq) and its PB float4 of the B slab ----
+  const int a_row = tid >> 2;
+  const int a_kq = (tid & 3) ^ ((0x78 >> (2 * ((tid >> 4) & 3))) & 3);
+  int bkq[PB], bcol[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int f = tid + 512 * p;
+    bkq[p] = f / BN;
+    bcol[p] = f % BN;
+  }
+  // running sources of the slab about to be issued: Ap = this thread's float4 of the A slab (per-thread pointer),
+  // Bp = first float4 of the B slab (wave-uniform: scalar registers) + voffB[p] = this thread's float4 inside the slab
+  // (never changes): loop-carried, so nothing about the 16 unrolled issues can be hoisted and spilled
+  const f32x4 *Ap, *Agn;
+  const f32x4 *Bp, *Bgn;
+  unsigned voffB[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) voffB[p] = (unsigned)(bkq[p] * Np + bcol[p]);
+  auto tile_ptrs = [&](int t, const f32x4*& ag, const f32x4*& bg) {
+    const int rt = t / col_groups, cg = t - rt * col_groups;
+    const int row = rt * BM + a_row;
+    ag = reinterpret_cast<const f32x4*>(a.A + (size_t)(row < M ? row : M - 1) * a.lda_g) + a_kq;
+    bg = reinterpret_cast<const f32x4*>(a.P) + (size_t)a.col0 + cg * BN;
+  };
+  tile_ptrs(t0, Ap, Bp);
+  tile_ptrs(t0 + 1 < t1 ? t0 + 1 : t0, Agn, Bgn);
+  int it_slot = 0;
+  const size_t b_step = (size_t)4 * Np;
+  auto dma = [&]() {  // the next slab of the tile being issued -> slot it_slot
+    float* as = As + it_slot * kA;
+    float* bs = Bs + it_slot * kB;
+    glds16(Ap, as + wbase);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) glds16(Bp + voffB[p], bs + p * 512 * 4 + wbase);
+    Ap += 4;
+    Bp += b_step;
+    it_slot = it_slot + 1 == S ? 0 : it_slot + 1;
+  };
+  // ---- consume side ----
+  const int a_off = (wr * 16 * RB + (lane & 15)) * 16 + 4 * ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3));
+  const int b_off = ((lane >> 4) * BN + wc * 16 * CB + (lane & 15)) * 4;
+  f32x4 acc[RB][CB], prev[RB][CB];
+  f32x4 af[2][RB], bf[2][CB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_slot = 0;  // slot of the slab being multiplied
+  auto rd = [&](int slot, f32x4* afb, f32x4* bfb) {
+    const float* as = As + slot * kA;
+    const float* bs = Bs + slot * kB;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) afb[r] = *reinterpret_cast<const f32x4*>(&as[a_off + r * 16 * 16]);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) bfb[c] = *reinterpret_cast<const f32x4*>(&bs[b_off + c * 64]);
+  };
+  auto mm = [&](const f32x4* afb, const f32x4* bfb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afb[r][t], bfb[c][t], acc[r][c], 0, 0, 0);
+  };
+  // element e (0 .. 4 NACC) of a wave tile = accumulator e / 4 = (r, c), row i = e % 4.  Its address is a wave-uniform
+  // base (scalar registers) + one per-lane 32-bit offset that never changes (saddr + voffset form).  The row stride is
+  // laundered through an empty asm so that the 64 offsets of a tile stay inside the k-loop (not hoisted and spilled).
+  const unsigned lane_row = (unsigned)(lane >> 4) * 4u;
+  const unsigned loff_y = lane_row * (unsigned)a.ldy + (unsigned)(lane & 15);
+  const unsigned loff_r = lane_row * (unsigned)a.ldr + (unsigned)(lane & 15);
+  const float* rbase = a.resid;
+  float* ybase = a.Y;
+  int urow0 = 0;
+  auto el_off = [&](int e, int ld_in, int& urow) -> unsigned {
+    const int ai = e >> 2, i = e & 3, r = ai % RB;
+    const int c = ai / RB;
+    int ld = ld_in;
+    asm volatile("" : "+s"(ld));
+    urow = urow0 + r * 16 + i;
+    return (unsigned)((r * 16 + i) * ld + c * 16);
+  };
+  float pbias[CB];
+
+  // prologue: slabs 0 .. L-1 of the first tile in flight; slab 0 landed for everyone, its fragments on the way to set 0
+#pragma unroll
+  for (int i = 0; i < L; ++i) dma();
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((L - 1) * DMA_OPS) : "memory");
+  rd(0, af[0], bf[0]);
+
+  // ONE instance of the 16 unrolled k-steps: whether the previous tile is dripped during them (first group of a tile
+  // that has a predecessor) and whether the slabs issued from step 16 - L on belong to the next tile (last group of a
+  // tile) are wave-uniform run-time flags
+  auto group = [&](auto drip_tag, const bool LAST) {
+    constexpr bool DRIP = decltype(drip_tag)::value;
+    // the residual of the elements stored at step j is loaded one step earlier (a full k-step of latency cover; the
+    // first set waits once per tile)
+    float rres[2][SPI];
+    auto res_load = [&](int j, float* dst) {
+#pragma unroll
+      for (int s = 0; s < SPI; ++s) {
+        int urow;
+        const float* rp = rbase + el_off(j * SPI + s, (int)a.ldr, urow);
+        dst[s] = gload_untracked(rp, loff_r * 4u);
+      }
+    };
+    if (DRIP && RES) res_load(0, rres[0]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // top of k-step g: slab g + 1 landed for everyone (slabs g + 2 .. g + S - 2 and the drips issued since may be in
+      // flight); everyone's MFMAs of step g - 1 are issued, i.e. the slot of slab g - 1 is free
+      constexpr int n_dma = (S - 3) * DMA_OPS;
+      if (j >= S - 2 && DRIP) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma + (S - 2) * SPI + (RES ? (S - 3) * SPI : 0)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma) : "memory");
+      c_slot = c_slot + 1 == S ? 0 : c_slot + 1;
+      if (DRIP && RES && j + 1 < 16) res_load(j + 1, rres[(j + 1) & 1]);
+      if (j + L == 16 && LAST) {  // the slabs issued from here on belong to the next tile
+        Ap = Agn;
+        Bp = Bgn;
+      }
+      // this step's fragments are in registers already: MFMAs first.  The reads of the next slab and the DMA issue
+      // (~100+ cycles each, in-order in this wave) go after the first quarter of the MFMAs in waves 0-3 and after the
+      // third quarter in waves 4-7 -- the two waves of a SIMD are w and w + 4, so one feeds the matrix pipe while the
+      // other issues memory instructions
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if ((t == 1 && wr == 0) || (t == 3 && wr == 1)) {
+          rd(c_slot, af[(j + 1) & 1], bf[(j + 1) & 1]);
+          dma();
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][r][t], bf[j & 1][c][t], acc[r][c], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (DRIP) {
+        if (RES) {
+          // issued after the loads of rres[j & 1]: this and the previous step's DMA, the previous step's stores and the
+          // next set's loads (before the loop for j = 0: the next set's loads and this step's DMA)
+          static_assert(SPI == 2, "vm_wait names two registers");
+          if (j == 0) vm_wait<SPI + DMA_OPS>(rres[0][0], rres[0][1]);
+          else if (j + 1 < 16) vm_wait<2 * DMA_OPS + 2 * SPI>(rres[j & 1][0], rres[j & 1][1]);
+          else vm_wait<2 * DMA_OPS + SPI>(rres[j & 1][0], rres[j & 1][1]);
+        }
+#pragma unroll
+        for (int s = 0; s < SPI; ++s) {
+          const int e = j * SPI + s;
+          int urow;
+          float* yp = ybase + el_off(e, (int)a.ldy, urow);
+          const int ai = e >> 2, r = ai % RB, c = ai / RB;
+          float pb = pbias[c];
+          asm volatile("" : "+v"(pb));
+          float v = prev[r][c][e & 3] + pb;
+          if (RES) v += rres[j & 1][s];
+          yp[loff_y] = v;
+        }
+      }
+    }
+  };
+
+  for (int t = t0; t < t1; ++t) {
+    for (int grp = 0; grp < ngrp; ++grp) {
+      if (grp == 0 && t > t0) group(std::true_type{}, grp == ngrp - 1);
+      else group(std::false_type{}, grp == ngrp - 1);
+    }
+    const int rt = t / col_groups, cg = t - rt * col_groups;
+    urow0 = rt * BM + wr * 16 * RB;
+    const int ucol0 = cg * BN + wc * 16 * CB;
+    ybase = a.Y + (size_t)urow0 * a.ldy + ucol0;
+    if (RES) rbase = a.resid + (size_t)urow0 * a.ldr + ucol0;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) pbias[c] = a.bias ? a.bias[ucol0 + c * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        prev[r][c] = acc[r][c];
+        acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    tile_ptrs(t + 2 < t1 ? t + 2 : t1 - 1, Agn, Bgn);
+  }
+  // the last tile's results (and the reloads issued past the end must have landed before the workgroup's LDS goes)
+#pragma unroll
+  for (int e = 0; e < 4 * NACC; ++e) {
+    int urow;
+    float* yp = ybase + el_off(e, (int)a.ldy, urow);
+    const int ai = e >> 2, r = ai % RB, c = ai / RB;
+    float v = prev[r][c][e & 3] + pbias[c];
+    if (RES) {
+      int u2;
+      v += (rbase + el_off(e, (int)a.ldr, u2))[loff_r];
+    }
+    yp[loff_y] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- variant 8: persistent, TWO 4-wave workgroups per CU (one wave per SIMD each, 256 registers per wave) ---------
+// Wave tile 64 x (16 CB), workgroup tile 128 x (32 CB), 2 x 2 waves.  The two workgroups of a CU have separate
+// barriers, so the barrier / DMA-issue bubbles of one are covered by the other's MFMAs (as in the baseline) while the
+// finished tile's accumulators are dripped to memory during the next tile's k-loop (as in variant 7); fragments are
+// single-buffered.  All DMA sources are scalar base + constant per-thread 32-bit offset.
+// Requires M % 128 == 0, K % 256 == 0, N % (32 CB) == 0, M * lda * 4 < 4 GB.
+template <int CB, int S, bool RES>
+__global__ __launch_bounds__(256, 2) void lin_pers4_kernel(const LinBigArgs a, const int row_tiles,
+                                                           const int col_groups, const int nwg) {
+  constexpr int RB = 4;
+  constexpr int BM = 128, BN = 32 * CB;
+  constexpr int kA = BM * 16, kB = 16 * BN;
+  constexpr int PA = 2;               // A pieces (float4) per thread and slab
+  constexpr int PB = 4 * BN / 256;    // B pieces
+  constexpr int NACC = RB * CB;
+  constexpr int SPI = 4 * NACC / 16;  // dripped stores per k-step
+  constexpr int DMA_OPS = PA + PB;
+  constexpr int L = S - 1;
+  extern __shared__ __attribute__((aligned(16))) float lds_p[];
+  float* As = lds_p;
+  float* Bs = lds_p + S * kA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int M = a.M, Np = a.Np;
+  const int ngrp = a.K >> 8;
+  const int tiles = row_tiles * col_groups;
+  const int wg = blockIdx.x;
+  const int t0 = (int)((long)tiles * wg / nwg), t1 = (int)((long)tiles * (wg + 1) / nwg);
+  if (t0 >= t1) return;
+  const int wbase = wave * 64 * 4;
+  unsigned voffA[PA], voffB[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int f = tid + 256 * p, row = f >> 2;
+    const int kq = (f & 3) ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
+    voffA[p] = (unsigned)row * (unsigned)a.lda_g * 4u + (unsigned)kq * 16u;  // bytes
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int f = tid + 256 * p;
+    voffB[p] = ((unsigned)(f / BN) * (unsigned)Np + (unsigned)(f % BN)) * 16u;  // bytes
+  }
+  const char *Ap, *Agn, *Bp, *Bgn;  // wave-uniform running slab origins (bytes)
+  auto tile_ptrs = [&](int t, const char*& ag, const char*& bg) {
+    const int rt = t / col_groups, cg = t - rt * col_groups;
+    ag = reinterpret_cast<const char*>(a.A + (size_t)rt * BM * a.lda_g);
+    bg = reinterpret_cast<const char*>(reinterpret_cast<const f32x4*>(a.P) + (size_t)a.col0 + cg * BN);
+  };
+  tile_ptrs(t0, Ap, Bp);
+  tile_ptrs(t0 + 1 < t1 ? t0 + 1 : t0, Agn, Bgn);
+  int it_slot = 0;
+  const size_t b_step = (size_t)4 * Np * 16;
+  auto dma = [&]() {
+    float* as = As + it_slot * kA;
+    float* bs = Bs + it_slot * kB;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) glds16(Ap + voffA[p], as + p * 256 * 4 + wbase);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) glds16(Bp + voffB[p], bs + p * 256 * 4 + wbase);
+    Ap += 64;
+    Bp += b_step;
+    it_slot = it_slot + 1 == S ? 0 : it_slot + 1;
+  };
+  const int a_off = (wr * 64 + (lane & 15)) * 16 + 4 * ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3));
+  const int b_off = ((lane >> 4) * BN + wc * 16 * CB + (lane & 15)) * 4;
+  f32x4 acc[RB][CB], prev[RB][CB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_slot = 0;
+  const unsigned lane_row = (unsigned)(lane >> 4) * 4u;
+  const unsigned loff_y = lane_row * (unsigned)a.ldy + (unsigned)(lane & 15);
+  const unsigned loff_r = lane_row * (unsigned)a.ldr + (unsigned)(lane & 15);
+  const float* rbase = a.resid;
+  float* ybase = a.Y;
+  auto el_off = [&](int e, int ld_in) -> unsigned {
+    const int ai = e >> 2, i = e & 3, r = ai % RB;
+    const int c = ai / RB;
+    int ld = ld_in;
+    asm volatile("" : "+s"(ld));
+    return (unsigned)((r * 16 + i) * ld + c * 16);
+  };
+  float pbias[CB];
+#pragma unroll
+  for (int i = 0; i < L; ++i) dma();
+
+  auto group = [&](auto drip_tag, auto last_tag) {
+    constexpr bool DRIP = decltype(drip_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;
+    float rres[SPI];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // top of k-step g: slab g landed for everyone (slabs g + 1 .. g + L - 1 and the drips issued since may be in
+      // flight); everyone's MFMAs of step g - 1 are issued, i.e. the slot of slab g - 1 is free for slab g + L
+      constexpr int n_dma = (L - 1) * DMA_OPS;
+      if (DRIP && j >= L) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma + L * SPI * (RES ? 2 : 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma) : "memory");
+      f32x4 af[RB], bf[CB];
+      {
+        const float* as = As + c_slot * kA;
+        const float* bs = Bs + c_slot * kB;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) af[r] = *reinterpret_cast<const f32x4*>(&as[a_off + r * 16 * 16]);
+#pragma unroll
+        for (int c = 0; c < CB; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&bs[b_off + c * 64]);
+      }
+      c_slot = c_slot + 1 == S ? 0 : c_slot + 1;
+      if (LAST && j + L == 16) {
+        Ap = Agn;
+        Bp = Bgn;
+      }
+      dma();
+      if (DRIP && RES) {
+#pragma unroll
+        for (int s = 0; s < SPI; ++s) rres[s] = (rbase + el_off(j * SPI + s, (int)a.ldr))[loff_r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][t], bf[c][t], acc[r][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (DRIP) {
+#pragma unroll
+        for (int s = 0; s < SPI; ++s) {
+          const int e = j * SPI + s;
+          float* yp = ybase + el_off(e, (int)a.ldy);
+          const int ai = e >> 2, r = ai % RB, c = ai / RB;
+          float pb = pbias[c];
+          asm volatile("" : "+v"(pb));
+          float v = prev[r][c][e & 3] + pb;
+          if (RES) v += rres[s];
+          yp[loff_y] = v;
+        }
+      }
+    }
+  };
+
+  for (int t = t0; t < t1; ++t) {
+    for (int grp = 0; grp < ngrp; ++grp) {
+      const bool drip = grp == 0 && t > t0, last = grp == ngrp - 1;
+      if (drip) {
+        if (last) group(std::true_type{}, std::true_type{});
+        else group(std::true_type{}, std::false_type{});
+      } else {
+        if (last) group(std::false_type{}, std::true_type{});
+        else group(std::false_type{}, std::false_type{});
+      }
+    }
+    const int rt = t / col_groups, cg = t - rt * col_groups;
+    const int urow0 = rt * BM + wr * 64;
+    const int ucol0 = cg * BN + wc * 16 * CB;
+    ybase = a.Y + (size_t)urow0 * a.ldy + ucol0;
+    if (RES) rbase = a.resid + (size_t)urow0 * a.ldr + ucol0;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) pbias[c] = a.bias ? a.bias[ucol0 + c * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        prev[r][c] = acc[r][c];
+        acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    tile_ptrs(t + 2 < t1 ? t + 2 : t1 - 1, Agn, Bgn);
+  }
+#pragma unroll
+  for (int e = 0; e < 4 * NACC; ++e) {
+    float* yp = ybase + el_off(e, (int)a.ldy);
+    const int ai = e >> 2, r = ai % RB, c = ai / RB;
+    float v = prev[r][c][e & 3] + pbias[c];
+    if (RES) v += (rbase + el_off(e, (int)a.ldr))[loff_r];
+    yp[loff_y] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int CB, int S, bool RES>
+float run_pers4(const LinBigArgs& b, int reps, int nwg) {
+  auto k = lin_pers4_kernel<CB, S, RES>;
+  const size_t lds = sizeof(float) * S * (128 * 16 + 16 * 32 * CB);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int row_tiles = b.M / 128, col_groups = b.N / (32 * CB);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, b, row_tiles, col_groups, nwg);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, b, row_tiles, col_groups, nwg);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / reps;
+}
+
+template <int RB, int CB, int S, bool RES>
+float run_pers(const LinBigArgs& b, int reps, int nwg) {
+  auto k = lin_pers_kernel<RB, CB, S, RES>;
+  const size_t lds = sizeof(float) * S * (32 * RB * 16 + 16 * 64 * CB);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int row_tiles = (b.M + 32 * RB - 1) / (32 * RB), col_groups = b.N / (64 * CB);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, 0, b, row_tiles, col_groups, nwg);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, 0, b, row_tiles, col_groups, nwg);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / reps;
+}
+
+template <int TAIL, int VAR>
+float run(const LinBigArgs& b, int reps) {
+  auto k = linear_big_kernel<TAIL, VAR>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLbLds));
+  const int rows = TAIL ? 160 : 128;
+  dim3 grid((b.M + rows - 1) / rows, b.N / 256, 1);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), kLbLds, 0, b);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(512), kLbLds, 0, b);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / reps;
+}
+
+template <int VAR>
+float run_v(const LinBigArgs& b, int tail, int reps) {
+  return tail ? run<1, VAR>(b, reps) : run<0, VAR>(b, reps);
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 81920;
+  struct Shape { int K, N, tail, res; };
+  const Shape shapes[] = {{256, 1024, 0, 0}, {256, 768, 0, 0}, {1024, 256, 1, 1}, {256, 256, 1, 1}, {768, 256, 1, 0}, {1024, 256, 1, 0}};
+  const int maxK = 1024, maxN = 1024;
+  std::vector<float> hA((size_t)M * maxK), hP((size_t)maxK * maxN), hb(maxN);
+  uint32_t s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+  for (auto& v : hA) v = rnd();
+  for (auto& v : hP) v = rnd();
+  for (auto& v : hb) v = rnd();
+  float *dA, *dP, *db, *dY, *dY0, *dR;
+  CK(hipMalloc(&dA, hA.size() * 4));
+  CK(hipMalloc(&dP, hP.size() * 4));
+  CK(hipMalloc(&db, hb.size() * 4));
+  CK(hipMalloc(&dY, (size_t)M * maxN * 4));
+  CK(hipMalloc(&dY0, (size_t)M * maxN * 4));
+  CK(hipMalloc(&dR, (size_t)M * maxN * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dP, hP.data(), hP.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dR, hA.data(), (size_t)M * maxN * 4, hipMemcpyHostToDevice));
+  std::vector<float> y0((size_t)M * maxN), y((size_t)M * maxN);
+  const int reps = 20;
+  for (const Shape& sh : shapes) {
+    LinBigArgs b;
+    b.A = dA; b.P = dP; b.bias = db; b.resid = sh.res ? dR : nullptr; b.Y = dY0;
+    b.lda_g = sh.K; b.ldr = sh.N; b.ldy = sh.N;
+    b.M = M; b.K = sh.K; b.N = sh.N; b.Np = sh.N; b.col0 = 0;
+    const double gf = 2.0 * M * sh.K * sh.N * 1e-9;
+    printf("M=%d K=%d N=%d tail=%d resid=%d  (%.1f GF, %.1f us at 157.3 TF/s)\n", M, sh.K, sh.N, sh.tail, sh.res, gf, gf / 157.3e3 * 1e6);
+    CK(hipMemset(dY0, 0, (size_t)M * sh.N * 4));
+    float t0 = run_v<0>(b, sh.tail, reps);
+    CK(hipMemcpy(y0.data(), dY0, (size_t)M * sh.N * 4, hipMemcpyDeviceToHost));
+    // CPU check of variant 0 on sampled elements (packed layout P[q = k/4][n][k%4])
+    double maxerr = 0;
+    for (int i = 0; i < 64; ++i) {
+      const int r = (int)(((uint64_t)i * 2654435761u) % M), c = (int)(((uint64_t)i * 40503u) % sh.N);
+      double acc = hb[c];
+      for (int k = 0; k < sh.K; ++k) acc += (double)hA[(size_t)r * sh.K + k] * hP[((size_t)(k / 4) * sh.N + c) * 4 + (k & 3)];
+      maxerr = fmax(maxerr, fabs(acc - y0[(size_t)r * sh.N + c]));
+    }
+    printf("  v0 %8.1f us  %.3f of peak   (cpu check max err %.2e)\n", t0, gf * 1e3 / t0 / 157.3, maxerr);
+    b.Y = dY;
+    auto report = [&](int v, float t, bool check) {
+      double md = 0;
+      if (check) {
+        CK(hipMemcpy(y.data(), dY, (size_t)M * sh.N * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)M * sh.N; ++i) md = fmax(md, fabs((double)y[i] - y0[i]));
+      }
+      printf("  v%d %8.1f us  %.3f of peak   max |y - y_v0| %.2e\n", v, t, gf * 1e3 / t / 157.3, md);
+    };
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(1, run_v<1>(b, sh.tail, reps), true);
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(2, run_v<2>(b, sh.tail, reps), true);
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(3, run_v<3>(b, sh.tail, reps), true);
+    report(4, run_v<4>(b, sh.tail, reps), false);
+    report(5, run_v<5>(b, sh.tail, reps), false);
+    if (b.resid) {
+      CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(724, run_pers<4, 2, 4, true>(b, reps, 256), true);
+    } else {
+      CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(724, run_pers<4, 2, 4, false>(b, reps, 256), true);
+    }
+  }
+  return 0;
+}
