@@ -327,7 +327,9 @@ int osrl_mlp_backward_dw_tiles_adam(const osrl_dw_entry_t* d_entries, const int3
                                     float* slabs, int64_t slab_stride, const osrl_dw_adam_t* opt, void* stream);
 /* The same contract for items given in units of 128 (out) x 64 (in) tiles that lie fully inside their dW (only
  * full tiles may be listed): one wave per tile and row split, 128-register accumulator tiles, one wave per SIMD -- the big-row-count (token matrix) variant; db of an entry is written by its it == 0 tiles.
- * Splits beyond a plan's own n_splits are never written (the caller keeps them zero). */
+ * Splits beyond a plan's own n_splits are never written (the caller keeps them zero).
+ * The operands are read with 16-byte loads: dz / a of every listed entry 16-byte aligned, row strides % 4 == 0, and the
+ * gradient slab 16-byte aligned with w_off % 4 == 0 (the caller checks: entries are device memory). */
 int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items, int32_t rows,
                              int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
 

@@ -19,6 +19,7 @@
 
 #include "../../include/osrl_amd.h"
 #include "philox.h"
+#include "gelu.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -54,10 +55,6 @@ __device__ __forceinline__ float block_sum1024(float v, float* sm) {
   }
   __syncthreads();
   return sm[16];
-}
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_g(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
 }
 
 // LayerNorm of one row held as v[j] (feature lane + 64 j); returns mean / rstd, writes y

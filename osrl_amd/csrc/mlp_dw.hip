@@ -394,36 +394,48 @@ struct DwBigFrag {
   f32x4 a[kDwbO], b[kDwbI];
 };
 
-__device__ __forceinline__ void dwb_load(DwBigFrag& f, const float* __restrict__ dz, const float* __restrict__ av,
+// Round 4 (tools/dw_lab.hip, bit-identical to the round-3 kernel, 3388 -> 3164 us for the 12 CDT projections): the
+// fragment registers are filled by dwordx4 loads of 4 CONSECUTIVE columns -- register a[4 q + j] of lane (m, kq) =
+// dz[row][o0 + 64 q + 4 m + j], i.e. as an MFMA operand the permuted 16-column block {o0 + 64 q + 4 i + j : i = 0..15};
+// the store undoes the permutation with 16-byte stores.  12 loads of 4 rows x 256 B per k-step instead of 48 of
+// 4 rows x 64 B, no row guard outside the tail, and running fragment pointers (8 64-bit adds per k-step instead of the
+// row * stride multiplies: the f32 MFMA runs on the vector ALUs, so every VALU instruction is time taken from it).
+// The same (row -> MFMA, k-lane) map as before: the same bits.  Needs 16-byte aligned operands and strides % 4 == 0
+// (the plan builder, engine/core.py DwPlan, sends other layers to mlp_dw_kernel).  What is left (0.78 of the roof):
+// with every operand row cache-resident the same loop runs at 0.82 -- each (tile, split) wave streams its own
+// 2560 x 192 block, 18 GB per launch through L2 / MALL; a workgroup-wide 256 x 256 tile through LDS would halve it.
+template <bool GUARD>
+__device__ __forceinline__ void dwp_load(DwBigFrag& f, const float* __restrict__ dz, const float* __restrict__ av,
                                          size_t ldz, size_t lda_g, int r0, int r_end, int m, int kq) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int r = r0 + 4 * kq + t;
-    const bool rok = r < r_end;
+    const bool rok = !GUARD || r < r_end;
     const size_t rc = (size_t)(rok ? r : r_end - 1);
-    const float* __restrict__ pz = dz + rc * ldz + m;
-    const float* __restrict__ pa = av + rc * lda_g + m;
+    const float* __restrict__ pz = dz + rc * ldz + 4 * m;
+    const float* __restrict__ pa = av + rc * lda_g + 4 * m;
 #pragma unroll
-    for (int ob = 0; ob < kDwbO; ++ob) {
-      const float v = pz[ob * 16];
-      f.a[ob][t] = rok ? v : 0.f;
+    for (int q = 0; q < kDwbO / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pz + 64 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.a[4 * q + j][t] = rok ? v[j] : 0.f;
     }
 #pragma unroll
-    for (int ib = 0; ib < kDwbI; ++ib) {
-      const float v = pa[ib * 16];
-      f.b[ib][t] = rok ? v : 0.f;
+    for (int q = 0; q < kDwbI / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pa + 64 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.b[4 * q + j][t] = rok ? v[j] : 0.f;
     }
   }
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_dw_big_kernel(const osrl_dw_entry_t* __restrict__ entries,
-                                                            const int32_t* __restrict__ items, int n_items, int rows,
-                                                            int rows_per_split, float* __restrict__ slabs,
-                                                            int64_t slab_stride) {
+                                                    const int32_t* __restrict__ items, int n_items, int rows,
+                                                    int rows_per_split, float* __restrict__ slabs, int64_t slab_stride) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * 4 + wave;
-  if (item >= n_items) return;  // whole wave; the kernel has no barrier
+  if (item >= n_items) return;
   const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
   const osrl_dw_entry_t E = entries[ei];
   const int out = E.out, in = E.in;
@@ -437,7 +449,6 @@ __global__ __launch_bounds__(256, 1) void mlp_dw_big_kernel(const osrl_dw_entry_
   const bool want_db = it == 0;
   const float* __restrict__ dz = E.dz + o0;
   const float* __restrict__ av = E.a + i0;
-
   f32x4 acc[kDwbO][kDwbI];
 #pragma unroll
   for (int ob = 0; ob < kDwbO; ++ob)
@@ -446,53 +457,91 @@ __global__ __launch_bounds__(256, 1) void mlp_dw_big_kernel(const osrl_dw_entry_
   float dbacc[kDwbO];
 #pragma unroll
   for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] = 0.f;
+  auto mma = [&](const DwBigFrag& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+        for (int ib = 0; ib < kDwbI; ++ib)
+          acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ob][t], f.b[ib][t], acc[ob][ib], 0, 0, 0);
+    if (want_db) {
+#pragma unroll
+      for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] += (f.a[ob][0] + f.a[ob][1]) + (f.a[ob][2] + f.a[ob][3]);
+    }
+  };
   if (r_begin < r_end) {
     DwBigFrag f[2];
-    dwb_load(f[0], dz, av, ldz, lda_g, r_begin, r_end, m, kq);
-    auto step = [&](auto s_c, int r0) {
-      constexpr int c = decltype(s_c)::value;
-      // the next step's fragments first (rows past r_end load a clamped row and become zeros)
-      dwb_load(f[c ^ 1], dz, av, ldz, lda_g, r0 + 16, r_end, m, kq);
+    const int n_steps = (r_end - r_begin + 15) >> 4;
+    const int n_full = (r_end - r_begin) >> 4;
+    // the rows lane (m, kq) reads in a step: r0 + 4 kq + t, t = 0..3 (consecutive rows: one pointer + t * stride)
+    const float* pz = dz + (size_t)(r_begin + 4 * kq) * ldz + 4 * m;
+    const float* pa = av + (size_t)(r_begin + 4 * kq) * lda_g + 4 * m;
+    const size_t zstep = 16 * ldz, astep = 16 * lda_g;
+    auto load_fast = [&](DwBigFrag& g) __attribute__((always_inline)) {  // the step the pointers stand on; advances them
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int ob = 0; ob < kDwbO; ++ob)
+        for (int q = 0; q < kDwbO / 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(pz + t * ldz + 64 * q);
 #pragma unroll
-          for (int ib = 0; ib < kDwbI; ++ib)
-            acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[c].a[ob][t], f[c].b[ib][t], acc[ob][ib], 0, 0, 0);
-      if (want_db) {
+          for (int j = 0; j < 4; ++j) g.a[4 * q + j][t] = v[j];
+        }
 #pragma unroll
-        for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] += (f[c].a[ob][0] + f[c].a[ob][1]) + (f[c].a[ob][2] + f[c].a[ob][3]);
+        for (int q = 0; q < kDwbI / 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(pa + t * lda_g + 64 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g.b[4 * q + j][t] = v[j];
+        }
       }
-      __builtin_amdgcn_sched_group_barrier(0x020, 4 * (kDwbO + kDwbI), 0);  // VMEM reads of the next step
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kDwbO * kDwbI, 0);    // this step's MFMAs
+      pz += zstep;
+      pa += astep;
     };
-    using std::integral_constant;
-    int r0 = r_begin;
-    for (; r0 + 32 <= r_end; r0 += 32) {
-      step(integral_constant<int, 0>{}, r0);
-      step(integral_constant<int, 1>{}, r0 + 16);
+    int st = 0;
+    if (n_full >= 1) load_fast(f[0]);
+    else dwp_load<true>(f[0], dz, av, ldz, lda_g, r_begin, r_end, m, kq);
+    // unguarded pairs of steps: the prefetched step st + 1 / st + 2 must be whole
+    while (st + 3 <= n_full) {
+      load_fast(f[1]);
+      mma(f[0]);
+      __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kDwbO * kDwbI, 0);
+      load_fast(f[0]);
+      mma(f[1]);
+      __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kDwbO * kDwbI, 0);
+      st += 2;
     }
-    if (r0 < r_end) {
-      step(integral_constant<int, 0>{}, r0);
-      if (r0 + 16 < r_end) step(integral_constant<int, 1>{}, r0 + 16);
+    // guarded tail: f[st & 1] holds step st
+    while (st < n_steps) {
+      if ((st & 1) == 0) {
+        dwp_load<true>(f[1], dz, av, ldz, lda_g, r_begin + 16 * (st + 1), r_end, m, kq);
+        mma(f[0]);
+      } else {
+        dwp_load<true>(f[0], dz, av, ldz, lda_g, r_begin + 16 * (st + 1), r_end, m, kq);
+        mma(f[1]);
+      }
+      ++st;
     }
   }
   float* __restrict__ slab = slabs + (size_t)s * slab_stride;
 #pragma unroll
   for (int ob = 0; ob < kDwbO; ++ob)
 #pragma unroll
-    for (int ib = 0; ib < kDwbI; ++ib)
+    for (int qb = 0; qb < kDwbI / 4; ++qb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        slab[E.w_off + (size_t)(o0 + ob * 16 + kq * 4 + r) * in + i0 + ib * 16 + m] = acc[ob][ib][r];
+      for (int r = 0; r < 4; ++r) {
+        const int orow = o0 + 64 * (ob >> 2) + 4 * (4 * kq + r) + (ob & 3);
+        const f32x4 v = {acc[ob][4 * qb + 0][r], acc[ob][4 * qb + 1][r], acc[ob][4 * qb + 2][r], acc[ob][4 * qb + 3][r]};
+        *reinterpret_cast<f32x4*>(&slab[E.w_off + (size_t)orow * in + i0 + 64 * qb + 4 * m]) = v;
+      }
   if (want_db) {
 #pragma unroll
     for (int ob = 0; ob < kDwbO; ++ob) {
       float v = dbacc[ob];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (kq == 0) slab[E.b_off + o0 + ob * 16 + m] = v;
+      if (kq == 0) slab[E.b_off + o0 + 64 * (ob >> 2) + 4 * m + (ob & 3)] = v;
     }
   }
 }

@@ -554,7 +554,10 @@ class DwPlan:
                         for sp in range(nsp):
                             work += [i, ot, it, sp | (nsp << 16)]
                 continue
-            if use_big and out_f % 128 == 0 and in_f % 64 == 0:
+            # osrl_mlp_backward_dw_big fills its fragments with 16-byte loads: aligned operands, strides % 4 == 0
+            aligned = (arr[i].dz % 16 == 0 and arr[i].a % 16 == 0 and (ldz or out_f) % 4 == 0 and (lda_ or in_f) % 4 == 0
+                       and arr[i].w_off % 4 == 0)
+            if use_big and out_f % 128 == 0 and in_f % 64 == 0 and aligned:
                 # token-matrix sized GEMMs (CDT projections): every 128x64 tile to osrl_mlp_backward_dw_big
                 for ot in range(out_f // 128):
                     for it in range(in_f // 64):

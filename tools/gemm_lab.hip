@@ -9,6 +9,7 @@
 #include <cmath>
 #include <vector>
 #include <type_traits>
+#include "../osrl_amd/csrc/gelu.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -19,6 +20,7 @@ struct LinBigArgs {
   const float* bias;
   const float* resid;
   float* Y;
+  float* Y2;
   int64_t lda_g, ldr, ldy;
   int32_t M, K, N, Np, col0;
 };
@@ -209,7 +211,9 @@ __device__ __forceinline__ void vm_wait(float& r0, float& r1) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N));
 }
 
-template <int RB, int CB, int S, bool RES>
+// EPI: 0 y = acc + bias | 1 y = acc + bias + resid | 2 y = acc + bias, y2 = gelu(y) | 3 y = (acc + bias) * gelu'(aux)
+// (aux / resid read through a.resid with row stride a.ldr; y2 through a.Y2 with row stride a.ldy)
+template <int RB, int CB, int S, int EPI>
 __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, const int row_tiles, const int col_groups,
                                                           const int nwg) {
   constexpr int BM = 32 * RB, BN = 64 * CB;
@@ -219,6 +223,8 @@ __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, co
   constexpr int SPI = 4 * NACC / 16;  // dripped stores per k-step
   constexpr int DMA_OPS = 1 + PB;
   constexpr int L = S - 1;            // slabs in flight ahead of the one being multiplied
+  constexpr bool RES = EPI == 1 || EPI == 3;  // an operand of the epilogue is loaded (one k-step ahead)
+  constexpr int ST = SPI * (EPI == 2 ? 2 : 1), LD = RES ? SPI : 0;  // dripped stores / loads per k-step
   static_assert(BM == 128, "A slab = one float4 per thread");
   extern __shared__ __attribute__((aligned(16))) float lds_p[];
   float* As = lds_p;
@@ -306,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, co
   const unsigned loff_r = lane_row * (unsigned)a.ldr + (unsigned)(lane & 15);
   const float* rbase = a.resid;
   float* ybase = a.Y;
+  float* y2base = a.Y2;
   int urow0 = 0;
   auto el_off = [&](int e, int ld_in, int& urow) -> unsigned {
     const int ai = e >> 2, i = e & 3, r = ai % RB;
@@ -328,9 +335,12 @@ __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, co
   // tile) are wave-uniform run-time flags
   auto group = [&](auto drip_tag, const bool LAST) {
     constexpr bool DRIP = decltype(drip_tag)::value;
-    // the residual of the elements stored at step j is loaded one step earlier (a full k-step of latency cover; the
-    // first set waits once per tile)
-    float rres[2][SPI];
+    // the epilogue operand (residual / GELU input) of the elements stored at step j is loaded TWO steps earlier and
+    // waited for at the top of step j, so that the epilogue arithmetic can sit between the step's MFMAs.  (Every
+    // untracked load is waited for inside the group: one left in flight would land in a register the compiler has
+    // given to something else.)
+    static_assert(S == 4, "the vmcnt bookkeeping below is written for a lead of two k-steps");
+    float rres[3][SPI];
     auto res_load = [&](int j, float* dst) {
 #pragma unroll
       for (int s = 0; s < SPI; ++s) {
@@ -339,57 +349,83 @@ __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, co
         dst[s] = gload_untracked(rp, loff_r * 4u);
       }
     };
-    if (DRIP && RES) res_load(0, rres[0]);
+    if (DRIP && RES) {
+      res_load(0, rres[0]);
+      res_load(1, rres[1]);
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       // top of k-step g: slab g + 1 landed for everyone (slabs g + 2 .. g + S - 2 and the drips issued since may be in
       // flight); everyone's MFMAs of step g - 1 are issued, i.e. the slot of slab g - 1 is free
       constexpr int n_dma = (S - 3) * DMA_OPS;
-      if (j >= S - 2 && DRIP) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma + (S - 2) * SPI + (RES ? (S - 3) * SPI : 0)) : "memory");
+      if (j >= S - 2 && DRIP) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma + 2 * ST + (j <= 14 ? LD : 0)) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n_dma) : "memory");
       c_slot = c_slot + 1 == S ? 0 : c_slot + 1;
-      if (DRIP && RES && j + 1 < 16) res_load(j + 1, rres[(j + 1) & 1]);
+      float outv[SPI], out2[SPI];
+      if (DRIP && RES) {
+        // issued after the loads of set j: (j = 0) set 1 | (j = 1) set 2, step 0's DMA and stores | (j >= 2) two steps'
+        // DMA and stores and one set of loads
+        static_assert(SPI == 2, "vm_wait names two registers");
+        if (j == 0) vm_wait<LD>(rres[0][0], rres[0][1]);
+        else if (j == 1) vm_wait<LD + DMA_OPS + ST>(rres[1][0], rres[1][1]);
+        else if (j + 1 < 16) vm_wait<LD + 2 * DMA_OPS + 2 * ST>(rres[j % 3][0], rres[j % 3][1]);
+        else vm_wait<2 * DMA_OPS + 2 * ST>(rres[j % 3][0], rres[j % 3][1]);
+        if (j + 2 < 16) res_load(j + 2, rres[(j + 2) % 3]);
+      }
       if (j + L == 16 && LAST) {  // the slabs issued from here on belong to the next tile
         Ap = Agn;
         Bp = Bgn;
       }
+      auto epi = [&](int s) {  // the arithmetic of dripped element s of this step
+        const int e = j * SPI + s;
+        const int ai = e >> 2, r = ai % RB, c = ai / RB;
+        float pb = pbias[c];
+        asm volatile("" : "+v"(pb));
+        float v = prev[r][c][e & 3] + pb;
+        if (EPI == 1) v += rres[j % 3][s];
+        if (EPI == 3) v *= gelu_g(rres[j % 3][s]);
+        outv[s] = v;
+        if (EPI == 2) out2[s] = gelu_f(v);
+      };
       // this step's fragments are in registers already: MFMAs first.  The reads of the next slab and the DMA issue
       // (~100+ cycles each, in-order in this wave) go after the first quarter of the MFMAs in waves 0-3 and after the
       // third quarter in waves 4-7 -- the two waves of a SIMD are w and w + 4, so one feeds the matrix pipe while the
-      // other issues memory instructions
+      // other issues memory instructions.  The epilogue arithmetic of the two dripped elements is interleaved with the
+      // MFMAs of the first quarter (element 0) and of the middle half (element 1): the matrix pipe runs an MFMA for 32
+      // cycles while the wave issues vector instructions beside it.
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if ((t == 1 && wr == 0) || (t == 3 && wr == 1)) {
           rd(c_slot, af[(j + 1) & 1], bf[(j + 1) & 1]);
           dma();
         }
+        if (DRIP && t == 0) epi(0);
+        if (DRIP && t == 1 && SPI > 1) epi(1);
 #pragma unroll
         for (int c = 0; c < CB; ++c)
 #pragma unroll
           for (int r = 0; r < RB; ++r)
             acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][r][t], bf[j & 1][c][t], acc[r][c], 0, 0, 0);
+        if (DRIP && EPI >= 2 && (t == 0 || t == 1)) {
+          // one MFMA, then a few of the vector instructions, ...; the empty asm keeps the element's arithmetic in this
+          // block (it would otherwise sink to the stores behind the last MFMA)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
+          if (EPI == 2) asm volatile("" : "+v"(out2[t]));
+          else asm volatile("" : "+v"(outv[t]));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (DRIP) {
-        if (RES) {
-          // issued after the loads of rres[j & 1]: this and the previous step's DMA, the previous step's stores and the
-          // next set's loads (before the loop for j = 0: the next set's loads and this step's DMA)
-          static_assert(SPI == 2, "vm_wait names two registers");
-          if (j == 0) vm_wait<SPI + DMA_OPS>(rres[0][0], rres[0][1]);
-          else if (j + 1 < 16) vm_wait<2 * DMA_OPS + 2 * SPI>(rres[j & 1][0], rres[j & 1][1]);
-          else vm_wait<2 * DMA_OPS + SPI>(rres[j & 1][0], rres[j & 1][1]);
-        }
 #pragma unroll
         for (int s = 0; s < SPI; ++s) {
           const int e = j * SPI + s;
           int urow;
-          float* yp = ybase + el_off(e, (int)a.ldy, urow);
-          const int ai = e >> 2, r = ai % RB, c = ai / RB;
-          float pb = pbias[c];
-          asm volatile("" : "+v"(pb));
-          float v = prev[r][c][e & 3] + pb;
-          if (RES) v += rres[j & 1][s];
-          yp[loff_y] = v;
+          (ybase + el_off(e, (int)a.ldy, urow))[loff_y] = outv[s];
+          if (EPI == 2) (y2base + el_off(e, (int)a.ldy, urow))[loff_y] = out2[s];
         }
       }
     }
@@ -404,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, co
     urow0 = rt * BM + wr * 16 * RB;
     const int ucol0 = cg * BN + wc * 16 * CB;
     ybase = a.Y + (size_t)urow0 * a.ldy + ucol0;
+    if (EPI == 2) y2base = a.Y2 + (size_t)urow0 * a.ldy + ucol0;
     if (RES) rbase = a.resid + (size_t)urow0 * a.ldr + ucol0;
 #pragma unroll
     for (int c = 0; c < CB; ++c) pbias[c] = a.bias ? a.bias[ucol0 + c * 16 + (lane & 15)] : 0.f;
@@ -425,9 +462,11 @@ __global__ __launch_bounds__(512, 2) void lin_pers_kernel(const LinBigArgs a, co
     float v = prev[r][c][e & 3] + pbias[c];
     if (RES) {
       int u2;
-      v += (rbase + el_off(e, (int)a.ldr, u2))[loff_r];
+      const float x = (rbase + el_off(e, (int)a.ldr, u2))[loff_r];
+      v = EPI == 1 ? v + x : v * gelu_g(x);
     }
     yp[loff_y] = v;
+    if (EPI == 2) (y2base + el_off(e, (int)a.ldy, urow))[loff_y] = gelu_f(v);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -633,9 +672,9 @@ float run_pers4(const LinBigArgs& b, int reps, int nwg) {
   return ms * 1000.f / reps;
 }
 
-template <int RB, int CB, int S, bool RES>
+template <int RB, int CB, int S, int EPI>
 float run_pers(const LinBigArgs& b, int reps, int nwg) {
-  auto k = lin_pers_kernel<RB, CB, S, RES>;
+  auto k = lin_pers_kernel<RB, CB, S, EPI>;
   const size_t lds = sizeof(float) * S * (32 * RB * 16 + 16 * 64 * CB);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int row_tiles = (b.M + 32 * RB - 1) / (32 * RB), col_groups = b.N / (64 * CB);
@@ -678,7 +717,65 @@ float run_v(const LinBigArgs& b, int tail, int reps) {
   return tail ? run<1, VAR>(b, reps) : run<0, VAR>(b, reps);
 }
 
+__global__ void gelu_fwd_k(const float* __restrict__ x, float* __restrict__ y, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    reinterpret_cast<f32x4*>(y)[i] = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+  }
+}
+__global__ void gelu_bwd_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i], g = reinterpret_cast<const f32x4*>(dy)[i];
+    reinterpret_cast<f32x4*>(dx)[i] = f32x4{g[0] * gelu_g(v[0]), g[1] * gelu_g(v[1]), g[2] * gelu_g(v[2]), g[3] * gelu_g(v[3])};
+  }
+}
+template <class F>
+float time_it(F f, int reps) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) f();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / reps;
+}
+
+__global__ void erf_sweep_k(unsigned long long* bad, unsigned* first) {
+  const unsigned long long n = 1ull << 32;
+  unsigned long long local = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((unsigned)i);
+    const float a = erff(x), b = erf_sel(x);
+    const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+    if (!same) {
+      ++local;
+      atomicMin(first, (unsigned)i);
+    }
+  }
+  if (local) atomicAdd(bad, local);
+}
+
 int main(int argc, char** argv) {
+  {
+    unsigned long long* dbad;
+    unsigned* dfirst;
+    CK(hipMalloc(&dbad, 8));
+    CK(hipMalloc(&dfirst, 4));
+    CK(hipMemset(dbad, 0, 8));
+    CK(hipMemset(dfirst, 0xff, 4));
+    hipLaunchKernelGGL(erf_sweep_k, dim3(4096), dim3(256), 0, 0, dbad, dfirst);
+    unsigned long long bad = 0;
+    unsigned first = 0;
+    CK(hipMemcpy(&bad, dbad, 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&first, dfirst, 4, hipMemcpyDeviceToHost));
+    printf("erf_sel vs erff over all 2^32 floats: %llu differ (first bits 0x%08x)\n", bad, first);
+  }
   const int M = argc > 1 ? atoi(argv[1]) : 81920;
   struct Shape { int K, N, tail, res; };
   const Shape shapes[] = {{256, 1024, 0, 0}, {256, 768, 0, 0}, {1024, 256, 1, 1}, {256, 256, 1, 1}, {768, 256, 1, 0}, {1024, 256, 1, 0}};
@@ -704,7 +801,7 @@ int main(int argc, char** argv) {
   const int reps = 20;
   for (const Shape& sh : shapes) {
     LinBigArgs b;
-    b.A = dA; b.P = dP; b.bias = db; b.resid = sh.res ? dR : nullptr; b.Y = dY0;
+    b.A = dA; b.P = dP; b.bias = db; b.resid = sh.res ? dR : nullptr; b.Y = dY0; b.Y2 = nullptr;
     b.lda_g = sh.K; b.ldr = sh.N; b.ldy = sh.N;
     b.M = M; b.K = sh.K; b.N = sh.N; b.Np = sh.N; b.col0 = 0;
     const double gf = 2.0 * M * sh.K * sh.N * 1e-9;
@@ -736,9 +833,39 @@ int main(int argc, char** argv) {
     report(4, run_v<4>(b, sh.tail, reps), false);
     report(5, run_v<5>(b, sh.tail, reps), false);
     if (b.resid) {
-      CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(724, run_pers<4, 2, 4, true>(b, reps, 256), true);
+      CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(724, run_pers<4, 2, 4, 1>(b, reps, 256), true);
     } else {
-      CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(724, run_pers<4, 2, 4, false>(b, reps, 256), true);
+      CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); report(724, run_pers<4, 2, 4, 0>(b, reps, 256), true);
+    }
+    if (sh.K == 256 && sh.N == 1024) {  // the MLP's GELU folded into fc1's / d_fc2's drip
+      const size_t n = (size_t)M * sh.N;
+      float *dG, *dG2;
+      CK(hipMalloc(&dG, n * 4));
+      CK(hipMalloc(&dG2, n * 4));
+      std::vector<float> ref(n), got(n);
+      // forward: y = pre-activation (== v0's), y2 = gelu(y)
+      const float tf = time_it([&] { hipLaunchKernelGGL(gelu_fwd_k, dim3(8192), dim3(256), 0, 0, dY0, dG, (int64_t)(n / 4)); }, reps);
+      LinBigArgs e = b;
+      e.resid = nullptr; e.Y = dY; e.Y2 = dG2;
+      CK(hipMemset(dY, 0, n * 4));
+      const float t2 = run_pers<4, 2, 4, 2>(e, reps, 256);
+      CK(hipMemcpy(ref.data(), dG, n * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(got.data(), dG2, n * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(y.data(), dY, n * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < n; ++i) bad += (ref[i] != got[i]) + (y[i] != y0[i]);
+      printf("  gelu fwd: separate pass %.1f us; folded GEMM %.1f us (plain pers GEMM above); mismatches %zu\n", tf, t2, bad);
+      // backward: y = (acc) * gelu'(aux), aux = dR
+      const float tb = time_it([&] { hipLaunchKernelGGL(gelu_bwd_k, dim3(8192), dim3(256), 0, 0, dY0, dR, dG, (int64_t)(n / 4)); }, reps);
+      e.resid = dR; e.Y = dG2; e.Y2 = nullptr;
+      const float t3 = run_pers<4, 2, 4, 3>(e, reps, 256);
+      CK(hipMemcpy(ref.data(), dG, n * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(got.data(), dG2, n * 4, hipMemcpyDeviceToHost));
+      bad = 0;
+      for (size_t i = 0; i < n; ++i) bad += ref[i] != got[i];
+      printf("  gelu bwd: separate pass %.1f us; folded GEMM %.1f us; mismatches %zu\n", tb, t3, bad);
+      CK(hipFree(dG));
+      CK(hipFree(dG2));
     }
   }
   return 0;
