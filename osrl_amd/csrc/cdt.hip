@@ -252,6 +252,171 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// ---- the same two kernels for E % 256 == 0 (round 4): a lane owns FOUR CONSECUTIVE features per 256-feature chunk --
+// every tensor moves as one 16-byte access per lane and chunk (the kernels above issue four dword accesses 256 B apart),
+// and the dropout site costs ONE Philox call per lane and chunk: the four words of a call are the masks of four
+// consecutive elements, so the kernels above evaluated the generator four times per element group and kept one word of
+// each (~100 VALU instructions per call; profiles/r4_cdt_kernel_stats.csv: ln_bwd<true> 131 us = 3.2 TB/s for its
+// 420 MB).  Same arithmetic per element and the same masks; the row reductions add the lanes' partial sums in a different
+// grouping (last-bit differences in mean / rstd against the kernels above: both are within the parity tolerance).
+// The backward loads the next row of the wave while it works on the current one.
+template <bool DROP>
+__device__ __forceinline__ f32x4 drop_keep4(const DropSite& d, uint32_t step, uint64_t i4) {  // elements 4 i4 .. 4 i4 + 3
+  if constexpr (!DROP) return f32x4{1.f, 1.f, 1.f, 1.f};
+  const osrl_rng::U4 w = osrl_rng::drop_words(i4, step, d.site, d.k0, d.k1);
+  return f32x4{w.x >= d.thresh ? d.scale : 0.f, w.y >= d.thresh ? d.scale : 0.f, w.z >= d.thresh ? d.scale : 0.f,
+               w.w >= d.thresh ? d.scale : 0.f};
+}
+
+template <bool DROP, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ delta,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float* __restrict__ xout, float* __restrict__ y,
+                                                        float* __restrict__ stats, int M, const DropSite ds) {
+  constexpr int E = 256 * NCH;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  uint32_t step = 0;
+  if constexpr (DROP) step = ds.st ? (uint32_t)ds.st->step : 0u;
+  const size_t base = (size_t)row * E + 4 * lane;
+  f32x4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(x + base + 256 * c);
+    if (delta) {
+      f32x4 d = *reinterpret_cast<const f32x4*>(delta + base + 256 * c);
+      if constexpr (DROP) {
+        const f32x4 k = drop_keep4<DROP>(ds, step, (base + 256 * c) >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __fmul_rn(d[j], k[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = __fadd_rn(t[j], d[j]);
+    }
+    if (xout) *reinterpret_cast<f32x4*>(xout + base + 256 * c) = t;
+    v[c] = t;
+    s += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+  const float mean = wsum(s) / (float)E;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q += (v[c][j] - mean) * (v[c][j] - mean);
+  const float rstd = 1.0f / sqrtf(wsum(q) / (float)E + kLnEps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * lane + 256 * c);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 4 * lane + 256 * c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * gg[j] + bb[j];
+    *reinterpret_cast<f32x4*>(y + base + 256 * c) = o;
+  }
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+template <bool DROP, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ stats, const float* __restrict__ g,
+                                                        const float* __restrict__ dres, float* __restrict__ dx,
+                                                        float* __restrict__ partial, int M, float* __restrict__ dxd,
+                                                        const DropSite ds, const int n_wg) {
+  constexpr int E = 256 * NCH;
+  __shared__ float sm[4][2 * E];
+  uint32_t step = 0;
+  if constexpr (DROP) step = ds.st ? (uint32_t)ds.st->step : 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 dg[NCH], db[NCH], gg[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    dg[c] = db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gg[c] = *reinterpret_cast<const f32x4*>(g + 4 * lane + 256 * c);
+  }
+  struct Row {
+    f32x4 d[NCH], xv[NCH], r[NCH];
+    float mean, rstd;
+  };
+  auto load = [&](int row, Row& R) __attribute__((always_inline)) {
+    const size_t base = (size_t)row * E + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      R.d[c] = *reinterpret_cast<const f32x4*>(dy + base + 256 * c);
+      R.xv[c] = *reinterpret_cast<const f32x4*>(x + base + 256 * c);
+      if (dres) R.r[c] = *reinterpret_cast<const f32x4*>(dres + base + 256 * c);
+    }
+    R.mean = stats[2 * row];
+    R.rstd = stats[2 * row + 1];
+  };
+  auto work = [&](int row, const Row& R) __attribute__((always_inline)) {
+    const size_t base = (size_t)row * E + 4 * lane;
+    f32x4 xh[NCH], dxh[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = R.d[c][j];
+        xh[c][j] = (R.xv[c][j] - R.mean) * R.rstd;
+        dxh[c][j] = d * gg[c][j];
+        dg[c][j] += d * xh[c][j];
+        db[c][j] += d;
+        s1 += dxh[c][j];
+        s2 += dxh[c][j] * xh[c][j];
+      }
+    s1 = wsum(s1) / (float)E;
+    s2 = wsum(s2) / (float)E;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = R.rstd * (dxh[c][j] - s1 - xh[c][j] * s2);
+        if (dres) v[j] += R.r[c][j];
+      }
+      *reinterpret_cast<f32x4*>(dx + base + 256 * c) = v;
+      if constexpr (DROP) {
+        const f32x4 k = drop_keep4<DROP>(ds, step, (base + 256 * c) >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __fmul_rn(v[j], k[j]);
+        *reinterpret_cast<f32x4*>(dxd + base + 256 * c) = v;
+      }
+    }
+  };
+  const int stride = n_wg * 4;
+  int row = blockIdx.x * 4 + wave;
+  if (row < M) {
+    Row A, B;
+    load(row, A);
+    for (;;) {
+      const int r1 = row + stride;
+      if (r1 < M) load(r1, B);
+      work(row, A);
+      if (r1 >= M) break;
+      const int r2 = r1 + stride;
+      if (r2 < M) load(r2, A);
+      work(r1, B);
+      if (r2 >= M) break;
+      row = r2;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sm[wave][256 * c + 4 * lane + j] = dg[c][j];
+      sm[wave][E + 256 * c + 4 * lane + j] = db[c][j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * E; i += 256)
+    partial[(size_t)blockIdx.x * 2 * E + i] = (sm[0][i] + sm[1][i]) + (sm[2][i] + sm[3][i]);
+}
+
 // dgamma -> slab[g_off + f], dbeta -> slab[b_off + f]  (fixed-order sum of the per-workgroup partials;
 // 64 columns per workgroup, the 4 waves split the partial rows, then a 4-way LDS reduction)
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, int nparts, int E,
@@ -1007,10 +1172,27 @@ int osrl_cdt_embed_ln(const float* states, const float* actions, const float* re
   DONE();
 }
 
+// the 16-byte-per-lane LayerNorm kernels: E = 256 or 512, every tensor 16-byte aligned (rows are then aligned too)
+static bool ln_v4_ok(int E, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+  if (E != 256 && E != 512) return false;
+  const uintptr_t m = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                      reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f);
+  return (m & 15) == 0;
+}
+
 int osrl_layernorm_fwd(const float* x, const float* delta, const float* gamma, const float* beta, float* xout,
                        float* y, float* stats, int32_t M, int32_t E, void* stream) {
   if (!x || !gamma || !beta || !y || !stats || M < 1 || E < 1 || E > 64 * kMaxEPL) return -1;
   CLEAR();
+  if (ln_v4_ok(E, x, delta, gamma, beta, xout, y)) {
+    if (E == 256)
+      hipLaunchKernelGGL((ln_fwd_v4_kernel<false, 1>), dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y,
+                         stats, M, DropSite{});
+    else
+      hipLaunchKernelGGL((ln_fwd_v4_kernel<false, 2>), dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y,
+                         stats, M, DropSite{});
+    DONE();
+  }
   hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M,
                      E, DropSite{});
   DONE();
@@ -1033,6 +1215,15 @@ int osrl_layernorm_fwd_drop(const float* x, const float* delta, const osrl_dropo
   if (drop && !(drop->p < 1.0f)) return -1;
   if (!drop_site(drop, &d)) return osrl_layernorm_fwd(x, delta, gamma, beta, xout, y, stats, M, E, stream);
   CLEAR();
+  if (ln_v4_ok(E, x, delta, gamma, beta, xout, y)) {
+    if (E == 256)
+      hipLaunchKernelGGL((ln_fwd_v4_kernel<true, 1>), dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y,
+                         stats, M, d);
+    else
+      hipLaunchKernelGGL((ln_fwd_v4_kernel<true, 2>), dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y,
+                         stats, M, d);
+    DONE();
+  }
   hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, S, x, delta, gamma, beta, xout, y, stats, M, E,
                      d);
   DONE();
@@ -1044,6 +1235,14 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
   if (!dy || !x || !stats || !gamma || !dx || !partial_ws || !slab || n_parts < 1 || M < 1 || E > 64 * kMaxEPL)
     return -1;
   CLEAR();
+  if (ln_v4_ok(E, dy, x, gamma, dres, dx, dx)) {
+    if (E == 256)
+      hipLaunchKernelGGL((ln_bwd_v4_kernel<false, 1>), dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx,
+                         partial_ws, M, nullptr, DropSite{}, n_parts);
+    else
+      hipLaunchKernelGGL((ln_bwd_v4_kernel<false, 2>), dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx,
+                         partial_ws, M, nullptr, DropSite{}, n_parts);
+  } else
   hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M,
                      E, nullptr, DropSite{});
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
@@ -1060,6 +1259,14 @@ int osrl_layernorm_bwd_drop(const float* dy, const float* x, const float* stats,
   DropSite d{};
   if (!drop_site(drop, &d)) return -1;
   CLEAR();
+  if (ln_v4_ok(E, dy, x, gamma, dres, dx, dx_dropped)) {
+    if (E == 256)
+      hipLaunchKernelGGL((ln_bwd_v4_kernel<true, 1>), dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx,
+                         partial_ws, M, dx_dropped, d, n_parts);
+    else
+      hipLaunchKernelGGL((ln_bwd_v4_kernel<true, 2>), dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx,
+                         partial_ws, M, dx_dropped, d, n_parts);
+  } else
   hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E,
                      dx_dropped, d);
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,

@@ -112,7 +112,7 @@ def test_layernorm_gelu_attention_kernels():
     from osrl_amd.engine.core import cur_stream
     lib = L.load()
     rs = np.random.RandomState(1)
-    for (M, E) in [(37, 16), (260, 128), (1000, 256)]:
+    for (M, E) in [(37, 16), (260, 128), (1000, 256), (301, 512)]:
         x, d = rs.randn(M, E), rs.randn(M, E) * 0.3
         gm, bt = 1 + 0.1 * rs.randn(E), 0.1 * rs.randn(E)
         f = lambda a: t(np.asarray(a, np.float32))  # noqa: E731
@@ -176,6 +176,48 @@ def test_layernorm_gelu_attention_kernels():
         dq, dk = dS @ k / math.sqrt(d), dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
         ref = np.concatenate([x.transpose(0, 2, 1, 3).reshape(B, S, E) for x in (dq, dk, dv)], -1)
         assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), (B, T, E, H)
+
+
+def test_layernorm_16_byte_kernels_equal_the_generic_ones():
+    """E = 256 / 512 with 16-byte aligned tensors take the kernels whose lanes own four consecutive features; a 4-byte
+    offset of one operand sends the same call to the generic kernels.  Element-wise results that involve no row
+    reduction (x + delta * mask, and the positions the dropout site zeroes) are bit-equal; LayerNorm outputs agree to
+    rounding (the lanes' partial sums meet in a different order)."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import StepState, cur_stream
+    lib = L.load()
+    rs = np.random.RandomState(3)
+    st = StepState(torch.device(DEV), ["x"])
+    st.tick()
+    for E in (256, 512):
+        M, p, nparts = 333, 0.25, 64
+        f = lambda a: t(np.asarray(a, np.float32))  # noqa: E731
+        gm, bt = f(1 + 0.1 * rs.randn(E)), f(0.1 * rs.randn(E))
+        x, dl, dy, dres = (rs.randn(M * E + 1).astype(np.float32) for _ in range(4))
+        outs = []
+        for off in (0, 1):  # 0: aligned operands; 1: x / dy start 4 bytes further (same values)
+            xt, dyt = f(x[:M * E]), f(dy[:M * E])
+            if off:
+                xt = f(np.concatenate([[0.0], x[:M * E]]))[1:]
+                dyt = f(np.concatenate([[0.0], dy[:M * E]]))[1:]
+            dlt, drt = f(dl[:M * E]), f(dres[:M * E])
+            xo, y, stt = torch.zeros(M * E, device=DEV), torch.zeros(M * E, device=DEV), torch.zeros(M, 2, device=DEV)
+            d = L.DropoutT(p, 5, 77, st.ptr)
+            L.check(lib.osrl_layernorm_fwd_drop(xt.data_ptr(), dlt.data_ptr(), C.byref(d), gm.data_ptr(), bt.data_ptr(),
+                                                xo.data_ptr(), y.data_ptr(), stt.data_ptr(), M, E, cur_stream()), "lnf")
+            dx, dxd = torch.zeros(M * E, device=DEV), torch.zeros(M * E, device=DEV)
+            ws, slab = torch.zeros(nparts, 2 * E, device=DEV), torch.zeros(2 * E, device=DEV)
+            L.check(lib.osrl_layernorm_bwd_drop(dyt.data_ptr(), xo.data_ptr(), stt.data_ptr(), gm.data_ptr(),
+                                                drt.data_ptr(), dx.data_ptr(), dxd.data_ptr(), C.byref(d), ws.data_ptr(),
+                                                nparts, M, E, slab.data_ptr(), 0, E, cur_stream()), "lnb")
+            outs.append([v.cpu().numpy() for v in (xo, y, stt, dx, dxd, slab)])
+        (xo0, y0, s0, dx0, dxd0, sl0), (xo1, y1, s1, dx1, dxd1, sl1) = outs
+        assert np.array_equal(xo0, xo1)
+        assert np.array_equal(dxd0 == 0, dxd1 == 0) and 0.15 < (dxd0 == 0).mean() < 0.35
+        assert np.abs(y0 - y1).max() < 3e-6 and np.abs(s0 - s1).max() < 3e-6 * max(1, np.abs(s1).max())
+        assert np.abs(dx0 - dx1).max() < 1e-5 and np.abs(dxd0 - dxd1).max() < 2e-5
+        assert np.abs(sl0 - sl1).max() < 1e-4 * max(1, np.abs(sl1).max())
 
 
 def test_dropout_kernels():
