@@ -522,7 +522,7 @@ __device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& a, const f32x4& b
 // load one [S, d] slice of qkv / dout into a zero-padded row-major LDS tile (and optionally its transpose).
 // 8 independent global loads per thread are issued before the first LDS store so their latencies overlap
 // (one load per loop iteration serialises ~40 L2 round trips per workgroup: measured 3x slower kernels).
-__device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, size_t row_stride, int S_, int d, int Sp,
+__device__ __forceinline__ void attn_load_tile_any(const float* __restrict__ src, size_t row_stride, int S_, int d, int Sp,
                                                int dp, float* dst, int ld, float* dst_t, int ld_t) {
   const int total = Sp * dp;
   for (int base = 0; base < total; base += 8 * 256) {
@@ -545,6 +545,48 @@ __device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, si
       }
     }
   }
+}
+
+// The same copy for d == dp == DPC (a compile-time head width) with 16-byte aligned rows: float4 per thread, row /
+// column of an element by shifts.  (Round 4, PMC: the generic copy above spends two integer divisions by the run-time
+// dp, a 64-bit multiply and the bounds tests on every ELEMENT -- ~60 vector instructions each, and vector instructions
+// are what the attention kernels are made of: 2100 per wave in the forward against 60 MFMAs, VALU + MFMA = 95 % of the
+// vector ALUs' cycles.)
+template <int DPC>
+__device__ __forceinline__ void attn_load_tile_v(const float* __restrict__ src, size_t row_stride, int S_, int Sp,
+                                                 float* dst, int ld, float* dst_t, int ld_t) {
+  constexpr int C4 = DPC / 4;  // float4 per row
+  const int total4 = Sp * C4;
+  for (int base = 0; base < total4; base += 4 * 256) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * 256 + (int)threadIdx.x;
+      const int i = idx / C4, c4 = idx % C4;
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < total4 && i < S_) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)i * row_stride + 4 * c4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * 256 + (int)threadIdx.x;
+      if (idx < total4) {
+        const int i = idx / C4, c4 = idx % C4;
+        if (dst) *reinterpret_cast<f32x4*>(dst + i * ld + 4 * c4) = v[j];
+        if (dst_t) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dst_t[(4 * c4 + t) * ld_t + i] = v[j][t];
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, size_t row_stride, int S_, int d, int Sp,
+                                               int dp, float* dst, int ld, float* dst_t, int ld_t) {
+  const bool vec = d == dp && (row_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (ld & 3) == 0;
+  if (vec && dp == 32) attn_load_tile_v<32>(src, row_stride, S_, Sp, dst, ld, dst_t, ld_t);
+  else if (vec && dp == 64) attn_load_tile_v<64>(src, row_stride, S_, Sp, dst, ld, dst_t, ld_t);
+  else if (vec && dp == 16) attn_load_tile_v<16>(src, row_stride, S_, Sp, dst, ld, dst_t, ld_t);
+  else attn_load_tile_any(src, row_stride, S_, d, Sp, dp, dst, ld, dst_t, ld_t);
 }
 
 __device__ __forceinline__ void attn_key_valid(const AttnArgs& a, int b, int Sp, float* kvalid) {
