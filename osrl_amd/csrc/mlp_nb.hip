@@ -548,6 +548,16 @@ __global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_k
   mlp_fwd_nb_body<4, true, 8, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
 }
 
+// the 8-wave form of the 13..16-block (<= 256-wide) nets: 2 column blocks per wave, two waves per SIMD (the 4-wave form
+// runs ONE wave per SIMD -- its 84.5 KB activation tile allows one workgroup per CU -- so nothing covers a wave's
+// barrier / weight-latency stalls)
+__global__ __launch_bounds__(512, 2) void mlp_fwd_nb8n_kernel(const NbArgs a) {
+  mlp_fwd_nb_body<2, false, 8, const NbArgs&>(a);
+}
+__global__ __launch_bounds__(512, 2) void mlp_fwd_nb8n_kernel_p(const void* p) {
+  mlp_fwd_nb_body<2, false, 8, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
+}
+
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
 template <int NCB, bool SHARED = false>
 static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
@@ -614,6 +624,26 @@ __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* n
     else
       hipLaunchKernelGGL(mlp_fwd_nb8_kernel, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
     return (int)hipGetLastError();
+  }
+  if (ncb == 4 && lda >= 8 * ((NL + 15) & ~15)) {
+    // 8 waves from 512 tiles per net on (BCQ-Lag / BEAR-Lag at B = 4096, N = 10: C3 604 -> 621 steps/s); at CPQ's 256 tiles
+    // per net, launched beside the 2048-row chain kernels, the 4-wave form is the faster neighbour (C2 2256 vs 2211).
+    // OSRL_NB256_WAVES = 4 / 8 forces either (read per launch: A/B runs and a test flip it)
+    const char* w256 = getenv("OSRL_NB256_WAVES");
+    const bool eight = w256 && w256[0] ? atoi(w256) == 8 : tiles >= 512;
+    if (eight) {
+      const void* dev_args = osrl_argmem::slot(a);
+      hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb8n_kernel_p)
+                                                  : reinterpret_cast<const void*>(mlp_fwd_nb8n_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return (int)e;
+      (void)hipGetLastError();
+      if (dev_args)
+        hipLaunchKernelGGL(mlp_fwd_nb8n_kernel_p, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, dev_args);
+      else
+        hipLaunchKernelGGL(mlp_fwd_nb8n_kernel, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
+      return (int)hipGetLastError();
+    }
   }
   if (shared) return launch_nb<7, true>(a, tiles, nets, lds_bytes, stream);
   return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);
