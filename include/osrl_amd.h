@@ -332,6 +332,11 @@ int osrl_mlp_backward_dw_tiles_adam(const osrl_dw_entry_t* d_entries, const int3
  * gradient slab 16-byte aligned with w_off % 4 == 0 (the caller checks: entries are device memory). */
 int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items, int32_t rows,
                              int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
+/* The same contract for items in units of 256 (out) x 256 (in) tiles (out % 256 == 0, in % 256 == 0): one 8-wave
+ * workgroup per tile and row split, the operands staged through LDS by DMA and shared by the eight waves.  rows % 16 == 0;
+ * alignment as above.  db of an entry is written by its it == 0 tiles. */
+int osrl_mlp_backward_dw_coop(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items, int32_t rows,
+                              int32_t n_splits, float* slabs, int64_t slab_stride, void* stream);
 
 /* ---- optimizer (optim.hip): torch.optim.Adam/AdamW.step + _soft_update (cpq.py:107-113,232-238) ---- */
 /* Advance the device step state (t += 1, bias corrections, LR-warmup factor).  If stats_cur/ring are

@@ -179,6 +179,7 @@ PROTOTYPES = {
     "osrl_mlp_backward_dw": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_mlp_backward_dw_tiles": [_vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp],
     "osrl_mlp_backward_dw_big": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
+    "osrl_mlp_backward_dw_coop": [_vp, _vp, _i32, _i32, _i32, _fp, _i64, _vp],
     "osrl_mlp_backward_dw_tiles_adam": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _P(DwAdamT), _vp],
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
     "osrl_step_begin": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _fp, _i64, _u64, _u32, _i32, _P(_fp), _P(_fp),

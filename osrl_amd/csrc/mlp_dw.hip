@@ -546,6 +546,149 @@ __global__ __launch_bounds__(256, 1) void mlp_dw_big_kernel(const osrl_dw_entry_
   }
 }
 
+
+// ---- dW for big row counts, 256 x 256 tiles through LDS (round 4; tools/dw_lab.hip) ---------------------------------
+// The waves of mlp_dw_big_kernel stream private 2560 x 192 operand blocks: 18 GB per launch of the CDT projections through
+// L2 / MALL (with the operand rows cache-resident the same loop runs at 0.82 of the roof instead of 0.78).  Here the eight
+// waves of a workgroup (2 x 4: 128 out-columns x 64 in-columns each, the same 128-register accumulator tile and the same
+// permuted-column fragment registers) share one DMA-fed slab ring: 16 rows x (256 + 256) columns = 32 KB per k-step, every
+// DMA piece one whole 1 KB row (lane l <- 16 bytes at column 4 l), 4 slots, conflict-free ds_read_b128 (row pitch 1 KB,
+// lanes of a service group on 16 different 16-byte slots), the DMA issue point staggered between the two waves of a
+// SIMD.  6 GB per launch; 3390 (round 3) / 3170 (mlp_dw_big_kernel now) -> 2980 us, 0.83 of the fp32 MFMA roof, and as
+// few row splits as fill the CUs once (36 tiles x 7).  Fragments are single-buffered: 128 + 48 registers of the 256 a
+// wave has at two per SIMD (double-buffered they spill).
+// Requires out % 256 == 0, in % 256 == 0, rows % 16 == 0, 16-byte aligned operands / strides % 4 == 0 (DwPlan checks).
+constexpr int kCoS = 4;  // slots
+__device__ __forceinline__ void dwc_glds16(const void* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__global__ __launch_bounds__(512, 2) void mlp_dw_coop_kernel(const osrl_dw_entry_t* __restrict__ entries,
+                                                  const int32_t* __restrict__ items, int n_items, int rows,
+                                                  int rows_per_split, float* __restrict__ slabs, int64_t slab_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds_co[];
+  constexpr int kSlot = 2 * 16 * 256;  // floats: [mat][row][256]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave >> 2, wi = wave & 3;
+  const int item = blockIdx.x;
+  const int ei = items[item * 4 + 0], ot = items[item * 4 + 1], it = items[item * 4 + 2];
+  const osrl_dw_entry_t E = entries[ei];
+  const int out = E.out, in = E.in;
+  const size_t ldz = E.ldz > 0 ? (size_t)E.ldz : (size_t)out, lda_g = E.lda > 0 ? (size_t)E.lda : (size_t)in;
+  const int o0 = ot * 256, i0 = it * 256;
+  const int s = blockIdx.y;
+  const int r_begin = s * rows_per_split;
+  int r_end = r_begin + rows_per_split;
+  r_end = r_end > rows ? rows : r_end;
+  const int m = lane & 15, kq = lane >> 4;
+  const bool want_db = it == 0 && wi == 0;
+  const int G = (r_end - r_begin) >> 4;  // k-steps (whole: host)
+  f32x4 acc[kDwbO][kDwbI];
+#pragma unroll
+  for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < kDwbI; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc[kDwbO];
+#pragma unroll
+  for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] = 0.f;
+  if (G > 0) {
+    // ---- issue side: pieces p = 0..3 of this wave: (matrix, row) = ((4 wave + p) >> 4, (4 wave + p) & 15)
+    const char* src[4];
+    size_t step_b[4];
+    int dst_off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = 4 * wave + p, mat = idx >> 4, row = idx & 15;
+      const float* base = mat ? E.a + i0 : E.dz + o0;
+      const size_t ld = mat ? lda_g : ldz;
+      src[p] = reinterpret_cast<const char*>(base + (size_t)(r_begin + row) * ld + 4 * lane);
+      step_b[p] = 16 * ld * sizeof(float);
+      dst_off[p] = mat * 16 * 256 + row * 256;  // floats; the wave writes the whole 1 KB row (lane * 16 B)
+    }
+    int it_slot = 0, it_g = 0;
+    auto dma = [&]() __attribute__((always_inline)) {
+      if (it_g < G) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          dwc_glds16(src[p], lds_co + it_slot * kSlot + dst_off[p]);
+          src[p] += step_b[p];
+        }
+      }
+      ++it_g;
+      it_slot = it_slot + 1 == kCoS ? 0 : it_slot + 1;
+    };
+    // ---- consume side
+    const int z_off = (4 * kq) * 256 + wo * 128 + 4 * m;             // + t * 256 + 64 q
+    const int a_off = 16 * 256 + (4 * kq) * 256 + wi * 64 + 4 * m;   // + t * 256
+    DwBigFrag f;  // single-buffered: 128 accumulator + 48 fragment registers of the 256 a wave has at two per SIMD
+    auto rd = [&](int slot, DwBigFrag& g) __attribute__((always_inline)) {
+      const float* sl = lds_co + slot * kSlot;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // by t: the MFMAs of t = 0 need only the first three reads
+#pragma unroll
+        for (int q = 0; q < kDwbO / 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sl + z_off + t * 256 + 64 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g.a[4 * q + j][t] = v[j];
+        }
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sl + a_off + t * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g.b[j][t] = v[j];
+      }
+    };
+    auto mma_t = [&](const DwBigFrag& g, int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+        for (int ib = 0; ib < kDwbI; ++ib)
+          acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(g.a[ob][t], g.b[ib][t], acc[ob][ib], 0, 0, 0);
+    };
+    constexpr int L = kCoS - 1, DMA_OPS = 4;
+#pragma unroll
+    for (int i = 0; i < L; ++i) dma();
+    int c_slot = 0;
+    for (int g = 0; g < G; ++g) {
+      // top of k-step g: slab g landed for everyone (slabs g + 1, g + 2 may be in flight); everyone's MFMAs of step
+      // g - 1 are issued, i.e. the slot of slab g - 1 is free for slab g + 3
+      if (g + L <= G) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((L - 1) * DMA_OPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      rd(c_slot, f);
+      c_slot = c_slot + 1 == kCoS ? 0 : c_slot + 1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if ((t == 0 && wo == 0) || (t == 2 && wo == 1)) dma();
+        mma_t(f, t);
+      }
+      if (want_db) {
+#pragma unroll
+        for (int ob = 0; ob < kDwbO; ++ob) dbacc[ob] += (f.a[ob][0] + f.a[ob][1]) + (f.a[ob][2] + f.a[ob][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  float* __restrict__ slab = slabs + (size_t)s * slab_stride;
+  const int ow = o0 + wo * 128, iw = i0 + wi * 64;
+#pragma unroll
+  for (int ob = 0; ob < kDwbO; ++ob)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = ow + 64 * (ob >> 2) + 4 * (4 * kq + r) + (ob & 3);
+      const f32x4 v = {acc[ob][0][r], acc[ob][1][r], acc[ob][2][r], acc[ob][3][r]};
+      *reinterpret_cast<f32x4*>(&slab[E.w_off + (size_t)orow * in + iw + 4 * m]) = v;
+    }
+  if (want_db) {
+#pragma unroll
+    for (int ob = 0; ob < kDwbO; ++ob) {
+      float v = dbacc[ob];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0) slab[E.b_off + ow + 64 * (ob >> 2) + 4 * m + (ob & 3)] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
@@ -561,6 +704,26 @@ extern "C" int osrl_mlp_backward_dw_big(const osrl_dw_entry_t* d_entries, const 
   (void)hipGetLastError();
   hipLaunchKernelGGL(mlp_dw_big_kernel, dim3((n_items + 3) / 4, n_splits, 1), dim3(256), kLds, (hipStream_t)stream,
                      d_entries, d_items, n_items, rows, rps, slabs, slab_stride);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_mlp_backward_dw_coop(const osrl_dw_entry_t* d_entries, const int32_t* d_items, int32_t n_items,
+                                         int32_t rows, int32_t n_splits, float* slabs, int64_t slab_stride,
+                                         void* stream) {
+  if (!d_entries || !d_items || n_items < 1 || rows < 16 || (rows & 15) || n_splits < 1 || !slabs) return -1;
+  int rps = (rows + n_splits - 1) / n_splits;
+  rps = (rps + 15) & ~15;  // whole 16-row k-steps
+  constexpr int kLds = sizeof(float) * kCoS * 2 * 16 * 256;  // 128 KB: one workgroup (two waves per SIMD) per CU
+  static bool set = false;
+  if (!set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_coop_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e != hipSuccess) return (int)e;
+    set = true;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(mlp_dw_coop_kernel, dim3(n_items, n_splits, 1), dim3(512), kLds, (hipStream_t)stream, d_entries,
+                     d_items, n_items, rows, rps, slabs, slab_stride);
   return (int)hipGetLastError();
 }
 

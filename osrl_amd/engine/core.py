@@ -505,6 +505,7 @@ class DwPlan:
     """Static work list for osrl_mlp_backward_dw over one optimizer group."""
 
     BIG_ROWS = 8192  # from this many rows on, fully 128x128-tiled layers take the one-wave-per-tile kernel
+    COOP = os.environ.get("OSRL_DW_COOP", "1") == "1"  # ... and fully 256x256-tiled ones the workgroup-per-tile kernel
     FLAT_DEFAULT = os.environ.get("OSRL_DW_FLAT", "1") == "1"
 
     def __init__(self, group: FlatGroup, entries: Sequence[Tuple[torch.Tensor, torch.Tensor, str, str]],
@@ -526,6 +527,7 @@ class DwPlan:
         arr = (L.DwEntryT * len(entries))()
         items: List[int] = []
         big_items: List[int] = []
+        coop_items: List[int] = []
         work: List[int] = []
         s_full = max(1, min(rows // 512, 8)) if n_splits is None else int(n_splits)  # row splits of a full tile
         for i, ent in enumerate(entries):
@@ -557,8 +559,14 @@ class DwPlan:
             # osrl_mlp_backward_dw_big fills its fragments with 16-byte loads: aligned operands, strides % 4 == 0
             aligned = (arr[i].dz % 16 == 0 and arr[i].a % 16 == 0 and (ldz or out_f) % 4 == 0 and (lda_ or in_f) % 4 == 0
                        and arr[i].w_off % 4 == 0)
+            if use_big and self.COOP and out_f % 256 == 0 and in_f % 256 == 0 and aligned and rows % 16 == 0:
+                # token-matrix sized GEMMs (CDT projections): every 256x256 tile to osrl_mlp_backward_dw_coop
+                for ot in range(out_f // 256):
+                    for it in range(in_f // 256):
+                        coop_items += [i, ot, it, 0]
+                continue
             if use_big and out_f % 128 == 0 and in_f % 64 == 0 and aligned:
-                # token-matrix sized GEMMs (CDT projections): every 128x64 tile to osrl_mlp_backward_dw_big
+                # (128x64 tiles, one wave each: what the 256x256 form does not take) osrl_mlp_backward_dw_big
                 for ot in range(out_f // 128):
                     for it in range(in_f // 64):
                         big_items += [i, ot, it, 0]
@@ -568,6 +576,7 @@ class DwPlan:
                     items += [i, ot, it, 0]
         self.n_items = len(items) // 4
         self.n_big = len(big_items) // 4
+        self.n_coop = len(coop_items) // 4
         self.n_work = len(work) // 4
         self.d_work = torch.tensor(work, dtype=torch.int32, device=device) if work else None
         # arrival counters of the fused dW + optimizer launch (launch_adam): one per tile, shared by its row splits
@@ -584,6 +593,7 @@ class DwPlan:
         self.d_entries = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.d_items = torch.tensor(items if items else [0, 0, 0, 0], dtype=torch.int32, device=device)
         self.d_big = torch.tensor(big_items, dtype=torch.int32, device=device) if big_items else None
+        self.d_coop = torch.tensor(coop_items, dtype=torch.int32, device=device) if coop_items else None
         self._keep = [e[0] for e in entries] + [e[1] for e in entries] + [e[6:] for e in entries if len(e) > 6]
         if n_splits is None:
             # one workgroup per (tile, split): aim at >= 4 rounds of the 512 resident workgroups (2 per CU at
@@ -601,7 +611,16 @@ class DwPlan:
                 if eff > best_eff + 1e-9:
                     best, best_eff = S, eff
             self.n_splits_big = best
-        self.n_splits = max(self.n_splits_small, self.n_splits_big, 1)
+        # 256x256 tiles: one 8-wave workgroup per CU -> the FEWEST row splits that fill whole rounds of the 256 CUs best
+        self.n_splits_coop = 0
+        if self.n_coop:
+            best, best_eff = 1, 0.0
+            for S in range(1, min(32, max(rows // 2048, 1)) + 1):
+                eff = self.n_coop * S / (256.0 * ((self.n_coop * S + 255) // 256))
+                if eff > best_eff + 1e-9:
+                    best, best_eff = S, eff
+            self.n_splits_coop = best
+        self.n_splits = max(self.n_splits_small, self.n_splits_big, self.n_splits_coop, 1)
         if self.n_work:
             self.n_splits = max(w >> 16 for w in work[3::4])
         group.ensure_slabs(self.n_splits)
@@ -653,6 +672,10 @@ class DwPlan:
             L.check(L.load().osrl_mlp_backward_dw(self.d_entries.data_ptr(), self.d_items.data_ptr(), self.n_items,
                                                   self.rows, self.n_splits_small, g.slabs.data_ptr(), g.n, cur_stream()),
                     "osrl_mlp_backward_dw")
+        if self.n_coop:
+            L.check(L.load().osrl_mlp_backward_dw_coop(self.d_entries.data_ptr(), self.d_coop.data_ptr(), self.n_coop,
+                                                       self.rows, self.n_splits_coop, g.slabs.data_ptr(), g.n,
+                                                       cur_stream()), "osrl_mlp_backward_dw_coop")
         if self.n_big:
             L.check(L.load().osrl_mlp_backward_dw_big(self.d_entries.data_ptr(), self.d_big.data_ptr(), self.n_big,
                                                       self.rows, self.n_splits_big, g.slabs.data_ptr(), g.n,

@@ -884,6 +884,35 @@ def test_dw_big_rows_kernel(rows, out_f, in_f, force_big):
         assert np.abs(grp.grad_view(bk).cpu().numpy() - wb).max() <= 2e-5 * max(1.0, np.abs(wb).max()), bk
 
 
+@pytest.mark.parametrize("rows,out_f,in_f", [(16384, 512, 256), (8192 + 16 * 5, 256, 768), (40960, 256, 256)])
+def test_dw_workgroup_tile_kernel(rows, out_f, in_f):
+    """osrl_mlp_backward_dw_coop (one 8-wave workgroup per 256x256 tile and row split, operands shared through LDS) vs
+    fp64, next to a 384-wide layer that stays with the one-wave-per-tile kernel and a ragged one with the 64x64 tiles;
+    a row count that is not a multiple of 16 sends the same layer back to the one-wave-per-tile kernel."""
+    from osrl_amd.engine.core import DwPlan, FlatGroup
+    dev = _dev()
+    rs = np.random.RandomState(rows % 89)
+    grp = FlatGroup("t", dev)
+    for k, shp in (("a.w", (out_f, in_f)), ("a.b", (out_f,)), ("m.w", (384, 128)), ("m.b", (384,)), ("s.w", (40, 24)),
+                   ("s.b", (40,))):
+        grp.add(k, shp)
+    grp.finalize()
+    mk = lambda n: torch.tensor(rs.randn(rows, n), dtype=torch.float32, device=dev)  # noqa: E731
+    ents = [(mk(out_f), mk(in_f), "a.w", "a.b"), (mk(384), mk(128), "m.w", "m.b"), (mk(40), mk(24), "s.w", "s.b")]
+    plan = DwPlan(grp, ents, rows, dev)
+    assert plan.n_coop == (out_f // 256) * (in_f // 256) and plan.n_big == 3 * 2 and plan.n_items > 0
+    plan.launch()
+    torch.cuda.synchronize()
+    for (z, x, wk, bk) in ents:
+        want = z.cpu().numpy().astype(np.float64).T @ x.cpu().numpy().astype(np.float64)
+        got = grp.grad_view(wk).cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (wk, np.abs(got - want).max())
+        wb = z.cpu().numpy().astype(np.float64).sum(0)
+        assert np.abs(grp.grad_view(bk).cpu().numpy() - wb).max() <= 2e-5 * max(1.0, np.abs(wb).max()), bk
+    odd = DwPlan(grp, [(e[0][:rows - 3], e[1][:rows - 3]) + e[2:] for e in ents], rows - 3, dev)
+    assert odd.n_coop == 0 and odd.n_big == (out_f // 128) * (in_f // 64) + 6
+
+
 @pytest.mark.parametrize("rows,T,splits,target", [(2048, 5, 3, True), (2048, 4, None, True), (300, 4, 1, False),
                                                   (1000, 2, 4, True), (2048 + 37, 3, 2, False), (4096, 4, 12, True)])
 def test_dw_tiles_adam_one_launch_equals_dw_then_adam(rows, T, splits, target):

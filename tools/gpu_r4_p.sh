@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r4p; rm -rf $O; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_cdt.py -q -x -k "dw or cdt" > $O/t1.log 2>&1; grep -n "passed\|failed" $O/t1.log | tail -2
+for i in 1 2; do timeout 300 python bench.py --config c5 --no-extras --no-cpu-baseline --no-roofline --no-cold 2>>$O/bench.err | cut -c1-100; done
+OSRL_DW_COOP=0 timeout 300 python bench.py --config c5 --no-extras --no-cpu-baseline --no-roofline --no-cold 2>>$O/bench.err | cut -c1-100
