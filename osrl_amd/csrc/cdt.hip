@@ -142,6 +142,99 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedArgs a) {
   }
 }
 
+// The same for E = 256 / 512 (round 4): lanes own four consecutive features per 256-feature chunk (16-byte accesses of
+// seq / x0 / the timestep row), and the state / action embedding weights -- which the kernel above reads per element with
+// a lane stride of od floats, ~90 scattered dword loads per token: 109 us for the 81920 tokens of C5, bound by the
+// texture-address path -- are staged ONCE per workgroup, transposed ([input][feature]), into LDS; a workgroup walks many
+// tokens.  The products are added in the same order (bias first, inputs ascending): the pre-LayerNorm sequence is
+// bit-equal, the LayerNorm sums meet in a different order (as in ln_fwd_v4_kernel).
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_ln_v4_kernel(const EmbedArgs a, const int n_wg) {
+  constexpr int E = 256 * NCH;
+  extern __shared__ __attribute__((aligned(16))) float wt[];  // [od + ad][E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int idx = threadIdx.x; idx < (a.od + a.ad) * E; idx += 256) {
+    const int i = idx / E, f = idx - i * E;
+    wt[idx] = i < a.od ? a.Ws[(size_t)f * a.od + i] : a.Wa[(size_t)f * a.ad + (i - a.od)];
+  }
+  __syncthreads();
+  const int S_ = a.R * a.T + a.prefix, rows = a.B * S_;
+  f32x4 gg[NCH], bb[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    gg[c] = *reinterpret_cast<const f32x4*>(a.g + 4 * lane + 256 * c);
+    bb[c] = *reinterpret_cast<const f32x4*>(a.b + 4 * lane + 256 * c);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += n_wg * 4) {
+    const int b = row / S_, pos = row - b * S_;
+    const bool is_prefix = a.prefix && pos == 0;
+    const int tp = pos - a.prefix;
+    const int t = is_prefix ? 0 : tp / a.R, slot = is_prefix ? 0 : tp - t * a.R;
+    const int bt = b * a.T + t;
+    int which = slot + (4 - a.R);  // slot -> token kind (0 return, 1 cost, 2 state, 3 action)
+    if (a.R == 3 && a.use_rew) which = slot == 0 ? 0 : slot + 1;
+    const float* __restrict__ te = (a.te && !is_prefix) ? a.te + (size_t)a.time_steps[bt] * E : nullptr;
+    const float ret = a.use_rew ? a.returns[bt] : 0.f;
+    const float ctg = a.use_cost ? (a.cost_transform ? 50.0f - a.ctg[bt] : a.ctg[bt]) : 0.f;
+    if (!is_prefix && which == 1 && lane == 0) a.ctg_t[bt] = ctg;
+    const float ec = is_prefix ? a.episode_cost[b] : 0.f;
+    const size_t base = (size_t)row * E + 4 * lane;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int f0 = 4 * lane + 256 * c;
+      f32x4 x;
+      if (is_prefix || which < 2) {  // rank-1 embeddings: scalar * W[:, 0] + bias
+        const float sc = is_prefix ? ec : (which == 0 ? ret : ctg);
+        const float* W = is_prefix ? a.Wp : (which == 0 ? a.Wr : a.Wc);
+        const float* bv = is_prefix ? a.bp : (which == 0 ? a.br : a.bc);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + f0), b4 = *reinterpret_cast<const f32x4*>(bv + f0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = sc * w4[j] + b4[j];
+      } else {
+        const bool st = which == 2;
+        const int n_in = st ? a.od : a.ad;
+        const float* __restrict__ in = st ? a.states + (size_t)bt * a.od : a.actions + (size_t)bt * a.ad;
+        const float* __restrict__ w = wt + (size_t)(st ? 0 : a.od) * E + f0;
+        x = *reinterpret_cast<const f32x4*>((st ? a.bs : a.ba) + f0);
+        for (int i = 0; i < n_in; ++i) {
+          const float xi = in[i];
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + (size_t)i * E);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[j] += xi * w4[j];
+        }
+      }
+      if (te) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(te + f0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] += t4[j];
+      }
+      *reinterpret_cast<f32x4*>(a.seq + base + 256 * c) = x;
+      v[c] = x;
+      s += (x[0] + x[1]) + (x[2] + x[3]);
+    }
+    const float mean = wsum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q += (v[c][j] - mean) * (v[c][j] - mean);
+    const float rstd = 1.0f / sqrtf(wsum(q) / (float)E + kLnEps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * gg[c][j] + bb[c][j];
+      *reinterpret_cast<f32x4*>(a.x0 + base + 256 * c) = o;
+    }
+    if (lane == 0) {
+      a.stats[2 * row] = mean;
+      a.stats[2 * row + 1] = rstd;
+    }
+  }
+}
+
 // the dropout keep-multiplier of flat element i at a site (the mask of dropout_kernel: one Philox call per 4 consecutive
 // elements, word i & 3) -- for kernels whose lanes do not own 4 consecutive elements
 struct DropSite {
@@ -1210,6 +1303,23 @@ int osrl_cdt_embed_ln(const float* states, const float* actions, const float* re
               use_rew ? 1 : 0, use_cost ? 1 : 0};
   const int rows = B * (R * T + (prefix ? 1 : 0));
   CLEAR();
+  {  // E = 256 / 512, aligned tensors, the transposed state / action weights within 48 KB of LDS: the 16-byte form
+    const size_t wt_bytes = sizeof(float) * (size_t)(od + ad) * E;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(seq) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(bs) |
+                         reinterpret_cast<uintptr_t>(ba) | reinterpret_cast<uintptr_t>(Wc) | reinterpret_cast<uintptr_t>(bc) |
+                         reinterpret_cast<uintptr_t>(Wr) | reinterpret_cast<uintptr_t>(br) | reinterpret_cast<uintptr_t>(Wp) |
+                         reinterpret_cast<uintptr_t>(bp) | reinterpret_cast<uintptr_t>(timestep_emb) |
+                         reinterpret_cast<uintptr_t>(ln_g) | reinterpret_cast<uintptr_t>(ln_b);
+    if ((E == 256 || E == 512) && wt_bytes <= 48 * 1024 && (al & 15) == 0 && rows >= 4096) {
+      int n_wg = (rows + 3) / 4;
+      n_wg = n_wg > 2048 ? 2048 : n_wg;
+      if (E == 256)
+        hipLaunchKernelGGL(embed_ln_v4_kernel<1>, dim3(n_wg), dim3(256), wt_bytes, S, a, n_wg);
+      else
+        hipLaunchKernelGGL(embed_ln_v4_kernel<2>, dim3(n_wg), dim3(256), wt_bytes, S, a, n_wg);
+      DONE();
+    }
+  }
   hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, S, a);
   DONE();
 }

@@ -220,6 +220,42 @@ def test_layernorm_16_byte_kernels_equal_the_generic_ones():
         assert np.abs(sl0 - sl1).max() < 1e-4 * max(1, np.abs(sl1).max())
 
 
+@pytest.mark.parametrize("use_rew,use_cost,prefix,E", [(1, 1, 0, 256), (0, 1, 1, 256), (1, 0, 0, 512)])
+def test_embed_layernorm_16_byte_kernel_equals_the_generic_one(use_rew, use_cost, prefix, E):
+    """osrl_cdt_embed_ln at E = 256 / 512 and >= 4096 token rows takes the kernel that stages the transposed state / action
+    embedding weights in LDS and gives every lane four consecutive features; with `seq` 4 bytes off a 16-byte boundary the
+    same call takes the generic kernel.  The embedded sequence is bit-equal, the LayerNorm output agrees to rounding."""
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import cur_stream
+    lib = L.load()
+    rs = np.random.RandomState(11 + E)
+    B, T, od, ad = 72, 20, 11, 3
+    R = 2 + use_rew + use_cost
+    S = R * T + prefix
+    f = lambda *shape: t((rs.randn(*shape) * 0.5).astype(np.float32))  # noqa: E731
+    states, actions, returns, ctg, ec = f(B, T, od), f(B, T, ad), f(B, T), f(B, T), f(B)
+    ts = t(rs.randint(0, 50, size=(B, T)).astype(np.int64))
+    Ws, bs, Wa, ba, Wc, bc, Wr, br, Wp, bp = f(E, od), f(E), f(E, ad), f(E), f(E), f(E), f(E), f(E), f(E), f(E)
+    te, g, b = f(50, E), f(E), f(E)
+    outs = []
+    for off in (0, 1):
+        seq = torch.zeros(B * S * E + 4, device=DEV)[off:off + B * S * E]
+        x0, stats, ctg_t = torch.zeros(B * S * E, device=DEV), torch.zeros(B * S, 2, device=DEV), torch.zeros(B * T, device=DEV)
+        L.check(lib.osrl_cdt_embed_ln(states.data_ptr(), actions.data_ptr(), returns.data_ptr() if use_rew else None,
+                                      ctg.data_ptr() if use_cost else None, ec.data_ptr() if prefix else None,
+                                      ts.data_ptr(), Ws.data_ptr(), bs.data_ptr(), Wa.data_ptr(), ba.data_ptr(),
+                                      Wc.data_ptr() if use_cost else None, bc.data_ptr() if use_cost else None,
+                                      Wr.data_ptr() if use_rew else None, br.data_ptr() if use_rew else None,
+                                      Wp.data_ptr() if prefix else None, bp.data_ptr() if prefix else None, te.data_ptr(),
+                                      g.data_ptr(), b.data_ptr(), B, T, od, ad, E, 1, use_rew, use_cost, prefix,
+                                      seq.data_ptr(), x0.data_ptr(), stats.data_ptr(),
+                                      ctg_t.data_ptr() if use_cost else None, cur_stream()), "embed")
+        outs.append([v.clone().cpu().numpy() for v in (seq, x0, stats, ctg_t)])
+    (q0, x00, s0, c0), (q1, x01, s1, c1) = outs
+    assert np.array_equal(q0, q1) and np.array_equal(c0, c1) and np.abs(q0).max() > 0.1
+    assert np.abs(x00 - x01).max() < 5e-6 and np.abs(s0 - s1).max() < 5e-6 * max(1, np.abs(s1).max())
+
+
 def test_dropout_kernels():
     """osrl_dropout: keep-rate, scale, determinism in (seed, step, site), odd sizes / unaligned pointers; attention
     probability dropout forward + backward against numpy with the exported mask."""
