@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libosrl_amd.so")
-SOURCES = ["mlp.hip", "mlp_nb.hip", "mlp_dw.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "diag.hip"]
+SOURCES = ["mlp.hip", "mlp_nb.hip", "mlp_nb64.hip", "mlp_dw.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "diag.hip"]
 
 
 def _hipcc() -> str:
@@ -79,7 +79,9 @@ def _build_locked(verbose: bool, force: bool = False) -> str:
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
-        stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + common)
+        extra = [os.path.join(CSRC, "mlp_nb.hip")] if s == "mlp_nb64.hip" else []  # (it is that file, compiled again)
+        stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj)
+                                                       for d in [src] + extra + common)
         if stale:
             cmd = [hip] + FLAGS + ["-c", src, "-o", obj]
             if verbose:

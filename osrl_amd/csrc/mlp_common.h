@@ -199,3 +199,6 @@ constexpr size_t kLdsMax = 160 * 1024;
 // kl / kl_L: the OSRL_TAIL_VAE_KL tail (per-row KL of net 0's (mean | log_std) output), NULL = none
 __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream,
                                                              float* kl = nullptr, int kl_L = 0);
+// the same kernels on 64-row tiles (mlp_nb64.hip = mlp_nb.hip compiled with OSRL_NB_RB = 4)
+__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb64(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream,
+                                                             float* kl = nullptr, int kl_L = 0);

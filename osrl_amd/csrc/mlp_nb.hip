@@ -42,7 +42,16 @@ constexpr float kNbLsMin = -4.0f, kNbLsMax = 15.0f;  // net.py:325 (== kVaeLsMin
 #ifndef OSRL_NB_INTERLEAVE
 #define OSRL_NB_INTERLEAVE 1
 #endif
-constexpr int kNbRb = 5;  // row blocks per tile (80 rows)
+// Row blocks per tile: 5 (80 rows) here; mlp_nb64.hip compiles this file a second time with OSRL_NB_RB = 4 (64-row tiles:
+// the 67.6 KB activation tile of a 256-wide net then allows TWO workgroups per CU) and its own launcher name
+#ifndef OSRL_NB_RB
+#define OSRL_NB_RB 5
+#endif
+#ifndef OSRL_NB_LAUNCH
+#define OSRL_NB_LAUNCH osrl_launch_fwd_nb
+#endif
+constexpr int kNbRb = OSRL_NB_RB;
+constexpr int kNbRows = 16 * OSRL_NB_RB;
 
 // Biases of a wave's column blocks, branch-free (clamped address + select): every load is in flight at once.  The
 // obvious "col < N ? bias[col] : 0.f" compiles to one exec-masked global_load + s_waitcnt vmcnt(0) PER BLOCK, i.e.
@@ -529,11 +538,11 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   WG_LOG(1);
 }
 template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel(const NbArgs a) {
+__global__ __launch_bounds__(256, kNbRb == 4 ? 2 : 1) void mlp_fwd_nb_kernel(const NbArgs a) {
   mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&>(a);
 }
 template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_nb_kernel_p(const void* p) {
+__global__ __launch_bounds__(256, kNbRb == 4 ? 2 : 1) void mlp_fwd_nb_kernel_p(const void* p) {
   mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
 }
 // the 8-wave form (25-block layers): NCB - 1 = 3 column blocks per wave
@@ -576,10 +585,10 @@ static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hip
 
 }  // namespace
 
-__attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream,
+__attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, const osrl_rows_t* in, const osrl_mlp_acts_t* out, hipStream_t stream,
                                                              float* kl, int kl_L) {
   const int L = net->n_layers, nets = net->n_nets;
-  if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNbNotTaken;
+  if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNbNotTaken;  // (80 = "the big-row inference form")
   for (int e = 0; e < nets; ++e)
     for (int l = 0; l + 1 < L; ++l)
       if (out->h[e][l]) return kNbNotTaken;  // training launches keep hidden activations: mlp_fwd_kernel
@@ -595,8 +604,8 @@ __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* n
   if (NL > 32 || nkl < 4 || nkl > 32) return kNbNotTaken;  // narrow head, K split over 4 waves (<= 8 steps each)
   const int lda = ((wmax + 15) & ~15) + 8;
   if (lda < 4 * ((NL + 15) & ~15)) return kNbNotTaken;  // the head's 4 partial tiles live in the activation tile
-  size_t lds_bytes = (size_t)80 * lda * sizeof(float);
-  if (lds_bytes <= 80 * 1024) lds_bytes = 80 * 1024 + 256;  // more than half of the 160 KB: one workgroup per CU
+  size_t lds_bytes = (size_t)kNbRows * lda * sizeof(float);
+  if (kNbRb == 5 && lds_bytes <= 80 * 1024) lds_bytes = 80 * 1024 + 256;  // more than half of the 160 KB: one workgroup per CU
   if (lds_bytes > kLdsMax) return kNbNotTaken;
   NbArgs a{};
   a.net = *net;
@@ -605,7 +614,7 @@ __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* n
   a.lda = lda;
   a.kl = kl;
   a.kl_L = kl_L;
-  const int tiles = (in->rows + 79) / 80;
+  const int tiles = (in->rows + kNbRows - 1) / kNbRows;
   bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
   for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;
   // 8 waves for the 25-block layers (OSRL_NB_WAVES=4: the one-wave-per-SIMD form, for A/B runs); the head's 8 partial
@@ -626,11 +635,21 @@ __attribute__((visibility("hidden"))) int osrl_launch_fwd_nb(const osrl_mlp_t* n
     return (int)hipGetLastError();
   }
   if (ncb == 4 && lda >= 8 * ((NL + 15) & ~15)) {
-    // 8 waves from 512 tiles per net on (BCQ-Lag / BEAR-Lag at B = 4096, N = 10: C3 604 -> 621 steps/s); at CPQ's 256 tiles
-    // per net, launched beside the 2048-row chain kernels, the 4-wave form is the faster neighbour (C2 2256 vs 2211).
-    // OSRL_NB256_WAVES = 4 / 8 forces either (read per launch: A/B runs and a test flip it)
+    // 13..16-block (<= 256-wide) nets.  The 4-wave 80-row form runs ONE wave per SIMD (its 84.5 KB activation tile allows one
+    // workgroup per CU).  From 512 80-row tiles per net on (BCQ-Lag / BEAR-Lag at B = 4096, N = 10) the 64-row form of
+    // mlp_nb64.hip takes the launch: two 4-wave workgroups per CU with independent barriers -- C3 604 -> 639 steps/s (the
+    // 8-wave 80-row form below: 622).  At CPQ's 256 tiles per net, launched beside the 2048-row chain kernels, the 80-row
+    // 4-wave form is the faster neighbour (C2 2237 vs 2210 with 64-row tiles, 2211 with 8 waves).
+    // OSRL_NB64 = 0 / 1 and OSRL_NB256_WAVES = 4 / 8 force a form (read per launch: A/B runs and a test flip them)
     const char* w256 = getenv("OSRL_NB256_WAVES");
-    const bool eight = w256 && w256[0] ? atoi(w256) == 8 : tiles >= 512;
+    const bool eight = OSRL_NB_RB == 5 && w256 && atoi(w256) == 8;
+#if OSRL_NB_RB == 5
+    {
+      const char* e64 = getenv("OSRL_NB64");
+      const bool use64 = e64 && e64[0] ? atoi(e64) == 1 : (tiles >= 512 && !eight && !(w256 && atoi(w256) == 4));
+      if (use64) return osrl_launch_fwd_nb64(net, in, out, stream, kl, kl_L);
+    }
+#endif
     if (eight) {
       const void* dev_args = osrl_argmem::slot(a);
       hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb8n_kernel_p)

@@ -235,20 +235,24 @@ def test_mlp_fwd_big_rows(ci):
     src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
     src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
     outs = []
-    for tile_rows, waves in ((32, 0), (16, 0), (80, 0), (80, 4), (80, 8)):  # 80: one workgroup per CU (shapes the kernel does
+    for tile_rows, waves in ((32, 0), (16, 0), (80, 0), (80, 4), (80, 8), (80, 64)):  # 80: one workgroup per CU (shapes the kernel does
         # not take -- hidden layers of neither 13-16 nor 25-28 column blocks, wide last layer -- fall back to the default
         # tile); 25-block layers take its 8-wave form unless OSRL_NB_WAVES=4 asks for one wave per SIMD, 13-16-block
-        # layers take theirs from 512 tiles per net on or when OSRL_NB256_WAVES=8 asks for it
+        # layers take theirs when OSRL_NB256_WAVES=8 asks for it and the 64-row form (two workgroups per CU) from 512
+        # tiles per net on or when OSRL_NB64=1 asks for it
         desc = NetDesc(refs, acts, oscale)
         desc.c.tile_rows = tile_rows
         run = MlpRun(desc, rows, False, dev)
-        if waves:
+        if waves == 64:
+            os.environ["OSRL_NB64"] = "1"
+        elif waves:
             os.environ["OSRL_NB_WAVES"] = os.environ["OSRL_NB256_WAVES"] = str(waves)
         try:
             y = run.forward(src0, src1, map0=map0, div0=div0)
         finally:
             os.environ.pop("OSRL_NB_WAVES", None)
             os.environ.pop("OSRL_NB256_WAVES", None)
+            os.environ.pop("OSRL_NB64", None)
         torch.cuda.synchronize()
         outs.append(torch.stack([t.clone() for t in y]).cpu().numpy() if isinstance(y, (list, tuple)) else y.clone().cpu().numpy())
     idx0 = {0: np.arange(rows), 1: np.arange(rows) % div0, 2: np.arange(rows) // div0}[map0]
@@ -261,7 +265,7 @@ def test_mlp_fwd_big_rows(ci):
             h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
         h = h * oscale
         for nm, got in (("tile32", outs[0][e]), ("tile16", outs[1][e]), ("tile80", outs[2][e]), ("tile80w4", outs[3][e]),
-                        ("tile80w8", outs[4][e])):
+                        ("tile80w8", outs[4][e]), ("tile64", outs[5][e])):
             err = np.abs(got.reshape(h.shape) - h).max()
             assert err < 3e-5 * max(1.0, np.abs(h).max()), f"case {ci} {nm} kernel net {e}: max err {err}"
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
