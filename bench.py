@@ -369,66 +369,76 @@ def collectives_in_step(eng, dp, iters=30):
     return out
 
 
-def roofline(eng):
-    """Dominant kernels of the CPQ step: the two N*B-row forward launches (69% of the step's FLOPs).  Needs no trained
-    state (the in-step probe snapshots and restores the engine), so main() runs it BEFORE the timed region; ``step_frac``
-    is filled in afterwards."""
+def roofline(eng, cfg_name="c2"):
+    """Dominant kernels of the CPQ step: the two N*B-row forward launches (half of the step's issued FLOPs).  Needs no
+    trained state (the in-step probe snapshots and restores the engine), so main() runs it BEFORE the timed region;
+    ``step_frac`` is filled in afterwards.  The headline entry is the launch that takes the most time INSIDE the step (=
+    the top kernel of the rocprofv3 --kernel-trace --stats summary of this command under profiles/); both launches are
+    carried under ``kernels`` with their in-step and isolated figures, algorithmic bytes and counted HBM traffic."""
     from osrl_amd import _lib as L
     cands = {
         "mlp_fwd<vae-encoder, N*B rows>": (eng.r_enc_ood, lambda: eng.r_enc_ood.forward(
-            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B)),
+            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B), "enc_ood", "mlp_fwd_nb8_kernel_p"),
         "mlp_fwd<cost_critic_old x2, N*B rows>": (eng.r_costold_ood, lambda: eng.r_costold_ood.forward(
-            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B)),
+            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B), "costold_ood", "mlp_fwd_nb_kernel_p<4, false>"),
     }
     # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
     # issue out of step with its peers -- N > 1 reports the isolated figure only.  It goes first: its
     # step bodies leave a sampled minibatch and the N*B sampled actions in the buffers the isolated launches read
     sites = in_step_us(eng) if eng.dist is None else {}
-    mean_us, med_us = sites.get("enc_ood", (float("nan"), float("nan")))
     if eng.dist is not None:  # no step has run yet: time the launches on data, not on the zero-initialised buffers
         eng.obs.normal_()
         eng.sampled.normal_()
-    res = {}
-    for name, (run, fn) in cands.items():
-        t = time_kernel(fn)
-        res[name] = dict(seconds=t, flops=mlp_fwd_flops(run))
-    # dominant = the launch with the most algorithmic FLOPs (the VAE encoder on the N*B rows)
-    dom = max(res, key=lambda k: res[k]["flops"])
-    ach = res[dom]["flops"] / res[dom]["seconds"] / 1e12
-    # HBM bytes per launch come from hardware counters, which cannot be read from inside this process: the figure is the
-    # one a separate `rocprofv3 --pmc FETCH_SIZE WRITE_SIZE` pass of tools/gpu_pmc.sh measured for this kernel
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    # HBM bytes per launch come from hardware counters, which cannot be read from inside this process: the figures are the
+    # ones a separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` pass pair measured for THESE launches of THIS
+    # config (tools/pmc_nb.py under tools/gpu_r5_pmc.sh -> profiles/pmc_traffic.json, keyed by config)
+    pmc, traffic_src = {}, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc)).get(dom)
-            traffic_src = "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of " \
-                          "tools/gpu_pmc.sh, not measured in this run)"
+            js = json.load(open(pmc_path))
+            pmc = js.get(cfg_name, {}) if isinstance(js.get(cfg_name), dict) else {}
+            traffic_src = js.get("source", "static: profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE passes of tools/gpu_r5_pmc.sh; not measured in this run)")
         except Exception:
-            traffic = None
-    # headline `frac` / `achieved` = the launch AS IT RUNS INSIDE THE STEP (HIP events around it in the eagerly issued
-    # two-stream step body; the rocprofv3 average of the same kernel over graph replays is the cross-check under
-    # profiles/); `isolated_*` = the same launch alone on the device.  (Under data parallelism the in-step probe is not
-    # run -- its step bodies hold collectives -- and the isolated figure is reported, labelled.)
-    in_run = mean_us == mean_us
-    ach_run = res[dom]["flops"] / (mean_us * 1e-6) / 1e12 if in_run else ach
-    return {"bound": "mfma", "kernel": dom, "achieved": round(ach_run, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_run / PEAK_FP32_TFLOPS, 4),
-            "frac_is": "in-run (inside the step, beside the other branch's launches)" if in_run else "isolated (N > 1: no in-step probe)",
-            "isolated_achieved": round(ach, 3), "isolated_frac": round(ach / PEAK_FP32_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes": int(4 * (eng.r_enc_ood.rows * (eng.r_enc_ood.net.dims[0] + eng.r_enc_ood.net.dims[-1])
-                                          + lin(eng.r_enc_ood.net.dims) + sum(eng.r_enc_ood.net.dims[1:]))),
-            "in_step_sites_us": {k: round(v[0], 2) for k, v in sites.items()} or None,
-            "isolated_us": round(res[dom]["seconds"] * 1e6, 2),
-            "in_step_us": None if mean_us != mean_us else round(mean_us, 2),
-            "in_step_us_median": None if med_us != med_us else round(med_us, 2),
-            "in_step_frac": None if mean_us != mean_us else
-            round(res[dom]["flops"] / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
-            "step_frac": None,  # main(): algorithmic GFLOP per step / measured ms per step / peak
-            "kernels": {k: {"us": round(v["seconds"] * 1e6, 2), "tflops": round(v["flops"] / v["seconds"] / 1e12, 2),
-                            "wg_cap": int(cands[k][0].fwd_c.wg_cap)}
-                        for k, v in res.items()}}
+            pmc = {}
+    res = {}
+    for name, (run, fn, site, sym) in cands.items():
+        t = time_kernel(fn)
+        fl = mlp_fwd_flops(run)
+        mean_us, med_us = sites.get(site, (float("nan"), float("nan")))
+        in_run = mean_us == mean_us
+        d = run.net.dims
+        # algorithmic HBM bytes of the launch: its DISTINCT input rows (the N*B rows read observation r % B and sampled
+        # action r: B x obs_dim + N*B x act_dim floats), the weights + biases of every net once, the [rows, out] result
+        alg = 4 * (eng.B * eng.obs.shape[1] + run.rows * eng.sampled.shape[1] + run.net.E * (lin(d) + sum(d[1:]))
+                   + run.net.E * run.rows * d[-1])
+        res[name] = dict(symbol=sym, gflop=round(fl / 1e9, 3), isolated_us=round(t * 1e6, 2),
+                         isolated_frac=round(fl / t / 1e12 / PEAK_FP32_TFLOPS, 4),
+                         in_step_us=round(mean_us, 2) if in_run else None,
+                         in_step_us_median=round(med_us, 2) if in_run else None,
+                         in_step_frac=round(fl / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4) if in_run else None,
+                         algorithmic_bytes=int(alg), traffic=pmc.get(name), wg_cap=int(run.fwd_c.wg_cap), _fl=fl, _t=t,
+                         _us=mean_us)
+    have_run = all(v["in_step_us"] is not None for v in res.values())
+    # dominant = the launch that takes the most time inside the step (N > 1: the most FLOPs)
+    dom = max(res, key=(lambda k: res[k]["_us"]) if have_run else (lambda k: res[k]["_fl"]))
+    r = res[dom]
+    ach_iso = r["_fl"] / r["_t"] / 1e12
+    ach = r["_fl"] / (r["_us"] * 1e-6) / 1e12 if have_run else ach_iso
+    out = {"bound": "mfma", "kernel": dom, "symbol": r["symbol"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+           "frac_is": "in-run (inside the step, beside the other branch's launches); kernel = the launch with the largest "
+                      "in-step duration" if have_run else "isolated (N > 1: no in-step probe)",
+           "isolated_achieved": round(ach_iso, 3), "isolated_frac": round(ach_iso / PEAK_FP32_TFLOPS, 4),
+           "traffic": r["traffic"], "traffic_source": traffic_src if r["traffic"] is not None else None,
+           "algorithmic_bytes": r["algorithmic_bytes"],
+           "in_step_sites_us": {k: round(v[0], 2) for k, v in sites.items()} or None,
+           "isolated_us": r["isolated_us"], "in_step_us": r["in_step_us"], "in_step_us_median": r["in_step_us_median"],
+           "in_step_frac": r["in_step_frac"],
+           "step_frac": None,  # main(): algorithmic GFLOP per step / measured ms per step / peak
+           "kernels": {k: {kk: vv for kk, vv in v.items() if not kk.startswith("_")} for k, v in res.items()}}
+    return out
 
 
 def cpu_baseline(budget_s=24.0):
@@ -507,29 +517,42 @@ def cpu_baseline(budget_s=24.0):
                       f"{rate(probe[('torch', min(cands))]):.2f} steps/s"}
 
 
-def cpu_baseline_others(which=("c1", "c3", "c5")):
-    """CPU figures for the other BASELINE configs (SURVEY.md 8d's timing plan): the numpy oracle of each algorithm on the
-    config's shapes, at 4 BLAS threads (the reference's default, *_configs.py `threads`) and at the host's full pool.
-    Bounded samples: c1 ~1.5 s per setting; c3 >= 3 steps; c5 on a 128-sample slice of the 1024-sample batch (the loss is a
-    sum over samples; the figure is divided by 8) -- a reported baseline beside the GPU numbers, not a target."""
+def cpu_baseline_others(which=("c1", "c3", "c4", "c5")):
+    """CPU figures for the other BASELINE configs (SURVEY.md 8d's timing plan: "the build's own plain-PyTorch restatement"
+    on the host cores): the torch CPU + autograd + torch.optim restatement of each algorithm (oracle/torch_cpu_baselines.py
+    for BC / BCQ-Lag / CDT, oracle/torch_cpq_cpu.py for C4's CPQ; each pinned to the reference's golden vectors by
+    tests/test_oracle_golden.py) on the config's shapes, at 4 threads (the reference's default, *_configs.py ``threads``)
+    and at a wide pool, plus the numpy oracle at 4 BLAS threads.  Bounded samples: c1 ~1 s per setting; c3 / c4 >= 3
+    steps; c5 on a 128-sample slice of the 1024-sample batch with dropout 0.1 active (the loss is a sum over samples; the
+    figure is divided by 8) -- reported baselines beside the GPU numbers, not targets."""
     import dataclasses
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from cases import Case, make_batch, make_cdt_batch, make_noise
+    from cases import Case, hyper, make_batch, make_cdt_batch, make_cdt_params, make_noise, make_params
+    from oracle.torch_cpq_cpu import TorchCPQ
+    from oracle.torch_cpu_baselines import TorchBC, TorchBCQL, TorchCDT
     from oracle_util import build_oracle
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
     ncpu = os.cpu_count() or 1
-    wide = min(ncpu, 64)
+    wide = min(ncpu, 16)  # C2's probe (cpu_baseline) finds the torch optimum at 8-16 threads on the 256-cpu hosts
 
-    def at(nthreads, fn):
+    def at_blas(nthreads, fn):
         ctx = threadpool_limits(limits=nthreads, user_api="blas") if threadpool_limits else None
         try:
             return fn()
         finally:
             if ctx is not None:
                 ctx.unregister() if hasattr(ctx, "unregister") else ctx.__exit__(None, None, None)
+
+    def at_torch(nthreads, fn):
+        keep = torch.get_num_threads()
+        torch.set_num_threads(nthreads)
+        try:
+            return fn()
+        finally:
+            torch.set_num_threads(keep)
 
     def rate(step, min_steps, budget):
         step()
@@ -551,38 +574,108 @@ def cpu_baseline_others(which=("c1", "c3", "c5")):
     for name in which:
         try:
             cfg = CONFIGS[name]
+            np_step = None
             if cfg["algo"] == "cdt":
                 from test_gpu_cdt import C5_FULL
                 from test_oracle_cdt_golden import build_cdt_oracle
-                c = dataclasses.replace(C5_FULL, B=128, dropout=0.0)
-                o = build_cdt_oracle(c, np.float32)
+                c = dataclasses.replace(C5_FULL, B=128)
+                t = TorchCDT(make_cdt_params(c), seq_len=c.T, num_heads=c.heads, num_layers=c.layers,
+                             cost_transform=c.cost_transform, stochastic=c.stochastic, init_temperature=0.1,
+                             target_entropy=-c.ad, learning_rate=c.lr, weight_decay=c.wd, clip_grad=c.clip,
+                             lr_warmup_steps=c.warmup, loss_cost_weight=c.cost_w, loss_state_weight=c.state_w, dropout=0.1)
                 b = make_cdt_batch(c)
                 a = (b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
                      b["episode_cost"], b["costs"])
-                step, scale, mins, budget = (lambda: o.train_one_step(*a)), 128.0 / cfg["B"], 2, 0.0
-                what = f"CDT oracle (oracle/cdt_oracle.py, fp32) on a 128-sample slice of the {cfg['B']}-sample batch, x 1/8"
+                step, scale, mins, budget = (lambda: t.train_one_step(*a)), 128.0 / cfg["B"], 2, 0.0
+                o = build_cdt_oracle(dataclasses.replace(c, dropout=0.0), np.float32)
+                np_step = lambda: o.train_one_step(*a)  # noqa: E731
+                what = (f"torch restatement of CDT (oracle/torch_cpu_baselines.py TorchCDT, dropout 0.1) on a 128-sample slice "
+                        f"of the {cfg['B']}-sample batch, x 1/8")
             else:
                 c = Case("bench_" + name, cfg["algo"], od=cfg["od"], ad=cfg["ad"], B=cfg["B"], hidden=HID, vae_hidden=VAE_H,
                          N=NS, steps=1, episode_len=cfg["episode_len"])
-                o = build_oracle(c)
-                b = make_batch(c)
+                hp, b, o = hyper(c), make_batch(c), build_oracle(c)
+                scale = 1.0
                 if cfg["algo"] == "bc":
-                    step, mins, budget = (lambda: o.train_one_step(b["observations"], b["actions"])), 20, 1.5
+                    t = TorchBC(make_params(c), c.max_action, hp["actor_lr"])
+                    step, mins, budget = (lambda: t.train_one_step(b["observations"], b["actions"])), 20, 1.0
+                    np_step = lambda: o.train_one_step(b["observations"], b["actions"])  # noqa: E731
                 else:
                     nz = make_noise(c, 0)
-                    step = lambda: o.train_one_step(b["observations"], b["next_observations"], b["actions"],  # noqa: E731
-                                                    b["rewards"], b["costs"], b["done"], nz)
-                    mins, budget = 3, 0.0
-                scale = 1.0
-                what = f"numpy oracle (oracle/osrl_oracle.py) of {cfg['algo']} at ({cfg['od']}, {cfg['ad']}) B={cfg['B']}"
-            n4, d4 = at(min(4, ncpu), lambda: rate(step, mins, budget))
-            nw, dw = at(wide, lambda: rate(step, mins, budget)) if wide > 4 else (n4, d4)
+                    args_ = (b["observations"], b["next_observations"], b["actions"], b["rewards"], b["costs"], b["done"], nz)
+                    if cfg["algo"] == "cpq":
+                        t = TorchCPQ(make_params(c), max_action=c.max_action, sample_action_num=c.N, gamma=hp["gamma"],
+                                     tau=hp["tau"], beta=hp["beta"], qc_scalar=hp["qc_scalar"], cost_limit=c.cost_limit,
+                                     episode_len=c.episode_len, actor_lr=hp["actor_lr"], critic_lr=hp["critic_lr"],
+                                     alpha_lr=hp["alpha_lr"], vae_lr=hp["vae_lr"])
+                    else:
+                        t = TorchBCQL(make_params(c), max_action=c.max_action, sample_action_num=c.N, gamma=hp["gamma"],
+                                      tau=hp["tau"], phi=hp["phi"], lmbda=hp["lmbda"], beta=hp["beta"], PID_gains=hp["PID"],
+                                      cost_limit=c.cost_limit, episode_len=c.episode_len, actor_lr=hp["actor_lr"],
+                                      critic_lr=hp["critic_lr"], vae_lr=hp["vae_lr"])
+                    step, mins, budget = (lambda: t.train_one_step(*args_)), 3, 1.0
+                    np_step = lambda: o.train_one_step(*args_)  # noqa: E731
+                what = (f"torch restatement of {cfg['algo']} (oracle/torch_c{'pq_cpu' if cfg['algo'] == 'cpq' else 'pu_baselines'}.py) "
+                        f"at ({cfg['od']}, {cfg['ad']}) B={cfg['B']}")
+            n4, d4 = at_torch(min(4, ncpu), lambda: rate(step, mins, budget))
+            nw, dw = at_torch(wide, lambda: rate(step, mins, budget)) if wide > 4 else (n4, d4)
             r4, rw = n4 / d4 * scale, nw / dw * scale
+            variants = {"torch@4": round(r4, 4), f"torch@{wide}": round(rw, 4)}
+            if np_step is not None:
+                nn_, dn = at_blas(min(4, ncpu), lambda: rate(np_step, 2 if cfg["algo"] != "bc" else 20, 0.0))
+                variants["numpy_oracle@4"] = round(nn_ / dn * scale, 4)
             best_threads = wide if rw >= r4 else min(4, ncpu)
             out[name] = {"value": round(max(r4, rw), 4), "unit": "grad-steps/s", "cores": int(best_threads), "kind": "port",
-                         "at_4_threads": round(r4, 4), f"at_{wide}_threads": round(rw, 4),
-                         "sample": f"{what}: {n4} steps in {d4:.1f}s at 4 BLAS threads, {nw} in {dw:.1f}s at {wide} "
-                                   f"(host: {ncpu} cpus)"}
+                         "variants": variants,
+                         "sample": f"{what}: {n4} steps in {d4:.1f}s at 4 threads (the reference's default), {nw} in "
+                                   f"{dw:.1f}s at {wide} (host: {ncpu} cpus)"}
+        except Exception as e:  # a failing side measurement must not take the headline line down
+            out[name] = {"error": repr(e)[:200]}
+    return out
+
+
+def cost_return_gap(device) -> dict:
+    """BASELINE.json's metric, second half: "(+ cost-return gap vs ref)".  After the timed region: the small CPQ / BCQ-Lag /
+    BC cases of tests/cases.py are TRAINED through the HIP path (case.steps = 10 gradient steps on the seeded batch with
+    the seeded noise -- the steps the train-step goldens pin) and evaluated with the batched on-device ``evaluate()`` on
+    the synthetic safe env; the reference side is tests/golden/eval_rollouts_trained.npz = the REFERENCE models trained
+    by the reference's own train_one_step on the same inputs and rolled out by the reference's own rollout()
+    (cpq.py:294-347; generated by tests/golden/make_golden_eval_trained.py, data only).  Reported per algorithm: mean
+    episode return / cost on both sides and the worst per-episode gap over the 12 seeded episodes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import CASES
+    from gpu_util import build_gpu, gpu_batch, gpu_step
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    from osrl_amd.engine.rollout import BatchedRollout
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eval_rollouts_trained.npz"), allow_pickle=False)
+    E, EL, cost_scale = 12, 25, 2.0  # tests/golden/make_golden_eval.py EVAL
+    out = {"what": "per-episode |gpu - reference| after case.steps train steps on both sides; 12 seeded episodes x 25 "
+                   "steps of the synthetic safe env; reference = tests/golden/eval_rollouts_trained.npz"}
+    for name in ("cpq_small", "bcql_small", "bc_small"):
+        try:
+            c = CASES[name]
+            m, tr, _ = build_gpu(c, device=str(device), use_graph=True)
+            b = gpu_batch(c, device=str(device))
+            for s_ in range(c.steps):
+                gpu_step(tr, c, b, s_)
+            m.episode_len = EL
+            cs = cost_scale if c.algo != "bc" else 1.0
+            tr.cost_scale = cs
+            env = SyntheticSafeEnv(c.od, c.ad, 50, seed=1, init_noise=0.7)
+            venv = VecSyntheticSafeEnv(env, E, device, base_seed=100)
+            tr.env = venv
+            if c.algo == "bcql":
+                rets, costs, lens = BatchedRollout(m, venv, "bcql", cs, z=torch.tensor(g[name + "_z"], device=device)).run()
+            else:
+                tr.evaluate(E)
+                rets, costs, lens = tr._rollout[1].run()
+            ref = g[name]
+            out[name] = {"train_steps": int(c.steps),
+                         "return_gpu": round(float(np.mean(rets)), 5), "return_ref": round(float(ref[:, 0].mean()), 5),
+                         "cost_gpu": round(float(np.mean(costs)), 5), "cost_ref": round(float(ref[:, 1].mean()), 5),
+                         "return_gap_max_rel": float(f"{np.max(np.abs(rets - ref[:, 0]) / np.maximum(1.0, np.abs(ref[:, 0]))):.3e}"),
+                         "cost_gap_max": round(float(np.max(np.abs(costs - ref[:, 1]))), 5),
+                         "lengths_equal": bool(np.array_equal(lens, ref[:, 2]))}
         except Exception as e:  # a failing side measurement must not take the headline line down
             out[name] = {"error": repr(e)[:200]}
     return out
@@ -660,7 +753,7 @@ def main():
     roof = None
     if not args.no_roofline and cfg["algo"] == "cpq":
         try:
-            roof = roofline(eng)
+            roof = roofline(eng, args.config)
         except Exception as e:  # a failing probe must not take the headline line down
             roof = {"error": repr(e)[:300]}
             torch.cuda.synchronize()
@@ -759,7 +852,12 @@ def main():
             "config": {"workload": cfg["desc"] + "; on-device minibatch sampling from a HBM-resident synthetic store + "
                                                  "Philox noise inside the step",
                        "name": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "graph": bool(getattr(eng, "graph", None) is not None)},
+                       "graph": bool(getattr(eng, "graph", None) is not None),
+                       # both timing protocols where a reader of the driver's record sees them: `value` is
+                       # measured behind `preroll_ms` of untimed GEMM work, `no_preroll_value` is the same W + K steps
+                       # timed first, straight after the probes
+                       "timing": {"preroll_ms": round(pre_ms, 1),
+                                  "no_preroll_value": None if dt_cold is None else round(world * args.steps / dt_cold, 2)}},
             "optimizer_steps_per_s": round(args.steps / dt, 2),
             "preroll_ms": round(pre_ms, 1),  # untimed GEMM work queued before the W warm-up steps (see preroll())
             # the same W + K steps timed FIRST, without the pre-roll (rounds 1-3's protocol: the device's power state is
@@ -794,6 +892,12 @@ def main():
             del wl, eng
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(args.config, device)
+        if world == 1 and not force_dp and not args.no_extras:
+            gap = out["cost_return_gap"] = cost_return_gap(device)
+            # the metric's second half, compact, where the driver's record keeps it (config is carried over verbatim)
+            out["config"]["cost_return_gap_vs_ref"] = {
+                k: {"return_gap_max_rel": v.get("return_gap_max_rel"), "cost_gap_max": v.get("cost_gap_max")}
+                for k, v in gap.items() if isinstance(v, dict)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if args.config == "c2":

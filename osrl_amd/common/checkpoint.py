@@ -32,6 +32,10 @@ _SCALARS = ("log_alpha", "pid_state", "log_temperature", "scalar_leaves")
 def engine_handoff(model, new_engine, old_engine) -> None:
     """The train-step count (Adam bias correction, LR warm-up, Philox offsets) and CDT's temperature moments
     belong to the MODEL's training state, not to one batch size's launch plan: hand them to a rebuilt engine."""
+    # the engine's dW plans are complete here: record the slab epochs they were built against NOW, not at the engine's
+    # first step -- an engine built, not stepped, and then superseded must be flagged stale (ADVICE r4)
+    from ..engine.core import slab_epochs
+    new_engine._slab_epochs = slab_epochs(model)
     if old_engine is not None:
         step = old_engine.st.device_step()
     else:

@@ -2016,7 +2016,9 @@ static int mlp_forward2_impl(const osrl_mlp_t* net0, const osrl_rows_t* in0, con
   if (!fwd_tail_ok(tail0, net0) || !fwd_tail_ok(tail1, net1)) return -1;
   TileChoice t0 = choose_tile(net0, in0->rows, 0), t1 = choose_tile(net1, in1->rows, 0);
   // pair only 16-row-tile launches of equal tile shape; anything else runs as two launches
-  const bool pair = t0.nrb == 1 && t1.nrb == 1 && t0.ncb == t1.ncb && t0.nw == t1.nw &&
+  // a KL tail exists on the single-launch path only (80-row kernel or a follow-up osrl_vae_kl_rows launch)
+  const bool kl_tail = (tail0 && tail0->kind == OSRL_TAIL_VAE_KL) || (tail1 && tail1->kind == OSRL_TAIL_VAE_KL);
+  const bool pair = !kl_tail && t0.nrb == 1 && t1.nrb == 1 && t0.ncb == t1.ncb && t0.nw == t1.nw &&
                     ((t0.nw == 8 && (t0.ncb == 2 || t0.ncb == 4)) || (t0.nw == 4 && (t0.ncb == 4 || t0.ncb == 7)));
   if (!pair) {
     const int rc = mlp_forward_impl(net0, in0, out0, tail0, stream);

@@ -14,6 +14,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The in-launch exchanges of this library (seed statistics in mlp.hip, slab tiles in mlp_dwt_adam_body, the one-launch BC
+// step's arrival counter) publish device-coherent words as: relaxed agent-scope stores (sc1) -> `s_waitcnt vmcnt(0)`
+// (asm volatile with a memory clobber: neither the compiler nor the wave moves the arrival atomic above it) -> relaxed
+// agent-scope fetch_add; readers: barrier -> relaxed agent-scope loads.  That is a release/acquire on gfx942/gfx950
+// because sc1 stores are tracked by vmcnt and complete at the memory side; a target with a separate store counter
+// (vscnt) would need `s_waitcnt_vscnt` there.  Pin the family instead of hoping:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "osrl_amd's in-launch exchanges assume gfx950 memory counters (sc1 stores tracked by vmcnt): build with --offload-arch=gfx950"
+#endif
+
 #ifdef OSRL_PHASE_TIMING  // tools/mlp_phase.hip: per-phase cycle stamps of workgroup 0 (debug builds only)
 __device__ long long g_phase_t[4][64];
 __device__ long long g_phase_all[8192][4][16];  // every workgroup (first 8192), for phase averages

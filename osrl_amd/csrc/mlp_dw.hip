@@ -714,13 +714,10 @@ extern "C" int osrl_mlp_backward_dw_coop(const osrl_dw_entry_t* d_entries, const
   int rps = (rows + n_splits - 1) / n_splits;
   rps = (rps + 15) & ~15;  // whole 16-row k-steps
   constexpr int kLds = sizeof(float) * kCoS * 2 * 16 * 256;  // 128 KB: one workgroup (two waves per SIMD) per CU
-  static bool set = false;
-  if (!set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_coop_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    if (e != hipSuccess) return (int)e;
-    set = true;
-  }
+  // per device and stateless, like every sibling launcher: the attribute belongs to the CURRENT device
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_coop_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  if (e != hipSuccess) return (int)e;
   (void)hipGetLastError();
   hipLaunchKernelGGL(mlp_dw_coop_kernel, dim3(n_items, n_splits, 1), dim3(512), kLds, (hipStream_t)stream, d_entries,
                      d_items, n_items, rows, rps, slabs, slab_stride);

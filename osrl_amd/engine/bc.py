@@ -127,6 +127,7 @@ class BCEngine:
         self._arena_direct = None
 
     def _run(self, use_graph: bool) -> None:
+        check_plans_current(self)  # (also before the replay of an already captured graph)
         if use_graph and self.dist is None and self.one_launch and self.direct:
             if self._arena_direct is None:  # this step records the launch's descriptor; the later ones read it from HBM
                 arena = ArgArena(self.st.state.device, capacity=1 << 14)

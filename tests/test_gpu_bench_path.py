@@ -1,0 +1,94 @@
+"""Oracle check of the EXACT entry point ``bench.py`` times.
+
+The timed call of the bench is ``Workload.step()`` = ``engine.step_replay(use_graph=True)``: a replayed hipGraph whose
+first launch draws the minibatch from the HBM-resident store and the step's Gaussian noise from the device Philox stream
+(reference: TransitionDataset.__prepare_sample + DataLoader, osrl/common/dataset.py:832-847, feeding
+CPQTrainer.train_one_step osrl/algorithms/cpq.py:294-313 / BCQLTrainer.train_one_step bcql.py:283-306).  The other parity
+tests drive ``train_one_step`` with caller batches and injected noise; here nothing is injected: after every REPLAYED step
+the six gathered batch tensors and the noise buffer the step consumed are read back and handed to the pinned oracle, which
+starts from the bench model's own initial parameters.  Gates: statistics <= 1e-4, Adam first moments (= the gradients) at
+``GROUP_GATE`` of each tensor's scale (or the absolute kink floor, counted), ``log_alpha`` / PID state.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle.osrl_oracle import OracleBCQL, OracleCPQ  # noqa: E402
+from test_gpu_train_step import GROUP_GATE, KINK_FLOOR, _note  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+BATCH = ("obs", "nobs", "act", "rew", "cost", "done")
+
+
+def _oracle(wl, dtype):
+    """The oracle twin of the bench's model: same initial parameters, the hyper-parameters bench.Workload passes."""
+    cfg, m = wl.cfg, wl.model
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    if cfg["algo"] == "cpq":
+        return OracleCPQ(sd, max_action=1.0, sample_action_num=10, gamma=0.99, tau=0.005, beta=0.5, qc_scalar=1.5,
+                         cost_limit=10, episode_len=cfg["episode_len"], actor_lr=1e-4, critic_lr=1e-3, alpha_lr=1e-4,
+                         vae_lr=1e-3, dtype=dtype)
+    return OracleBCQL(sd, max_action=1.0, sample_action_num=10, gamma=0.99, tau=0.005, phi=0.05, lmbda=0.75, beta=0.5,
+                      PID_gains=(0.1, 0.003, 0.001), cost_limit=10, episode_len=cfg["episode_len"], actor_lr=1e-3,
+                      critic_lr=1e-3, vae_lr=1e-3, dtype=dtype)
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4"])
+def test_bench_path_matches_oracle(name):
+    import bench
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload(name, dev, 0, 1, None, n_store=1 << 16, use_graph=True)
+    eng, m = wl.eng, wl.model
+    o64, o32 = _oracle(wl, np.float64), _oracle(wl, np.float32)
+    groups = {"actor": "opt_actor", "critic": "opt_critic", "cost_critic": "opt_cost", "vae": "opt_vae"}
+    store_obs = wl.store.tables[0] if hasattr(wl.store, "tables") else None
+    n_steps = 3 if name != "c3" else 2
+    prev = None
+    for s in range(n_steps):
+        wl.step()  # == the bench's timed call
+        torch.cuda.synchronize()
+        assert eng.graph is not None, "the bench path must be the captured graph"
+        batch = [getattr(eng, k).detach().cpu().numpy().copy() for k in BATCH]
+        noise = {k: v.detach().cpu().numpy().copy() for k, v in eng.noise.items()}
+        # a replayed step draws a NEW minibatch and NEW noise every time (tick inside the graph)
+        if prev is not None:
+            assert not np.array_equal(prev[0], batch[0]) and not np.array_equal(prev[1], noise["eps_vae"])
+        prev = (batch[0], noise["eps_vae"])
+        assert all(np.isfinite(x).all() for x in batch) and abs(float(noise["eps_vae"].std()) - 1.0) < 0.05
+        if store_obs is not None and s == 0:  # the gathered observations are rows of the store
+            rows = {r.tobytes() for r in store_obs.detach().cpu().numpy()}
+            assert all(r.tobytes() in rows for r in batch[0][:64])
+        st64 = o64.train_one_step(*batch, noise)
+        o32.train_one_step(*batch, noise)
+        got = eng.st.read_stats()
+        for k, r in st64.items():
+            assert abs(got[k] - r) <= 1e-4 * max(1.0, abs(r)), f"{name} replayed step {s + 1} {k}: gpu {got[k]} vs oracle {r}"
+        n_floor, worst = {}, {}
+        for gname, oname in groups.items():
+            grp = m.groups[gname]
+            for k, mo in getattr(o64, oname).m.items():
+                mg = grp._view(grp.m, k).cpu().numpy()
+                m32 = getattr(o32, oname).m[k]
+                scale = max(np.abs(mo).max(), 1e-12)
+                el = np.minimum(np.abs(mg - mo), np.abs(mg - m32))
+                d = el.max()
+                worst[gname] = max(worst.get(gname, 0.0), d / scale)
+                n_floor[gname] = n_floor.get(gname, 0) + int((el > GROUP_GATE * scale).sum())
+                # later steps start from parameters that already differ by fp32 round-off: the floor scales with them
+                assert d <= max(GROUP_GATE * scale, KINK_FLOOR) * (s + 1), \
+                    f"{name} replayed step {s + 1} first moment {k} ({gname}): {d:.3e} vs scale {scale:.3e}"
+        _note(f"bench path {name} step {s + 1}: first-moment diff / scale " +
+              ", ".join(f"{g}={v:.2e}" for g, v in worst.items()) + "; needed the kink floor: " +
+              ", ".join(f"{g}={v}" for g, v in n_floor.items()))
+        if wl.cfg["algo"] == "cpq":
+            assert abs(m.log_alpha.item() - o64.log_alpha) < 1e-5
+        else:
+            assert abs(m.controller.error_old - o64.controller.error_old) < 1e-4
+            assert abs(m.controller.error_integral - o64.controller.error_integral) < 1e-4
+    assert eng.st.device_step() == n_steps

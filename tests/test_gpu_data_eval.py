@@ -458,6 +458,41 @@ def test_evaluate_cost_return_gap_vs_reference(name):
     _check_gap(name, rets, costs, lens, g[name])
 
 
+@pytest.mark.parametrize("name", ["bc_small", "cpq_small", "bcql_small"])
+def test_trained_cost_return_gap_vs_reference(name):
+    """The metric's second half AFTER training: ``case.steps`` train steps through the HIP path (seeded batch + injected
+    noise = the steps the train-step goldens pin), then the batched on-device evaluate(), against rollouts of the
+    REFERENCE models trained by the reference's own train_one_step on the same inputs and rolled out by the reference's
+    own rollout() (tests/golden/make_golden_eval_trained.py; cpq.py:294-347)."""
+    from gpu_util import gpu_batch, gpu_step
+    from oracle_util import load_golden
+    from osrl_amd.common.synthetic_env import SyntheticSafeEnv, VecSyntheticSafeEnv
+    from osrl_amd.engine.rollout import BatchedRollout
+    g = load_golden("eval_rollouts_trained")
+    c = CASES[name]
+    m, tr, lg = build_gpu(c, use_graph=True)
+    b = gpu_batch(c)
+    assert int(g[name + "_steps"]) == c.steps
+    for s in range(c.steps):
+        gpu_step(tr, c, b, s)
+    E, EL = EVAL["episodes"], EVAL["episode_len"]
+    m.episode_len = EL
+    cs = EVAL["cost_scale"] if c.algo != "bc" else 1.0
+    tr.cost_scale = cs
+    env = SyntheticSafeEnv(c.od, c.ad, 50, seed=EVAL["env_seed"], init_noise=EVAL["init_noise"])
+    venv = VecSyntheticSafeEnv(env, E, DEV, base_seed=EVAL["base_seed"])
+    tr.env = venv
+    if c.algo == "bcql":
+        rets, costs, lens = BatchedRollout(m, venv, "bcql", cs, z=torch.tensor(g[name + "_z"], device=DEV)).run()
+    else:
+        tr.evaluate(E)
+        rets, costs, lens = tr._rollout[1].run()
+    _check_gap(name + " (trained)", rets, costs, lens, g[name])
+    # ... and the training moved the policy: the untrained fixture is a different set of episodes
+    g0 = load_golden("eval_rollouts")
+    assert np.abs(g0[name][:, 0] - g[name][:, 0]).max() > 1e-3
+
+
 def test_cdt_evaluate_cost_return_gap_vs_reference():
     from oracle_util import load_golden
     from osrl_amd.algorithms import CDT, CDTTrainer

@@ -977,3 +977,49 @@ def test_dw_tiles_adam_one_launch_equals_dw_then_adam(rows, T, splits, target):
             x, y = getattr(ga, n), getattr(gb, n)
             assert torch.equal(x, y), (step, n, float((x - y).abs().max()))
     assert float((ga.p - p0).abs().max()) > 1e-3  # the steps moved the parameters
+
+
+@pytest.mark.parametrize("rows,od,ad,hid", [(48, 7, 3, 40), (2048, 76, 2, 400)])
+def test_forward2_with_a_kl_tail_writes_the_kl_rows(rows, od, ad, hid):
+    """osrl_mlp_forward2_tail with an OSRL_TAIL_VAE_KL tail on one problem (the paired kernel does not act on
+    that tail kind -- the call must take the two-launch path and still write ``tail->out``) == the encoder forward
+    followed by osrl_vae_kl_rows, bit for bit; the partner problem's result is untouched by the choice."""
+    from osrl_amd.engine import glue as G
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
+    dev = _dev()
+    rs = np.random.RandomState(rows + ad)
+    Lz = 2 * ad
+
+    def mk(dims, acts, name):
+        grp = FlatGroup(name, dev)
+        for l in range(len(dims) - 1):
+            grp.add(f"{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{l}.w")
+            grp.add(f"{l}.b", (dims[l + 1],))
+        grp.finalize()
+        rr = []
+        for l in range(len(dims) - 1):
+            W, b = grp.view(f"{l}.w"), grp.view(f"{l}.b")
+            W.copy_(torch.tensor(rs.uniform(-0.2, 0.2, W.shape), dtype=torch.float32))
+            b.copy_(torch.tensor(rs.uniform(-0.2, 0.2, b.shape), dtype=torch.float32))
+            rr.append(LayerRef(W, b, grp, f"{l}.w", f"{l}.b"))
+        grp.repack()
+        return grp, NetDesc([rr], acts, 1.0)
+
+    _, enc = mk([od + ad, hid, hid, 2 * Lz], ["relu", "relu", "id"], "enc")
+    _, dec = mk([od + Lz, hid, hid, ad], ["relu", "relu", "tanh"], "dec")  # same tile shape as enc: a pairable partner
+    obs, act, z = torch.randn(rows, od, device=dev), torch.rand(rows, ad, device=dev) * 2 - 1, torch.randn(rows, Lz, device=dev)
+    r_e0, r_d0 = MlpRun(enc, rows, False, dev), MlpRun(dec, rows, False, dev)
+    r_e1, r_d1 = MlpRun(enc, rows, False, dev), MlpRun(dec, rows, False, dev)
+    kl0, kl1 = torch.full((rows,), 7.0, device=dev), torch.full((rows,), -7.0, device=dev)
+    h0, u0 = r_e0.forward_with((obs, act), r_d0, (obs, z))
+    G.vae_kl_rows(h0[0], rows, Lz, kl0)
+    h1, u1 = r_e1.forward_with((obs, act), r_d1, (obs, z), tail=G.vae_kl_tail(Lz, kl1))
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and torch.equal(u0, u1)
+    assert torch.equal(kl0, kl1), "the KL tail of a paired forward was not applied"
+    # the tail on the SECOND problem of the pair
+    kl2 = torch.full((rows,), 3.0, device=dev)
+    r_d1.forward_with((obs, z), r_e1, (obs, act), other_tail=G.vae_kl_tail(Lz, kl2))
+    torch.cuda.synchronize()
+    assert torch.equal(kl0, kl2)

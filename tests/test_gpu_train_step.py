@@ -93,6 +93,8 @@ def _note(msg: str) -> None:
             f.write(msg + "\n")
 
 
+_C2_ACTOR_FLOOR = {}  # case name -> elements of the actor group that needed the kink floor (filled by the test below)
+
 FULL_CASES = {
     # BASELINE.json C2 / C3 shapes at their full batch sizes: no reference golden (the fixtures stay small), the
     # pinned oracle is the checker.  These are the only parity runs that reach the N*B-row launches (32-row tiles,
@@ -101,6 +103,9 @@ FULL_CASES = {
     # a second seed of C2: the loose actor / critic-head gates of cpq_c2_full are claimed to be a property of THAT
     # seed's gradient (a heavily cancelling batch sum), not of the kernels -- this one takes the tight gate everywhere
     "cpq_c2_full_s2": dict(algo="cpq", od=76, ad=2, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=31),
+    # a third seed: on seed 21 about half of the actor group's elements pass only through the absolute
+    # kink floor; test_c2_actor_gradient_needs_no_floor_on_two_of_three_seeds requires that to be the exception
+    "cpq_c2_full_s3": dict(algo="cpq", od=76, ad=2, B=2048, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=41),
     "bcql_c3_full": dict(algo="bcql", od=33, ad=8, B=4096, hidden=[256, 256], vae_hidden=400, N=10, steps=1, seed=22),
     # BASELINE.json C4 per-GPU shape: CPQ on OfflineHalfCheetah dims (17, 6) -> latent 12, VAE inputs 23 / 29 wide,
     # q inputs 23 wide: other paddings / column-block splits than C2 (cpq_configs.py:359 task)
@@ -167,6 +172,8 @@ def test_full_size_train_step_matches_oracle(name):
     # heavily cancelling batch sum of scale 1e-5, so 2e-5 of scale is 2e-10 and half its elements sit between that and
     # the 1e-7 floor; critic 93; cost critic and VAE 0).  Gated coarsely: a kernel defect large enough to hide under the
     # floor moves the MAJORITY of a group there, or shows in a group that needs no floor at all today.
+    if name.startswith("cpq_c2_full"):
+        _C2_ACTOR_FLOOR[name] = n_floor.get("actor", 0)
     for gname, cnt in n_floor.items():
         total = sum(int(np.prod(v.shape)) for v in opts[gname].m.values())
         limit = 0.6 * total if gname == "actor" else max(256, total // 200)
@@ -179,6 +186,19 @@ def test_full_size_train_step_matches_oracle(name):
         assert np.median(d) <= 2e-6, f"{name} final param {k}: median diff {np.median(d):.3e}"
     if c.algo in ("cpq", "bearl"):
         assert abs(m.log_alpha.item() - o.log_alpha) < 1e-5
+
+
+def test_c2_actor_gradient_needs_no_floor_on_two_of_three_seeds():
+    """C2's actor gradient at initialisation is a heavily cancelling batch sum (scale ~1e-5): on ONE seed half of its
+    elements sit between 2e-5 of that scale and the 1e-7 absolute floor.  That must stay the exception -- at least two
+    of the three C2 seeds verify the whole actor group at the RELATIVE gate (zero elements through the floor)."""
+    seeds = [k for k in FULL_CASES if k.startswith("cpq_c2_full")]
+    if any(k not in _C2_ACTOR_FLOOR for k in seeds):
+        pytest.skip("needs the three cpq_c2_full* cases of test_full_size_train_step_matches_oracle in this session")
+    clean = [k for k in seeds if _C2_ACTOR_FLOOR[k] == 0]
+    _note("C2 actor group, elements through the kink floor per seed: " +
+          ", ".join(f"{k}={_C2_ACTOR_FLOOR[k]}" for k in seeds))
+    assert len(clean) >= 2, _C2_ACTOR_FLOOR
 
 
 def test_state_dict_roundtrip_and_keys():

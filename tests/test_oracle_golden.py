@@ -160,3 +160,57 @@ def test_torch_cpu_baseline_matches_numpy_oracle():
     for k, v in o.p.items():
         d = float(np.abs(v - t.p[k].detach().numpy()).max())
         assert d <= 2e-5 * max(1.0, float(np.abs(v).max())), (k, d)
+
+
+@pytest.mark.parametrize("name", ["bc_small", "bcql_small", "bcql_pid", "cdt_small", "cdt_det", "cdt_mid"])
+def test_torch_cpu_baselines_match_reference_goldens(name):
+    """oracle/torch_cpu_baselines.py (bench.py's torch-on-CPU baselines for C1 / C3 / C5: autograd + torch.optim) pinned
+    DIRECTLY to the vectors captured from the reference: every step's logged statistics and the parameters at the
+    snapshot steps -- so what bench.py times as "the reference's CPU path" of those configs computes the reference's step
+    (bc.py:103-109, bcql.py:283-306, cdt.py:343-418)."""
+    import torch
+    from cases import CASES, CDT_CASES, hyper, make_batch, make_cdt_batch, make_cdt_params, make_noise, make_params
+    from oracle.torch_cpu_baselines import TorchBC, TorchBCQL, TorchCDT
+    from oracle_util import load_golden
+    torch.manual_seed(0)
+    g = load_golden(name)
+    keys = [str(k) for k in g["stat_keys"]]
+    if name.startswith("cdt"):
+        c = CDT_CASES[name]
+        t = TorchCDT(make_cdt_params(c), seq_len=c.T, num_heads=c.heads, num_layers=c.layers,
+                     cost_transform=c.cost_transform, stochastic=c.stochastic, init_temperature=0.1, target_entropy=-c.ad,
+                     learning_rate=c.lr, weight_decay=c.wd, clip_grad=c.clip, lr_warmup_steps=c.warmup,
+                     loss_cost_weight=c.cost_w, loss_state_weight=c.state_w)
+        b = make_cdt_batch(c)
+        step = lambda s: t.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"],  # noqa: E731
+                                          b["mask"], b["episode_cost"], b["costs"])
+    else:
+        c = CASES[name]
+        hp = hyper(c)
+        b = make_batch(c)
+        if c.algo == "bc":
+            t = TorchBC(make_params(c), c.max_action, hp["actor_lr"])
+            step = lambda s: t.train_one_step(b["observations"], b["actions"])  # noqa: E731
+        else:
+            t = TorchBCQL(make_params(c), max_action=c.max_action, sample_action_num=c.N, gamma=hp["gamma"], tau=hp["tau"],
+                          phi=hp["phi"], lmbda=hp["lmbda"], beta=hp["beta"], PID_gains=hp["PID"], cost_limit=c.cost_limit,
+                          episode_len=c.episode_len, actor_lr=hp["actor_lr"], critic_lr=hp["critic_lr"], vae_lr=hp["vae_lr"])
+            step = lambda s: t.train_one_step(b["observations"], b["next_observations"], b["actions"], b["rewards"],  # noqa: E731
+                                              b["costs"], b["done"], make_noise(c, s))
+    for s in range(c.steps):
+        st = step(s)
+        ref = dict(zip(keys, g["stats"][s]))
+        tol = 1e-5 if s == 0 else 1e-4
+        for k in keys:
+            assert abs(st[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (name, s, k, st[k], ref[k])
+        if f"s{s + 1}/log_temperature" in g:
+            assert abs(t.log_temperature.item() - float(g[f"s{s + 1}/log_temperature"])) < 1e-6
+        if f"s{s + 1}/pid_error_old" in g:
+            assert abs(t.error_old - float(g[f"s{s + 1}/pid_error_old"])) < 1e-5
+            assert abs(t.error_integral - float(g[f"s{s + 1}/pid_error_integral"])) < 1e-5
+        for k, v in t.p.items():
+            a = v.detach().numpy()
+            if f"p{s + 1}/{k}" in g:
+                np.testing.assert_allclose(a, g[f"p{s + 1}/{k}"], rtol=0, atol=2e-5, err_msg=f"{name} step {s + 1} {k}")
+            elif f"p{s + 1}/smp/{k}" in g:
+                np.testing.assert_allclose(a.reshape(-1)[::97], g[f"p{s + 1}/smp/{k}"], rtol=0, atol=2e-5)
