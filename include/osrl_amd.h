@@ -281,6 +281,47 @@ typedef struct {
 } osrl_mlp_step_t;
 int osrl_mlp_regress_step(const osrl_mlp_step_t* s, void* stream);
 
+/* ---- the VAE's forward and backward on the training rows as ALL-CU layer launches (vae_ns.hip, round 5) -------------
+ * VAE.forward + the reconstruction / KL loss + its autograd through decoder and encoder (osrl/common/net.py:290-339,
+ * osrl/algorithms/cpq.py:125-135 == bcql.py:122-133 == bearl.py vae_loss): the same results in the same buffers as
+ *   osrl_mlp_forward_tail(enc, VAE_LATENT) -> osrl_mlp_forward(dec) -> osrl_mlp_backward_dz_seed(dec, MSE + KL statistic,
+ *   VAE_LATENT_BWD tail) -> osrl_mlp_backward_dz(enc)
+ * (statistic and gradients equal up to fp32 summation order), launched differently: at 2048 rows a fused 16-row-tile
+ * launch of a 400-wide net occupies 128 of the 256 CUs and spends most of its time walking the 400 x 400 layer; here
+ * every H x H layer is one launch of [48 rows x 80 columns] output tiles over ALL CUs (4 waves split K, operands
+ * requested k-steps ahead, partial tiles meet in LDS), the narrow first layers are one launch for both nets, and the
+ * narrow heads / the latent's dX ride as split-K partial rows ("slabs", one per 80-column group) in the epilogue of the
+ * wide launch that produces their input and are summed by the prologue of the launch that consumes them:
+ *   forward : l0 (enc layer 0 | the observation part of dec layer 0) -> enc wide (+ head slabs) -> dec wide (prologue:
+ *             head = sum slabs, z = mean + sd eps, h0 = relu(P + Wz z + b); + output slabs)
+ *   backward: dec wide^T (prologue: u = max_action tanh(sum slabs), dY of the MSE, dZ2, the logged loss; A operand =
+ *             (dZ2 W2) * relu'(h1); epilogue: dZ0 = . * relu'(h0), + dL/dz slabs) -> enc wide^T (prologue: dL/d(mean |
+ *             log_std) through z and the KL term)
+ * Requirements (osrl_vae_ns_supported; else callers keep the fused launches): both nets [in, H, H, out] with relu, relu,
+ * (id | tanh); H % 80 == 0, 80 <= H <= 448; obs + act <= 128 and obs + L <= 128 columns; L <= 16; act <= 16.
+ * HOST struct; every pointer is device memory.  enc / dec: n_nets 1, n_layers 3 (the descriptors of the fused launches). */
+typedef struct {
+  const osrl_mlp_t* enc;     /* [od + ad, H, H, 2 L]  relu, relu, id   (mean | log_std) */
+  const osrl_mlp_t* dec;     /* [od + L,  H, H, ad]   relu, relu, tanh, out_scale = max_action */
+  int32_t rows, od, ad, L;
+  int32_t rows_global;       /* the loss is a mean over this many rows (<= 0: rows) */
+  float beta;                /* KL weight (cpq.py:129) */
+  const float *obs, *act, *eps; /* [rows, od], [rows, ad], [rows, L] */
+  osrl_mlp_acts_t enc_acts;  /* out: x [rows, od + ad], h[0][0..1] [rows, H], h[0][2] = head [rows, 2 L] */
+  osrl_mlp_acts_t dec_acts;  /* out: x [rows, od + L],  h[0][0..1] [rows, H], h[0][2] = u [rows, ad] */
+  float* z;                  /* out [rows, L] */
+  osrl_mlp_grads_t enc_g;    /* out: dz[0][0..2] (backward) */
+  osrl_mlp_grads_t dec_g;    /* out: dz[0][0..2] (backward) */
+  float* P;                  /* scratch [rows, H] */
+  float* slabs;              /* scratch 3 * (H / 80) * rows * 32 floats */
+  float* partials;           /* scratch 2 * ceil(rows / 48) floats: per-tile partials of the logged loss */
+  uint32_t* counter;         /* one word, ZERO before the first launch (re-armed by the launch) */
+  float* stat;               /* out: loss_vae = mse + beta * kl (cpq.py:127-129) */
+} osrl_vae_ns_t;
+int osrl_vae_ns_supported(const osrl_vae_ns_t* v);   /* 1 / 0; no launch */
+int osrl_vae_ns_forward(const osrl_vae_ns_t* v, void* stream);
+int osrl_vae_ns_backward(const osrl_vae_ns_t* v, void* stream);
+
 /* General linear layer on packed weights: Y[M,N] = A[M,K] * P (+ bias[N]) (+ resid[M,N]).  P is the forward
  * pack of W[N,K] (y = x W^T; Np = round16(N), col0 = 0) or the backward pack of W[N',K'] for dx = dy W
  * (then K = N', N = K' or a column slice starting at col0, Np = round16(K')+16).  K <= 1024; N is

@@ -70,6 +70,14 @@ class SeedT(C.Structure):  # osrl_mlp_seed_t
 SEED_NONE, SEED_MSE, SEED_CPQ_CRITIC, SEED_CPQ_COST, SEED_CPQ_ACTOR, SEED_GAUSS_HEAD, SEED_BCQ_CRITIC = 0, 1, 2, 3, 4, 5, 6
 
 
+class VaeNsT(C.Structure):  # osrl_vae_ns_t
+    _fields_ = [("enc", C.POINTER(MlpT)), ("dec", C.POINTER(MlpT)), ("rows", C.c_int32), ("od", C.c_int32),
+                ("ad", C.c_int32), ("L", C.c_int32), ("rows_global", C.c_int32), ("beta", C.c_float),
+                ("obs", _fp), ("act", _fp), ("eps", _fp), ("enc_acts", ActsT), ("dec_acts", ActsT), ("z", _fp),
+                ("enc_g", GradsT), ("dec_g", GradsT), ("P", _fp), ("slabs", _fp), ("partials", _fp),
+                ("counter", C.c_void_p), ("stat", _fp)]
+
+
 class DwEntryT(C.Structure):
     _fields_ = [("dz", _fp), ("a", _fp), ("w_off", C.c_int64), ("b_off", C.c_int64),
                 ("out", C.c_int32), ("in_", C.c_int32), ("ldz", C.c_int32), ("lda", C.c_int32)]
@@ -168,6 +176,9 @@ PROTOTYPES = {
     "osrl_start_index_prob": [_vp, _vp, _vp, _i32, C.c_double, _vp, _vp, _vp],
     "osrl_bc_select": [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "osrl_gather_rows": [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp],
+    "osrl_vae_ns_supported": [_P(VaeNsT)],
+    "osrl_vae_ns_forward": [_P(VaeNsT), _vp],
+    "osrl_vae_ns_backward": [_P(VaeNsT), _vp],
     "osrl_mlp_forward2": [_P(MlpT), _P(RowsT), _P(ActsT), _P(MlpT), _P(RowsT), _P(ActsT), _vp],
     "osrl_mlp_backward_dz": [_P(MlpT), _i32, _P(ActsT), _P(GradsT), _vp],
     "osrl_mlp_forward_tail": [_P(MlpT), _P(RowsT), _P(ActsT), _P(TailT), _vp],

@@ -121,6 +121,12 @@ class BCQLEngine:
                                           self.rows_global, G.SeedStat(dev, 2 * nqc, B),
                                           self.st.stat_ptr("loss/cost_critic_loss")),
             }
+        # round 5: the VAE phase as all-CU layer launches where the library takes the shape (glue.VaeNs, engine/cpq.py)
+        self.vae_ns = None
+        ns_mode = os.environ.get("OSRL_VAE_NS", "auto")
+        if self.seeds is not None and (ns_mode == "1" or (ns_mode == "auto" and G.VAE_NS_AUTO and G.vae_ns_auto(B, m.state_dim, m.action_dim))):
+            self.vae_ns = G.VaeNs.build(self.r_enc, self.r_dec, self.obs, self.act, self.noise["eps_vae"], self.z,
+                                        m.latent_dim, m.beta, self.rows_global, self.st.stat_ptr("loss/loss_vae"))
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
 
@@ -160,16 +166,23 @@ class BCQLEngine:
         for k in ("z_c", "z_cc", "z_actor"):  # net.py:334-335 clamps the latent draw
             G.clamp_(nz[k], -0.5, 0.5)
 
-        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
-        u = self.r_dec.forward(self.obs, self.z)[0]
         sd = self.seeds
-        if sd is not None:
+        if self.vae_ns is not None:
+            self.vae_ns.forward()
+            self.vae_ns.backward()
+        else:
+            head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
+            u = self.r_dec.forward(self.obs, self.z)[0]
+        if self.vae_ns is not None:
+            pass
+        elif sd is not None:
             self.r_dec.backward_dz(tail=G.vae_latent_bwd_tail(head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc),
                                    seed=sd["vae"])
         else:
             G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"), ws=self.ws_vae)
             G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
-        self.r_enc.backward_dz()
+        if self.vae_ns is None:
+            self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
         # round 3 (profiles/r3_bcql_timeline.txt): both branches are linear chains from here (a side branch forked BEFORE
         # the VAE phase, to run the online forwards beside it, made the graph executor put both 950 us target pipelines

@@ -170,6 +170,15 @@ class CPQEngine:
                 "head": G.seed_gauss_head(self.noise["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, m.max_action),
             }
 
+        # round 5: the VAE phase's forward / backward as all-CU layer launches (csrc/vae_ns.hip, glue.VaeNs) where the
+        # library takes the shape; OSRL_VAE_NS: "0" the four fused launches, "1" force, "auto" by measurement (DESIGN_LOG
+        # round 5)
+        self.vae_ns = None
+        ns_mode = os.environ.get("OSRL_VAE_NS", "auto")
+        if self.seeds is not None and (ns_mode == "1" or (ns_mode == "auto" and G.VAE_NS_AUTO and G.vae_ns_auto(B, od, ad))):
+            self.vae_ns = G.VaeNs.build(self.r_enc, self.r_dec, self.obs, self.act, self.noise["eps_vae"], self.z, Lz,
+                                        m.beta, rg, st.stat_ptr("loss/loss_vae"))
+
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
         self.parallel_branches = True
@@ -233,16 +242,24 @@ class CPQEngine:
                     self.seed, device_noise)
         par.fork(0)
         # ---- main: vae_loss  (cpq.py:125-135)
-        head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
-        u = self.r_dec.forward(self.obs, self.z)[0]
         sd = self.seeds
-        if sd is not None:  # reconstruction gradient + the logged loss by the decoder's backward launch itself
+        if self.vae_ns is not None:  # five all-CU layer launches instead of the four fused ones (same buffers)
+            self.vae_ns.forward()
+            self.vae_ns.backward()
+            head = self.r_enc.y[0]
+        else:
+            head = G.vae_encode(self.r_enc, self.obs, self.act, nz["eps_vae"], Lz, self.z)
+            u = self.r_dec.forward(self.obs, self.z)[0]
+        if self.vae_ns is not None:
+            pass
+        elif sd is not None:  # reconstruction gradient + the logged loss by the decoder's backward launch itself
             self.r_dec.backward_dz(tail=G.vae_latent_bwd_tail(head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc),
                                    seed=sd["vae"])
         else:
             G.vae_loss(u, self.act, head, B, ad, Lz, m.beta, rg, self.du, st.stat_ptr("loss/loss_vae"))
             G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
-        self.r_enc.backward_dz()
+        if self.vae_ns is None:
+            self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
         ev_vae = torch.cuda.Event() if par.enabled else None
         if ev_vae is not None:

@@ -5,6 +5,7 @@ asynchronous launch on the current stream.  No arithmetic happens in Python.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Optional
 
@@ -95,6 +96,59 @@ def vae_decoder_backward(r_dec, head, eps, Lz, beta, rows_global, dhead):
         return
     r_dec.backward_dz()
     vae_latent_bwd(head, eps, r_dec.dx, r_dec.rows, Lz, beta, rows_global, dhead)
+
+
+VAE_NS_AUTO = True  # OSRL_VAE_NS=auto: the all-CU VAE launches where vae_ns_auto() says the measurements favour them
+
+
+def vae_ns_auto(rows: int, od: int, ad: int) -> bool:
+    """Where the five all-CU launches beat the four fused ones INSIDE the step (A/B on MI355X, DESIGN_LOG round 5,
+    gpurun_out/r5a): C4's (17, 6) at 2048 rows +4.5 %; C2's (76, 2) at 2048 rows +0.2 % (noise); C3's (33, 8) at 4096 rows
+    -3.6 % (two rounds of 48-row tiles against one round of 256 fused 16-row tiles).  The rule below is those three
+    points, not a model: one round of tiles (<= 2048 rows) and a first layer of <= 48 input columns (three k-steps)."""
+    return 1024 <= rows <= 2048 and od + ad <= 48
+
+
+class VaeNs:
+    """The VAE phase's forward + backward as all-CU layer launches (csrc/vae_ns.hip, ``osrl_vae_ns_forward`` /
+    ``osrl_vae_ns_backward``): the same buffers the four fused launches fill -- the encoder's / decoder's saved
+    activations, ``z``, every dZ the dW plan reads, the logged ``loss_vae`` -- so everything behind it (dW, Adam) is
+    unchanged.  ``r_enc`` / ``r_dec``: the training-row MlpRuns with their backward already set up.
+    ``VaeNs.build`` returns None where the library does not take the shape (hidden width % 80, <= 448, ...)."""
+
+    def __init__(self, r_enc, r_dec, obs, act, eps, z, Lz, beta, rows_global, stat):
+        import torch
+        dev, rows, H = obs.device, r_enc.rows, r_enc.net.dims[1]
+        v = self.c = L.VaeNsT()
+        v.enc, v.dec = C.pointer(r_enc.net.c), C.pointer(r_dec.net.c)
+        v.rows, v.od, v.ad, v.L = rows, obs.shape[1], act.shape[1], int(Lz)
+        v.rows_global, v.beta = int(rows_global), float(beta)
+        v.obs, v.act, v.eps = _p(obs), _p(act), _p(eps)
+        v.enc_acts, v.dec_acts, v.z = r_enc.acts_c, r_dec.acts_c, _p(z)
+        v.enc_g, v.dec_g = r_enc.grads_c, r_dec.grads_c
+        f = dict(dtype=torch.float32, device=dev)
+        self.P = torch.zeros(rows, H, **f)
+        self.slabs = torch.zeros(3 * (H // 80) * rows * 32, **f)
+        self.partials = torch.zeros(2 * ((rows + 47) // 48), **f)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        v.P, v.slabs, v.partials, v.counter, v.stat = _p(self.P), _p(self.slabs), _p(self.partials), \
+            self.counter.data_ptr(), _p(stat)
+        self._keep = (r_enc, r_dec, obs, act, eps, z)
+
+    @staticmethod
+    def build(r_enc, r_dec, obs, act, eps, z, Lz, beta, rows_global, stat):
+        if r_enc.grads_c is None or r_dec.grads_c is None or r_enc.net.E != 1 or r_dec.net.E != 1 or r_enc.net.nl != 3:
+            return None
+        if r_enc.net.dims[1] % 80 or r_enc.net.dims[1] > 448:
+            return None
+        ns = VaeNs(r_enc, r_dec, obs, act, eps, z, Lz, beta, rows_global, stat)
+        return ns if L.load().osrl_vae_ns_supported(C.byref(ns.c)) == 1 else None
+
+    def forward(self) -> None:
+        L.check(L.load().osrl_vae_ns_forward(C.byref(self.c), cur_stream()), "osrl_vae_ns_forward")
+
+    def backward(self) -> None:
+        L.check(L.load().osrl_vae_ns_backward(C.byref(self.c), cur_stream()), "osrl_vae_ns_backward")
 
 
 def loss_ws(device):

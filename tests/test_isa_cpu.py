@@ -25,7 +25,7 @@ def listings(tmp_path_factory):
     from isa_loads import scan
     d = tmp_path_factory.mktemp("isa")
     procs = {}
-    for name in ("glue", "optim", "mlp", "mlp_nb"):
+    for name in ("glue", "optim", "mlp", "mlp_nb", "vae_ns"):
         out = str(d / f"{name}.s")
         cmd = [HIPCC] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "osrl_amd", "csrc", f"{name}.hip"), "-o", out]
         procs[name] = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), out)
@@ -105,3 +105,19 @@ def test_one_launch_step_kernel_fits_its_registers(listings):
         for r in (a, b):
             assert 0 < r["vgprs"] <= 256, (inst, r)
         assert abs(a["vgprs"] - b["vgprs"]) <= 16, (inst, a["vgprs"], b["vgprs"])
+
+
+def test_vae_ns_kernels_fit_beside_the_nb_launch(listings):
+    """csrc/vae_ns.hip: the wide launches run beside the N*B-row launch of the other graph branch (one 197-register wave
+    per SIMD, 84 KB of LDS), so one wave per SIMD of theirs has to fit in 512 - 200 = 312 registers -- a kernel that
+    grows past it does not fail, it WAITS for CUs to retire (round 3 measured 12 us of work taking 84-88 us that way).
+    Held here for the instances the CPQ plan launches (the <*, 2> forms belong to 4096-row / wide-latent shapes that the
+    auto rule does not pick); no scratch anywhere; the descriptor-in-memory twins the same shape."""
+    t = listings["vae_ns"]
+    for needle in ("fwd_enc_kernelILi1E", "gen_kernelILi0ELi1E", "gen_kernelILi1ELi1E", "gen_kernelILi2ELi1E",
+                   "gen_kernelILi2ELi2E"):
+        a, b = _one(t, "vae_ns_" + needle), _one(t, "vae_ns_" + needle.replace("kernelI", "kernel_pI"))
+        for r in (a, b):
+            assert r["scratch"] == 0 and 0 < r["vgprs"] <= 312, (needle, r)
+    for k, r in t.items():
+        assert r["scratch"] == 0, (k, r)

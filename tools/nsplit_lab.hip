@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64 * KS, 1) void gemm_ns(const GArgs a) {
 #pragma unroll
     for (int c = 0; c < CB; ++c)
       bf[j][c] = *reinterpret_cast<const f32x4*>(a.P + ((size_t)(ks * 4 + kq) * a.Np + col0 + c * 16 + m) * 4);
+    __builtin_amdgcn_sched_barrier(0);  // requests leave in k-step order: the MFMAs of step j wait for steps <= j only
   }
   f32x4 acc[RB][CB];
 #pragma unroll
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(64 * KS, 1) void gemm_ns(const GArgs a) {
     for (int c = 0; c < CB; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NKW; ++j) {
+    __builtin_amdgcn_sched_barrier(0);
     if (j < cnt) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -109,6 +111,10 @@ __global__ __launch_bounds__(64 * KS, 1) void gemm_ns(const GArgs a) {
       *reinterpret_cast<f32x4*>(a.Y + (size_t)gr * a.N + col0 + 4 * c4) = o;
     }
   }
+}
+
+__global__ void null_kernel(const GArgs a) {
+  if (a.rows < 0) a.Y[0] = 0.f;
 }
 
 template <class K>
@@ -177,6 +183,8 @@ int main() {
     GArgs a{dX, dP, db, dY, rows, K, N, Kp, Np, 0, 0};
     printf("y[%d, %d] = relu(x[%d, %d] W^T + b): %.1f MFLOP, MFMA floor on 256 CUs %.2f us\n", rows, N, rows, K,
            2.0 * rows * K * N * 1e-6, 2.0 * rows * K * N / 157.3e6);
+    if (shape == 0) printf("  empty kernel, 240 wg x 256 thr, same back-to-back launch loop: %.2f us\n",
+                           time_k(null_kernel, dim3(240), 256, 0, a, 100));
     if (shape == 0) {
       run<3, 5, 4, 7, true>("48x80 KS4 xcd", a, hX, hW, hb);
       run<3, 5, 4, 7, false>("48x80 KS4", a, hX, hW, hb);
@@ -184,8 +192,6 @@ int main() {
       run<2, 5, 4, 7, true>("32x80 KS4 xcd", a, hX, hW, hb);
       run<2, 5, 8, 4, true>("32x80 KS8 xcd", a, hX, hW, hb);
       run<4, 5, 4, 7, true>("64x80 KS4 xcd", a, hX, hW, hb);
-      run<4, 5, 8, 4, true>("64x80 KS8 xcd", a, hX, hW, hb);
-      run<2, 5, 2, 13, true>("32x80 KS2 xcd", a, hX, hW, hb);
     } else if (shape == 1) {
       run<3, 4, 4, 4, true>("48x64 KS4 xcd", a, hX, hW, hb);
       run<2, 4, 4, 4, true>("32x64 KS4 xcd", a, hX, hW, hb);
