@@ -319,7 +319,7 @@ def in_step_us(eng, iters=40):
     {site: (mean us, median us)}; "enc_ood" is the dominant one.  The rocprofv3 --kernel-trace --stats summary of this
     command (profiles/) lists the same kernels' averages over graph replays."""
     from osrl_amd.engine.core import Branches
-    par = Branches(True, 1)
+    par = Branches(True, 2 if eng.dist is not None else 1)
     mk = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))  # noqa: E731
     evs = [{k: mk() for k in PROBE_SITES} for _ in range(iters)]
     snap = eng._snapshot()
@@ -346,7 +346,7 @@ def collectives_in_step(eng, dp, iters=30):
     order -- 4 entries for CPQ: VAE gradient, [critic | cost-critic] gradients, KL all-gather, [actor | statistics |
     qc_ood] -- whose sum against ms_per_step is the step's exposed communication."""
     from osrl_amd.engine.core import Branches
-    par = Branches(True, 1)
+    par = Branches(True, 2 if eng.dist is not None else 1)
     snap = eng._snapshot()
     recs = []
     try:

@@ -9,6 +9,7 @@ from typing import Optional
 import torch
 
 from .. import _lib as L
+from . import plan as _plan
 from ..common.net import net_desc_seq
 from . import glue as G
 from .core import ArgArena, DwPlan, MlpRun, StepState, capture_step, cur_stream, load_into, check_plans_current
@@ -37,7 +38,7 @@ class BCEngine:
         # gather -> forward -> MSE -> backward -> dW -> Adam -> tick as one launch (include/osrl_amd.h
         # osrl_mlp_regress_step): single device, one row split per dW tile (no gradient slabs to sum), a work list and
         # a row-tile count that fit the resident grid; the library has the last word (OSRL_E_UNSUPPORTED -> the plan)
-        self.one_launch = (os.environ.get("OSRL_BC_ONE_LAUNCH", "1") == "1" and dist is None and self.plan.tile_blocks == 4
+        self.one_launch = (_plan.knob("OSRL_BC_ONE_LAUNCH", "1", "the BC step as one launch") == "1" and dist is None and self.plan.tile_blocks == 4
                            and self.plan.n_splits == 1 and 0 < self.plan.n_work <= L.STEP_MAX_WG
                            and B <= 16 * L.STEP_MAX_WG)
         self.step_ws = torch.zeros(L.STEP_WS, **f) if self.one_launch else None
@@ -48,7 +49,7 @@ class BCEngine:
         # launch itself costs 39.2 (tools/bc_eager_vs_graph.py).  Its descriptor still lives in HBM (ArgArena:
         # recorded by the first step, looked up by the later ones), so a box that keeps kernel arguments in host
         # memory does not fetch 3 KB per wave over PCIe.  OSRL_BC_DIRECT=0: capture it like every other step.
-        self.direct = os.environ.get("OSRL_BC_DIRECT", "1") == "1"
+        self.direct = _plan.knob("OSRL_BC_DIRECT", "1", "the one-launch BC step launched directly (no graph)") == "1"
         self._arena_direct: Optional[ArgArena] = None
         # the one-launch step's own dW work list: 32 x 32 tiles when they fit the resident grid (a 256-row batch gives a
         # 64 x 64 tile 3.4 us of MFMA work on ONE CU; a quarter of that on four CUs), else the plan's 64 x 64 list
@@ -59,7 +60,7 @@ class BCEngine:
                 out_f, in_f = m.groups["actor"].layout[wk][1]
                 work += [v for ot in range((out_f + 31) // 32) for it in range((in_f + 31) // 32)
                          for v in (i, ot, it, 0 | (1 << 16))]
-            if len(work) // 4 <= L.STEP_MAX_WG and os.environ.get("OSRL_BC_STEP_T", "2") == "2":
+            if len(work) // 4 <= L.STEP_MAX_WG and _plan.knob("OSRL_BC_STEP_T", "2", "dW tile of the one-launch BC step (16-blocks)") == "2":
                 self._step_work, self._step_T = torch.tensor(work, dtype=torch.int32, device=dev), 2
 
     def _one_launch_args(self) -> "L.MlpStepT":

@@ -17,6 +17,7 @@ import torch
 from .. import _lib as L
 from ..common.net import net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
+from . import plan as P
 from .core import Branches, DwPlan, MlpRun, StepState, capture_step, concat_nets, load_into, check_plans_current
 
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/actor_loss", "loss/qc_penalty",
@@ -64,7 +65,8 @@ class BCQLEngine:
         self.z, self.du, self.dhead_enc = z(B, Lz), z(1, B, ad), z(1, B, 2 * Lz)
         self.r_dec.setup_backward(self.du, dx_cols=(od, Lz))
         self.r_enc.setup_backward(self.dhead_enc)
-        if int(m.vae_hidden_sizes) % 80 == 0 and B >= 1024 and os.environ.get("OSRL_VAE_DW_T5", "1") == "1":
+        pl = self.plan = P.bcql_plan(od, ad, B, int(m.vae_hidden_sizes), N, seeds=G.SEEDS and G.VAE_TAILS and G.VAE_NS_AUTO)
+        if pl.vae_dw_tile:
             # 400-wide layers = 5 x 5 column blocks: 80 x 80 tiles, 3 row splits per 2048 rows (engine/cpq.py)
             self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
                                 n_splits=max(1, (3 * B) // 2048), tile_blocks=5)
@@ -73,7 +75,7 @@ class BCQLEngine:
 
         # target pipeline buffers (shared by the critic and the cost-critic phases)
         NB = N * B
-        tr = int(os.environ.get("OSRL_BCQ_TILE", "80"))  # 80: mlp_fwd_nb_kernel (round 3: 564 vs 554.5 steps/s at C3); 0: tile kernel
+        tr = pl.target_tile  # 80: mlp_fwd_nb_kernel (round 3: 564 vs 554.5 steps/s at C3); 0: tile kernel
         self.r_dec_t = MlpRun(self.d_dec, NB, False, dev, tile_rows=tr)
         self.r_actor_old_t = MlpRun(self.d_actor_old, NB, False, dev, tile_rows=tr)
         self.a_t = z(NB, ad)
@@ -123,8 +125,7 @@ class BCQLEngine:
             }
         # round 5: the VAE phase as all-CU layer launches where the library takes the shape (glue.VaeNs, engine/cpq.py)
         self.vae_ns = None
-        ns_mode = os.environ.get("OSRL_VAE_NS", "auto")
-        if self.seeds is not None and (ns_mode == "1" or (ns_mode == "auto" and G.VAE_NS_AUTO and G.vae_ns_auto(B, m.state_dim, m.action_dim))):
+        if self.seeds is not None and pl.vae_ns:
             self.vae_ns = G.VaeNs.build(self.r_enc, self.r_dec, self.obs, self.act, self.noise["eps_vae"], self.z,
                                         m.latent_dim, m.beta, self.rows_global, self.st.stat_ptr("loss/loss_vae"))
         self.graph: Optional[torch.cuda.CUDAGraph] = None

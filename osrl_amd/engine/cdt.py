@@ -19,9 +19,10 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _lib as L
+from . import plan as _plan
 from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into, check_plans_current
 
-FUSE_DROP = os.environ.get("OSRL_CDT_FUSE_DROP", "1") == "1"  # residual-branch dropout inside the LayerNorm launches
+FUSE_DROP = _plan.knob("OSRL_CDT_FUSE_DROP", "1", "residual-branch dropout inside the LayerNorm launches") == "1"  # residual-branch dropout inside the LayerNorm launches
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
 
 

@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .. import _lib as L
+from . import plan as _plan
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -498,15 +499,15 @@ class MlpRun:
 # 11.5 + 6.6 us isolated, critic 41.9 vs 20.5 + 8.0; C2 1935 vs 2230 steps/s) -- so "auto" fuses only plans whose tiles
 # have ONE split (the gradient is then complete in LDS: no slab, no exchange; small batches).  "1" forces it for every
 # flat plan (the bit-equality test, A/B runs), "0" never fuses.
-FUSE_DW_ADAM = os.environ.get("OSRL_FUSE_DW_ADAM", "auto")
+FUSE_DW_ADAM = _plan.knob("OSRL_FUSE_DW_ADAM", "auto", "dW + optimizer step in one launch: 1 / 0 / auto (one-split plans)")
 
 
 class DwPlan:
     """Static work list for osrl_mlp_backward_dw over one optimizer group."""
 
     BIG_ROWS = 8192  # from this many rows on, fully 128x128-tiled layers take the one-wave-per-tile kernel
-    COOP = os.environ.get("OSRL_DW_COOP", "1") == "1"  # ... and fully 256x256-tiled ones the workgroup-per-tile kernel
-    FLAT_DEFAULT = os.environ.get("OSRL_DW_FLAT", "1") == "1"
+    COOP = _plan.knob("OSRL_DW_COOP", "1", "token-matrix dW on 256 x 256 workgroup tiles") == "1"  # ... and fully 256x256-tiled ones the workgroup-per-tile kernel
+    FLAT_DEFAULT = _plan.knob("OSRL_DW_FLAT", "1", "dW on the flat (tile, split) work list") == "1"
 
     def __init__(self, group: FlatGroup, entries: Sequence[Tuple[torch.Tensor, torch.Tensor, str, str]],
                  rows: int, device, n_splits: Optional[int] = None, big: Optional[bool] = None,
@@ -733,7 +734,7 @@ class ArgArena:
     wave fetches its 1-2 KB descriptor over PCIe -- the CPQ step measured 1690 instead of 2150 steps/s.
     ``OSRL_ARG_ARENA=0`` disables it (A/B measurements)."""
 
-    ENABLED = os.environ.get("OSRL_ARG_ARENA", "1") == "1"
+    ENABLED = _plan.knob("OSRL_ARG_ARENA", "1", "launch descriptors of a captured step in device memory") == "1"
 
     def __init__(self, device, capacity: int = 1 << 18):
         self.device = torch.device(device)
@@ -802,7 +803,7 @@ def capture_step(device, warm, captured):
     return g, arena
 
 
-FUSED_BEGIN = os.environ.get("OSRL_FUSED_BEGIN", "1") == "1"
+FUSED_BEGIN = _plan.knob("OSRL_FUSED_BEGIN", "1", "tick + minibatch gather + noise as one prologue launch") == "1"
 
 
 class StepState:

@@ -20,16 +20,23 @@ import torch
 from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
+from . import plan as P
 from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, check_plans_current
 
-# Every action draw of the step by the actor trunks' own forward launch (osrl_mlp_forward2_tail; bit-identical to the four
-# gauss_head / gauss_ood launches).  Round 3 measured it SLOWER (2042 vs 2180 steps/s: the N*B cost-critic launch then
-# started 25 us earlier, beside the VAE backward instead of its dW); with round 4's plan (seeded backward launches, the
-# 8-wave encoder launch, small dW tiles) the same switch is +4.9 % at C2 (2135-2138 -> 2237-2245 steps/s, two A/B pairs
-# on one box, gpurun_out/r4e).
-# At C4's (17, 6) the tails cost 1 % instead (2295 vs 2319-2320; the OOD draws alone as a launch: 2272-2285): the tail of
-# the 128 actor tiles writes N x ad values per row, three times C2's.  "auto" (default) = tails while N * action_dim <= 32.
-HEAD_TAILS = os.environ.get("OSRL_HEAD_TAILS", "auto")
+# Plan choices that depend on the shape live in engine/plan.py (cpq_plan: head tails, dW tiles, the all-CU VAE launches;
+# the measurements behind each rule are in DESIGN_LOG.md).  What is left here are lab switches of the plan's STRUCTURE:
+# Data parallel, round 5: the two collectives that feed only the side branch (the VAE gradient's all-reduce, the KL values'
+# all-gather) issued from a branch of their own / the side branch instead of the main one.  Order-safe without a second
+# communicator: every rank ISSUES the four collectives in the same program order and RCCL executes them on its own stream
+# in that order; only the streams that wait for them differ.  Built, verified (world-2 / world-8 in-process capture tests)
+# and measured with forced data parallelism on one rank: SLOWER, C2 1991 vs 2021 steps/s, C4 2065 vs 2213
+# (gpurun_out/r5d): the extra branch and the collectives' fork / join edges on the side queue cost the graph executor more
+# than the two 17 us collectives they take off the main chain.  Default "0" = round 4's placement (all four on the main
+# branch).
+DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather issued off the main branch") == "1"
+# single GPU: the VAE's optimizer step at the head of the side branch's second half instead of on the main chain
+# (C2 2256 vs 2240 steps/s, C4 2340 vs 2416: off)
+VAE_ADAM_SIDE = P.knob("OSRL_VAE_ADAM_SIDE", "0", "VAE Adam on the side branch") == "1"
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -49,6 +56,8 @@ class CPQEngine:
         z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
         self.st = StepState(dev, STAT_KEYS)
         nq, nqc = m.num_q, m.num_qc
+        pl = self.plan = P.cpq_plan(od, ad, B, int(m.vae_hidden_sizes), N, seeds=G.SEEDS and G.VAE_TAILS and max(nq, nqc) <= 4
+                                    and G.VAE_NS_AUTO)
 
         # static inputs (a replayed graph reads these addresses)
         self.obs, self.nobs, self.act = z(B, od), z(B, od), z(B, ad)
@@ -90,14 +99,12 @@ class CPQEngine:
         # measure best at the default 256 rows (2175 vs 2110 at 512, 2010 at 1024)
         # round 3: 400-wide layers are 25 = 5 x 5 column blocks -- on 80 x 80 tiles with a flat (tile, split) work list
         # the VAE's dW is 250 even workgroups in one round (core.DwPlan tile_blocks; OSRL_VAE_DW_T5=0: the 64 x 64 form)
-        t5 = os.environ.get("OSRL_VAE_DW_T5", "1") == "1" and int(m.vae_hidden_sizes) % 80 == 0 and B >= 1024
-        if t5:
+        if pl.vae_dw_tile:
             self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
-                                n_splits=int(os.environ.get("OSRL_VAE_DW_SPLITS", "0")) or max(1, (3 * B) // 2048),
-                                tile_blocks=5)  # 70 tiles x 3 splits = 210 workgroups: one round (tools/dw_bench.py)
+                                n_splits=pl.vae_dw_splits, tile_blocks=pl.vae_dw_tile)  # 70 tiles x 3 splits = 210 workgroups: one round (tools/dw_bench.py)
         else:
             self.p_vae = DwPlan(g["vae"], self.r_enc.dw_entries() + self.r_dec.dw_entries(), B, dev,
-                                n_splits=int(os.environ.get("OSRL_VAE_DW_SPLITS", "0")) or max(1, B // 1024))
+                                n_splits=pl.vae_dw_splits)
 
         # ---- critic phase
         self.r_actor_next = MlpRun(self.d_actor, B, False, dev)
@@ -110,11 +117,10 @@ class CPQEngine:
         # workgroups fit on a CU beside the 8-wave N*B-row encoder launch (130 KB, 2 x 152 registers per SIMD), which a
         # 64 x 64 tile's 68 KB / 304 registers do not -- the cost critics' dW runs beside that launch on the main branch
         # (84 -> 65 us there; C2 2245 -> 2260-2267 steps/s with both groups, gpurun_out/r4c)
-        small_dw = B >= 1024
-        t_def, s_def = ("2", 2) if small_dw else ("0", None)
+        t_def, s_def = ("2", 2) if pl.small_dw else ("0", None)
         self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev,
-                               tile_blocks=int(os.environ.get("OSRL_DW_T_CRITIC", t_def)),
-                               n_splits=(int(os.environ["OSRL_DW_S_CRITIC"]) if "OSRL_DW_S_CRITIC" in os.environ else s_def))
+                               tile_blocks=int(P.knob("OSRL_DW_T_CRITIC", t_def, "dW tile of the critic group (16-blocks)")),
+                               n_splits=(int(P.knob("OSRL_DW_S_CRITIC", "0")) if P.knob_set("OSRL_DW_S_CRITIC") else s_def))
 
         # ---- cost-critic phase
         self.a_next2 = z(B, ad)
@@ -127,11 +133,13 @@ class CPQEngine:
         # room on every CU.  (Until the kernel's epilogue / bias / stage-in rework of round 2 the capped 32-row tile
         # loop was the better neighbour for the VAE phase: 1968 vs 1876 steps/s; now 80-row tiles give 2095 vs 2020.
         # OSRL_OOD_TILE=0 OSRL_OOD_WG_CAP=512 restores the old form.)
-        ood_tile = int(os.environ.get("OSRL_OOD_TILE", "80"))
+        ood_tile = pl.ood_tile
         self.r_costold_ood = MlpRun(self.d_cost_old, N * B, False, dev,
-                                    wg_cap=int(os.environ.get("OSRL_OOD_WG_CAP", "0")), tile_rows=ood_tile)
-        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev, wg_cap=int(os.environ.get("OSRL_ENC_WG_CAP", "0")),
-                                tile_rows=int(os.environ.get("OSRL_ENC_TILE", str(ood_tile or 80))))
+                                    wg_cap=int(P.knob("OSRL_OOD_WG_CAP", "0", "workgroup cap of the N*B cost-critic launch")),
+                                    tile_rows=ood_tile)
+        self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev,
+                                wg_cap=int(P.knob("OSRL_ENC_WG_CAP", "0", "workgroup cap of the N*B encoder launch")),
+                                tile_rows=int(P.knob("OSRL_ENC_TILE", str(ood_tile or 80), "row tile of the N*B encoder launch")))
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)
@@ -139,8 +147,8 @@ class CPQEngine:
         self.dqc = z(nqc, B, 1)
         self.r_cost.setup_backward(self.dqc)
         self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev,
-                             tile_blocks=int(os.environ.get("OSRL_DW_T_COST", t_def)),
-                             n_splits=(int(os.environ["OSRL_DW_S_COST"]) if "OSRL_DW_S_COST" in os.environ else s_def))
+                             tile_blocks=int(P.knob("OSRL_DW_T_COST", t_def, "dW tile of the cost-critic group (16-blocks)")),
+                             n_splits=(int(P.knob("OSRL_DW_S_COST", "0")) if P.knob_set("OSRL_DW_S_COST") else s_def))
 
         # ---- actor phase
         self.a_pi, self.tanh_u = z(B, ad), z(B, ad)
@@ -170,12 +178,10 @@ class CPQEngine:
                 "head": G.seed_gauss_head(self.noise["eps_actor"], self.tanh_u, self.r_pi_q.dx, nq, B, m.max_action),
             }
 
-        # round 5: the VAE phase's forward / backward as all-CU layer launches (csrc/vae_ns.hip, glue.VaeNs) where the
-        # library takes the shape; OSRL_VAE_NS: "0" the four fused launches, "1" force, "auto" by measurement (DESIGN_LOG
-        # round 5)
+        # round 5: the VAE phase's forward / backward as all-CU layer launches (csrc/vae_ns.hip, glue.VaeNs) where the plan
+        # says so (engine/plan.py vae_ns_auto: by measurement) and the library takes the shape
         self.vae_ns = None
-        ns_mode = os.environ.get("OSRL_VAE_NS", "auto")
-        if self.seeds is not None and (ns_mode == "1" or (ns_mode == "auto" and G.VAE_NS_AUTO and G.vae_ns_auto(B, od, ad))):
+        if self.seeds is not None and pl.vae_ns:
             self.vae_ns = G.VaeNs.build(self.r_enc, self.r_dec, self.obs, self.act, self.noise["eps_vae"], self.z, Lz,
                                         m.beta, rg, st.stat_ptr("loss/loss_vae"))
 
@@ -260,15 +266,36 @@ class CPQEngine:
             G.vae_decoder_backward(self.r_dec, head, nz["eps_vae"], Lz, m.beta, rg, self.dhead_enc)
         if self.vae_ns is None:
             self.r_enc.backward_dz()
-        self._optim("vae", self.p_vae, 0.0)
-        ev_vae = torch.cuda.Event() if par.enabled else None
-        if ev_vae is not None:
-            ev_vae.record()
+        if dp is not None and par.enabled and len(par.side) > 1 and DP_SIDE_COLL:
+            # data parallel, round 5: nothing on the main branch reads the VAE's parameters in this step (its only reader
+            # is the N*B-row encoder launch of the side branch), so the gradient's all-reduce and the optimizer step
+            # leave the critical chain: a short branch of their own behind the dW launch.  The collective is still ISSUED
+            # here, first of the step's four, on every rank (RCCL runs them on its own stream in issue order)
+            self._pr("vae_dw", 0)
+            self.p_vae.launch()
+            self._pr("vae_dw", 1)
+            par.fork(1)
+            with par.on(1):
+                self._update("vae", 0.0)
+                ev_vae = par.mark(1)
+        else:
+            # (single GPU, OSRL_VAE_ADAM_SIDE=1: the VAE's optimizer step at the head of the side branch's second half,
+            # in front of its only reader, instead of on the main chain -- an A/B switch, DESIGN_LOG round 5)
+            vae_adam_side = dp is None and par.enabled and VAE_ADAM_SIDE and not self.p_vae.can_fuse_adam()
+            if vae_adam_side:
+                self._pr("vae_dw", 0)
+                self.p_vae.launch()
+                self._pr("vae_dw", 1)
+            else:
+                self._optim("vae", self.p_vae, 0.0)
+            ev_vae = torch.cuda.Event() if par.enabled else None
+            if ev_vae is not None:
+                ev_vae.record()
 
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
-            if HEAD_TAILS == "1" or (HEAD_TAILS == "auto" and N * ad <= 32):
+            if self.plan.head_tails:
                 # every action draw of the step (cpq.py:141 a_next, :159 a_next2, :164-176 the N OOD draws, :209 the
                 # actor-phase sample) by the actor trunks' own forward launch, from its LDS-resident head tiles: four
                 # single-purpose launches (30 us on this branch inside the step, profiles/r3_timeline_*.txt) fewer
@@ -306,7 +333,7 @@ class CPQEngine:
                 self._optim("critic", self.p_critic, m.tau)
             else:  # collectives stay on the capture stream (same order on every rank): reduced + stepped over there
                 self.p_critic.launch()
-                if os.environ.get("OSRL_DP_SIDE_REDUCE", "1") == "1":
+                if P.knob("OSRL_DP_SIDE_REDUCE", "1", "DP: the critic group's slab sum on the side branch") == "1":
                     dp.reduce_local(m.groups["critic"])  # the per-rank slab sum is no collective: off the main chain
             ev_critic = par.mark(0)  # also: the side branch's last reader of cost_critic_old is enqueued
 
@@ -340,11 +367,21 @@ class CPQEngine:
         with par.on(0):
             if ev_vae is not None:
                 par.side[0].wait_event(ev_vae)
+            if dp is None and par.enabled and VAE_ADAM_SIDE and not self.p_vae.can_fuse_adam():
+                self._update("vae", 0.0)
             self._pr("enc_ood", 0)  # bench.py: HIP events around the dominant launch as it runs inside the step
             # (the KL rows of cpq.py:178-182 by the encoder launch itself: OSRL_TAIL_VAE_KL)
             self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl))
             self._pr("enc_ood", 1)
-            if dp is not None:
+            kl_on_side = dp is not None and par.enabled and DP_SIDE_COLL
+            if kl_on_side:
+                # the batch-GLOBAL quantile (cpq.py:183 over all world * N * B values): gather, selection and masked mean
+                # stay on this branch -- the third collective of the step in issue order on every rank (behind [critic |
+                # cost-critic gradients], which the main branch issued above); the main branch never waits for it
+                kl_all = dp.all_gather_concat(self.kl)
+                dp.quantile_select(kl_all, 0.75, self.quant)
+                G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            elif dp is not None:
                 ev_kl = par.mark(0)
             elif N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
                 G.cpq_ood_stat(qc_s, nqc, self.kl, 0.75, N, B, rg, self.quant, self.ood_mean)
@@ -357,14 +394,15 @@ class CPQEngine:
         self._pr("actor_phase_fwd", 0)
         y = self.r_pi_q.forward(self.obs, self.a_pi)
         self._pr("actor_phase_fwd", 1)
-        if dp is not None:
+        if dp is not None and not kl_on_side:
+            # (OSRL_DP_SIDE_COLL=0 or no branches: round 4's placement)
             # the batch-GLOBAL quantile (cpq.py:183 over all world * N * B values): the gather is a collective, so it
             # is issued from the capture stream -- here, behind the actor phase's forward launch, which is about when
             # the side branch has its KL rows (profiles/r2_timeline.txt: 397 us vs 405 us); the selection and the
             # masked mean go back to the side branch and run beside the actor phase's backward
             par.wait(ev_kl)
             kl_all = dp.all_gather_concat(self.kl)
-            if os.environ.get("OSRL_DP_SIDE_QUANT", "1") == "1":
+            if P.knob("OSRL_DP_SIDE_QUANT", "1", "DP: quantile + masked mean back on the side branch") == "1":
                 ev_g = torch.cuda.Event() if par.enabled else None
                 if ev_g is not None:
                     ev_g.record()
@@ -414,7 +452,7 @@ class CPQEngine:
         snap = self._snapshot()
         # data parallel: the side branch holds no collective (the critic group's all-reduce + Adam run on the
         # capture stream after the join), so every rank issues its RCCL calls in the same order on one stream
-        par = Branches(self.parallel_branches, 1)
+        par = Branches(self.parallel_branches, 2 if self.dist is not None else 1)
         try:  # the warm-up pass and the capture pass both advance the model: ALWAYS put the snapshot back, also
             # when the capture is refused and the caller falls back to eager launches
             s = torch.cuda.Stream()

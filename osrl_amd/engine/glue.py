@@ -10,6 +10,7 @@ import os
 from typing import Optional
 
 from .. import _lib as L
+from . import plan as _plan
 from .core import cur_stream
 
 
@@ -62,7 +63,7 @@ def vae_kl_tail(Lz, kl) -> "L.TailT":
     return t
 
 
-VAE_TAILS = os.environ.get("OSRL_VAE_TAILS", "1") == "1"  # 0: the reparameterisation and its backward as own launches
+VAE_TAILS = _plan.knob("OSRL_VAE_TAILS", "1", "reparameterisation / its backward as tails of the MLP launches") == "1"  # 0: the reparameterisation and its backward as own launches
 
 
 def gauss_tail(ad, max_action, eps=None, a=None, eps2=None, a2=None, tanh2=None, eps_ood=None, n_samples=0,
@@ -98,15 +99,7 @@ def vae_decoder_backward(r_dec, head, eps, Lz, beta, rows_global, dhead):
     vae_latent_bwd(head, eps, r_dec.dx, r_dec.rows, Lz, beta, rows_global, dhead)
 
 
-VAE_NS_AUTO = True  # OSRL_VAE_NS=auto: the all-CU VAE launches where vae_ns_auto() says the measurements favour them
-
-
-def vae_ns_auto(rows: int, od: int, ad: int) -> bool:
-    """Where the five all-CU launches beat the four fused ones INSIDE the step (A/B on MI355X, DESIGN_LOG round 5,
-    gpurun_out/r5a): C4's (17, 6) at 2048 rows +4.5 %; C2's (76, 2) at 2048 rows +0.2 % (noise); C3's (33, 8) at 4096 rows
-    -3.6 % (two rounds of 48-row tiles against one round of 256 fused 16-row tiles).  The rule below is those three
-    points, not a model: one round of tiles (<= 2048 rows) and a first layer of <= 48 input columns (three k-steps)."""
-    return 1024 <= rows <= 2048 and od + ad <= 48
+VAE_NS_AUTO = True  # False: the plan chooser never picks the all-CU VAE launches (the seeds-vs-loss-launches bit-equality test)
 
 
 class VaeNs:
@@ -270,7 +263,7 @@ def clamp_(x, lo, hi):
 
 
 # ---- loss seeds (osrl_mlp_seed_t): the backward launch computes dL/d(output) itself --------------------------------
-SEEDS = os.environ.get("OSRL_SEEDS", "1") == "1"  # 0: the loss kernels as launches of their own (A/B, bit-equality tests)
+SEEDS = _plan.knob("OSRL_SEEDS", "1", "backward launches compute the gradient they start from") == "1"  # 0: the loss kernels as launches of their own (A/B, bit-equality tests)
 
 
 class SeedStat:

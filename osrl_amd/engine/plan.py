@@ -1,0 +1,131 @@
+"""Launch-plan choices in ONE place: a shape-keyed chooser with the BASELINE configs' rows pinned, and
+the registry of every tuning switch the engines know.
+
+Two kinds of thing used to be spread over ~35 ``os.environ`` reads in engine/*.py:
+
+  * **shape rules** -- what a step plan does differently for (obs_dim, act_dim, batch, widths): which dW tile a group
+    takes, whether the action draws ride on the actor trunks' forward launch, whether the VAE phase runs as all-CU layer
+    launches, ...  They are functions of the shape, calibrated on the BASELINE configs (reference configs:
+    examples/configs/cpq_configs.py:27-50, bcql_configs.py:31-51).  ``cpq_plan`` / ``bcql_plan`` compute them,
+    ``PINNED`` states what they must return for C2 / C3 / C4 (tests/test_host_cpu.py holds the chooser to it), and
+    tests/test_gpu_train_step.py::test_random_shape_tuples_match_the_oracle sweeps random tuples through whatever plan
+    the chooser picks, against the oracle -- so no reachable plan is untested.
+  * **lab switches** -- A/B knobs of the kernel work (``OSRL_*``).  ``knob()`` registers each with its default and a
+    one-line meaning and reads the environment ONLY when ``OSRL_LAB=1``: a production run's plan does not depend on
+    stray variables, a lab run (tools/gpu_*.sh export OSRL_LAB=1) can still flip them.  ``python -m osrl_amd.engine.plan``
+    prints the registry and the pinned rows.
+
+Operator switches that are not plan choices stay plain environment variables: OSRL_LIB (alternative library build),
+OSRL_DP_EAGER (run the data-parallel step without capturing its collectives), OSRL_FORCE_DP (bench.py), OSRL_LAB.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from dataclasses import asdict, dataclass
+from typing import Dict, Optional, Tuple
+
+KNOBS: Dict[str, Tuple[str, str]] = {}
+_warned = set()
+
+
+def lab() -> bool:
+    return os.environ.get("OSRL_LAB") == "1"
+
+
+def knob(name: str, default: str, doc: str = "") -> str:
+    """The value of lab switch ``name``: its default, or -- only under OSRL_LAB=1 -- what the environment says."""
+    KNOBS.setdefault(name, (default, doc))
+    if name in os.environ:
+        if lab():
+            return os.environ[name]
+        if name not in _warned and os.environ[name] != default:
+            _warned.add(name)
+            warnings.warn(f"osrl_amd: {name}={os.environ[name]} is ignored (lab switches need OSRL_LAB=1); using {default!r}")
+    return default
+
+
+def knob_set(name: str) -> bool:
+    """True when a lab run set ``name`` explicitly (switches whose default is "derive it from the shape")."""
+    return lab() and name in os.environ
+
+
+@dataclass(frozen=True)
+class CPQPlan:
+    """What the CPQ step plan derives from the shape (engine/cpq.py reads these, nothing else)."""
+    head_tails: bool          # every action draw of the step by the actor trunks' forward launch (N * act_dim <= 32)
+    vae_dw_tile: int          # dW tile of the VAE group in 16-blocks: 5 (80 x 80, 400-wide layers are 5 x 5) or 0 (default)
+    vae_dw_splits: int        # row splits of that plan
+    small_dw: bool            # critic / cost-critic dW on 32 x 32 tiles x 2 splits (fit beside the N*B encoder launch)
+    ood_tile: int             # row tile of the N*B-row launches (80 = one workgroup per CU)
+    vae_ns: bool              # the VAE phase as all-CU layer launches (csrc/vae_ns.hip)
+
+
+def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> CPQPlan:
+    head_tails = {"1": True, "0": False}.get(knob("OSRL_HEAD_TAILS", "auto", "action draws as forward tails: 1 / 0 / auto"),
+                                             N * ad <= 32)
+    t5 = knob("OSRL_VAE_DW_T5", "1", "VAE dW on 80 x 80 tiles where the width allows") == "1" and vae_hidden % 80 == 0 and B >= 1024
+    splits = int(knob("OSRL_VAE_DW_SPLITS", "0", "row splits of the VAE dW plan (0 = by rule)")) or \
+        (max(1, (3 * B) // 2048) if t5 else max(1, B // 1024))
+    ns_mode = knob("OSRL_VAE_NS", "auto", "VAE phase as all-CU layer launches: 1 / 0 / auto")
+    ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
+    vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad)))
+    return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=5 if t5 else 0, vae_dw_splits=splits, small_dw=B >= 1024,
+                   ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
+                   vae_ns=bool(vae_ns))
+
+
+def vae_ns_auto(rows: int, od: int, ad: int) -> bool:
+    """Where the five all-CU VAE launches beat the four fused ones INSIDE the step (A/B on MI355X, DESIGN_LOG round 5,
+    gpurun_out/r5a): C4's (17, 6) at 2048 rows +4.5 %; C2's (76, 2) at 2048 rows +0.2 % (noise); C3's (33, 8) at 4096 rows
+    -3.6 % (two rounds of 48-row tiles against one round of 256 fused 16-row tiles).  The rule is those three points, not
+    a model: one round of tiles (<= 2048 rows) and a first layer of <= 48 input columns (three k-steps)."""
+    return 1024 <= rows <= 2048 and od + ad <= 48
+
+
+@dataclass(frozen=True)
+class BCQLPlan:
+    vae_dw_tile: int
+    target_tile: int          # row tile of the N*B-row target pipelines (80 = mlp_fwd_nb_kernel)
+    vae_ns: bool
+
+
+def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> BCQLPlan:
+    t5 = knob("OSRL_VAE_DW_T5", "1") == "1" and vae_hidden % 80 == 0 and B >= 1024
+    ns_mode = knob("OSRL_VAE_NS", "auto")
+    ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
+    vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad)))
+    return BCQLPlan(vae_dw_tile=5 if t5 else 0,
+                    target_tile=int(knob("OSRL_BCQ_TILE", "80", "row tile of BCQ-Lag's N*B-row target pipelines")),
+                    vae_ns=bool(vae_ns))
+
+
+# BASELINE.json configs -> the plan the chooser must give (tests/test_host_cpu.py::test_plan_rows_are_pinned); a changed
+# rule that moves one of these rows is a deliberate act with a measurement behind it (DESIGN_LOG)
+PINNED = {
+    "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
+           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=False)),
+    "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
+           CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True)),
+    "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
+           BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False)),
+    "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4),
+                  CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False)),
+}
+
+
+def describe(plan) -> Dict[str, object]:
+    return asdict(plan)
+
+
+if __name__ == "__main__":  # pragma: no cover
+    import importlib
+    for mod in ("core", "glue", "cpq", "bcql", "bc", "cdt"):  # importing the engines registers their knobs
+        try:
+            importlib.import_module(f"osrl_amd.engine.{mod}")
+        except Exception as e:  # no library on this host: the registry of the modules that did import is still printed
+            print(f"({mod}: {e!r})")
+    for name, (fn, kw, want) in PINNED.items():
+        print(f"{name:10s} {kw} -> {fn(**kw)}")
+    for k, (d, doc) in sorted(KNOBS.items()):
+        print(f"{k:24s} default {d!r:8s} {doc}")

@@ -128,6 +128,7 @@ def test_the_c_abi_refuses_bad_descriptors():
 
 def test_one_launch_captured_in_a_graph_too(monkeypatch):
     """OSRL_BC_DIRECT=0: the one-kernel step inside a hipGraph (what an outer capture of several steps would do)."""
+    monkeypatch.setenv("OSRL_LAB", "1")  # (lab switches are read only under OSRL_LAB=1: engine/plan.py)
     monkeypatch.setenv("OSRL_BC_DIRECT", "0")
     ma, mb = _pair(8, 2, [256, 256])
     ea, eb = ma.engine(256), mb.engine(256)

@@ -253,22 +253,48 @@ def test_world2_cdt_sharded_step_equals_concatenated_batch(case):
 # split update of the two critic groups after the join -- with a peer whose values differ.  (RCCL's own kernels as
 # graph nodes are covered by the 1-rank NCCL capture tests; RCCL peer traffic inside a graph needs >1 GPU.)
 class _Hub:
+    """The in-process process group.  Like RCCL it owns ONE stream on which every exchange runs, in the order the
+    replicas issue them: an exchange waits for the issuing stream of every replica (main or a side branch: an event
+    recorded where the collective is called), and each replica's issuing stream waits for the exchange -- the
+    dependency structure torch's ProcessGroupNCCL puts around a collective.  ``log`` keeps, per exchange, what every
+    replica deposited (label, element count): the replicas must issue the SAME sequence (round 5: two of CPQ's four
+    collectives are issued from side branches, which is order-safe exactly because of this)."""
+
     def __init__(self, world):
         self.world, self.slots, self.parent = world, [None] * world, None
+        self.xs = None
+        self.log = []
 
     def run(self, fns):
         import greenlet
         self.parent = greenlet.getcurrent()
+        if self.xs is None:
+            self.xs = torch.cuda.Stream()
+        # the replicas share this THREAD, hence torch's thread-local current stream: every replica starts on the caller's
+        # stream, puts its own stream back when it resumes (GreenDist._exchange), and the caller gets its stream back at
+        # the end -- separate processes have this for free
+        base = torch.cuda.current_stream()
         gs = [greenlet.greenlet(f) for f in fns]
         for g in gs:
+            torch.cuda.set_stream(base)
             g.switch()  # up to its first collective (or to the end)
+        torch.cuda.set_stream(base)
         while not all(g.dead for g in gs):
             assert not any(g.dead for g in gs) and all(s is not None for s in self.slots), \
                 "replicas issued different numbers of collectives"
-            parts = [s.clone() for s in self.slots]  # stream order makes every deposit visible here
+            sig = {(lab, int(t.numel())) for (t, ev, lab) in self.slots}
+            assert len(sig) == 1, f"replicas are at different collectives: {sorted(sig)}"
+            self.log.append(next(iter(sig)))
+            for (t, ev, lab) in self.slots:
+                self.xs.wait_event(ev)
+            with torch.cuda.stream(self.xs):
+                parts = [t.clone() for (t, ev, lab) in self.slots]
+                done = torch.cuda.Event()
+                done.record(self.xs)
             self.slots = [None] * self.world
             for g in gs:
-                g.switch(parts)
+                g.switch((parts, done))
+            torch.cuda.set_stream(base)
 
 
 def make_green(hub, rank):
@@ -277,13 +303,20 @@ def make_green(hub, rank):
     class GreenDist(DataParallel):
         def __init__(self):
             self.group, self.world, self.rank, self._gather_buf, self.src0 = None, hub.world, rank, None, 0
+            self._probe = None
 
-        def _exchange(self, t):
-            hub.slots[rank] = t
-            return hub.parent.switch()
+        def _exchange(self, t, label):
+            mine = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(mine)  # on the stream the collective is issued from
+            hub.slots[rank] = (t, ev, label)
+            parts, done = hub.parent.switch()
+            torch.cuda.set_stream(mine)  # (the other replicas ran on this thread meanwhile)
+            mine.wait_event(done)
+            return parts
 
         def all_reduce_(self, t):
-            parts = self._exchange(t)
+            parts = self._exchange(t, "all_reduce")
             acc = parts[0]
             for p in parts[1:]:
                 acc = acc + p
@@ -291,25 +324,31 @@ def make_green(hub, rank):
             return t
 
         def broadcast_(self, t):
-            t.copy_(self._exchange(t)[0])
+            t.copy_(self._exchange(t, "broadcast")[0])
             return t
 
         def all_agree(self, ok, device):
             return bool(ok)
 
         def all_gather_concat(self, t):
-            return torch.cat([p.reshape(-1) for p in self._exchange(t)])
+            return torch.cat([p.reshape(-1) for p in self._exchange(t, "all_gather")])
 
     return GreenDist()
 
 
-@pytest.mark.parametrize("algo,W", [("cpq", 2), ("cpq_c4", 2), ("cpq_c4_w8", 8)])
-def test_captured_data_parallel_graph_equals_concatenated_batch(algo, W):
+@pytest.mark.parametrize("algo,W,side_coll", [("cpq", 2, False), ("cpq_c4", 2, False), ("cpq_c4_w8", 8, False),
+                                              ("cpq", 2, True), ("cpq_c4_w8", 8, True)])
+def test_captured_data_parallel_graph_equals_concatenated_batch(algo, W, side_coll, monkeypatch):
     """W replicas' data-parallel step bodies in ONE captured graph == the single-device step on the concatenated batch.
     W = 8 is BASELINE.json's C4 job shape (8 x 2048 rows at (17, 6)): rows_global = 16384, the batch-global quantile
     over 163840 gathered KL values runs as the grid select inside the step; the single-device run's step-1 statistics
     are refereed by the fp64 oracle."""
+    from osrl_amd.engine import cpq as cpq_engine
     from osrl_amd.engine.core import Branches
+    # side_coll (round 5, OSRL_DP_SIDE_COLL=1; not the default plan: measured slower on one rank, DESIGN_LOG round 5): the
+    # VAE gradient's all-reduce issued from a branch of its own and the KL gather from the side branch -- same results,
+    # and the hub asserts at every exchange that all replicas are at the SAME collective (one total order)
+    monkeypatch.setattr(cpq_engine, "DP_SIDE_COLL", bool(side_coll))
     c = DP_CASES[algo]
     B, N = c.B, c.N
     Bl = B // W
@@ -334,7 +373,7 @@ def test_captured_data_parallel_graph_equals_concatenated_batch(algo, W):
     def build(r):
         engs[r] = reps[r][0].engine(Bl, rows_global=B, dist=make_green(hub, r))
     hub.run([lambda r=r: build(r) for r in range(W)])
-    pars = [Branches(True, 1) for _ in range(W)]
+    pars = [Branches(True, 2) for _ in range(W)]
     bodies = [lambda r=r: engs[r].body(False, pars[r]) for r in range(W)]
     snaps = [e._snapshot() for e in engs]
     side = torch.cuda.Stream()
@@ -343,9 +382,21 @@ def test_captured_data_parallel_graph_equals_concatenated_batch(algo, W):
         hub.run(bodies)  # warm-up pass (torch requires one before capture)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
+    hub.log = []
     with torch.cuda.graph(graph):
-        hub.run(bodies)
+        try:
+            hub.run(bodies)
+        except BaseException:  # (an exception inside a capture otherwise dies in the graph's destructor, unseen)
+            import traceback
+            traceback.print_exc()
+            raise
     torch.cuda.synchronize()
+    # ONE total order of the step's collectives, the same on every replica (asserted per exchange in _Hub.run): the VAE
+    # gradient first (issued from its own branch), [critic | cost-critic] + the partial qc_ood mean... as all_reduce calls,
+    # the KL gather third (issued from the side branch), [actor | statistics | qc_ood] last
+    kinds = [k for k, _ in hub.log]
+    assert kinds.count("all_gather") == 1 and kinds[0] == "all_reduce" and kinds[-1] == "all_reduce", kinds
+    assert kinds.index("all_gather") > 1, kinds  # behind the VAE's and the critic groups' all-reduces
     for e, sn in zip(engs, snaps):
         e._restore(sn)
     for s in range(c.steps):

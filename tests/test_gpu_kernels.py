@@ -1017,7 +1017,7 @@ def test_forward2_with_a_kl_tail_writes_the_kl_rows(rows, od, ad, hid):
     h1, u1 = r_e1.forward_with((obs, act), r_d1, (obs, z), tail=G.vae_kl_tail(Lz, kl1))
     torch.cuda.synchronize()
     # (the partner problem may run on another kernel form in the two-launch path: same sums in another order)
-    assert torch.allclose(h0, h1, rtol=1e-5, atol=1e-6) and torch.allclose(u0, u1, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(h0, h1, rtol=1e-5, atol=2e-5) and torch.allclose(u0, u1, rtol=1e-5, atol=2e-5)
     G.vae_kl_rows(h1[0], rows, Lz, kl0)  # the reference rows from the SAME head values
     torch.cuda.synchronize()
     assert torch.equal(kl0, kl1), "the KL tail of a paired forward was not applied"
@@ -1025,7 +1025,7 @@ def test_forward2_with_a_kl_tail_writes_the_kl_rows(rows, od, ad, hid):
     kl2 = torch.full((rows,), 3.0, device=dev)
     r_d1.forward_with((obs, z), r_e1, (obs, act), other_tail=G.vae_kl_tail(Lz, kl2))
     torch.cuda.synchronize()
-    assert torch.allclose(kl0, kl2, rtol=1e-5, atol=1e-6) and float(kl2.min()) != 3.0
+    assert torch.allclose(kl0, kl2, rtol=1e-4, atol=2e-5) and float(kl2.min()) != 3.0
 
 
 @pytest.mark.parametrize("rows,od,ad,hid,rg", [(100, 7, 3, 80, 0), (64, 76, 2, 400, 0), (2048, 17, 6, 400, 16384),

@@ -185,3 +185,25 @@ def test_ctypes_struct_layouts_match_the_compiled_header():
         assert tok[0] == cname
         want = [C.sizeof(cls)] + [getattr(cls, fname).offset for fname, _ in cls._fields_]
         assert [int(x) for x in tok[1:]] == want, (cname, tok[1:], want)
+
+
+def test_plan_rows_are_pinned(monkeypatch):
+    """engine/plan.py: the shape-keyed plan chooser returns the pinned rows for the BASELINE configs, and a lab switch in
+    the environment changes nothing unless OSRL_LAB=1 says this is a lab run."""
+    import warnings
+    from osrl_amd.engine import plan as P
+    monkeypatch.delenv("OSRL_LAB", raising=False)
+    for name, (fn, kw, want) in P.PINNED.items():
+        assert fn(**kw) == want, (name, fn(**kw), want)
+    monkeypatch.setenv("OSRL_HEAD_TAILS", "0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert P.cpq_plan(76, 2, 2048, 400, 10).head_tails is True       # ignored: not a lab run
+    monkeypatch.setenv("OSRL_LAB", "1")
+    assert P.cpq_plan(76, 2, 2048, 400, 10).head_tails is False          # a lab run may flip it
+    monkeypatch.delenv("OSRL_HEAD_TAILS")
+    # the all-CU VAE launches: only the measured region (one round of 48-row tiles, narrow first layer), never without
+    # the seeded backward launches, never outside the library's shapes
+    assert P.cpq_plan(17, 6, 2048, 400, 10).vae_ns and not P.cpq_plan(17, 6, 2048, 400, 10, seeds=False).vae_ns
+    assert not P.cpq_plan(17, 6, 4096, 400, 10).vae_ns and not P.cpq_plan(17, 6, 2048, 256, 10).vae_ns
+    assert not P.cpq_plan(76, 2, 2048, 400, 10).vae_ns and not P.cpq_plan(17, 6, 512, 400, 10).vae_ns

@@ -3,6 +3,7 @@
 # full-size parity with OSRL_VAE_NS=1, then A/B of the step at c2 / c3 / c4
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+export OSRL_LAB=1  # lab switches (OSRL_*) are read only under this (engine/plan.py)
 O=$GRAFT_REPO_ROOT/gpurun_out/r5a; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_bench_path.py "tests/test_gpu_kernels.py::test_forward2_with_a_kl_tail_writes_the_kl_rows" \
   "tests/test_gpu_data_eval.py::test_trained_cost_return_gap_vs_reference" -q > $O/t_new.log 2>&1; tail -6 $O/t_new.log

@@ -2,6 +2,7 @@
 # round 5: rocprofv3 kernel trace of a standalone lab binary (per-kernel durations without torch)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+export OSRL_LAB=1  # lab switches (OSRL_*) are read only under this (engine/plan.py)
 O=$GRAFT_REPO_ROOT/gpurun_out/r5lab; mkdir -p $O
 b=$1
 (cd /tmp && HIP_FORCE_DEV_KERNARG=${KERNARG:-1} rocprofv3 --kernel-trace --stats -f csv -d $O/prof_$b -o p -- $GRAFT_REPO_ROOT/tools/_lab/$b > $O/${b}_prof.log 2>&1)
