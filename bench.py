@@ -409,16 +409,19 @@ def roofline(eng, cfg_name="c2"):
         mean_us, med_us = sites.get(site, (float("nan"), float("nan")))
         in_run = mean_us == mean_us
         d = run.net.dims
-        # algorithmic HBM bytes of the launch: its DISTINCT input rows (the N*B rows read observation r % B and sampled
-        # action r: B x obs_dim + N*B x act_dim floats), the weights + biases of every net once, the [rows, out] result
-        alg = 4 * (eng.B * eng.obs.shape[1] + run.rows * eng.sampled.shape[1] + run.net.E * (lin(d) + sum(d[1:]))
-                   + run.net.E * run.rows * d[-1])
+        # algorithmic bytes of the launch as SURVEY.md 8d counts them: every row of the virtual [N*B, in] input, the weights
+        # + biases of every net once, the [rows, out] result.  `distinct_bytes`: the same with the input's DISTINCT rows only
+        # (row r reads observation r % B and sampled action r: B x obs_dim + N*B x act_dim floats) -- the counted traffic
+        # lies between the two (the 80-row tiles re-read observation rows that other tiles already brought on die)
+        wts = run.net.E * (lin(d) + sum(d[1:]))
+        alg = 4 * (run.rows * d[0] + wts + run.net.E * run.rows * d[-1])
+        distinct = 4 * (eng.B * eng.obs.shape[1] + run.rows * eng.sampled.shape[1] + wts + run.net.E * run.rows * d[-1])
         res[name] = dict(symbol=sym, gflop=round(fl / 1e9, 3), isolated_us=round(t * 1e6, 2),
                          isolated_frac=round(fl / t / 1e12 / PEAK_FP32_TFLOPS, 4),
                          in_step_us=round(mean_us, 2) if in_run else None,
                          in_step_us_median=round(med_us, 2) if in_run else None,
                          in_step_frac=round(fl / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4) if in_run else None,
-                         algorithmic_bytes=int(alg), traffic=pmc.get(name), wg_cap=int(run.fwd_c.wg_cap), _fl=fl, _t=t,
+                         algorithmic_bytes=int(alg), distinct_bytes=int(distinct), traffic=pmc.get(name), wg_cap=int(run.fwd_c.wg_cap), _fl=fl, _t=t,
                          _us=mean_us)
     have_run = all(v["in_step_us"] is not None for v in res.values())
     # dominant = the launch that takes the most time inside the step (N > 1: the most FLOPs)
@@ -853,6 +856,8 @@ def main():
                                                  "Philox noise inside the step",
                        "name": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
                        "graph": bool(getattr(eng, "graph", None) is not None),
+                       # what the shape-keyed plan chooser picked for this workload (engine/plan.py)
+                       "plan": (lambda pl: None if pl is None else {k: v for k, v in vars(pl).items()})(getattr(eng, "plan", None)),
                        # both timing protocols where a reader of the driver's record sees them: `value` is
                        # measured behind `preroll_ms` of untimed GEMM work, `no_preroll_value` is the same W + K steps
                        # timed first, straight after the probes

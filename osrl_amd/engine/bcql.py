@@ -51,6 +51,9 @@ class BCQLEngine:
             self.noise[k] = self.noise_flat[o:o + n].view(shapes[k])
             o += n
 
+        z0 = int(torch.Size(shapes["eps_vae"]).numel())
+        self._z_all = self.noise_flat[z0:z0 + sum(int(torch.Size(shapes[k]).numel()) for k in ("z_c", "z_cc", "z_actor"))]
+        assert self._z_all.data_ptr() == self.noise["z_c"].data_ptr()
         twin = lambda mod: net_desc_seq(mod.all_nets(), 1.0)  # noqa: E731
         self.d_actor = net_desc_seq([m.actor.pi], 1.0)
         self.d_actor_old = net_desc_seq([m.actor_old.pi], 1.0)
@@ -164,8 +167,9 @@ class BCQLEngine:
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat, self.seed, device_noise)
-        for k in ("z_c", "z_cc", "z_actor"):  # net.py:334-335 clamps the latent draw
-            G.clamp_(nz[k], -0.5, 0.5)
+        # net.py:334-335 clamps the latent draws: z_c | z_cc | z_actor are adjacent in the flat noise buffer -- ONE launch
+        # over the range instead of three (round 5: 3 x 5.2 us on the step's head, profiles/r4_bcql_timeline.txt)
+        G.clamp_(self._z_all, -0.5, 0.5)
 
         sd = self.seeds
         if self.vae_ns is not None:

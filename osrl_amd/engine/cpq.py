@@ -34,9 +34,6 @@ from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, lo
 # than the two 17 us collectives they take off the main chain.  Default "0" = round 4's placement (all four on the main
 # branch).
 DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather issued off the main branch") == "1"
-# single GPU: the VAE's optimizer step at the head of the side branch's second half instead of on the main chain
-# (C2 2256 vs 2240 steps/s, C4 2340 vs 2416: off)
-VAE_ADAM_SIDE = P.knob("OSRL_VAE_ADAM_SIDE", "0", "VAE Adam on the side branch") == "1"
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -279,9 +276,9 @@ class CPQEngine:
                 self._update("vae", 0.0)
                 ev_vae = par.mark(1)
         else:
-            # (single GPU, OSRL_VAE_ADAM_SIDE=1: the VAE's optimizer step at the head of the side branch's second half,
-            # in front of its only reader, instead of on the main chain -- an A/B switch, DESIGN_LOG round 5)
-            vae_adam_side = dp is None and par.enabled and VAE_ADAM_SIDE and not self.p_vae.can_fuse_adam()
+            # (single GPU, plan.vae_adam_side: the VAE's optimizer step at the head of the side branch's second half, in
+            # front of its only reader, instead of on the main chain -- +0.7 % at C2, DESIGN_LOG round 5)
+            vae_adam_side = dp is None and par.enabled and self.plan.vae_adam_side and not self.p_vae.can_fuse_adam()
             if vae_adam_side:
                 self._pr("vae_dw", 0)
                 self.p_vae.launch()
@@ -367,8 +364,8 @@ class CPQEngine:
         with par.on(0):
             if ev_vae is not None:
                 par.side[0].wait_event(ev_vae)
-            if dp is None and par.enabled and VAE_ADAM_SIDE and not self.p_vae.can_fuse_adam():
-                self._update("vae", 0.0)
+            if dp is None and par.enabled and self.plan.vae_adam_side and not self.p_vae.can_fuse_adam():
+                self._update("vae", 0.0)  # (engine/plan.py vae_adam_side: off the main chain, in front of its only reader)
             self._pr("enc_ood", 0)  # bench.py: HIP events around the dominant launch as it runs inside the step
             # (the KL rows of cpq.py:178-182 by the encoder launch itself: OSRL_TAIL_VAE_KL)
             self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl))

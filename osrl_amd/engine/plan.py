@@ -59,6 +59,7 @@ class CPQPlan:
     small_dw: bool            # critic / cost-critic dW on 32 x 32 tiles x 2 splits (fit beside the N*B encoder launch)
     ood_tile: int             # row tile of the N*B-row launches (80 = one workgroup per CU)
     vae_ns: bool              # the VAE phase as all-CU layer launches (csrc/vae_ns.hip)
+    vae_adam_side: bool       # single GPU: the VAE's optimizer step at the head of the side branch's second half
 
 
 def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> CPQPlan:
@@ -70,9 +71,14 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     ns_mode = knob("OSRL_VAE_NS", "auto", "VAE phase as all-CU layer launches: 1 / 0 / auto")
     ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
     vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad)))
+    # the VAE's Adam off the main chain (its only reader this step is the side branch's N*B-row encoder launch): C2
+    # 2260 / 2260 / 2267 vs 2250 / 2242 / 2245 steps/s (three A/B pairs, gpurun_out/r5h); with the all-CU VAE launches the
+    # side branch is the longer one and the same move costs 3 % (C4 2340 vs 2416, gpurun_out/r5d) -> only without them
+    side = {"1": True, "0": False}.get(knob("OSRL_VAE_ADAM_SIDE", "auto", "VAE Adam on the side branch: 1 / 0 / auto"),
+                                       B >= 1024 and not vae_ns)
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=5 if t5 else 0, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
-                   vae_ns=bool(vae_ns))
+                   vae_ns=bool(vae_ns), vae_adam_side=bool(side))
 
 
 def vae_ns_auto(rows: int, od: int, ad: int) -> bool:
@@ -104,13 +110,13 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 # rule that moves one of these rows is a deliberate act with a measurement behind it (DESIGN_LOG)
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
-           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=False)),
+           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=False, vae_adam_side=True)),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
-           CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True)),
+           CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False)),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
            BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4),
-                  CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False)),
+                  CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False, vae_adam_side=False)),
 }
 
 

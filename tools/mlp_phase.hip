@@ -8,6 +8,9 @@ extern "C" int osrl_vae_latent_bwd(const float*, const float*, const float*, int
                                    void*) { return -1; }
 extern "C" int osrl_gauss_head(const float*, const float*, int32_t, int32_t, float, float*, float*, float*, void*) { return -1; }
 extern "C" int osrl_gauss_ood_sample(const float*, const float*, int32_t, int32_t, int32_t, float*, void*) { return -1; }
+extern "C" int osrl_vae_kl_rows(const float*, int32_t, int32_t, float*, void*) { return -1; }
+// (the 64-row twin of the N*B-row kernels is a second compile of mlp_nb.hip, mlp_nb64.hip: not part of this build)
+int osrl_launch_fwd_nb64(const osrl_mlp_t*, const osrl_rows_t*, const osrl_mlp_acts_t*, hipStream_t, float*, int) { return -1; }
 namespace osrl_argmem {
 Arena* current() { return nullptr; }  // (defined in optim.hip in the library)
 }
