@@ -339,6 +339,45 @@ def in_step_us(eng, iters=40):
     return res
 
 
+def in_graph_us(eng, sites=("enc_ood", "costold_ood"), iters=60):
+    """Durations of named launches INSIDE THE REPLAYED GRAPH: the step is captured with a one-lane stamp launch
+    (osrl_stamp_realtime: the device's 100 MHz real-time counter) in front of and behind each named launch, on that
+    launch's own stream, plus one more right behind the closing stamp (stamp-to-stamp = one queue boundary, subtracted
+    twice: the bracket holds two); after each replay the stamps are read.  This is the figure the rocprofv3 --kernel-trace
+    average of the same kernel (profiles/) has to agree with -- HIP events around EAGERLY issued launches (in_step_us)
+    do not: the host cannot keep two queues fed the way a replayed graph does, so the overlap differs.  The stamped
+    graph is thrown away afterwards (the timed region captures a clean one).  Returns {site: (mean us, median us)}."""
+    buf = torch.zeros(3 * len(sites), dtype=torch.int64, device=eng.dev)
+    snap = eng._snapshot()
+    res = {}
+    try:
+        eng._probe = {k: buf.data_ptr() + 24 * i for i, k in enumerate(sites)}
+        eng.graph = None
+        eng.capture()
+        samples = {k: [] for k in sites}  # (+ "<site>/boundary": the stamp-to-stamp cost that was subtracted twice)
+        for it in range(5 + iters):
+            eng.graph.replay()
+            eng.st.host_step += 1
+            torch.cuda.synchronize()
+            if it >= 5:
+                v = buf.tolist()
+                for i, k in enumerate(sites):
+                    # (t1 - t0) = the launch + TWO queue boundaries (stamp -> launch, launch -> stamp); the adjacent pair
+                    # (t2 - t1) is one such boundary measured in place; 10 ns ticks -> us
+                    pair = (v[3 * i + 2] - v[3 * i + 1]) * 0.01
+                    samples[k].append((v[3 * i + 1] - v[3 * i]) * 0.01 - 2.0 * pair)
+                    samples.setdefault(k + "/boundary", []).append(pair)
+        for k, ts in samples.items():
+            ts.sort()
+            res[k] = (float(np.mean(ts)), float(ts[len(ts) // 2]))
+    finally:
+        eng._probe = None
+        eng.graph = None
+        torch.cuda.synchronize()
+        eng._restore(snap)
+    return res
+
+
 def collectives_in_step(eng, dp, iters=30):
     """Every collective of the data-parallel step AS IT RUNS INSIDE THE STEP: the step body is issued eagerly on the
     graph's two streams (as in_step_us does) with the DataParallel hook recording HIP events around each collective on
@@ -386,6 +425,11 @@ def roofline(eng, cfg_name="c2"):
     # issue out of step with its peers -- N > 1 reports the isolated figure only.  It goes first: its
     # step bodies leave a sampled minibatch and the N*B sampled actions in the buffers the isolated launches read
     sites = in_step_us(eng) if eng.dist is None else {}
+    # ... and the two N*B-row launches as they run inside the REPLAYED graph (device-side stamps): the headline figure
+    try:
+        graph_sites = in_graph_us(eng) if eng.dist is None and eng.replay is not None else {}
+    except Exception as e:  # (a failing probe must not take the line down: the eager figure is reported instead)
+        graph_sites = {"error": repr(e)[:200]}
     if eng.dist is not None:  # no step has run yet: time the launches on data, not on the zero-initialised buffers
         eng.obs.normal_()
         eng.sampled.normal_()
@@ -406,7 +450,11 @@ def roofline(eng, cfg_name="c2"):
     for name, (run, fn, site, sym) in cands.items():
         t = time_kernel(fn)
         fl = mlp_fwd_flops(run)
-        mean_us, med_us = sites.get(site, (float("nan"), float("nan")))
+        mean_us, med_us = graph_sites.get(site, (float("nan"), float("nan"))) if "error" not in graph_sites else (float("nan"),) * 2
+        how = "graph"
+        if mean_us != mean_us:  # no in-graph figure: the eager two-stream probe
+            mean_us, med_us = sites.get(site, (float("nan"), float("nan")))
+            how = "eager"
         in_run = mean_us == mean_us
         d = run.net.dims
         # algorithmic bytes of the launch as SURVEY.md 8d counts them: every row of the virtual [N*B, in] input, the weights
@@ -421,6 +469,8 @@ def roofline(eng, cfg_name="c2"):
                          in_step_us=round(mean_us, 2) if in_run else None,
                          in_step_us_median=round(med_us, 2) if in_run else None,
                          in_step_frac=round(fl / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4) if in_run else None,
+                         in_step_how=how if in_run else None,
+                         stamp_boundary_us=round(graph_sites[site + "/boundary"][0], 2) if site + "/boundary" in graph_sites else None, in_step_eager_us=round(sites[site][0], 2) if site in sites else None,
                          algorithmic_bytes=int(alg), distinct_bytes=int(distinct), traffic=pmc.get(name), wg_cap=int(run.fwd_c.wg_cap), _fl=fl, _t=t,
                          _us=mean_us)
     have_run = all(v["in_step_us"] is not None for v in res.values())
@@ -431,12 +481,17 @@ def roofline(eng, cfg_name="c2"):
     ach = r["_fl"] / (r["_us"] * 1e-6) / 1e12 if have_run else ach_iso
     out = {"bound": "mfma", "kernel": dom, "symbol": r["symbol"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-           "frac_is": "in-run (inside the step, beside the other branch's launches); kernel = the launch with the largest "
-                      "in-step duration" if have_run else "isolated (N > 1: no in-step probe)",
+           "frac_is": ("in-run: the launch inside the REPLAYED graph, bracketed by device-side 100 MHz stamps on its own stream "
+                       "(in_graph_us; the rocprofv3 --kernel-trace average of the same kernel under profiles/ is the cross-"
+                       "check); kernel = the launch with the largest in-step duration" if r.get("in_step_how") == "graph" else
+                       "in-run (eagerly issued two-stream step body, HIP events)") if have_run else
+                      "isolated (N > 1: no in-step probe)",
            "isolated_achieved": round(ach_iso, 3), "isolated_frac": round(ach_iso / PEAK_FP32_TFLOPS, 4),
            "traffic": r["traffic"], "traffic_source": traffic_src if r["traffic"] is not None else None,
            "algorithmic_bytes": r["algorithmic_bytes"],
+           # five launches of the step by HIP events around EAGERLY issued launches (two streams): indicative only
            "in_step_sites_us": {k: round(v[0], 2) for k, v in sites.items()} or None,
+           "in_step_sites_how": "eager two-stream step body, HIP events (not the replayed graph)" if sites else None,
            "isolated_us": r["isolated_us"], "in_step_us": r["in_step_us"], "in_step_us_median": r["in_step_us_median"],
            "in_step_frac": r["in_step_frac"],
            "step_frac": None,  # main(): algorithmic GFLOP per step / measured ms per step / peak

@@ -829,6 +829,10 @@ int osrl_policy_destroy(void* handle);
  * 0 host memory (every wave then fetches its launch arguments over PCIe; see osrl_args_begin), -1 unknown.  dev_scratch:
  * 8 bytes of device memory.  Synchronises `stream`; not for the hot path. */
 int osrl_kernarg_probe(uint64_t* dev_scratch, int32_t* where, uint64_t* address, void* stream);
+/* (new, diagnostics) out[0] = the device's constant 100 MHz real-time counter when this one-lane launch executes.
+ * Asynchronous, hipGraph-capturable: two of them around a launch of a captured step give that launch's duration inside
+ * the replayed graph (bench.py `roofline.frac`; torch has no counterpart: its events cannot be timed inside a capture). */
+int osrl_stamp_realtime(uint64_t* out, void* stream);
 
 const char* osrl_version(void);
 

@@ -247,6 +247,7 @@ PROTOTYPES = {
     "osrl_clip_grad_scale": [_fp, _i64, _f32, _fp, _i32, _fp, _vp],
     "osrl_cdt_temperature_step": [_fp, _fp, _fp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     "osrl_kernarg_probe": [_vp, _P(_i32), _P(_u64), _vp],
+    "osrl_stamp_realtime": [_vp, _vp],
     "osrl_mlp_regress_step": [_P(MlpStepT), _vp],
     "osrl_args_begin": [_vp, _vp, _i64, _i64, _i32],
     "osrl_args_end": [_P(_i64), _P(_i32), _P(_i32), _P(_i32)],

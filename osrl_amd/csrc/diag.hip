@@ -15,7 +15,21 @@ namespace {
 __global__ void kernarg_probe_kernel(uint64_t* out) {
   if (threadIdx.x == 0) out[0] = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
 }
+__global__ void stamp_kernel(uint64_t* out) {
+  if (threadIdx.x == 0) out[0] = __builtin_amdgcn_s_memrealtime();  // the constant 100 MHz counter (10 ns ticks)
+}
 }  // namespace
+
+// osrl_stamp_realtime: one lane writes the device's 100 MHz real-time counter to out[0].  Asynchronous and
+// hipGraph-capturable: bench.py brackets a launch INSIDE the captured step with two of these (on the launch's own
+// stream) and reads the difference after a replay -- how long the launch takes inside the replayed graph, which HIP
+// events around eagerly issued launches do not tell (the host cannot keep two queues fed: the overlap differs).
+extern "C" int osrl_stamp_realtime(uint64_t* out, void* stream) {
+  if (!out) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  return (int)hipGetLastError();
+}
 
 // where: 1 = device memory (a GPU agent owns the allocation), 0 = host memory, -1 = unknown to the pointer database.
 // dev_scratch: 8 bytes of device memory.  Synchronises the stream (diagnostic call, not for the hot path).

@@ -213,7 +213,14 @@ class CPQEngine:
     def _pr(self, site: str, i: int) -> None:
         """bench.py's in-step probe: HIP events (on the launching stream) around a named launch of the step body."""
         if self._probe is not None and site in self._probe:
-            self._probe[site][i].record()
+            p = self._probe[site]
+            if isinstance(p, int):  # device address of three uint64: stamps INSIDE the captured graph (osrl_stamp_realtime)
+                cs = torch.cuda.current_stream().cuda_stream
+                L.check(L.load().osrl_stamp_realtime(p + 8 * i, cs), "osrl_stamp_realtime")
+                if i == 1:  # a second stamp right behind the closing one: the cost of a stamp itself (bench.py subtracts it)
+                    L.check(L.load().osrl_stamp_realtime(p + 16, cs), "osrl_stamp_realtime")
+            else:
+                p[i].record()
 
     def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
         """One step, single GPU or data parallel (``self.dist``): the launch plan below.  Data parallel adds four
