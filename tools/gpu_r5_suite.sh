@@ -1,0 +1,6 @@
+#!/bin/bash
+# the full GPU suite as the driver runs it at round end (+ durations of the slowest tests)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r5suite; rm -rf $O; mkdir -p $O
+timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest.log 2>&1; tail -25 $O/pytest.log
