@@ -71,22 +71,24 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     ns_mode = knob("OSRL_VAE_NS", "auto", "VAE phase as all-CU layer launches: 1 / 0 / auto")
     ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
     vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad)))
-    # the VAE's Adam off the main chain (its only reader this step is the side branch's N*B-row encoder launch): C2
-    # 2260 / 2260 / 2267 vs 2250 / 2242 / 2245 steps/s (three A/B pairs, gpurun_out/r5h); with the all-CU VAE launches the
-    # side branch is the longer one and the same move costs 3 % (C4 2340 vs 2416, gpurun_out/r5d) -> only without them
+    # the VAE's Adam off the main chain (its only reader this step is the side branch's N*B-row encoder launch): C2 +0.7 %
+    # with the fused VAE launches (gpurun_out/r5h), +1.1 % with the all-CU ones (r5k2).  At C4 the side branch is the longer
+    # one -- its action draws are four launches of their own there (head_tails off) -- and the same move costs 3 % (2340 vs
+    # 2416, gpurun_out/r5d): the optimizer step goes where the draws ride on the actor launch
     side = {"1": True, "0": False}.get(knob("OSRL_VAE_ADAM_SIDE", "auto", "VAE Adam on the side branch: 1 / 0 / auto"),
-                                       B >= 1024 and not vae_ns)
+                                       B >= 1024 and bool(head_tails))
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=5 if t5 else 0, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
                    vae_ns=bool(vae_ns), vae_adam_side=bool(side))
 
 
 def vae_ns_auto(rows: int, od: int, ad: int) -> bool:
-    """Where the five all-CU VAE launches beat the four fused ones INSIDE the step (A/B on MI355X, DESIGN_LOG round 5,
-    gpurun_out/r5a): C4's (17, 6) at 2048 rows +4.5 %; C2's (76, 2) at 2048 rows +0.2 % (noise); C3's (33, 8) at 4096 rows
-    -3.6 % (two rounds of 48-row tiles against one round of 256 fused 16-row tiles).  The rule is those three points, not
-    a model: one round of tiles (<= 2048 rows) and a first layer of <= 48 input columns (three k-steps)."""
-    return 1024 <= rows <= 2048 and od + ad <= 48
+    """Where the five all-CU VAE launches beat the four fused ones INSIDE the step (A/B on MI355X, DESIGN_LOG round 5):
+    C4's (17, 6) at 2048 rows +4.5 % (gpurun_out/r5a); C2's (76, 2) at 2048 rows +0.2 % on their own but +1.1 % together
+    with the VAE's Adam on the side branch (three pairs, gpurun_out/r5k2: 2280 / 2274 / 2282 vs 2250 / 2257 / 2252); C3's
+    (33, 8) at 4096 rows -3.6 % (two rounds of 48-row tiles against one round of 256 fused 16-row tiles).  The rule is
+    those points, not a model: one round of tiles."""
+    return 1024 <= rows <= 2048
 
 
 @dataclass(frozen=True)
@@ -110,7 +112,7 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 # rule that moves one of these rows is a deliberate act with a measurement behind it (DESIGN_LOG)
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
-           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=False, vae_adam_side=True)),
+           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True)),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False)),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),

@@ -206,4 +206,7 @@ def test_plan_rows_are_pinned(monkeypatch):
     # the seeded backward launches, never outside the library's shapes
     assert P.cpq_plan(17, 6, 2048, 400, 10).vae_ns and not P.cpq_plan(17, 6, 2048, 400, 10, seeds=False).vae_ns
     assert not P.cpq_plan(17, 6, 4096, 400, 10).vae_ns and not P.cpq_plan(17, 6, 2048, 256, 10).vae_ns
-    assert not P.cpq_plan(76, 2, 2048, 400, 10).vae_ns and not P.cpq_plan(17, 6, 512, 400, 10).vae_ns
+    assert P.cpq_plan(76, 2, 2048, 400, 10).vae_ns and not P.cpq_plan(17, 6, 512, 400, 10).vae_ns
+    # the VAE's Adam goes to the side branch where the action draws ride on the actor launch (C2), not where they are four
+    # launches of their own on that branch (C4)
+    assert P.cpq_plan(76, 2, 2048, 400, 10).vae_adam_side and not P.cpq_plan(17, 6, 2048, 400, 10).vae_adam_side
