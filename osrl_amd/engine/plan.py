@@ -102,7 +102,8 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
     t5 = knob("OSRL_VAE_DW_T5", "1") == "1" and vae_hidden % 80 == 0 and B >= 1024
     ns_mode = knob("OSRL_VAE_NS", "auto")
     ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
-    vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad)))
+    # (BCQ-Lag: the all-CU VAE launches only on request -- the one measurement there is C3's 4096 rows, -3.6 %)
+    vae_ns = seeds and ns_shape and ns_mode == "1"
     return BCQLPlan(vae_dw_tile=5 if t5 else 0,
                     target_tile=int(knob("OSRL_BCQ_TILE", "80", "row tile of BCQ-Lag's N*B-row target pipelines")),
                     vae_ns=bool(vae_ns))

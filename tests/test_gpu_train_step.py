@@ -568,16 +568,21 @@ def _random_cases():
 
 
 @pytest.mark.parametrize("c", _random_cases(), ids=lambda c: f"{c.name}-{c.od}x{c.ad}-B{c.B}-V{c.vae_hidden}")
-def test_random_shape_tuples_match_the_oracle(c):
+def test_random_shape_tuples_match_the_oracle(c, monkeypatch):
     """One train step of whatever plan the chooser picks for an arbitrary shape == the pinned oracle (fp32 and fp64, the
     closer one): statistics <= 1e-5, parameters <= 1e-4, the dual variable / PID state.  With the pinned rows of
     engine/plan.py (tests/test_host_cpu.py) this leaves no reachable plan untested."""
+    if c.algo == "bcql" and c.name.startswith("rand_ns"):  # BCQ-Lag takes the all-CU VAE launches on request only
+        monkeypatch.setenv("OSRL_LAB", "1")
+        monkeypatch.setenv("OSRL_VAE_NS", "1")
     m, tr, lg = build_gpu(c)
     o32, o64 = build_oracle(c, np.float32), build_oracle(c, np.float64)
     b = gpu_batch(c)
     gpu_step(tr, c, b, 0)
     s32, s64 = oracle_step(o32, c, 0), oracle_step(o64, c, 0)
     eng = m._engine
+    if c.name.startswith("rand_ns"):
+        assert eng.vae_ns is not None, "this case is meant to run the all-CU VAE launches"
     _note(f"{c.name}: plan {eng.plan}; all-CU VAE launches {'on' if eng.vae_ns is not None else 'off'}")
     if eng.plan.vae_ns:
         assert eng.vae_ns is not None, "the plan chose the all-CU VAE launches but the library refused the shape"
