@@ -47,6 +47,14 @@ constexpr int kPL = 68;                      // row stride of a wave's private [
 constexpr int kNKW = 7;                      // k-steps per wave, upper bound (H <= 448)
 constexpr float kLsMin = -4.0f, kLsMax = 15.0f;  // net.py:325
 
+#ifdef VAE_NS_STAMPS  // tools/vae_ns_lab.hip: per-phase 100 MHz stamps of wave 0 of every workgroup (lab builds only)
+__device__ unsigned long long g_ns_stamp[512][12];
+#define NS_STAMP(i)                                                                                     \
+  if (threadIdx.x == 0 && blockIdx.x < 512) g_ns_stamp[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define NS_STAMP(i)
+#endif
+
 struct NsArgs {
   int rows, od, ad, L, H, row_tiles, col_groups;
   float max_action, beta, inv_rows;
@@ -309,6 +317,7 @@ __device__ __forceinline__ void gen_body(AR a) {
   const int cg_inv = 65536 / n_cg + 1;  // (r * cg_inv) >> 16 == r / n_cg for r < 48, n_cg <= 5
   int ks0, cnt;
   k_range(H >> 4, wave, &ks0, &cnt);
+  NS_STAMP(0);
   float* S = lds;                                             // [48][kSL] row tile of the prologue
   float* priv = lds + kBM * kSL + (size_t)wave * kBM * kPL;   // [48][kPL] this wave's A columns
   // main-product weights: forward pack of layer 1 (row stride H) / backward pack (row stride H + 16)
@@ -344,6 +353,7 @@ __device__ __forceinline__ void gen_body(AR a) {
       }
   };
   f32x4 ax[12];
+  f32x4 bvh = f32x4{0.f, 0.f, 0.f, 0.f};
   auto issue_aux = [&](int jh0, int ch) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -352,9 +362,14 @@ __device__ __forceinline__ void gen_body(AR a) {
       const int col = (ks0 + jh0) * 16 + (4 * c4 < 16 * ch ? 4 * c4 : 0);
       ax[i] = *reinterpret_cast<const f32x4*>(aux + (size_t)grc * H + col);
     }
+    // (the fix-up's bias columns depend on the lane alone: requested here, not in the fix-up -- a load there is a round trip
+    // in front of the half's k-steps, 0.8 us per half in the phase stamps of tools/vae_ns_lab.hip)
+    if (MODE == MODE_DEC_FWD)
+      bvh = *reinterpret_cast<const f32x4*>(a.db0 + (ks0 + jh0) * 16 + (4 * (lane & 15) < 16 * ch ? 4 * (lane & 15) : 0));
   };
   issue_small(0, ch0);
   issue_aux(0, ch0);
+  NS_STAMP(1);
   // ---- prologue: the 48 rows' slabs -> row-local results -> S
   constexpr int SWD = 16 * NKS;
   float l0 = 0.f, l1 = 0.f;
@@ -519,6 +534,7 @@ __device__ __forceinline__ void gen_body(AR a) {
           for (int r = 0; r < 4; ++r) priv[(rb * 16 + kq * 4 + r) * kPL + jj * 16 + m] = t3[rb][r];
       }
     }
+    NS_STAMP(3 + 3 * hsel);
     // fix-up, element-wise in row-major order; the generated rows leave from here (each column group a share of the rows)
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -527,9 +543,8 @@ __device__ __forceinline__ void gen_body(AR a) {
         const int gk = (ks0 + jh0) * 16 + 4 * c4;
         f32x4 v = *reinterpret_cast<const f32x4*>(priv + r * kPL + 4 * c4);
         if (MODE == MODE_DEC_FWD) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.db0 + gk);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] + ax[i][q] + bv[q], 0.f);
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] + ax[i][q] + bvh[q], 0.f);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ax[i][q] > 0.f ? v[q] : 0.f;
@@ -545,6 +560,7 @@ __device__ __forceinline__ void gen_body(AR a) {
       issue_aux(ch0, ch1);
     }
     if (hsel == 1) issue_epilogue();
+    NS_STAMP(4 + 3 * hsel);
     // main k-steps of this half
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -568,13 +584,17 @@ __device__ __forceinline__ void gen_body(AR a) {
       }
     }
   };
+  NS_STAMP(2);
   half(0, ch0, 0);
+  NS_STAMP(5);
   half(4, ch1, 1);
+  NS_STAMP(8);
 
   // ---- the four partial tiles -> sum -> epilogue
   __syncthreads();  // every wave is through with S and its private region: the partial buffers alias them
   park_partials(lds, wave, m, kq, acc);
   __syncthreads();
+  NS_STAMP(9);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
@@ -596,10 +616,12 @@ __device__ __forceinline__ void gen_body(AR a) {
       if (MODE != MODE_ENC_BWD) *reinterpret_cast<f32x4*>(lds + r * kLD + 4 * c4) = s;
     }
   }
+  NS_STAMP(10);
   if (MODE != MODE_ENC_BWD) {
     __syncthreads();
     slab_product<1>(lds, wave, m, kq, wb, MODE == MODE_DEC_FWD ? a.slabD : a.slabX, cg, row0, rows);
   }
+  NS_STAMP(11);
   if (MODE == MODE_DEC_BWD && cg == 0) {
     // the logged loss: the last first-column-group workgroup to get here sums every tile's partials in tile order
     // (wait-free: a workgroup is the last one or leaves; protocol of mlp.hip's seeded backward)

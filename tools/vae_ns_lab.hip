@@ -3,6 +3,7 @@
 // double-precision CPU evaluation of VAE.forward + loss + autograd (net.py:319-339, cpq.py:125-135), and times the two
 // calls.  No torch:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/vae_ns_lab.hip -o tools/_lab/vae_ns_lab && tools/_lab/vae_ns_lab
+#define VAE_NS_STAMPS 1
 #include "../osrl_amd/csrc/vae_ns.hip"
 
 static osrl_argmem::Arena g_ar{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
@@ -326,6 +327,34 @@ static int run_case(int rows, int od, int ad, int H, int rows_global) {
       printf("  %s %.2f us", names[k], ms * 1e3 / reps);
     }
     printf("\n");
+  }
+  {  // phase stamps (wave 0 of every workgroup, 10 ns ticks) of the three generated-operand launches, one eager pass each
+    const char* ph[11] = {"issue", "prologue+barrier", "h0 small", "h0 fix-up", "h0 main", "h1 small", "h1 fix-up", "h1 main",
+                          "barrier+park+barrier", "reduce+store", "slab product"};
+    NsArgs na;
+    fill(&v, &na, true);
+    const int nks = (od + L - 1) / 16 - od / 16 + 1;
+    for (int k = 0; k < 3; ++k) {
+      if (k == 0) { if (nks == 1) NS_LAUNCH(vae_ns_gen_kernel, MODE_DEC_FWD, 1), wide_grid(na), 256, kWideLds, nullptr, na); else NS_LAUNCH(vae_ns_gen_kernel, MODE_DEC_FWD, 2), wide_grid(na), 256, kWideLds, nullptr, na); }
+      if (k == 1) NS_LAUNCH(vae_ns_gen_kernel, MODE_DEC_BWD, 1), wide_grid(na), 256, kWideLds, nullptr, na);
+      if (k == 2) { if (2 * L <= 16) NS_LAUNCH(vae_ns_gen_kernel, MODE_ENC_BWD, 1), wide_grid(na), 256, kWideLds, nullptr, na); else NS_LAUNCH(vae_ns_gen_kernel, MODE_ENC_BWD, 2), wide_grid(na), 256, kWideLds, nullptr, na); }
+      CK(hipDeviceSynchronize());
+      static unsigned long long st[512][12];
+      CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ns_stamp), sizeof(st)));
+      const int nwg = wide_grid(na) < 512 ? wide_grid(na) : 512;
+      double acc[11] = {0};
+      int live = 0;
+      for (int g = 0; g < nwg; ++g) {
+        if (st[g][11] <= st[g][0]) continue;  // (an id beyond the last tile returns before its first stamp)
+        ++live;
+        for (int i = 0; i < 11; ++i) acc[i] += (double)(st[g][i + 1] - st[g][i]) * 0.01;
+      }
+      printf("  phases of %s (us, mean of %d workgroups):", k == 0 ? "dec wide" : k == 1 ? "dec wide^T" : "enc wide^T", live);
+      double tot = 0;
+      for (int i = 0; i < 11; ++i) { printf(" %s %.2f", ph[i], acc[i] / (live ? live : 1)); tot += acc[i] / (live ? live : 1); }
+      printf("  total %.2f\n", tot);
+      CK(hipMemset(st, 0, 0));
+    }
   }
   printf("  replayed graph: forward + backward %.2f us  (forward alone %.2f, backward alone %.2f)\n", g_ms * 1e3 / reps,
          gf_ms * 1e3 / reps, gb_ms * 1e3 / reps);
