@@ -411,6 +411,12 @@ int osrl_adam_step_packed(float* p, float* m, float* v, float* tgt, const float*
 /* flat[i] = sum_s slabs[s][i]  (pre-reduction before an RCCL all-reduce in the data-parallel path) */
 int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
                       void* stream);
+/* The same sum with a row-split count per 1024-float chunk of the flat gradient (counts: device bytes, ceil(n / 1024) of
+ * them, each >= 1): a group whose ranges were written by plans with different split counts (CDT: cdt.py:396-400 needs the
+ * summed gradient for clip_grad_norm_) reads only the slabs that hold something.  Same bits as osrl_reduce_slabs with the
+ * largest count, since the slabs beyond a range's own count are zero. */
+int osrl_reduce_slabs_counts(float* flat, const float* slabs, const uint8_t* counts, int64_t slab_stride, int64_t n,
+                             void* stream);
 
 /* ---- device-resident argument blocks for the launches of a captured step (csrc/argmem.h) --------------------
  * New (nothing in the reference to mirror: torch passes kernel arguments through the runtime).  The fused-MLP
@@ -591,6 +597,12 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
  * the keep-multiplier of `drop` to `delta` on the way in (== osrl_dropout(delta) then osrl_layernorm_fwd, bit for bit;
  * drop NULL or p <= 0: the plain call); backward also writes dx_dropped = dx * keep-multiplier of `drop` (the gradient
  * that enters the residual branch whose output fed this LayerNorm's input: == osrl_dropout on dx). */
+/* slab == NULL in the two backward calls: the per-workgroup partials of (dgamma | dbeta) stay in partial_ws
+ * ([n_parts, 2E]) and the caller sums them later -- osrl_layernorm_param_reduce does it for up to 16 LayerNorms in ONE
+ * launch (site k: partials at partial_ws + k * ws_stride, results at slab[g_offs[k] ..], slab[b_offs[k] ..]; g_offs /
+ * b_offs are HOST arrays).  Same bits as the per-call reduction (net.py:402-403,427,440 under autograd). */
+int osrl_layernorm_param_reduce(const float* partial_ws, int64_t ws_stride, int32_t n_sites, int32_t n_parts, int32_t E,
+                                float* slab, const int64_t* g_offs, const int64_t* b_offs, void* stream);
 int osrl_layernorm_fwd_drop(const float* x, const float* delta, const osrl_dropout_t* drop, const float* gamma,
                             const float* beta, float* xout, float* y, float* stats, int32_t M, int32_t E,
                             void* stream);
@@ -608,8 +620,8 @@ int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, i
  * y[i] = x[i] * keep_i / (1-p), may run in place.  keep_i is a pure function of (seed, st->step, site, i)
  * (Philox4x32-10), so calling it again on the incoming gradient IS the backward pass; nothing is stored.
  * `drop` of the attention entry points is the attention-probability dropout of nn.MultiheadAttention
- * (net.py:406-409), NULL or p = 0 = off; its logical mask layout is [B*H, S, 16, 8] with element
- * ((bh*S + i)*16 + j%16)*8 + j/16 <-> P[bh][i][j], so osrl_dropout on a ones tensor of that size exports it. */
+ * (net.py:406-409), NULL or p = 0 = off; its logical mask layout is [B*H, S, Sp] (Sp = S rounded up to 16) with element
+ * (bh*S + i)*Sp + j <-> P[bh][i][j], so osrl_dropout on a ones tensor of that size exports it. */
 int osrl_dropout(const float* x, float* y, int64_t n, const osrl_dropout_t* drop, void* stream);
 /* nn.GELU() (exact erf) and its derivative; n a multiple of 4 */
 int osrl_gelu_fwd(const float* x, float* y, int64_t n, void* stream);

@@ -200,6 +200,8 @@ PROTOTYPES = {
     "osrl_adam_step_packed": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,
                               _vp, _vp, _vp, _fp, _fp, _fp, _vp],
     "osrl_reduce_slabs": [_fp, _fp, _i32, _i64, _i64, _vp],
+    "osrl_reduce_slabs_counts": [_fp, _fp, _vp, _i64, _i64, _vp],
+    "osrl_layernorm_param_reduce": [_fp, _i64, _i32, _i32, _i32, _fp, _vp, _vp, _vp],
     "osrl_randn_fill": [_fp, _i64, _u64, _u32, _vp, _vp],
     "osrl_replay_gather": [_i32, _P(_fp), _P(_fp), _P(_i32), _P(_f32), _i64, _i32, _vp, _u64, _u32, _vp, _vp],
     "osrl_seq_window_gather": [_fp, _fp, _fp, _fp, _fp, _vp, _vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _fp, _fp,

@@ -67,6 +67,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          # kernel arguments in host memory those s_loads are PCIe round trips at the head of every wave: CPQ step
          # 1884 -> 2092 steps/s there, 2176 -> 2190 with device-resident kernargs (profiles/r3_kernarg_ab.txt)
          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+# per-file additions.  cdt.hip: its only MFMA users are the attention kernels, whose accumulators are consumed by vector
+# instructions right away (mask, softmax, dS) -- results in AGPRs cost one v_accvgpr_read per element (192 in the
+# backward's listing); with the VGPR form the register file is one pool (160 -> 131 registers) and the reads are gone
+# (tools/attn_lab.hip: backward 263.6 -> 258.8 us at C5's shape)
+FILE_FLAGS = {"cdt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 OBJDIR = os.path.join(LIBDIR, "obj")  # git-ignored (*.o); the objects are a build cache only
 
 
@@ -83,7 +88,7 @@ def _build_locked(verbose: bool, force: bool = False) -> str:
         stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj)
                                                        for d in [src] + extra + common)
         if stale:
-            cmd = [hip] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hip] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             jobs.append((s, subprocess.Popen(cmd)))

@@ -540,6 +540,39 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
   }
 }
 
+// the same reduction for up to 16 LayerNorms in one launch (blockIdx.y = site): the eight reductions of a 3-layer step
+// were eight 5 us launches in the backward chain
+struct LnSites {
+  int64_t g_off[16], b_off[16];
+};
+__global__ __launch_bounds__(1024) void ln_param_reduce_many_kernel(const float* __restrict__ partial, int64_t ws_stride,
+                                                                    int nparts, int E, float* __restrict__ slab,
+                                                                    const LnSites sites) {
+  __shared__ float sm[16][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
+  partial += (size_t)blockIdx.y * ws_stride;
+  float s = 0.f;
+  if (i < 2 * E) {
+    int p = grp;
+    for (; p + 16 * 7 < nparts; p += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 16 * u) * 2 * E + i];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; p < nparts; p += 16) s += partial[(size_t)p * 2 * E + i];
+  }
+  sm[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && i < 2 * E) {
+    float t = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) t += sm[gq][cl];
+    slab[(i < E ? sites.g_off[blockIdx.y] + i : sites.b_off[blockIdx.y] + (i - E))] = t;
+  }
+}
+
 // ---------------- attention: one workgroup (4 waves) per (batch, head), fp32 MFMA 16x16x4 -------------
 // S tokens (<= 128) x head dim d (<= 64).  Q, K, (V | V^T), dO live in LDS as row-major tiles padded to
 // multiples of 16 (row stride = width + 8 floats => conflict-free ds_read_b128 fragments, as in mlp.hip);
@@ -682,13 +715,20 @@ __device__ __forceinline__ void attn_load_tile(const float* __restrict__ src, si
   else attn_load_tile_any(src, row_stride, S_, d, Sp, dp, dst, ld, dst_t, ld_t);
 }
 
-__device__ __forceinline__ void attn_key_valid(const AttnArgs& a, int b, int Sp, float* kvalid) {
+// key padding (net.py:433) as an ADDITIVE bias of the scaled scores: 0 for a valid key, -inf for a padded one (and for
+// the columns past S) -- one fma per score instead of a compare / select chain
+__device__ __forceinline__ void attn_key_bias(const AttnArgs& a, int b, int Sp, float* kbias) {
   const int T = (a.S - a.prefix) / a.rep;
   for (int j = threadIdx.x; j < Sp; j += blockDim.x) {
     const int t = j < a.prefix ? 0 : (j - a.prefix) / a.rep;
-    kvalid[j] = (j < a.S && a.mask[(size_t)b * T + t] > 0.f) ? 1.f : 0.f;
+    kbias[j] = (j < a.S && a.mask[(size_t)b * T + t] > 0.f) ? 0.f : -INFINITY;
   }
 }
+// softmax in base 2: the scores are scaled by log2(e) / sqrt(d) on the way out of the accumulators, so a probability is
+// ONE v_exp_f32 (exp2) behind a subtract -- expf is ~15 vector instructions, and vector instructions are what these
+// kernels are made of (profiles/r4_pmc_cdt_table.txt: 2970 per wave of the backward against 210 MFMAs)
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // one [16, 4-column] fragment of a row-major global matrix in frag_row layout: X[row0 + (lane & 15)][k0 + 4*(lane>>4) ..+3],
 // zero outside [0, rows) x [0, cols)
@@ -725,11 +765,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float *Ks = sm, *Vt = Ks + Sp * ldq, *kvalid = Vt + dp * ldp;
+  float *Ks = sm, *Vt = Ks + Sp * ldq, *kbias = Vt + dp * ldp;
   const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
   attn_load_tile(base + a.E, 3 * a.E, a.S, d, Sp, dp, Ks, ldq, nullptr, 0);
   attn_load_tile(base + 2 * a.E, 3 * a.E, a.S, d, Sp, dp, nullptr, 0, Vt, ldp);
-  attn_key_valid(a, b, Sp, kvalid);
+  attn_key_bias(a, b, Sp, kbias);
   const int nb = Sp >> 4, ncb = dp >> 4;
   // deal the row blocks, largest first, each to the least loaded wave (every wave computes the same deal)
   unsigned mine = 0;
@@ -744,8 +784,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
   }
   __syncthreads();
-  const float scale = 1.0f / sqrtf((float)d);
+  const float sc2 = kLog2e / sqrtf((float)d);
   const int q4 = 4 * (lane >> 4), m = lane & 15;
+  // causal mask (net.py:417-418): only the diagonal block of a row block holds keys j > i -- there, key q4 + r of the
+  // block against row m of the block
+  const f32x4 dbias = {q4 + 0 <= m ? 0.f : -INFINITY, q4 + 1 <= m ? 0.f : -INFINITY, q4 + 2 <= m ? 0.f : -INFINITY,
+                       q4 + 3 <= m ? 0.f : -INFINITY};
   for (int ib = nb - 1; ib >= 0; --ib) {
     if (!((mine >> ib) & 1u)) continue;
     f32x4 qf[4];
@@ -764,11 +808,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (c < ncb) mfma4(s[jb], frag_row(Ks, ldq, jb * 16, c * 16, lane), qf[c]);
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kvalid + jb * 16 + q4);
+        f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + jb * 16 + q4);
+        if (jb == ib) kb += dbias;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = jb * 16 + q4 + r;
-          s[jb][r] = (j <= i && kv[r] > 0.f) ? s[jb][r] * scale : -INFINITY;
+          s[jb][r] = __builtin_fmaf(s[jb][r], sc2, kb[r]);
           mx = fmaxf(mx, s[jb][r]);
         }
       }
@@ -776,13 +820,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const bool live = i < a.S && mx > -INFINITY;
+    const float mxs = live ? mx : 0.f;  // (a row without a valid key: exp2(-inf - 0) = 0 everywhere, and 1 / sum is not used)
     float sum = 0.f;
 #pragma unroll
     for (int jb = 0; jb < NBMAX; ++jb) {
       if (jb <= ib) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = (live && s[jb][r] > -INFINITY) ? expf(s[jb][r] - mx) : 0.f;
+          const float e = exp2_fast(s[jb][r] - mxs);
           s[jb][r] = e;
           sum += e;
         }
@@ -857,18 +902,23 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nb = Sp >> 4, ncb = dp >> 4;
   const int q4 = 4 * (lane >> 4), m = lane & 15;
-  float *T0 = sm, *T1 = T0 + Sp * ldq, *rmax = T1 + Sp * ldq, *rinv = rmax + Sp, *rdot = rinv + Sp, *kvalid = rdot + Sp;
-  unsigned char* Mb = reinterpret_cast<unsigned char*>(kvalid + Sp);  // [Sp][Sp] keep flags
+  float *T0 = sm, *T1 = T0 + Sp * ldq, *rmax = T1 + Sp * ldq, *rinv = rmax + Sp, *rdot = rinv + Sp, *kbias = rdot + Sp;
+  unsigned char* Mb = reinterpret_cast<unsigned char*>(kbias + Sp);  // [Sp][Sp] keep flags
   const size_t ldg = 3 * (size_t)a.E;
   const float* __restrict__ base = a.qkv + (size_t)b * a.S * 3 * a.E + h * d;
   const float* __restrict__ dob = a.dout + (size_t)b * a.S * a.E + h * d;
   float* __restrict__ dq_out = a.dqkv + (size_t)b * a.S * 3 * a.E + h * d;
-  const float scale = 1.0f / sqrtf((float)d);
+  const float scale = 1.0f / sqrtf((float)d), sc2 = kLog2e * scale;
+  // causal mask on the diagonal blocks: pass A holds (row m, keys q4 + r), pass B (rows q4 + r, key m) of the block
+  const f32x4 dbiasA = {q4 + 0 <= m ? 0.f : -INFINITY, q4 + 1 <= m ? 0.f : -INFINITY, q4 + 2 <= m ? 0.f : -INFINITY,
+                        q4 + 3 <= m ? 0.f : -INFINITY};
+  const f32x4 dbiasB = {m <= q4 + 0 ? 0.f : -INFINITY, m <= q4 + 1 ? 0.f : -INFINITY, m <= q4 + 2 ? 0.f : -INFINITY,
+                        m <= q4 + 3 ? 0.f : -INFINITY};
 
   // ---- pass A: T0 = K, T1 = V
   attn_load_tile(base + a.E, ldg, a.S, d, Sp, dp, T0, ldq, nullptr, 0);
   attn_load_tile(base + 2 * a.E, ldg, a.S, d, Sp, dp, T1, ldq, nullptr, 0);
-  attn_key_valid(a, b, Sp, kvalid);
+  attn_key_bias(a, b, Sp, kbias);
   const unsigned my_rows = attn_deal(nb, wave, true), my_cols = attn_deal(nb, wave, false);
   __syncthreads();
   for (int ib = nb - 1; ib >= 0; --ib) {
@@ -895,11 +945,11 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
             mfma4(s[jb], frag_row(T0, ldq, jb * 16, c * 16, lane), qf[c]);
             mfma4(g[jb], frag_row(T1, ldq, jb * 16, c * 16, lane), dof[c]);  // dP'[i][j] = sum_c dO[i][c] V[j][c]
           }
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kvalid + jb * 16 + q4);
+        f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + jb * 16 + q4);
+        if (jb == ib) kb += dbiasA;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = jb * 16 + q4 + r;
-          s[jb][r] = (j <= i && kv[r] > 0.f) ? s[jb][r] * scale : -INFINITY;
+          s[jb][r] = __builtin_fmaf(s[jb][r], sc2, kb[r]);
           mx = fmaxf(mx, s[jb][r]);
         }
       }
@@ -907,13 +957,14 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const bool live = i < a.S && mx > -INFINITY;
+    const float mxs = live ? mx : 0.f;
     float sum = 0.f;
 #pragma unroll
     for (int jb = 0; jb < NBMAX; ++jb)
       if (jb <= ib) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = (live && s[jb][r] > -INFINITY) ? expf(s[jb][r] - mx) : 0.f;
+          const float e = exp2_fast(s[jb][r] - mxs);
           s[jb][r] = e;
           sum += e;
         }
@@ -948,7 +999,7 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
     rd += __shfl_xor(rd, 16);
     rd += __shfl_xor(rd, 32);
     if (q4 == 0) {
-      rmax[i] = live ? mx : 0.f;
+      rmax[i] = mxs;  // (base-2 domain, like the scores pass B rebuilds)
       rinv[i] = inv;
       rdot[i] = rd;
     }
@@ -992,7 +1043,7 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
       }
     }
     const int j = jb * 16 + m;
-    const bool jok = kvalid[j] > 0.f;
+    const float kbj = kbias[j];
     for (int ib = jb; ib < nb; ++ib) {
       f32x4 sv = {0.f, 0.f, 0.f, 0.f}, gp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1005,10 +1056,12 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
       const f32x4 ivv = *reinterpret_cast<const f32x4*>(rinv + ib * 16 + q4);
       const f32x4 rdv = *reinterpret_cast<const f32x4*>(rdot + ib * 16 + q4);
       f32x4 pp, dsv;
+      f32x4 kb = {kbj, kbj, kbj, kbj};
+      if (ib == jb) kb += dbiasB;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = ib * 16 + q4 + r;
-        const float P = (jok && j <= i) ? expf(sv[r] * scale - mxv[r]) * ivv[r] : 0.f;
+        const float P = exp2_fast(__builtin_fmaf(sv[r], sc2, kb[r]) - mxv[r]) * ivv[r];
         const float km = a.drop_thresh ? (Mb[i * Sp + j] ? a.drop_scale : 0.f) : 1.0f;
         pp[r] = P * km;                        // P'
         dsv[r] = pp[r] * gp[r] - P * rdv[r];   // dS
@@ -1034,6 +1087,432 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 3 : 2) void attn_bwd_kernel(const
         }
       }
   }
+}
+
+// ======================================================================================================================
+// Round 5: the same two kernels for head widths of 16 / 32 floats with 16-byte aligned rows -- every CDT configuration of
+// the reference (embedding_dim / num_heads = 128 / 8, examples/configs/cdt_configs.py:24-26; BASELINE C5: 256 / 8).  The
+// algorithm and the register layouts are those of attn_fwd_kernel / attn_bwd_kernel above (which stay for other widths);
+// what changed is everything AROUND the MFMAs, because that is what the kernels spend their time on
+// (profiles/r4_pmc_cdt_table.txt: 2970 vector instructions per wave of the backward against 210 MFMAs, 2.6 waves per SIMD):
+//   * the row block a wave works on is a TEMPLATE parameter: which key blocks exist, which one is the diagonal, every LDS
+//     offset and every register-array index are compile-time facts -- no exec-mask bookkeeping around `jb <= ib`;
+//   * 3 waves per (sample, head) at 5 row blocks: row block ib costs ib + 1 key blocks, so four waves carry 5 / 4 / 3 / 3
+//     blocks and wait a quarter of the time at the barriers; three carry 5 / 4 + 1 / 3 + 2.  (2 waves up to 4 row blocks,
+//     3 at 5-6, 4 at 7-8: the splits without a remainder);
+//   * base-2 softmax with additive masks (attn_key_bias, exp2_fast), the causal test only on diagonal blocks;
+//   * operand tiles by guard-free float4 copies (rows clamped, zeros selected afterwards), pointers formed once.
+template <int NW>
+__device__ __forceinline__ unsigned attn_deal_n(int nb, int wave, bool rows) {
+  unsigned mine = 0;
+  int load[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) load[k] = 0;
+  for (int t = 0; t < nb; ++t) {
+    const int blk = rows ? nb - 1 - t : t;
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < NW; ++k)
+      if (load[k] < load[w]) w = k;
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      if (k == w) load[k] += rows ? blk + 1 : nb - blk;
+    if (w == wave) mine |= 1u << blk;
+  }
+  return mine;
+}
+
+// [S, 16 NCB] slice of a row-major global matrix -> zero-padded LDS tile (row pitch 16 NCB + 8) and / or its transpose, in
+// two halves: every float4 of the slice is REQUESTED by attn_tile_ld (at most four per thread: S <= 16 NB, 64 NW threads,
+// see attn_launch_v) and lands in LDS by attn_tile_st -- so a workgroup puts all the global loads of a phase in flight
+// before it waits for the first one (two tiles + the key mask one after the other were three round trips, 5.5 us of a
+// 29 us wave life in tools/attn_lab.hip's stamps), and the second pass's tiles travel under the first pass's arithmetic
+template <int NCB, int NT>
+__device__ __forceinline__ void attn_tile_ld(const float* __restrict__ src, int row_stride, int S_, f32x4 (&v)[4]) {
+  constexpr int C4 = NCB * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = k * NT + (int)threadIdx.x;
+    const int i = idx / C4, c4 = idx % C4;
+    const int ic = i < S_ ? i : S_ - 1;
+    v[k] = *reinterpret_cast<const f32x4*>(src + __mul24(ic, row_stride) + 4 * c4);
+  }
+}
+template <int NCB, int NT>
+__device__ __forceinline__ void attn_tile_st(const f32x4 (&v)[4], int S_, int Sp, float* dst, float* dst_t, int ld_t) {
+  constexpr int C4 = NCB * 4, LD = NCB * 16 + 8;
+  const int total4 = Sp * C4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = k * NT + (int)threadIdx.x;
+    const int i = idx / C4, c4 = idx % C4;
+    if (idx < total4) {
+      const f32x4 w = i < S_ ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dst) *reinterpret_cast<f32x4*>(dst + i * LD + 4 * c4) = w;
+      if (dst_t) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst_t[(4 * c4 + t) * ld_t + i] = w[t];
+      }
+    }
+  }
+}
+// the key-padding bias in the same two halves (thread j < Sp owns key j; the division by `rep` as a multiply: exact for
+// j < 128)
+__device__ __forceinline__ float attn_key_mask_ld(const AttnArgs& a, int b, int Sp) {
+  const int T = (a.S - a.prefix) / a.rep, j = threadIdx.x;
+  const int t = j < a.prefix ? 0 : (int)(((float)(j - a.prefix) + 0.5f) * (1.0f / (float)a.rep));
+  return a.mask[(size_t)b * T + (j < a.S ? t : 0)];
+}
+__device__ __forceinline__ void attn_key_bias_st(const AttnArgs& a, float mv, int Sp, float* kbias) {
+  const int j = threadIdx.x;
+  if (j < Sp) kbias[j] = (j < a.S && mv > 0.f) ? 0.f : -INFINITY;
+}
+
+struct AttnCtx {
+  const float *T0, *T1;        // the two operand tiles of the running pass
+  float *rmax, *rinv, *rdot;   // per-row softmax statistics (pass A -> pass B)
+  const float* kbias;
+  unsigned char* Mb;           // keep flags [16 NB][16 NB]
+  const float *q, *dob;        // this (sample, head)'s q columns of qkv (k at + E, v at + 2 E) / dout columns
+  float* dq;                   // its dq columns of dqkv
+  int ldg, Sp, lane, m, q4, bh;
+  float scale, sc2;
+  f32x4 dbiasA, dbiasB;
+};
+
+// one [16, 4]-fragment per 16 columns of row (row0 + m) of a global matrix, zero for rows >= S
+template <int NCB>
+__device__ __forceinline__ void attn_gfrags(const float* __restrict__ base, int ld, int row, int S_, int q4, f32x4 (&f)[NCB]) {
+  const bool ok = row < S_;
+  const float* __restrict__ p = base + (__mul24(ok ? row : S_ - 1, ld) + q4);
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) f[c] = *reinterpret_cast<const f32x4*>(p + 16 * c);
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) f[c] = ok ? f[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// forward, row block IB of one (sample, head): O[IB] = dropout(softmax(Q[IB] K^T)) V
+template <int NB, int NCB, int IB>
+__device__ __forceinline__ void attn_fwd_rows(const AttnCtx& c, const AttnArgs& a, float* __restrict__ o_rows) {
+  constexpr int LDQ = 16 * NCB + 8, LDP = 16 * NB + 8;
+  const int lane = c.lane, m = c.m, q4 = c.q4;
+  const int row = IB * 16 + m;
+  f32x4 qf[NCB];
+  attn_gfrags<NCB>(c.q, c.ldg, row, a.S, q4, qf);
+  f32x4 s[IB + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb) {
+    s[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NCB; ++cc) mfma4(s[jb], frag_row(c.T0, LDQ, jb * 16, cc * 16, lane), qf[cc]);
+    f32x4 kb = *reinterpret_cast<const f32x4*>(c.kbias + jb * 16 + q4);
+    if (jb == IB) kb += c.dbiasA;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[jb][r] = __builtin_fmaf(s[jb][r], c.sc2, kb[r]);
+      mx = fmaxf(mx, s[jb][r]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const bool live = row < a.S && mx > -INFINITY;
+  const float mxs = live ? mx : 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[jb][r] = exp2_fast(s[jb][r] - mxs);
+      sum += s[jb][r];
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = live ? 1.0f / sum : 0.f;
+  if (a.drop_thresh && row < a.S) {
+#pragma unroll
+    for (int jb = 0; jb <= IB; ++jb) s[jb] *= attn_drop_mult4(a, c.bh, row, jb * 16 + q4, c.Sp);
+  }
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb) s[jb] *= inv;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jb = 0; jb <= IB; ++jb) mfma4(acc, s[jb], frag_row(c.T1, LDP, cb * 16, jb * 16, lane));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int io = IB * 16 + q4 + r;
+      if (io < a.S) o_rows[__mul24(io, a.E) + cb * 16 + m] = acc[r];
+    }
+  }
+}
+template <int NB, int NCB, int IB>
+__device__ __forceinline__ void attn_fwd_rows_from(const AttnCtx& c, const AttnArgs& a, float* __restrict__ o_rows, unsigned mine) {
+  if constexpr (IB >= 0) {
+    if ((mine >> IB) & 1u) attn_fwd_rows<NB, NCB, IB>(c, a, o_rows);
+    attn_fwd_rows_from<NB, NCB, IB - 1>(c, a, o_rows, mine);
+  }
+}
+
+template <int NB, int NCB, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_v_kernel(const AttnArgs a) {
+  constexpr int NT = 64 * NW, D = 16 * NCB, LDQ = D + 8, LDP = 16 * NB + 8;
+  __shared__ __attribute__((aligned(16))) float Ks[16 * NB * LDQ];
+  __shared__ __attribute__((aligned(16))) float Vt[D * LDP];
+  __shared__ __attribute__((aligned(16))) float kbias[16 * NB];
+  const int Sp = (a.S + 15) & ~15, nb = Sp >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  AttnCtx c;
+  c.lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  c.m = c.lane & 15;
+  c.q4 = 4 * (c.lane >> 4);
+  c.ldg = 3 * a.E;
+  c.Sp = Sp;
+  c.bh = blockIdx.x;
+  c.q = a.qkv + (size_t)b * a.S * c.ldg + h * D;
+  c.T0 = Ks;
+  c.T1 = Vt;
+  c.kbias = kbias;
+  c.sc2 = kLog2e / sqrtf((float)D);
+  c.dbiasA = f32x4{c.q4 + 0 <= c.m ? 0.f : -INFINITY, c.q4 + 1 <= c.m ? 0.f : -INFINITY,
+                   c.q4 + 2 <= c.m ? 0.f : -INFINITY, c.q4 + 3 <= c.m ? 0.f : -INFINITY};
+  {
+    f32x4 tk[4], tv[4];
+    attn_tile_ld<NCB, NT>(c.q + a.E, c.ldg, a.S, tk);
+    attn_tile_ld<NCB, NT>(c.q + 2 * a.E, c.ldg, a.S, tv);
+    const float mv = attn_key_mask_ld(a, b, Sp);
+    attn_tile_st<NCB, NT>(tk, a.S, Sp, Ks, nullptr, 0);
+    attn_tile_st<NCB, NT>(tv, a.S, Sp, nullptr, Vt, LDP);
+    attn_key_bias_st(a, mv, Sp, kbias);
+  }
+  const unsigned mine = attn_deal_n<NW>(nb, wave, true);
+  __syncthreads();
+  attn_fwd_rows_from<NB, NCB, NB - 1>(c, a, a.o + (size_t)b * a.S * a.E + h * D, mine);
+}
+
+// backward, pass A for row block IB (statistics, keep flags, dQ)
+template <int NB, int NCB, int IB>
+__device__ __forceinline__ void attn_bwd_rows(const AttnCtx& c, const AttnArgs& a) {
+  constexpr int LDQ = 16 * NCB + 8, MP = 16 * NB;
+  const int lane = c.lane, m = c.m, q4 = c.q4;
+  const int row = IB * 16 + m;
+  f32x4 qf[NCB], dof[NCB];
+  attn_gfrags<NCB>(c.q, c.ldg, row, a.S, q4, qf);
+  attn_gfrags<NCB>(c.dob, a.E, row, a.S, q4, dof);
+  f32x4 s[IB + 1], g[IB + 1], pk[IB + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb) {
+    s[jb] = g[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NCB; ++cc) {
+      mfma4(s[jb], frag_row(c.T0, LDQ, jb * 16, cc * 16, lane), qf[cc]);
+      mfma4(g[jb], frag_row(c.T1, LDQ, jb * 16, cc * 16, lane), dof[cc]);  // dP'[i][j] = sum_c dO[i][c] V[j][c]
+    }
+    f32x4 kb = *reinterpret_cast<const f32x4*>(c.kbias + jb * 16 + q4);
+    if (jb == IB) kb += c.dbiasA;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[jb][r] = __builtin_fmaf(s[jb][r], c.sc2, kb[r]);
+      mx = fmaxf(mx, s[jb][r]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const bool live = row < a.S && mx > -INFINITY;
+  const float mxs = live ? mx : 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[jb][r] = exp2_fast(s[jb][r] - mxs);
+      sum += s[jb][r];
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = live ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb) {
+    s[jb] *= inv;  // P
+    pk[jb] = s[jb];
+  }
+  if (a.drop_thresh) {  // P' = P M / (1-p); the keep flags of the tile go to LDS for pass B
+#pragma unroll
+    for (int jb = 0; jb <= IB; ++jb) {
+      const f32x4 dm = row < a.S ? attn_drop_mult4(a, c.bh, row, jb * 16 + q4, c.Sp) : f32x4{0.f, 0.f, 0.f, 0.f};
+      pk[jb] *= dm;
+      const uint32_t flags = (dm[0] != 0.f ? 1u : 0u) | (dm[1] != 0.f ? 0x100u : 0u) | (dm[2] != 0.f ? 0x10000u : 0u) |
+                             (dm[3] != 0.f ? 0x1000000u : 0u);
+      *reinterpret_cast<uint32_t*>(c.Mb + row * MP + jb * 16 + q4) = flags;
+    }
+  }
+  float rd = 0.f;  // r_i = sum_j P'_ij dP'_ij
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rd = __builtin_fmaf(pk[jb][r], g[jb][r], rd);
+  rd += __shfl_xor(rd, 16);
+  rd += __shfl_xor(rd, 32);
+  if (q4 == 0) {
+    c.rmax[row] = mxs;
+    c.rinv[row] = inv;
+    c.rdot[row] = rd;
+  }
+#pragma unroll
+  for (int jb = 0; jb <= IB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[jb][r] = pk[jb][r] * g[jb][r] - s[jb][r] * rd;  // dS
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {  // dQ[IB] = scale * dS[IB] K
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jb = 0; jb <= IB; ++jb) mfma4(acc, g[jb], frag_col(c.T0, LDQ, jb * 16, cb * 16, lane));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int io = IB * 16 + q4 + r;
+      if (io < a.S) c.dq[__mul24(io, c.ldg) + cb * 16 + m] = acc[r] * c.scale;
+    }
+  }
+}
+template <int NB, int NCB, int IB>
+__device__ __forceinline__ void attn_bwd_rows_from(const AttnCtx& c, const AttnArgs& a, unsigned mine) {
+  if constexpr (IB >= 0) {
+    if ((mine >> IB) & 1u) attn_bwd_rows<NB, NCB, IB>(c, a);
+    attn_bwd_rows_from<NB, NCB, IB - 1>(c, a, mine);
+  }
+}
+
+// backward, pass B for key block jb (dK, dV): T0 = Q, T1 = dO
+template <int NB, int NCB>
+__device__ __forceinline__ void attn_bwd_cols(const AttnCtx& c, const AttnArgs& a, const int jb, const int nb) {
+  constexpr int LDQ = 16 * NCB + 8, MP = 16 * NB;
+  const int lane = c.lane, m = c.m, q4 = c.q4;
+  const int col = jb * 16 + m;
+  f32x4 kf[NCB], vf[NCB], accK[NCB], accV[NCB];
+  attn_gfrags<NCB>(c.q + a.E, c.ldg, col, a.S, q4, kf);
+  attn_gfrags<NCB>(c.q + 2 * a.E, c.ldg, col, a.S, q4, vf);
+#pragma unroll
+  for (int cc = 0; cc < NCB; ++cc) accK[cc] = accV[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float kbj = c.kbias[col];
+  auto block = [&](const int ib, const bool diag) __attribute__((always_inline)) {
+    f32x4 sv = {0.f, 0.f, 0.f, 0.f}, gp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NCB; ++cc) {
+      mfma4(sv, frag_row(c.T0, LDQ, ib * 16, cc * 16, lane), kf[cc]);  // S[i][j]
+      mfma4(gp, frag_row(c.T1, LDQ, ib * 16, cc * 16, lane), vf[cc]);  // dP'[i][j]
+    }
+    const f32x4 mxv = *reinterpret_cast<const f32x4*>(c.rmax + ib * 16 + q4);
+    const f32x4 ivv = *reinterpret_cast<const f32x4*>(c.rinv + ib * 16 + q4);
+    const f32x4 rdv = *reinterpret_cast<const f32x4*>(c.rdot + ib * 16 + q4);
+    f32x4 kb = {kbj, kbj, kbj, kbj};
+    if (diag) kb += c.dbiasB;
+    const unsigned char* mb = c.Mb + (ib * 16 + q4) * MP + col;
+    f32x4 pp, dsv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float P = exp2_fast(__builtin_fmaf(sv[r], c.sc2, kb[r]) - mxv[r]) * ivv[r];
+      const float km = a.drop_thresh ? (mb[r * MP] ? a.drop_scale : 0.f) : 1.0f;
+      pp[r] = P * km;                        // P'
+      dsv[r] = pp[r] * gp[r] - P * rdv[r];   // dS
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      mfma4(accV[cb], pp, frag_col(c.T1, LDQ, ib * 16, cb * 16, lane));   // dV[j][c] += P'[i][j] dO[i][c]
+      mfma4(accK[cb], dsv, frag_col(c.T0, LDQ, ib * 16, cb * 16, lane));  // dK[j][c] += dS[i][j] Q[i][c]
+    }
+  };
+  block(jb, true);
+  for (int ib = jb + 1; ib < nb; ++ib) block(ib, false);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jo = jb * 16 + q4 + r;
+      if (jo < a.S) {
+        c.dq[__mul24(jo, c.ldg) + a.E + cb * 16 + m] = accK[cb][r] * c.scale;
+        c.dq[__mul24(jo, c.ldg) + 2 * a.E + cb * 16 + m] = accV[cb][r];
+      }
+    }
+}
+
+#ifdef ATTN_STAMPS  // tools/attn_lab.hip: 100 MHz stamps per wave of the first 512 workgroups (lab builds only)
+__device__ unsigned long long g_attn_stamp[512][4][8];
+#define ATTN_STAMP(i) if ((threadIdx.x & 63) == 0 && blockIdx.x >= 4096 && blockIdx.x < 4608) g_attn_stamp[blockIdx.x - 4096][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define ATTN_STAMP(i)
+#endif
+template <int NB, int NCB, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_v_kernel(const AttnArgs a) {
+  constexpr int NT = 64 * NW, D = 16 * NCB, LDQ = D + 8, SPM = 16 * NB;
+  __shared__ __attribute__((aligned(16))) float T0[SPM * LDQ];
+  __shared__ __attribute__((aligned(16))) float T1[SPM * LDQ];
+  __shared__ __attribute__((aligned(16))) float stats[4 * SPM];  // row max | 1 / sum | r | key bias
+  __shared__ __attribute__((aligned(16))) unsigned char Mb[SPM * SPM];
+  const int Sp = (a.S + 15) & ~15, nb = Sp >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  AttnCtx c;
+  c.lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  c.m = c.lane & 15;
+  c.q4 = 4 * (c.lane >> 4);
+  c.ldg = 3 * a.E;
+  c.Sp = Sp;
+  c.bh = blockIdx.x;
+  c.q = a.qkv + (size_t)b * a.S * c.ldg + h * D;
+  c.dob = a.dout + (size_t)b * a.S * a.E + h * D;
+  c.dq = a.dqkv + (size_t)b * a.S * c.ldg + h * D;
+  c.T0 = T0;
+  c.T1 = T1;
+  c.rmax = stats;
+  c.rinv = stats + SPM;
+  c.rdot = stats + 2 * SPM;
+  c.kbias = stats + 3 * SPM;
+  c.Mb = Mb;
+  c.scale = 1.0f / sqrtf((float)D);
+  c.sc2 = kLog2e * c.scale;
+  c.dbiasA = f32x4{c.q4 + 0 <= c.m ? 0.f : -INFINITY, c.q4 + 1 <= c.m ? 0.f : -INFINITY,
+                   c.q4 + 2 <= c.m ? 0.f : -INFINITY, c.q4 + 3 <= c.m ? 0.f : -INFINITY};
+  c.dbiasB = f32x4{c.m <= c.q4 + 0 ? 0.f : -INFINITY, c.m <= c.q4 + 1 ? 0.f : -INFINITY,
+                   c.m <= c.q4 + 2 ? 0.f : -INFINITY, c.m <= c.q4 + 3 ? 0.f : -INFINITY};
+  // ---- pass A: T0 = K, T1 = V
+  ATTN_STAMP(0);
+  constexpr bool kAhead = NB <= 5;  // pass B's tiles requested before pass A (32 registers; the 8-block forms keep theirs)
+  f32x4 tq[4], tdo[4];
+  {
+    f32x4 tk[4], tv[4];
+    attn_tile_ld<NCB, NT>(c.q + a.E, c.ldg, a.S, tk);
+    attn_tile_ld<NCB, NT>(c.q + 2 * a.E, c.ldg, a.S, tv);
+    const float mv = attn_key_mask_ld(a, b, Sp);
+    attn_tile_st<NCB, NT>(tk, a.S, Sp, T0, nullptr, 0);
+    attn_tile_st<NCB, NT>(tv, a.S, Sp, T1, nullptr, 0);
+    attn_key_bias_st(a, mv, Sp, stats + 3 * SPM);
+  }
+  if (kAhead) {
+    attn_tile_ld<NCB, NT>(c.q, c.ldg, a.S, tq);
+    attn_tile_ld<NCB, NT>(c.dob, a.E, a.S, tdo);
+  }
+  const unsigned my_rows = attn_deal_n<NW>(nb, wave, true), my_cols = attn_deal_n<NW>(nb, wave, false);
+  __syncthreads();
+  ATTN_STAMP(1);
+  attn_bwd_rows_from<NB, NCB, NB - 1>(c, a, my_rows);
+  ATTN_STAMP(2);
+  __syncthreads();  // K, V tiles are done with; row statistics and keep flags are complete
+  ATTN_STAMP(3);
+  // ---- pass B: T0 = Q, T1 = dO
+  if (!kAhead) {
+    attn_tile_ld<NCB, NT>(c.q, c.ldg, a.S, tq);
+    attn_tile_ld<NCB, NT>(c.dob, a.E, a.S, tdo);
+  }
+  attn_tile_st<NCB, NT>(tq, a.S, Sp, T0, nullptr, 0);
+  attn_tile_st<NCB, NT>(tdo, a.S, Sp, T1, nullptr, 0);
+  __syncthreads();
+  ATTN_STAMP(4);
+  for (int jb = 0; jb < nb; ++jb)
+    if ((my_cols >> jb) & 1u) attn_bwd_cols<NB, NCB>(c, a, jb, nb);
+  ATTN_STAMP(5);
 }
 
 // ---------------- dropout (nn.Dropout: cdt.py:87,222; net.py:404,414,439)
@@ -1277,6 +1756,37 @@ __global__ void temperature_step_kernel(float* logT, float* mv, const float* ent
   }
 }
 
+// the round-5 kernels: head width 16 or 32, every row of every operand 16-byte aligned
+static bool attn_vec_ok(int E, int H, const void* p0, const void* p1, const void* p2, const void* p3) {
+  const int d = E / H;
+  if (d != 16 && d != 32) return false;
+  for (const void* p : {p0, p1, p2, p3})
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+  return true;
+}
+template <bool FWD, int NB, int NCB, int NW>
+static void attn_launch_one(const AttnArgs& a, hipStream_t stream) {
+  if (FWD)
+    hipLaunchKernelGGL((attn_fwd_v_kernel<NB, NCB, NW>), dim3(a.B * a.H), dim3(64 * NW), 0, stream, a);
+  else
+    hipLaunchKernelGGL((attn_bwd_v_kernel<NB, NCB, NW>), dim3(a.B * a.H), dim3(64 * NW), 0, stream, a);
+}
+template <bool FWD>
+static void attn_launch_v(const AttnArgs& a, hipStream_t stream) {
+  const int nb = (a.S + 15) / 16, ncb = a.E / a.H / 16;
+  // waves per (sample, head): the splits of 1 + 2 + .. + nb key blocks without a remainder (2 up to 4 row blocks, 3 at
+  // 5-6, 4 at 7-8)
+  if (nb <= 4) {
+    if (ncb == 1) attn_launch_one<FWD, 5, 1, 2>(a, stream); else attn_launch_one<FWD, 5, 2, 2>(a, stream);
+  } else if (nb == 5) {
+    if (ncb == 1) attn_launch_one<FWD, 5, 1, 3>(a, stream); else attn_launch_one<FWD, 5, 2, 3>(a, stream);
+  } else if (nb == 6) {
+    if (ncb == 1) attn_launch_one<FWD, 8, 1, 3>(a, stream); else attn_launch_one<FWD, 8, 2, 3>(a, stream);
+  } else {
+    if (ncb == 1) attn_launch_one<FWD, 8, 1, 4>(a, stream); else attn_launch_one<FWD, 8, 2, 4>(a, stream);
+  }
+}
+
 #define S ((hipStream_t)stream)
 #define CLEAR() (void)hipGetLastError()
 #define DONE() return (int)hipGetLastError()
@@ -1384,7 +1894,7 @@ int osrl_layernorm_fwd_drop(const float* x, const float* delta, const osrl_dropo
 int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
                        float* dx, float* partial_ws, int32_t n_parts, int32_t M, int32_t E, float* slab,
                        int64_t g_off, int64_t b_off, void* stream) {
-  if (!dy || !x || !stats || !gamma || !dx || !partial_ws || !slab || n_parts < 1 || M < 1 || E > 64 * kMaxEPL)
+  if (!dy || !x || !stats || !gamma || !dx || !partial_ws || n_parts < 1 || M < 1 || E > 64 * kMaxEPL)
     return -1;
   CLEAR();
   if (ln_v4_ok(E, dy, x, gamma, dres, dx, dx)) {
@@ -1397,15 +1907,32 @@ int osrl_layernorm_bwd(const float* dy, const float* x, const float* stats, cons
   } else
   hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M,
                      E, nullptr, DropSite{});
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
-                     g_off, b_off);
+  if (slab)
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
+                       g_off, b_off);
+  DONE();
+}
+
+int osrl_layernorm_param_reduce(const float* partial_ws, int64_t ws_stride, int32_t n_sites, int32_t n_parts, int32_t E,
+                                float* slab, const int64_t* g_offs, const int64_t* b_offs, void* stream) {
+  if (!partial_ws || !slab || !g_offs || !b_offs || n_sites < 1 || n_sites > 16 || n_parts < 1 || E < 1 ||
+      ws_stride < (int64_t)n_parts * 2 * E)
+    return -1;
+  LnSites sites{};
+  for (int k = 0; k < n_sites; ++k) {
+    sites.g_off[k] = g_offs[k];
+    sites.b_off[k] = b_offs[k];
+  }
+  CLEAR();
+  hipLaunchKernelGGL(ln_param_reduce_many_kernel, dim3((2 * E + 63) / 64, n_sites), dim3(1024), 0, S, partial_ws, ws_stride,
+                     n_parts, E, slab, sites);
   DONE();
 }
 
 int osrl_layernorm_bwd_drop(const float* dy, const float* x, const float* stats, const float* gamma, const float* dres,
                             float* dx, float* dx_dropped, const osrl_dropout_t* drop, float* partial_ws, int32_t n_parts,
                             int32_t M, int32_t E, float* slab, int64_t g_off, int64_t b_off, void* stream) {
-  if (!dy || !x || !stats || !gamma || !dx || !dx_dropped || !partial_ws || !slab || n_parts < 1 || M < 1 ||
+  if (!dy || !x || !stats || !gamma || !dx || !dx_dropped || !partial_ws || n_parts < 1 || M < 1 ||
       E > 64 * kMaxEPL)
     return -1;
   DropSite d{};
@@ -1421,8 +1948,9 @@ int osrl_layernorm_bwd_drop(const float* dy, const float* x, const float* stats,
   } else
   hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(n_parts), dim3(256), 0, S, dy, x, stats, gamma, dres, dx, partial_ws, M, E,
                      dx_dropped, d);
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
-                     g_off, b_off);
+  if (slab)
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * E + 63) / 64), dim3(1024), 0, S, partial_ws, n_parts, E, slab,
+                       g_off, b_off);
   DONE();
 }
 
@@ -1469,6 +1997,11 @@ int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S
     return -1;
   AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep, prefix};
   if (!attn_drop_args(drop, &a)) return -1;
+  if (attn_vec_ok(E, H, qkv, o, nullptr, nullptr)) {
+    CLEAR();
+    attn_launch_v<true>(a, S);
+    DONE();
+  }
   const size_t lds = attn_lds(S_, E / H, false);
   if (lds > kMaxLds) return -1;
   CLEAR();
@@ -1487,6 +2020,11 @@ int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, i
     return -1;
   AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep, prefix};
   if (!attn_drop_args(drop, &a)) return -1;
+  if (attn_vec_ok(E, H, qkv, nullptr, dout, dqkv)) {
+    CLEAR();
+    attn_launch_v<false>(a, S);
+    DONE();
+  }
   const size_t lds = attn_lds(S_, E / H, true);
   if (lds > kMaxLds) return -1;
   if (lds > 64 * 1024) {  // opt in to a large dynamic allocation (S = 128 with head_dim 64)

@@ -188,6 +188,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ f
   }
 }
 
+// the same sum with a split count per 1024-float chunk (a group whose ranges come from plans with different row splits:
+// CDT's 81920-row projections take 2-8, its 20480-row heads 32 -- summing 32 slabs of everything reads 320 MB of zeros)
+__global__ __launch_bounds__(256) void reduce_slabs_counts_kernel(float* __restrict__ flat, const float* __restrict__ slabs,
+                                                                  const uint8_t* __restrict__ counts, int64_t slab_stride,
+                                                                  int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ns = __builtin_amdgcn_readfirstlane((int)counts[i >> 8]);  // (a wave's 64 float4 sit in one chunk)
+    reinterpret_cast<f32x4*>(flat)[i] = slab_sum(slabs, ns, slab_stride, i);
+  }
+}
+
 inline int stream_grid(int64_t n4) {
   int64_t b = (n4 + 255) / 256;
   return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
@@ -253,6 +264,15 @@ extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_spli
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, flat, slabs,
                      n_splits, slab_stride, n / 4);
+  return (int)hipGetLastError();
+}
+
+extern "C" int osrl_reduce_slabs_counts(float* flat, const float* slabs, const uint8_t* counts, int64_t slab_stride,
+                                        int64_t n, void* stream) {
+  if (!flat || !slabs || !counts || n < 4 || (n & 3) || (slab_stride & 3)) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(reduce_slabs_counts_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, flat, slabs,
+                     counts, slab_stride, n / 4);
   return (int)hipGetLastError();
 }
 

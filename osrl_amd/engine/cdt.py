@@ -22,6 +22,8 @@ from .. import _lib as L
 from . import plan as _plan
 from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into, check_plans_current
 
+LN_BATCH = _plan.knob("OSRL_CDT_LN_BATCH", "1", "CDT: the LayerNorm parameter reductions of a step in one launch") == "1"
+SLAB_COUNTS = _plan.knob("OSRL_CDT_SLAB_COUNTS", "1", "CDT: gradient slabs summed per range by its own split count") == "1"
 FUSE_DROP = _plan.knob("OSRL_CDT_FUSE_DROP", "1", "residual-branch dropout inside the LayerNorm launches") == "1"  # residual-branch dropout inside the LayerNorm launches
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
 
@@ -119,12 +121,18 @@ class CDTEngine:
         self.datt = [z(M, E) if self.p_res > 0 else self.dxm[l] for l in range(NL)]      # grad wrt out_proj output
         self.dmo = [z(M, E) if self.p_res > 0 else self.dxo[l + 1] for l in range(NL)]   # grad wrt mlp.2 output
         self.n_parts = max(1, min(1024, (M + 31) // 32))  # ~8 rows per wave per LayerNorm-backward workgroup
-        self.ln_ws = z(self.n_parts, 2 * E)
+        # (dgamma | dbeta) partials of every LayerNorm of the step (out_norm, norm2 / norm1 of each block, emb_norm): one
+        # workspace per site, summed by ONE launch behind the last backward (osrl_layernorm_param_reduce) -- eight 5 us
+        # launches inside the backward chain at C5 before
+        self.ln_sites: List[str] = []
+        self.ln_batch = LN_BATCH and 2 * NL + 2 <= 16
+        self.ln_ws = z(2 * NL + 2 if self.ln_batch else 1, self.n_parts, 2 * E)
         self.clip_ws, self.clip_out = z(1024), z(4)
         self.temp_mv = z(2)
         self.counts = z(4)
         self.loss_ws = z(8 * ((BT + 1023) // 1024) + 8)
         self._graph_failed = False
+        self._ln_pending: List[str] = []
 
         # dW plans
         tok, bt = [], []
@@ -170,6 +178,16 @@ class CDTEngine:
                 self.p_pre = DwPlan(g, [(self.dseq.data_ptr(), self.episode_cost.data_ptr(), "cdt.prefix_emb.weight",
                                          "cdt.prefix_emb.bias", self.S * E, 0)], B, dev)
                 self.n_splits = max(self.n_splits, self.p_pre.n_splits)
+        # row splits per 1024-float chunk of the flat gradient (what osrl_reduce_slabs_counts sums): the plans' own counts
+        # for the ranges they write, 1 for everything written straight into slab 0 (LayerNorm parameters, timestep rows)
+        self.slab_counts = None
+        if not self.inference and SLAB_COUNTS:
+            cnt = [1] * ((g.n + 1023) // 1024)
+            for pl in (self.p_tok, self.p_bt, self.p_pre):
+                for off, ln, ns in (pl.split_ranges() if pl is not None else ()):
+                    for ch in range(off // 1024, (off + max(ln, 1) - 1) // 1024 + 1):
+                        cnt[ch] = max(cnt[ch], min(ns, self.n_splits))
+            self.slab_counts = torch.tensor(cnt, dtype=torch.uint8, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.store = None
         m.repack()
@@ -223,21 +241,38 @@ class CDTEngine:
         """``drop`` = (site, p), ``dx_dropped``: also write dx * keep-multiplier of that site (the gradient entering the
         residual branch whose dropout output fed this LayerNorm's input)."""
         g = self.g
+        ws, slab = self.ln_ws.data_ptr(), g.slabs.data_ptr()
+        if self.ln_batch:  # this site's own workspace; the reduction waits for _ln_param_reduce()
+            ws, slab = self.ln_ws[len(self._ln_pending)].data_ptr(), None
+            self._ln_pending.append(key)
         if drop is not None and drop[1] > 0 and FUSE_DROP:
             d = self._site(*drop)
             L.check(L.load().osrl_layernorm_bwd_drop(
                 dy.data_ptr(), x.data_ptr(), stats.data_ptr(), self._v(key + ".weight"),
                 None if dres is None else dres.data_ptr(), dx.data_ptr(), dx_dropped.data_ptr(), ctypes.byref(d),
-                self.ln_ws.data_ptr(), self.n_parts, self.M, self.E, g.slabs.data_ptr(), g.offset(key + ".weight"),
+                ws, self.n_parts, self.M, self.E, slab, g.offset(key + ".weight"),
                 g.offset(key + ".bias"), cur_stream()), "osrl_layernorm_bwd_drop")
             return
         L.check(L.load().osrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), self._v(key + ".weight"),
                                             None if dres is None else dres.data_ptr(), dx.data_ptr(),
-                                            self.ln_ws.data_ptr(), self.n_parts, self.M, self.E, g.slabs.data_ptr(),
+                                            ws, self.n_parts, self.M, self.E, slab,
                                             g.offset(key + ".weight"), g.offset(key + ".bias"), cur_stream()),
                 "osrl_layernorm_bwd")
         if drop is not None and drop[1] > 0:
             self._drop(dx, dx_dropped, drop[0], drop[1])
+
+    def _ln_param_reduce(self) -> None:
+        """dgamma / dbeta of every LayerNorm whose backward ran since the last call, in one launch."""
+        keys, self._ln_pending = self._ln_pending, []
+        if not keys:
+            return
+        g = self.g
+        n = len(keys)
+        g_offs = (ctypes.c_int64 * n)(*[g.offset(k + ".weight") for k in keys])
+        b_offs = (ctypes.c_int64 * n)(*[g.offset(k + ".bias") for k in keys])
+        L.check(L.load().osrl_layernorm_param_reduce(self.ln_ws.data_ptr(), self.n_parts * 2 * self.E, n, self.n_parts,
+                                                     self.E, g.slabs.data_ptr(), g_offs, b_offs, cur_stream()),
+                "osrl_layernorm_param_reduce")
 
     # ---- dropout sites: 0 = embedding; layer l: 1+3l attention probabilities, 2+3l / 3+3l the two residual branches
     def _site(self, site: int, p: float):
@@ -422,6 +457,7 @@ class CDTEngine:
         if self.p_emb > 0:
             self._drop(self.dxo[0], self.dxo[0], 0, self.p_emb)
         self._ln_bwd(self.dxo[0], self.seq, self.st_emb, "cdt.emb_norm", None, self.dseq)
+        self._ln_param_reduce()
         # ---- parameter gradients
         if m.time_emb:
             te_off, (te_rows, _) = g.layout["cdt.timestep_emb.weight"]
@@ -436,8 +472,12 @@ class CDTEngine:
         self.p_bt.launch()
         g.cur_splits = self.n_splits
         # ---- clip_grad_norm_ + AdamW (cdt.py:396-400)
-        L.check(lib.osrl_reduce_slabs(g.slabs.data_ptr(), g.slabs.data_ptr(), g.cur_splits, g.n, g.n, cur_stream()),
-                "osrl_reduce_slabs")
+        if self.slab_counts is not None:
+            L.check(lib.osrl_reduce_slabs_counts(g.slabs.data_ptr(), g.slabs.data_ptr(), self.slab_counts.data_ptr(), g.n,
+                                                 g.n, cur_stream()), "osrl_reduce_slabs_counts")
+        else:
+            L.check(lib.osrl_reduce_slabs(g.slabs.data_ptr(), g.slabs.data_ptr(), g.cur_splits, g.n, g.n, cur_stream()),
+                    "osrl_reduce_slabs")
         g.cur_splits = 1
         if self.dist is not None:  # ONE all-reduce of the flat gradient; the clip norm is of the reduced gradient
             self.dist.all_reduce_(g.slabs[0])

@@ -531,6 +531,7 @@ class DwPlan:
         coop_items: List[int] = []
         work: List[int] = []
         s_full = max(1, min(rows // 512, 8)) if n_splits is None else int(n_splits)  # row splits of a full tile
+        kinds: List[str] = []  # which launch takes entry i ("work" / "coop" / "big" / "items"): its row-split count
         for i, ent in enumerate(entries):
             dz, a, wk, bk = ent[:4]
             # optional 5th/6th items: (ptr, row stride, width) views for strided operands
@@ -556,6 +557,7 @@ class DwPlan:
                         nsp = s_full
                         for sp in range(nsp):
                             work += [i, ot, it, sp | (nsp << 16)]
+                kinds.append("work")
                 continue
             # osrl_mlp_backward_dw_big fills its fragments with 16-byte loads: aligned operands, strides % 4 == 0
             aligned = (arr[i].dz % 16 == 0 and arr[i].a % 16 == 0 and (ldz or out_f) % 4 == 0 and (lda_ or in_f) % 4 == 0
@@ -565,16 +567,22 @@ class DwPlan:
                 for ot in range(out_f // 256):
                     for it in range(in_f // 256):
                         coop_items += [i, ot, it, 0]
+                kinds.append("coop")
                 continue
             if use_big and out_f % 128 == 0 and in_f % 64 == 0 and aligned:
                 # (128x64 tiles, one wave each: what the 256x256 form does not take) osrl_mlp_backward_dw_big
                 for ot in range(out_f // 128):
                     for it in range(in_f // 64):
                         big_items += [i, ot, it, 0]
+                kinds.append("big")
                 continue
+            kinds.append("items")
             for ot in range((out_f + 63) // 64):
                 for it in range((in_f + 63) // 64):
                     items += [i, ot, it, 0]
+        self._kinds = kinds
+        self._ranges = [(int(arr[i].w_off), int(arr[i].out) * int(arr[i].in_), int(arr[i].b_off), int(arr[i].out))
+                        for i in range(len(entries))]
         self.n_items = len(items) // 4
         self.n_big = len(big_items) // 4
         self.n_coop = len(coop_items) // 4
@@ -625,6 +633,15 @@ class DwPlan:
         if self.n_work:
             self.n_splits = max(w >> 16 for w in work[3::4])
         group.ensure_slabs(self.n_splits)
+
+    def split_ranges(self) -> List[Tuple[int, int, int]]:
+        """(float offset, length, row splits) of every parameter range this plan writes: the slabs a range's consumer has
+        to sum (``launch()``: slabs beyond a range's own split count stay zero)."""
+        per = {"work": self.n_splits, "coop": self.n_splits_coop, "big": self.n_splits_big, "items": self.n_splits_small}
+        out = []
+        for kind, (w_off, w_len, b_off, b_len) in zip(self._kinds, self._ranges):
+            out += [(w_off, w_len, max(per[kind], 1)), (b_off, b_len, max(per[kind], 1))]
+        return out
 
     def can_fuse_adam(self) -> bool:
         """The fused dW + optimizer launch covers a group whose whole plan is the flat (tile, split) work list."""

@@ -327,6 +327,118 @@ def test_dropout_kernels():
         assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), (B, T, E, H)
 
 
+@pytest.mark.parametrize("S,E,H,rep,prefix,p", [
+    (16, 128, 8, 4, 0, 0.1),    # 1 row block, head width 16: 2 waves per (sample, head)
+    (40, 128, 8, 4, 0, 0.1),    # the reference's default CDT shape (seq_len 10, 128 / 8)
+    (41, 256, 8, 4, 1, 0.1),    # cost-prefix token, ragged last row block
+    (80, 256, 8, 4, 0, 0.1),    # C5: 5 row blocks on 3 waves
+    (80, 256, 8, 4, 0, 0.0),
+    (96, 256, 16, 4, 0, 0.2),   # 6 row blocks on 3 waves (the 8-block instantiation), head width 16
+    (128, 256, 8, 2, 0, 0.1),   # 8 row blocks on 4 waves
+    (81, 512, 8, 4, 1, 0.1),    # head width 64: the generic kernels
+])
+def test_attention_wave_splits_padding_and_dropout(S, E, H, rep, prefix, p):
+    """Round 5's attention kernels (head widths 16 / 32: row block as a template parameter, 2 / 3 / 4 waves per (sample,
+    head), base-2 softmax with additive masks) and the generic ones behind the same two entry points, against numpy:
+    key padding at the tail AND at the front (query rows without any valid key give zero rows, as the oracle's masked
+    softmax does), the cost-prefix token, probability dropout with the exported mask."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import StepState, cur_stream
+    lib = L.load()
+    st = StepState(torch.device(DEV), ["x"])
+    st.tick()
+    rs = np.random.RandomState(S * 7 + E + H)
+    B, d, T = 7, E // H, (S - prefix) // rep
+    qkv = (0.7 * rs.randn(B, S, 3 * E)).astype(np.float32)
+    mk = np.ones((B, T), np.float32)
+    for b in range(B):
+        pad = int(rs.randint(0, max(T - 1, 1)))
+        if b % 3 == 0:
+            mk[b, T - pad:] = 0
+        elif b % 3 == 1:
+            mk[b, :pad] = 0
+    do = rs.randn(B, S, E).astype(np.float32)
+    o, dqkv = torch.full((B, S, E), 7.0, device=DEV), torch.full((B, S, 3 * E), 7.0, device=DEV)
+    qt, mt, dot = t(qkv), t(mk), t(do)
+    dr = L.DropoutT(p, 9, 13, st.ptr)
+    drp = C.byref(dr) if p > 0 else None
+    L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, rep, prefix, drp, o.data_ptr(), cur_stream()), "a")
+    L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, rep, prefix, drp,
+                                   dqkv.data_ptr(), cur_stream()), "ab")
+    Mk = np.ones((B, H, S, S))
+    if p > 0:
+        Sp = (S + 15) // 16 * 16
+        raw, ones = torch.empty(B * H, S, Sp, device=DEV), torch.ones(B * H, S, Sp, device=DEV)
+        L.check(lib.osrl_dropout(ones.data_ptr(), raw.data_ptr(), raw.numel(), drp, cur_stream()), "m")
+        Mk = raw.cpu().numpy()[:, :, :S].reshape(B, H, S, S).astype(np.float64)
+    key_ok = np.repeat(mk > 0, rep, 1)
+    if prefix:
+        key_ok = np.concatenate([key_ok[:, :1], key_ok], 1)  # the prefix token is masked like timestep 0 (cdt.py:216-218)
+    q64 = qkv.astype(np.float64)
+    q, k, v = (q64[..., i * E:(i + 1) * E].reshape(B, S, H, d).transpose(0, 2, 1, 3) for i in range(3))
+    blocked = np.triu(np.ones((S, S), bool), 1)[None, None] | ~key_ok[:, None, None, :]
+    sc = np.where(blocked, -np.inf, q @ k.transpose(0, 1, 3, 2) / math.sqrt(d))
+    mx = sc.max(-1, keepdims=True)
+    dead = ~np.isfinite(mx)
+    P = np.exp(sc - np.where(dead, 0.0, mx))
+    P = np.where(dead, 0.0, P / np.where(dead, 1.0, P.sum(-1, keepdims=True)))
+    Pd = P * Mk
+    oref = (Pd @ v).transpose(0, 2, 1, 3).reshape(B, S, E)
+    assert np.abs(o.cpu().numpy() - oref).max() < 3e-5, "o"
+    dO = do.astype(np.float64).reshape(B, S, H, d).transpose(0, 2, 1, 3)
+    dP = (dO @ v.transpose(0, 1, 3, 2)) * Mk
+    dv = Pd.transpose(0, 1, 3, 2) @ dO
+    dS = P * (dP - (dP * P).sum(-1, keepdims=True))
+    dq, dk = dS @ k / math.sqrt(d), dS.transpose(0, 1, 3, 2) @ q / math.sqrt(d)
+    ref = np.concatenate([x.transpose(0, 2, 1, 3).reshape(B, S, E) for x in (dq, dk, dv)], -1)
+    assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), "dqkv"
+
+
+def test_layernorm_param_reduce_and_counted_slab_sum():
+    """osrl_layernorm_param_reduce (every LayerNorm's dgamma | dbeta in one launch) and osrl_reduce_slabs_counts (a split
+    count per 1024-float chunk) return the bits of the per-call forms they replace in the CDT step."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import cur_stream
+    lib = L.load()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, E, nparts, sites = 4096, 256, 128, 5
+    slab_a, slab_b = torch.zeros(8192, device=DEV), torch.zeros(8192, device=DEV)
+    ws = torch.zeros(sites, nparts, 2 * E, device=DEV)
+    gam = (1 + 0.1 * torch.randn(E, generator=g)).to(DEV)
+    offs = [(16 + 1000 * k, 16 + 1000 * k + 400) for k in range(sites)]
+    for k in range(sites):
+        dy, x = torch.randn(M, E, generator=g).to(DEV), torch.randn(M, E, generator=g).to(DEV)
+        stats = torch.stack([x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+        dx = torch.zeros(M, E, device=DEV)
+        one = torch.zeros(nparts, 2 * E, device=DEV)
+        L.check(lib.osrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), gam.data_ptr(), None, dx.data_ptr(),
+                                       one.data_ptr(), nparts, M, E, slab_a.data_ptr(), offs[k][0], offs[k][1], cur_stream()), "a")
+        L.check(lib.osrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), stats.data_ptr(), gam.data_ptr(), None, dx.data_ptr(),
+                                       ws[k].data_ptr(), nparts, M, E, None, 0, 0, cur_stream()), "b")
+    g_offs = (C.c_int64 * sites)(*[o[0] for o in offs])
+    b_offs = (C.c_int64 * sites)(*[o[1] for o in offs])
+    L.check(lib.osrl_layernorm_param_reduce(ws.data_ptr(), nparts * 2 * E, sites, nparts, E, slab_b.data_ptr(), g_offs, b_offs,
+                                            cur_stream()), "many")
+    assert torch.equal(slab_a, slab_b) and slab_a.abs().sum().item() > 0
+    assert lib.osrl_layernorm_param_reduce(ws.data_ptr(), nparts * 2 * E, 17, nparts, E, slab_b.data_ptr(), g_offs, b_offs,
+                                           cur_stream()) != 0
+    # counted slab sum: chunk c holds gradients in its first counts[c] slabs, zeros behind
+    n, S = 10 * 1024 + 512, 8
+    counts = torch.tensor([1, 8, 3, 2, 8, 1, 5, 7, 4, 2, 6], dtype=torch.uint8)
+    slabs = torch.randn(S, n, generator=g)
+    for c, k in enumerate(counts.tolist()):
+        slabs[k:, 1024 * c:1024 * (c + 1)] = 0
+    s1, s2 = slabs.clone().to(DEV), slabs.clone().to(DEV)
+    cd = counts.to(DEV)
+    L.check(lib.osrl_reduce_slabs(s1.data_ptr(), s1.data_ptr(), S, n, n, cur_stream()), "r")
+    L.check(lib.osrl_reduce_slabs_counts(s2.data_ptr(), s2.data_ptr(), cd.data_ptr(), n, n, cur_stream()), "rc")
+    assert torch.equal(s1[0], s2[0])
+    ref = slabs.double().sum(0)
+    assert (s2[0].cpu().double() - ref).abs().max().item() < 1e-5
+
+
 def build_cdt_gpu(c, **kw):
     from osrl_amd.algorithms import CDT, CDTTrainer
     from osrl_amd.common.logger import DummyLogger
