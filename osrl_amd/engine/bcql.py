@@ -89,14 +89,15 @@ class BCQLEngine:
         self.r_actor_old_t2 = MlpRun(self.d_actor_old, NB, False, dev, tile_rows=tr)
         self.a_t2 = z(NB, ad)
 
+        dws = pl.dw_splits or None  # (engine/plan.py)
         self.r_critic = MlpRun(self.d_critic, B, True, dev)
         self.dq = z(2 * nq, B, 1)
         self.r_critic.setup_backward(self.dq)
-        self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev)
+        self.p_critic = DwPlan(g["critic"], self.r_critic.dw_entries(), B, dev, n_splits=dws)
         self.r_cost = MlpRun(self.d_cost, B, True, dev)
         self.dqc = z(2 * nqc, B, 1)
         self.r_cost.setup_backward(self.dqc)
-        self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev)
+        self.p_cost = DwPlan(g["cost_critic"], self.r_cost.dw_entries(), B, dev, n_splits=dws)
 
         # actor phase
         self.r_dec_b = MlpRun(self.d_dec, B, False, dev)
@@ -108,7 +109,7 @@ class BCQLEngine:
         self.dt = z(1, B, ad)
         self.pi_means = z(4)
         self.r_actor.setup_backward(self.dt)
-        self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev)
+        self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), B, dev, n_splits=dws)
         # batch-sum losses on a grid beyond 2048 rows (one workgroup walking 4096 rows x 10 samples x 4 nets alone: 44 us)
         big = B > 2048
         self.ws_vae, self.ws_c, self.ws_cc = (G.loss_ws(dev) if big else None for _ in range(3))

@@ -96,6 +96,7 @@ class BCQLPlan:
     vae_dw_tile: int
     target_tile: int          # row tile of the N*B-row target pipelines (80 = mlp_fwd_nb_kernel)
     vae_ns: bool
+    dw_splits: int            # row splits of the critic / cost-critic / actor dW plans (0 = DwPlan's rule)
 
 
 def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> BCQLPlan:
@@ -104,9 +105,14 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
     ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
     # (BCQ-Lag: the all-CU VAE launches only on request -- the one measurement there is C3's 4096 rows, -3.6 %)
     vae_ns = seeds and ns_shape and ns_mode == "1"
+    # DwPlan's rule aims at ~2048 (tile, split) workgroups: 16 splits of 256 rows for the 48 tiles of a twin ensemble at
+    # 4096 rows = 768 workgroups, one and a half rounds of the 512 resident slots, 16 k-steps each.  6 splits (288
+    # workgroups of 43 k-steps, one round): C3 648-650 vs 639-642 steps/s, the same at 4 and 8 (gpurun_out/r5n2)
+    dws = int(knob("OSRL_BCQ_DW_SPLITS", "0", "BCQ-Lag: row splits of the critic / cost-critic / actor dW plans (0 = by rule)")) \
+        or (6 if B >= 4096 else 0)
     return BCQLPlan(vae_dw_tile=5 if t5 else 0,
                     target_tile=int(knob("OSRL_BCQ_TILE", "80", "row tile of BCQ-Lag's N*B-row target pipelines")),
-                    vae_ns=bool(vae_ns))
+                    vae_ns=bool(vae_ns), dw_splits=dws)
 
 
 # BASELINE.json configs -> the plan the chooser must give (tests/test_host_cpu.py::test_plan_rows_are_pinned); a changed
@@ -117,7 +123,7 @@ PINNED = {
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False)),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
-           BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False)),
+           BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4),
                   CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False, vae_adam_side=False)),
 }
