@@ -1735,10 +1735,15 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
-__global__ void clip_scale_kernel(const float* __restrict__ partial, int n, float clip, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < n; ++i) t += (double)partial[i];
+// one wave: lane l sums partials l, l + 64, ... in fp64, then a fixed butterfly over the lanes (one thread walking 512
+// partials was a 26 us chain of dependent loads and adds in the step's tail, profiles/r5_cdt_trace_summary.txt)
+__global__ __launch_bounds__(64) void clip_scale_kernel(const float* __restrict__ partial, int n, float clip,
+                                                        float* __restrict__ out) {
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) t += (double)partial[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+  if (threadIdx.x == 0) {
     const float norm = (float)sqrt(t);
     out[0] = clip > 0.f ? fminf(1.0f, clip / (norm + 1e-6f)) : 1.0f;
     out[1] = norm;
