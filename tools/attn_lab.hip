@@ -1,7 +1,8 @@
 // attn_lab.hip -- the attention core of csrc/cdt.hip (osrl_attention_fwd / _bwd) on its own: C5's shape (1024 x 8 heads,
 // 80 tokens, head width 32, probability dropout 0.1, ragged key padding) against a double-precision CPU restatement of
 // nn.MultiheadAttention's core (net.py:406-409,417-435) on a sample of (sample, head) pairs, + per-launch times.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/attn_lab.hip -o tools/_lab/attn_lab
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form tools/attn_lab.hip -o tools/_lab/attn_lab
+//   (the flag is cdt.hip's own in osrl_amd/build.py FILE_FLAGS)
 #define ATTN_STAMPS 1
 #include "../osrl_amd/csrc/cdt.hip"
 #undef S

@@ -18,4 +18,15 @@ for cfg in c2 c4; do
   rm -rf $O/prof_$cfg
 done
 OSRL_FORCE_DP=1 timeout 600 python bench.py --steps 300 --warmup 20 > $O/bench_c2_forced_dp.json 2>>$O/bench.err; cut -c1-80 $O/bench_c2_forced_dp.json
-head -30 $O/timeline_c4.txt
+# C3 (BCQ-Lag) timeline and C5 (CDT) per-kernel stats of the final library
+(cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d $O/prof_c3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --config c3 --no-cpu-baseline --no-extras --no-roofline --steps 100 --warmup 10 > $O/bench_profiled_c3.json 2> $O/prof_c3.err)
+T=$(find $O/prof_c3 -name "*kernel_trace.csv" | head -1)
+python tools/timeline.py $T > $O/timeline_c3.txt 2>&1
+python tools/trace_summary.py $T > $O/trace_summary_c3.txt 2>&1
+rm -rf $O/prof_c3
+(cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d $O/prof_c5 -o cdt -- python $GRAFT_REPO_ROOT/bench.py --config c5 --no-cpu-baseline --no-extras --no-roofline --steps 10 --warmup 3 > $O/bench_profiled_c5.json 2> $O/prof_c5.err)
+cp $(find $O/prof_c5 -name "*kernel_stats.csv" | head -1) $O/cdt_kernel_stats.csv
+python tools/trace_summary.py $(find $O/prof_c5 -name "*kernel_trace.csv" | head -1) > $O/cdt_trace_summary.txt 2>&1
+rm -rf $O/prof_c5
+cut -c1-100 $O/bench_profiled_c3.json $O/bench_profiled_c5.json
+head -12 $O/timeline_c3.txt
