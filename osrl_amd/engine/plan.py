@@ -77,7 +77,8 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     # 2416, gpurun_out/r5d): the optimizer step goes where the draws ride on the actor launch
     side = {"1": True, "0": False}.get(knob("OSRL_VAE_ADAM_SIDE", "auto", "VAE Adam on the side branch: 1 / 0 / auto"),
                                        B >= 1024 and bool(head_tails))
-    return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=5 if t5 else 0, vae_dw_splits=splits, small_dw=B >= 1024,
+    vt = int(knob("OSRL_VAE_DW_TILE", "0", "dW tile of the VAE group in 16-blocks (0 = by rule)")) or (5 if t5 else 0)
+    return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
                    vae_ns=bool(vae_ns), vae_adam_side=bool(side))
 
