@@ -803,6 +803,16 @@ class ArgArena:
         return ArgArena._Ctx(self, 2)
 
 
+def graph_capture(g: "torch.cuda.CUDAGraph"):
+    """``torch.cuda.graph(g)`` in THREAD-LOCAL capture mode.  The default (global) mode makes a capture fail when ANY thread
+    of the process calls a capture-unsafe runtime function meanwhile -- and a process that holds an NCCL (= RCCL) process
+    group has such a thread: the group's watchdog polls the events of collectives still in flight (``hipEventQuery``), e.g.
+    those of the warm-up pass a data-parallel engine runs right before it captures its step.  Seen once in four runs of the
+    GPU suite: "operation not permitted when stream is capturing" thrown on the watchdog thread, which aborts the process.
+    Thread-local mode restricts the check to the capturing thread, which is the one that must not make such calls."""
+    return torch.cuda.graph(g, capture_error_mode="thread_local")
+
+
 def capture_step(device, warm, captured):
     """hipGraph capture of one step: ``warm()`` runs eagerly on a side stream (torch's warm-up requirement) while
     the fused-MLP launches' argument blocks are recorded, the blocks go to HBM, then ``captured()`` is captured with
@@ -815,7 +825,7 @@ def capture_step(device, warm, captured):
     torch.cuda.current_stream().wait_stream(s)
     arena.upload()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g), arena.replay():
+    with graph_capture(g), arena.replay():
         captured()
     return g, arena
 

@@ -21,7 +21,7 @@ from .. import _lib as L
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc, vae_enc_desc
 from . import glue as G
 from . import plan as P
-from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, check_plans_current
+from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, load_into, check_plans_current, graph_capture
 
 # Plan choices that depend on the shape live in engine/plan.py (cpq_plan: head tails, dW tiles, the all-CU VAE launches;
 # the measurements behind each rule are in DESIGN_LOG.md).  What is left here are lab switches of the plan's STRUCTURE:
@@ -469,7 +469,7 @@ class CPQEngine:
             g = torch.cuda.CUDAGraph()
             # (capturing on a high-priority stream to favour the critical chain halves the throughput: measured 980
             # vs 1755 steps/s -- every kernel of the step ran ~2x slower)
-            with torch.cuda.graph(g), arena.replay():
+            with graph_capture(g), arena.replay():
                 self.body(True, par)
             self._par = par  # keep the side streams alive with the graph
             self._arena = arena  # ... and the argument blocks its kernels read

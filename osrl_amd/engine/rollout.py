@@ -22,7 +22,7 @@ import torch
 
 from ..common.net import actor_head_desc, net_desc_seq, vae_dec_desc
 from . import glue as G
-from .core import MlpRun, StepState, randn_fill
+from .core import MlpRun, StepState, randn_fill, graph_capture
 
 _Z_STREAM = 11  # Philox stream id of the BCQL decode noise drawn during evaluation
 _CHUNK = 20     # env steps per captured graph: one replay costs ~25 us of launch latency, a step's kernels far less;
@@ -94,7 +94,7 @@ class BatchedRollout:
             self.body()
         torch.cuda.current_stream().wait_stream(s)
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        with graph_capture(gr):
             for _ in range(_CHUNK):
                 self.body()
         torch.cuda.synchronize()
@@ -203,7 +203,7 @@ class CDTBatchedRollout:
             self.body()
         torch.cuda.current_stream().wait_stream(s)
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        with graph_capture(gr):
             for _ in range(_CHUNK):
                 self.body()
         torch.cuda.synchronize()

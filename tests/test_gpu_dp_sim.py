@@ -386,7 +386,7 @@ def test_captured_data_parallel_graph_equals_concatenated_batch(algo, W, side_co
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     hub.log = []
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # (engine/core.py graph_capture)
         try:
             hub.run(bodies)
         except BaseException:  # (an exception inside a capture otherwise dies in the graph's destructor, unseen)
