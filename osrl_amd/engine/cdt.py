@@ -126,7 +126,7 @@ class CDTEngine:
         # launches inside the backward chain at C5 before
         self.ln_sites: List[str] = []
         self.ln_batch = LN_BATCH and 2 * NL + 2 <= 16
-        self.ln_ws = z(2 * NL + 2 if self.ln_batch else 1, self.n_parts, 2 * E)
+        self.ln_ws = z(2 * NL + 2 if (self.ln_batch and not inference) else 1, self.n_parts, 2 * E)
         self.clip_ws, self.clip_out = z(1024), z(4)
         self.temp_mv = z(2)
         self.counts = z(4)
@@ -381,6 +381,7 @@ class CDTEngine:
         st = self.st
         if self.inference:
             raise RuntimeError("this CDTEngine was built for inference (no dW plans): it cannot run a train step")
+        self._ln_pending = []  # (a step that raised half way must not leave sites behind)
         st.tick()
         if self.store is not None:  # draw the minibatch of windows on device (SequenceDataset, dataset.py:749-787)
             self.store.gather(self.states, self.actions, self.returns, self.ctg, self.time_steps, self.mask,
