@@ -743,7 +743,7 @@ class ArgArena:
         with arena.record():      # the warm-up pass: descriptors are copied into the host staging buffer
             body()
         arena.upload()            # one host -> device copy, outside the capture
-        with torch.cuda.graph(g), arena.replay():
+        with graph_capture(g), arena.replay():
             body()                # launches whose descriptor is in the arena read it from HBM
         keep = arena              # the device copy must outlive the graph
 

@@ -210,3 +210,21 @@ def test_plan_rows_are_pinned(monkeypatch):
     # the VAE's Adam goes to the side branch where the action draws ride on the actor launch (C2), not where they are four
     # launches of their own on that branch (C4)
     assert P.cpq_plan(76, 2, 2048, 400, 10).vae_adam_side and not P.cpq_plan(17, 6, 2048, 400, 10).vae_adam_side
+
+
+def test_every_graph_capture_is_thread_local():
+    """A process that holds an RCCL process group has a watchdog thread polling events; in torch's default (global) capture
+    mode its queries make an open capture fail and abort the process (DESIGN_LOG round 5).  Every capture of the package
+    goes through engine/core.py graph_capture() = thread-local mode -- held here so that a new capture site cannot bring
+    the race back."""
+    import inspect
+    import re
+    calls = []
+    for dp_, _, files in os.walk(os.path.join(ROOT, "osrl_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp_, f)).read()
+                calls += [(f, m.group(0)) for m in re.finditer(r"(with|return) +torch\.cuda\.graph\([^\n]*", src)]
+    assert len(calls) == 1 and calls[0][0] == "core.py" and 'capture_error_mode="thread_local"' in calls[0][1], calls
+    from osrl_amd.engine import core
+    assert 'capture_error_mode="thread_local"' in inspect.getsource(core.graph_capture)

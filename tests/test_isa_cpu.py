@@ -21,13 +21,14 @@ pytestmark = pytest.mark.skipif(HIPCC is None, reason="no hipcc")
 
 @pytest.fixture(scope="module")
 def listings(tmp_path_factory):
-    from osrl_amd.build import FLAGS
+    from osrl_amd.build import FILE_FLAGS, FLAGS
     from isa_loads import scan
     d = tmp_path_factory.mktemp("isa")
     procs = {}
-    for name in ("glue", "optim", "mlp", "mlp_nb", "vae_ns"):
+    for name in ("glue", "optim", "mlp", "mlp_nb", "vae_ns", "cdt"):
         out = str(d / f"{name}.s")
-        cmd = [HIPCC] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "osrl_amd", "csrc", f"{name}.hip"), "-o", out]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(f"{name}.hip", []) + \
+            ["-S", "--cuda-device-only", os.path.join(ROOT, "osrl_amd", "csrc", f"{name}.hip"), "-o", out]
         procs[name] = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), out)
     res = {}
     for name, (p, out) in procs.items():
@@ -121,3 +122,21 @@ def test_vae_ns_kernels_fit_beside_the_nb_launch(listings):
             assert r["scratch"] == 0 and 0 < r["vgprs"] <= 312, (needle, r)
     for k, r in t.items():
         assert r["scratch"] == 0, (k, r)
+
+
+def test_attention_kernels_keep_their_residency(listings):
+    """csrc/cdt.hip, round 5's attention kernels (built with the file's own flags, build.py FILE_FLAGS: MFMA results in
+    VGPRs): the backward for 5 row blocks on 3 waves runs FOUR workgroups per CU = 3 waves per SIMD (<= 168 registers; its
+    33 KB of LDS allow the same four), the forward six (<= 84 ... 128 registers keeps four); no scratch in any
+    instantiation, and no accumulator-register traffic (`v_accvgpr_*`) left in the listing's register file split."""
+    t = listings["cdt"]
+    bwd = _one(t, "attn_bwd_v_kernelILi5ELi2ELi3E")
+    fwd = _one(t, "attn_fwd_v_kernelILi5ELi2ELi3E")
+    assert bwd["scratch"] == 0 and 0 < bwd["vgprs"] <= 168, bwd
+    assert fwd["scratch"] == 0 and 0 < fwd["vgprs"] <= 128, fwd
+    n = 0
+    for k, r in t.items():
+        if "attn_fwd_v_kernel" in k or "attn_bwd_v_kernel" in k:
+            n += 1
+            assert r["scratch"] == 0 and r["vgprs"] <= 256, (k, r)
+    assert n == 16, n  # 2 kernels x (5 | 8 row blocks) x (head width 16 | 32) x 2 wave counts
