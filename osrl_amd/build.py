@@ -72,7 +72,40 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
 # backward's listing); with the VGPR form the register file is one pool (160 -> 131 registers) and the reads are gone
 # (tools/attn_lab.hip: backward 263.6 -> 258.8 us at C5's shape)
 FILE_FLAGS = {"cdt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+OPTIONAL_FLAGS = {("-mllvm", "-amdgpu-mfma-vgpr-form")}  # speed only: dropped where the compiler does not know them
 OBJDIR = os.path.join(LIBDIR, "obj")  # git-ignored (*.o); the objects are a build cache only
+_flag_ok: dict = {}
+
+
+def _flag_supported(hip: str, flag: tuple) -> bool:
+    """An unknown ``-mllvm`` option is FATAL to hipcc: probe an optional one once on an empty translation unit
+    and drop it where the compiler predates it -- the kernels are correct without it."""
+    if flag not in _flag_ok:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as f:
+                f.write("__global__ void k() {}\n")
+            r = subprocess.run([hip, "--offload-arch=gfx950", *flag, "-c", src, "-o", os.path.join(d, "probe.o")],
+                               capture_output=True)
+            _flag_ok[flag] = r.returncode == 0
+    return _flag_ok[flag]
+
+
+def file_flags(hip: str, source: str) -> list:
+    out, fl = [], FILE_FLAGS.get(source, [])
+    i = 0
+    while i < len(fl):
+        pair = tuple(fl[i:i + 2]) if fl[i] == "-mllvm" else (fl[i],)
+        if pair not in OPTIONAL_FLAGS or _flag_supported(hip, pair):
+            out += list(pair)
+        i += len(pair)
+    return out
+
+
+def _flag_key(cmd_flags: list) -> str:
+    import hashlib
+    return hashlib.sha256(" ".join(cmd_flags).encode()).hexdigest()[:16]
 
 
 def _build_locked(verbose: bool, force: bool = False) -> str:
@@ -85,14 +118,27 @@ def _build_locked(verbose: bool, force: bool = False) -> str:
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
         extra = [os.path.join(CSRC, "mlp_nb.hip")] if s == "mlp_nb64.hip" else []  # (it is that file, compiled again)
-        stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj)
-                                                       for d in [src] + extra + common)
+        flags = FLAGS + file_flags(hip, s)
+        # the flag set is part of an object's staleness key (a changed flag must rebuild it: mtimes alone would not)
+        keyf, key = obj + ".flags", _flag_key(flags)
+        try:
+            same_flags = open(keyf).read().strip() == key
+        except OSError:
+            same_flags = False
+        stale = force or not os.path.exists(obj) or not same_flags or any(
+            os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + extra + common)
         if stale:
-            cmd = [hip] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
+            cmd = [hip] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            jobs.append((s, subprocess.Popen(cmd)))
-    failed = [s for s, p in jobs if p.wait() != 0]
+            jobs.append((s, subprocess.Popen(cmd), keyf, key))
+    failed = []
+    for s, p, keyf, key in jobs:
+        if p.wait() != 0:
+            failed.append(s)
+        else:
+            with open(keyf, "w") as f:
+                f.write(key + "\n")
     if failed:
         raise RuntimeError(f"hipcc failed on {failed}")
     tmp = LIB + f".tmp{os.getpid()}"

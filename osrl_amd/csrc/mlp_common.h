@@ -19,7 +19,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (asm volatile with a memory clobber: neither the compiler nor the wave moves the arrival atomic above it) -> relaxed
 // agent-scope fetch_add; readers: barrier -> relaxed agent-scope loads.  That is a release/acquire on gfx942/gfx950
 // because sc1 stores are tracked by vmcnt and complete at the memory side; a target with a separate store counter
-// (vscnt) would need `s_waitcnt_vscnt` there.  Pin the family instead of hoping:
+// (vscnt) would need `s_waitcnt_vscnt` there.  Pin the family instead of hoping.  gfx950 is the ONLY supported
+// target of this library (README "Build"; every tile shape, LDS budget and ISA guard is calibrated on it) -- the protocol
+// itself would also hold on gfx942, which is deliberately not admitted here:
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "osrl_amd's in-launch exchanges assume gfx950 memory counters (sc1 stores tracked by vmcnt): build with --offload-arch=gfx950"
 #endif

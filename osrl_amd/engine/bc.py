@@ -33,12 +33,16 @@ class BCEngine:
         self.du = torch.zeros(1, B, m.action_dim, **f)
         self.r_pi.setup_backward(self.du)
         self.plan = DwPlan(m.groups["actor"], self.r_pi.dw_entries(), B, dev)
+        # every dW plan of this engine is built: the slab epochs they were built against are recorded NOW (not at the
+        # first step), so an engine that is constructed directly, never stepped and then superseded is flagged stale
+        from .core import slab_epochs
+        self._slab_epochs = slab_epochs(self.model)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
         # gather -> forward -> MSE -> backward -> dW -> Adam -> tick as one launch (include/osrl_amd.h
         # osrl_mlp_regress_step): single device, one row split per dW tile (no gradient slabs to sum), a work list and
         # a row-tile count that fit the resident grid; the library has the last word (OSRL_E_UNSUPPORTED -> the plan)
-        self.one_launch = (_plan.knob("OSRL_BC_ONE_LAUNCH", "1", "the BC step as one launch") == "1" and dist is None and self.plan.tile_blocks == 4
+        self.one_launch = (_plan.knob("OSRL_BC_ONE_LAUNCH", "1", "the BC step as one launch", operator=True) == "1" and dist is None and self.plan.tile_blocks == 4
                            and self.plan.n_splits == 1 and 0 < self.plan.n_work <= L.STEP_MAX_WG
                            and B <= 16 * L.STEP_MAX_WG)
         self.step_ws = torch.zeros(L.STEP_WS, **f) if self.one_launch else None

@@ -94,6 +94,10 @@ class BEARLEngine:
         self.coef, self.pi_means = z(4), z(4)
         self.r_actor.setup_backward(self.dhead)
         self.p_actor = DwPlan(g["actor"], self.r_actor.dw_entries(), BM, dev)
+        # every dW plan of this engine is built: the slab epochs they were built against are recorded NOW (not at the
+        # first step), so an engine that is constructed directly, never stepped and then superseded is flagged stale
+        from .core import slab_epochs
+        self._slab_epochs = slab_epochs(self.model)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
 

@@ -188,6 +188,11 @@ class CDTEngine:
                     for ch in range(off // 1024, (off + max(ln, 1) - 1) // 1024 + 1):
                         cnt[ch] = max(cnt[ch], min(ns, self.n_splits))
             self.slab_counts = torch.tensor(cnt, dtype=torch.uint8, device=dev)
+        # every dW plan of this engine is built: the slab epochs they were built against are recorded NOW (not at the
+        # first step), so an engine that is constructed directly, never stepped and then superseded is flagged stale
+        from .core import slab_epochs
+        self._slab_epochs = slab_epochs(self.model)
+        self._slab_probe = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.store = None
         m.repack()
@@ -473,6 +478,8 @@ class CDTEngine:
         self.p_bt.launch()
         g.cur_splits = self.n_splits
         # ---- clip_grad_norm_ + AdamW (cdt.py:396-400)
+        if self._slab_probe is not None:  # tests: the complete slabs of a real step, before they are summed in place
+            self._slab_probe(g.slabs, self.n_splits, self.slab_counts)
         if self.slab_counts is not None:
             L.check(lib.osrl_reduce_slabs_counts(g.slabs.data_ptr(), g.slabs.data_ptr(), self.slab_counts.data_ptr(), g.n,
                                                  g.n, cur_stream()), "osrl_reduce_slabs_counts")

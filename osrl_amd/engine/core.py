@@ -250,8 +250,8 @@ def check_plans_current(engine) -> None:
     rows are written (FlatGroup.ensure_slabs) and a captured graph of it would sum rows the newcomer fills.
     ``model.engine(...)`` always hands out the newest engine; holding on to an old one is the misuse this catches."""
     cur = slab_epochs(engine.model)
-    if getattr(engine, "_slab_epochs", None) is None:
-        engine._slab_epochs = cur  # (first step of this engine: its own plans are the newest)
+    if getattr(engine, "_slab_epochs", None) is None:  # (every engine records them at the end of its __init__)
+        raise RuntimeError("osrl_amd: step engine without recorded slab epochs (engine __init__ must set _slab_epochs)")
     if cur != engine._slab_epochs:
         raise RuntimeError("osrl_amd: this step engine is stale -- another engine was built on the same model after it "
                            "(different batch size / plan); use the engine model.engine(...) returns now")
@@ -499,7 +499,7 @@ class MlpRun:
 # 11.5 + 6.6 us isolated, critic 41.9 vs 20.5 + 8.0; C2 1935 vs 2230 steps/s) -- so "auto" fuses only plans whose tiles
 # have ONE split (the gradient is then complete in LDS: no slab, no exchange; small batches).  "1" forces it for every
 # flat plan (the bit-equality test, A/B runs), "0" never fuses.
-FUSE_DW_ADAM = _plan.knob("OSRL_FUSE_DW_ADAM", "auto", "dW + optimizer step in one launch: 1 / 0 / auto (one-split plans)")
+FUSE_DW_ADAM = _plan.knob("OSRL_FUSE_DW_ADAM", "auto", "dW + optimizer step in one launch: 1 / 0 / auto (one-split plans)", operator=True)
 
 
 class DwPlan:
@@ -751,7 +751,7 @@ class ArgArena:
     wave fetches its 1-2 KB descriptor over PCIe -- the CPQ step measured 1690 instead of 2150 steps/s.
     ``OSRL_ARG_ARENA=0`` disables it (A/B measurements)."""
 
-    ENABLED = _plan.knob("OSRL_ARG_ARENA", "1", "launch descriptors of a captured step in device memory") == "1"
+    ENABLED = _plan.knob("OSRL_ARG_ARENA", "1", "launch descriptors of a captured step in device memory", operator=True) == "1"
 
     def __init__(self, device, capacity: int = 1 << 18):
         self.device = torch.device(device)

@@ -182,6 +182,10 @@ class CPQEngine:
             self.vae_ns = G.VaeNs.build(self.r_enc, self.r_dec, self.obs, self.act, self.noise["eps_vae"], self.z, Lz,
                                         m.beta, rg, st.stat_ptr("loss/loss_vae"))
 
+        # every dW plan of this engine is built: the slab epochs they were built against are recorded NOW (not at the
+        # first step), so an engine that is constructed directly, never stepped and then superseded is flagged stale
+        from .core import slab_epochs
+        self._slab_epochs = slab_epochs(self.model)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.replay = None
         self.parallel_branches = True

@@ -263,7 +263,7 @@ def clamp_(x, lo, hi):
 
 
 # ---- loss seeds (osrl_mlp_seed_t): the backward launch computes dL/d(output) itself --------------------------------
-SEEDS = _plan.knob("OSRL_SEEDS", "1", "backward launches compute the gradient they start from") == "1"  # 0: the loss kernels as launches of their own (A/B, bit-equality tests)
+SEEDS = _plan.knob("OSRL_SEEDS", "1", "backward launches compute the gradient they start from", operator=True) == "1"  # 0: the loss kernels as launches of their own (A/B, bit-equality tests)
 
 
 class SeedStat:

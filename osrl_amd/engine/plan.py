@@ -16,12 +16,13 @@ Two kinds of thing used to be spread over ~35 ``os.environ`` reads in engine/*.p
     prints the registry and the pinned rows.
 
 Operator switches that are not plan choices stay plain environment variables: OSRL_LIB (alternative library build),
-OSRL_DP_EAGER (run the data-parallel step without capturing its collectives), OSRL_FORCE_DP (bench.py), OSRL_LAB.
+OSRL_DP_EAGER (run the data-parallel step without capturing its collectives), OSRL_FORCE_DP (bench.py), OSRL_LAB -- and
+the four safety switches registered with ``knob(..., operator=True)``: OSRL_ARG_ARENA, OSRL_BC_ONE_LAUNCH,
+OSRL_FUSE_DW_ADAM, OSRL_SEEDS (bit-equal fallback forms, honoured without OSRL_LAB).
 """
 from __future__ import annotations
 
 import os
-import warnings
 from dataclasses import asdict, dataclass
 from typing import Dict, Optional, Tuple
 
@@ -33,15 +34,22 @@ def lab() -> bool:
     return os.environ.get("OSRL_LAB") == "1"
 
 
-def knob(name: str, default: str, doc: str = "") -> str:
-    """The value of lab switch ``name``: its default, or -- only under OSRL_LAB=1 -- what the environment says."""
-    KNOBS.setdefault(name, (default, doc))
+def knob(name: str, default: str, doc: str = "", operator: bool = False) -> str:
+    """The value of switch ``name``: its default, or what the environment says -- for a LAB switch only under OSRL_LAB=1;
+    ``operator=True`` marks a safety switch (a bit-equal alternative form an operator may need to fall back to:
+    OSRL_ARG_ARENA, OSRL_BC_ONE_LAUNCH, OSRL_FUSE_DW_ADAM, OSRL_SEEDS), which is honoured in every run like OSRL_DP_EAGER
+    (ADVICE r5).  An ignored lab switch is reported once per process on stderr (``warnings.warn`` is deduplicated or
+    filtered by many launchers)."""
+    KNOBS.setdefault(name, (default, doc + (" [operator switch]" if operator else "")))
     if name in os.environ:
-        if lab():
+        if operator or lab():
             return os.environ[name]
         if name not in _warned and os.environ[name] != default:
             _warned.add(name)
-            warnings.warn(f"osrl_amd: {name}={os.environ[name]} is ignored (lab switches need OSRL_LAB=1); using {default!r}")
+            import sys
+            print(f"osrl_amd: {name}={os.environ[name]} is IGNORED -- lab switches are read only under OSRL_LAB=1 "
+                  f"(using {default!r}); operator switches: OSRL_ARG_ARENA, OSRL_BC_ONE_LAUNCH, OSRL_FUSE_DW_ADAM, OSRL_SEEDS, "
+                  f"OSRL_DP_EAGER", file=sys.stderr, flush=True)
     return default
 
 
@@ -70,7 +78,7 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
         (max(1, (3 * B) // 2048) if t5 else max(1, B // 1024))
     ns_mode = knob("OSRL_VAE_NS", "auto", "VAE phase as all-CU layer launches: 1 / 0 / auto")
     ns_shape = vae_hidden % 80 == 0 and 80 <= vae_hidden <= 448 and ad <= 8 and od + 2 * ad <= 128
-    vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad)))
+    vae_ns = seeds and ns_shape and (ns_mode == "1" or (ns_mode == "auto" and vae_ns_auto(B, od, ad, vae_hidden)))
     # the VAE's Adam off the main chain (its only reader this step is the side branch's N*B-row encoder launch): C2 +0.7 %
     # with the fused VAE launches (gpurun_out/r5h), +1.1 % with the all-CU ones (r5k2).  At C4 the side branch is the longer
     # one -- its action draws are four launches of their own there (head_tails off) -- and the same move costs 3 % (2340 vs
@@ -83,13 +91,17 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
                    vae_ns=bool(vae_ns), vae_adam_side=bool(side))
 
 
-def vae_ns_auto(rows: int, od: int, ad: int) -> bool:
+def vae_ns_auto(rows: int, od: int, ad: int, vae_hidden: int = 400) -> bool:
     """Where the five all-CU VAE launches beat the four fused ones INSIDE the step (A/B on MI355X, DESIGN_LOG round 5):
     C4's (17, 6) at 2048 rows +4.5 % (gpurun_out/r5a); C2's (76, 2) at 2048 rows +0.2 % on their own but +1.1 % together
     with the VAE's Adam on the side branch (three pairs, gpurun_out/r5k2: 2280 / 2274 / 2282 vs 2250 / 2257 / 2252); C3's
     (33, 8) at 4096 rows -3.6 % (two rounds of 48-row tiles against one round of 256 fused 16-row tiles).  The rule is
-    those points, not a model: one round of tiles."""
-    return 1024 <= rows <= 2048
+    those points, not a model: one round of tiles, at the ONE hidden width that was timed (400 = 5 column groups; other
+    widths are parity-tested -- tests/test_gpu_kernels.py test_vae_ns_launches_equal_the_fused_launches covers 80 / 160 /
+    240 / 320 / 400 -- but nobody timed them, so they stay on the fused launches unless OSRL_VAE_NS=1 asks).
+    A shape outside the calibrated points can be timed at engine construction: OSRL_LAB=1 OSRL_PLAN_TIME=1 runs both VAE
+    forms once and logs which won (engine/cpq.py time_vae_forms)."""
+    return 1024 <= rows <= 2048 and vae_hidden == 400
 
 
 @dataclass(frozen=True)

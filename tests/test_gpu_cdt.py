@@ -439,6 +439,46 @@ def test_layernorm_param_reduce_and_counted_slab_sum():
     assert (s2[0].cpu().double() - ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("case", ["cdt_c5_slice", "cdt_v_prefix", "cdt_small"])
+def test_counted_slab_sum_equals_full_slab_sum_on_a_real_step(case):
+    """``osrl_reduce_slabs_counts`` sums only each range's OWN split count per 1024-float chunk -- correct only
+    while every slab row beyond a range's count is zero.  On the complete slabs of a REAL CDT step (token-matrix plan,
+    per-sample plan, the prefix plan, LayerNorm / timestep rows written straight into slab 0) the counted sum must equal the
+    sum over ALL slab rows bit for bit; and no slab row beyond a chunk's count may hold a non-zero (a writer missing from
+    ``DwPlan.split_ranges()`` would show up here as dropped gradient)."""
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import cur_stream
+    c = C5_SLICE if case == "cdt_c5_slice" else CDT_CASES[case]
+    m, tr, lg = build_cdt_gpu(c, seed=1234)
+    b = {k: t(v) for k, v in make_cdt_batch(c).items()}
+    eng = m.engine(c.B, tr.cfg)
+    seen = []
+
+    def probe(slabs, n_splits, counts):
+        lib = L.load()
+        assert counts is not None, "the counted slab sum must be the shipped path"
+        S, n = slabs.shape
+        a, bb = slabs.clone(), slabs.clone()
+        L.check(lib.osrl_reduce_slabs(a.data_ptr(), a.data_ptr(), S, n, n, cur_stream()), "r")
+        L.check(lib.osrl_reduce_slabs_counts(bb.data_ptr(), bb.data_ptr(), counts.data_ptr(), n, n, cur_stream()), "rc")
+        torch.cuda.synchronize()
+        cnt = counts.cpu().numpy().astype(np.int64)
+        rows = np.arange(S)[:, None] >= np.repeat(cnt, 1024)[None, :n]  # [S, n]: True = beyond the chunk's count
+        stray = int((slabs.cpu().numpy()[rows] != 0).sum())
+        seen.append((bool(torch.equal(a[0], bb[0])), stray, S, int(cnt.max()), float(a[0].abs().sum())))
+
+    eng._slab_probe = probe
+    for _ in range(2):
+        tr.train_one_step(b["states"], b["actions"], b["returns"], b["costs_return"], b["time_steps"], b["mask"],
+                          b["episode_cost"], b["costs"])
+    eng._slab_probe = None
+    assert len(seen) == 2
+    for eq, stray, S, cmax, mass in seen:
+        assert eq, "counted slab sum differs from the sum over all slab rows"
+        assert stray == 0, f"{stray} non-zero gradient words beyond their chunk's split count"
+        assert mass > 0 and cmax <= S
+
+
 def build_cdt_gpu(c, **kw):
     from osrl_amd.algorithms import CDT, CDTTrainer
     from osrl_amd.common.logger import DummyLogger

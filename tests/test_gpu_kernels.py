@@ -1029,13 +1029,15 @@ def test_forward2_with_a_kl_tail_writes_the_kl_rows(rows, od, ad, hid):
 
 
 @pytest.mark.parametrize("rows,od,ad,hid,rg", [(100, 7, 3, 80, 0), (64, 76, 2, 400, 0), (2048, 17, 6, 400, 16384),
-                                                (1000, 33, 8, 400, 0), (2048, 76, 2, 160, 0)])
+                                                (1000, 33, 8, 400, 0), (2048, 76, 2, 160, 0), (1536, 20, 4, 240, 0),
+                                                (2048, 11, 3, 320, 4096)])
 def test_vae_ns_launches_equal_the_fused_launches(rows, od, ad, hid, rg):
     """osrl_vae_ns_forward / _backward (csrc/vae_ns.hip: the VAE phase as five all-CU layer launches) fill the SAME buffers as
     the four fused launches they replace -- forward_tail(enc, VAE_LATENT), forward(dec), backward_dz_seed(dec, MSE + KL
     statistic, VAE_LATENT_BWD tail), backward_dz(enc) -- up to fp32 summation order: every saved activation, z, every dZ
     the dW plan reads, the logged loss.  Shapes: ragged rows / odd dims / one column group; C2's widths; C4's with the
-    8-GPU job's rows_global; a latent that straddles two k-steps of the decoder's first layer (33 + 16); two groups."""
+    8-GPU job's rows_global; a latent that straddles two k-steps of the decoder's first layer (33 + 16); two, three and four
+    column groups (H = 160 / 240 / 320: ADVICE r5)."""
     from osrl_amd.engine import glue as G
     from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
     dev = _dev()
