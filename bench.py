@@ -165,7 +165,7 @@ class Workload:
     """One BASELINE config as ``step()`` = one train step on a minibatch drawn on device from a HBM-resident store."""
 
     def __init__(self, name: str, device, rank: int, world: int, dp, n_store: int = 1 << 20, seed: int = 0,
-                 use_graph: bool = True):
+                 use_graph: bool = True, steps_per_graph: int = 1):
         from osrl_amd.common.replay import ReplayStore, SequenceStore, synthetic_transitions
         cfg = self.cfg = CONFIGS[name]
         self.name, self.device, self.use_graph = name, device, use_graph
@@ -222,9 +222,25 @@ class Workload:
                                      cost_scale=1.0, seed=1, rank=rank, world=1)
             self.eng.attach_replay(self.store)
             self._step = lambda: self.eng.step_replay(self.use_graph)
+        # several steps per hipGraph, software-pipelined across steps (osrl_amd/engine/pipeline.py): CPQ / BCQ-Lag on one
+        # GPU.  Both graphs (n-step and one-step) are captured HERE, outside any timed region
+        self.pipe = None
+        if steps_per_graph > 1 and use_graph and dp is None and cfg["algo"] in ("cpq", "bcql"):
+            from osrl_amd.engine.pipeline import PipelinedSteps
+            self.pipe = PipelinedSteps(self.eng, steps_per_graph)
+            self.pipe.capture()
+            self.eng.capture()
 
     def step(self) -> None:
         self._step()
+
+    def run(self, n: int) -> None:
+        """EXACTLY n train steps: whole pipelined graphs + the remainder as single-step replays (or n single steps)."""
+        if self.pipe is not None:
+            self.pipe.run(n)
+        else:
+            for _ in range(n):
+                self._step()
 
     def api_batch(self):
         """Device-resident synthetic batch for the Trainer-API path (train_one_step(tensors))."""
@@ -246,15 +262,15 @@ class Workload:
 
 
 def timed_steps(step, steps: int, warmup: int, barrier=None):
-    for _ in range(warmup):
-        step()
+    """``step``: a callable for ONE step, or a Workload (its ``run(n)`` = exactly n steps, possibly several per graph)."""
+    run = step.run if hasattr(step, "run") else (lambda n: [step() for _ in range(n)])
+    run(warmup)
     torch.cuda.synchronize()
     if barrier:
         barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run(steps)
     torch.cuda.synchronize()
     if barrier:
         barrier()
@@ -308,6 +324,8 @@ def mlp_fwd_flops(run):
     d = run.net.dims
     return 2.0 * run.rows * run.net.E * lin(d)
 
+
+DEFAULT_STEPS_PER_GRAPH = 4
 
 PROBE_SITES = ("enc_ood", "costold_ood", "vae_dw", "actor_phase_fwd", "critic_fwd")
 
@@ -761,6 +779,9 @@ def main():
                          "headline fields alone (0 = no watchdog)")
     ap.add_argument("--no-extras", action="store_true", help="skip api_path / other_configs (N=1 extras)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
+    ap.add_argument("--steps-per-graph", type=int, default=DEFAULT_STEPS_PER_GRAPH,
+                    help="train steps per replayed hipGraph, software-pipelined across steps (CPQ / BCQ-Lag, one GPU; "
+                         "1 = one step per graph).  K timed steps = K // n graphs + K %% n single-step replays")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the N-rank job (one process per GPU over RCCL)
@@ -794,7 +815,8 @@ def main():
         dp = DataParallel()
         rccl_ranks = dist.get_world_size()
 
-    wl = Workload(args.config, device, rank, world, dp, use_graph=not args.eager)
+    wl = Workload(args.config, device, rank, world, dp, use_graph=not args.eager,
+                  steps_per_graph=1)  # (the probes below run on the one-step engine; the pipeline is built behind them)
     cfg, eng = wl.cfg, wl.eng
 
     def barrier():
@@ -825,14 +847,20 @@ def main():
 
     # Both protocols are measured and reported: first W warm-up + K timed steps straight after the probes
     # (`no_preroll`: what the same command measured in rounds 1-3's records), then the pre-roll + W + K again: `value`.
+    spg = args.steps_per_graph if (dp is None and not args.eager and cfg["algo"] in ("cpq", "bcql")) else 1
+    if spg > 1:
+        from osrl_amd.engine.pipeline import PipelinedSteps
+        wl.pipe = PipelinedSteps(eng, spg)
+        wl.pipe.capture()  # both graphs are captured here, outside the timed regions
+        eng.capture()
     n_done = 0
     dt_cold = None
     if args.preroll_ms > 0 and not args.no_cold:
         torch.cuda.synchronize()
-        dt_cold = max_over_ranks(timed_steps(wl.step, args.steps, args.warmup, barrier))
+        dt_cold = max_over_ranks(timed_steps(wl, args.steps, args.warmup, barrier))
         n_done += args.warmup + args.steps
     pre_ms = preroll(device, args.preroll_ms)
-    dt = max_over_ranks(timed_steps(wl.step, args.steps, args.warmup, barrier))
+    dt = max_over_ranks(timed_steps(wl, args.steps, args.warmup, barrier))
     n_done += args.warmup + args.steps
 
     stats = eng.st.read_stats()
@@ -911,6 +939,9 @@ def main():
                                                  "Philox noise inside the step",
                        "name": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
                        "graph": bool(getattr(eng, "graph", None) is not None),
+                       # train steps per replayed graph (engine/pipeline.py: step k+1's head under step k's tail); the K
+                       # timed steps are K // n such replays + K % n single-step replays
+                       "steps_per_graph": spg,
                        # what the shape-keyed plan chooser picked for this workload (engine/plan.py)
                        "plan": (lambda pl: None if pl is None else {k: v for k, v in vars(pl).items()})(getattr(eng, "plan", None)),
                        # both timing protocols where a reader of the driver's record sees them: `value` is
@@ -951,7 +982,7 @@ def main():
             out["api_path"] = api_path(wl)
             del wl, eng
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(args.config, device)
+            out["other_configs"] = other_configs(args.config, device, args.steps_per_graph)
         if world == 1 and not force_dp and not args.no_extras:
             gap = out["cost_return_gap"] = cost_return_gap(device)
             # the metric's second half, compact, where the driver's record keeps it (config is carried over verbatim)
@@ -994,22 +1025,23 @@ def api_path(wl, steps=200, warmup=20):
             "what": "trainer.train_one_step(device tensors), stats_mode='lazy', DummyLogger"}
 
 
-def other_configs(skip: str, device):
+def other_configs(skip: str, device, steps_per_graph: int = 1):
     """Short runs of the other single-GPU BASELINE configs (same step definition), so the driver's line carries them."""
     res = {}
     for name, (steps, warm) in (("c1", (500, 50)), ("c2", (200, 20)), ("c3", (60, 10)), ("c4", (200, 20)), ("c5", (10, 3))):
         if name == skip:
             continue
         try:
-            w = Workload(name, device, 0, 1, None, n_store=1 << 18)
-            dt = timed_steps(w.step, steps, warm)
+            w = Workload(name, device, 0, 1, None, n_store=1 << 18, steps_per_graph=steps_per_graph)
+            dt = timed_steps(w, steps, warm)
             fl = flops_per_step(w.cfg)
             fx = executed_flops_per_step(w.cfg)
             res[name] = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
                          "gflop_per_step": round(fl / 1e9, 2),
                          "step_frac": round(fl / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
                          "executed_gflop_per_step": round(fx / 1e9, 2),
-                         "step_frac_executed": round(fx / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4)}
+                         "step_frac_executed": round(fx / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                         "steps_per_graph": w.pipe.n if w.pipe is not None else 1}
             del w
             torch.cuda.empty_cache()
         except Exception as e:  # a failing side measurement must not take the headline line down

@@ -394,6 +394,18 @@ int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, int32_t war
                     uint64_t noise_seed, uint32_t noise_stream, int32_t n_fields, const float* const* src,
                     float* const* dst, const int32_t* width, const float* scale, int64_t n_rows, int32_t batch,
                     uint64_t gather_seed, uint32_t gather_stream, void* stream);
+/* The two calls above for TWO step states that take turns (software-pipelined train steps: step k+1's prologue runs while
+ * step k's last optimizer launches still read step k's bias corrections, so consecutive steps cannot share one state).
+ * `st` receives t = max(st->step, peer->step) + 1 and commits ITS OWN previous statistics (those of step st->step) to the
+ * ring slot of that step; `peer` is only read.  peer == NULL: exactly osrl_step_tick / osrl_step_begin.  The reference has
+ * no counterpart (its optimizer steps are host-serialised, cpq.py:294-313); same arithmetic per step as the plain calls. */
+int osrl_step_tick_peer(osrl_step_state_t* st, const osrl_step_state_t* peer, float beta1, float beta2, int32_t warmup,
+                        const float* stats_cur, float* ring, int32_t n_stats, int32_t ring_len, void* stream);
+int osrl_step_begin_peer(osrl_step_state_t* st, const osrl_step_state_t* peer, float beta1, float beta2, int32_t warmup,
+                         const float* stats_cur, float* ring, int32_t n_stats, int32_t ring_len, float* noise,
+                         int64_t noise_n, uint64_t noise_seed, uint32_t noise_stream, int32_t n_fields,
+                         const float* const* src, float* const* dst, const int32_t* width, const float* scale,
+                         int64_t n_rows, int32_t batch, uint64_t gather_seed, uint32_t gather_stream, void* stream);
 /* g = sum_s slabs[s][i] (* *gscale if gscale != NULL); AdamW decay if weight_decay != 0;
  * then tgt = tau*p + (1-tau)*tgt if tgt != NULL.  n and slab_stride must be multiples of 4. */
 int osrl_adam_step(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,

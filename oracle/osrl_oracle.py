@@ -54,12 +54,70 @@ def _act_grad_from_out(name: str, y: Array) -> Array:
     raise ValueError(name)
 
 
+class KinkBook:
+    """Test bookkeeping for ReLU units that sit within fp32 round-off of their kink.
+
+    ``threshold_backward`` passes gradient where the activation OUTPUT is > 0.  A unit whose pre-activation is within
+    the rounding error of an fp32 dot product of zero can land on either side depending on the summation order, and
+    then one row's contribution to one row of dW appears or vanishes.  While ``MLP.kink`` is set to a KinkBook,
+    ``MLP.backward``
+      (a) records for every relu layer the (row, unit) pairs with ``|pre| <= ulps * 2^-24 * (|x| @ |W|^T + |b|)`` under
+          ``near[layer key]`` (one entry per backward call);
+      (b) overrides relu' at the pairs listed in ``force[layer key] = (rows, units, values)`` -- a test can hand the
+          oracle the decisions the device took (read off its saved activations) and demand agreement at the strict gate;
+      (c) accumulates in ``allow[parameter key]`` an elementwise BOUND on what those undecidable units can change in
+          that parameter's gradient: a flip at (r, j) moves dz[r, j] by |dy[r, j]|, hence row j of dW by |dy[r, j]| |x[r, :]|
+          and db[j] by |dy[r, j]|; the uncertainty is carried down the same MLP (|U| @ |W| through each layer's
+          derivative) so the rank-one change it makes to the layers below is bounded too.  A gradient element may then
+          miss the strict gate only by its own ``allow`` -- not by a blanket budget.
+    The uncertainty is NOT carried across networks (a critic's dX into the actor head): callers keep the absolute kink
+    floor for that."""
+
+    def __init__(self, ulps: float = 2.0):
+        self.ulps = float(ulps)
+        self.near: Dict[str, list] = {}
+        self.force: Dict[str, tuple] = {}
+        self.allow: Dict[str, Array] = {}
+
+    def mask(self, key: str, x: Array, W: Array, b: Array, y: Array) -> Array:
+        m = y > 0
+        pre = x @ W.T + b
+        bound = self.ulps * 2.0 ** -24 * (np.abs(x) @ np.abs(W).T + np.abs(b))
+        rows, units = np.nonzero(np.abs(pre) <= bound)
+        self.near.setdefault(key, []).append((rows, units))
+        f = self.force.get(key)
+        if f is not None:
+            m = m.copy()
+            m[f[0], f[1]] = np.asarray(f[2], bool)
+        return m.astype(y.dtype)
+
+    def layer(self, key: str, act: str, x: Array, W: Array, b: Array, y: Array, dy: Array, U: Optional[Array]):
+        """dz of one layer + the uncertainty of the next dy.  ``U``: bound on |delta dy| coming from the layers above."""
+        if act == "relu":
+            m = self.mask(key, x, W, b, y)
+        else:
+            m = _act_grad_from_out(act, y)
+        dz = dy * m
+        Uz = np.zeros_like(dz) if U is None else U * np.abs(m)
+        if act == "relu":
+            rows, units = self.near[key][-1]
+            if len(rows):
+                Uz[rows, units] = np.maximum(Uz[rows, units], 0) + np.abs(dy[rows, units]) + (0 if U is None else U[rows, units])
+        if Uz.any():
+            ax = np.abs(x)
+            self.allow[key + ".weight"] = self.allow.get(key + ".weight", 0) + Uz.T @ ax
+            self.allow[key + ".bias"] = self.allow.get(key + ".bias", 0) + Uz.sum(0)
+            return dz, Uz @ np.abs(W)
+        return dz, None
+
+
 class MLP:
     """``mlp()`` of osrl/common/net.py:12-30: ``y = act(x @ W.T + b)`` per layer.
 
     ``keys`` is the list of state_dict prefixes (``"critic.q_nets.0.0"`` ...),
     ``acts`` the activation after each layer.
     """
+    kink: Optional["KinkBook"] = None  # tests only (KinkBook)
 
     def __init__(self, keys: Sequence[str], acts: Sequence[str]):
         assert len(keys) == len(acts)
@@ -76,9 +134,14 @@ class MLP:
     def backward(self, p: State, cache: List[Array], dy: Array, grads: State,
                  need_dx: bool = True) -> Optional[Array]:
         """Accumulates dW/db into ``grads`` (+=) and returns dX (or None)."""
+        U = None  # (KinkBook: bound on what ulp-close relu units above may change in dy)
         for li in range(len(self.keys) - 1, -1, -1):
             k, a = self.keys[li], self.acts[li]
-            dz = dy * _act_grad_from_out(a, cache[li + 1])
+            if MLP.kink is not None:
+                dz, U = MLP.kink.layer(k, a, cache[li], p[k + ".weight"], p[k + ".bias"], cache[li + 1], dy,
+                                       U if li < len(self.keys) - 1 else None)
+            else:
+                dz = dy * _act_grad_from_out(a, cache[li + 1])
             grads[k + ".weight"] = grads.get(k + ".weight", 0) + dz.T @ cache[li]
             grads[k + ".bias"] = grads.get(k + ".bias", 0) + dz.sum(0)
             if li == 0 and not need_dx:

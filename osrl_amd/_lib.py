@@ -195,6 +195,9 @@ PROTOTYPES = {
     "osrl_step_tick": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
     "osrl_step_begin": [_vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _fp, _i64, _u64, _u32, _i32, _P(_fp), _P(_fp),
                         _P(_i32), _P(_f32), _i64, _i32, _u64, _u32, _vp],
+    "osrl_step_tick_peer": [_vp, _vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _vp],
+    "osrl_step_begin_peer": [_vp, _vp, _f32, _f32, _i32, _fp, _fp, _i32, _i32, _fp, _i64, _u64, _u32, _i32, _P(_fp), _P(_fp),
+                             _P(_i32), _P(_f32), _i64, _i32, _u64, _u32, _vp],
     "osrl_adam_step": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,
                        _vp, _vp],
     "osrl_adam_step_packed": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,

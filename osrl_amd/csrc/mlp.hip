@@ -750,6 +750,7 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
   if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
 #endif
 
+  BWD_STAMP(0);
   // steps: l = L-1 .. 1 (dH_{l-1} = dZ_l W_l), then step 0 = the dX slice; begin_step issues a step's first weight loads
   f32x4 ring[ring_depth<NW>()][NCB];
   auto begin_step = [&](int l) {
@@ -843,6 +844,7 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
     }
     if (a.g.dz[e][L - 1]) tile_to_global<64 * NW>(lds, lda, BM, NL, a.g.dz[e][L - 1], row0, rows);
   }
+  BWD_STAMP(1);  // dZ_{L-1} staged
   constexpr bool kWarm = OSRL_L2_WARM && NW == 8;
   float warm[OSRL_MAX_LAYERS - 1][kWarmLines];
   if (kWarm) {  // the later steps' W^T packs (step L-1's first loads are already in flight)
@@ -882,7 +884,9 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
     // packed W^T: contraction over the layer's outputs (K), columns = the layer's inputs (N) (+16 pad)
     if (cnt > 0) layer_run<NRB, NCB>(lds, lda, round16(K) >> 4, a.net.Wb[e][l], round16(N) + 16, cb0 * 16, cnt, acc, ring);
     begin_step(l - 1);
+    BWD_STAMP(2 + 3 * (L - 1 - l));  // k-loop done
     __syncthreads();
+    BWD_STAMP(3 + 3 * (L - 1 - l));  // barrier
     // activation switch hoisted out of the element loop (see fwd_epilogue)
     auto epilogue = [&](auto act_c) {
       constexpr int ACT = decltype(act_c)::value;
@@ -916,6 +920,7 @@ __device__ __forceinline__ void mlp_bwd_dz_body(AR a, const int e, const int til
       epilogue(std::integral_constant<int, OSRL_ACT_ID>{});
     __syncthreads();
     if (a.g.dz[e][l - 1]) tile_to_global<64 * NW>(lds, lda, BM, N, a.g.dz[e][l - 1], row0, rows);
+    BWD_STAMP(4 + 3 * (L - 1 - l));  // epilogue + barrier + dZ stored
     if (kWarm && l == L - 1) {
       for (int w = L - 2; w >= (a.g.dx[e] ? 0 : 1); --w) l2_warm_done(warm[w]);
     }
@@ -2167,6 +2172,9 @@ static int launch_step(const StepArgs& k, size_t lds_bytes, hipStream_t stream) 
 #ifdef OSRL_STEP_STAMPS
 extern "C" int osrl_debug_step_stamps(long long* host_out /* [OSRL_STEP_MAX_WG][16] */) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_stamp), sizeof(long long) * OSRL_STEP_MAX_WG * 16);
+}
+extern "C" int osrl_debug_step_phases(long long* host_out /* [OSRL_STEP_MAX_WG][2][16] */) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_phase), sizeof(long long) * OSRL_STEP_MAX_WG * 2 * 16);
 }
 #endif
 

@@ -47,9 +47,20 @@ __device__ long long g_wg_log[16384][4];
       g_wg_log[wg_][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                  \
     }                                                                                                 \
   }
+#elif defined(OSRL_STEP_STAMPS)  // tools/step_stamps.py: per-layer wall-clock stamps inside the one-launch BC step's forward /
+// backward bodies (thread 0 of every workgroup, 100 MHz counter); [0] = mlp_fwd_body's PHASE_STAMP sites, [1] = BWD_STAMP
+__device__ long long g_step_phase[OSRL_STEP_MAX_WG][2][16];
+#define PHASE_STAMP(i) \
+  if (threadIdx.x == 0 && blockIdx.x < OSRL_STEP_MAX_WG && blockIdx.y == 0 && (i) < 16) g_step_phase[blockIdx.x][0][i] = wall_clock64();
+#define BWD_STAMP(i) \
+  if (threadIdx.x == 0 && blockIdx.x < OSRL_STEP_MAX_WG && blockIdx.y == 0 && (i) < 16) g_step_phase[blockIdx.x][1][i] = wall_clock64();
+#define WG_LOG(slot)
 #else
 #define PHASE_STAMP(i)
 #define WG_LOG(slot)
+#endif
+#ifndef BWD_STAMP
+#define BWD_STAMP(i)
 #endif
 
 // Wave priority (s_setprio 0..3, default 0): launches on at most OSRL_CHAIN_PRIO rows -- the 2048-row latency chain of a

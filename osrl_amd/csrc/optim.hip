@@ -22,13 +22,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__global__ void step_tick_kernel(osrl_step_state_t* st, float beta1, float beta2, int warmup,
-                                 const float* __restrict__ stats_cur, float* __restrict__ ring, int n_stats,
+__global__ void step_tick_kernel(osrl_step_state_t* st, const osrl_step_state_t* peer, float beta1, float beta2,
+                                 int warmup, const float* __restrict__ stats_cur, float* __restrict__ ring, int n_stats,
                                  int ring_len) {
-  const int64_t t_old = st->step;
-  osrl_step::commit_stats(t_old, stats_cur, ring, n_stats, ring_len);
+  const int64_t t_own = st->step;  // the step whose statistics stats_cur holds
+  const int64_t t_peer = peer ? peer->step : t_own;
+  osrl_step::commit_stats(t_own, stats_cur, ring, n_stats, ring_len);
   __syncthreads();
-  if (threadIdx.x == 0) osrl_step::advance(st, t_old, beta1, beta2, warmup);
+  if (threadIdx.x == 0) osrl_step::advance(st, t_peer > t_own ? t_peer : t_own, beta1, beta2, warmup);
 }
 
 // sum_s slabs[s][i] in slab order; 8 loads are issued before the first add so their latencies overlap
@@ -206,14 +207,20 @@ inline int stream_grid(int64_t n4) {
 
 }  // namespace
 
+extern "C" int osrl_step_tick_peer(osrl_step_state_t* st, const osrl_step_state_t* peer, float beta1, float beta2,
+                                   int32_t warmup, const float* stats_cur, float* ring, int32_t n_stats,
+                                   int32_t ring_len, void* stream) {
+  if (!st || peer == st) return -1;
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st, peer, beta1, beta2, warmup,
+                     stats_cur, ring, n_stats, ring_len > 0 ? ring_len : 1);
+  return (int)hipGetLastError();
+}
+
 extern "C" int osrl_step_tick(osrl_step_state_t* st, float beta1, float beta2, int32_t warmup,
                               const float* stats_cur, float* ring, int32_t n_stats, int32_t ring_len,
                               void* stream) {
-  if (!st) return -1;
-  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st, beta1, beta2, warmup,
-                     stats_cur, ring, n_stats, ring_len > 0 ? ring_len : 1);
-  return (int)hipGetLastError();
+  return osrl_step_tick_peer(st, nullptr, beta1, beta2, warmup, stats_cur, ring, n_stats, ring_len, stream);
 }
 
 static int adam_launch(float* p, float* m, float* v, float* tgt, const float* slabs, int32_t n_splits,

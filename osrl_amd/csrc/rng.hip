@@ -74,14 +74,22 @@ struct BeginArgs {
   int64_t noise_n;
   uint32_t nk0, nk1, noise_stream;
   int32_t g_blocks, r_blocks;
+  // osrl_step_begin_peer: a SECOND step state that takes turns with `st` (software-pipelined steps, engine/pipeline.py):
+  // the new step count is max(st->step, peer->step) + 1, `st` receives it; nullptr = `st` counts alone
+  const osrl_step_state_t* peer;
 };
 
 template <class BR, class AR>
 __device__ __forceinline__ void step_begin_body(BR b, AR a) {
-  __shared__ int64_t s_t;
+  __shared__ int64_t s_t, s_own;
   __shared__ int s_last;
   __shared__ float s_tick[3];
-  if (threadIdx.x == 0) s_t = __atomic_load_n(&b.st->step, __ATOMIC_RELAXED);
+  if (threadIdx.x == 0) {
+    const int64_t own = __atomic_load_n(&b.st->step, __ATOMIC_RELAXED);
+    const int64_t other = b.peer ? __atomic_load_n(&b.peer->step, __ATOMIC_RELAXED) : own;
+    s_own = own;  // the step whose statistics `stats_cur` holds (this state's previous turn)
+    s_t = other > own ? other : own;
+  }
   __syncthreads();
   const int64_t t_old = s_t;
   // The tick's bias corrections (osrl_step::tick_values: two double-precision pow, ~2 us on one lane) used to run in the
@@ -111,7 +119,7 @@ __device__ __forceinline__ void step_begin_body(BR b, AR a) {
   }
   __syncthreads();
   if (s_last) {  // every workgroup holds t_old in registers by now: the state may move
-    osrl_step::commit_stats<kBeginThreads>(t_old, b.stats_cur, b.ring, b.n_stats, b.ring_len);
+    osrl_step::commit_stats<kBeginThreads>(s_own, b.stats_cur, b.ring, b.n_stats, b.ring_len);
     if (threadIdx.x == 0) {
       b.st->step = t_old + 1;
       b.st->bc1 = s_tick[0];
@@ -282,7 +290,18 @@ extern "C" int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, 
                                uint64_t noise_seed, uint32_t noise_stream, int32_t n_fields, const float* const* src,
                                float* const* dst, const int32_t* width, const float* scale, int64_t n_rows,
                                int32_t batch, uint64_t gather_seed, uint32_t gather_stream, void* stream) {
-  if (!st || n_fields < 0 || n_fields > OSRL_MAX_FIELDS || (noise && noise_n < 1)) return -1;
+  return osrl_step_begin_peer(st, nullptr, beta1, beta2, warmup, stats_cur, ring, n_stats, ring_len, noise, noise_n,
+                              noise_seed, noise_stream, n_fields, src, dst, width, scale, n_rows, batch, gather_seed,
+                              gather_stream, stream);
+}
+
+extern "C" int osrl_step_begin_peer(osrl_step_state_t* st, const osrl_step_state_t* peer, float beta1, float beta2,
+                                    int32_t warmup, const float* stats_cur, float* ring, int32_t n_stats,
+                                    int32_t ring_len, float* noise, int64_t noise_n, uint64_t noise_seed,
+                                    uint32_t noise_stream, int32_t n_fields, const float* const* src, float* const* dst,
+                                    const int32_t* width, const float* scale, int64_t n_rows, int32_t batch,
+                                    uint64_t gather_seed, uint32_t gather_stream, void* stream) {
+  if (!st || peer == st || n_fields < 0 || n_fields > OSRL_MAX_FIELDS || (noise && noise_n < 1)) return -1;
   if (n_fields > 0 && (!src || !dst || !width || n_rows < 1 || batch < 1)) return -1;
   BeginPack k{};
   GatherArgs& a = k.a;
@@ -315,6 +334,7 @@ extern "C" int osrl_step_begin(osrl_step_state_t* st, float beta1, float beta2, 
   b.nk0 = (uint32_t)noise_seed;
   b.nk1 = (uint32_t)(noise_seed >> 32);
   b.noise_stream = noise_stream;
+  b.peer = peer;
   constexpr int kWaves = kBeginThreads / 64;
   b.g_blocks = n_fields > 0 ? (batch + kWaves - 1) / kWaves : 0;
   int64_t rb = noise ? ((noise_n + 3) / 4 + kBeginThreads - 1) / kBeginThreads : 0;

@@ -162,15 +162,15 @@ class BCQLEngine:
             self.dist.allreduce_group(grp)
         grp.adam_step(self.model._lrs[name], self.st.ptr, tau=tau)
 
-    def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
-        """``par`` (graph capture): cost_critic_loss (bcql.py:157-179) reads only the updated VAE, actor_old and
-        cost_critic_old -- nothing the critic phase writes -- so it runs on a side branch beside critic_loss; its
-        optimizer step waits for the join (it Polyak-updates nothing the critic branch reads, but a data-parallel
-        all-reduce must stay on the capture stream)."""
-        par = par or Branches(False)
+    def head(self, device_noise: bool) -> None:
+        """The part of a step that depends on nothing the PREVIOUS step's critic / actor phases write: prologue (tick +
+        minibatch gather + noise), the latent clamp, and the whole VAE phase (``vae_loss`` bcql.py:122-132 + its optimizer
+        step).  Its inputs are this engine's own batch / noise buffers and the VAE, whose last reader in a step is the
+        second target pipeline's decoder launch -- so in a pipelined graph (engine/pipeline.py) the NEXT step's head runs
+        on the side queue under this step's actor phase."""
         m, st, nz, B = self.model, self.st, self.noise, self.B
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
-        nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
+        rg = self.rows_global
         st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat, self.seed, device_noise)
         # net.py:334-335 clamps the latent draws: z_c | z_cc | z_actor are adjacent in the flat noise buffer -- ONE launch
         # over the range instead of three (round 5: 3 x 5.2 us on the step's head, profiles/r4_bcql_timeline.txt)
@@ -194,6 +194,26 @@ class BCQLEngine:
         if self.vae_ns is None:
             self.r_enc.backward_dz()
         self._optim("vae", self.p_vae, 0.0)
+
+    def body(self, device_noise: bool, par: Optional[Branches] = None, nxt: Optional["BCQLEngine"] = None,
+             head_done: bool = False) -> None:
+        """``par`` (graph capture): cost_critic_loss (bcql.py:157-179) reads only the updated VAE, actor_old and
+        cost_critic_old -- nothing the critic phase writes -- so it runs on a side branch beside critic_loss; its
+        optimizer step waits for the join (it Polyak-updates nothing the critic branch reads, but a data-parallel
+        all-reduce must stay on the capture stream).
+
+        ``nxt`` / ``head_done`` (engine/pipeline.py, several steps per graph): behind the join the side queue is idle for
+        the whole actor phase (profiles/r5_timeline_c3.txt: 1318-1540 us), and the main queue runs the next step's VAE phase
+        alone (0-205 us) -- so the NEXT step's ``head()``, on the twin engine ``nxt``'s buffers and step state, is issued
+        on the side branch right behind the join; the next step then runs with ``head_done=True``."""
+        par = par or Branches(False)
+        m, st, nz, B = self.model, self.st, self.noise, self.B
+        od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
+        nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
+        sd = self.seeds
+        assert nxt is None or self.dist is None, "pipelined steps are a single-GPU plan"
+        if not head_done:
+            self.head(device_noise)
         # round 3 (profiles/r3_bcql_timeline.txt): both branches are linear chains from here (a side branch forked BEFORE
         # the VAE phase, to run the online forwards beside it, made the graph executor put both 950 us target pipelines
         # on one queue: 1881 vs 1788 us).  The online critics' forwards (critic / cost critic on (obs, act),
@@ -233,6 +253,9 @@ class BCQLEngine:
         else:  # reduced together with the cost critic's gradient after the join: one collective instead of two
             self.p_critic.launch()
         par.join(0)
+        if nxt is not None:  # (pipelined: the next step's prologue + VAE phase under this step's actor phase)
+            with par.on(0):
+                nxt.head(device_noise)
         if self.dist is None:
             self._update("cost_critic", m.tau)
         else:
@@ -259,6 +282,8 @@ class BCQLEngine:
             ga = m.groups["actor"]
             self.dist.all_reduce_many_([self.dist.reduce_local(ga), st.stats])
             ga.adam_step(m._lrs["actor"], st.ptr, tau=m.tau)
+        if nxt is not None:
+            par.join(0)  # the next step's critic / actor phases need its head (the VAE's optimizer step)
 
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:
         load_into(((self.obs, observations), (self.nobs, next_observations), (self.act, actions),

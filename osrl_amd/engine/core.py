@@ -845,15 +845,45 @@ class StepState:
         self.state = torch.zeros(24, dtype=torch.uint8, device=device)
         self.stats = torch.zeros(self.n_stats, dtype=torch.float32, device=device)
         self.ring = torch.zeros(ring_len, self.n_stats, dtype=torch.float32, device=device)
-        self.host_step = 0
+        self._clock = [0]  # host mirror of the train-step count; shared with a linked peer (link())
+        self.peer: Optional["StepState"] = None
         # callables run at every point where the host synchronises with the step anyway (statistics reads, device_step):
         # an engine whose launches can flag a failure on device (the one-launch BC step's bounded wait) registers its
         # check here, so the flag cannot go unread for longer than one statistics flush
         self.health_checks: list = []
 
+    @property
+    def host_step(self) -> int:
+        return self._clock[0]
+
+    @host_step.setter
+    def host_step(self, v: int) -> None:
+        self._clock[0] = int(v)
+
+    def link(self, other: "StepState") -> None:
+        """Make ``other`` this state's PEER: the two take turns (software-pipelined steps, engine/pipeline.py -- step k+1's
+        prologue ticks one state while step k's last optimizer launches still read the other's bias corrections).  Every
+        tick of either gives it ``max(own, peer) + 1`` (osrl_step_tick_peer / osrl_step_begin_peer), so any interleaving of
+        the two -- strict alternation inside a pipelined graph, single steps on one of them in between -- counts 1, 2, 3,
+        ...  They share the host step mirror and ONE statistics ring (slot = step - 1: no collisions); each keeps its own
+        ``stats`` buffer, committed to the ring at its own next tick."""
+        assert other is not self and other.n_stats == self.n_stats and other.ring_len == self.ring_len
+        assert (other.betas, other.warmup) == (self.betas, self.warmup)
+        self.peer, other.peer = other, self
+        other._clock = self._clock
+        other.ring = self.ring
+        other.state.copy_(self.state)
+        other.state[20:24].zero_()  # (its own arrival counter)
+
+    def _peer_ptr(self) -> Optional[int]:
+        return None if self.peer is None else self.peer.state.data_ptr()
+
     def _health(self) -> None:
         for f in self.health_checks:
             f()
+        if self.peer is not None:
+            for f in self.peer.health_checks:
+                f()
 
     @property
     def ptr(self) -> int:
@@ -863,9 +893,9 @@ class StepState:
         return self.stats.data_ptr() + 4 * self.index[key]
 
     def tick(self) -> None:
-        L.check(L.load().osrl_step_tick(self.ptr, self.betas[0], self.betas[1], self.warmup, self.stats.data_ptr(),
-                                        self.ring.data_ptr(), self.n_stats, self.ring_len, cur_stream()),
-                "osrl_step_tick")
+        L.check(L.load().osrl_step_tick_peer(self.ptr, self._peer_ptr(), self.betas[0], self.betas[1], self.warmup,
+                                             self.stats.data_ptr(), self.ring.data_ptr(), self.n_stats, self.ring_len,
+                                             cur_stream()), "osrl_step_tick")
         self.host_step += 1
 
     def begin(self, noise: Optional[torch.Tensor] = None, noise_seed: int = 0, noise_stream: int = 0,
@@ -875,8 +905,8 @@ class StepState:
         gather described by ``gather`` = ``store.gather_args(dst)``.  Same results as the three separate launches."""
         n_f, src, dst, w, sc, n_rows, B, g_seed, g_stream, _keep = gather if gather is not None else \
             (0, None, None, None, None, 0, 0, 0, 0, None)
-        L.check(L.load().osrl_step_begin(
-            self.ptr, self.betas[0], self.betas[1], self.warmup, self.stats.data_ptr(), self.ring.data_ptr(),
+        L.check(L.load().osrl_step_begin_peer(
+            self.ptr, self._peer_ptr(), self.betas[0], self.betas[1], self.warmup, self.stats.data_ptr(), self.ring.data_ptr(),
             self.n_stats, self.ring_len, None if noise is None else noise.data_ptr(),
             0 if noise is None else noise.numel(), noise_seed, noise_stream, n_f, src, dst, w, sc, n_rows, B, g_seed,
             g_stream, cur_stream()), "osrl_step_begin")
@@ -904,18 +934,37 @@ class StepState:
         """Continue counting from ``step`` completed train steps (engine rebuild, checkpoint resume): the next
         tick makes it step+1 and recomputes the bias corrections / warm-up scale from that."""
         self.state[:8].view(torch.int64).fill_(int(step))
+        if self.peer is not None:  # (max(own, peer) + 1 is then step + 1 whichever of the two ticks next)
+            self.peer.state[:8].view(torch.int64).fill_(int(step))
         self.host_step = int(step)
 
+    def _own_step(self) -> int:
+        return int(self.state[:8].view(torch.int64).item())
+
     def device_step(self) -> int:
-        v = int(self.state[:8].view(torch.int64).item())
+        v = self._own_step()
+        if self.peer is not None:
+            v = max(v, self.peer._own_step())
         self._health()
         return v
+
+    def _holder(self, step: int) -> Optional["StepState"]:
+        """The state whose ``stats`` buffer holds train step ``step`` (not yet committed to the ring), or None."""
+        if self.peer is None:
+            return self if step == self.host_step else None
+        for c in (self, self.peer):
+            if c._own_step() == step:
+                return c
+        return None
 
     def read_stats(self, step: Optional[int] = None) -> Dict[str, float]:
         """Statistics of train step ``step`` (1-based; default = the latest).  Synchronises."""
         self._health()
-        if step is None or step == self.host_step:
-            v = self.stats.tolist()
+        if step is None:
+            step = self.host_step
+        h = self._holder(step)
+        if h is not None:
+            v = h.stats.tolist()
         else:
             if self.host_step - step >= self.ring_len:
                 raise RuntimeError("statistics of that step were already overwritten in the ring")
@@ -930,6 +979,20 @@ class StepState:
             return {}
         if min(steps) < 1 or self.host_step - min(steps) >= self.ring_len:
             raise RuntimeError("statistics of that step were already overwritten in the ring")
+        if self.peer is not None:  # two uncommitted steps may be outstanding: which state holds which is read off the device
+            held = {c._own_step(): c for c in (self.peer, self)}
+            both = torch.cat([self.ring.reshape(-1), self.stats, self.peer.stats]).tolist()
+            self._health()
+            n = self.n_stats
+            bufs = {id(self): both[self.ring_len * n:(self.ring_len + 1) * n], id(self.peer): both[(self.ring_len + 1) * n:]}
+            out = {}
+            for s_ in steps:
+                if s_ in held:
+                    out[s_] = bufs[id(held[s_])]
+                else:
+                    r = (s_ - 1) % self.ring_len
+                    out[s_] = both[r * n:(r + 1) * n]
+            return out
         both = torch.cat([self.ring.reshape(-1), self.stats]).tolist()  # one kernel, one synchronising copy
         self._health()
         n = self.n_stats

@@ -34,6 +34,7 @@ from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, lo
 # than the two 17 us collectives they take off the main chain.  Default "0" = round 4's placement (all four on the main
 # branch).
 DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather issued off the main branch") == "1"
+PIPE_PROLOGUE = P.knob("OSRL_PIPE_PROLOGUE", "side", "pipelined steps: the next step's prologue on the side branch / main")
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -226,8 +227,19 @@ class CPQEngine:
             else:
                 p[i].record()
 
-    def body(self, device_noise: bool, par: Optional[Branches] = None) -> None:
-        """One step, single GPU or data parallel (``self.dist``): the launch plan below.  Data parallel adds four
+    def prologue(self, device_noise: bool) -> None:
+        """tick + minibatch gather + Philox noise of ONE step into this engine's buffers (one launch)."""
+        self.st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat,
+                         self.seed, device_noise)
+
+    def body(self, device_noise: bool, par: Optional[Branches] = None, nxt: Optional["CPQEngine"] = None,
+             prologue_done: bool = False) -> None:
+        """One step, single GPU or data parallel (``self.dist``): the launch plan below.
+
+        ``nxt`` / ``prologue_done`` (engine/pipeline.py, several steps per graph): the NEXT step's prologue -- into the
+        twin engine ``nxt``'s buffers and step state -- is issued at the tail of THIS step's side branch, behind the OOD
+        statistic, where the side queue would otherwise idle until the join; the next step is then run with
+        ``prologue_done=True``.  Data parallel adds four
         collectives, ALL issued from the capture stream in the same order on every rank: the VAE gradient (before its
         Adam), [critic | cost-critic gradients] (where the main branch waits for the side branch's critic dW anyway),
         the all-gather of the N*B KL values for the batch-global quantile (the selection itself and the masked mean
@@ -252,8 +264,9 @@ class CPQEngine:
         od, ad, Lz, N = m.state_dim, m.action_dim, m.latent_dim, m.sample_action_num
         nq, nqc, rg = m.num_q, m.num_qc, self.rows_global
         par = par or Branches(False)
-        st.prologue(self.replay, (self.obs, self.nobs, self.act, self.rew, self.cost, self.done), self.noise_flat,
-                    self.seed, device_noise)
+        assert nxt is None or dp is None, "pipelined steps are a single-GPU plan"
+        if not prologue_done:
+            self.prologue(device_noise)
         par.fork(0)
         # ---- main: vae_loss  (cpq.py:125-135)
         sd = self.seeds
@@ -396,6 +409,8 @@ class CPQEngine:
             else:
                 G.quantile(self.kl, N * B, 0.75, self.quant)
                 G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            if nxt is not None and PIPE_PROLOGUE == "side":
+                nxt.prologue(device_noise)  # (pipelined: the next step's minibatch + noise + tick, off the main chain)
 
         # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch: this stream waited for
         # ev_critic above -- a second wait on it is one more graph edge, ~6 us on the chain) and cost critic (here)
@@ -444,6 +459,8 @@ class CPQEngine:
         # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains); under
         # data parallelism the statistics are already the global ones here, so the global term is added once
         G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
+        if nxt is not None and PIPE_PROLOGUE != "side":
+            nxt.prologue(device_noise)  # (lab: the pipelined graph with the next prologue on the main chain, as a control)
 
     # ------------------------------------------------------------------ #
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:

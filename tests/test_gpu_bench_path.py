@@ -46,6 +46,7 @@ def test_bench_path_matches_oracle(name):
     wl = bench.Workload(name, dev, 0, 1, None, n_store=1 << 16, use_graph=True)
     eng, m = wl.eng, wl.model
     o64, o32 = _oracle(wl, np.float64), _oracle(wl, np.float32)
+    sd0 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items() if k.startswith("vae.")}
     groups = {"actor": "opt_actor", "critic": "opt_critic", "cost_critic": "opt_cost", "vae": "opt_vae"}
     store_obs = wl.store.tables[0] if hasattr(wl.store, "tables") else None
     n_steps = 3 if name != "c3" else 2
@@ -69,7 +70,7 @@ def test_bench_path_matches_oracle(name):
         got = eng.st.read_stats()
         for k, r in st64.items():
             assert abs(got[k] - r) <= 1e-4 * max(1.0, abs(r)), f"{name} replayed step {s + 1} {k}: gpu {got[k]} vs oracle {r}"
-        n_floor, worst = {}, {}
+        n_floor, worst, vae_missed = {}, {}, []
         for gname, oname in groups.items():
             grp = m.groups[gname]
             for k, mo in getattr(o64, oname).m.items():
@@ -86,18 +87,13 @@ def test_bench_path_matches_oracle(name):
                 # scale (observed 1.3e-2 on C3's vae.d1.weight at step 2) -- gated at 5e-2 (a kernel error would be O(1));
                 # the logged statistics of every step stay at the 1e-4 gate above
                 gate = max(GROUP_GATE * scale, KINK_FLOOR) if s == 0 else max(5e-2 * scale, KINK_FLOOR * (s + 1))
-                if s == 0 and d > gate:
-                    # ReLU kinks: the bench's torch-initialised nets are not the seed-calibrated ones of the full-size
-                    # tests -- a hidden unit of ONE row within an ulp of zero falls on the other side than in both
-                    # oracles and moves one row of a 400-wide layer's dW by ~(1 - beta1) |dz h| (observed: 3e-3 of the
-                    # scale on C3's vae.d2.weight).  Budget: <= 1 % of a tensor's elements beyond the strict gate, none
-                    # beyond 1e-2 of its scale (a wrong kernel moves most elements by O(scale))
-                    n_bad = int((el > gate).sum())
-                    assert d <= 1e-2 * scale and n_bad <= max(4, el.size // 100), \
-                        f"{name} replayed step 1 first moment {k} ({gname}): {d:.3e} vs scale {scale:.3e}, {n_bad} elements"
+                if s == 0 and d > gate and gname == "vae":
+                    vae_missed.append((k, d, scale))  # settled below, by the kink check -- not by a budget
                     continue
                 assert d <= gate, \
                     f"{name} replayed step {s + 1} first moment {k} ({gname}): {d:.3e} vs scale {scale:.3e}"
+        if s == 0 and vae_missed:
+            _vae_kink_check(name, eng, m, sd0, batch, noise, vae_missed)
         _note(f"bench path {name} step {s + 1}: first-moment diff / scale " +
               ", ".join(f"{g}={v:.2e}" for g, v in worst.items()) + "; needed the kink floor: " +
               ", ".join(f"{g}={v}" for g, v in n_floor.items()))
@@ -107,3 +103,151 @@ def test_bench_path_matches_oracle(name):
             assert abs(m.controller.error_old - o64.controller.error_old) < 1e-4
             assert abs(m.controller.error_integral - o64.controller.error_integral) < 1e-4
     assert eng.st.device_step() == n_steps
+
+
+def _vae_kink_check(name, eng, m, sd0, batch, noise, missed):
+    """a VAE tensor missed the strict first-moment gate at step 1.  The claim is that a ReLU unit of ONE row
+    sits within fp32 round-off of its kink and fell on the other side on the device than in both oracles (the bench's
+    torch-initialised nets are not the seed-calibrated ones of the full-size tests).  Checked, not budgeted: the VAE phase
+    of step 1 (``vae_loss`` cpq.py:125-135 / bcql.py:122-132: initial parameters, the gathered batch, eps_vae) is re-run in
+    the fp64 oracle with a KinkBook -- (a) there must BE units within 2 ulp of the dot product's absolute sum of zero, and
+    only a handful; (b) with relu' at exactly those (row, unit) pairs set to what the DEVICE decided (its saved activation
+    is > 0 or not) every VAE tensor must meet the strict gate, no floor, no budget; (c) at least one of the forced
+    decisions must differ from the oracle's own, otherwise the miss is unexplained and the test fails."""
+    from oracle.osrl_oracle import MLP, VAE, KinkBook
+    obs, act = batch[0].astype(np.float64), batch[2].astype(np.float64)
+    eps = noise["eps_vae"].astype(np.float64)
+    vae = VAE(1.0)
+    saved = {"vae.e1": eng.r_enc.h[0][0], "vae.e2": eng.r_enc.h[0][1], "vae.d1": eng.r_dec.h[0][0], "vae.d2": eng.r_dec.h[0][1]}
+    book = KinkBook(ulps=2.0)
+    MLP.kink = book
+    try:
+        vae.loss_and_grads(sd0, obs, act, eps, m.beta)
+        near = {k: v[0] for k, v in book.near.items()}
+        n_near = sum(len(r) for r, _ in near.values())
+        assert 1 <= n_near <= 64, f"{name}: {n_near} ReLU units within 2 ulp of their kink (missed: {missed})"
+        flipped = 0
+        for k, (rows, units) in near.items():
+            if not len(rows):
+                continue
+            dev_on = (saved[k][torch.as_tensor(rows), torch.as_tensor(units)] > 0).cpu().numpy()
+            book.force[k] = (rows, units, dev_on)
+        book.near.clear()
+        # the oracle's own decisions at those pairs: forward once more without forcing and read the activations
+        mean, std, ls_raw, h, ecache = vae.encode(sd0, obs, act)
+        z = mean + std * eps
+        _, dcache = vae.decode(sd0, obs, z)
+        acts = {"vae.e1": ecache[1], "vae.e2": ecache[2], "vae.d1": dcache[1], "vae.d2": dcache[2]}
+        for k, (rows, units, dev_on) in book.force.items():
+            flipped += int((dev_on != (acts[k][rows, units] > 0)).sum())
+        assert flipped >= 1, f"{name}: the device took the oracle's side at all {n_near} near-kink units, yet {missed} missed"
+        _, grads = vae.loss_and_grads(sd0, obs, act, eps, m.beta)
+    finally:
+        MLP.kink = None
+    grp = m.groups["vae"]
+    worst = 0.0
+    for k, g in grads.items():
+        want = (1.0 - 0.9) * g
+        got = grp._view(grp.m, k).cpu().numpy().astype(np.float64)
+        scale = max(np.abs(want).max(), 1e-12)
+        d = np.abs(got - want).max()
+        worst = max(worst, d / scale)
+        assert d <= GROUP_GATE * scale, \
+            f"{name} step 1 first moment {k} with the device's {flipped} kink decision(s) forced: {d:.3e} vs scale {scale:.3e}"
+    _note(f"bench path {name} step 1: {[k for k, _, _ in missed]} missed the strict gate by a ReLU kink -- {n_near} unit(s) "
+          f"within 2 ulp of zero, {flipped} decided differently on the device; with those forced every VAE tensor is "
+          f"within {worst:.2e} of its scale")
+
+
+def test_bench_path_matches_oracle_c1():
+    """C1, the bench's timed call: ``BCEngine.step_replay`` = ONE launch (osrl_mlp_regress_step: in-kernel gather of
+    (obs, act) from the store, forward, MSE, backward, dW, Adam, tick) launched directly.  After each step the gathered
+    (observations, actions) are read back and handed to the fp64 / fp32 oracle started from the bench model's own initial
+    parameters (reference: bc.py:45-52,103-109; TransitionDataset.__prepare_sample dataset.py:832-847): loss <= 1e-5,
+    Adam first moments at GROUP_GATE of each tensor's scale, parameters <= 1e-6 after 3 steps -- the gates of ``bc_c1``."""
+    import bench
+    from oracle.osrl_oracle import OracleBC
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload("c1", dev, 0, 1, None, n_store=1 << 16, use_graph=True)
+    eng, m = wl.eng, wl.model
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    o64, o32 = OracleBC(sd, 1.0, 1e-3, dtype=np.float64), OracleBC(sd, 1.0, 1e-3, dtype=np.float32)
+    store_obs = wl.store.tables[0] if hasattr(wl.store, "tables") else None
+    prev = None
+    for s in range(3):
+        wl.step()
+        torch.cuda.synchronize()
+        assert eng.one_launch and eng.graph is None, "C1's bench path is the directly launched one-launch step"
+        obs, act = eng.obs.detach().cpu().numpy().copy(), eng.act.detach().cpu().numpy().copy()
+        if prev is not None:
+            assert not np.array_equal(prev, obs), "a step draws a new minibatch (tick inside the launch)"
+        prev = obs
+        if store_obs is not None and s == 0:
+            rows = {r.tobytes() for r in store_obs.detach().cpu().numpy()}
+            assert all(r.tobytes() in rows for r in obs[:64])
+        r64 = o64.train_one_step(obs, act)["loss/actor_loss"]
+        o32.train_one_step(obs, act)
+        got = eng.st.read_stats()["loss/actor_loss"]
+        assert abs(got - r64) <= 1e-5 * max(1.0, abs(r64)), f"c1 step {s + 1}: loss gpu {got} vs oracle {r64}"
+        grp = m.groups["actor"]
+        worst = 0.0
+        for k, mo in o64.opt.m.items():
+            mg = grp._view(grp.m, k).cpu().numpy()
+            scale = max(np.abs(mo).max(), 1e-12)
+            d = min(np.abs(mg - mo).max(), np.abs(mg - o32.opt.m[k]).max())
+            worst = max(worst, d / scale)
+            # (later steps: Adam moved every element by ~lr whatever its gradient's size, so the two trajectories' NEXT
+            # gradients differ by more than round-off -- same reasoning and gate as the c2 / c3 / c4 test above)
+            gate = max(GROUP_GATE * scale, KINK_FLOOR) if s == 0 else max(5e-2 * scale, KINK_FLOOR * (s + 1))
+            assert d <= gate, f"c1 step {s + 1} first moment {k}: {d:.3e} vs scale {scale:.3e}"
+        _note(f"bench path c1 step {s + 1}: loss diff {abs(got - r64):.2e}, worst first-moment diff / scale {worst:.2e}")
+    assert eng.st.device_step() == 3
+    for k, v in m.state_dict().items():
+        d = min(np.abs(v.cpu().numpy() - o64.p[k]).max(), np.abs(v.cpu().numpy() - o32.p[k]).max())
+        assert d <= 2.5e-3, f"c1 param {k} after 3 steps: {d:.3e}"  # (2 lr per step at most, lr = 1e-3)
+        assert np.median(np.abs(v.cpu().numpy() - o64.p[k])) <= 1e-6, k
+
+
+def test_bench_path_matches_oracle_c5():
+    """C5, the bench's timed call: ``CDTEngine.step_store`` = a REPLAYED graph whose first launches gather B = 1024
+    windows from the HBM-resident SequenceStore and whose dropout masks (0.1 at all four nn.Dropout sites) come from the
+    device Philox stream.  After the replayed step the window batch is read back, the step's keep-masks are exported
+    (``dropout_masks()``: osrl_dropout on ones with the step's own counters), and the fp64 oracle -- started from the bench
+    model's own parameters -- runs forward AND backward in 64-sample chunks on exactly that batch with exactly those
+    masks (reference: SequenceDataset.__prepare_sample dataset.py:749-787, CDTTrainer.train_one_step cdt.py:343-418):
+    statistics <= 1e-4, all gradient tensors (clipped by their global norm) within 2e-5 of their scale."""
+    import bench
+    from oracle.cdt_oracle import OracleCDT
+    from test_gpu_cdt import chunked_oracle_check
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload("c5", dev, 0, 1, None, n_store=1 << 16, use_graph=True)
+    cfg, eng, m = wl.cfg, wl.eng, wl.model
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items() if v.dtype != torch.bool}
+    o = OracleCDT(sd, seq_len=cfg["T"], num_heads=cfg["heads"], num_layers=cfg["layers"], cost_transform=True,
+                  stochastic=True, init_temperature=0.1, target_entropy=-cfg["ad"], learning_rate=1e-4, weight_decay=1e-4,
+                  clip_grad=0.25, lr_warmup_steps=500, loss_cost_weight=0.02, loss_state_weight=0.0, dtype=np.float64)
+    wl.step()  # == the bench's timed call
+    torch.cuda.synchronize()
+    assert eng.graph is not None, "the bench path must be the captured graph"
+    bn = {"states": eng.states, "actions": eng.actions, "returns": eng.returns, "costs_return": eng.ctg,
+          "time_steps": eng.time_steps, "mask": eng.mask, "episode_cost": eng.episode_cost, "costs": eng.costs}
+    bn = {k: v.detach().cpu().numpy().copy() for k, v in bn.items()}
+    B, T = cfg["B"], cfg["T"]
+    assert bn["states"].shape == (B, T, cfg["od"]) and np.isfinite(bn["states"]).all()
+    assert 0 < (bn["mask"] == 0).sum() < 0.5 * B * T, "the store's windows carry tail padding"
+    assert (bn["time_steps"][:, 1:] - bn["time_steps"][:, :-1] == 1).all()
+    masks = eng.dropout_masks()
+    assert all(abs(float((v > 0).float().mean()) - 0.9) < 0.02 for v in masks.values()), "keep rate 0.9 at every site"
+    got = eng.st.read_stats()
+    got = {k.split("/")[-1]: v for k, v in got.items()}
+    worst, coef, n_cmp = chunked_oracle_check(o, bn, masks, got, m.groups["cdt"], ad=cfg["ad"], od=cfg["od"], clip=0.25,
+                                              cost_w=0.02, state_w=0.0, temp=0.1, label="bench path c5")
+    _note(f"bench path c5 step 1: {n_cmp} gradient tensors vs the chunked fp64 oracle on the replayed step's own windows and "
+          f"dropout masks, worst first-moment diff / scale {worst:.2e}, clip coefficient {coef:.4f}")
+    assert eng.st.device_step() == 1
+    # a second replay draws other windows and other masks
+    wl.step()
+    torch.cuda.synchronize()
+    assert not np.array_equal(bn["states"], eng.states.detach().cpu().numpy())
+    m2 = eng.dropout_masks()
+    assert any((m2[k] != masks[k]).any() for k in masks)

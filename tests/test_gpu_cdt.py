@@ -587,6 +587,65 @@ C5_FULL = CDTCase("cdt_c5_full", od=11, ad=3, B=1024, T=20, E=256, heads=8, laye
                   warmup=500, dropout=0.1, seed=6)
 
 
+def chunked_oracle_check(o, bn, masks, got, grp, *, ad, od, clip, cost_w, state_w, temp, label, CH=64):
+    """Step-1 statistics and the full-batch GRADIENT of a CDT step against the fp64 oracle ``o`` (which must hold the
+    parameters the step started from), on the batch ``bn`` (numpy) with the device's own dropout keep-multipliers ``masks``
+    replayed.  The forward is per-sample independent and, with the global normalisers fixed, the loss is a sum over samples:
+    the host evaluates forward and backward in ``CH``-sample chunks (``grads_only``, ``norm``), sums the chunks' gradients,
+    clips by their global norm (cdt.py:398-399) and compares with the device's Adam first moments / (1 - beta1) per tensor.
+    ``got``: the device's logged statistics by short key.  Returns (worst diff / scale, clip coefficient, tensors compared)."""
+    import math
+    B, T = bn["mask"].shape
+    f8 = lambda a: np.asarray(a, np.float64)  # noqa: E731
+    acc = dict(ll=0.0, ent=0.0, nv=0.0, cl=0.0, hit=0.0, msum=0.0, sl=0.0)
+    norm = dict(nv=max(int((bn["mask"] > 0).sum()), 1) * ad, bt=B * T, state_n=B * (T - 1) * od, act_n=B * T * ad)
+    gsum = {}
+    for i in range(0, B, CH):
+        sl = slice(i, i + CH)
+        drop = {k: v[sl].cpu().numpy().astype(np.float64) for k, v in masks.items()}
+        st_, ac_, mk_ = f8(bn["states"][sl]), f8(bn["actions"][sl]), f8(bn["mask"][sl])
+        gch = o.train_one_step(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_,
+                               f8(bn["episode_cost"][sl]), bn["costs"][sl], drop=drop, norm=norm, grads_only=True)
+        for k, v in gch.items():
+            gsum[k] = gsum.get(k, 0.0) + np.asarray(v, np.float64)
+        res, _ = o.forward(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_, drop)
+        valid = (mk_ > 0)[..., None]
+        zz = (ac_ - res["mu"]) / np.exp(res["ls"])
+        acc["ll"] += ((-0.5 * zz * zz - res["ls"] - 0.5 * math.log(2 * math.pi)) * valid).sum()
+        acc["ent"] += ((0.5 + 0.5 * math.log(2 * math.pi) + res["ls"]) * valid).sum()
+        acc["nv"] += valid.sum() * ad
+        ci = bn["costs"][sl].astype(np.int64)
+        lp = res["cost_logp"]
+        acc["cl"] += (-(np.take_along_axis(lp, ci[..., None], -1)[..., 0]) * mk_).sum()
+        acc["hit"] += ((lp.argmax(-1) == ci) * mk_).sum()
+        acc["msum"] += mk_.sum()
+        diff = res["state_pred"][:, :-1] - st_[:, 1:]
+        acc["sl"] += ((diff ** 2) * mk_[:, :-1, None]).sum()
+    want = dict(nll=-acc["ll"] / acc["nv"], ent=acc["ent"] / acc["nv"], cost_loss=acc["cl"] / (B * T),
+                cost_acc=acc["hit"] / acc["msum"], state_loss=acc["sl"] / (B * (T - 1) * od))
+    want["act_loss"] = want["nll"] - temp * want["ent"]
+    want["all_loss"] = want["act_loss"] + cost_w * want["cost_loss"] + state_w * want["state_loss"]
+    for k, r in want.items():
+        assert abs(got[k] - r) <= 1e-4 * max(1.0, abs(r)), f"{label} {k}: gpu {got[k]} vs fp64 oracle forward {r}"
+    # gradients: clip by the global norm (cdt.py:398-399), compare with Adam's first moments after this ONE step
+    tot = math.sqrt(sum(float((v ** 2).sum()) for v in gsum.values()))
+    coef = min(1.0, clip / (tot + 1e-6)) if clip is not None else 1.0
+    worst, n_cmp = 0.0, 0
+    for k, gv in gsum.items():
+        gk = "cdt." + k
+        if gk not in grp.layout or gk in grp.aliases:
+            continue
+        want_m = (1.0 - 0.9) * coef * gv
+        got_m = grp._view(grp.m, gk).cpu().numpy().astype(np.float64)
+        scale = max(np.abs(want_m).max(), 1e-12)
+        d = np.abs(got_m - want_m.reshape(got_m.shape)).max()
+        worst = max(worst, d / scale)
+        n_cmp += 1
+        assert d <= 2e-5 * scale + 1e-9, f"{label}, Adam first moment {k}: max diff {d:.3e} vs scale {scale:.3e}"
+    assert n_cmp == len(gsum), (n_cmp, len(gsum), sorted(set(gsum) - {k[4:] for k in grp.layout}))
+    return worst, coef, n_cmp
+
+
 def test_cdt_c5_full_batch_forward_stats_and_graph():
     """BASELINE.json C5 at its full batch (B = 1024 -> 81920 token rows): the only run of linear_big_kernel's
     640-workgroup grids, the 81920-row dW launch and the 8192 attention workgroups under test.
@@ -610,57 +669,8 @@ def test_cdt_c5_full_batch_forward_stats_and_graph():
     got = {k: lg.last("train/" + k) for k in ("nll", "ent", "cost_loss", "cost_acc", "state_loss", "act_loss", "all_loss")}
     assert all(np.isfinite(v) for v in got.values()), got
     masks = m.engine(c.B).dropout_masks()
-    f8 = lambda a: np.asarray(a, np.float64)  # noqa: E731
-    acc = dict(ll=0.0, ent=0.0, nv=0.0, cl=0.0, hit=0.0, msum=0.0, sl=0.0)
-    CH = 64
-    norm = dict(nv=max(int((bn["mask"] > 0).sum()), 1) * c.ad, bt=c.B * c.T, state_n=c.B * (c.T - 1) * c.od,
-                act_n=c.B * c.T * c.ad)
-    gsum = {}
-    for i in range(0, c.B, CH):
-        sl = slice(i, i + CH)
-        drop = {k: v[sl].cpu().numpy().astype(np.float64) for k, v in masks.items()}
-        st_, ac_, mk_ = f8(bn["states"][sl]), f8(bn["actions"][sl]), f8(bn["mask"][sl])
-        gch = o.train_one_step(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_,
-                               f8(bn["episode_cost"][sl]), bn["costs"][sl], drop=drop, norm=norm, grads_only=True)
-        for k, v in gch.items():
-            gsum[k] = gsum.get(k, 0.0) + np.asarray(v, np.float64)
-        res, _ = o.forward(st_, ac_, f8(bn["returns"][sl]), f8(bn["costs_return"][sl]), bn["time_steps"][sl], mk_, drop)
-        valid = (mk_ > 0)[..., None]
-        zz = (ac_ - res["mu"]) / np.exp(res["ls"])
-        acc["ll"] += ((-0.5 * zz * zz - res["ls"] - 0.5 * math.log(2 * math.pi)) * valid).sum()
-        acc["ent"] += ((0.5 + 0.5 * math.log(2 * math.pi) + res["ls"]) * valid).sum()
-        acc["nv"] += valid.sum() * c.ad
-        ci = bn["costs"][sl].astype(np.int64)
-        lp = res["cost_logp"]
-        acc["cl"] += (-(np.take_along_axis(lp, ci[..., None], -1)[..., 0]) * mk_).sum()
-        acc["hit"] += ((lp.argmax(-1) == ci) * mk_).sum()
-        acc["msum"] += mk_.sum()
-        diff = res["state_pred"][:, :-1] - st_[:, 1:]
-        acc["sl"] += ((diff ** 2) * mk_[:, :-1, None]).sum()
-    temp = 0.1  # init_temperature of build_cdt_gpu / build_cdt_oracle
-    want = dict(nll=-acc["ll"] / acc["nv"], ent=acc["ent"] / acc["nv"], cost_loss=acc["cl"] / (c.B * c.T),
-                cost_acc=acc["hit"] / acc["msum"], state_loss=acc["sl"] / (c.B * (c.T - 1) * c.od))
-    want["act_loss"] = want["nll"] - temp * want["ent"]
-    want["all_loss"] = want["act_loss"] + c.cost_w * want["cost_loss"] + c.state_w * want["state_loss"]
-    for k, r in want.items():
-        assert abs(got[k] - r) <= 1e-4 * max(1.0, abs(r)), f"C5 full batch {k}: gpu {got[k]} vs fp64 oracle forward {r}"
-    # (d) gradients: clip by the global norm (cdt.py:398-399), compare with Adam's first moments after this ONE step
-    tot = math.sqrt(sum(float((v ** 2).sum()) for v in gsum.values()))
-    coef = min(1.0, c.clip / (tot + 1e-6)) if getattr(c, "clip", None) is not None else 1.0
-    grp = m.groups["cdt"]
-    worst, n_cmp = 0.0, 0
-    for k, gv in gsum.items():
-        gk = "cdt." + k
-        if gk not in grp.layout or gk in grp.aliases:
-            continue
-        want_m = (1.0 - 0.9) * coef * gv
-        got_m = grp._view(grp.m, gk).cpu().numpy().astype(np.float64)
-        scale = max(np.abs(want_m).max(), 1e-12)
-        d = np.abs(got_m - want_m.reshape(got_m.shape)).max()
-        worst = max(worst, d / scale)
-        n_cmp += 1
-        assert d <= 2e-5 * scale + 1e-9, f"C5 full batch, Adam first moment {k}: max diff {d:.3e} vs scale {scale:.3e}"
-    assert n_cmp == len(gsum), (n_cmp, len(gsum), sorted(set(gsum) - {k[4:] for k in grp.layout}))
+    worst, coef, n_cmp = chunked_oracle_check(o, bn, masks, got, m.groups["cdt"], ad=c.ad, od=c.od, clip=c.clip, cost_w=c.cost_w,
+                                              state_w=c.state_w, temp=0.1, label="C5 full batch")
     print(f"C5 full batch: {n_cmp} tensors, worst first-moment diff / scale {worst:.2e}, clip coefficient {coef:.4f}")
     del masks, m, tr
     torch.cuda.empty_cache()

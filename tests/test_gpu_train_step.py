@@ -570,16 +570,27 @@ def _random_cases():
 @pytest.mark.parametrize("c", _random_cases(), ids=lambda c: f"{c.name}-{c.od}x{c.ad}-B{c.B}-V{c.vae_hidden}")
 def test_random_shape_tuples_match_the_oracle(c, monkeypatch):
     """One train step of whatever plan the chooser picks for an arbitrary shape == the pinned oracle (fp32 and fp64, the
-    closer one): statistics <= 1e-5, parameters <= 1e-4, the dual variable / PID state.  With the pinned rows of
-    engine/plan.py (tests/test_host_cpu.py) this leaves no reachable plan untested."""
-    if c.algo == "bcql" and c.name.startswith("rand_ns"):  # BCQ-Lag takes the all-CU VAE launches on request only
-        monkeypatch.setenv("OSRL_LAB", "1")
+    closer one): statistics <= 1e-5; the GRADIENTS (Adam first moments after this one step) at ``GROUP_GATE`` = 2e-5 of
+    each tensor's scale or the absolute kink floor, as in the full-size tests; the dual variable / PID state.  The
+    parameters themselves are only bounded by what Adam can do to an element whose gradient is round-off noise (it moves
+    by ~lr whatever the gradient's size: max 2.5 lr apart, median <= 2e-6) -- the 1e-4 claim of north_star is carried by
+    the statistics and the gradients, not by that bound.  With the pinned rows of engine/plan.py
+    (tests/test_host_cpu.py) this leaves no reachable plan untested."""
+    if c.name.startswith("rand_ns"):  # the all-CU VAE launches on request: BCQ-Lag always, CPQ away from the one hidden
+        monkeypatch.setenv("OSRL_LAB", "1")  # width (400) the chooser's rule was timed at (engine/plan.py vae_ns_auto)
         monkeypatch.setenv("OSRL_VAE_NS", "1")
     m, tr, lg = build_gpu(c)
     o32, o64 = build_oracle(c, np.float32), build_oracle(c, np.float64)
     b = gpu_batch(c)
     gpu_step(tr, c, b, 0)
-    s32, s64 = oracle_step(o32, c, 0), oracle_step(o64, c, 0)
+    from oracle.osrl_oracle import MLP, KinkBook
+    book = KinkBook(ulps=2.0)  # which ReLU units sit within fp32 round-off of their kink, and what they may change
+    s32 = oracle_step(o32, c, 0)
+    MLP.kink = book
+    try:
+        s64 = oracle_step(o64, c, 0)
+    finally:
+        MLP.kink = None
     eng = m._engine
     if c.name.startswith("rand_ns"):
         assert eng.vae_ns is not None, "this case is meant to run the all-CU VAE launches"
@@ -590,6 +601,29 @@ def test_random_shape_tuples_match_the_oracle(c, monkeypatch):
         got = lg.last(k)
         d = min(abs(got - s64[k]), abs(got - s32[k]))
         assert d <= 1e-5 * max(1.0, abs(s64[k])), f"{c.name} {k}: gpu {got} vs oracle {s64[k]} / {s32[k]}"
+    opt_names = {"actor": "opt_actor", "critic": "opt_critic", "cost_critic": "opt_cost", "vae": "opt_vae"}
+    # A miss of the strict gate is admitted only where the oracle itself says a ReLU unit within 2 ulp of its kink can move
+    # THAT element, and only by that much: KinkBook.allow bounds, per gradient element, what flipping the undecidable
+    # units changes (row j of dW by |dy[r, j]| |x[r, :]|, carried down the MLP) -- no blanket budget.
+    worst, n_floor, n_kink = {}, 0, 0
+    n_near = sum(len(r) for calls in book.near.values() for r, _ in calls)
+    for gname, oname in opt_names.items():
+        grp = m.groups[gname]
+        for k, mo in getattr(o64, oname).m.items():
+            mg = grp._view(grp.m, k).cpu().numpy()
+            scale = max(np.abs(mo).max(), 1e-12)
+            el = np.minimum(np.abs(mg - mo), np.abs(mg - getattr(o32, oname).m[k]))
+            worst[gname] = max(worst.get(gname, 0.0), el.max() / scale)
+            strict = max(GROUP_GATE * scale, KINK_FLOOR)
+            n_floor += int((el > GROUP_GATE * scale).sum())
+            n_kink += int((el > strict).sum())
+            allow = (1.0 - 0.9) * np.asarray(book.allow.get(k, 0.0)) * 1.01
+            over = el - (strict + allow)
+            assert over.max() <= 0, \
+                f"{c.name} Adam first moment {k} ({gname}): max diff {el.max():.3e} vs scale {scale:.3e}; " \
+                f"{int((over > 0).sum())} element(s) beyond the strict gate + what the {n_near} near-kink unit(s) can move"
+    _note(f"{c.name}: first-moment diff / scale " + ", ".join(f"{g}={v:.2e}" for g, v in worst.items()) +
+          f"; elements that needed the kink floor: {n_floor}; beyond it, covered by the {n_near} near-kink unit(s)' bound: {n_kink}")
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     for k, v in o64.p.items():
         d = min(np.abs(sd[k] - v).max(), np.abs(sd[k] - o32.p[k]).max())

@@ -43,3 +43,19 @@ for mode in ("eager", "graph"):
     nt = (B + 15) // 16
     d = np.diff(st[:nt], axis=1)
     print("     " + " ".join(f"{x:8.2f}" for x in [0.0] + list(d.mean(0))))
+    # per-layer stamps inside the forward / backward bodies (csrc/mlp_common.h PHASE_STAMP / BWD_STAMP under OSRL_STEP_STAMPS)
+    ph = np.zeros((L.STEP_MAX_WG, 2, 16), np.int64)
+    fp = getattr(L.load(), "osrl_debug_step_phases", None)
+    if fp is not None:
+        fp.argtypes = [C.c_void_p]
+        assert fp(ph.ctypes.data) == 0
+        ph = ph[:nt].astype(np.float64) * 0.01
+        FW = ["start", "staged"] + [f"L{l}:{n}" for l in range(3) for n in ("kloop", "barrier", "epilog", "saved")]
+        BW = ["start", "dZstaged"] + [f"L{l}:{n}" for l in (2, 1) for n in ("kloop", "barrier", "stored")]
+        for name, arr, names in (("forward", ph[:, 0], FW), ("backward", ph[:, 1], BW)):
+            k = len(names)
+            a = arr[:, :k]
+            seg = np.diff(a, axis=1)
+            print(f"  {name} body, us per phase (mean over the {nt} row tiles; body total {np.mean(a[:, k - 1] - a[:, 0]):.2f} us):")
+            print("    " + " ".join(f"{n:>10s}" for n in names[1:]))
+            print("    " + " ".join(f"{x:10.2f}" for x in seg.mean(0)))
