@@ -225,11 +225,22 @@ class Workload:
         # several steps per hipGraph, software-pipelined across steps (osrl_amd/engine/pipeline.py): CPQ / BCQ-Lag on one
         # GPU.  Both graphs (n-step and one-step) are captured HERE, outside any timed region
         self.pipe = None
-        if steps_per_graph > 1 and use_graph and dp is None and cfg["algo"] in ("cpq", "bcql"):
+        if steps_per_graph != 1:
+            self.build_pipe(steps_per_graph)
+
+    def build_pipe(self, steps_per_graph: int = 0) -> int:
+        """Several steps per replayed graph (0 = the plan's choice); both graphs -- n-step and one-step -- are captured
+        here, outside any timed region.  Returns the steps per graph in effect."""
+        cfg, eng = self.cfg, self.eng
+        if not (self.use_graph and getattr(eng, "dist", None) is None and cfg["algo"] in ("cpq", "bcql")):
+            return 1
+        spg = int(steps_per_graph) or int(eng.plan.steps_per_graph)
+        if spg > 1:
             from osrl_amd.engine.pipeline import PipelinedSteps
-            self.pipe = PipelinedSteps(self.eng, steps_per_graph)
+            self.pipe = eng._pipe = PipelinedSteps(eng, spg)
             self.pipe.capture()
-            self.eng.capture()
+            eng.capture()
+        return spg
 
     def step(self) -> None:
         self._step()
@@ -325,7 +336,7 @@ def mlp_fwd_flops(run):
     return 2.0 * run.rows * run.net.E * lin(d)
 
 
-DEFAULT_STEPS_PER_GRAPH = 4
+DEFAULT_STEPS_PER_GRAPH = 0  # 0 = what the engine's plan says (engine/plan.py steps_per_graph: C2 4, C3 10, C4 1)
 
 PROBE_SITES = ("enc_ood", "costold_ood", "vae_dw", "actor_phase_fwd", "critic_fwd")
 
@@ -780,8 +791,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip api_path / other_configs (N=1 extras)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     ap.add_argument("--steps-per-graph", type=int, default=DEFAULT_STEPS_PER_GRAPH,
-                    help="train steps per replayed hipGraph, software-pipelined across steps (CPQ / BCQ-Lag, one GPU; "
-                         "1 = one step per graph).  K timed steps = K // n graphs + K %% n single-step replays")
+                    help="train steps per replayed hipGraph, software-pipelined across steps (CPQ / BCQ-Lag, one GPU; 0 = the "
+                         "plan's choice, 1 = one step per graph).  K timed steps = K // n graphs + K %% n single-step replays")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the N-rank job (one process per GPU over RCCL)
@@ -847,12 +858,7 @@ def main():
 
     # Both protocols are measured and reported: first W warm-up + K timed steps straight after the probes
     # (`no_preroll`: what the same command measured in rounds 1-3's records), then the pre-roll + W + K again: `value`.
-    spg = args.steps_per_graph if (dp is None and not args.eager and cfg["algo"] in ("cpq", "bcql")) else 1
-    if spg > 1:
-        from osrl_amd.engine.pipeline import PipelinedSteps
-        wl.pipe = PipelinedSteps(eng, spg)
-        wl.pipe.capture()  # both graphs are captured here, outside the timed regions
-        eng.capture()
+    spg = wl.build_pipe(args.steps_per_graph) if dp is None else 1  # (graphs captured here, outside the timed regions)
     n_done = 0
     dt_cold = None
     if args.preroll_ms > 0 and not args.no_cold:

@@ -322,6 +322,24 @@ class BCQLEngine:
         """Sample minibatches on device from ``store`` (common/replay.py) inside the step itself."""
         self.replay = store
         self.graph = None
+        self._pipe = None
+
+    def steps_replay(self, n: int, steps_per_graph: Optional[int] = None) -> None:
+        """EXACTLY ``n`` train steps on minibatches drawn on device from the attached replay store.  Where the plan says so
+        (``plan.steps_per_graph`` > 1, single GPU) whole multiples go through graphs of that many steps, software-pipelined
+        across steps (engine/pipeline.py: bit-equal to ``n`` calls of ``step_replay()``); the remainder through the
+        one-step graph.  The loop of examples/train/train_cpq.py:138-144 / train_bcql.py:142-148 with the DataLoader
+        folded into the step."""
+        spg = int(self.plan.steps_per_graph if steps_per_graph is None else steps_per_graph)
+        if spg <= 1 or self.dist is not None:
+            for _ in range(int(n)):
+                self.step_replay(True)
+            return
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None or pipe.n != spg:
+            from .pipeline import PipelinedSteps
+            pipe = self._pipe = PipelinedSteps(self, spg)
+        pipe.run(n)
 
     def step_replay(self, use_graph: bool = True) -> None:
         """One train step on a minibatch drawn on device from the attached replay store."""

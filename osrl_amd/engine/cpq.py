@@ -34,7 +34,8 @@ from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, lo
 # than the two 17 us collectives they take off the main chain.  Default "0" = round 4's placement (all four on the main
 # branch).
 DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather issued off the main branch") == "1"
-PIPE_PROLOGUE = P.knob("OSRL_PIPE_PROLOGUE", "side", "pipelined steps: the next step's prologue on the side branch / main")
+PIPE_PROLOGUE = P.knob("OSRL_PIPE_PROLOGUE", "early", "pipelined steps: the next step's prologue behind the OOD statistic (side) / in front of it (early) / on the main chain (main)")
+PIPE_DUAL = P.knob("OSRL_PIPE_DUAL", "main", "pipelined steps: the dual step behind the join (main) / on the side branch behind the OOD statistic (side)")
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -237,13 +238,12 @@ class CPQEngine:
         """One step, single GPU or data parallel (``self.dist``): the launch plan below.
 
         ``nxt`` / ``prologue_done`` (engine/pipeline.py, several steps per graph): the NEXT step's prologue -- into the
-        twin engine ``nxt``'s buffers and step state -- is issued at the tail of THIS step's side branch, behind the OOD
-        statistic, where the side queue would otherwise idle until the join; the next step is then run with
-        ``prologue_done=True``.  Data parallel adds four
-        collectives, ALL issued from the capture stream in the same order on every rank: the VAE gradient (before its
-        Adam), [critic | cost-critic gradients] (where the main branch waits for the side branch's critic dW anyway),
-        the all-gather of the N*B KL values for the batch-global quantile (the selection itself and the masked mean
-        return to the side branch), and [actor gradient | statistics | partial qc_ood mean] after the join.
+        twin engine ``nxt``'s buffers and step state -- is issued at the tail of THIS step's side branch, between the N*B-row
+        encoder launch and the single-workgroup OOD statistic (C2: +1.2 .. +2.6 % against +0.5 % behind it, gpurun_out/r6e);
+        the next step is then run with ``prologue_done=True``.  (Measured and removed, round 6: the two streams SWAPPING roles from step to step, so that
+        no cross-queue edge stands in front of the next VAE phase -- the graph executor then opens a third queue for the
+        swapped main chain, C2 1884-2062 vs 2300-2325 steps/s, and a replay of that graph segfaulted in the runtime:
+        profiles/r6_timeline_4step_swap_c2.txt, DESIGN_LOG round 6.)
 
         What the plan exploits (cpq.py:155-201): everything the OOD penalty is made of -- the N*B sampled actions, the
         target cost critics on them, the VAE encoder on them, the KL rows, their 0.75-quantile, ``qc_ood`` -- sits
@@ -367,6 +367,11 @@ class CPQEngine:
             G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0,
                             None, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
             self.r_cost.backward_dz()
+        dual_on_side = nxt is not None and PIPE_DUAL == "side" and par.enabled
+        ev_cost_stat = None
+        if dual_on_side:  # (lab: the Bellman part of the logged cost loss is complete here)
+            ev_cost_stat = torch.cuda.Event()
+            ev_cost_stat.record()
         fuse_cost = dp is None and self.p_cost.can_fuse_adam()
         if not fuse_cost:
             self.p_cost.launch()
@@ -405,10 +410,15 @@ class CPQEngine:
             elif dp is not None:
                 ev_kl = par.mark(0)
             elif N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
+                if nxt is not None and PIPE_PROLOGUE == "early":
+                    nxt.prologue(device_noise)
                 G.cpq_ood_stat(qc_s, nqc, self.kl, 0.75, N, B, rg, self.quant, self.ood_mean)
             else:
                 G.quantile(self.kl, N * B, 0.75, self.quant)
                 G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
+            if dual_on_side:
+                par.side[0].wait_event(ev_cost_stat)
+                G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
             if nxt is not None and PIPE_PROLOGUE == "side":
                 nxt.prologue(device_noise)  # (pipelined: the next step's minibatch + noise + tick, off the main chain)
 
@@ -458,8 +468,9 @@ class CPQEngine:
         # dual step + the OOD term of the logged loss (cpq.py:186-195): after the join, so that the side branch has no
         # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains); under
         # data parallelism the statistics are already the global ones here, so the global term is added once
-        G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
-        if nxt is not None and PIPE_PROLOGUE != "side":
+        if not dual_on_side:
+            G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
+        if nxt is not None and PIPE_PROLOGUE == "main":
             nxt.prologue(device_noise)  # (lab: the pipelined graph with the next prologue on the main chain, as a control)
 
     # ------------------------------------------------------------------ #
@@ -527,6 +538,7 @@ class CPQEngine:
         """Sample minibatches on device from ``store`` (common/replay.py) inside the step itself."""
         self.replay = store
         self.graph = None
+        self._pipe = None
 
     def _run(self, use_graph: bool) -> None:
         """Replay the captured step (capturing it first).  With a DataParallel hook the RCCL collectives
@@ -551,6 +563,23 @@ class CPQEngine:
                 self.st.host_step += 1
                 return
         self.body(True)
+
+    def steps_replay(self, n: int, steps_per_graph: Optional[int] = None) -> None:
+        """EXACTLY ``n`` train steps on minibatches drawn on device from the attached replay store.  Where the plan says so
+        (``plan.steps_per_graph`` > 1, single GPU) whole multiples go through graphs of that many steps, software-pipelined
+        across steps (engine/pipeline.py: bit-equal to ``n`` calls of ``step_replay()``); the remainder through the
+        one-step graph.  The loop of examples/train/train_cpq.py:138-144 / train_bcql.py:142-148 with the DataLoader
+        folded into the step."""
+        spg = int(self.plan.steps_per_graph if steps_per_graph is None else steps_per_graph)
+        if spg <= 1 or self.dist is not None:
+            for _ in range(int(n)):
+                self.step_replay(True)
+            return
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None or pipe.n != spg:
+            from .pipeline import PipelinedSteps
+            pipe = self._pipe = PipelinedSteps(self, spg)
+        pipe.run(n)
 
     def step_replay(self, use_graph: bool = True) -> None:
         """One train step on a minibatch drawn on device from the attached replay store."""

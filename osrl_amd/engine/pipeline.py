@@ -26,11 +26,9 @@ from typing import Optional
 
 import torch
 
-from . import plan as P
 from .core import ArgArena, Branches, graph_capture, slab_epochs, check_plans_current
 
-STEPS_PER_GRAPH = int(P.knob("OSRL_PIPE_STEPS", "4", "train steps per pipelined graph"))
-
+STEPS_PER_GRAPH = 4  # (default of PipelinedSteps(engine); engines take their plan's steps_per_graph, engine/plan.py)
 
 class PipelinedSteps:
     """``run(n)``: n train steps of ``engine`` (CPQ or BCQ-Lag, single GPU, replay store attached) on minibatches drawn

@@ -68,6 +68,7 @@ class CPQPlan:
     ood_tile: int             # row tile of the N*B-row launches (80 = one workgroup per CU)
     vae_ns: bool              # the VAE phase as all-CU layer launches (csrc/vae_ns.hip)
     vae_adam_side: bool       # single GPU: the VAE's optimizer step at the head of the side branch's second half
+    steps_per_graph: int      # engine.steps_replay(): train steps per replayed hipGraph (engine/pipeline.py); 1 = one step
 
 
 def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> CPQPlan:
@@ -86,9 +87,13 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     side = {"1": True, "0": False}.get(knob("OSRL_VAE_ADAM_SIDE", "auto", "VAE Adam on the side branch: 1 / 0 / auto"),
                                        B >= 1024 and bool(head_tails))
     vt = int(knob("OSRL_VAE_DW_TILE", "0", "dW tile of the VAE group in 16-blocks (0 = by rule)")) or (5 if t5 else 0)
+    # several steps per graph with the next step's prologue on the side branch (engine/pipeline.py, round 6): C2 +1.2 .. +2.6 %
+    # at 4 steps per graph (2335-2365 vs 2305, gpurun_out/r6e), C4 within +-1 % of one step per graph -- its side branch is the
+    # longer one (separate action-draw launches) and gets the extra prologue: on where the draws ride on the actor launch
+    spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or (4 if (head_tails and B >= 1024) else 1)
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
-                   vae_ns=bool(vae_ns), vae_adam_side=bool(side))
+                   vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg)
 
 
 def vae_ns_auto(rows: int, od: int, ad: int, vae_hidden: int = 400) -> bool:
@@ -110,6 +115,7 @@ class BCQLPlan:
     target_tile: int          # row tile of the N*B-row target pipelines (80 = mlp_fwd_nb_kernel)
     vae_ns: bool
     dw_splits: int            # row splits of the critic / cost-critic / actor dW plans (0 = DwPlan's rule)
+    steps_per_graph: int      # engine.steps_replay(): train steps per replayed hipGraph (engine/pipeline.py); 1 = one step
 
 
 def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> BCQLPlan:
@@ -123,22 +129,30 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
     # workgroups of 43 k-steps, one round): C3 648-650 vs 639-642 steps/s, the same at 4 and 8 (gpurun_out/r5n2)
     dws = int(knob("OSRL_BCQ_DW_SPLITS", "0", "BCQ-Lag: row splits of the critic / cost-critic / actor dW plans (0 = by rule)")) \
         or (6 if B >= 4096 else 0)
+    # several steps per graph, the next step's prologue + VAE phase on the side queue under this step's actor phase
+    # (engine/pipeline.py, round 6): C3 651 -> 659-663 at 4 steps per graph, 670 at 10 (gpurun_out/r6b) -- the overlapped
+    # phases are throughput-bound (450 us together against 205 + 222 alone, profiles/r6_timeline_4step_c3.txt), what is
+    # gained are the boundary's bubbles; measured at 4096 rows only
+    spg = int(knob("OSRL_PIPE_STEPS", "0")) or (10 if B >= 4096 else 1)
     return BCQLPlan(vae_dw_tile=5 if t5 else 0,
                     target_tile=int(knob("OSRL_BCQ_TILE", "80", "row tile of BCQ-Lag's N*B-row target pipelines")),
-                    vae_ns=bool(vae_ns), dw_splits=dws)
+                    vae_ns=bool(vae_ns), dw_splits=dws, steps_per_graph=spg)
 
 
 # BASELINE.json configs -> the plan the chooser must give (tests/test_host_cpu.py::test_plan_rows_are_pinned); a changed
 # rule that moves one of these rows is a deliberate act with a measurement behind it (DESIGN_LOG)
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
-           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True)),
+           CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True,
+                   steps_per_graph=4)),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
-           CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False)),
+           CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
+                   steps_per_graph=1)),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
-           BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6)),
+           BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6, steps_per_graph=10)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4),
-                  CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False, vae_adam_side=False)),
+                  CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False, vae_adam_side=False,
+                           steps_per_graph=1)),
 }
 
 

@@ -77,9 +77,10 @@ def test_pipelined_steps_equal_one_step_graph_replays(name, spg, total):
     torch.cuda.empty_cache()
 
     m_b, e_b = build(name)
-    pipe = PipelinedSteps(e_b, steps_per_graph=spg)
-    pipe.run(total)
+    e_b.steps_replay(total, steps_per_graph=spg)  # (the engine-level entry point; builds its PipelinedSteps on first use)
     torch.cuda.synchronize()
+    pipe = e_b._pipe
+    assert isinstance(pipe, PipelinedSteps) and pipe.n == spg
     assert pipe.graph is not None and e_b.st.device_step() == total and e_b.st.host_step == total
     got = _state(m_b, e_b)
     assert set(got) == set(ref)
@@ -98,6 +99,21 @@ def test_pipelined_steps_equal_one_step_graph_replays(name, spg, total):
     torch.cuda.synchronize()
     assert e_b.st.device_step() == total + 1
     assert all(np.isfinite(v) for v in e_b.st.read_stats().values())
+
+
+def test_steps_replay_follows_the_plan():
+    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 4 at C2's shape, 1 at C4's) and leaves
+    the engine n steps further either way."""
+    m, e = _bench("c2")
+    assert e.plan.steps_per_graph == 4
+    e.steps_replay(9)
+    torch.cuda.synchronize()
+    assert e._pipe is not None and e._pipe.n == 4 and e.st.device_step() == 9
+    m4, e4 = _bench("c4")
+    assert e4.plan.steps_per_graph == 1
+    e4.steps_replay(3)
+    torch.cuda.synchronize()
+    assert getattr(e4, "_pipe", None) is None and e4.st.device_step() == 3
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])
