@@ -336,7 +336,7 @@ def mlp_fwd_flops(run):
     return 2.0 * run.rows * run.net.E * lin(d)
 
 
-DEFAULT_STEPS_PER_GRAPH = 0  # 0 = what the engine's plan says (engine/plan.py steps_per_graph: C2 4, C3 10, C4 1)
+DEFAULT_STEPS_PER_GRAPH = 0  # 0 = what the engine's plan says (engine/plan.py steps_per_graph: C2 5, C3 10, C4 1)
 
 PROBE_SITES = ("enc_ood", "costold_ood", "vae_dw", "actor_phase_fwd", "critic_fwd")
 
@@ -510,11 +510,17 @@ def roofline(eng, cfg_name="c2"):
     ach = r["_fl"] / (r["_us"] * 1e-6) / 1e12 if have_run else ach_iso
     out = {"bound": "mfma", "kernel": dom, "symbol": r["symbol"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-           "frac_is": ("in-run: the launch inside the REPLAYED graph, bracketed by device-side 100 MHz stamps on its own stream "
-                       "(in_graph_us; the rocprofv3 --kernel-trace average of the same kernel under profiles/ is the cross-"
-                       "check); kernel = the launch with the largest in-step duration" if r.get("in_step_how") == "graph" else
+           "frac_is": ("in-run: the launch inside the REPLAYED one-step graph, bracketed by device-side 100 MHz stamps on its own "
+                       "stream (in_graph_us; the rocprofv3 --kernel-trace average of the same kernel under profiles/ is the cross-"
+                       "check).  'Dominant' is PER LAUNCH: kernel = the single launch with the largest in-step duration; by TOTAL "
+                       "time per step the top symbol is another one (top_by_total)" if r.get("in_step_how") == "graph" else
                        "in-run (eagerly issued two-stream step body, HIP events)") if have_run else
                       "isolated (N > 1: no in-step probe)",
+           # the symbol with the largest TOTAL time per step in the rocprofv3 --kernel-trace --stats summary of this command
+           # (profiles/r6_bench_kernel_stats_c2.csv): three launches per step of the 16-row paired forward (actor trunks,
+           # critic-phase and cost-phase forwards), ~105 us per step between them at MFMA-busy 0.28 (profiles/r6_pmc_c2.json)
+           "top_by_total": {"symbol": "mlp_fwd2_kernel_p<1, 2, 8>", "launches_per_step": 3,
+                            "source": "static: profiles/r6_bench_kernel_stats_c2.csv"} if cfg_name == "c2" else None,
            "isolated_achieved": round(ach_iso, 3), "isolated_frac": round(ach_iso / PEAK_FP32_TFLOPS, 4),
            "traffic": r["traffic"], "traffic_source": traffic_src if r["traffic"] is not None else None,
            "algorithmic_bytes": r["algorithmic_bytes"],

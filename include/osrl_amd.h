@@ -628,6 +628,18 @@ int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S
                        int32_t prefix, const osrl_dropout_t* drop, float* o, void* stream);
 int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S, int32_t E,
                        int32_t H, int32_t rep, int32_t prefix, const osrl_dropout_t* drop, float* dqkv, void* stream);
+/* The same pair with the attention-probability dropout's keep decisions handed from the forward launch to the backward
+ * launch instead of being regenerated there (head widths E / H = 16 or 32; net.py:406-409 -- torch keeps its dropout mask
+ * for autograd the same way).  `keep`: caller-allocated, osrl_attention_keep_bytes(B, S, E, H) bytes (0 = shape not
+ * supported: pass NULL), one nibble of four key decisions per byte; written by _fwd_keep when drop is active, read by
+ * _bwd_keep of the SAME step.  The decisions are the Philox words' tests either way: results are bit-identical to the plain
+ * pair, which the NULL form is. */
+int64_t osrl_attention_keep_bytes(int32_t B, int32_t S, int32_t E, int32_t H);
+int osrl_attention_fwd_keep(const float* qkv, const float* mask, int32_t B, int32_t S, int32_t E, int32_t H, int32_t rep,
+                            int32_t prefix, const osrl_dropout_t* drop, float* o, unsigned char* keep, void* stream);
+int osrl_attention_bwd_keep(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S, int32_t E,
+                            int32_t H, int32_t rep, int32_t prefix, const osrl_dropout_t* drop, float* dqkv,
+                            const unsigned char* keep, void* stream);
 /* nn.Dropout in training mode (cdt.py:87,222 embedding; net.py:404,439 residual; net.py:414 MLP tail):
  * y[i] = x[i] * keep_i / (1-p), may run in place.  keep_i is a pure function of (seed, st->step, site, i)
  * (Philox4x32-10), so calling it again on the incoming gradient IS the backward pass; nothing is stored.

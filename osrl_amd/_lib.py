@@ -243,6 +243,9 @@ PROTOTYPES = {
     "osrl_layernorm_bwd_drop": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _P(DropoutT), _fp, _i32, _i32, _i32, _fp, _i64, _i64, _vp],
     "osrl_attention_fwd": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
     "osrl_attention_bwd": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp],
+    "osrl_attention_keep_bytes": [_i32, _i32, _i32, _i32],
+    "osrl_attention_fwd_keep": [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp, _vp],
+    "osrl_attention_bwd_keep": [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _P(DropoutT), _fp, _vp, _vp],
     "osrl_dropout": [_fp, _fp, _i64, _P(DropoutT), _vp],
     "osrl_gelu_fwd": [_fp, _fp, _i64, _vp],
     "osrl_gelu_bwd": [_fp, _fp, _fp, _i64, _vp],
@@ -263,7 +266,7 @@ _LIB: Optional[C.CDLL] = None
 
 LOSS_WS = 132  # floats of scratch for the grid loss kernels (include/osrl_amd.h OSRL_LOSS_WS)
 QUANTILE_WS = 1032  # uint32 elements of scratch for osrl_quantile_ws (include/osrl_amd.h OSRL_QUANTILE_WS)
-RESTYPES = {"osrl_ingest_ws_elems": C.c_int64}  # everything else returns int (0 = ok)
+RESTYPES = {"osrl_ingest_ws_elems": C.c_int64, "osrl_attention_keep_bytes": C.c_int64}  # everything else returns int (0 = ok)
 
 
 def lib_path() -> str:

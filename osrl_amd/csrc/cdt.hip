@@ -592,6 +592,11 @@ struct AttnArgs {
   uint32_t drop_thresh, drop_site, k0, k1;
   float drop_scale;
   const osrl_step_state_t* st;
+  // round 6 (head widths 16 / 32): the keep decisions of the probability dropout, one NIBBLE (four keys of one query) per
+  // byte, written by the forward launch and read back by the backward launch instead of 15 Philox calls per lane --
+  // layout [B*H][key block][query row (Sp)][key quad]: the 64 lanes of a (row block, key block) pair touch 64
+  // consecutive bytes.  nullptr: every launch regenerates its masks (same decisions: the bytes ARE the Philox words' tests)
+  unsigned char* keep;
 };
 
 // keep-multipliers of the four probabilities P[bh][i][j0 .. j0+3] (j0 a multiple of 4) one lane owns in the register
@@ -605,6 +610,16 @@ __device__ __forceinline__ f32x4 attn_drop_mult4(const AttnArgs& a, int bh, int 
   const osrl_rng::U4 w = osrl_rng::drop_words(e4, step, a.drop_site, a.k0, a.k1);
   return f32x4{w.x >= a.drop_thresh ? a.drop_scale : 0.f, w.y >= a.drop_thresh ? a.drop_scale : 0.f,
                w.z >= a.drop_thresh ? a.drop_scale : 0.f, w.w >= a.drop_thresh ? a.drop_scale : 0.f};
+}
+
+__device__ __forceinline__ size_t attn_keep_at(int bh, int nb, int jb, int Sp, int row, int q4) {
+  return (((size_t)bh * nb + jb) * Sp + row) * 4 + (q4 >> 2);
+}
+__device__ __forceinline__ unsigned attn_keep_bits(const f32x4& dm) {
+  return (dm[0] != 0.f ? 1u : 0u) | (dm[1] != 0.f ? 2u : 0u) | (dm[2] != 0.f ? 4u : 0u) | (dm[3] != 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ f32x4 attn_keep_mult4(unsigned bits, float scale) {
+  return f32x4{(bits & 1u) ? scale : 0.f, (bits & 2u) ? scale : 0.f, (bits & 4u) ? scale : 0.f, (bits & 8u) ? scale : 0.f};
 }
 
 // 16-lane (one DPP row) butterfly reductions: 4 VALU DPP ops instead of 4-6 ds_bpermute round trips
@@ -1231,7 +1246,11 @@ __device__ __forceinline__ void attn_fwd_rows(const AttnCtx& c, const AttnArgs& 
   const float inv = live ? 1.0f / sum : 0.f;
   if (a.drop_thresh && row < a.S) {
 #pragma unroll
-    for (int jb = 0; jb <= IB; ++jb) s[jb] *= attn_drop_mult4(a, c.bh, row, jb * 16 + q4, c.Sp);
+    for (int jb = 0; jb <= IB; ++jb) {
+      const f32x4 dm = attn_drop_mult4(a, c.bh, row, jb * 16 + q4, c.Sp);
+      if (a.keep) a.keep[attn_keep_at(c.bh, c.Sp >> 4, jb, c.Sp, row, q4)] = (unsigned char)attn_keep_bits(dm);
+      s[jb] *= dm;
+    }
   }
 #pragma unroll
   for (int jb = 0; jb <= IB; ++jb) s[jb] *= inv;
@@ -1301,6 +1320,12 @@ __device__ __forceinline__ void attn_bwd_rows(const AttnCtx& c, const AttnArgs& 
   f32x4 qf[NCB], dof[NCB];
   attn_gfrags<NCB>(c.q, c.ldg, row, a.S, q4, qf);
   attn_gfrags<NCB>(c.dob, a.E, row, a.S, q4, dof);
+  unsigned kbits[IB + 1];  // the forward launch's keep decisions (requested here, used behind the softmax)
+  if (a.drop_thresh && a.keep) {
+#pragma unroll
+    for (int jb = 0; jb <= IB; ++jb)
+      kbits[jb] = row < a.S ? a.keep[attn_keep_at(c.bh, c.Sp >> 4, jb, c.Sp, row, q4)] : 0u;
+  }
   f32x4 s[IB + 1], g[IB + 1], pk[IB + 1];
   float mx = -INFINITY;
 #pragma unroll
@@ -1342,7 +1367,8 @@ __device__ __forceinline__ void attn_bwd_rows(const AttnCtx& c, const AttnArgs& 
   if (a.drop_thresh) {  // P' = P M / (1-p); the keep flags of the tile go to LDS for pass B
 #pragma unroll
     for (int jb = 0; jb <= IB; ++jb) {
-      const f32x4 dm = row < a.S ? attn_drop_mult4(a, c.bh, row, jb * 16 + q4, c.Sp) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 dm = a.keep ? attn_keep_mult4(kbits[jb], a.drop_scale)
+                              : (row < a.S ? attn_drop_mult4(a, c.bh, row, jb * 16 + q4, c.Sp) : f32x4{0.f, 0.f, 0.f, 0.f});
       pk[jb] *= dm;
       const uint32_t flags = (dm[0] != 0.f ? 1u : 0u) | (dm[1] != 0.f ? 0x100u : 0u) | (dm[2] != 0.f ? 0x10000u : 0u) |
                              (dm[3] != 0.f ? 0x1000000u : 0u);
@@ -1996,17 +2022,30 @@ int osrl_dropout(const float* x, float* y, int64_t n, const osrl_dropout_t* dr, 
 
 int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S_, int32_t E, int32_t H, int32_t rep,
                        int32_t prefix, const osrl_dropout_t* drop, float* o, void* stream) {
+  return osrl_attention_fwd_keep(qkv, mask, B, S_, E, H, rep, prefix, drop, o, nullptr, stream);
+}
+
+int64_t osrl_attention_keep_bytes(int32_t B, int32_t S_, int32_t E, int32_t H) {
+  if (B < 1 || S_ < 1 || S_ > 128 || H < 1 || E % H || !(E / H == 16 || E / H == 32)) return 0;
+  const int64_t Sp = (S_ + 15) & ~15;
+  return (int64_t)B * H * (Sp >> 4) * Sp * 4;
+}
+
+int osrl_attention_fwd_keep(const float* qkv, const float* mask, int32_t B, int32_t S_, int32_t E, int32_t H, int32_t rep,
+                            int32_t prefix, const osrl_dropout_t* drop, float* o, unsigned char* keep, void* stream) {
   prefix = prefix ? 1 : 0;
   if (!qkv || !mask || !o || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || rep < 1 || (S_ - prefix) % rep ||
       S_ - prefix < rep)
     return -1;
   AttnArgs a{qkv, mask, o, nullptr, nullptr, B, S_, E, H, rep, prefix};
   if (!attn_drop_args(drop, &a)) return -1;
+  a.keep = a.drop_thresh ? keep : nullptr;
   if (attn_vec_ok(E, H, qkv, o, nullptr, nullptr)) {
     CLEAR();
     attn_launch_v<true>(a, S);
     DONE();
   }
+  if (keep) return -1;  // the keep hand-off exists for the head-width 16 / 32 kernels only (osrl_attention_keep_bytes == 0)
   const size_t lds = attn_lds(S_, E / H, false);
   if (lds > kMaxLds) return -1;
   CLEAR();
@@ -2019,17 +2058,25 @@ int osrl_attention_fwd(const float* qkv, const float* mask, int32_t B, int32_t S
 
 int osrl_attention_bwd(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S_, int32_t E,
                        int32_t H, int32_t rep, int32_t prefix, const osrl_dropout_t* drop, float* dqkv, void* stream) {
+  return osrl_attention_bwd_keep(qkv, mask, dout, B, S_, E, H, rep, prefix, drop, dqkv, nullptr, stream);
+}
+
+int osrl_attention_bwd_keep(const float* qkv, const float* mask, const float* dout, int32_t B, int32_t S_, int32_t E,
+                            int32_t H, int32_t rep, int32_t prefix, const osrl_dropout_t* drop, float* dqkv,
+                            const unsigned char* keep, void* stream) {
   prefix = prefix ? 1 : 0;
   if (!qkv || !mask || !dout || !dqkv || B < 1 || S_ < 1 || S_ > 128 || E % H || E / H > 64 || rep < 1 ||
       (S_ - prefix) % rep || S_ - prefix < rep)
     return -1;
   AttnArgs a{qkv, mask, nullptr, dout, dqkv, B, S_, E, H, rep, prefix};
   if (!attn_drop_args(drop, &a)) return -1;
+  a.keep = a.drop_thresh ? const_cast<unsigned char*>(keep) : nullptr;
   if (attn_vec_ok(E, H, qkv, nullptr, dout, dqkv)) {
     CLEAR();
     attn_launch_v<false>(a, S);
     DONE();
   }
+  if (keep) return -1;
   const size_t lds = attn_lds(S_, E / H, true);
   if (lds > kMaxLds) return -1;
   if (lds > 64 * 1024) {  // opt in to a large dynamic allocation (S = 128 with head_dim 64)

@@ -33,6 +33,10 @@ struct NbArgs {
   float* y[OSRL_MAX_NETS];
   int32_t lda, kl_L;
   float* kl;  // OSRL_TAIL_VAE_KL: [rows] per-row KL of net 0's (mean | log_std) output, or NULL
+  // round 6: a ONE-output head (every Q network: 256 -> 1) is not run as a layer -- the last wide layer's epilogue takes
+  // the dot product of its activated accumulators with the head's weight column straight from the registers (nb_head_dot):
+  // no activation write-back, no 16-column MFMA pass for one real column, no partial tiles, two barriers fewer
+  int32_t fuse_head;
 };
 constexpr float kNbLsMin = -4.0f, kNbLsMax = 15.0f;  // net.py:325 (== kVaeLsMin / kVaeLsMax of glue.hip)
 
@@ -204,15 +208,58 @@ __device__ __forceinline__ void nb_epilogue(float* lds, int lda, const f32x4 (&a
   }
 }
 
+// The one-output head on the last wide layer's accumulators.  A lane holds out[row = lane & 15][4 consecutive columns] of
+// each (row block, column block) register tile (nb_mm: transposed tiles), the head's packed weight column is
+// PF[k / 4][n = 0][k % 4] with 16 padded outputs, i.e. the four weights of a lane's columns are ONE aligned float4 at
+// hw + (col / 4) * 64: partial[rb] = sum over the lane's columns of act(acc) * w, summed over the four lanes of a row
+// (xor 16, 32), one partial per wave and row into `part` [waves][rows]; the caller sums the waves in order.  (hwv: requested
+// by the caller in front of the k-loop.)
+template <int CNT>
+__device__ __forceinline__ void nb_head_dot(const f32x4 (&acc)[kNbRb][CNT], const f32x4 (&hwv)[CNT], int act, int lane,
+                                            float* __restrict__ part) {
+  float rd[kNbRb];
+#pragma unroll
+  for (int rb = 0; rb < kNbRb; ++rb) rd[rb] = 0.f;
+  auto run = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c)
+#pragma unroll
+      for (int rb = 0; rb < kNbRb; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd[rb] = __builtin_fmaf(act_fwd(ACT, acc[rb][c][r]), hwv[c][r], rd[rb]);
+  };
+  if (act == OSRL_ACT_RELU) run(std::integral_constant<int, OSRL_ACT_RELU>{});
+  else if (act == OSRL_ACT_TANH) run(std::integral_constant<int, OSRL_ACT_TANH>{});
+  else run(std::integral_constant<int, OSRL_ACT_ID>{});
+#pragma unroll
+  for (int rb = 0; rb < kNbRb; ++rb) {
+    rd[rb] += __shfl_xor(rd[rb], 16);
+    rd[rb] += __shfl_xor(rd[rb], 32);
+    if (lane < 16) part[rb * 16 + lane] = rd[rb];
+  }
+}
+
 template <int CNT, bool ADB = true>
 __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
-                                              const float* __restrict__ bias, int act, int cb0, int lane, int pl) {
+                                              const float* __restrict__ bias, int act, int cb0, int lane, int pl,
+                                              const float* __restrict__ hw = nullptr, float* __restrict__ part = nullptr) {
   (void)pl;  // layer number, for the debug build's phase stamps only
   f32x4 braw[CNT];
   nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
+  f32x4 hwv[CNT];
+  if (hw) {  // (wave-uniform) the head's weights for this lane's columns: in flight under the k-loop
+#pragma unroll
+    for (int c = 0; c < CNT; ++c)
+      hwv[c] = *reinterpret_cast<const f32x4*>(hw + (size_t)((cb0 + c) * 4 + (lane >> 4)) * 64);
+  }
   f32x4 acc[kNbRb][CNT];
   nb_mm<CNT, ADB>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
   PHASE_STAMP(2 + 4 * pl);
+  if (hw) {  // the tile is not written again: no barrier in front, the caller's barrier behind
+    nb_head_dot<CNT>(acc, hwv, act, lane, part);
+    return;
+  }
   __syncthreads();  // every wave finished reading the previous activations
   PHASE_STAMP(3 + 4 * pl);
   nb_epilogue<CNT, kNbRb>(lds, lda, acc, cb0, 0, N, act, lane);
@@ -361,6 +408,7 @@ template <int NCB, bool SHARED, int NW, class AR>
 __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * kNbRb;
+  __shared__ float s_head[SHARED ? 1 : NW * BM];  // fuse_head: per-wave partial dot products of the one-output head
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int e = blockIdx.y, row0 = blockIdx.x * BM;
@@ -441,11 +489,27 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     } else {
       int cb0, cnt;
       wave_blocks<NW>(nblk, wave, &cb0, &cnt);
+      const bool headl = a.fuse_head && l == L - 2;  // (uniform) the one-output head rides on this layer's accumulators
+      const float* __restrict__ hw = headl ? a.net.Wf[e][L - 1] : nullptr;
+      float* part = headl ? s_head + wave * BM : nullptr;
       if (cnt == NCB)
-        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
+        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l, hw, part);
       else
-        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l);
+        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l, hw, part);
     }
+  }
+  if (!SHARED && a.fuse_head) {  // ---- one-output head: the waves' partial dot products, summed in wave order
+    __syncthreads();
+    const int l = L - 1;
+    if (tid < BM && row0 + tid < rows) {
+      float sacc = s_head[tid];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sacc += s_head[w * BM + tid];
+      a.y[e][row0 + tid] = act_fwd(a.net.acts[l], sacc + a.net.b[e][l][0]) * a.net.out_scale;
+    }
+    PHASE_STAMP(5 + 4 * l);
+    WG_LOG(1);
+    return;
   }
   {  // ---- narrow head: K split over the 4 waves, every weight fragment of a wave's share loaded up front
     const int l = L - 1;
@@ -614,6 +678,11 @@ __attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, 
   a.lda = lda;
   a.kl = kl;
   a.kl_L = kl_L;
+  {  // one-output heads (Q networks) on the 13..16-block forms: fused into the last wide layer's epilogue.  OSRL_NB_HEAD=0
+    // restores the head as a layer (read per launch: A/B runs and the kernel-equality test flip it)
+    const char* fh = getenv("OSRL_NB_HEAD");
+    a.fuse_head = (NL == 1 && ncb == 4 && !kl && !(fh && atoi(fh) == 0)) ? 1 : 0;
+  }
   const int tiles = (in->rows + kNbRows - 1) / kNbRows;
   bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
   for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;

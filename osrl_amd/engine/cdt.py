@@ -23,6 +23,7 @@ from . import plan as _plan
 from .core import DwPlan, FlatGroup, StepState, capture_step, cur_stream, load_into, check_plans_current
 
 LN_BATCH = _plan.knob("OSRL_CDT_LN_BATCH", "1", "CDT: the LayerNorm parameter reductions of a step in one launch") == "1"
+ATTN_KEEP = _plan.knob("OSRL_CDT_ATTN_KEEP", "1", "CDT: attention dropout decisions handed from forward to backward") == "1"
 SLAB_COUNTS = _plan.knob("OSRL_CDT_SLAB_COUNTS", "1", "CDT: gradient slabs summed per range by its own split count") == "1"
 FUSE_DROP = _plan.knob("OSRL_CDT_FUSE_DROP", "1", "residual-branch dropout inside the LayerNorm launches") == "1"  # residual-branch dropout inside the LayerNorm launches
 STAT_KEYS = ["nll", "ent", "ent_reg", "all_loss", "act_loss", "cost_loss", "cost_acc", "state_loss", "train_lr"]
@@ -68,6 +69,12 @@ class CDTEngine:
         self.n1 = [z(M, E) for _ in range(NL)]
         self.st1 = [z(M, 2) for _ in range(NL)]
         self.qkv = [z(M, 3 * E) for _ in range(NL)]
+        # round 6: the attention-probability dropout's keep decisions, handed from the forward to the backward launch of a
+        # layer (one nibble per four keys; head widths 16 / 32) instead of 15 Philox calls per lane in the backward
+        self.attn_keep = None
+        kb = int(L.load().osrl_attention_keep_bytes(B, self.S, E, self.H)) if (ATTN_KEEP and not inference) else 0
+        if kb > 0 and m.attention_dropout > 0:
+            self.attn_keep = [torch.zeros(kb, dtype=torch.uint8, device=dev) for _ in range(NL)]
         self.o = [z(M, E) for _ in range(NL)]
         self.att = z(M, E)
         self.xmid = [z(M, E) for _ in range(NL)]
@@ -338,9 +345,10 @@ class CDTEngine:
                 self._ln_fwd(self.xin[0], None, p + "norm1", None, self.n1[0], self.st1[0])
             self._lin(self.n1[l], E, M, p + "attention.in_proj_weight", self.qkv[l], 3 * E)
             da = self._site(1 + 3 * l, p_attn)
-            L.check(lib.osrl_attention_fwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.B, self.S, E, self.H,
-                                           self.R, self.P, ctypes.byref(da) if p_attn > 0 else None, self.o[l].data_ptr(),
-                                           cur_stream()), "osrl_attention_fwd")
+            keep = self.attn_keep[l].data_ptr() if (train and self.attn_keep is not None and p_attn > 0) else None
+            L.check(lib.osrl_attention_fwd_keep(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.B, self.S, E, self.H,
+                                                self.R, self.P, ctypes.byref(da) if p_attn > 0 else None,
+                                                self.o[l].data_ptr(), keep, cur_stream()), "osrl_attention_fwd")
             self._lin(self.o[l], E, M, p + "attention.out_proj.weight", self.att, E)
             self._ln_fwd(self.xin[l], self.att, p + "norm2", self.xmid[l], self.n2[l], self.st2[l],
                          drop=(2 + 3 * l, p_res))
@@ -450,10 +458,11 @@ class CDTEngine:
                          drop=(2 + 3 * l, self.p_res), dx_dropped=self.datt[l])
             self._lin_dx(self.datt[l], E, M, p + "attention.out_proj.weight", self.do, E)
             da = self._site(1 + 3 * l, self.p_attn)
-            L.check(lib.osrl_attention_bwd(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.do.data_ptr(), self.B,
-                                           self.S, E, self.H, self.R, self.P,
-                                           ctypes.byref(da) if self.p_attn > 0 else None,
-                                           self.dqkv[l].data_ptr(), cur_stream()), "attn_bwd")
+            keep = self.attn_keep[l].data_ptr() if (self.attn_keep is not None and self.p_attn > 0) else None
+            L.check(lib.osrl_attention_bwd_keep(self.qkv[l].data_ptr(), self.mask.data_ptr(), self.do.data_ptr(), self.B,
+                                                self.S, E, self.H, self.R, self.P,
+                                                ctypes.byref(da) if self.p_attn > 0 else None,
+                                                self.dqkv[l].data_ptr(), keep, cur_stream()), "attn_bwd")
             self._lin_dx(self.dqkv[l], 3 * E, M, p + "attention.in_proj_weight", self.dn, E)
             if l > 0:
                 self._ln_bwd(self.dn, self.xin[l], self.st1[l], p + "norm1", self.dxm[l], self.dxo[l],

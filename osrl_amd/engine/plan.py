@@ -88,9 +88,11 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
                                        B >= 1024 and bool(head_tails))
     vt = int(knob("OSRL_VAE_DW_TILE", "0", "dW tile of the VAE group in 16-blocks (0 = by rule)")) or (5 if t5 else 0)
     # several steps per graph with the next step's prologue on the side branch (engine/pipeline.py, round 6): C2 +1.2 .. +2.6 %
-    # at 4 steps per graph (2335-2365 vs 2305, gpurun_out/r6e), C4 within +-1 % of one step per graph -- its side branch is the
-    # longer one (separate action-draw launches) and gets the extra prologue: on where the draws ride on the actor launch
-    spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or (4 if (head_tails and B >= 1024) else 1)
+    # at 4 steps per graph over 200 steps (2335-2365 vs 2305, gpurun_out/r6e); on the driver's K = 20 / W = 5 command, medians of
+    # five alternating rounds: 2293 (1) / 2308 (2) / 2317 (4) / 2329 (5) / 2328 (10) (profiles/r6_k20_steps_per_graph.txt) -> 5.
+    # C4 within +-1 % of one step per graph -- its side branch is the longer one (separate action-draw launches) and gets the
+    # extra prologue: on where the draws ride on the actor launch
+    spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or (5 if (head_tails and B >= 1024) else 1)
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
                    vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg)
@@ -144,7 +146,7 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True,
-                   steps_per_graph=4)),
+                   steps_per_graph=5)),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
                    steps_per_graph=1)),

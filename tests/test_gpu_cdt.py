@@ -395,6 +395,66 @@ def test_attention_wave_splits_padding_and_dropout(S, E, H, rep, prefix, p):
     assert np.abs(dqkv.cpu().numpy() - ref).max() < 5e-5 * max(1, np.abs(ref).max()), "dqkv"
 
 
+@pytest.mark.parametrize("S,E,H,rep,prefix,p", [(80, 256, 8, 4, 0, 0.1), (81, 128, 8, 4, 1, 0.3), (96, 256, 16, 4, 0, 0.2),
+                                                 (36, 64, 2, 2, 0, 0.1), (128, 256, 8, 2, 0, 0.1)])
+def test_attention_keep_handoff_is_bit_identical(S, E, H, rep, prefix, p):
+    """osrl_attention_fwd_keep / _bwd_keep (round 6: the probability dropout's keep decisions written by the forward launch,
+    one nibble per four keys, and read back by the backward launch instead of regenerated) == the plain pair bit for bit, at
+    head widths 16 / 32, ragged S, the prefix token, 2 / 3 / 4 waves per pair; the bytes themselves == the exported Philox
+    mask; a shape without the fast kernels reports 0 bytes and refuses a keep buffer."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import StepState, cur_stream
+    lib = L.load()
+    st = StepState(torch.device(DEV), ["x"])
+    st.tick()
+    rs = np.random.RandomState(S + E)
+    B, T = 5, (S - prefix) // rep
+    qt = t((0.7 * rs.randn(B, S, 3 * E)).astype(np.float32))
+    mk = np.ones((B, T), np.float32)
+    mk[1, T - 3:] = 0
+    mk[2, :2] = 0
+    mt, dot = t(mk), t(rs.randn(B, S, E).astype(np.float32))
+    dr = L.DropoutT(p, 9, 13, st.ptr)
+    drp = C.byref(dr)
+    nbytes = int(lib.osrl_attention_keep_bytes(B, S, E, H))
+    Sp = (S + 15) // 16 * 16
+    assert nbytes == B * H * (Sp // 16) * Sp * 4
+    keep = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=DEV)
+    o0, o1 = torch.zeros(B, S, E, device=DEV), torch.zeros(B, S, E, device=DEV)
+    g0, g1 = torch.zeros(B, S, 3 * E, device=DEV), torch.zeros(B, S, 3 * E, device=DEV)
+    L.check(lib.osrl_attention_fwd(qt.data_ptr(), mt.data_ptr(), B, S, E, H, rep, prefix, drp, o0.data_ptr(), cur_stream()), "f")
+    L.check(lib.osrl_attention_bwd(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, rep, prefix, drp, g0.data_ptr(),
+                                   cur_stream()), "b")
+    L.check(lib.osrl_attention_fwd_keep(qt.data_ptr(), mt.data_ptr(), B, S, E, H, rep, prefix, drp, o1.data_ptr(),
+                                        keep.data_ptr(), cur_stream()), "fk")
+    L.check(lib.osrl_attention_bwd_keep(qt.data_ptr(), mt.data_ptr(), dot.data_ptr(), B, S, E, H, rep, prefix, drp,
+                                        g1.data_ptr(), keep.data_ptr(), cur_stream()), "bk")
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(g0, g1)
+    assert o0.abs().sum().item() > 0 and g0.abs().sum().item() > 0
+    # the bytes against the exported mask: keep[bh][jb][row][quad] bit r <-> mask[bh, row, 16 jb + 4 quad + r] (lower triangle)
+    raw, ones = torch.empty(B * H, S, Sp, device=DEV), torch.ones(B * H, S, Sp, device=DEV)
+    L.check(lib.osrl_dropout(ones.data_ptr(), raw.data_ptr(), raw.numel(), drp, cur_stream()), "m")
+    Mk = (raw.cpu().numpy() > 0)
+    kb = keep.cpu().numpy().reshape(B * H, Sp // 16, Sp, 4)
+    for jb in range(Sp // 16):
+        rows = np.arange(16 * jb, S)  # row blocks ib >= jb hold key block jb
+        for quad in range(4):
+            for r in range(4):
+                j = 16 * jb + 4 * quad + r
+                want = Mk[:, rows, j]
+                got = (kb[:, jb, rows, quad] >> r) & 1
+                assert np.array_equal(got.astype(bool), want), (jb, quad, r)
+    # head width 64: no fast kernels, no hand-off
+    assert int(lib.osrl_attention_keep_bytes(B, 80, 512, 8)) == 0
+    q2 = torch.zeros(B, 80, 3 * 512, device=DEV)
+    o2 = torch.zeros(B, 80, 512, device=DEV)
+    m2 = torch.ones(B, 20, device=DEV)
+    assert lib.osrl_attention_fwd_keep(q2.data_ptr(), m2.data_ptr(), B, 80, 512, 8, 4, 0, drp, o2.data_ptr(), keep.data_ptr(),
+                                       cur_stream()) != 0
+
+
 def test_layernorm_param_reduce_and_counted_slab_sum():
     """osrl_layernorm_param_reduce (every LayerNorm's dgamma | dbeta in one launch) and osrl_reduce_slabs_counts (a split
     count per 1024-float chunk) return the bits of the per-call forms they replace in the CDT step."""

@@ -199,6 +199,10 @@ BIG_CASES = [
     # tanh in a wide layer, zero-padded k of the next layer
     (1, [78, 200, 250, 6], ["tanh", "relu", "id"], 1.0, 20480 + 3, (76, 1, 2048)),
     (1, [40, 420, 440, 3], ["relu", "tanh", "id"], 2.0, 10240, (33, 0, 1)),         # 27 / 28 blocks: the 7-block form
+    # round 6, the ONE-output head fused into the last wide layer's epilogue (nb_head_dot): a single wide layer in front of
+    # it; ragged widths (14 / 15 blocks: waves with 4 and 3 blocks) with tanh in the last wide layer, a tanh * scale head
+    (2, [23, 256, 1], ["relu", "id"], 1.0, 9000, (17, 0, 1)),
+    (3, [41, 250, 230, 1], ["tanh", "tanh", "tanh"], 2.0, 12000 + 11, (33, 2, 10)),
 ]
 
 
@@ -235,7 +239,8 @@ def test_mlp_fwd_big_rows(ci):
     src0 = torch.tensor(rs.randn(n0, d0), dtype=torch.float32, device=dev)
     src1 = torch.tensor(rs.randn(rows, d1), dtype=torch.float32, device=dev) if d1 else None
     outs = []
-    for tile_rows, waves in ((32, 0), (16, 0), (80, 0), (80, 4), (80, 8), (80, 64)):  # 80: one workgroup per CU (shapes the kernel does
+    # (negative wave counts: the same form with OSRL_NB_HEAD=0 -- a one-output head run as a layer, as before round 6)
+    for tile_rows, waves in ((32, 0), (16, 0), (80, 0), (80, 4), (80, 8), (80, 64), (80, -4), (80, -8), (80, -64)):  # 80: one workgroup per CU (shapes the kernel does
         # not take -- hidden layers of neither 13-16 nor 25-28 column blocks, wide last layer -- fall back to the default
         # tile); 25-block layers take its 8-wave form unless OSRL_NB_WAVES=4 asks for one wave per SIMD, 13-16-block
         # layers take theirs when OSRL_NB256_WAVES=8 asks for it and the 64-row form (two workgroups per CU) from 512
@@ -243,16 +248,19 @@ def test_mlp_fwd_big_rows(ci):
         desc = NetDesc(refs, acts, oscale)
         desc.c.tile_rows = tile_rows
         run = MlpRun(desc, rows, False, dev)
-        if waves == 64:
+        if waves < 0:
+            os.environ["OSRL_NB_HEAD"] = "0"
+        if abs(waves) == 64:
             os.environ["OSRL_NB64"] = "1"
         elif waves:
-            os.environ["OSRL_NB_WAVES"] = os.environ["OSRL_NB256_WAVES"] = str(waves)
+            os.environ["OSRL_NB_WAVES"] = os.environ["OSRL_NB256_WAVES"] = str(abs(waves))
         try:
             y = run.forward(src0, src1, map0=map0, div0=div0)
         finally:
             os.environ.pop("OSRL_NB_WAVES", None)
             os.environ.pop("OSRL_NB256_WAVES", None)
             os.environ.pop("OSRL_NB64", None)
+            os.environ.pop("OSRL_NB_HEAD", None)
         torch.cuda.synchronize()
         outs.append(torch.stack([t.clone() for t in y]).cpu().numpy() if isinstance(y, (list, tuple)) else y.clone().cpu().numpy())
     idx0 = {0: np.arange(rows), 1: np.arange(rows) % div0, 2: np.arange(rows) // div0}[map0]
@@ -265,7 +273,8 @@ def test_mlp_fwd_big_rows(ci):
             h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
         h = h * oscale
         for nm, got in (("tile32", outs[0][e]), ("tile16", outs[1][e]), ("tile80", outs[2][e]), ("tile80w4", outs[3][e]),
-                        ("tile80w8", outs[4][e]), ("tile64", outs[5][e])):
+                        ("tile80w8", outs[4][e]), ("tile64", outs[5][e]), ("tile80w4 head as a layer", outs[6][e]),
+                        ("tile80w8 head as a layer", outs[7][e]), ("tile64 head as a layer", outs[8][e])):
             err = np.abs(got.reshape(h.shape) - h).max()
             assert err < 3e-5 * max(1.0, np.abs(h).max()), f"case {ci} {nm} kernel net {e}: max err {err}"
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())

@@ -102,13 +102,13 @@ def test_pipelined_steps_equal_one_step_graph_replays(name, spg, total):
 
 
 def test_steps_replay_follows_the_plan():
-    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 4 at C2's shape, 1 at C4's) and leaves
+    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 5 at C2's shape, 1 at C4's) and leaves
     the engine n steps further either way."""
     m, e = _bench("c2")
-    assert e.plan.steps_per_graph == 4
+    assert e.plan.steps_per_graph == 5
     e.steps_replay(9)
     torch.cuda.synchronize()
-    assert e._pipe is not None and e._pipe.n == 4 and e.st.device_step() == 9
+    assert e._pipe is not None and e._pipe.n == 5 and e.st.device_step() == 9
     m4, e4 = _bench("c4")
     assert e4.plan.steps_per_graph == 1
     e4.steps_replay(3)
