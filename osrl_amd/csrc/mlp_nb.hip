@@ -455,10 +455,10 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
         const int c = j * 16 + cl;
         const bool ok = rok && c < K0;
         const float* q = c < d0 ? p0 + c : p1 + c;
-        v[p][j] = *(ok ? q : s0);
-        v[p][j] = ok ? v[p][j] : 0.f;
-      }
-    }
+        v[p][j] = *(ok ? q : s0);      // (round 6, measured and not kept, profiles/r6_stagein_ab.txt / r6_tilewalk_ab.txt: requesting
+        v[p][j] = ok ? v[p][j] : 0.f;  // only the chunks below the input's padded width behind uniform branches: C3 / C2 -1.6 %, the
+      }                                // branches break the one-batch issue of the loads; workgroups WALKING several tiles with
+    }                                  // the next tile's rows requested under the last wide layer: +60-80 registers, -1.5 .. -4 %)
 #pragma unroll
     for (int p = 0; p < kPasses; ++p)
 #pragma unroll
