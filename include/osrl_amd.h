@@ -861,6 +861,38 @@ int osrl_policy_io(void* handle, float** obs, float** noise, float** act, float*
 int osrl_policy_act(void* handle, int32_t rows, int32_t deterministic, int32_t host_noise, uint64_t seed, void* stream);
 int osrl_policy_destroy(void* handle);
 
+/* ---- data-parallel exchanges through IPC-mapped device buffers (ipc.hip, round 6; nothing to mirror in the reference: it
+ * has no distributed code).  What the ranks of a data-parallel step exchange (flat
+ * gradients per optimizer phase, CPQ's KL values, statistics) is latency-bound; a collective-library launch costs 16-19 us
+ * even on one rank.  Here every rank owns a published buffer (2 halves of half_floats) and a 64-byte control block in ITS
+ * device memory (osrl_ipc_alloc), hands the two handles to its peers by any means (the engines use torch.distributed's
+ * object all-gather, once) and maps theirs (osrl_ipc_open).  An exchange is ONE asynchronous, hipGraph-capturable kernel
+ * launch per rank: publish -> flag -> wait for every rank's flag -> sum in RANK ORDER (replicas stay bit-identical) or
+ * gather.  Every rank must issue the same sequence of exchanges on ONE stream; a peer that never arrives makes the launch
+ * give up after ~2 s and set the error word (osrl_ipc_status), it does not hang the device. */
+#define OSRL_IPC_MAX_WORLD 8
+#define OSRL_IPC_MAX_SEG 8
+#define OSRL_IPC_HANDLE_BYTES 64
+typedef struct {
+  int32_t world, rank;
+  float* pub[OSRL_IPC_MAX_WORLD];    /* published buffers, [rank] = this process's own allocation, the others mapped */
+  uint32_t* ctl[OSRL_IPC_MAX_WORLD]; /* control blocks (>= 64 bytes, zeroed): flag | arrivals | error | exchanges done */
+  int64_t half_floats;               /* floats per published half (a message must fit; multiple of 4) */
+} osrl_ipc_t;
+/* hipMalloc + zero + hipIpcGetMemHandle / hipIpcOpenMemHandle / Close / hipFree (setup time, synchronous). */
+int osrl_ipc_alloc(int64_t bytes, void** dev_ptr, void* handle64);
+int osrl_ipc_open(const void* handle64, void** dev_ptr);
+int osrl_ipc_close(void* mapped_ptr);
+int osrl_ipc_free(void* dev_ptr);
+/* bufs[i][0 .. lens[i]) += the same ranges of every other rank (in place, n_bufs <= OSRL_IPC_MAX_SEG, together <=
+ * half_floats: OSRL_E_UNSUPPORTED otherwise) -- dist.all_reduce(SUM) of several tensors as one launch. */
+int osrl_ipc_all_reduce(const osrl_ipc_t* x, float* const* bufs, const int64_t* lens, int32_t n_bufs, void* stream);
+/* dst[r * n + i] = rank r's src[i] -- dist.all_gather_into_tensor. */
+int osrl_ipc_all_gather(const osrl_ipc_t* x, const float* src, int64_t n, float* dst, void* stream);
+/* words4 = this rank's control words (flag, arrivals, error: 0 = fine, 1 + r = rank r never arrived, exchanges done).
+ * Synchronous copy: for the points where the host synchronises anyway. */
+int osrl_ipc_status(const osrl_ipc_t* x, uint32_t* words4);
+
 /* Diagnostics (diag.hip): where the HIP runtime of this process keeps kernel arguments -- *where = 1 device memory,
  * 0 host memory (every wave then fetches its launch arguments over PCIe; see osrl_args_begin), -1 unknown.  dev_scratch:
  * 8 bytes of device memory.  Synchronises `stream`; not for the hot path. */

@@ -116,6 +116,14 @@ class DropoutT(C.Structure):
     _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64), ("st", C.c_void_p)]
 
 
+IPC_MAX_WORLD, IPC_MAX_SEG, IPC_HANDLE_BYTES = 8, 8, 64  # include/osrl_amd.h OSRL_IPC_*
+
+
+class IpcT(C.Structure):  # osrl_ipc_t
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("pub", C.c_void_p * IPC_MAX_WORLD),
+                ("ctl", C.c_void_p * IPC_MAX_WORLD), ("half_floats", C.c_int64)]
+
+
 class EnvT(C.Structure):
     _fields_ = [("At", C.c_void_p), ("Bt", C.c_void_p), ("w", C.c_void_p), ("goal", C.c_void_p),
                 ("state_dim", C.c_int32), ("action_dim", C.c_int32), ("episode_len", C.c_int32), ("pad_", C.c_int32),
@@ -256,6 +264,13 @@ PROTOTYPES = {
     "osrl_cdt_temperature_step": [_fp, _fp, _fp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     "osrl_kernarg_probe": [_vp, _P(_i32), _P(_u64), _vp],
     "osrl_stamp_realtime": [_vp, _vp],
+    "osrl_ipc_alloc": [_i64, _P(C.c_void_p), _vp],
+    "osrl_ipc_open": [_vp, _P(C.c_void_p)],
+    "osrl_ipc_close": [_vp],
+    "osrl_ipc_free": [_vp],
+    "osrl_ipc_all_reduce": [_P(IpcT), _P(C.c_void_p), _P(_i64), _i32, _vp],
+    "osrl_ipc_all_gather": [_P(IpcT), _vp, _i64, _vp, _vp],
+    "osrl_ipc_status": [_P(IpcT), _P(C.c_uint32)],
     "osrl_mlp_regress_step": [_P(MlpStepT), _vp],
     "osrl_args_begin": [_vp, _vp, _i64, _i64, _i32],
     "osrl_args_end": [_P(_i64), _P(_i32), _P(_i32), _P(_i32)],

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libosrl_amd.so")
-SOURCES = ["mlp.hip", "mlp_nb.hip", "mlp_nb64.hip", "mlp_dw.hip", "vae_ns.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "diag.hip"]
+SOURCES = ["mlp.hip", "mlp_nb.hip", "mlp_nb64.hip", "mlp_dw.hip", "vae_ns.hip", "optim.hip", "rng.hip", "glue.hip", "cdt.hip", "env.hip", "ingest.hip", "bear.hip", "dice.hip", "act.hip", "ipc.hip", "diag.hip"]
 
 
 def _hipcc() -> str:

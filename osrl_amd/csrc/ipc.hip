@@ -1,0 +1,198 @@
+// ipc.hip -- the data-parallel step's exchanges WITHOUT collective-library launches.
+//
+// The reference has no distributed code; what a data-parallel train step exchanges is what a single
+// device would have reduced over the batch: per optimizer phase the flat gradient of a group (0.3-1.6 MB),
+// CPQ's N*B KL values (80 KB per rank) and a few statistics -- every message latency-bound.  An RCCL launch costs 16-19 us
+// on ONE rank (profiles/r5_bench_c2_forced_dp.json), four of them per CPQ step on the critical chain.  Here every rank owns
+// a PUBLISHED buffer (two halves, used alternately) and a control block in its device memory, exported with
+// hipIpcGetMemHandle and mapped by every peer.  One exchange = ONE kernel launch per rank:
+//     P1  copy the local segments into the rank's published half (sequence number s = own flag + 1, half = s & 1);
+//     rel every wave waits for its stores, one thread per workgroup writes the L2 back (system scope) and signs in at
+//         the arrival counter; the LAST workgroup publishes flag = s;
+//     P2  one thread per workgroup waits until EVERY rank's flag has reached s (bounded poll; system-scope acquire);
+//     P3  all-reduce: dst[i] = sum over ranks IN RANK ORDER of their published values -- every rank adds the same numbers
+//         in the same order, so replicas stay bit-identical; all-gather: dst[r * n + i] = rank r's value.
+// Two halves suffice: a rank leaves exchange s only after every peer has published s, and a peer publishes s + 1 only after
+// it finished reading s -- nobody can reach s + 2 (which reuses half s & 1) while somebody still reads half s & 1.
+// The launch is an ordinary kernel: asynchronous on the caller's stream, hipGraph-capturable, no host state; all ranks must
+// issue the same sequence of exchanges (as with any collective).  Measured with two PROCESSES on one MI355X
+// (tools/ipc_slab_lab.hip, profiles/r6_ipc_slab_lab.txt): flag one way 0.45 us, "both published -> summed" 4.7-5.0 us at 64
+// workgroups for 1.6 MB -- the mechanism, not xGMI.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/osrl_amd.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSpinMax = 1 << 22;  // x ~0.5 us per system-scope poll: ~2 s, then the error word is set and the launch goes on
+
+__device__ __forceinline__ unsigned ld_sys(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(uint32_t* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct IpcArgs {
+  float* pub[OSRL_IPC_MAX_WORLD];
+  uint32_t* ctl[OSRL_IPC_MAX_WORLD];  // [0] flag = last published sequence number  [1] arrivals  [2] error  [3] exchanges done
+  int64_t half;                       // floats per published half
+  float* seg[OSRL_IPC_MAX_SEG];       // local tensors (all-reduce: in place; all-gather: seg[0] = source, seg[1] = destination)
+  int64_t len[OSRL_IPC_MAX_SEG], off[OSRL_IPC_MAX_SEG];
+  int64_t total;                      // floats this rank publishes
+  int32_t world, rank, n_seg, gather;
+};
+
+__global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a) {
+  __shared__ unsigned s_seq;
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  uint32_t* my = a.ctl[a.rank];
+  // every workgroup reads the OLD flag before anyone can publish the new one (publishing needs all arrivals)
+  if (tid == 0) s_seq = ld_sys(&my[0]) + 1u;
+  __syncthreads();
+  const unsigned seq = s_seq;
+  const int64_t h = (int64_t)(seq & 1u) * a.half;
+  const int64_t stride = (int64_t)gridDim.x * kThreads, i0 = (int64_t)blockIdx.x * kThreads + tid;
+  // ---- P1: publish
+  float* __restrict__ mine = a.pub[a.rank] + h;
+  const int n_src = a.gather ? 1 : a.n_seg;
+  for (int s = 0; s < n_src; ++s) {
+    const float* __restrict__ src = a.seg[s];
+    float* __restrict__ dst = mine + a.off[s];
+    for (int64_t i = i0; i < a.len[s]; i += stride) dst[i] = src[i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a barrier does not wait for global stores)
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence_system();  // release: this workgroup's part of the half has left its XCD's L2
+    const unsigned seen = atomicAdd(&my[1], 1u);
+    if (seen == gridDim.x - 1) {
+      my[1] = 0u;
+      __threadfence_system();
+      st_sys(&my[0], seq);
+    }
+    // ---- P2: every rank (this one included) has published `seq`
+    int ok = 1;
+    for (int r = 0; r < a.world && ok; ++r) {
+      int polls = 0;
+      while ((int)(ld_sys(&a.ctl[r][0]) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++polls > kSpinMax) {
+          ok = 0;
+          st_sys(&my[2], 1u + (unsigned)r);  // which peer never arrived (osrl_ipc_status)
+          break;
+        }
+      }
+    }
+    __threadfence_system();  // acquire
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) return;  // (the destination keeps its local values; the host reads the error word at its next sync point)
+  // ---- P3
+  if (a.gather) {
+    float* __restrict__ dst = a.seg[1];
+    const int64_t n = a.len[0];
+    for (int r = 0; r < a.world; ++r) {
+      const float* __restrict__ p = a.pub[r] + h + a.off[0];
+      for (int64_t i = i0; i < n; i += stride) dst[(int64_t)r * n + i] = p[i];
+    }
+  } else {
+    for (int s = 0; s < a.n_seg; ++s) {
+      float* __restrict__ dst = a.seg[s];
+      const int64_t o = h + a.off[s];
+      for (int64_t i = i0; i < a.len[s]; i += stride) {
+        float acc = a.pub[0][o + i];
+        for (int r = 1; r < a.world; ++r) acc += a.pub[r][o + i];  // rank order: the same sum on every rank
+        dst[i] = acc;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) my[3] = seq;
+}
+
+int launch(const osrl_ipc_t* x, float* const* seg, const int64_t* len, int n_seg, int gather, void* stream) {
+  if (!x || x->world < 1 || x->world > OSRL_IPC_MAX_WORLD || x->rank < 0 || x->rank >= x->world || !seg || !len ||
+      n_seg < 1 || n_seg > OSRL_IPC_MAX_SEG || x->half_floats < 4)
+    return -1;
+  IpcArgs a{};
+  for (int r = 0; r < x->world; ++r) {
+    if (!x->pub[r] || !x->ctl[r]) return -1;
+    a.pub[r] = x->pub[r];
+    a.ctl[r] = x->ctl[r];
+  }
+  a.half = x->half_floats;
+  a.world = x->world;
+  a.rank = x->rank;
+  a.n_seg = n_seg;
+  a.gather = gather;
+  int64_t off = 0;
+  const int n_pub = gather ? 1 : n_seg;
+  for (int s = 0; s < n_seg; ++s) {
+    if (!seg[s] || len[s] < 1) return -1;
+    a.seg[s] = seg[s];
+    a.len[s] = len[s];
+    a.off[s] = off;
+    if (s < n_pub) off += (len[s] + 3) & ~(int64_t)3;
+  }
+  if (off > x->half_floats) return OSRL_E_UNSUPPORTED;  // the caller splits the message or builds a larger exchange
+  a.total = off;
+  // 64 workgroups: one L2 write-back each behind the publish (the fences, not the bytes, are what an exchange costs:
+  // tools/ipc_slab_lab.hip -- 4.7 us at 64 workgroups, 9.5 us at 256 for the same 1.6 MB); small messages take fewer
+  int64_t want = (off + 4 * kThreads - 1) / (4 * kThreads);
+  const int grid = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ipc_exchange_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int osrl_ipc_alloc(int64_t bytes, void** dev_ptr, void* handle64) {
+  if (bytes < 16 || !dev_ptr || !handle64) return -1;
+  static_assert(sizeof(hipIpcMemHandle_t) == OSRL_IPC_HANDLE_BYTES, "handle size");
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, (size_t)bytes);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return (int)e;
+  }
+  memcpy(handle64, &h, sizeof h);
+  *dev_ptr = p;
+  return 0;
+}
+
+extern "C" int osrl_ipc_open(const void* handle64, void** dev_ptr) {
+  if (!handle64 || !dev_ptr) return -1;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof h);
+  return (int)hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
+}
+
+extern "C" int osrl_ipc_close(void* mapped_ptr) { return mapped_ptr ? (int)hipIpcCloseMemHandle(mapped_ptr) : -1; }
+extern "C" int osrl_ipc_free(void* dev_ptr) { return dev_ptr ? (int)hipFree(dev_ptr) : -1; }
+
+extern "C" int osrl_ipc_all_reduce(const osrl_ipc_t* x, float* const* bufs, const int64_t* lens, int32_t n_bufs, void* stream) {
+  return launch(x, bufs, lens, n_bufs, 0, stream);
+}
+
+extern "C" int osrl_ipc_all_gather(const osrl_ipc_t* x, const float* src, int64_t n, float* dst, void* stream) {
+  if (!src || !dst || n < 1) return -1;
+  float* seg[2] = {const_cast<float*>(src), dst};
+  const int64_t len[2] = {n, n};
+  return launch(x, seg, len, 2, 1, stream);
+}
+
+extern "C" int osrl_ipc_status(const osrl_ipc_t* x, uint32_t* words4) {
+  if (!x || !words4 || x->rank < 0 || x->rank >= OSRL_IPC_MAX_WORLD || !x->ctl[x->rank]) return -1;
+  return (int)hipMemcpy(words4, x->ctl[x->rank], 16, hipMemcpyDeviceToHost);  // synchronises: not for the hot path
+}

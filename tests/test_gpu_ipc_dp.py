@@ -1,0 +1,148 @@
+"""Data parallelism with a REAL peer on one GPU: two PROCESSES share cuda:0 and exchange through IPC-mapped device buffers
+(osrl_amd/engine/dist_ipc.py, csrc/ipc.hip) -- the RCCL-free exchange of DESIGN.md section 7.  RCCL refuses two ranks on one
+device; this path needs torch.distributed only for its set-up (gloo here), so the sharded step finally runs against a peer
+that is another process with its own HIP context, streams and graph.
+
+Oracle (as tests/test_gpu_dp_sim.py): the sharded step on 2 x B rows == the single-device step on the
+concatenated 2B-row batch (reference step: cpq.py:294-313, bcql.py:283-306, bc.py:103-109).  Then the captured data-parallel
+step (exchange launches as hipGraph nodes, minibatches drawn on device from each rank's shard): replicas bit-identical to
+each other after every replay, no exchange gave up.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+W = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, algo, out_dir):
+    """One rank: its half of the concatenated batch through the Trainer API with injected noise (eager step body), then
+    graph-replayed steps on its shard of a device-resident store."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        from cases import make_batch, make_noise
+        from gpu_util import build_gpu
+        from osrl_amd.common.replay import ReplayStore, synthetic_transitions
+        from osrl_amd.engine.dist_ipc import IpcDataParallel
+        from test_gpu_dp_sim import DP_CASES, _shard
+        c = DP_CASES[algo]
+        B, N, M = c.B, c.N, int(c.hp.get("M", 1))
+        Bl = B // W
+        batch = make_batch(c)
+        keys = ("observations", "actions") if algo == "bc" else \
+            ("observations", "next_observations", "actions", "rewards", "costs", "done")
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+        m, tr, lg = build_gpu(c)
+        dp = IpcDataParallel()
+        eng = m.engine(Bl, rows_global=B, dist=dp)
+        args = [t(batch[k][rank * Bl:(rank + 1) * Bl]) for k in keys]
+        for s in range(c.steps):
+            if algo == "bc":
+                tr.train_one_step(*args)
+            else:
+                nz = {k: t(_shard(v, k, rank, W, B, N, M)) for k, v in make_noise(c, s).items()}
+                tr.train_one_step(*args, noise=nz)
+        torch.cuda.synchronize()
+        dp.check()
+        res = {"params": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "stats": dict(eng.st.read_stats()),
+               "exchanges": dp.status()["done"]}
+        for k in ("log_alpha", "pid_state"):
+            if isinstance(getattr(m, k, None), torch.Tensor):
+                res[k] = getattr(m, k).detach().cpu().clone()
+        # ---- the captured data-parallel step: exchange launches inside the replayed graph, on-device minibatches
+        if algo != "bc":
+            store = ReplayStore(synthetic_transitions(4096, c.od, c.ad, seed=5, max_action=c.max_action), torch.device(DEV),
+                                reward_scale=0.1, cost_scale=1.0, seed=3, rank=rank, world=W)
+            eng.attach_replay(store)
+            before = dp.status()["done"]
+            for _ in range(4):
+                eng.step_replay(True)
+            torch.cuda.synchronize()
+            dp.check()
+            res["graph"] = eng.graph is not None
+            res["graph_exchanges"] = dp.status()["done"] - before
+            res["graph_params"] = {n: g.p.detach().cpu().clone() for n, g in m.groups.items()}
+            res["graph_stats"] = dict(eng.st.read_stats())
+            res["obs_row0"] = eng.obs[0].detach().cpu().clone()
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+        dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["cpq", "bcql", "bc", "cpq_c4"])
+def test_two_processes_one_gpu_sharded_step_equals_concatenated_batch(algo):
+    import torch.multiprocessing as mp
+    from cases import make_batch, make_noise
+    from gpu_util import build_gpu
+    from test_gpu_dp_sim import DP_CASES
+    c = DP_CASES[algo]
+    keys = ("observations", "actions") if algo == "bc" else \
+        ("observations", "next_observations", "actions", "rewards", "costs", "done")
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+    # single device, concatenated batch
+    batch = make_batch(c)
+    m1, tr1, lg1 = build_gpu(c)
+    for s in range(c.steps):
+        if algo == "bc":
+            tr1.train_one_step(*[t(batch[k]) for k in keys])
+        else:
+            tr1.train_one_step(*[t(batch[k]) for k in keys], noise={k: t(v) for k, v in make_noise(c, s).items()})
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu() for k, v in m1.state_dict().items()}
+    want_stats = dict(m1._engine.st.read_stats())
+    with tempfile.TemporaryDirectory() as d:
+        import time
+        ctx = mp.spawn(_worker, args=(_free_port(), algo, d), nprocs=W, join=False)
+        deadline = time.time() + 600
+        while not ctx.join(timeout=5):  # (raises if a rank failed)
+            if time.time() > deadline:
+                for p in ctx.processes:
+                    p.kill()
+                pytest.fail("the two ranks did not finish within 600 s")
+        res = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(W)]
+    n_coll = {"cpq": 4, "cpq_c4": 4, "bcql": 4, "bc": 2}[algo]
+    for r in range(W):
+        assert res[r]["exchanges"] >= n_coll * c.steps, (r, res[r]["exchanges"])
+        for k, v in want.items():
+            if v.dtype == torch.bool:
+                continue
+            d_ = (res[r]["params"][k] - v).abs().max().item()
+            assert d_ <= 2e-5, f"{algo} rank {r} param {k}: sharded vs concatenated {d_:.3e}"
+        for k, v in want_stats.items():
+            assert abs(res[r]["stats"][k] - v) <= 1e-4 * max(1.0, abs(v)), (algo, r, k, res[r]["stats"][k], v)
+    # replicas bit-identical to each other (the sum runs in rank order on every rank)
+    for k, v in res[0]["params"].items():
+        assert torch.equal(v, res[1]["params"][k]), f"{algo}: replicas differ in {k}"
+    for k in ("log_alpha", "pid_state"):
+        if k in res[0]:
+            assert torch.equal(res[0][k], res[1][k]), k
+    if algo != "bc":
+        for r in range(W):
+            if c.algo == "cpq":  # (BCQ-Lag's data-parallel step is issued eagerly: engine/bcql.py step_replay)
+                assert res[r]["graph"], "the data-parallel step must have been captured with its exchanges"
+            assert res[r]["graph_exchanges"] >= 4 * 4, res[r]["graph_exchanges"]
+            assert all(np.isfinite(v) for v in res[r]["graph_stats"].values()), res[r]["graph_stats"]
+        for n, p in res[0]["graph_params"].items():
+            assert torch.equal(p, res[1]["graph_params"][n]), f"{algo}: replicas differ in group {n} after graph replays"
+        assert res[0]["graph_stats"] == res[1]["graph_stats"]
+        assert not torch.equal(res[0]["obs_row0"], res[1]["obs_row0"]), "the ranks draw from different shards"
