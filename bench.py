@@ -816,21 +816,34 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # OSRL_DP_EXCHANGE=ipc: the step's exchanges through IPC-mapped device buffers (engine/dist_ipc.py) instead of RCCL
+    # launches; OSRL_IPC_ONE_GPU=1 (lab, implies ipc): every rank on device 0 with gloo as the control plane -- a real peer
+    # PROCESS on a one-GPU box (the ranks share the device, so `value` is no scaling figure there)
+    one_gpu = os.environ.get("OSRL_IPC_ONE_GPU") == "1"
+    exchange = "ipc" if one_gpu else os.environ.get("OSRL_DP_EXCHANGE", "rccl")
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dp, rccl_ranks = None, 0
     force_dp = world == 1 and os.environ.get("OSRL_FORCE_DP") == "1"  # debug: the data-parallel step on one rank
     if world > 1 or force_dp:
         import torch.distributed as dist
+        backend = "gloo" if one_gpu else "nccl"
+        kw_pg = {} if one_gpu else dict(device_id=device)
         if force_dp:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist.init_process_group(backend, rank=0, world_size=1, **kw_pg)
         else:
-            dist.init_process_group("nccl", device_id=device)
-        from osrl_amd.engine.dist import DataParallel
-        dp = DataParallel()
-        rccl_ranks = dist.get_world_size()
+            dist.init_process_group(backend, **kw_pg)
+        if exchange == "ipc":
+            from osrl_amd.engine.dist_ipc import IpcDataParallel
+            dp = IpcDataParallel(device=device)
+        else:
+            from osrl_amd.engine.dist import DataParallel
+            dp = DataParallel()
+        rccl_ranks = dist.get_world_size() if exchange != "ipc" else 0
 
     wl = Workload(args.config, device, rank, world, dp, use_graph=not args.eager,
                   steps_per_graph=1)  # (the probes below run on the one-step engine; the pipeline is built behind them)
@@ -969,6 +982,9 @@ def main():
                                                        "ms_per_step": round(dt_cold / args.steps * 1e3, 4)},
             "transitions_per_s": round(world * B * args.steps / dt, 1),
             "rccl_ranks": rccl_ranks,
+            # what carries the data-parallel step's exchanges: RCCL launches, or IPC-mapped buffers + flags (engine/dist_ipc.py)
+            "dp_exchange": None if dp is None else {"kind": exchange, "ranks": world, "one_gpu": one_gpu,
+                                                    "status": dp.status() if exchange == "ipc" else None},
             # data parallel only: each collective of the step timed inside the eagerly issued step body (issue order);
             # sum / (1e3 * ms_per_step) = the share of the step spent in exposed communication
             "collectives_in_step": coll,

@@ -20,6 +20,7 @@
 // workgroups for 1.6 MB -- the mechanism, not xGMI.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/osrl_amd.h"
@@ -46,6 +47,80 @@ struct IpcArgs {
   int32_t world, rank, n_seg, gather;
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// PUBLISHED data never rests in an L2: it is written with system-scope write-through stores (sc0 sc1: complete at the memory
+// side, tracked by vmcnt) and read with system-scope loads (sc0 sc1: served from memory, not from this XCD's L2).  The first
+// version of this kernel used plain accesses between an L2 write-back and an L2 invalidate per workgroup: the exchange
+// itself was as fast (17 / 16 / 11 / 13 us for the CPQ step's four against RCCL's 16 / 17 / 19 / 17 on one rank), but 64
+// write-back + invalidate pairs per exchange slowed the kernels of the OTHER graph branch -- the forced-data-parallel C2
+// step ran 1860 steps/s against 2000 with RCCL (profiles/r6_ipc_wgs_sweep.txt).  The 16-byte forms are inline assembly
+// (the atomic builtins stop at 8 bytes); their completion is waited for explicitly: the compiler's counter bookkeeping
+// does not see them.
+__device__ __forceinline__ void st16_sys(f32x4* p, const f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld16_sys_x4(const f32x4* p0, const f32x4* p1, const f32x4* p2, const f32x4* p3, f32x4& v0,
+                                            f32x4& v1, f32x4& v2, f32x4& v3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+__device__ __forceinline__ float ld_sys_f(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void st_sys_f(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// local -> published: pub[0..n) = src[0..n) (four float4 per lane in flight where both ends are 16-byte aligned)
+__device__ __forceinline__ void publish_seg(float* pub, const float* __restrict__ src, int64_t n, int64_t i0, int64_t stride) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(pub) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(src);
+  f32x4* d4 = reinterpret_cast<f32x4*>(pub);
+  for (int64_t i = i0; i < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = i + k * stride;
+      v[k] = s4[j < n4 ? j : i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = i + k * stride;
+      if (j < n4) st16_sys(d4 + j, v[k]);
+    }
+  }
+  for (int64_t i = 4 * n4 + i0; i < n; i += stride) st_sys_f(pub + i, src[i]);
+}
+
+// published (any rank's) -> local: dst[0..n) = pub[0..n)
+__device__ __forceinline__ void fetch_seg(float* __restrict__ dst, const float* pub, int64_t n, int64_t i0, int64_t stride) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(pub)) & 15) == 0;
+  const int64_t n4 = vec ? n >> 2 : 0;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(pub);
+  f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dst);
+  for (int64_t i = i0; i < n4; i += 4 * stride) {
+    int64_t j[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) j[k] = i + k * stride < n4 ? i + k * stride : i;
+    f32x4 v0, v1, v2, v3;
+    ld16_sys_x4(s4 + j[0], s4 + j[1], s4 + j[2], s4 + j[3], v0, v1, v2, v3);
+    d4[j[0]] = v0;
+    if (j[1] != i) d4[j[1]] = v1;
+    if (j[2] != i) d4[j[2]] = v2;
+    if (j[3] != i) d4[j[3]] = v3;
+  }
+  for (int64_t i = 4 * n4 + i0; i < n; i += stride) dst[i] = ld_sys_f(pub + i);
+}
+
 __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a) {
   __shared__ unsigned s_seq;
   __shared__ int s_ok;
@@ -57,22 +132,17 @@ __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a)
   const unsigned seq = s_seq;
   const int64_t h = (int64_t)(seq & 1u) * a.half;
   const int64_t stride = (int64_t)gridDim.x * kThreads, i0 = (int64_t)blockIdx.x * kThreads + tid;
-  // ---- P1: publish
+  // ---- P1: publish (float4 x 4 in flight per lane where the segment is 16-byte aligned: a 1.56 MB gradient is two
+  // rounds of the 64 workgroups; one float per lane and iteration made the exchange 36 us long inside the step)
   float* __restrict__ mine = a.pub[a.rank] + h;
   const int n_src = a.gather ? 1 : a.n_seg;
-  for (int s = 0; s < n_src; ++s) {
-    const float* __restrict__ src = a.seg[s];
-    float* __restrict__ dst = mine + a.off[s];
-    for (int64_t i = i0; i < a.len[s]; i += stride) dst[i] = src[i];
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a barrier does not wait for global stores)
+  for (int s = 0; s < n_src; ++s) publish_seg(mine + a.off[s], a.seg[s], a.len[s], i0, stride);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // release: this wave's write-through stores are complete at the memory side
   __syncthreads();
   if (tid == 0) {
-    __threadfence_system();  // release: this workgroup's part of the half has left its XCD's L2
-    const unsigned seen = atomicAdd(&my[1], 1u);
+    const unsigned seen = __hip_atomic_fetch_add(&my[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seen == gridDim.x - 1) {
-      my[1] = 0u;
-      __threadfence_system();
+      __hip_atomic_store(&my[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       st_sys(&my[0], seq);
     }
     // ---- P2: every rank (this one included) has published `seq`
@@ -88,8 +158,7 @@ __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a)
         }
       }
     }
-    __threadfence_system();  // acquire
-    s_ok = ok;
+    s_ok = ok;  // (no acquire fence: what follows reads the published halves with system-scope loads only)
   }
   __syncthreads();
   if (!s_ok) return;  // (the destination keeps its local values; the host reads the error word at its next sync point)
@@ -97,17 +166,44 @@ __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a)
   if (a.gather) {
     float* __restrict__ dst = a.seg[1];
     const int64_t n = a.len[0];
-    for (int r = 0; r < a.world; ++r) {
-      const float* __restrict__ p = a.pub[r] + h + a.off[0];
-      for (int64_t i = i0; i < n; i += stride) dst[(int64_t)r * n + i] = p[i];
-    }
+    for (int r = 0; r < a.world; ++r) fetch_seg(dst + (int64_t)r * n, a.pub[r] + h + a.off[0], n, i0, stride);
   } else {
     for (int s = 0; s < a.n_seg; ++s) {
       float* __restrict__ dst = a.seg[s];
-      const int64_t o = h + a.off[s];
-      for (int64_t i = i0; i < a.len[s]; i += stride) {
-        float acc = a.pub[0][o + i];
-        for (int r = 1; r < a.world; ++r) acc += a.pub[r][o + i];  // rank order: the same sum on every rank
+      const int64_t o = h + a.off[s], n = a.len[s];
+      const bool vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;  // (published offsets are multiples of 4 floats)
+      const int64_t n4 = vec ? n >> 2 : 0;
+      if (a.world == 1) {  // (one rank: the sum is the published value)
+        fetch_seg(dst, a.pub[0] + o, n, i0, stride);
+        continue;
+      }
+      for (int64_t i = i0; i < n4; i += 4 * stride) {  // four float4 per lane and rank in flight
+        int64_t j[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) j[k] = i + k * stride < n4 ? i + k * stride : i;
+        f32x4 acc[4];
+        {
+          const f32x4* p = reinterpret_cast<const f32x4*>(a.pub[0] + o);
+          ld16_sys_x4(p + j[0], p + j[1], p + j[2], p + j[3], acc[0], acc[1], acc[2], acc[3]);
+        }
+        for (int r = 1; r < a.world; ++r) {  // rank order: the same sum on every rank
+          const f32x4* p = reinterpret_cast<const f32x4*>(a.pub[r] + o);
+          f32x4 v0, v1, v2, v3;
+          ld16_sys_x4(p + j[0], p + j[1], p + j[2], p + j[3], v0, v1, v2, v3);
+          acc[0] += v0;
+          acc[1] += v1;
+          acc[2] += v2;
+          acc[3] += v3;
+        }
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+        d4[j[0]] = acc[0];
+        if (j[1] != i) d4[j[1]] = acc[1];
+        if (j[2] != i) d4[j[2]] = acc[2];
+        if (j[3] != i) d4[j[3]] = acc[3];
+      }
+      for (int64_t i = 4 * n4 + i0; i < n; i += stride) {
+        float acc = ld_sys_f(a.pub[0] + o + i);
+        for (int r = 1; r < a.world; ++r) acc += ld_sys_f(a.pub[r] + o + i);
         dst[i] = acc;
       }
     }
@@ -143,8 +239,13 @@ int launch(const osrl_ipc_t* x, float* const* seg, const int64_t* len, int n_seg
   a.total = off;
   // 64 workgroups: one L2 write-back each behind the publish (the fences, not the bytes, are what an exchange costs:
   // tools/ipc_slab_lab.hip -- 4.7 us at 64 workgroups, 9.5 us at 256 for the same 1.6 MB); small messages take fewer
-  int64_t want = (off + 4 * kThreads - 1) / (4 * kThreads);
-  const int grid = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+  int64_t want = (off + 16 * kThreads - 1) / (16 * kThreads);  // ~4 float4 per lane
+  int cap = 64;
+  if (const char* e = getenv("OSRL_IPC_WGS")) {  // (lab: read per launch)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 256) cap = v;
+  }
+  const int grid = (int)(want < 1 ? 1 : want > cap ? cap : want);
   (void)hipGetLastError();
   hipLaunchKernelGGL(ipc_exchange_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();

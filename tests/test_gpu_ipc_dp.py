@@ -22,7 +22,6 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-W = 2
 
 
 def _free_port():
@@ -31,7 +30,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, port, algo, out_dir):
+def _worker(rank, W, port, algo, out_dir):
     """One rank: its half of the concatenated batch through the Trainer API with injected noise (eager step body), then
     graph-replayed steps on its shard of a device-resident store."""
     import torch.distributed as dist
@@ -89,8 +88,10 @@ def _worker(rank, port, algo, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("algo", ["cpq", "bcql", "bc", "cpq_c4"])
-def test_two_processes_one_gpu_sharded_step_equals_concatenated_batch(algo):
+@pytest.mark.parametrize("algo,W", [("cpq", 2), ("bcql", 2), ("bc", 2), ("cpq_c4", 2), ("cpq", 4), ("cpq", 8), ("bcql", 4)])
+def test_processes_on_one_gpu_sharded_step_equals_concatenated_batch(algo, W):
+    """W processes share cuda:0 (W = 8: the job shape of BASELINE's multi-GPU config; sums in rank order over 8 published
+    buffers, 8-way gather of the KL values under the batch-global quantile)."""
     import torch.multiprocessing as mp
     from cases import make_batch, make_noise
     from gpu_util import build_gpu
@@ -112,13 +113,13 @@ def test_two_processes_one_gpu_sharded_step_equals_concatenated_batch(algo):
     want_stats = dict(m1._engine.st.read_stats())
     with tempfile.TemporaryDirectory() as d:
         import time
-        ctx = mp.spawn(_worker, args=(_free_port(), algo, d), nprocs=W, join=False)
+        ctx = mp.spawn(_worker, args=(W, _free_port(), algo, d), nprocs=W, join=False)
         deadline = time.time() + 600
         while not ctx.join(timeout=5):  # (raises if a rank failed)
             if time.time() > deadline:
                 for p in ctx.processes:
                     p.kill()
-                pytest.fail("the two ranks did not finish within 600 s")
+                pytest.fail(f"the {W} ranks did not finish within 600 s")
         res = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(W)]
     n_coll = {"cpq": 4, "cpq_c4": 4, "bcql": 4, "bc": 2}[algo]
     for r in range(W):
@@ -131,18 +132,20 @@ def test_two_processes_one_gpu_sharded_step_equals_concatenated_batch(algo):
         for k, v in want_stats.items():
             assert abs(res[r]["stats"][k] - v) <= 1e-4 * max(1.0, abs(v)), (algo, r, k, res[r]["stats"][k], v)
     # replicas bit-identical to each other (the sum runs in rank order on every rank)
-    for k, v in res[0]["params"].items():
-        assert torch.equal(v, res[1]["params"][k]), f"{algo}: replicas differ in {k}"
-    for k in ("log_alpha", "pid_state"):
-        if k in res[0]:
-            assert torch.equal(res[0][k], res[1][k]), k
+    for r in range(1, W):
+        for k, v in res[0]["params"].items():
+            assert torch.equal(v, res[r]["params"][k]), f"{algo}: replicas 0 and {r} differ in {k}"
+        for k in ("log_alpha", "pid_state"):
+            if k in res[0]:
+                assert torch.equal(res[0][k], res[r][k]), k
     if algo != "bc":
         for r in range(W):
             if c.algo == "cpq":  # (BCQ-Lag's data-parallel step is issued eagerly: engine/bcql.py step_replay)
                 assert res[r]["graph"], "the data-parallel step must have been captured with its exchanges"
             assert res[r]["graph_exchanges"] >= 4 * 4, res[r]["graph_exchanges"]
             assert all(np.isfinite(v) for v in res[r]["graph_stats"].values()), res[r]["graph_stats"]
-        for n, p in res[0]["graph_params"].items():
-            assert torch.equal(p, res[1]["graph_params"][n]), f"{algo}: replicas differ in group {n} after graph replays"
-        assert res[0]["graph_stats"] == res[1]["graph_stats"]
+        for r in range(1, W):
+            for n, p in res[0]["graph_params"].items():
+                assert torch.equal(p, res[r]["graph_params"][n]), f"{algo}: replicas 0 and {r} differ in group {n} after graph replays"
+            assert res[0]["graph_stats"] == res[r]["graph_stats"]
         assert not torch.equal(res[0]["obs_row0"], res[1]["obs_row0"]), "the ranks draw from different shards"
