@@ -887,6 +887,11 @@ int osrl_ipc_free(void* dev_ptr);
 /* bufs[i][0 .. lens[i]) += the same ranges of every other rank (in place, n_bufs <= OSRL_IPC_MAX_SEG, together <=
  * half_floats: OSRL_E_UNSUPPORTED otherwise) -- dist.all_reduce(SUM) of several tensors as one launch. */
 int osrl_ipc_all_reduce(const osrl_ipc_t* x, float* const* bufs, const int64_t* lens, int32_t n_bufs, void* stream);
+/* The same where bufs[i] is slab 0 of n_slabs[i] split-K gradient slabs slab_strides[i] floats apart (what the dW kernels
+ * leave): the rank's own slab sum -- slab order, the bits of osrl_reduce_slabs -- is formed while publishing, and slab 0
+ * receives the sum over slabs AND ranks: osrl_reduce_slabs + osrl_ipc_all_reduce in one launch. */
+int osrl_ipc_all_reduce_slabs(const osrl_ipc_t* x, float* const* bufs, const int64_t* lens, const int32_t* n_slabs,
+                              const int64_t* slab_strides, int32_t n_bufs, void* stream);
 /* dst[r * n + i] = rank r's src[i] -- dist.all_gather_into_tensor. */
 int osrl_ipc_all_gather(const osrl_ipc_t* x, const float* src, int64_t n, float* dst, void* stream);
 /* words4 = this rank's control words (flag, arrivals, error: 0 = fine, 1 + r = rank r never arrived, exchanges done).

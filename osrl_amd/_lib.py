@@ -269,6 +269,7 @@ PROTOTYPES = {
     "osrl_ipc_close": [_vp],
     "osrl_ipc_free": [_vp],
     "osrl_ipc_all_reduce": [_P(IpcT), _P(C.c_void_p), _P(_i64), _i32, _vp],
+    "osrl_ipc_all_reduce_slabs": [_P(IpcT), _P(C.c_void_p), _P(_i64), _P(_i32), _P(_i64), _i32, _vp],
     "osrl_ipc_all_gather": [_P(IpcT), _vp, _i64, _vp, _vp],
     "osrl_ipc_status": [_P(IpcT), _P(C.c_uint32)],
     "osrl_mlp_regress_step": [_P(MlpStepT), _vp],

@@ -45,6 +45,10 @@ struct IpcArgs {
   int64_t len[OSRL_IPC_MAX_SEG], off[OSRL_IPC_MAX_SEG];
   int64_t total;                      // floats this rank publishes
   int32_t world, rank, n_seg, gather;
+  // a segment may be the first of n_slabs split-K gradient slabs `sstride` floats apart: the rank's own slab sum (slab
+  // order, the fixed order of osrl_reduce_slabs / the Adam kernel) is formed WHILE publishing -- one launch fewer per group
+  int32_t n_slabs[OSRL_IPC_MAX_SEG];
+  int64_t sstride[OSRL_IPC_MAX_SEG];
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -80,11 +84,14 @@ __device__ __forceinline__ void st_sys_f(float* p, float v) {
 }
 
 // local -> published: pub[0..n) = src[0..n) (four float4 per lane in flight where both ends are 16-byte aligned)
-__device__ __forceinline__ void publish_seg(float* pub, const float* __restrict__ src, int64_t n, int64_t i0, int64_t stride) {
-  const bool vec = ((reinterpret_cast<uintptr_t>(pub) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+// (n_slabs > 1: src is slab 0 of n_slabs gradient slabs sstride floats apart; what is published is their sum in slab order)
+__device__ __forceinline__ void publish_seg(float* pub, const float* __restrict__ src, int64_t n, int64_t i0, int64_t stride,
+                                            int n_slabs, int64_t sstride) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(pub) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && (sstride & 3) == 0;
   const int64_t n4 = vec ? n >> 2 : 0;
   const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(src);
   f32x4* d4 = reinterpret_cast<f32x4*>(pub);
+  const int64_t ss4 = sstride >> 2;
   for (int64_t i = i0; i < n4; i += 4 * stride) {
     f32x4 v[4];
 #pragma unroll
@@ -92,13 +99,27 @@ __device__ __forceinline__ void publish_seg(float* pub, const float* __restrict_
       const int64_t j = i + k * stride;
       v[k] = s4[j < n4 ? j : i];
     }
+    for (int sl = 1; sl < n_slabs; ++sl) {
+      f32x4 w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t j = i + k * stride;
+        w[k] = s4[(j < n4 ? j : i) + sl * ss4];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += w[k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t j = i + k * stride;
       if (j < n4) st16_sys(d4 + j, v[k]);
     }
   }
-  for (int64_t i = 4 * n4 + i0; i < n; i += stride) st_sys_f(pub + i, src[i]);
+  for (int64_t i = 4 * n4 + i0; i < n; i += stride) {
+    float acc = src[i];
+    for (int sl = 1; sl < n_slabs; ++sl) acc += src[i + sl * sstride];
+    st_sys_f(pub + i, acc);
+  }
 }
 
 // published (any rank's) -> local: dst[0..n) = pub[0..n)
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a)
   // rounds of the 64 workgroups; one float per lane and iteration made the exchange 36 us long inside the step)
   float* __restrict__ mine = a.pub[a.rank] + h;
   const int n_src = a.gather ? 1 : a.n_seg;
-  for (int s = 0; s < n_src; ++s) publish_seg(mine + a.off[s], a.seg[s], a.len[s], i0, stride);
+  for (int s = 0; s < n_src; ++s) publish_seg(mine + a.off[s], a.seg[s], a.len[s], i0, stride, a.n_slabs[s], a.sstride[s]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // release: this wave's write-through stores are complete at the memory side
   __syncthreads();
   if (tid == 0) {
@@ -211,7 +232,8 @@ __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(const IpcArgs a)
   if (blockIdx.x == 0 && tid == 0) my[3] = seq;
 }
 
-int launch(const osrl_ipc_t* x, float* const* seg, const int64_t* len, int n_seg, int gather, void* stream) {
+int launch(const osrl_ipc_t* x, float* const* seg, const int64_t* len, int n_seg, int gather, void* stream,
+           const int32_t* n_slabs = nullptr, const int64_t* sstride = nullptr) {
   if (!x || x->world < 1 || x->world > OSRL_IPC_MAX_WORLD || x->rank < 0 || x->rank >= x->world || !seg || !len ||
       n_seg < 1 || n_seg > OSRL_IPC_MAX_SEG || x->half_floats < 4)
     return -1;
@@ -233,6 +255,9 @@ int launch(const osrl_ipc_t* x, float* const* seg, const int64_t* len, int n_seg
     a.seg[s] = seg[s];
     a.len[s] = len[s];
     a.off[s] = off;
+    a.n_slabs[s] = (n_slabs && !gather && n_slabs[s] > 1) ? n_slabs[s] : 1;
+    a.sstride[s] = (sstride && a.n_slabs[s] > 1) ? sstride[s] : 0;
+    if (a.n_slabs[s] > 1 && a.sstride[s] < len[s]) return -1;
     if (s < n_pub) off += (len[s] + 3) & ~(int64_t)3;
   }
   if (off > x->half_floats) return OSRL_E_UNSUPPORTED;  // the caller splits the message or builds a larger exchange
@@ -284,6 +309,11 @@ extern "C" int osrl_ipc_free(void* dev_ptr) { return dev_ptr ? (int)hipFree(dev_
 
 extern "C" int osrl_ipc_all_reduce(const osrl_ipc_t* x, float* const* bufs, const int64_t* lens, int32_t n_bufs, void* stream) {
   return launch(x, bufs, lens, n_bufs, 0, stream);
+}
+
+extern "C" int osrl_ipc_all_reduce_slabs(const osrl_ipc_t* x, float* const* bufs, const int64_t* lens, const int32_t* n_slabs,
+                                         const int64_t* slab_strides, int32_t n_bufs, void* stream) {
+  return launch(x, bufs, lens, n_bufs, 0, stream, n_slabs, slab_strides);
 }
 
 extern "C" int osrl_ipc_all_gather(const osrl_ipc_t* x, const float* src, int64_t n, float* dst, void* stream) {

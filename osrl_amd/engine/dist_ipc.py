@@ -16,6 +16,7 @@ Reference: none -- the reference has no distributed code (SURVEY.md section 5); 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -59,7 +60,21 @@ class IpcDataParallel(DataParallel):
                 x.pub[r], x.ctl[r] = pp.value, pc.value
                 self._mapped += [pp.value, pc.value]
         self.x = x
+        self._pending = {}
         dist.barrier(group=group)  # every rank has mapped every buffer before the first exchange can publish into one
+
+    # ---- the rank's own split-K slab sum rides on the exchange ----
+    FUSE_SLABS = os.environ.get("OSRL_IPC_FUSE_SLABS", "1") == "1"  # (0: reduce_local launches the slab sum; the test compares)
+
+    def reduce_local(self, grp) -> torch.Tensor:
+        """``DataParallel.reduce_local`` launches the rank's slab sum; here it is only NOTED: the exchange that follows
+        forms it while publishing (csrc/ipc.hip publish_seg: same slab order, same bits) and leaves the sum over slabs and
+        ranks in slab 0.  The engines hand the returned tensor straight to ``all_reduce_`` / ``all_reduce_many_``."""
+        if not self.FUSE_SLABS or grp.cur_splits <= 1:
+            return super().reduce_local(grp)
+        self._pending[grp.slabs.data_ptr()] = (int(grp.cur_splits), int(grp.n))
+        grp.cur_splits = 1
+        return grp.slabs[0]
 
     # ---- the three primitives the engines use ----
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
@@ -81,9 +96,12 @@ class IpcDataParallel(DataParallel):
             chunk = ts[i:j]
             bufs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
             lens = (C.c_int64 * len(chunk))(*[t.numel() for t in chunk])
+            pend = [self._pending.pop(t.data_ptr(), (1, 0)) for t in chunk]  # (slab 0 of a group whose local sum is due)
+            nsl = (C.c_int32 * len(chunk))(*[p[0] for p in pend])
+            sst = (C.c_int64 * len(chunk))(*[p[1] for p in pend])
             self._timed(f"ipc all_reduce x{len(chunk)}", 4 * sum(t.numel() for t in chunk),
-                        lambda: L.check(L.load().osrl_ipc_all_reduce(C.byref(self.x), bufs, lens, len(chunk), cur_stream()),
-                                        "osrl_ipc_all_reduce"))
+                        lambda: L.check(L.load().osrl_ipc_all_reduce_slabs(C.byref(self.x), bufs, lens, nsl, sst, len(chunk),
+                                                                           cur_stream()), "osrl_ipc_all_reduce_slabs"))
             i = j
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:

@@ -149,3 +149,33 @@ def test_processes_on_one_gpu_sharded_step_equals_concatenated_batch(algo, W):
                 assert torch.equal(p, res[r]["graph_params"][n]), f"{algo}: replicas 0 and {r} differ in group {n} after graph replays"
             assert res[0]["graph_stats"] == res[r]["graph_stats"]
         assert not torch.equal(res[0]["obs_row0"], res[1]["obs_row0"]), "the ranks draw from different shards"
+
+
+def _run_ranks(algo, W):
+    import time
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.spawn(_worker, args=(W, _free_port(), algo, d), nprocs=W, join=False)
+        deadline = time.time() + 600
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                for p in ctx.processes:
+                    p.kill()
+                pytest.fail(f"the {W} ranks did not finish within 600 s")
+        return [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(W)]
+
+
+def test_slab_sum_fused_into_the_exchange_equals_the_separate_launch(monkeypatch):
+    """``IpcDataParallel.reduce_local`` only notes the rank's split-K slab sum; the exchange forms it while publishing
+    (osrl_ipc_all_reduce_slabs).  Same slab order as osrl_reduce_slabs: parameters after the eager steps AND after the
+    graph replays are bit-equal to the run with the slab sum as a launch of its own (OSRL_IPC_FUSE_SLABS=0), at C4's widths
+    (3 slabs for the VAE group, 2 for the critics)."""
+    monkeypatch.setenv("OSRL_IPC_FUSE_SLABS", "1")
+    fused = _run_ranks("cpq_c4", 2)
+    monkeypatch.setenv("OSRL_IPC_FUSE_SLABS", "0")
+    plain = _run_ranks("cpq_c4", 2)
+    for k, v in fused[0]["params"].items():
+        assert torch.equal(v, plain[0]["params"][k]), k
+    for n, p in fused[0]["graph_params"].items():
+        assert torch.equal(p, plain[0]["graph_params"][n]), n
+    assert fused[0]["exchanges"] == plain[0]["exchanges"]
