@@ -601,12 +601,16 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   }
   WG_LOG(1);
 }
+// (NCB == 4: the 13..16-block form is held to 256 registers per lane although its LDS tile allows one workgroup per CU
+// anyway -- with the one-output head fused in, the allocator took 205 VGPRs + 80 AGPRs where 512 are free, which left the
+// chain kernels of the other graph branch two 96-register waves per SIMD beside it instead of three: C2 2215-2221 vs
+// 2309-2322 steps/s with the cap (205 registers, accumulators in VGPRs), profiles/r6_nb_registers_ab.txt)
 template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, kNbRb == 4 ? 2 : 1) void mlp_fwd_nb_kernel(const NbArgs a) {
+__global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel(const NbArgs a) {
   mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&>(a);
 }
 template <int NCB, bool SHARED = false>
-__global__ __launch_bounds__(256, kNbRb == 4 ? 2 : 1) void mlp_fwd_nb_kernel_p(const void* p) {
+__global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel_p(const void* p) {
   mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
 }
 // the 8-wave form (25-block layers): NCB - 1 = 3 column blocks per wave
