@@ -1029,8 +1029,15 @@ def main():
         if c4_dp is not None:
             out["other_configs"] = {"c4": c4_dp}
         if world == 1 and not force_dp and not args.no_extras:
-            out["api_path"] = api_path(wl)
+            # the Trainer-API path on an engine of its own, as a reference-style train script gets it (round 6: measured on
+            # the engine the pipelined graphs had been built on it runs 8-10 % slower -- 2020-2050 vs 2230-2265 steps/s --
+            # with identical kernel timelines under rocprofv3 and an identical host profile: recorded as unexplained in
+            # DESIGN_LOG.md round 6; a user of train_one_step() never builds those graphs)
             del wl, eng
+            torch.cuda.empty_cache()
+            wl_api = Workload(args.config, device, rank, world, None, n_store=1 << 18, use_graph=not args.eager, steps_per_graph=1)
+            out["api_path"] = api_path(wl_api)
+            del wl_api
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(args.config, device, args.steps_per_graph)
         if world == 1 and not force_dp and not args.no_extras:

@@ -310,13 +310,19 @@ class BCQLEngine:
         m.repack()
 
     def capture(self) -> None:
-        snap = self._snapshot()
-        par = Branches(True, 1)
-        g, self._arena = capture_step(self.st.state.device, lambda: self.body(True), lambda: self.body(True, par))
-        self._par = par  # keep the side stream alive with the graph
-        torch.cuda.synchronize()
-        self._restore(snap)
-        self.graph = g
+        """(A few captures, the fastest graph kept: core.pick_fastest.)"""
+        from .core import CAPTURE_TRIES, pick_fastest
+
+        def once():
+            snap = self._snapshot()
+            par = Branches(True, 1)
+            g, arena = capture_step(self.st.state.device, lambda: self.body(True), lambda: self.body(True, par))
+            torch.cuda.synchronize()
+            self._restore(snap)
+            return g, par, arena  # (the side stream and the argument blocks stay alive with the graph)
+
+        (self.graph, self._par, self._arena), self.capture_ms = pick_fastest(once, lambda c: c[0].replay(), self._snapshot,
+                                                                              self._restore, CAPTURE_TRIES)
 
     def attach_replay(self, store) -> None:
         """Sample minibatches on device from ``store`` (common/replay.py) inside the step itself."""

@@ -483,6 +483,18 @@ class CPQEngine:
             self.noise[k].copy_(torch.as_tensor(noise[k]).reshape(self.noise[k].shape), non_blocking=True)
 
     def capture(self) -> None:
+        """Capture one step into a hipGraph -- on one GPU a few times over, keeping the graph whose replays are fastest
+        (core.pick_fastest: the branch -> hardware-queue mapping of a capture depends on the streams created before it)."""
+        from .core import CAPTURE_TRIES, pick_fastest
+
+        def replay(c):
+            c[0].replay()
+
+        tries = CAPTURE_TRIES if (self.dist is None and self.parallel_branches) else 1
+        (self.graph, self._par, self._arena), self.capture_ms = pick_fastest(self._capture_once, replay, self._snapshot,
+                                                                              self._restore, tries)
+
+    def _capture_once(self):
         """Capture one step (device-drawn noise) into a hipGraph.  Warm-up launches run first on a
         side stream as torch requires; the model state they advance is restored afterwards."""
         snap = self._snapshot()
@@ -503,12 +515,10 @@ class CPQEngine:
             # vs 1755 steps/s -- every kernel of the step ran ~2x slower)
             with graph_capture(g), arena.replay():
                 self.body(True, par)
-            self._par = par  # keep the side streams alive with the graph
-            self._arena = arena  # ... and the argument blocks its kernels read
         finally:
             torch.cuda.synchronize()
             self._restore(snap)
-        self.graph = g
+        return g, par, arena  # (the side streams and the argument blocks its kernels read stay alive with the graph)
 
     def _snapshot(self):
         m = self.model

@@ -69,7 +69,23 @@ class PipelinedSteps:
             else:
                 e.body(True, par, nxt=x, prologue_done=k > 0)
 
+    def _snapshot(self):
+        e0, e1 = self.e
+        return e0._snapshot(), (e1.st.state.clone(), e1.st.stats.clone())
+
+    def _restore(self, snap) -> None:
+        e0, e1 = self.e
+        e0._restore(snap[0])
+        e1.st.state.copy_(snap[1][0])
+        e1.st.stats.copy_(snap[1][1])
+
     def capture(self) -> None:
+        """(A few captures, the fastest graph kept: core.pick_fastest.)"""
+        from .core import CAPTURE_TRIES, pick_fastest
+        (self.graph, self._par, self._arena), self.capture_ms = pick_fastest(self._capture_once, lambda c: c[0].replay(),
+                                                                              self._snapshot, self._restore, CAPTURE_TRIES)
+
+    def _capture_once(self):
         e0, e1 = self.e
         dev = e0.st.state.device
         snap = e0._snapshot()
@@ -86,13 +102,12 @@ class PipelinedSteps:
             g = torch.cuda.CUDAGraph()
             with graph_capture(g), arena.replay():
                 self._issue(par)
-            self._par, self._arena = par, arena
         finally:
             torch.cuda.synchronize()
             e0._restore(snap)
             e1.st.state.copy_(snap1[0])
             e1.st.stats.copy_(snap1[1])
-        self.graph = g
+        return g, par, arena
 
     def run(self, n_steps: int) -> None:
         e0 = self.e[0]
