@@ -179,3 +179,122 @@ def test_slab_sum_fused_into_the_exchange_equals_the_separate_launch(monkeypatch
     for n, p in fused[0]["graph_params"].items():
         assert torch.equal(p, plain[0]["graph_params"][n]), n
     assert fused[0]["exchanges"] == plain[0]["exchanges"]
+
+
+def _worker_more(rank, W, port, algo, out_dir):
+    """BEAR-L / COptiDICE / CDT ranks (the engines whose data-parallel step is issued eagerly): the Trainer API on the
+    rank's rows with injected noise."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        from osrl_amd.engine.dist_ipc import IpcDataParallel
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+        dp = IpcDataParallel()
+        if algo.startswith("cdt"):
+            from cases import CDT_CASES
+            from test_gpu_cdt import build_cdt_gpu
+            c = CDT_CASES[algo]
+            Bl = c.B // W
+            batch = _cdt_batch(c, W)
+            m, tr, lg = build_cdt_gpu(c)
+            eng = m.engine(Bl, tr.cfg, dist=dp)
+            args = [t(batch[k][rank * Bl:(rank + 1) * Bl]) for k in CDT_KEYS]
+            for s in range(3):
+                tr.train_one_step(*args)
+        else:
+            from cases import make_batch, make_noise
+            from gpu_util import build_gpu
+            from test_gpu_dp_sim import DP_CASES, _shard
+            c = DP_CASES[algo]
+            B, N, M = c.B, c.N, int(c.hp.get("M", 1))
+            Bl = B // W
+            batch = make_batch(c)
+            keys = TRANSITION_KEYS + (("is_init",) if c.algo == "coptidice" else ())
+            m, tr, lg = build_gpu(c)
+            eng = m.engine(Bl, rows_global=B, dist=dp)
+            args = [t(batch[k][rank * Bl:(rank + 1) * Bl]) for k in keys]
+            for s in range(c.steps):
+                nz = {k: t(_shard(v, k, rank, W, B, N, M)) for k, v in make_noise(c, s).items()}
+                if c.algo == "coptidice":
+                    tr.train_one_step(list(args), noise=nz)
+                else:
+                    tr.train_one_step(*args, noise=nz)
+        torch.cuda.synchronize()
+        dp.check()
+        res = {"params": {k: v.detach().cpu() for k, v in m.state_dict().items()},
+               "log": {k: [float(x) for x in v] for k, v in lg.data.items()}, "exchanges": dp.status()["done"]}
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+        dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+TRANSITION_KEYS = ("observations", "next_observations", "actions", "rewards", "costs", "done")
+CDT_KEYS = ("states", "actions", "returns", "costs_return", "time_steps", "mask", "episode_cost", "costs")
+
+
+def _cdt_batch(c, W):
+    from cases import make_cdt_batch
+    batch = make_cdt_batch(c)
+    batch["mask"][0, 1:] = 0  # the shards hold different numbers of valid tokens (global counts in the means)
+    return batch
+
+
+@pytest.mark.parametrize("algo", ["bearl", "coptidice", "coptidice_nochi", "cdt_small", "cdt_v_norew"])
+def test_processes_on_one_gpu_other_engines(algo):
+    """The remaining data-parallel engines against a peer PROCESS over the IPC exchange: BEAR-L (critic groups in one
+    exchange, the MMD actor's batch means), COptiDICE (softmax over the all-gathered global batch, with and without
+    the chi net), CDT (global valid-token counts, clip by the norm of the REDUCED gradient, global entropy under the
+    temperature step).  Same statement as tests/test_gpu_dp_sim.py: sharded == concatenated, replicas bit-identical."""
+    import time
+    import torch.multiprocessing as mp
+    W = 2
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+    if algo.startswith("cdt"):
+        from cases import CDT_CASES
+        from test_gpu_cdt import build_cdt_gpu
+        c = CDT_CASES[algo]
+        batch = _cdt_batch(c, W)
+        m1, tr1, lg1 = build_cdt_gpu(c)
+        for s in range(3):
+            tr1.train_one_step(*[t(batch[k]) for k in CDT_KEYS])
+        tol = 2e-6
+    else:
+        from cases import make_batch, make_noise
+        from gpu_util import build_gpu
+        from test_gpu_dp_sim import DP_CASES
+        c = DP_CASES[algo]
+        batch = make_batch(c)
+        keys = TRANSITION_KEYS + (("is_init",) if c.algo == "coptidice" else ())
+        m1, tr1, lg1 = build_gpu(c)
+        for s in range(c.steps):
+            nz = {k: t(v) for k, v in make_noise(c, s).items()}
+            if c.algo == "coptidice":
+                tr1.train_one_step([t(batch[k]) for k in keys], noise=nz)
+            else:
+                tr1.train_one_step(*[t(batch[k]) for k in keys], noise=nz)
+        tol = 2e-5
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu() for k, v in m1.state_dict().items()}
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.spawn(_worker_more, args=(W, _free_port(), algo, d), nprocs=W, join=False)
+        deadline = time.time() + 600
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                for p in ctx.processes:
+                    p.kill()
+                pytest.fail(f"the {W} ranks did not finish within 600 s")
+        res = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(W)]
+    for r in range(W):
+        assert res[r]["exchanges"] >= 3, res[r]["exchanges"]
+        for k, v in want.items():
+            if v.dtype == torch.bool:
+                continue
+            d_ = (res[r]["params"][k].double() - v.double()).abs().max().item()
+            assert d_ <= tol, f"{algo} rank {r} param {k}: sharded vs concatenated {d_:.3e}"
+        for k, vals in lg1.data.items():
+            assert np.allclose(res[r]["log"][k], [float(x) for x in vals], rtol=1e-4, atol=1e-5), (algo, r, k)
+    for k, v in res[0]["params"].items():
+        assert torch.equal(v, res[1]["params"][k]), f"{algo}: the replicas differ in {k}"
