@@ -282,7 +282,14 @@ extern "C" int osrl_ipc_alloc(int64_t bytes, void** dev_ptr, void* handle64) {
   if (bytes < 16 || !dev_ptr || !handle64) return -1;
   static_assert(sizeof(hipIpcMemHandle_t) == OSRL_IPC_HANDLE_BYTES, "handle size");
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, (size_t)bytes);
+  // FINE-GRAINED device memory: what a peer DEVICE maps over xGMI must not be held in the reader's L2 across the flag
+  // handshake -- coarse-grained (plain hipMalloc) memory is only guaranteed coherent at kernel boundaries, and both the
+  // flags and the published halves are read by peers INSIDE a running kernel.  (Same-device peers share one L2 per XCD
+  // path and never saw the difference; the kernel's system-scope accesses stay as they are.  OSRL_IPC_COARSE=1: the plain
+  // allocation of the first version, kept for the A/B in profiles/r6_ipc_finegrained_ab.txt.)
+  static const bool coarse = [] { const char* v = getenv("OSRL_IPC_COARSE"); return v && v[0] == '1'; }();
+  hipError_t e = coarse ? hipMalloc(&p, (size_t)bytes)
+                        : hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) return (int)e;
   e = hipMemset(p, 0, (size_t)bytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();
