@@ -187,7 +187,7 @@ constexpr int kAst = 128 * 128;       // one fp32 A slab: 128 rows x 32 k
 constexpr int kPl = 128 * 64;         // one bf16 plane of 128 rows x 32 k
 constexpr int kV2Lds = 2 * kAst + 2 * 3 * kPl + 3 * 3 * kPl;  // 155648 B
 
-template <int NSETS, bool DO_SPLIT, bool DO_MMA, bool DO_DMA>
+template <int NSETS, bool DO_SPLIT, bool DO_MMA, bool DO_DMA, bool NO_BAR = false, bool NO_LDS = false>
 __global__ __launch_bounds__(512, 2) void split_gemm_v2_kernel(const SplitArgs a, const int row_tiles, const int col_tiles,
                                                                const int nwg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -261,6 +261,12 @@ __global__ __launch_bounds__(512, 2) void split_gemm_v2_kernel(const SplitArgs a
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[2][3], bf[3];
+      if (NO_LDS) {
+        u32x4 z = {0x3f803f80u + (unsigned)lane, 0x3f803f80u, 0x3f803f80u + (unsigned)step, 0x3f803f80u};
+        asm volatile("" : "+v"(z));
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { af[0][p] = __builtin_bit_cast(bf16x8, z); af[1][p] = __builtin_bit_cast(bf16x8, z); bf[p] = __builtin_bit_cast(bf16x8, z); }
+      } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int row = f_row_a + r * 32;
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void split_gemm_v2_kernel(const SplitArgs a
         const int off = f_row_b * 64 + (((2 * s + f_hi) ^ ((f_row_b >> 2) & 3)) * 16);
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + p * kPl + off));
+      }
       }
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -290,7 +297,8 @@ __global__ __launch_bounds__(512, 2) void split_gemm_v2_kernel(const SplitArgs a
   bool stored = false;
   for (int g = 0; g < nsteps; ++g) {
     // slab g + 1 landed (this wave's part; the stores of a tile that just ended may stay in flight), planes of slab g written
-    if (stored) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NO_BAR) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (stored) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stored = false;
     if (DO_DMA) dma();  // slab g + 2
@@ -327,9 +335,9 @@ __global__ __launch_bounds__(512, 2) void split_gemm_v2_kernel(const SplitArgs a
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSETS, bool DO_SPLIT, bool DO_MMA, bool DO_DMA>
+template <int NSETS, bool DO_SPLIT, bool DO_MMA, bool DO_DMA, bool NO_BAR = false, bool NO_LDS = false>
 static float run_v2(const SplitArgs& a, int reps) {
-  auto* kern = split_gemm_v2_kernel<NSETS, DO_SPLIT, DO_MMA, DO_DMA>;
+  auto* kern = split_gemm_v2_kernel<NSETS, DO_SPLIT, DO_MMA, DO_DMA, NO_BAR, NO_LDS>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
   int n_cu = 256;
   CK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0));
@@ -341,6 +349,191 @@ static float run_v2(const SplitArgs& a, int reps) {
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), kV2Lds, 0, a, rt, ct, n_cu);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / reps;
+}
+
+
+// ---- v3: 256-column tiles over 16-deep slabs (half the L2 -> LDS bytes per FLOP of v2), persistent 8-wave workgroup per CU.
+// <RB, CB, WR> = 32 x 32 blocks per wave (rows, columns) and wave rows: <4, 2, 2> = 256 x 256 tile, 128 x 64 per wave;
+// <5, 1, 1> = 160 x 256 tile (N = 256 at M = 81920: 512 tiles = two whole rounds of the 256 CUs), 160 x 32 per wave.
+// Plane rows are 32 B (16 k); the 16-byte chunk position is XOR-swizzled by (row >> 3) & 1.
+template <int RB, int CB, int WR, int NSETS>
+__global__ __launch_bounds__(512, 2) void split_gemm_v3_kernel(const SplitArgs a, const int row_tiles, const int col_tiles,
+                                                               const int nwg) {
+  constexpr int TM = WR * RB * 32, WC = 8 / WR;
+  static_assert(WC * CB * 32 == 256, "256-column tiles");
+  constexpr int kSt = TM * 64, kPa = TM * 32, kPb = 256 * 32;
+  constexpr int NA = TM / 16;  // A staging DMA instructions per slab (16 rows each)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const Ast = lds;
+  unsigned char* const Apl = lds + 2 * kSt;
+  unsigned char* const Bpl = Apl + 2 * 3 * kPa;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int K = a.K, nk = K >> 4;
+  const size_t pstride = (size_t)a.N * K;
+  const int tiles = row_tiles * col_tiles;
+  const int t0 = (int)((long)tiles * blockIdx.x / nwg), t1 = (int)((long)tiles * (blockIdx.x + 1) / nwg);
+  if (t0 >= t1) return;
+  const int nsteps = (t1 - t0) * nk;
+  int i_tile = t0, i_ks = 0, i_step = 0;
+  const int a_lrow = lane >> 2, a_chunk = lane & 3;                        // A staging: 16 rows x 4 chunks
+  const int b_lrow = lane >> 1, b_chunk = (lane & 1) ^ ((lane >> 4) & 1);  // W planes: 32 rows x 2 chunk slots, row >> 3 = lane >> 4
+  auto dma = [&]() {
+    const int rt = i_tile / col_tiles, ct = i_tile - rt * col_tiles;
+    const int sa = i_step & 1, sb = i_step % 3;
+#pragma unroll
+    for (int j = 0; j < (NA + 7) / 8; ++j) {
+      const int blk = wave + 8 * j;
+      if (blk < NA) {
+        const int row = rt * TM + 16 * blk + a_lrow;
+        glds16(a.A + (size_t)row * a.lda + i_ks * 16 + a_chunk * 4, Ast + sa * kSt + blk * 1024);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int col = ct * 256 + 32 * wave + b_lrow;
+      glds16(a.Wp + p * pstride + (size_t)col * K + i_ks * 16 + b_chunk * 8, Bpl + (sb * 3 + p) * kPb + wave * 1024);
+    }
+    ++i_step;
+    if (++i_ks == nk) { i_ks = 0; ++i_tile; if (i_tile >= t1) i_tile = t1 - 1; }
+  };
+  const int s_row = tid >> 1, s_h = tid & 1;
+  const int s_src = s_row * 64 + s_h * 32;
+  const int s_dst = s_row * 32 + ((s_h ^ ((s_row >> 3) & 1)) * 16);
+  auto split = [&](int step) {
+    if (TM * 2 < 512 && tid >= TM * 2) return;
+    const unsigned char* src = Ast + (step & 1) * kSt + s_src;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 16);
+    unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split3(x0[e], hh[e], mm[e], ll[e]); split3(x1[e], hh[4 + e], mm[4 + e], ll[4 + e]); }
+    u32x4 vh, vm, vl;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      vh[d] = pack_hi(hh[2 * d], hh[2 * d + 1]);
+      vm[d] = pack_hi(mm[2 * d], mm[2 * d + 1]);
+      vl[d] = pack_hi(ll[2 * d], ll[2 * d + 1]);
+    }
+    unsigned char* dst = Apl + (step & 1) * 3 * kPa + s_dst;
+    *reinterpret_cast<u32x4*>(dst) = vh;
+    *reinterpret_cast<u32x4*>(dst + kPa) = vm;
+    *reinterpret_cast<u32x4*>(dst + 2 * kPa) = vl;
+  };
+  const int f_hi = lane >> 5;
+  int offa[RB], offb[CB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = wr * RB * 32 + r * 32 + (lane & 31);
+    offa[r] = row * 32 + ((f_hi ^ ((row >> 3) & 1)) * 16);
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const int col = wc * CB * 32 + c * 32 + (lane & 31);
+    offb[c] = col * 32 + ((f_hi ^ ((col >> 3) & 1)) * 16);
+  }
+  f32x16 acc[NSETS][RB][CB];
+#pragma unroll
+  for (int q = 0; q < NSETS; ++q)
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[q][r][c][v] = 0.f;
+  auto mma = [&](int step) {
+    const unsigned char* ap = Apl + (step & 1) * 3 * kPa;
+    const unsigned char* bp = Bpl + (step % 3) * 3 * kPb;
+    bf16x8 af[RB][3], bf[CB][3];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + p * kPb + offb[c]));
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[r][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ap + p * kPa + offa[r]));
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int r0 = 0; r0 < RB; r0 += 2)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = r0; r < (r0 + 2 < RB ? r0 + 2 : RB); ++r)
+#pragma unroll
+          for (int c = 0; c < CB; ++c)
+            acc[t * NSETS / 6][r][c] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r][PA[t]], bf[c][PB[t]], acc[t * NSETS / 6][r][c], 0, 0, 0);
+  };
+  dma();
+  dma();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  split(0);
+  int tile = t0, ks = 0;
+  bool stored = false;
+  for (int g = 0; g < nsteps; ++g) {
+    if (stored) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stored = false;
+    dma();  // slab g + 2
+    if ((wave & 1) == 0) {
+      if (g + 1 < nsteps) split(g + 1);
+      mma(g);
+    } else {
+      mma(g);
+      if (g + 1 < nsteps) split(g + 1);
+    }
+    if (++ks == nk) {
+      ks = 0;
+      const int rt = tile / col_tiles, ct = tile - rt * col_tiles;
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int col = ct * 256 + wc * CB * 32 + c * 32 + (lane & 31);
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int row = rt * TM + wr * RB * 32 + r * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+            float y = acc[0][r][c][v];
+#pragma unroll
+            for (int q = 1; q < NSETS; ++q) y += acc[q][r][c][v];
+            y += bv;
+            if (a.resid) y += a.resid[(size_t)row * a.ldr + col];
+            a.Y[(size_t)row * a.ldy + col] = y;
+#pragma unroll
+            for (int q = 0; q < NSETS; ++q) acc[q][r][c][v] = 0.f;
+          }
+      }
+      stored = true;
+      ++tile;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int RB, int CB, int WR, int NSETS>
+static float run_v3(const SplitArgs& a, int reps) {
+  constexpr int TM = WR * RB * 32;
+  constexpr int kLdsV3 = 2 * TM * 64 + 2 * 3 * TM * 32 + 3 * 3 * 256 * 32;
+  auto* kern = split_gemm_v3_kernel<RB, CB, WR, NSETS>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsV3));
+  int n_cu = 256;
+  CK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0));
+  if (a.M % TM || a.N % 256) return -1.f;
+  const int rt = a.M / TM, ct = a.N / 256;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), kLdsV3, 0, a, rt, ct, n_cu);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), kLdsV3, 0, a, rt, ct, n_cu);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -369,7 +562,8 @@ static float run(const SplitArgs& a, int reps) {
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 81920;
   struct Shape { int K, N, res; };
-  const Shape shapes[] = {{256, 1024, 0}, {256, 768, 0}, {1024, 256, 1}, {256, 256, 1}, {768, 256, 0}};
+  const Shape all_shapes[] = {{256, 1024, 0}, {256, 768, 0}, {1024, 256, 1}, {256, 256, 1}, {768, 256, 0}};
+  std::vector<Shape> shapes(all_shapes, all_shapes + (argc > 2 ? 1 : 5));
   const int maxK = 1024, maxN = 1024;
   std::vector<float> hA((size_t)M * maxK), hW((size_t)maxK * maxN), hb(maxN), hR((size_t)M * 256);
   uint32_t s = 12345;
@@ -421,12 +615,20 @@ int main(int argc, char** argv) {
       printf("  %-22s %8.1f us  %6.1f TF/s-equivalent (%.2fx the f32 roof)   err vs fp64: max %.2e rms %.2e   [sequential fp32 fma: max %.2e rms %.2e; |y| max %.1f]\n",
              name, us, gf * 1e3 / us, gf * 1e3 / us / 157.3, e_max, sqrt(e_sq / ns), f_max, sqrt(f_sq / ns), scale);
     };
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v3 256x256", run_v3<4, 2, 2, 1>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v3 160x256", run_v3<5, 1, 1, 1>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v3 160x256, 2 acc sets", run_v3<5, 1, 1, 2>(a, reps));
+    if (argc > 2) {
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 1 acc set", run_v2<1, true, true, true>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 3 acc sets", run_v2<3, true, true, true>(a, reps));
-    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 3 sets, no split", run_v2<3, false, true, true>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 no mma", run_v2<3, true, false, true>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 mma only", run_v2<3, false, true, false>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 dma only", run_v2<3, false, false, true>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 mma only, no barrier", run_v2<3, false, true, false, true, false>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 mma only, no lds", run_v2<3, false, true, false, false, true>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 mma only, neither", run_v2<3, false, true, false, true, true>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 mma only 1 set, neither", run_v2<1, false, true, false, true, true>(a, reps));
+    }
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("6 products", run<6>(a, reps));
     if (argc > 2) {
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("9 products", run<9>(a, reps));
