@@ -533,6 +533,12 @@ def roofline(eng, cfg_name="c2"):
            "top_by_total": {"symbol": "mlp_fwd2_kernel_p<1, 2, 8>", "launches_per_step": 3,
                             "source": "static: profiles/r6_bench_kernel_stats_c2.csv"} if cfg_name == "c2" else None,
            "isolated_achieved": round(ach_iso, 3), "isolated_frac": round(ach_iso / PEAK_FP32_TFLOPS, 4),
+           # what a loop of nothing but independent v_mfma_f32_16x16x4_f32 sustains on all 256 CUs (one / two waves per SIMD):
+           # the nominal peak above assumes 32 cycles per instruction, the chip delivers 37-41.  Reported beside `peak`, never
+           # instead of it.
+           "sustained_peak": {"value": [122.1, 134.6], "unit": "TFLOP/s", "frac_of_it": round(ach / 134.6, 4),
+                              "isolated_frac_of_it": round(ach_iso / 134.6, 4),
+                              "source": "static: tools/mfma_bf16_probe.hip, profiles/r6_mfma_bf16_probe.txt"},
            "traffic": r["traffic"], "traffic_source": traffic_src if r["traffic"] is not None else None,
            "algorithmic_bytes": r["algorithmic_bytes"],
            # five launches of the step by HIP events around EAGERLY issued launches (two streams): indicative only
