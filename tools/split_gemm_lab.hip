@@ -70,12 +70,24 @@ struct SplitArgs {
   int32_t M, K, N;
 };
 
-template <int NPROD>
-__global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SplitArgs a) {
+template <int NPROD, int ORDER = 0, bool SW = false>
+__global__ __launch_bounds__(256, SW ? 3 : 2) void split_gemm_kernel(const SplitArgs a) {
+  constexpr int kPitch = SW ? 64 : 80, kPlane = 128 * kPitch;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int row0 = blockIdx.x * 128, col0 = blockIdx.y * 128;
+  int row0, col0;
+  if (ORDER == 0) {
+    row0 = blockIdx.x * 128; col0 = blockIdx.y * 128;
+  } else {
+    // 1-D grid; workgroup i runs on XCD i % 8: give every XCD a contiguous run of tiles, column tiles fastest, so the
+    // workgroups that share A rows (and the W planes) meet in ONE L2
+    const int n = gridDim.x, ct = a.N >> 7;
+    const int i = blockIdx.x, per = (n + 7) >> 3;
+    int t = (i & 7) * per + (i >> 3);
+    if (t >= n) return;
+    row0 = (t / ct) * 128; col0 = (t % ct) * 128;
+  }
   const int K = a.K, nk = K >> 5;
   const size_t pstride = (size_t)a.N * K;
   // ---- sources
@@ -87,9 +99,10 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SplitArgs a) {
   for (int j = 0; j < 6; ++j) {
     const int c = tid + 256 * j, p = c >> 9, rem = c & 511, col = rem >> 2, q = rem & 3;
     bp[j] = a.Wp + p * pstride + (size_t)(col0 + col) * K + q * 8;
-    boff[j] = (3 + p) * kPlane + col * kPitch + q * 16;
+    boff[j] = (3 + p) * kPlane + col * kPitch + (SW ? (q ^ ((col >> 2) & 3)) : q) * 16;
   }
-  const int aoff = arow * kPitch + ahalf * 32;
+  const int aoff = arow * kPitch;
+  const int asw = SW ? ((arow >> 2) & 3) : 0;
   f32x4 pa[4];
   u32x4 pb[6];
   auto fetch = [&](int ks) {
@@ -106,8 +119,9 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SplitArgs a) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
   // fragment addresses (bytes): plane p, K16 step s: + p * kPlane + s * 32
-  const int fa = (wr * 64 + (lane & 31)) * kPitch + (lane >> 5) * 16;
-  const int fb = 3 * kPlane + (wc * 64 + (lane & 31)) * kPitch + (lane >> 5) * 16;
+  const int fra = wr * 64 + (lane & 31), frb = wc * 64 + (lane & 31);  // (+ 32 per block: (row >> 2) & 3 unchanged)
+  const int fa = fra * kPitch, fb = 3 * kPlane + frb * kPitch;
+  const int swa = SW ? ((fra >> 2) & 3) : 0, swb = SW ? ((frb >> 2) & 3) : 0;
   fetch(0);
   for (int ks = 0; ks < nk; ++ks) {
     // ---- split this thread's 16 A values, write the planes; pass the pre-split W chunks through
@@ -123,9 +137,10 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SplitArgs a) {
         vm[d] = pack_hi(mm[2 * d], mm[2 * d + 1]);
         vl[d] = pack_hi(ll[2 * d], ll[2 * d + 1]);
       }
-      *reinterpret_cast<u32x4*>(lds + 0 * kPlane + aoff + h8 * 16) = vh;
-      *reinterpret_cast<u32x4*>(lds + 1 * kPlane + aoff + h8 * 16) = vm;
-      *reinterpret_cast<u32x4*>(lds + 2 * kPlane + aoff + h8 * 16) = vl;
+      const int ao = aoff + (((ahalf * 2 + h8) ^ asw) * 16);
+      *reinterpret_cast<u32x4*>(lds + 0 * kPlane + ao) = vh;
+      *reinterpret_cast<u32x4*>(lds + 1 * kPlane + ao) = vm;
+      *reinterpret_cast<u32x4*>(lds + 2 * kPlane + ao) = vl;
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(lds + boff[j]) = pb[j];
@@ -138,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SplitArgs a) {
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          af[r][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + fa + p * kPlane + r * 32 * kPitch + s * 32));
+          af[r][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + fa + p * kPlane + r * 32 * kPitch + (((2 * s + (lane >> 5)) ^ swa) * 16)));
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + fb + p * kPlane + c * 32 * kPitch + s * 32));
+          bf[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + fb + p * kPlane + c * 32 * kPitch + (((2 * s + (lane >> 5)) ^ swb) * 16)));
       // smallest terms first; the four blocks between two products on the same accumulator
       constexpr int PA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, PB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};  // the last NPROD are used
 #pragma unroll
@@ -157,22 +172,30 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SplitArgs a) {
     }
     __syncthreads();
   }
-  // ---- epilogue: 32 x 32 block layout: register v of lane l = row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32
+  // ---- epilogue: 32 x 32 block layout: register v of lane l = row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32.
+  // One lane-dependent base offset; everything else is wave-uniform (scalar) arithmetic.
+  {
+    const unsigned ldy = (unsigned)a.ldy, ldr = (unsigned)a.ldr;
+    const unsigned lrow = (unsigned)(wr * 64 + (lane >> 5) * 4), lcol = (unsigned)(wc * 64 + (lane & 31));
+    float* yb = a.Y + (size_t)row0 * a.ldy + col0;
+    const float* rb_ = a.resid ? a.resid + (size_t)row0 * a.ldr + col0 : nullptr;
+    const unsigned oy = lrow * ldy + lcol, orr = lrow * ldr + lcol;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int col = col0 + wc * 64 + c * 32 + (lane & 31);
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    for (int c = 0; c < 2; ++c) {
+      const float bv = a.bias ? a.bias[col0 + lcol + c * 32] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int row = row0 + wr * 64 + r * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
-        float y = acc[r][c][v] + bv;
-        if (a.resid) y += a.resid[(size_t)row * a.ldr + col];
-        a.Y[(size_t)row * a.ldy + col] = y;
-      }
+        for (int v = 0; v < 16; ++v) {
+          const unsigned ro = (unsigned)(r * 32 + (v >> 2) * 8 + (v & 3));
+          float y = acc[r][c][v] + bv;
+          if (rb_) y += rb_[orr + ro * ldr + c * 32];
+          yb[oy + ro * ldy + c * 32] = y;
+        }
+    }
   }
 }
+
 
 
 // ---- v2: persistent, one 8-wave workgroup per CU; A fp32 slabs and pre-split W planes arrive by DMA (global_load_lds),
@@ -541,17 +564,19 @@ static float run_v3(const SplitArgs& a, int reps) {
   return ms * 1000.f / reps;
 }
 
-template <int NPROD>
+template <int NPROD, int ORDER = 0, bool SW = false>
 static float run(const SplitArgs& a, int reps) {
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<NPROD>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  const int kLds = 6 * 128 * (SW ? 64 : 80);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<NPROD, ORDER, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
   dim3 grid(a.M / 128, a.N / 128);
+  if (ORDER == 1) grid = dim3(((a.M / 128) * (a.N / 128) + 7) / 8 * 8, 1);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(split_gemm_kernel<NPROD>, grid, dim3(256), kLds, 0, a);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((split_gemm_kernel<NPROD, ORDER, SW>), grid, dim3(256), kLds, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(split_gemm_kernel<NPROD>, grid, dim3(256), kLds, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((split_gemm_kernel<NPROD, ORDER, SW>), grid, dim3(256), kLds, 0, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -615,10 +640,10 @@ int main(int argc, char** argv) {
       printf("  %-22s %8.1f us  %6.1f TF/s-equivalent (%.2fx the f32 roof)   err vs fp64: max %.2e rms %.2e   [sequential fp32 fma: max %.2e rms %.2e; |y| max %.1f]\n",
              name, us, gf * 1e3 / us, gf * 1e3 / us / 157.3, e_max, sqrt(e_sq / ns), f_max, sqrt(f_sq / ns), scale);
     };
+    if (argc > 2) {
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v3 256x256", run_v3<4, 2, 2, 1>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v3 160x256", run_v3<5, 1, 1, 1>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v3 160x256, 2 acc sets", run_v3<5, 1, 1, 2>(a, reps));
-    if (argc > 2) {
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 1 acc set", run_v2<1, true, true, true>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 3 acc sets", run_v2<3, true, true, true>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 no mma", run_v2<3, true, false, true>(a, reps));
@@ -630,6 +655,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("v2 mma only 1 set, neither", run_v2<1, false, true, false, true, true>(a, reps));
     }
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("6 products", run<6>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("6 products, xcd order", run<6, 1>(a, reps));
+    CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("6 products, 3 wg/cu", run<6, 0, true>(a, reps));
     if (argc > 2) {
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("9 products", run<9>(a, reps));
     CK(hipMemset(dY, 0, (size_t)M * sh.N * 4)); check("3 products (bf16x2)", run<3>(a, reps));
