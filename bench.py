@@ -95,19 +95,28 @@ def flops_per_step(cfg) -> float:
     return 2.0 * per * Bsz
 
 
-def executed_flops_per_step(cfg) -> float:
+def executed_flops_per_step(cfg, ood_rows: bool = False) -> float:
     """FLOPs this build actually ISSUES per step.  The reference's step (flops_per_step) contains work whose result
     it discards or computes twice; the engine skips exactly that (same results):
       * CPQ ``cost_critic_loss`` runs the whole VAE on the N*B sampled actions and keeps only the KL of the ENCODER
         output (cpq.py:176-182: ``_, _, mean, std = self.vae(...)``): the decoder on N*B rows is never launched;
-      * the actor trunk on next_obs (cpq.py:141 and :159) and on obs (:164 and :209) is evaluated once each.
+      * the actor trunk on next_obs (cpq.py:141 and :159) and on obs (:164 and :209) is evaluated once each;
+      * ``ood_rows`` (the engine's plan.ood_rows on one GPU): the target cost critics on the quarter of the N*B sampled
+        actions that enters ``qc_ood`` (cpq.py:183-184) instead of all of them.
     Other algorithms: nothing skipped."""
     if cfg["algo"] != "cpq":
         return flops_per_step(cfg)
     od, ad, Bsz, H, V, N = cfg["od"], cfg["ad"], cfg["B"], HID, VAE_H, NS
     actor = lin([od] + H) + 2 * H[-1] * ad
     dec = lin([od + 2 * ad, V, V, ad])
-    return flops_per_step(cfg) - 2.0 * (N * dec + 2 * actor) * Bsz
+    fx = flops_per_step(cfg) - 2.0 * (N * dec + 2 * actor) * Bsz
+    if ood_rows:
+        # plan.ood_rows (round 6): qc_ood = ((KL >= quantile(KL, 0.75)) * qc_sampled).mean(0) -- the target cost critics run
+        # on the rows that pass only: n - floor(0.75 (n - 1)) - 1 of the n = N*B (torch.quantile 'linear'; ties add rows)
+        n = N * Bsz
+        kept = n - int(0.75 * (n - 1)) - 1
+        fx -= 2.0 * 2 * lin([od + ad] + H + [1]) * (n - kept)
+    return fx
 
 
 def lease_diagnostics(device) -> dict:
@@ -496,6 +505,11 @@ def roofline(eng, cfg_name="c2"):
             mean_us, med_us = sites.get(site, (float("nan"), float("nan")))
             how = "eager"
         in_run = mean_us == mean_us
+        fl_in = fl
+        if site == "costold_ood" and getattr(eng, "ood_rows", False):
+            # plan.ood_rows: inside the step this launch runs on the selected rows only (the isolated figure below is the
+            # same kernel form on all N*B rows); its in-step FLOPs are those of the rows the last probe step selected
+            fl_in = fl * float(int(eng.ood_count[0].item())) / float(run.rows)
         d = run.net.dims
         # algorithmic bytes of the launch as SURVEY.md 8d counts them: every row of the virtual [N*B, in] input, the weights
         # + biases of every net once, the [rows, out] result.  `distinct_bytes`: the same with the input's DISTINCT rows only
@@ -508,17 +522,18 @@ def roofline(eng, cfg_name="c2"):
                          isolated_frac=round(fl / t / 1e12 / PEAK_FP32_TFLOPS, 4),
                          in_step_us=round(mean_us, 2) if in_run else None,
                          in_step_us_median=round(med_us, 2) if in_run else None,
-                         in_step_frac=round(fl / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4) if in_run else None,
+                         in_step_frac=round(fl_in / (mean_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4) if in_run else None,
+                         in_step_gflop=round(fl_in / 1e9, 3),
                          in_step_how=how if in_run else None,
                          stamp_boundary_us=round(graph_sites[site + "/boundary"][0], 2) if site + "/boundary" in graph_sites else None, in_step_eager_us=round(sites[site][0], 2) if site in sites else None,
                          algorithmic_bytes=int(alg), distinct_bytes=int(distinct), traffic=pmc.get(name), wg_cap=int(run.fwd_c.wg_cap), _fl=fl, _t=t,
-                         _us=mean_us)
+                         _us=mean_us, _fl_in=fl_in)
     have_run = all(v["in_step_us"] is not None for v in res.values())
     # dominant = the launch that takes the most time inside the step (N > 1: the most FLOPs)
     dom = max(res, key=(lambda k: res[k]["_us"]) if have_run else (lambda k: res[k]["_fl"]))
     r = res[dom]
     ach_iso = r["_fl"] / r["_t"] / 1e12
-    ach = r["_fl"] / (r["_us"] * 1e-6) / 1e12 if have_run else ach_iso
+    ach = r["_fl_in"] / (r["_us"] * 1e-6) / 1e12 if have_run else ach_iso
     out = {"bound": "mfma", "kernel": dom, "symbol": r["symbol"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
            "frac_is": ("in-run: the launch inside the REPLAYED one-step graph, bracketed by device-side 100 MHz stamps on its own "
@@ -966,7 +981,7 @@ def main():
             t4 = torch.tensor([dt4], dtype=torch.float64, device=device)
             dist.all_reduce(t4, op=dist.ReduceOp.MAX)
             dt4 = float(t4.item())
-            f4, x4 = flops_per_step(w4.cfg), executed_flops_per_step(w4.cfg)
+            f4, x4 = flops_per_step(w4.cfg), executed_flops_per_step(w4.cfg, bool(getattr(w4.eng, "ood_rows", False)))
             c4_dp = {"value": round(world * 200 / dt4, 2), "optimizer_steps_per_s": round(200 / dt4, 2),
                      "ms_per_step": round(dt4 / 200 * 1e3, 4), "global_batch": w4.cfg["B"] * world,
                      "parallelism": f"dp{world}", "gflop_per_step_per_gpu": round(f4 / 1e9, 2),
@@ -979,7 +994,7 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        fl, fx = flops_per_step(cfg), executed_flops_per_step(cfg)
+        fl, fx = flops_per_step(cfg), executed_flops_per_step(cfg, bool(getattr(wl.eng, "ood_rows", False)))
         B = cfg["B"]
         out = {
             "metric": "grad-steps/sec", "value": round(world * args.steps / dt, 2),
@@ -1098,7 +1113,7 @@ def other_configs(skip: str, device, steps_per_graph: int = 1):
             w = Workload(name, device, 0, 1, None, n_store=1 << 18, steps_per_graph=steps_per_graph)
             dt = timed_steps(w, steps, warm)
             fl = flops_per_step(w.cfg)
-            fx = executed_flops_per_step(w.cfg)
+            fx = executed_flops_per_step(w.cfg, bool(getattr(w.eng, "ood_rows", False)))
             res[name] = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
                          "gflop_per_step": round(fl / 1e9, 2),
                          "step_frac": round(fl / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4),

@@ -75,6 +75,13 @@ typedef struct {
   int32_t d1, map1, div1;
   const float* src0;
   const float* src1; /* may be NULL when d1 == 0 */
+  /* Optional (both NULL = none): a launch over a row SET chosen on the device -- row r of the virtual input is row
+   * row_list[r] of the matrix described above, and only the first min(rows, *n_rows_dev) rows exist (rows = the list's
+   * capacity: it sizes the grid; workgroups past the count leave at once).  For cpq.py:183-184: of the N*B sampled actions
+   * only those whose KL reaches the batch quantile enter qc_ood -- the target cost critics run on those rows alone.
+   * Honoured by the 80-row inference forward of <= 256-wide nets (osrl_mlp_forward); every other entry point returns -3. */
+  const int32_t* row_list;
+  const int32_t* n_rows_dev;
 } osrl_rows_t;
 
 /* Activations written by forward / read by backward.  h[e][l] = post-activation output of
@@ -420,6 +427,11 @@ int osrl_adam_step_packed(float* p, float* m, float* v, float* tgt, const float*
                           float weight_decay, float tau, const float* gscale, const osrl_step_state_t* st,
                           const int32_t* map_f, const int32_t* map_b, float* pf, float* pb, float* tf,
                           void* stream);
+/* The Polyak step alone: tgt = tau p + (1 - tau) tgt, and tf[map_f[i]] = the new target where map_f[i] >= 0 (map_f / tf may
+ * be NULL) -- the bits osrl_adam_step(_packed) leaves when it carries the step.  For a plan whose last reader of the OLD
+ * targets runs after the group's optimizer step (reference order: every loss of cpq.py:294-313 reads the targets of the
+ * step's start, sync_weight() comes last).  n a multiple of 4. */
+int osrl_polyak(const float* p, float* tgt, int64_t n, float tau, const int32_t* map_f, float* tf, void* stream);
 /* flat[i] = sum_s slabs[s][i]  (pre-reduction before an RCCL all-reduce in the data-parallel path) */
 int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,
                       void* stream);
@@ -521,6 +533,19 @@ int osrl_cpq_ood_mean(const float* qc_sampled, int32_t n_qc_old, const float* kl
  * quant_out[0] = the quantile, out[0] = the OOD mean; same bits as the two calls.  n_samples*rows <= 32768 (-2). */
 int osrl_cpq_ood_stat(const float* qc_sampled, int32_t n_qc_old, const float* kl, float q, int32_t n_samples,
                       int32_t rows, int32_t rows_global, float* quant_out, float* out, void* stream);
+/* cpq.py:183-184 as a ROW SET instead of a mask: qc_ood = ((KL >= quantile) * qc_sampled).mean(0) multiplies three
+ * quarters of the N*B target-cost-critic outputs by zero; with the rows that count known BEFORE those networks run, they
+ * run on that quarter only (osrl_rows_t.row_list / n_rows_dev).
+ *   osrl_cpq_ood_select: quantile = *quantile_in if given, else the q-quantile of kl[0..n) (torch.quantile 'linear',
+ *     n <= 32768: -2 otherwise); list[0..count) = the indices i, ascending, with kl[i] >= quantile; count[0], quant_out[0].
+ *   osrl_cpq_ood_sum: out[0] = scale * sum_{r < min(*count, cap)} min_e qc_sel[e * cap + r]   (scale = 1 / (n_samples *
+ *     rows_global): the mean over the batch of the mean over the samples; fixed summation order).
+ * Equal to osrl_cpq_ood_stat on the full rows up to the order of the sum (and to a non-finite critic output on a row
+ * OUTSIDE the set, which the reference's multiplication by zero would turn into NaN). */
+int osrl_cpq_ood_select(const float* kl, const float* quantile_in, float q, int32_t n, float* quant_out, int32_t* list,
+                        int32_t* count, void* stream);
+int osrl_cpq_ood_sum(const float* qc_sel, int32_t n_qc, int32_t cap, const int32_t* count, float scale, float* out,
+                     void* stream);
 /* CPQ cost-critic loss (cpq.py:161,186-199): backup = c + gamma*min qc_old; dq = 2(qc-backup)/B;
  * log_alpha (device scalar) ascends with the GLOBAL ood_mean (device scalar) and is clamped to +-5;
  * stat[0] = loss, stat[1] = exp(log_alpha) after the update.  stat_share = 1/world_size scales the

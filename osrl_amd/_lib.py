@@ -36,7 +36,8 @@ class MlpT(C.Structure):
 class RowsT(C.Structure):
     _fields_ = [("rows", C.c_int32), ("d0", C.c_int32), ("map0", C.c_int32), ("div0", C.c_int32),
                 ("d1", C.c_int32), ("map1", C.c_int32), ("div1", C.c_int32),
-                ("src0", _fp), ("src1", _fp)]
+                ("src0", _fp), ("src1", _fp),
+                ("row_list", C.c_void_p), ("n_rows_dev", C.c_void_p)]  # (a device-chosen row set: include/osrl_amd.h)
 
 
 class ActsT(C.Structure):
@@ -210,6 +211,7 @@ PROTOTYPES = {
                        _vp, _vp],
     "osrl_adam_step_packed": [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _fp,
                               _vp, _vp, _vp, _fp, _fp, _fp, _vp],
+    "osrl_polyak": [_fp, _fp, _i64, _f32, _vp, _fp, _vp],
     "osrl_reduce_slabs": [_fp, _fp, _i32, _i64, _i64, _vp],
     "osrl_reduce_slabs_counts": [_fp, _fp, _vp, _i64, _i64, _vp],
     "osrl_layernorm_param_reduce": [_fp, _i64, _i32, _i32, _i32, _fp, _vp, _vp, _vp],
@@ -229,6 +231,8 @@ PROTOTYPES = {
     "osrl_cpq_critic_loss": [_fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _i32, _fp, _fp, _vp],
     "osrl_cpq_ood_mean": [_fp, _i32, _fp, _fp, _i32, _i32, _i32, _fp, _vp],
     "osrl_cpq_ood_stat": [_fp, _i32, _fp, _f32, _i32, _i32, _i32, _fp, _fp, _vp],
+    "osrl_cpq_ood_select": [_fp, _fp, _f32, _i32, _fp, _vp, _vp, _vp],
+    "osrl_cpq_ood_sum": [_fp, _i32, _i32, _vp, _f32, _fp, _vp],
     "osrl_cpq_cost_loss": [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _f32, _i32, _f32, _fp, _fp, _fp, _vp],
     "osrl_cpq_alpha_step": [_fp, _f32, _f32, _f32, _fp, _fp, _vp],
     "osrl_cpq_cost_loss_ood": [_fp, _i32, _fp, _fp, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _f32, _f32, _f32, _fp, _fp,

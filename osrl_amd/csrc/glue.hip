@@ -734,6 +734,61 @@ __global__ __launch_bounds__(kRed) void cpq_ood_stat_kernel(const float* __restr
   }
 }
 
+// The OOD rows as a SET (osrl_amd.h osrl_cpq_ood_select / _sum): quantile, then list = ascending indices with kl >= quantile.
+// Every thread owns a contiguous run of <= 32 indices; block-wide exclusive scan of the per-thread counts (wave scans by
+// shuffles, the 16 wave totals through LDS).
+__global__ __launch_bounds__(kRed) void cpq_ood_select_kernel(const float* __restrict__ kl, const float* __restrict__ quantile_in,
+                                                              float q, int n, float* __restrict__ quant_out,
+                                                              int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  __shared__ uint32_t cnt[34];
+  __shared__ uint32_t s_min[17];
+  __shared__ uint32_t s_tot[kRed / 64 + 1];
+  const float quant = quantile_in ? quantile_in[0] : quantile_regs(kl, (int64_t)n, q, cnt, s_min);
+  const int per = (n + kRed - 1) / kRed;  // <= 32 (host-checked)
+  const int i0 = threadIdx.x * per;
+  uint32_t bits = 0;
+  for (int k = 0; k < per; ++k) {
+    const int i = i0 + k;
+    if (i < n && kl[i] >= quant) bits |= 1u << k;
+  }
+  const uint32_t c = __builtin_popcount(bits);
+  uint32_t incl = c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();  // (quantile_regs is done with its scratch; s_tot is ours)
+  if (lane == 63) s_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < kRed / 64; ++w) {
+    const uint32_t t = s_tot[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  uint32_t pos = base + incl - c;
+  for (int k = 0; k < per; ++k)
+    if (bits & (1u << k)) list[pos++] = i0 + k;
+  if (threadIdx.x == 0) {
+    count[0] = (int32_t)total;
+    if (quant_out) quant_out[0] = quant;
+  }
+}
+
+__global__ __launch_bounds__(kRed) void cpq_ood_sum_kernel(const float* __restrict__ qc_sel, int n_qc, int cap,
+                                                           const int32_t* __restrict__ count, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ float sm[20];
+  int n = count[0];
+  n = n < cap ? n : cap;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < n; r += kRed) s += min_over(qc_sel, n_qc, cap, r);
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
 struct OodArgs {  // non-NULL qc_sampled: compute the OOD mean here (single-GPU step: one launch less)
   const float* qc_sampled;
   const float* kl;
@@ -1295,6 +1350,23 @@ int osrl_cpq_ood_stat(const float* qc_sampled, int32_t n_qc_old, const float* kl
   else
     hipLaunchKernelGGL(cpq_ood_stat_kernel<false>, dim3(1), dim3(kRed), 0, S, qc_sampled, n_qc_old, kl, q, n_samples,
                        rows, inv, quant_out, out);
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_ood_select(const float* kl, const float* quantile_in, float q, int32_t n, float* quant_out, int32_t* list,
+                        int32_t* count, void* stream) {
+  if (!kl || !list || !count || n < 1 || q < 0.f || q > 1.f) return -1;
+  if ((int64_t)n > (int64_t)32 * kRed) return -2;  // keys in the workgroup's registers, <= 32 indices per thread
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(cpq_ood_select_kernel, dim3(1), dim3(kRed), 0, S, kl, quantile_in, q, n, quant_out, list, count);
+  LAUNCH_CHECK();
+}
+
+int osrl_cpq_ood_sum(const float* qc_sel, int32_t n_qc, int32_t cap, const int32_t* count, float scale, float* out,
+                     void* stream) {
+  if (!qc_sel || !count || !out || n_qc < 1 || cap < 1) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(cpq_ood_sum_kernel, dim3(1), dim3(kRed), 0, S, qc_sel, n_qc, cap, count, scale, out);
   LAUNCH_CHECK();
 }
 

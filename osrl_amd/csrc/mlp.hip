@@ -1944,9 +1944,11 @@ static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const 
     const int rc = osrl_launch_fwd_nb(net, in, out, (hipStream_t)stream, kl_tail ? tail->out : nullptr, kl_tail ? tail->L : 0);
     if (rc != kNbNotTaken) {  // the 80-row kernel keeps no output tile in LDS: any other tail is its own launch
       if (rc != 0 || !want_tail || kl_tail) return rc;
+      if (in->row_list) return -3;
       return fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
     }
   }
+  if (in->row_list || in->n_rows_dev) return -3;  // a device-chosen row set: only the 80-row inference forward reads it
   if (want_tail && tail->kind == OSRL_TAIL_VAE_KL) {  // tile kernels: the plain forward, then the rows kernel
     const int rc = mlp_forward_impl(net, in, out, nullptr, stream);
     return rc != 0 ? rc : fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
@@ -2018,6 +2020,7 @@ static int mlp_forward2_impl(const osrl_mlp_t* net0, const osrl_rows_t* in0, con
                              const osrl_mlp_tail_t* tail0, const osrl_mlp_t* net1, const osrl_rows_t* in1,
                              const osrl_mlp_acts_t* out1, const osrl_mlp_tail_t* tail1, void* stream) {
   if (!valid_net(net0) || !valid_net(net1) || !in0 || !in1 || !out0 || !out1) return -1;
+  if (in0->row_list || in0->n_rows_dev || in1->row_list || in1->n_rows_dev) return -3;  // (osrl_mlp_forward only)
   if (!fwd_tail_ok(tail0, net0) || !fwd_tail_ok(tail1, net1)) return -1;
   TileChoice t0 = choose_tile(net0, in0->rows, 0), t1 = choose_tile(net1, in1->rows, 0);
   // pair only 16-row-tile launches of equal tile shape; anything else runs as two launches

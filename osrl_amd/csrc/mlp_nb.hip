@@ -404,7 +404,7 @@ __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int 
 // owns 3 column blocks, the 25th is shared by rows over waves 0..4 -- 16 / 15 register tiles per wave instead of 32 / 31,
 // i.e. <= 160 registers per lane instead of 339: the chain's 8-wave workgroups (2 x 96 registers per SIMD) then fit on
 // the CU beside this one, which at one 339-register wave per SIMD they do not; DESIGN.md section 3 "round 4")
-template <int NCB, bool SHARED, int NW, class AR>
+template <int NCB, bool SHARED, int NW, class AR, bool LIST = false>
 __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * kNbRb;
@@ -412,7 +412,13 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int e = blockIdx.y, row0 = blockIdx.x * BM;
-  const int rows = a.in.rows, lda = a.lda, L = a.net.n_layers;
+  int rows = a.in.rows;
+  const int lda = a.lda, L = a.net.n_layers;
+  if constexpr (LIST) {  // a row set chosen on the device (osrl_rows_t.row_list): its size is a device word, the grid is sized
+    const int nd = a.in.n_rows_dev[0];  // for the list's capacity -- workgroups past the count leave before any barrier
+    rows = nd < rows ? nd : rows;
+    if (row0 >= rows) return;
+  }
   WG_LOG(0);
   PHASE_STAMP(0);
   {  // ---- stage cat(src0[map0(r)], src1[map1(r)]) zero padded to a multiple of 16 columns: every load of the tile
@@ -447,7 +453,8 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     for (int p = 0; p < kPasses; ++p) {
       const int gr = row0 + p * kRowsPass + rl;
       const bool rok = gr < rows_v && (BM % kRowsPass == 0 || p * kRowsPass + rl < BM);
-      const unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
+      unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
+      if constexpr (LIST) grc = (unsigned)a.in.row_list[grc];  // (one more dependent load in front of the tile's: this form only)
       const float* p0 = s0 + (size_t)mapped(grc, mod0, idn0, dv0) * d0v;
       const float* p1 = s1 + (size_t)mapped(grc, mod1, idn1, dv1) * d1v - d0v;
 #pragma unroll
@@ -605,13 +612,13 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
 // anyway -- with the one-output head fused in, the allocator took 205 VGPRs + 80 AGPRs where 512 are free, which left the
 // chain kernels of the other graph branch two 96-register waves per SIMD beside it instead of three: C2 2215-2221 vs
 // 2309-2322 steps/s with the cap (205 registers, accumulators in VGPRs), profiles/r6_nb_registers_ab.txt)
-template <int NCB, bool SHARED = false>
+template <int NCB, bool SHARED = false, bool LIST = false>
 __global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel(const NbArgs a) {
-  mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&>(a);
+  mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&, LIST>(a);
 }
-template <int NCB, bool SHARED = false>
+template <int NCB, bool SHARED = false, bool LIST = false>
 __global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel_p(const void* p) {
-  mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
+  mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&, LIST>(*(const OSRL_CAS NbArgs*)p);
 }
 // the 8-wave form (25-block layers): NCB - 1 = 3 column blocks per wave
 #ifndef OSRL_NB8_WPE
@@ -636,18 +643,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_nb8n_kernel_p(const void* p) {
 }
 
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
-template <int NCB, bool SHARED = false>
+template <int NCB, bool SHARED = false, bool LIST = false>
 static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
   const void* dev_args = osrl_argmem::slot(a);
-  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED>)
-                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED>),
+  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED, LIST>)
+                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED, LIST>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   (void)hipGetLastError();
   if (dev_args)
-    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED, LIST>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
   else
-    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED, LIST>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -657,6 +664,7 @@ __attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, 
                                                              float* kl, int kl_L) {
   const int L = net->n_layers, nets = net->n_nets;
   if (net->tile_rows != 80 || L < 2 || out->x || net->dims[0] > 128) return kNbNotTaken;  // (80 = "the big-row inference form")
+  // (a launch with osrl_rows_t.row_list that is not taken here is refused by the caller: mlp.hip mlp_forward_impl)
   for (int e = 0; e < nets; ++e)
     for (int l = 0; l + 1 < L; ++l)
       if (out->h[e][l]) return kNbNotTaken;  // training launches keep hidden activations: mlp_fwd_kernel
@@ -688,6 +696,15 @@ __attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, 
     a.fuse_head = (NL == 1 && ncb == 4 && !kl && !(fh && atoi(fh) == 0)) ? 1 : 0;
   }
   const int tiles = (in->rows + kNbRows - 1) / kNbRows;
+  if (in->row_list || in->n_rows_dev) {  // a device-chosen row set: the 4-wave 80-row form of the <= 256-wide nets only
+#if OSRL_NB_RB == 5
+    if (!in->row_list || !in->n_rows_dev) return -1;
+    if (ncb != 4 || kl) return -3;
+    return launch_nb<4, false, true>(a, tiles, nets, lds_bytes, stream);
+#else
+    return -3;
+#endif
+  }
   bool shared = ncb == 7;  // every wide layer 4*6 + 1 = 25 column blocks (400-wide): the balanced instantiation
   for (int l = 0; l + 1 < L; ++l) shared = shared && ((net->dims[l + 1] + 15) >> 4) == 25;
   // 8 waves for the 25-block layers (OSRL_NB_WAVES=4: the one-wave-per-SIMD form, for A/B runs); the head's 8 partial

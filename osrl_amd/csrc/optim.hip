@@ -200,6 +200,27 @@ __global__ __launch_bounds__(256) void reduce_slabs_counts_kernel(float* __restr
   }
 }
 
+// The Polyak step of a group ALONE (cpq.py:299-303 sync_weight, common/net.py soft update): tgt = tau p + (1 - tau) tgt and
+// the packed forward copy of the targets, with the bits adam_body leaves when it carries the step (same polyak1 on the same
+// fp32 values).  For a plan whose LAST reader of the old targets runs after the group's optimizer step (CPQ's OOD rows).
+__global__ __launch_bounds__(256) void polyak_kernel(const float* __restrict__ p, float* __restrict__ tgt, int64_t n4,
+                                                     float tau, const int32_t* __restrict__ map_f, float* __restrict__ tf) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i];
+    const f32x4 tv0 = reinterpret_cast<const f32x4*>(tgt)[i];
+    f32x4 tv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tv[k] = osrl_adam::polyak1(tau, pv[k], tv0[k]);
+    reinterpret_cast<f32x4*>(tgt)[i] = tv;
+    if (map_f) {
+      const i32x4 mf = reinterpret_cast<const i32x4*>(map_f)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (mf[k] >= 0) tf[mf[k]] = tv[k];
+    }
+  }
+}
+
 inline int stream_grid(int64_t n4) {
   int64_t b = (n4 + 255) / 256;
   return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
@@ -263,6 +284,13 @@ extern "C" int osrl_adam_step_packed(float* p, float* m, float* v, float* tgt, c
   if (!map_f || !pf || (map_b && !pb)) return -1;
   return adam_launch(p, m, v, tgt, slabs, n_splits, slab_stride, n, lr, beta1, beta2, eps, weight_decay, tau, gscale,
                      st, PackMap{map_f, map_b, pf, pb, tf}, stream);
+}
+
+extern "C" int osrl_polyak(const float* p, float* tgt, int64_t n, float tau, const int32_t* map_f, float* tf, void* stream) {
+  if (!p || !tgt || n < 4 || (n & 3) || (map_f && !tf)) return -1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, tgt, n / 4, tau, map_f, tf);
+  return (int)hipGetLastError();
 }
 
 extern "C" int osrl_reduce_slabs(float* flat, const float* slabs, int32_t n_splits, int64_t slab_stride, int64_t n,

@@ -239,6 +239,14 @@ class FlatGroup:
                     "osrl_adam_step")
 
 
+    def polyak_step(self, tau: float) -> None:
+        """The target update alone (after ``adam_step(..., polyak=False)``): same bits as the step carried by Adam."""
+        assert self.tgt is not None
+        L.check(L.load().osrl_polyak(self.p.data_ptr(), self.tgt.data_ptr(), self.n, tau,
+                                     self._map_f.data_ptr() if self.weights else None,
+                                     _ptr(self.tf) if self.weights else None, cur_stream()), "osrl_polyak")
+
+
 def slab_epochs(model) -> Tuple[int, ...]:
     """The slab epochs of a model's optimizer groups, as an engine records them when its plans are built."""
     return tuple(g.slab_epoch for g in model.groups.values())
@@ -411,10 +419,16 @@ class MlpRun:
         return self.y, other.y
 
     def forward(self, src0: torch.Tensor, src1: Optional[torch.Tensor] = None, map0=L.MAP_ID, div0=1,
-                map1=L.MAP_ID, div1=1, tail: Optional["L.TailT"] = None) -> torch.Tensor:
-        """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's output tile (osrl_mlp_forward_tail)."""
+                map1=L.MAP_ID, div1=1, tail: Optional["L.TailT"] = None, row_list: Optional[torch.Tensor] = None,
+                n_rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's output tile (osrl_mlp_forward_tail).
+        ``row_list`` / ``n_rows_dev`` (int32 device tensors): the launch runs on the rows ``row_list[0 .. n_rows_dev[0])``
+        of the virtual input, outputs compacted in that order (osrl_rows_t.row_list; ``self.rows`` = the capacity)."""
         r = L.RowsT()
         r.rows = self.rows
+        if row_list is not None:
+            assert row_list.dtype == torch.int32 and n_rows_dev.dtype == torch.int32 and row_list.numel() >= self.rows
+            r.row_list, r.n_rows_dev = row_list.data_ptr(), n_rows_dev.data_ptr()
         r.d0, r.map0, r.div0 = src0.shape[-1], map0, div0
         r.src0 = src0.data_ptr()
         if src1 is not None:

@@ -55,8 +55,11 @@ class CPQEngine:
         z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
         self.st = StepState(dev, STAT_KEYS)
         nq, nqc = m.num_q, m.num_qc
+        c_hidden = [int(l.out_features) for l in m.cost_critic_old.q_nets[0] if isinstance(l, torch.nn.Linear)][:-1]
         pl = self.plan = P.cpq_plan(od, ad, B, int(m.vae_hidden_sizes), N, seeds=G.SEEDS and G.VAE_TAILS and max(nq, nqc) <= 4
-                                    and G.VAE_NS_AUTO)
+                                    and G.VAE_NS_AUTO, c_hidden=c_hidden)
+        # the OOD rows as a set (plan.ood_rows) is a single-GPU plan: the data-parallel step keeps the masked mean over all rows
+        self.ood_rows = bool(pl.ood_rows) and dist is None
 
         # static inputs (a replayed graph reads these addresses)
         self.obs, self.nobs, self.act = z(B, od), z(B, od), z(B, ad)
@@ -142,6 +145,8 @@ class CPQEngine:
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)
+        self.ood_list = torch.zeros(N * B, dtype=torch.int32, device=dev)  # plan.ood_rows: the rows with KL >= quantile, ascending
+        self.ood_count = torch.zeros(4, dtype=torch.int32, device=dev)
         self.r_cost = MlpRun(self.d_cost, B, True, dev)
         self.dqc = z(nqc, B, 1)
         self.r_cost.setup_backward(self.dqc)
@@ -337,9 +342,11 @@ class CPQEngine:
                 G.gauss_ood_sample(head_obs, nz["eps_ood"], N, B, ad, self.sampled)
                 # the actor-phase sample (cpq.py:209) needs only this forward and its own noise
                 G.gauss_head(head_obs, nz["eps_actor"], B, ad, m.max_action, a=self.a_pi, tanh_u=self.tanh_u)
-            self._pr("costold_ood", 0)
-            qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
-            self._pr("costold_ood", 1)
+            qc_s = None
+            if not self.ood_rows:  # (plan.ood_rows: this forward runs BEHIND the KL quantile, on the rows that pass it)
+                self._pr("costold_ood", 0)
+                qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+                self._pr("costold_ood", 1)
             # critic_loss (cpq.py:137-153)
             self._pr("critic_fwd", 0)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
@@ -372,12 +379,16 @@ class CPQEngine:
         if dual_on_side:  # (lab: the Bellman part of the logged cost loss is complete here)
             ev_cost_stat = torch.cuda.Event()
             ev_cost_stat.record()
-        fuse_cost = dp is None and self.p_cost.can_fuse_adam()
+        fuse_cost = dp is None and self.p_cost.can_fuse_adam() and not self.ood_rows
         if not fuse_cost:
             self.p_cost.launch()
         par.wait(ev_critic)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the side branch
         if fuse_cost:
             self.p_cost.launch_adam(m._lrs["cost_critic"], st.ptr, tau=m.tau)
+        elif self.ood_rows:
+            # the targets' LAST reader of this step -- the forward on the selected OOD rows -- runs at the end of the side
+            # branch: the optimizer step here without its Polyak half, the target update behind that reader (polyak_step)
+            m.groups["cost_critic"].adam_step(m._lrs["cost_critic"], st.ptr, tau=m.tau, polyak=False)
         elif dp is None:
             self._update("cost_critic", m.tau)
         else:  # both critic groups' gradients in ONE collective (neither update reads the other's result)
@@ -409,6 +420,20 @@ class CPQEngine:
                 G.cpq_ood_mean(qc_s, nqc, self.kl, self.quant, N, B, rg, self.ood_mean)
             elif dp is not None:
                 ev_kl = par.mark(0)
+            elif self.ood_rows:
+                # cpq.py:183-184 as a row SET: quantile + ascending list of the rows with KL >= quantile in one
+                # single-workgroup launch, the target cost critics on those rows (a quarter of N*B; the grid is sized for
+                # all of them, workgroups past the count leave at once), their sum.  The cost critics' target update follows
+                # on the MAIN branch behind the join (a main -> side edge this late makes the graph executor serialise the
+                # actor phase behind this branch: 500 vs 428 us per step, profiles/r6_ood_rows_timeline_side_polyak.txt).
+                if nxt is not None and PIPE_PROLOGUE == "early":
+                    nxt.prologue(device_noise)
+                G.cpq_ood_select(self.kl, N * B, 0.75, self.quant, self.ood_list, self.ood_count)
+                self._pr("costold_ood", 0)
+                qc_sel = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, row_list=self.ood_list,
+                                                    n_rows_dev=self.ood_count)
+                self._pr("costold_ood", 1)
+                G.cpq_ood_sum(qc_sel, nqc, N * B, self.ood_count, 1.0 / (float(N) * float(rg if rg > 0 else B)), self.ood_mean)
             elif N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
                 if nxt is not None and PIPE_PROLOGUE == "early":
                     nxt.prologue(device_noise)
@@ -468,6 +493,8 @@ class CPQEngine:
         # dual step + the OOD term of the logged loss (cpq.py:186-195): after the join, so that the side branch has no
         # incoming edge from the main branch after the VAE's Adam (the graph executor keeps two linear chains); under
         # data parallelism the statistics are already the global ones here, so the global term is added once
+        if self.ood_rows:  # the cost critics' target update: behind its last reader (side branch, joined above)
+            m.groups["cost_critic"].polyak_step(m.tau)
         if not dual_on_side:
             G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
         if nxt is not None and PIPE_PROLOGUE == "main":

@@ -195,6 +195,17 @@ def cpq_ood_stat(qc_sampled, n_qc_old, kl, q, n_samples, rows, rows_global, quan
                                        _p(quant_out), _p(out), cur_stream()), "osrl_cpq_ood_stat")
 
 
+def cpq_ood_select(kl, n, q, quant_out, row_list, count, quantile_in=None):
+    """Quantile of kl[0..n) (or ``quantile_in``) and the ascending list of the indices that reach it (cpq.py:183-184)."""
+    L.check(L.load().osrl_cpq_ood_select(_p(kl), None if quantile_in is None else _p(quantile_in), q, n, _p(quant_out),
+                                         row_list.data_ptr(), count.data_ptr(), cur_stream()), "osrl_cpq_ood_select")
+
+
+def cpq_ood_sum(qc_sel, n_qc, cap, count, scale, out):
+    L.check(L.load().osrl_cpq_ood_sum(_p(qc_sel), n_qc, cap, count.data_ptr(), scale, _p(out), cur_stream()),
+            "osrl_cpq_ood_sum")
+
+
 def cpq_cost_loss(qc_old_next, n_qc_old, qc, n_qc, ood_mean, cost, rows, gamma, qc_thres, alpha_lr, rows_global,
                   stat_share, log_alpha, dq, stat):
     L.check(L.load().osrl_cpq_cost_loss(_p(qc_old_next), n_qc_old, _p(qc), n_qc, _p(ood_mean), _p(cost), rows, gamma,

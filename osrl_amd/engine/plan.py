@@ -69,9 +69,18 @@ class CPQPlan:
     vae_ns: bool              # the VAE phase as all-CU layer launches (csrc/vae_ns.hip)
     vae_adam_side: bool       # single GPU: the VAE's optimizer step at the head of the side branch's second half
     steps_per_graph: int      # engine.steps_replay(): train steps per replayed hipGraph (engine/pipeline.py); 1 = one step
+    ood_rows: bool = False    # single GPU: the target cost critics of the OOD penalty on the SELECTED rows only (cpq.py:183-184)
 
 
-def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True) -> CPQPlan:
+def ood_rows_ok(od: int, ad: int, B: int, N: int, c_hidden) -> bool:
+    """Shapes on which the row-set form of the N*B-row target-cost-critic launch exists (csrc/mlp_nb.hip, LIST
+    instantiation of the 4-wave 80-row kernel): every hidden layer 13..16 column blocks wide, input <= 128 columns, the
+    KL keys in one workgroup's registers."""
+    return (c_hidden is not None and len(c_hidden) >= 1 and all(13 <= (int(h) + 15) // 16 <= 16 for h in c_hidden)
+            and od + ad <= 128 and N * B <= 32768)
+
+
+def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = True, c_hidden=(256, 256)) -> CPQPlan:
     head_tails = {"1": True, "0": False}.get(knob("OSRL_HEAD_TAILS", "auto", "action draws as forward tails: 1 / 0 / auto"),
                                              N * ad <= 32)
     t5 = knob("OSRL_VAE_DW_T5", "1", "VAE dW on 80 x 80 tiles where the width allows") == "1" and vae_hidden % 80 == 0 and B >= 1024
@@ -93,9 +102,18 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     # C4 within +-1 % of one step per graph -- its side branch is the longer one (separate action-draw launches) and gets the
     # extra prologue: on where the draws ride on the actor launch
     spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or (5 if (head_tails and B >= 1024) else 1)
+    ood_tile = int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)"))
+    # qc_ood = ((KL >= quantile(KL, 0.75)) * qc_sampled).mean(0) (cpq.py:183-184) multiplies three quarters of the N*B target
+    # cost-critic outputs by zero: with the encoder launch, the quantile and a compaction in FRONT of that forward it runs on
+    # the selected quarter only -- 5.3 of C2's 29.6 issued GFLOP per step gone.  Built, parity-tested (same network
+    # parameters bit for bit) and measured at the end of round 6: C2 +0.3 %, C4 +1.3 % (profiles/r6_ood_rows_ab.txt) -- 18 % of
+    # the FLOPs buy one per cent because the step is not FLOP-bound; the forward moves from the idle
+    # early part of the side branch to its tail, behind a 30-50 us single-workgroup select.  Off unless asked for.
+    ood_rows = knob("OSRL_OOD_ROWS", "0", "target cost critics on the selected OOD rows only (single GPU): 1 / 0") == "1" \
+        and ood_tile == 80 and ood_rows_ok(od, ad, B, N, c_hidden)
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
-                   ood_tile=int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)")),
-                   vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg)
+                   ood_tile=ood_tile, vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg,
+                   ood_rows=bool(ood_rows))
 
 
 def vae_ns_auto(rows: int, od: int, ad: int, vae_hidden: int = 400) -> bool:
@@ -146,15 +164,15 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True,
-                   steps_per_graph=5)),
+                   steps_per_graph=5, ood_rows=False)),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
-                   steps_per_graph=1)),
+                   steps_per_graph=1, ood_rows=False)),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
            BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6, steps_per_graph=10)),
-    "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4),
+    "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4, c_hidden=(32, 32)),
                   CPQPlan(head_tails=True, vae_dw_tile=0, vae_dw_splits=1, small_dw=False, ood_tile=80, vae_ns=False, vae_adam_side=False,
-                           steps_per_graph=1)),
+                           steps_per_graph=1, ood_rows=False)),
 }
 
 

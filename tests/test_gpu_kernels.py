@@ -630,6 +630,148 @@ def test_cpq_ood_stat_equals_quantile_then_mean(N, B, nqc):
     assert abs(m1[0].item() - ref) <= 1e-5 * max(1.0, abs(ref))
 
 
+@pytest.mark.parametrize("n,ties", [(7, False), (1000, True), (20480, False), (20480, True), (32768, False)])
+def test_cpq_ood_select_lists_the_rows_that_reach_the_quantile(n, ties):
+    """osrl_cpq_ood_select (cpq.py:183-184 as a row set): the quantile has the bits of osrl_quantile / torch.quantile, the
+    list is exactly the ascending indices with kl >= quantile (ties at the quantile included), the count is their number;
+    with a given quantile the same list.  osrl_cpq_ood_sum over compacted values == the masked mean of the full rows."""
+    from osrl_amd.engine import glue as G
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(n + int(ties))
+    kl = 0.3 + 0.01 * torch.rand(n, generator=g)
+    if ties:  # a quarter of the values equal: the quantile lands on a run of equal keys
+        kl[torch.randperm(n, generator=g)[: n // 2]] = 0.3095
+    kl = kl.to(dev)
+    q0, q1 = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+    lst, cnt = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    G.quantile(kl, n, 0.75, q0)
+    G.cpq_ood_select(kl, n, 0.75, q1, lst, cnt)
+    torch.cuda.synchronize()
+    assert q0[0].item() == q1[0].item() == torch.quantile(kl, 0.75).item()
+    want = torch.nonzero(kl >= q1[0]).flatten().to(torch.int32)
+    c = int(cnt[0].item())
+    assert c == want.numel() and c >= n - int(0.75 * (n - 1)) - 1
+    assert torch.equal(lst[:c], want) and bool((lst[c:] == -1).all())
+    lst2, cnt2 = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    G.cpq_ood_select(kl, n, 0.75, None, lst2, cnt2, quantile_in=q0)
+    assert torch.equal(lst2, lst) and int(cnt2[0].item()) == c
+    # the sum over the compacted outputs against the masked mean over all rows (N = 1: n rows of one sample)
+    nqc = 2
+    qc = torch.randn(nqc, n, generator=g).to(dev)
+    sel = torch.zeros(nqc, n, device=dev)
+    sel[:, :c] = qc[:, want.long()]
+    out, ref = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+    G.cpq_ood_sum(sel, nqc, n, cnt, 1.0 / n, out)
+    G.cpq_ood_mean(qc, nqc, kl, q0, 1, n, n, ref)
+    torch.cuda.synchronize()
+    assert abs(out[0].item() - ref[0].item()) <= 2e-6 * max(1.0, abs(ref[0].item()))
+
+
+@pytest.mark.parametrize("E,dims,acts,rows,div0,k", [
+    (2, [78, 256, 256, 1], ["relu", "relu", "id"], 20480, 2048, 5120),   # C2's target cost critics on a quarter of the rows
+    (2, [23, 256, 256, 1], ["relu", "relu", "id"], 20480, 2048, 5133),   # C4's width, a ragged count
+    (1, [41, 208, 250, 1], ["tanh", "relu", "id"], 2560, 256, 1),        # one row
+    (2, [78, 256, 256, 1], ["relu", "relu", "id"], 2560, 256, 0),        # an empty set: nothing is written
+    (3, [40, 256, 1], ["relu", "id"], 4000, 400, 4000),                  # every row, permuted
+])
+def test_forward_on_a_device_chosen_row_set(E, dims, acts, rows, div0, k):
+    """osrl_rows_t.row_list / n_rows_dev: the 80-row inference forward on the rows list[0 .. *count) of the virtual input
+    [src0[r % div0] | src1[r]] writes, compacted in list order, the BITS the launch over all rows writes at those rows;
+    outputs past the count are not touched; the grid is sized for the capacity and the count is read on the device.
+    Entry points that cannot honour a list refuse it (-3)."""
+    import ctypes as C
+    from osrl_amd import _lib as L
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc, cur_stream
+    dev = _dev()
+    rs = np.random.RandomState(7 + k)
+    grp = FlatGroup("t", dev)
+    for e in range(E):
+        for l in range(len(dims) - 1):
+            grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{e}.{l}.w")
+            grp.add(f"{e}.{l}.b", (dims[l + 1],))
+    grp.finalize()
+    refs = []
+    for e in range(E):
+        rr = []
+        for l in range(len(dims) - 1):
+            kk = 1 / math.sqrt(dims[l])
+            W, b = grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")
+            W.copy_(torch.tensor(rs.uniform(-kk, kk, W.shape), dtype=torch.float32))
+            b.copy_(torch.tensor(rs.uniform(-kk, kk, b.shape), dtype=torch.float32))
+            rr.append(LayerRef(W, b, grp, f"{e}.{l}.w", f"{e}.{l}.b"))
+        refs.append(rr)
+    grp.repack()
+    d0 = dims[0] - 2
+    src0 = torch.tensor(rs.randn(div0, d0), dtype=torch.float32, device=dev)
+    src1 = torch.tensor(rs.randn(rows, 2), dtype=torch.float32, device=dev)
+    desc = NetDesc(refs, acts, 1.0)
+    desc.c.tile_rows = 80
+    full = MlpRun(desc, rows, False, dev)
+    y_full = full.forward(src0, src1, map0=L.MAP_MOD, div0=div0).clone()
+    perm = torch.tensor(rs.permutation(rows)[:k] if k < rows else rs.permutation(rows), dtype=torch.int32, device=dev)
+    lst = torch.zeros(rows, dtype=torch.int32, device=dev)
+    lst[:k] = perm if k == rows else torch.sort(perm).values
+    cnt = torch.tensor([k, 0, 0, 0], dtype=torch.int32, device=dev)
+    sel = MlpRun(desc, rows, False, dev)
+    sel.y.fill_(-77.0)
+    y_sel = sel.forward(src0, src1, map0=L.MAP_MOD, div0=div0, row_list=lst, n_rows_dev=cnt)
+    torch.cuda.synchronize()
+    # (not bit for bit: a workgroup starts its weight stream at a position that depends on its tile index, so a row's k
+    # order depends on the TILE it sits in -- 1.3e-7 at |y| <= 1; the identity list below is bit-equal)
+    want = y_full[:, lst[:k].long()]
+    if k:
+        assert (y_sel[:, :k] - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    assert bool((y_sel[:, k:] == -77.0).all()), "rows past the count must not be written"
+    y_again = sel.forward(src0, src1, map0=L.MAP_MOD, div0=div0, row_list=lst, n_rows_dev=cnt).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(y_again, y_sel), "the same list must give the same bits"
+    # a count above the capacity is clamped to it
+    cnt[0] = rows + 1000
+    lst2 = torch.arange(rows, dtype=torch.int32, device=dev)
+    y2 = sel.forward(src0, src1, map0=L.MAP_MOD, div0=div0, row_list=lst2, n_rows_dev=cnt)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y_full)
+    # refused where no kernel reads the list: 16-row tiles (training form), the paired forward
+    small = NetDesc(refs, acts, 1.0)
+    small.c.tile_rows = 16
+    r16 = MlpRun(small, rows, False, dev)
+    with pytest.raises(RuntimeError):
+        r16.forward(src0, src1, map0=L.MAP_MOD, div0=div0, row_list=lst2, n_rows_dev=cnt)
+
+
+def test_polyak_step_alone_equals_the_step_carried_by_adam():
+    """osrl_polyak after osrl_adam_step_packed(tgt = NULL) leaves the bits of the one-launch Adam + Polyak: flat targets
+    and their packed forward copy (the plan that moves the target update behind its last reader, engine/cpq.py)."""
+    from osrl_amd.engine.core import FlatGroup, StepState
+    dev = _dev()
+    outs = []
+    for split in (False, True):
+        rs = np.random.RandomState(5)
+        grp = FlatGroup("g", dev, with_target=True)
+        grp.add("a.w", (256, 78)); grp.mark_weight("a.w"); grp.add("a.b", (256,))
+        grp.add("b.w", (1, 256)); grp.mark_weight("b.w"); grp.add("b.b", (1,))
+        grp.finalize()
+        grp.p.copy_(torch.tensor(rs.randn(grp.n), dtype=torch.float32))
+        grp.tgt.copy_(torch.tensor(rs.randn(grp.n), dtype=torch.float32))
+        grp.repack()
+        grp.ensure_slabs(2)
+        grp.cur_splits = 2
+        st = StepState(dev, ["x"])
+        for _ in range(3):
+            grp.slabs.copy_(torch.tensor(rs.randn(2, grp.n), dtype=torch.float32))
+            st.tick()
+            if split:
+                grp.adam_step(1e-2, st.ptr, tau=0.005, polyak=False)
+                grp.polyak_step(0.005)
+            else:
+                grp.adam_step(1e-2, st.ptr, tau=0.005)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (grp.p, grp.m, grp.v, grp.tgt, grp.pf, grp.pb, grp.tf)])
+    for name, a, b in zip(("p", "m", "v", "tgt", "pf", "pb", "tf"), *outs):
+        assert torch.equal(a, b), name
+
+
 def test_randn_and_gather():
     from osrl_amd import _lib as L
     from osrl_amd.engine.core import StepState, cur_stream, randn_fill
