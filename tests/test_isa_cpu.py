@@ -71,7 +71,8 @@ def test_adam_requests_every_operand_up_front(listings):
 
 def test_nb_forward_kernel_shape(listings):
     """mlp_fwd_nb_kernel: no scratch, one wave's registers within the file, float4 epilogue stores."""
-    for inst in ("ILi7ELb1E", "ILi4ELb0E", "ILi7ELb0E"):
+    # (third template argument, round 6: the LIST instantiation that reads a device-chosen row set -- <4, false, true>)
+    for inst in ("ILi7ELb1ELb0E", "ILi4ELb0ELb0E", "ILi7ELb0ELb0E", "ILi4ELb0ELb1E"):
         shapes = []
         # by-value kernel and its device-resident-descriptor twin (csrc/argmem.h): the same body behind one extra
         # scalar load -- same registers, same stores
