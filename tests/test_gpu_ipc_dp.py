@@ -298,3 +298,61 @@ def test_processes_on_one_gpu_other_engines(algo):
             assert np.allclose(res[r]["log"][k], [float(x) for x in vals], rtol=1e-4, atol=1e-5), (algo, r, k)
     for k, v in res[0]["params"].items():
         assert torch.equal(v, res[1]["params"][k]), f"{algo}: the replicas differ in {k}"
+
+
+def _worker_missing_peer(rank, W, port, out_dir):
+    """Rank 1 skips the second exchange: rank 0's launch must give up after its bounded poll, leave the destination
+    unreduced, and ``check()`` must name the missing rank."""
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        from osrl_amd.engine.dist_ipc import IpcDataParallel
+        dp = IpcDataParallel(half_floats=1 << 12)
+        t = torch.full((1000,), float(rank + 1), device=DEV)
+        dp.all_reduce_(t)
+        torch.cuda.synchronize()
+        dp.check()
+        res = {"first": t.clone().cpu(), "raised": None, "seconds": None, "second": None, "status": None}
+        if rank == 0:
+            u = torch.full((1000,), 5.0, device=DEV)
+            t0 = time.time()
+            dp.all_reduce_(u)  # nobody answers
+            torch.cuda.synchronize()
+            res["seconds"] = time.time() - t0
+            res["second"] = u.clone().cpu()
+            res["status"] = dp.status()
+            try:
+                dp.check()
+            except RuntimeError as e:
+                res["raised"] = str(e)
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.barrier()  # (rank 1 stays alive -- its buffers mapped -- until rank 0's launch has given up)
+        dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_missing_peer_does_not_hang_the_device():
+    """The exchange's poll is bounded (csrc/ipc.hip kSpinMax): a rank whose peer never publishes gets its launch back
+    after a few seconds with the error word set, the destination left at its local values, and ``check()`` raising with
+    the peer's rank -- a dead rank costs a checkpoint restore, not a wedged GPU."""
+    import time
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.spawn(_worker_missing_peer, args=(2, _free_port(), d), nprocs=2, join=False)
+        deadline = time.time() + 300
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                for p in ctx.processes:
+                    p.kill()
+                pytest.fail("the ranks did not finish within 300 s: the bounded poll did not give up")
+        r0 = torch.load(os.path.join(d, "rank0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(d, "rank1.pt"), weights_only=False)
+    assert bool((r0["first"] == 3.0).all()) and bool((r1["first"] == 3.0).all())
+    assert r0["status"]["error"] == 2, r0["status"]            # 1 + the rank that never arrived
+    assert bool((r0["second"] == 5.0).all()), "an exchange that gave up must leave the destination unreduced"
+    assert r0["raised"] is not None and "rank 1" in r0["raised"], r0["raised"]
+    assert r0["seconds"] < 120, r0["seconds"]
