@@ -34,8 +34,9 @@ from .core import ArgArena, Branches, DwPlan, MlpRun, StepState, concat_nets, lo
 # than the two 17 us collectives they take off the main chain.  Default "0" = round 4's placement (all four on the main
 # branch).
 DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather issued off the main branch") == "1"
-PIPE_PROLOGUE = P.knob("OSRL_PIPE_PROLOGUE", "early", "pipelined steps: the next step's prologue behind the OOD statistic (side) / in front of it (early) / on the main chain (main)")
-PIPE_DUAL = P.knob("OSRL_PIPE_DUAL", "main", "pipelined steps: the dual step behind the join (main) / on the side branch behind the OOD statistic (side)")
+# (pipelined graphs: where the next prologue sits and whether the steps of a graph are joined are plan fields --
+# engine/plan.py pipe_prologue / pipe_no_join; the lab switch OSRL_PIPE_DUAL=side keeps round 6's side-branch dual step)
+PIPE_DUAL_SIDE = P.knob("OSRL_PIPE_DUAL", "auto") == "side"
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -54,6 +55,9 @@ class CPQEngine:
         f = dict(dtype=torch.float32, device=dev)
         z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
         self.st = StepState(dev, STAT_KEYS)
+        self._prologue_covered = False
+        self._ev_prologue = None    # (pipelined graphs, plan.pipe_no_join: event behind the next step's prologue)
+        self._dual_pending = False  # (this step's dual step is still to be issued by the next step of the graph)
         nq, nqc = m.num_q, m.num_qc
         c_hidden = [int(l.out_features) for l in m.cost_critic_old.q_nets[0] if isinstance(l, torch.nn.Linear)][:-1]
         pl = self.plan = P.cpq_plan(od, ad, B, int(m.vae_hidden_sizes), N, seeds=G.SEEDS and G.VAE_TAILS and max(nq, nqc) <= 4
@@ -239,7 +243,7 @@ class CPQEngine:
                          self.seed, device_noise)
 
     def body(self, device_noise: bool, par: Optional[Branches] = None, nxt: Optional["CPQEngine"] = None,
-             prologue_done: bool = False) -> None:
+             prologue_done: bool = False, prev: Optional["CPQEngine"] = None) -> None:
         """One step, single GPU or data parallel (``self.dist``): the launch plan below.
 
         ``nxt`` / ``prologue_done`` (engine/pipeline.py, several steps per graph): the NEXT step's prologue -- into the
@@ -272,6 +276,15 @@ class CPQEngine:
         assert nxt is None or dp is None, "pipelined steps are a single-GPU plan"
         if not prologue_done:
             self.prologue(device_noise)
+        # plan.pipe_no_join (pipelined graphs): the steps of a graph are not joined.  The main chain of step k+1 waits for
+        # its prologue only (issued on step k's side branch: ``_ev_prologue``), and step k's dual step runs at the head of
+        # step k+1's side branch, right behind the fork -- the one place of the side branch that already has an edge from
+        # the END of step k's main chain (so both halves of the logged cost loss are there) without a new mid-chain edge.
+        no_join = self.plan.pipe_no_join and par.enabled and dp is None and not self.ood_rows
+        carried = prev if (no_join and prev is not None and prev._dual_pending) else None
+        self._ev_prologue, self._prologue_covered = None, False
+        if carried is not None and carried._ev_prologue is not None:
+            par.wait(carried._ev_prologue)
         par.fork(0)
         # ---- main: vae_loss  (cpq.py:125-135)
         sd = self.seeds
@@ -321,6 +334,11 @@ class CPQEngine:
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
+            if carried is not None:
+                # (created HERE, behind the main chain's VAE launches: the graph executor keeps the FIRST-created successor
+                # of a node on that node's queue -- issued right at the fork, the dual step was the first successor of the
+                # previous step's last Adam and the two chains swapped queues at every boundary: 2155 vs 2320 steps/s)
+                carried.dual_step()
             if self.plan.head_tails:
                 # every action draw of the step (cpq.py:141 a_next, :159 a_next2, :164-176 the N OOD draws, :209 the
                 # actor-phase sample) by the actor trunks' own forward launch, from its LDS-resident head tiles: four
@@ -347,6 +365,11 @@ class CPQEngine:
                 self._pr("costold_ood", 0)
                 qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
                 self._pr("costold_ood", 1)
+            if nxt is not None and self.plan.pipe_prologue == "critic":
+                # the next step's prologue HERE: the main chain waits for this branch's critic Adam below (ev_critic), so
+                # the next step's first launch needs no edge of its own from this branch
+                nxt.prologue(device_noise)
+                self._prologue_covered = True
             # critic_loss (cpq.py:137-153)
             self._pr("critic_fwd", 0)
             y_old, q = self.r_old_next.forward_with((self.nobs, self.a_next), self.r_critic, (self.obs, self.act))
@@ -374,7 +397,7 @@ class CPQEngine:
             G.cpq_cost_loss(qc_old_next, nqc, qc, nqc, None, self.cost, B, m.gamma, m.qc_thres, m.alpha_lr, rg, 1.0,
                             None, self.dqc, st.stat_ptr("loss/cost_critic_loss"))
             self.r_cost.backward_dz()
-        dual_on_side = nxt is not None and PIPE_DUAL == "side" and par.enabled
+        dual_on_side = nxt is not None and PIPE_DUAL_SIDE and par.enabled and not no_join
         ev_cost_stat = None
         if dual_on_side:  # (lab: the Bellman part of the logged cost loss is complete here)
             ev_cost_stat = torch.cuda.Event()
@@ -426,7 +449,7 @@ class CPQEngine:
                 # all of them, workgroups past the count leave at once), their sum.  The cost critics' target update follows
                 # on the MAIN branch behind the join (a main -> side edge this late makes the graph executor serialise the
                 # actor phase behind this branch: 500 vs 428 us per step, profiles/r6_ood_rows_timeline_side_polyak.txt).
-                if nxt is not None and PIPE_PROLOGUE == "early":
+                if nxt is not None and self.plan.pipe_prologue == "early":
                     nxt.prologue(device_noise)
                 G.cpq_ood_select(self.kl, N * B, 0.75, self.quant, self.ood_list, self.ood_count)
                 self._pr("costold_ood", 0)
@@ -435,8 +458,9 @@ class CPQEngine:
                 self._pr("costold_ood", 1)
                 G.cpq_ood_sum(qc_sel, nqc, N * B, self.ood_count, 1.0 / (float(N) * float(rg if rg > 0 else B)), self.ood_mean)
             elif N * B <= 32768:  # quantile + masked mean in one single-workgroup launch (keys in registers)
-                if nxt is not None and PIPE_PROLOGUE == "early":
+                if nxt is not None and self.plan.pipe_prologue == "early":
                     nxt.prologue(device_noise)
+                    self._ev_prologue = par.mark(0)
                 G.cpq_ood_stat(qc_s, nqc, self.kl, 0.75, N, B, rg, self.quant, self.ood_mean)
             else:
                 G.quantile(self.kl, N * B, 0.75, self.quant)
@@ -444,7 +468,7 @@ class CPQEngine:
             if dual_on_side:
                 par.side[0].wait_event(ev_cost_stat)
                 G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
-            if nxt is not None and PIPE_PROLOGUE == "side":
+            if nxt is not None and self.plan.pipe_prologue == "side":
                 nxt.prologue(device_noise)  # (pipelined: the next step's minibatch + noise + tick, off the main chain)
 
         # ---- main: actor_loss  (cpq.py:203-222): needs the updated critic (side branch: this stream waited for
@@ -483,6 +507,9 @@ class CPQEngine:
             self.r_actor_obs.backward_dz()
         if dp is None:
             self._optim("actor", self.p_actor, m.tau)
+            if no_join and nxt is not None and (self._ev_prologue is not None or self._prologue_covered):
+                self._dual_pending = True  # (the next step of this graph runs it: dual_step())
+                return
             par.join(0)
         else:  # actor gradient, the per-rank partial statistics and the partial qc_ood mean in one collective
             self.p_actor.launch()
@@ -496,9 +523,15 @@ class CPQEngine:
         if self.ood_rows:  # the cost critics' target update: behind its last reader (side branch, joined above)
             m.groups["cost_critic"].polyak_step(m.tau)
         if not dual_on_side:
-            G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, st.stat_ptr("loss/cost_critic_loss"))
-        if nxt is not None and PIPE_PROLOGUE == "main":
+            self.dual_step()
+        if nxt is not None and self.plan.pipe_prologue == "main":
             nxt.prologue(device_noise)  # (lab: the pipelined graph with the next prologue on the main chain, as a control)
+
+    def dual_step(self) -> None:
+        """log_alpha's ascent + the OOD term of this step's logged cost loss (cpq.py:186-195), on the current stream."""
+        m = self.model
+        G.cpq_alpha_step(self.ood_mean, m.qc_thres, m.alpha_lr, 1.0, m.log_alpha, self.st.stat_ptr("loss/cost_critic_loss"))
+        self._dual_pending = False
 
     # ------------------------------------------------------------------ #
     def load_batch(self, observations, next_observations, actions, rewards, costs, done) -> None:

@@ -67,7 +67,7 @@ class PipelinedSteps:
             if hasattr(e, "head"):
                 e.body(True, par, nxt=x, head_done=k > 0)
             else:
-                e.body(True, par, nxt=x, prologue_done=k > 0)
+                e.body(True, par, nxt=x, prologue_done=k > 0, prev=E[(k - 1) % 2] if k > 0 else None)
 
     def _snapshot(self):
         e0, e1 = self.e

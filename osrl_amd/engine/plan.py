@@ -70,6 +70,10 @@ class CPQPlan:
     vae_adam_side: bool       # single GPU: the VAE's optimizer step at the head of the side branch's second half
     steps_per_graph: int      # engine.steps_replay(): train steps per replayed hipGraph (engine/pipeline.py); 1 = one step
     ood_rows: bool = False    # single GPU: the target cost critics of the OOD penalty on the SELECTED rows only (cpq.py:183-184)
+    pipe_no_join: bool = False   # pipelined graphs: no join between the steps of a graph (the dual step of step k at the head
+    #                              of step k+1's side branch)
+    pipe_prologue: str = "early"  # pipelined graphs: where step k+1's prologue sits on step k's side branch: in front of the
+    #                              OOD statistic ("early") / in front of the critic phase ("critic": covered by ev_critic)
 
 
 def ood_rows_ok(od: int, ad: int, B: int, N: int, c_hidden) -> bool:
@@ -101,7 +105,23 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     # five alternating rounds: 2293 (1) / 2308 (2) / 2317 (4) / 2329 (5) / 2328 (10) (profiles/r6_k20_steps_per_graph.txt) -> 5.
     # C4 within +-1 % of one step per graph -- its side branch is the longer one (separate action-draw launches) and gets the
     # extra prologue: on where the draws ride on the actor launch
-    spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or (5 if (head_tails and B >= 1024) else 1)
+    # Second session of round 6 (gpurun_out/r6nj3, un-profiled, two alternating rounds): graphs whose steps are NOT joined -- step
+    # k's dual step at the head of step k+1's side branch, the next prologue in front of the critic phase so that the main
+    # chain's wait for the critic's Adam covers it -- C4 2411-2416 at 4 steps per graph against 2330-2360 joined and 2361-2368 at
+    # one step per graph (+2 %): there the side branch is the longer one and the main chain no longer waits for it at every
+    # boundary.  C2 LOSES with every such form (2230-2283 vs 2318-2325: both chains are tight at the critic's Adam, 14 us of
+    # prologue in front of it delay the main chain) although its kernel timeline under rocprofv3 is 5 us per step SHORTER
+    # (427 vs 435 us: the profiler's queue interception changes what a cross-queue wait costs) -- un-profiled clocks decide.
+    side_long = not head_tails and B >= 1024
+    spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or \
+        (5 if (head_tails and B >= 1024) else 4 if side_long else 1)
+    dual = knob("OSRL_PIPE_DUAL", "auto", "pipelined steps: the dual step behind the join (main) / on the side branch behind the "
+                "OOD statistic (side) / at the head of the NEXT step's side branch, no join between the steps of a graph (next)")
+    pro = knob("OSRL_PIPE_PROLOGUE", "auto", "pipelined steps: the next step's prologue behind the OOD statistic (side) / in "
+               "front of it (early) / on the main chain (main) / on the side branch in front of the critic phase (critic: the "
+               "main chain's wait for the critic's Adam then covers it)")
+    no_join = side_long if dual == "auto" else dual == "next"
+    pro = ("critic" if side_long else "early") if pro == "auto" else pro
     ood_tile = int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)"))
     # qc_ood = ((KL >= quantile(KL, 0.75)) * qc_sampled).mean(0) (cpq.py:183-184) multiplies three quarters of the N*B target
     # cost-critic outputs by zero: with the encoder launch, the quantile and a compaction in FRONT of that forward it runs on
@@ -113,7 +133,7 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
         and ood_tile == 80 and ood_rows_ok(od, ad, B, N, c_hidden)
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=ood_tile, vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg,
-                   ood_rows=bool(ood_rows))
+                   ood_rows=bool(ood_rows), pipe_no_join=bool(no_join), pipe_prologue=pro)
 
 
 def vae_ns_auto(rows: int, od: int, ad: int, vae_hidden: int = 400) -> bool:
@@ -167,7 +187,7 @@ PINNED = {
                    steps_per_graph=5, ood_rows=False)),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
-                   steps_per_graph=1, ood_rows=False)),
+                   steps_per_graph=4, ood_rows=False, pipe_no_join=True, pipe_prologue="critic")),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
            BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6, steps_per_graph=10)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4, c_hidden=(32, 32)),

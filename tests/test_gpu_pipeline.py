@@ -101,19 +101,64 @@ def test_pipelined_steps_equal_one_step_graph_replays(name, spg, total):
     assert all(np.isfinite(v) for v in e_b.st.read_stats().values())
 
 
+@pytest.mark.parametrize("prologue", ["early", "critic"])
+@pytest.mark.parametrize("name,spg,total", [("cpq_small", 2, 6), ("cpq_small", 4, 9), ("cpq_odd", 3, 7), ("cpq_wide", 2, 4),
+                                             ("c2", 4, 8), ("c4", 4, 8)])
+def test_unjoined_pipelined_steps_equal_one_step_graph_replays(name, spg, total, prologue, monkeypatch):
+    """The no-join form of a pipelined CPQ graph (plan.pipe_no_join; C4's pinned plan; forced here on every case through the
+    lab switches): the steps of a graph are not joined, step k's dual step (cpq.py:186-195) is issued at the head of step
+    k+1's side branch, and the next prologue sits either in front of the OOD statistic (an event of its own for the main
+    chain) or in front of the critic phase (covered by the wait for the critic's Adam).  Same contract as above: parameters,
+    moments, targets, ``log_alpha``, EVERY step's statistics (the cost loss's OOD term is added one step later on another
+    queue) and the step count are bit-equal to replays of the one-step graph."""
+    from osrl_amd.engine.pipeline import PipelinedSteps
+    build = _bench if name in ("c2", "c4") else _small
+    m_a, e_a = build(name)
+    for _ in range(total):
+        e_a.step_replay(True)
+    torch.cuda.synchronize()
+    ref = _state(m_a, e_a)
+    ref_stats = [e_a.st.read_stats(s) for s in range(1, total + 1)]
+    del m_a, e_a
+    torch.cuda.empty_cache()
+
+    monkeypatch.setenv("OSRL_LAB", "1")
+    monkeypatch.setenv("OSRL_PIPE_DUAL", "next")
+    monkeypatch.setenv("OSRL_PIPE_PROLOGUE", prologue)
+    m_b, e_b = build(name)
+    assert e_b.plan.pipe_no_join and e_b.plan.pipe_prologue == prologue
+    e_b.steps_replay(total, steps_per_graph=spg)
+    torch.cuda.synchronize()
+    pipe = e_b._pipe
+    assert isinstance(pipe, PipelinedSteps) and pipe.n == spg and pipe.e[1].plan == e_b.plan
+    assert not pipe.e[0]._dual_pending and not pipe.e[1]._dual_pending, "a graph's last step runs its own dual step"
+    assert e_b.st.device_step() == total
+    got = _state(m_b, e_b)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), f"{name} spg={spg} no-join/{prologue}: {k} differs after {total} steps " \
+                                             f"(max |d| = {(ref[k] - got[k]).abs().max().item():.3e})"
+    for s in range(1, total + 1):
+        st = e_b.st.read_stats(s)
+        for k, v in ref_stats[s - 1].items():
+            assert st[k] == v or (np.isnan(st[k]) and np.isnan(v)), f"{name} no-join/{prologue}: statistic {k} of step {s}: {st[k]} vs {v}"
+    many = e_b.st.read_stats_many(range(1, total + 1))
+    for s in range(1, total + 1):
+        assert many[s] == [ref_stats[s - 1][k] for k in e_b.st.keys], f"read_stats_many, step {s}"
+
+
 def test_steps_replay_follows_the_plan():
-    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 5 at C2's shape, 1 at C4's) and leaves
-    the engine n steps further either way."""
+    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 5 at C2's shape, 4 -- not joined -- at
+    C4's) and leaves the engine n steps further either way."""
     m, e = _bench("c2")
-    assert e.plan.steps_per_graph == 5
+    assert e.plan.steps_per_graph == 5 and not e.plan.pipe_no_join
     e.steps_replay(9)
     torch.cuda.synchronize()
     assert e._pipe is not None and e._pipe.n == 5 and e.st.device_step() == 9
     m4, e4 = _bench("c4")
-    assert e4.plan.steps_per_graph == 1
-    e4.steps_replay(3)
+    assert e4.plan.steps_per_graph == 4 and e4.plan.pipe_no_join and e4.plan.pipe_prologue == "critic"
+    e4.steps_replay(7)
     torch.cuda.synchronize()
-    assert getattr(e4, "_pipe", None) is None and e4.st.device_step() == 3
+    assert e4._pipe is not None and e4._pipe.n == 4 and e4.st.device_step() == 7
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])

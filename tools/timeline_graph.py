@@ -40,6 +40,10 @@ durs = [(b[0][0] - a[0][0]) / 1e3 for a, b in zip(reps[:-1], reps[1:])]
 n_k = sum(len(v) for _, v in common)
 print(f"replay duration us (median of {len(reps)} replays of {spg} steps) {statistics.median(durs):.1f} = "
       f"{statistics.median(durs) / spg:.1f} per step; n kernels {n_k}")
+ds = sorted(durs)
+if ds:
+    print("replay start-to-start us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f mean %.1f (n %d)" % (
+        ds[0], ds[len(ds) // 10], ds[len(ds) // 2], ds[(9 * len(ds)) // 10], ds[-1], sum(ds) / len(ds), len(ds)))
 ent = []
 for q, names in common:
     pq = [per_queue(r)[q] for r in reps]
