@@ -24,7 +24,7 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (needed to build libosrl_amd.so for gfx950)")
 
 
-HEADERS = ["philox.h", "step.h", "argmem.h", "adam.h", "gather.h", "mlp_common.h", "dwt.h", "gelu.h"]  # csrc headers shared between translation units
+HEADERS = ["philox.h", "step.h", "argmem.h", "adam.h", "gather.h", "mlp_common.h", "dwt.h", "gelu.h", "trace.h"]  # csrc headers shared between translation units
 
 
 def _common_deps():

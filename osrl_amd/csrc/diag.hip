@@ -55,3 +55,34 @@ extern "C" int osrl_kernarg_probe(uint64_t* dev_scratch, int32_t* where, uint64_
   *where = dt == HSA_DEVICE_TYPE_GPU ? 1 : 0;
   return 0;
 }
+
+#ifdef OSRL_TRACE
+// LAB ONLY (csrc/trace.h, tools/build_trace_lib.sh): every translation unit keeps its own copy of the ring pointer (the
+// build links plain objects, no relocatable device code) and registers its setter here from a static constructor.
+namespace {
+typedef void (*trace_setter_t)(unsigned long long*);
+struct TraceSetters {
+  trace_setter_t fn[32];
+  int n;
+};
+TraceSetters& trace_setters() {
+  static TraceSetters s{};  // (function-local: ready whichever translation unit's constructor runs first)
+  return s;
+}
+}  // namespace
+extern "C" void osrl_trace_register(void (*set)(unsigned long long*)) {
+  TraceSetters& s = trace_setters();
+  if (s.n < 32) s.fn[s.n++] = set;
+}
+// ring: device memory, uint64 [2 + 3 * capacity]: ring[0] = cursor (reset to 0 here), ring[1] = capacity; NULL switches off
+extern "C" int osrl_debug_trace_set(uint64_t* ring, int64_t capacity) {
+  if (ring) {
+    const unsigned long long head[2] = {0ull, (unsigned long long)capacity};
+    hipError_t e = hipMemcpy(ring, head, sizeof head, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+  }
+  TraceSetters& s = trace_setters();
+  for (int i = 0; i < s.n; ++i) s.fn[i]((unsigned long long*)ring);
+  return s.n;
+}
+#endif

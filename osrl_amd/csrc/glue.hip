@@ -15,6 +15,7 @@
 
 #include "../../include/osrl_amd.h"
 #include "argmem.h"
+#include "trace.h"
 
 namespace {
 
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(kRed) void cpq_ood_stat_kernel(const float* __restr
   __shared__ uint32_t cnt[34];
   __shared__ uint32_t s_min[17];
   __shared__ float sm[20];
+  OSRL_TRACE_BEGIN(12, kl);
   const float quant = quantile_regs(kl, (int64_t)n_samples * rows, q, cnt, s_min);
   const float ood = cpq_ood_mean_block<SMALL>(qc_sampled, n_qc_old, kl, quant, n_samples, rows, inv_rows, sm);
   if (threadIdx.x == 0) {
@@ -875,6 +877,7 @@ __global__ __launch_bounds__(kRed) void cpq_cost_loss_kernel_p(const void* p) {
 // -exp(log_alpha)*(ood_mean - thres) term, log_alpha ascends and is clamped, stat[1] = exp(log_alpha)
 __global__ void cpq_alpha_step_kernel(const float* __restrict__ ood_mean, float qc_thres, float alpha_lr,
                                       float stat_share, float* __restrict__ log_alpha, float* __restrict__ stat) {
+  OSRL_TRACE_BEGIN(13, ood_mean);
   float la = log_alpha[0];
   const float ea = expf(la);
   if (stat) stat[0] -= stat_share * ea * (ood_mean[0] - qc_thres);

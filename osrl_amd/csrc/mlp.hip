@@ -35,6 +35,7 @@
 #include "adam.h"
 #include "gather.h"
 #include "step.h"
+#include "trace.h"
 
 namespace {
 
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
 // the same kernel with its descriptor in device memory (argmem.h)
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(5, p);
   mlp_fwd_body<NRB, NCB, NW, const OSRL_CAS FwdArgs&>(*(const OSRL_CAS FwdArgs*)p, blockIdx.y, blockIdx.x);
 }
 
@@ -610,6 +612,7 @@ struct Fwd2Args {  // device-resident form of the pair launch (argmem.h)
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd(NRB, NCB))) void mlp_fwd2_kernel_p(
     const void* p) {
+  OSRL_TRACE_BEGIN(6, p);
   const OSRL_CAS Fwd2Args& f = *(const OSRL_CAS Fwd2Args*)p;
   if ((int)blockIdx.y < f.nets0) {
     if ((int)blockIdx.x >= f.tiles0) return;
@@ -1007,6 +1010,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_
 }
 template <int NRB, int NCB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? (NCB <= 2 ? 4 : 2) : waves_per_simd_bwd(NRB, NCB))) void mlp_bwd_dz_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(7, p);
   mlp_bwd_dz_body<NRB, NCB, NW, const OSRL_CAS BwdArgs&>(*(const OSRL_CAS BwdArgs*)p, blockIdx.y, blockIdx.x);
 }
 

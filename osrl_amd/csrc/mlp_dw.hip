@@ -4,6 +4,7 @@
 // row counts (mlp_dw_big_kernel).  Split from mlp.hip in round 4 (compile time); design notes at the kernels.
 #include "dwt.h"
 #include "adam.h"
+#include "trace.h"
 
 namespace {
 
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dwt_kernel(const osrl_dw_entry_t* 
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][16T][16T+1] partials + [4][16T] bias partials
   constexpr int TW = 16 * T, LD = TW + 1;
   const int tid = threadIdx.x;
+  OSRL_TRACE_BEGIN(100 + T, entries);
 #if OSRL_CHAIN_PRIO > 0
   if (rows <= OSRL_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
 #endif

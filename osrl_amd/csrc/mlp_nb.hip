@@ -2,6 +2,7 @@
 // Split from mlp.hip (round 4) so that the two units compile side by side; design notes at the kernel below and in
 // mlp.hip's header.
 #include "mlp_common.h"
+#include "trace.h"
 
 namespace {
 
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd
 }
 template <int NCB, bool SHARED = false, bool LIST = false>
 __global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(8, p);
   mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&, LIST>(*(const OSRL_CAS NbArgs*)p);
 }
 // the 8-wave form (25-block layers): NCB - 1 = 3 column blocks per wave
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_k
   mlp_fwd_nb_body<4, true, 8, const NbArgs&>(a);
 }
 __global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(9, p);
   mlp_fwd_nb_body<4, true, 8, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
 }
 

@@ -17,6 +17,7 @@
 #include "step.h"
 #include "argmem.h"
 #include "adam.h"
+#include "trace.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -176,6 +177,7 @@ struct AdamArgs {
 };
 static_assert(sizeof(AdamArgs) == 8 * 4 + 8 + 3 * 8 + 2 * 8 + sizeof(PackMap) + 8 * 4, "AdamArgs has implicit padding");
 __global__ __launch_bounds__(256) void adam_kernel_p(const void* ptr) {
+  OSRL_TRACE_BEGIN(11, ptr);
   const OSRL_CAS AdamArgs& a = *(const OSRL_CAS AdamArgs*)ptr;
   const PackMap pk{a.pk.map_f, a.pk.map_b, a.pk.pf, a.pk.pb, a.pk.tf};
   adam_body(a.p, a.m, a.v, a.tgt, a.slabs, a.n_splits, a.slab_stride, a.n4, a.lr, a.b1, a.b2, a.eps, a.wd, a.tau,

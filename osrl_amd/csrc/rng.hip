@@ -18,6 +18,7 @@
 #include "gather.h"
 #include "step.h"
 #include "argmem.h"
+#include "trace.h"
 
 namespace {
 
@@ -137,6 +138,7 @@ struct BeginPack {  // both descriptors as one device-resident block (argmem.h):
   GatherArgs a;
 };
 __global__ __launch_bounds__(kBeginThreads) void step_begin_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(1, p);
   const OSRL_CAS BeginPack& k = *(const OSRL_CAS BeginPack*)p;
   step_begin_body<const OSRL_CAS BeginArgs&, const OSRL_CAS GatherArgs&>(k.b, k.a);
 }

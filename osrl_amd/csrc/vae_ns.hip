@@ -30,6 +30,7 @@
 
 #include "../../include/osrl_amd.h"
 #include "argmem.h"
+#include "trace.h"
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "vae_ns.hip: the in-launch statistic exchange assumes gfx950 memory counters (see mlp_common.h)"
@@ -658,18 +659,21 @@ template <int NKW>
 __global__ __launch_bounds__(256) void vae_ns_l0_kernel(const NsArgs a) { l0_body<NKW, const NsArgs&>(a); }
 template <int NKW>
 __global__ __launch_bounds__(256) void vae_ns_l0_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(2, p);
   l0_body<NKW, const OSRL_CAS NsArgs&>(*(const OSRL_CAS NsArgs*)p);
 }
 template <int NHB>
 __global__ __launch_bounds__(256) void vae_ns_fwd_enc_kernel(const NsArgs a) { fwd_enc_body<NHB, const NsArgs&>(a); }
 template <int NHB>
 __global__ __launch_bounds__(256) void vae_ns_fwd_enc_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(3, p);
   fwd_enc_body<NHB, const OSRL_CAS NsArgs&>(*(const OSRL_CAS NsArgs*)p);
 }
 template <int MODE, int NKS>
 __global__ __launch_bounds__(256) void vae_ns_gen_kernel(const NsArgs a) { gen_body<MODE, NKS, const NsArgs&>(a); }
 template <int MODE, int NKS>
 __global__ __launch_bounds__(256) void vae_ns_gen_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(40 + MODE, p);
   gen_body<MODE, NKS, const OSRL_CAS NsArgs&>(*(const OSRL_CAS NsArgs*)p);
 }
 

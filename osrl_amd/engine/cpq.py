@@ -339,6 +339,11 @@ class CPQEngine:
                 # of a node on that node's queue -- issued right at the fork, the dual step was the first successor of the
                 # previous step's last Adam and the two chains swapped queues at every boundary: 2155 vs 2320 steps/s)
                 carried.dual_step()
+            if nxt is not None and self.plan.pipe_prologue == "head":
+                # (lab: the next step's prologue FIRST on this branch -- covered by ev_critic like "critic", and the N*B-row
+                # launch behind it starts ~14 us later against the main chain's VAE launches)
+                nxt.prologue(device_noise)
+                self._prologue_covered = True
             if self.plan.head_tails:
                 # every action draw of the step (cpq.py:141 a_next, :159 a_next2, :164-176 the N OOD draws, :209 the
                 # actor-phase sample) by the actor trunks' own forward launch, from its LDS-resident head tiles: four

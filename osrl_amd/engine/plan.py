@@ -73,7 +73,8 @@ class CPQPlan:
     pipe_no_join: bool = False   # pipelined graphs: no join between the steps of a graph (the dual step of step k at the head
     #                              of step k+1's side branch)
     pipe_prologue: str = "early"  # pipelined graphs: where step k+1's prologue sits on step k's side branch: in front of the
-    #                              OOD statistic ("early") / in front of the critic phase ("critic": covered by ev_critic)
+    #                              OOD statistic ("early") / in front of the critic phase ("critic") or first on the branch
+    #                              ("head"): covered by the main chain's wait for the critic's Adam
 
 
 def ood_rows_ok(od: int, ad: int, B: int, N: int, c_hidden) -> bool:
@@ -105,23 +106,28 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     # five alternating rounds: 2293 (1) / 2308 (2) / 2317 (4) / 2329 (5) / 2328 (10) (profiles/r6_k20_steps_per_graph.txt) -> 5.
     # C4 within +-1 % of one step per graph -- its side branch is the longer one (separate action-draw launches) and gets the
     # extra prologue: on where the draws ride on the actor launch
-    # Second session of round 6 (gpurun_out/r6nj3, un-profiled, two alternating rounds): graphs whose steps are NOT joined -- step
-    # k's dual step at the head of step k+1's side branch, the next prologue in front of the critic phase so that the main
-    # chain's wait for the critic's Adam covers it -- C4 2411-2416 at 4 steps per graph against 2330-2360 joined and 2361-2368 at
-    # one step per graph (+2 %): there the side branch is the longer one and the main chain no longer waits for it at every
-    # boundary.  C2 LOSES with every such form (2230-2283 vs 2318-2325: both chains are tight at the critic's Adam, 14 us of
-    # prologue in front of it delay the main chain) although its kernel timeline under rocprofv3 is 5 us per step SHORTER
-    # (427 vs 435 us: the profiler's queue interception changes what a cross-queue wait costs) -- un-profiled clocks decide.
+    # Second session of round 6: graphs whose steps are NOT joined -- step k's dual step at the head of step k+1's side branch
+    # (it has no reader but itself), the next prologue early enough on the side branch that the main chain's wait for the
+    # critic's Adam covers it, so the next step's first VAE launch follows the actor group's Adam with no packet of its own
+    # in between (un-profiled start stamps, tools/trace_steps.py: 1.3 instead of 10 us between that Adam's end and the launch).
+    # WHERE the 14 us prologue sits decides how the N*B-row launch behind it lines up with the main chain's all-CU VAE launches,
+    # and that is worth more than the boundary itself (DESIGN_LOG): un-profiled clocks, alternating rounds --
+    #   C2 (draws ride on the actor launch; gpurun_out/r6nj4, r6nj5: 16 + 24 runs): prologue FIRST on the side branch ("head")
+    #      2356-2379 at K = 300 / 2342-2376 on the driver's K = 20 command against 2324-2328 / 2293-2345 joined: +1.8 %; in front
+    #      of the critic phase 2263-2283, in front of the OOD statistic with an event of its own 2230 (both LOSE: the VAE phase
+    #      stretches from 163 to 190 us when the N*B-row launch starts 6 us earlier against it);
+    #   C4 (separate draw launches, the side branch is the longer chain; gpurun_out/r6nj3, r6trace): in front of the critic
+    #      phase 2411-2417 at 4 steps per graph against 2330-2360 joined, 2361-2368 at one step per graph, 2358-2366 with "head": +2 %.
     side_long = not head_tails and B >= 1024
     spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or \
         (5 if (head_tails and B >= 1024) else 4 if side_long else 1)
     dual = knob("OSRL_PIPE_DUAL", "auto", "pipelined steps: the dual step behind the join (main) / on the side branch behind the "
                 "OOD statistic (side) / at the head of the NEXT step's side branch, no join between the steps of a graph (next)")
     pro = knob("OSRL_PIPE_PROLOGUE", "auto", "pipelined steps: the next step's prologue behind the OOD statistic (side) / in "
-               "front of it (early) / on the main chain (main) / on the side branch in front of the critic phase (critic: the "
-               "main chain's wait for the critic's Adam then covers it)")
-    no_join = side_long if dual == "auto" else dual == "next"
-    pro = ("critic" if side_long else "early") if pro == "auto" else pro
+               "front of it (early) / on the main chain (main) / on the side branch in front of the critic phase (critic) or "
+               "first on it (head): the main chain's wait for the critic's Adam then covers it")
+    no_join = B >= 1024 if dual == "auto" else dual == "next"
+    pro = ("critic" if side_long else "head" if B >= 1024 else "early") if pro == "auto" else pro
     ood_tile = int(knob("OSRL_OOD_TILE", "80", "row tile of the N*B-row launches (0 = 32-row tile loop)"))
     # qc_ood = ((KL >= quantile(KL, 0.75)) * qc_sampled).mean(0) (cpq.py:183-184) multiplies three quarters of the N*B target
     # cost-critic outputs by zero: with the encoder launch, the quantile and a compaction in FRONT of that forward it runs on
@@ -184,7 +190,7 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True,
-                   steps_per_graph=5, ood_rows=False)),
+                   steps_per_graph=5, ood_rows=False, pipe_no_join=True, pipe_prologue="head")),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
                    steps_per_graph=4, ood_rows=False, pipe_no_join=True, pipe_prologue="critic")),

@@ -101,14 +101,14 @@ def test_pipelined_steps_equal_one_step_graph_replays(name, spg, total):
     assert all(np.isfinite(v) for v in e_b.st.read_stats().values())
 
 
-@pytest.mark.parametrize("prologue", ["early", "critic"])
+@pytest.mark.parametrize("prologue", ["early", "critic", "head"])
 @pytest.mark.parametrize("name,spg,total", [("cpq_small", 2, 6), ("cpq_small", 4, 9), ("cpq_odd", 3, 7), ("cpq_wide", 2, 4),
                                              ("c2", 4, 8), ("c4", 4, 8)])
 def test_unjoined_pipelined_steps_equal_one_step_graph_replays(name, spg, total, prologue, monkeypatch):
     """The no-join form of a pipelined CPQ graph (plan.pipe_no_join; C4's pinned plan; forced here on every case through the
     lab switches): the steps of a graph are not joined, step k's dual step (cpq.py:186-195) is issued at the head of step
     k+1's side branch, and the next prologue sits either in front of the OOD statistic (an event of its own for the main
-    chain) or in front of the critic phase (covered by the wait for the critic's Adam).  Same contract as above: parameters,
+    chain), in front of the critic phase or first on the side branch (both covered by the wait for the critic's Adam).  Same contract as above: parameters,
     moments, targets, ``log_alpha``, EVERY step's statistics (the cost loss's OOD term is added one step later on another
     queue) and the step count are bit-equal to replays of the one-step graph."""
     from osrl_amd.engine.pipeline import PipelinedSteps
@@ -147,10 +147,10 @@ def test_unjoined_pipelined_steps_equal_one_step_graph_replays(name, spg, total,
 
 
 def test_steps_replay_follows_the_plan():
-    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 5 at C2's shape, 4 -- not joined -- at
-    C4's) and leaves the engine n steps further either way."""
+    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 5 at C2's shape, 4 at C4's, neither
+    joined inside a graph) and leaves the engine n steps further either way."""
     m, e = _bench("c2")
-    assert e.plan.steps_per_graph == 5 and not e.plan.pipe_no_join
+    assert e.plan.steps_per_graph == 5 and e.plan.pipe_no_join and e.plan.pipe_prologue == "head"
     e.steps_replay(9)
     torch.cuda.synchronize()
     assert e._pipe is not None and e._pipe.n == 5 and e.st.device_step() == 9
