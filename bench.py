@@ -356,7 +356,7 @@ def mlp_fwd_flops(run):
     return 2.0 * run.rows * run.net.E * lin(d)
 
 
-DEFAULT_STEPS_PER_GRAPH = 0  # 0 = what the engine's plan says (engine/plan.py steps_per_graph: C2 5, C3 10, C4 4 not joined)
+DEFAULT_STEPS_PER_GRAPH = 0  # 0 = what the engine's plan says (engine/plan.py steps_per_graph: C2 20, C3 10, C4 8; the CPQ graphs not joined inside)
 
 PROBE_SITES = ("enc_ood", "costold_ood", "vae_dw", "actor_phase_fwd", "critic_fwd")
 

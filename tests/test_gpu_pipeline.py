@@ -147,18 +147,18 @@ def test_unjoined_pipelined_steps_equal_one_step_graph_replays(name, spg, total,
 
 
 def test_steps_replay_follows_the_plan():
-    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 5 at C2's shape, 4 at C4's, neither
+    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 20 at C2's shape, 8 at C4's, neither
     joined inside a graph) and leaves the engine n steps further either way."""
     m, e = _bench("c2")
-    assert e.plan.steps_per_graph == 5 and e.plan.pipe_no_join and e.plan.pipe_prologue == "head"
-    e.steps_replay(9)
+    assert e.plan.steps_per_graph == 20 and e.plan.pipe_no_join and e.plan.pipe_prologue == "head"
+    e.steps_replay(45)
     torch.cuda.synchronize()
-    assert e._pipe is not None and e._pipe.n == 5 and e.st.device_step() == 9
+    assert e._pipe is not None and e._pipe.n == 20 and e.st.device_step() == 45
     m4, e4 = _bench("c4")
-    assert e4.plan.steps_per_graph == 4 and e4.plan.pipe_no_join and e4.plan.pipe_prologue == "critic"
-    e4.steps_replay(7)
+    assert e4.plan.steps_per_graph == 8 and e4.plan.pipe_no_join and e4.plan.pipe_prologue == "critic"
+    e4.steps_replay(19)
     torch.cuda.synchronize()
-    assert e4._pipe is not None and e4._pipe.n == 4 and e4.st.device_step() == 7
+    assert e4._pipe is not None and e4._pipe.n == 8 and e4.st.device_step() == 19
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])
