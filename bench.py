@@ -537,16 +537,19 @@ def roofline(eng, cfg_name="c2"):
     out = {"bound": "mfma", "kernel": dom, "symbol": r["symbol"], "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
            "frac_is": ("in-run: the launch inside the REPLAYED one-step graph, bracketed by device-side 100 MHz stamps on its own "
-                       "stream (in_graph_us; the rocprofv3 --kernel-trace average of the same kernel under profiles/ is the cross-"
-                       "check).  'Dominant' is PER LAUNCH: kernel = the single launch with the largest in-step duration; by TOTAL "
+                       "stream (in_graph_us; cross-check: the rocprofv3 --kernel-trace average of the same kernel over the one-step "
+                       "graph, profiles/r6b_bench_kernel_stats_c2_1step.csv; over the 20-step graph the timed region replays the "
+                       "profiler's average is ~7 % longer, r6b_bench_kernel_stats_c2.csv, while the un-profiled start stamps of "
+                       "that graph, r6b_trace_unprofiled_c2.txt, bound it by <= 96 us: rocprofv3 shifts how the two queues line "
+                       "up).  'Dominant' is PER LAUNCH: kernel = the single launch with the largest in-step duration; by TOTAL "
                        "time per step the top symbol is another one (top_by_total)" if r.get("in_step_how") == "graph" else
                        "in-run (eagerly issued two-stream step body, HIP events)") if have_run else
                       "isolated (N > 1: no in-step probe)",
            # the symbol with the largest TOTAL time per step in the rocprofv3 --kernel-trace --stats summary of this command
-           # (profiles/r6_bench_kernel_stats_c2.csv): three launches per step of the 16-row paired forward (actor trunks,
+           # (profiles/r6b_bench_kernel_stats_c2.csv): three launches per step of the 16-row paired forward (actor trunks,
            # critic-phase and cost-phase forwards), ~105 us per step between them at MFMA-busy 0.28 (profiles/r6_pmc_c2.json)
            "top_by_total": {"symbol": "mlp_fwd2_kernel_p<1, 2, 8>", "launches_per_step": 3,
-                            "source": "static: profiles/r6_bench_kernel_stats_c2.csv"} if cfg_name == "c2" else None,
+                            "source": "static: profiles/r6b_bench_kernel_stats_c2.csv"} if cfg_name == "c2" else None,
            "isolated_achieved": round(ach_iso, 3), "isolated_frac": round(ach_iso / PEAK_FP32_TFLOPS, 4),
            # what a loop of nothing but independent v_mfma_f32_16x16x4_f32 sustains on all 256 CUs (one / two waves per SIMD):
            # the nominal peak above assumes 32 cycles per instruction, the chip delivers 37-41.  Reported beside `peak`, never
@@ -917,7 +920,7 @@ def main():
     # about one run out of three (no_preroll 400-1100 instead of 2200 steps/s, gpurun_out/r6f / r6final / r6p; the collector
     # was ruled out: it happens with gc disabled).  Two regions' worth of replays back to back, once, before any timing.
     if not args.eager:
-        prime = 2 * max(args.steps, 1) if args.steps <= 64 else 0
+        prime = max(2 * max(args.steps, 1) if args.steps <= 64 else 0, 4 * spg if spg > 1 else 0)  # (>= 4 graphs in flight once)
         if prime:
             wl.run(prime)
             torch.cuda.synchronize()
@@ -1111,6 +1114,12 @@ def other_configs(skip: str, device, steps_per_graph: int = 1):
             continue
         try:
             w = Workload(name, device, 0, 1, None, n_store=1 << 18, steps_per_graph=steps_per_graph)
+            if w.pipe is not None:
+                # graph priming, as in front of the headline regions: the first time several replays of a graph are in
+                # flight at once the runtime stalls once (20-60 ms) -- and a warm-up shorter than a few graphs never has more
+                # than one (C4 at 8 steps per graph: 1435 instead of 2418 steps/s in one run of two, gpurun_out/r6bfinal)
+                w.run(4 * w.pipe.n)
+                torch.cuda.synchronize()
             dt = timed_steps(w, steps, warm)
             fl = flops_per_step(w.cfg)
             fx = executed_flops_per_step(w.cfg, bool(getattr(w.eng, "ood_rows", False)))
