@@ -37,6 +37,10 @@ DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather 
 # (pipelined graphs: where the next prologue sits and whether the steps of a graph are joined are plan fields --
 # engine/plan.py pipe_prologue / pipe_no_join; the lab switch OSRL_PIPE_DUAL=side keeps round 6's side-branch dual step)
 PIPE_DUAL_SIDE = P.knob("OSRL_PIPE_DUAL", "auto") == "side"
+# (lab, no-join graphs: the actor group's dW + Adam of step k at the head of step k+1's side branch instead of the tail of
+# step k's main chain -- nothing on the main chain reads the actor before the next trunk launch, which is on that branch)
+PIPE_ACTOR_SIDE = P.knob("OSRL_PIPE_ACTOR", "main", "no-join pipelined steps: the actor group's dW + Adam on the main chain (main) / "
+                         "carried to the head of the next step's side branch (side)") == "side"
 STAT_KEYS = ["loss/loss_vae", "loss/critic_loss", "loss/cost_critic_loss", "loss/alpha_value", "loss/actor_loss"]
 NOISE_KEYS = ["eps_vae", "eps_next_c", "eps_next_cc", "eps_ood", "eps_actor"]
 
@@ -56,6 +60,7 @@ class CPQEngine:
         z = lambda *s: torch.zeros(*s, **f)  # noqa: E731
         self.st = StepState(dev, STAT_KEYS)
         self._prologue_covered = False
+        self._actor_pending = False
         self._ev_prologue = None    # (pipelined graphs, plan.pipe_no_join: event behind the next step's prologue)
         self._dual_pending = False  # (this step's dual step is still to be issued by the next step of the graph)
         nq, nqc = m.num_q, m.num_qc
@@ -334,6 +339,9 @@ class CPQEngine:
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
+            if carried is not None and carried._actor_pending:
+                carried._optim("actor", carried.p_actor, m.tau)
+                carried._actor_pending = False
             if carried is not None:
                 # (created HERE, behind the main chain's VAE launches: the graph executor keeps the FIRST-created successor
                 # of a node on that node's queue -- issued right at the fork, the dual step was the first successor of the
@@ -511,8 +519,12 @@ class CPQEngine:
                              self.dhead_actor)
             self.r_actor_obs.backward_dz()
         if dp is None:
-            self._optim("actor", self.p_actor, m.tau)
-            if no_join and nxt is not None and (self._ev_prologue is not None or self._prologue_covered):
+            carry = no_join and nxt is not None and (self._ev_prologue is not None or self._prologue_covered)
+            if carry and PIPE_ACTOR_SIDE:
+                self._actor_pending = True  # (the next step issues it on its side branch, behind its fork)
+            else:
+                self._optim("actor", self.p_actor, m.tau)
+            if carry:
                 self._dual_pending = True  # (the next step of this graph runs it: dual_step())
                 return
             par.join(0)
