@@ -48,6 +48,17 @@ constexpr int kPL = 68;                      // row stride of a wave's private [
 constexpr int kNKW = 7;                      // k-steps per wave, upper bound (H <= 448)
 constexpr float kLsMin = -4.0f, kLsMax = 15.0f;  // net.py:325
 
+// Wave priority (mlp_common.h OSRL_CHAIN_PRIO): these launches ARE the latency chain's VAE phase and run beside the N*B-row
+// cost-critic launch of the side branch (priority 0) on every CU
+#ifndef OSRL_VAE_NS_PRIO
+#define OSRL_VAE_NS_PRIO 0
+#endif
+#if OSRL_VAE_NS_PRIO > 0
+#define NS_PRIO() __builtin_amdgcn_s_setprio(OSRL_VAE_NS_PRIO)
+#else
+#define NS_PRIO()
+#endif
+
 #ifdef VAE_NS_STAMPS  // tools/vae_ns_lab.hip: per-phase 100 MHz stamps of wave 0 of every workgroup (lab builds only)
 __device__ unsigned long long g_ns_stamp[512][12];
 #define NS_STAMP(i)                                                                                     \
@@ -104,6 +115,7 @@ __device__ __forceinline__ void k_range(int nk, int wave, int* ks0, int* cnt) {
 template <int NKW, class AR>
 __device__ __forceinline__ void l0_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  NS_PRIO();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kq = lane >> 4;
@@ -228,6 +240,7 @@ __device__ __forceinline__ void slab_product(const float* lds, int wave, int m, 
 template <int NHB, class AR>
 __device__ __forceinline__ void fwd_enc_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  NS_PRIO();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kq = lane >> 4;
@@ -306,6 +319,7 @@ enum { MODE_DEC_FWD = 0, MODE_DEC_BWD = 1, MODE_ENC_BWD = 2 };
 template <int MODE, int NKS, class AR>
 __device__ __forceinline__ void gen_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  NS_PRIO();
   __shared__ float s_red[2][kKS];
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63;
