@@ -95,14 +95,17 @@ def flops_per_step(cfg) -> float:
     return 2.0 * per * Bsz
 
 
-def executed_flops_per_step(cfg, ood_rows: bool = False) -> float:
+def executed_flops_per_step(cfg, ood_rows: bool = False, share=(0, 0)) -> float:
     """FLOPs this build actually ISSUES per step.  The reference's step (flops_per_step) contains work whose result
     it discards or computes twice; the engine skips exactly that (same results):
       * CPQ ``cost_critic_loss`` runs the whole VAE on the N*B sampled actions and keeps only the KL of the ENCODER
         output (cpq.py:176-182: ``_, _, mean, std = self.vae(...)``): the decoder on N*B rows is never launched;
       * the actor trunk on next_obs (cpq.py:141 and :159) and on obs (:164 and :209) is evaluated once each;
       * ``ood_rows`` (the engine's plan.ood_rows on one GPU): the target cost critics on the quarter of the N*B sampled
-        actions that enters ``qc_ood`` (cpq.py:183-184) instead of all of them.
+        actions that enters ``qc_ood`` (cpq.py:183-184) instead of all of them;
+      * ``share`` = (k16 of the target cost critics' launch, k16 of the encoder's; plan.ood_share): on tiles of shared
+        observations the first 16 k16 input columns of layer 0 are multiplied once per observation of a tile (5 copies each)
+        instead of once per row (osrl_rows_t.share0).
     Other algorithms: nothing skipped."""
     if cfg["algo"] != "cpq":
         return flops_per_step(cfg)
@@ -116,7 +119,14 @@ def executed_flops_per_step(cfg, ood_rows: bool = False) -> float:
         n = N * Bsz
         kept = n - int(0.75 * (n - 1)) - 1
         fx -= 2.0 * 2 * lin([od + ad] + H + [1]) * (n - kept)
+    kc, ke = share
+    fx -= 2.0 * (2 * 16 * kc * H[0] + 16 * ke * V) * (N * Bsz) * 4 / 5  # (2 target cost critics; the VAE encoder)
     return fx
+
+
+def _share(eng):
+    """(k16 of the cost-critic launch, k16 of the encoder launch) of an engine's shared-observation tiles, (0, 0) = plain."""
+    return int(getattr(eng, "pre_cost", 0) or 0), int(getattr(eng, "pre_enc", 0) or 0)
 
 
 def lease_diagnostics(device) -> dict:
@@ -465,10 +475,13 @@ def roofline(eng, cfg_name="c2"):
     carried under ``kernels`` with their in-step and isolated figures, algorithmic bytes and counted HBM traffic."""
     from osrl_amd import _lib as L
     cands = {
+        # (the launches exactly as the step issues them: on tiles of shared observations where the plan says so, plan.ood_share)
         "mlp_fwd<vae-encoder, N*B rows>": (eng.r_enc_ood, lambda: eng.r_enc_ood.forward(
-            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B), "enc_ood", "mlp_fwd_nb8_kernel_p"),
+            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B, share_k16=_share(eng)[1]), "enc_ood",
+            "mlp_fwd_nb8_pre_kernel_p" if _share(eng)[1] else "mlp_fwd_nb8_kernel_p", _share(eng)[1]),
         "mlp_fwd<cost_critic_old x2, N*B rows>": (eng.r_costold_ood, lambda: eng.r_costold_ood.forward(
-            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B), "costold_ood", "mlp_fwd_nb_kernel_p<4, false>"),
+            eng.obs, eng.sampled, map0=L.MAP_MOD, div0=eng.B, share_k16=_share(eng)[0]), "costold_ood",
+            "mlp_fwd_nb_kernel_p<4, false, false, true>" if _share(eng)[0] else "mlp_fwd_nb_kernel_p<4, false>", _share(eng)[0]),
     }
     # the in-step probe runs whole step bodies: under data parallelism those contain collectives, which rank 0 must not
     # issue out of step with its peers -- N > 1 reports the isolated figure only.  It goes first: its
@@ -496,9 +509,12 @@ def roofline(eng, cfg_name="c2"):
         except Exception:
             pmc = {}
     res = {}
-    for name, (run, fn, site, sym) in cands.items():
+    for name, (run, fn, site, sym, k16) in cands.items():
         t = time_kernel(fn)
-        fl = mlp_fwd_flops(run)
+        fl_alg = mlp_fwd_flops(run)
+        # FLOPs the launch ISSUES: on tiles of shared observations the first 16 k16 input columns of layer 0 are multiplied for
+        # one of a tile's five row blocks (csrc/mlp_nb.hip nb_share_acc) -- the fraction is priced on these, not on fl_alg
+        fl = fl_alg - 2.0 * run.net.E * 16 * k16 * run.net.dims[1] * run.rows * 4 / 5
         mean_us, med_us = graph_sites.get(site, (float("nan"), float("nan"))) if "error" not in graph_sites else (float("nan"),) * 2
         how = "graph"
         if mean_us != mean_us:  # no in-graph figure: the eager two-stream probe
@@ -518,7 +534,8 @@ def roofline(eng, cfg_name="c2"):
         wts = run.net.E * (lin(d) + sum(d[1:]))
         alg = 4 * (run.rows * d[0] + wts + run.net.E * run.rows * d[-1])
         distinct = 4 * (eng.B * eng.obs.shape[1] + run.rows * eng.sampled.shape[1] + wts + run.net.E * run.rows * d[-1])
-        res[name] = dict(symbol=sym, gflop=round(fl / 1e9, 3), isolated_us=round(t * 1e6, 2),
+        res[name] = dict(symbol=sym, gflop=round(fl / 1e9, 3), gflop_plain_tiles=round(fl_alg / 1e9, 3), share_k16=int(k16),
+                         isolated_us=round(t * 1e6, 2),
                          isolated_frac=round(fl / t / 1e12 / PEAK_FP32_TFLOPS, 4),
                          in_step_us=round(mean_us, 2) if in_run else None,
                          in_step_us_median=round(med_us, 2) if in_run else None,
@@ -984,7 +1001,7 @@ def main():
             t4 = torch.tensor([dt4], dtype=torch.float64, device=device)
             dist.all_reduce(t4, op=dist.ReduceOp.MAX)
             dt4 = float(t4.item())
-            f4, x4 = flops_per_step(w4.cfg), executed_flops_per_step(w4.cfg, bool(getattr(w4.eng, "ood_rows", False)))
+            f4, x4 = flops_per_step(w4.cfg), executed_flops_per_step(w4.cfg, bool(getattr(w4.eng, "ood_rows", False)), _share(w4.eng))
             c4_dp = {"value": round(world * 200 / dt4, 2), "optimizer_steps_per_s": round(200 / dt4, 2),
                      "ms_per_step": round(dt4 / 200 * 1e3, 4), "global_batch": w4.cfg["B"] * world,
                      "parallelism": f"dp{world}", "gflop_per_step_per_gpu": round(f4 / 1e9, 2),
@@ -997,7 +1014,7 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        fl, fx = flops_per_step(cfg), executed_flops_per_step(cfg, bool(getattr(wl.eng, "ood_rows", False)))
+        fl, fx = flops_per_step(cfg), executed_flops_per_step(cfg, bool(getattr(wl.eng, "ood_rows", False)), _share(wl.eng))
         B = cfg["B"]
         out = {
             "metric": "grad-steps/sec", "value": round(world * args.steps / dt, 2),
@@ -1122,7 +1139,7 @@ def other_configs(skip: str, device, steps_per_graph: int = 1):
                 torch.cuda.synchronize()
             dt = timed_steps(w, steps, warm)
             fl = flops_per_step(w.cfg)
-            fx = executed_flops_per_step(w.cfg, bool(getattr(w.eng, "ood_rows", False)))
+            fx = executed_flops_per_step(w.cfg, bool(getattr(w.eng, "ood_rows", False)), _share(w.eng))
             res[name] = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
                          "gflop_per_step": round(fl / 1e9, 2),
                          "step_frac": round(fl / (dt / steps) / 1e12 / PEAK_FP32_TFLOPS, 4),

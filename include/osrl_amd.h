@@ -82,6 +82,14 @@ typedef struct {
    * Honoured by the 80-row inference forward of <= 256-wide nets (osrl_mlp_forward); every other entry point returns -3. */
   const int32_t* row_list;
   const int32_t* n_rows_dev;
+  /* Optional (0 = off): SHARED SRC0 ROWS of an inference launch whose rows are n * div0 + b (map0 = OSRL_MAP_MOD: cpq.py:164-176,
+   * N sampled actions per observation).  share0 = 1: tiles are [copies] x [16 src0 rows] and the part of layer 0 that lies in
+   * the first 16 * share_k16 input columns (all of them columns of src0; share_k16 >= 1, at least one 16-column k-step left)
+   * is computed once per src0 row of a tile instead of once per launch row.  Same products, another order of a row's sum (a few
+   * ulp from the plain launch): for no_grad launches.  Needs div0 % 16 == 0 and (rows / div0) a multiple of the tile's row
+   * blocks (5; 4 on the 64-row form).  A HINT: taken by the 80-row inference forward of <= 256-wide (4-wave) and 400-wide
+   * (8-wave) nets (osrl_mlp_forward[_tail]); every other launch computes the same function on its plain tiles. */
+  int32_t share0, share_k16;
 } osrl_rows_t;
 
 /* Activations written by forward / read by backward.  h[e][l] = post-activation output of

@@ -37,7 +37,8 @@ class RowsT(C.Structure):
     _fields_ = [("rows", C.c_int32), ("d0", C.c_int32), ("map0", C.c_int32), ("div0", C.c_int32),
                 ("d1", C.c_int32), ("map1", C.c_int32), ("div1", C.c_int32),
                 ("src0", _fp), ("src1", _fp),
-                ("row_list", C.c_void_p), ("n_rows_dev", C.c_void_p)]  # (a device-chosen row set: include/osrl_amd.h)
+                ("row_list", C.c_void_p), ("n_rows_dev", C.c_void_p),  # (a device-chosen row set: include/osrl_amd.h)
+                ("share0", C.c_int32), ("share_k16", C.c_int32)]  # (tiles of shared src0 rows: include/osrl_amd.h)
 
 
 class ActsT(C.Structure):

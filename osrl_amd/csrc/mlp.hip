@@ -1952,7 +1952,7 @@ static int mlp_forward_impl(const osrl_mlp_t* net, const osrl_rows_t* in, const 
       return fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);
     }
   }
-  if (in->row_list || in->n_rows_dev) return -3;  // a device-chosen row set: only the 80-row inference forward reads it
+  if (in->row_list || in->n_rows_dev) return -3;  // a device-chosen row set: only the 80-row inference forward reads it (share0 is a hint)
   if (want_tail && tail->kind == OSRL_TAIL_VAE_KL) {  // tile kernels: the plain forward, then the rows kernel
     const int rc = mlp_forward_impl(net, in, out, nullptr, stream);
     return rc != 0 ? rc : fwd_tail_as_launches(tail, out->h[0][net->n_layers - 1], in->rows, stream);

@@ -88,20 +88,65 @@ __device__ __forceinline__ void nb_bias_acc(const f32x4 (&braw)[CNT], int col0, 
   }
 }
 
+// SHARED SRC0 ROWS (osrl_rows_t.share0, second session of round 6): the N*B rows of CPQ's OOD launches are the B observations
+// N times over beside N different sampled actions (cpq.py:164-176, row = n B + b), so the observation part of layer 0 is the
+// same for the N copies of an observation.  A tile of this form is [kNbRb samples] x [16 observations] -- row block rb is
+// sample s0 + rb of the SAME 16 observations -- and layer 0 runs in two phases: (A) the k-steps that lie wholly inside the
+// observation columns (kc0 of them: 4 of 5 at (76, 2)) on ONE row block, bias-initialised, every weight fragment used for 16
+// rows instead of 80; (B) every row block's accumulators start from that result and walk the remaining k-steps as before.
+// Same products; a row's sum is formed as (bias + first 16 kc0 terms in k order) + rest instead of one rotated walk -- a few
+// ulp from the plain form, which is why the plans use it for no_grad launches only.  (First built as a per-observation
+// prefix matrix computed by osrl_linear launches in front of the launch: the kernels gained 8 us each, the three small
+// launches cost 38 -- gpurun_out/r6prefix.)
+template <int CNT, int S>
+__device__ __forceinline__ void nb_share_step(const float* __restrict__ P, int Np, unsigned lane_off, const float* arow, int ks,
+                                              int kc0, f32x4 (&b)[2][CNT], f32x4 (&a0)[2], f32x4 (&ao)[1][CNT]) {
+  const int kn = ks + 1 < kc0 ? ks + 1 : ks;  // last step: a harmless re-load
+  const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) b[S ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
+  a0[S ^ 1] = *reinterpret_cast<const f32x4*>(arow + kn * 16);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) ao[0][c] = EXP_MFMA(b[S][c][t], a0[S][t], ao[0][c]);
+}
+// phase A: ao = bias + sum over k-steps [0, kc0) of row block 0 (b / a0: scratch fragment sets)
+template <int CNT>
+__device__ __forceinline__ void nb_share_acc(const float* __restrict__ P, int Np, unsigned lane_off, const float* arow, int kc0,
+                                             f32x4 (&b)[2][CNT], f32x4 (&ao)[1][CNT]) {
+  f32x4 a0[2];
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(P, lane_off + c * 256);
+  a0[0] = *reinterpret_cast<const f32x4*>(arow);
+  int ks = 0;
+  for (; ks + 2 <= kc0; ks += 2) {
+    nb_share_step<CNT, 0>(P, Np, lane_off, arow, ks, kc0, b, a0, ao);
+    nb_share_step<CNT, 1>(P, Np, lane_off, arow, ks + 1, kc0, b, a0, ao);
+  }
+  if (ks < kc0) nb_share_step<CNT, 0>(P, Np, lane_off, arow, ks, kc0, b, a0, ao);
+}
+
 // ADB: the activation fragments are double buffered (next step's ds_reads issued under this step's MFMAs: one wave per
 // SIMD has nothing else to hide them behind).  The 8-wave form reads them single buffered at the end of a step -- the
 // SIMD's other wave covers the LDS round trip -- which is what brings it under 160 registers per lane.
-template <int CNT, bool ADB = true>
-__device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
-                                      int N, const f32x4 (&braw)[CNT], f32x4 (&acc)[kNbRb][CNT], int pl) {
+template <int CNT, bool ADB = true, bool PRE = false>
+__device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk_all, const float* __restrict__ P, int Np, int col0,
+                                      int N, const f32x4 (&braw)[CNT], f32x4 (&acc)[kNbRb][CNT], int pl, const int kc0_in) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
   const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
+  const int kc0 = PRE ? kc0_in : 0, nk = nk_all - kc0;  // (shared src0 rows: phase B walks the k-steps from kc0 on)
   const int rot = k_rot(nk);
   f32x4 b[2][CNT], a[ADB ? 2 : 1][kNbRb];
+  f32x4 ao[1][CNT];
+  if constexpr (PRE) {  // phase A on row block 0 (every row block of the tile holds the same src0 rows)
+    nb_bias_acc<CNT, 1>(braw, col0, N, lane, ao);
+    nb_share_acc<CNT>(P, Np, lane_off, arow, kc0, b, ao);
+  }
   {
-    const int k0 = k_at(0, rot, nk, 0);
+    const int k0 = k_at(0, rot, nk, kc0);
     const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
@@ -109,12 +154,19 @@ __device__ __forceinline__ void nb_mm(const float* lds, int lda, int nk, const f
     for (int rb = 0; rb < kNbRb; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(arow + rb * 16 * lda + k0 * 16);
   }
   __builtin_amdgcn_sched_barrier(0);
-  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
+  if constexpr (PRE) {
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb)
+#pragma unroll
+      for (int c = 0; c < CNT; ++c) acc[rb][c] = ao[0][c];
+  } else {
+    nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
+  }
   if (pl == 1) { PHASE_STAMP(14); }  // debug build: layer 1's k-loop starts here
   auto step = [&](auto s_c, int kc) {
     constexpr int s = decltype(s_c)::value;
     constexpr int sa = ADB ? s : 0, sn = ADB ? (s ^ 1) : 0;
-    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
+    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, kc0);  // last step: a harmless re-load
     const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
@@ -241,10 +293,11 @@ __device__ __forceinline__ void nb_head_dot(const f32x4 (&acc)[kNbRb][CNT], cons
   }
 }
 
-template <int CNT, bool ADB = true>
+template <int CNT, bool ADB = true, bool PRE = false>
 __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N, const float* __restrict__ P,
                                               const float* __restrict__ bias, int act, int cb0, int lane, int pl,
-                                              const float* __restrict__ hw = nullptr, float* __restrict__ part = nullptr) {
+                                              const int kc0, const float* __restrict__ hw = nullptr,
+                                              float* __restrict__ part = nullptr) {
   (void)pl;  // layer number, for the debug build's phase stamps only
   f32x4 braw[CNT];
   nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
@@ -255,7 +308,7 @@ __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N,
       hwv[c] = *reinterpret_cast<const f32x4*>(hw + (size_t)((cb0 + c) * 4 + (lane >> 4)) * 64);
   }
   f32x4 acc[kNbRb][CNT];
-  nb_mm<CNT, ADB>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl);
+  nb_mm<CNT, ADB, PRE>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, N, braw, acc, pl, kc0);
   PHASE_STAMP(2 + 4 * pl);
   if (hw) {  // the tile is not written again: no barrier in front, the caller's barrier behind
     nb_head_dot<CNT>(acc, hwv, act, lane, part);
@@ -273,20 +326,53 @@ __device__ __forceinline__ void nb_wide_layer(float* lds, int lda, int K, int N,
 // Dealing 25 blocks as 7 + 6 + 6 + 6 makes the 7-block wave the layer's pace: 12 % over the mean.  Here wave 0 takes
 // row blocks {0, 1} of the shared block, waves 1..3 one row block each: 32 / 31 / 31 / 31 register tiles.
 // NX = row blocks of the shared column this wave owns (2: wave 0, 1: the others), starting at rbx0.
-template <int CNT, int NX, bool ADB = true>
-__device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const float* __restrict__ P, int Np, int col0,
+template <int CNT, int NX, bool ADB = true, bool PRE = false>
+__device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk_all, const float* __restrict__ P, int Np, int col0,
                                         int colx, int rbx0, int N, const f32x4 (&braw)[CNT], const f32x4 (&brawx)[1],
-                                        f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX], int pl) {
+                                        f32x4 (&acc)[kNbRb][CNT], f32x4 (&xacc)[NX], int pl, const int kc0_in) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, kq = lane >> 4;
   const float* arow = lds + m * lda + 4 * kq;
   const unsigned lane_off = (unsigned)((kq * Np + col0 + m) * 16);  // bytes
   const unsigned lane_offx = (unsigned)((kq * Np + colx + m) * 16);
+  const int kc0 = PRE ? kc0_in : 0, nk = nk_all - kc0;  // (shared src0 rows: phase B walks the k-steps from kc0 on)
   const int rot = k_rot(nk);
   const float* arowx = arow + rbx0 * 16 * lda;  // the shared column's row blocks (wave-uniform start)
   f32x4 b[2][CNT + 1], a[ADB ? 2 : 1][kNbRb], ax[ADB ? 2 : 1][NX];
+  f32x4 ao[1][CNT + 1];
+  if constexpr (PRE) {  // phase A on row block 0, this wave's CNT column blocks and the row-shared one (column offsets differ)
+    f32x4 b1[1][CNT], bx[1][1];
+    nb_bias_acc<CNT, 1>(braw, col0, N, lane, b1);
+    nb_bias_acc<1, 1>(brawx, colx, N, lane, bx);
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) ao[0][c] = b1[0][c];
+    ao[0][CNT] = bx[0][0];
+    f32x4 a0[2];
+    auto ldw = [&](int k, int sI) {
+      const float* __restrict__ Pk = P + (size_t)k * 16 * Np;
+#pragma unroll
+      for (int c = 0; c < CNT; ++c) b[sI][c] = load_bp_s(Pk, lane_off + c * 256);
+      b[sI][CNT] = load_bp_s(Pk, lane_offx);
+      a0[sI] = *reinterpret_cast<const f32x4*>(arow + k * 16);
+    };
+    auto stepA = [&](auto s_c, int ks) {
+      constexpr int sI = decltype(s_c)::value;
+      ldw(ks + 1 < kc0 ? ks + 1 : ks, sI ^ 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < CNT + 1; ++c) ao[0][c] = EXP_MFMA(b[sI][c][t], a0[sI][t], ao[0][c]);
+    };
+    ldw(0, 0);
+    int ks = 0;
+    for (; ks + 2 <= kc0; ks += 2) {
+      stepA(std::integral_constant<int, 0>{}, ks);
+      stepA(std::integral_constant<int, 1>{}, ks + 1);
+    }
+    if (ks < kc0) stepA(std::integral_constant<int, 0>{}, ks);
+  }
   {
-    const int k0 = k_at(0, rot, nk, 0);
+    const int k0 = k_at(0, rot, nk, kc0);
     const float* __restrict__ Pk = P + (size_t)k0 * 16 * Np;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) b[0][c] = load_bp_s(Pk, lane_off + c * 256);
@@ -297,8 +383,15 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
     for (int i = 0; i < NX; ++i) ax[0][i] = *reinterpret_cast<const f32x4*>(arowx + i * 16 * lda + k0 * 16);
   }
   __builtin_amdgcn_sched_barrier(0);
-  nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
-  {
+  if constexpr (PRE) {
+#pragma unroll
+    for (int rb = 0; rb < kNbRb; ++rb)
+#pragma unroll
+      for (int c = 0; c < CNT; ++c) acc[rb][c] = ao[0][c];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xacc[i] = ao[0][CNT];
+  } else {
+    nb_bias_acc<CNT, kNbRb>(braw, col0, N, lane, acc);
     f32x4 xa[NX][1];
     nb_bias_acc<1, NX>(brawx, colx, N, lane, xa);
 #pragma unroll
@@ -308,7 +401,7 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
   auto step = [&](auto s_c, int kc) {
     constexpr int s = decltype(s_c)::value;
     constexpr int sa = ADB ? s : 0, sn = ADB ? (s ^ 1) : 0;
-    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, 0);  // last step: a harmless re-load
+    const int kn = k_at(kc + 1 < nk ? kc + 1 : kc, rot, nk, kc0);  // last step: a harmless re-load
     const float* __restrict__ Pk = P + (size_t)kn * 16 * Np;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) b[s ^ 1][c] = load_bp_s(Pk, lane_off + c * 256);
@@ -373,16 +466,16 @@ __device__ __forceinline__ void nb_mm_x(const float* lds, int lda, int nk, const
   if (kc < nk) step(integral_constant<int, 0>{}, kc);
 }
 
-template <int CNT, int NX, bool ADB = true>
+template <int CNT, int NX, bool ADB = true, bool PRE = false>
 __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int N, const float* __restrict__ P,
                                                 const float* __restrict__ bias, int act, int cb0, int cbx, int rbx0,
-                                                int lane, int pl) {
+                                                int lane, int pl, const int kc0) {
   (void)pl;
   f32x4 acc[kNbRb][CNT], xacc[NX];
   f32x4 braw[CNT], brawx[1];
   nb_bias<CNT>(bias, cb0 * 16, N, lane, braw);
   nb_bias<1>(bias, cbx * 16, N, lane, brawx);
-  nb_mm_x<CNT, NX, ADB>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl);
+  nb_mm_x<CNT, NX, ADB, PRE>(lds, lda, round16(K) >> 4, P, round16(N), cb0 * 16, cbx * 16, rbx0, N, braw, brawx, acc, xacc, pl, kc0);
   PHASE_STAMP(2 + 4 * pl);
   __syncthreads();  // every wave finished reading the previous activations
   PHASE_STAMP(3 + 4 * pl);
@@ -405,7 +498,7 @@ __device__ __forceinline__ void nb_wide_layer_x(float* lds, int lda, int K, int 
 // owns 3 column blocks, the 25th is shared by rows over waves 0..4 -- 16 / 15 register tiles per wave instead of 32 / 31,
 // i.e. <= 160 registers per lane instead of 339: the chain's 8-wave workgroups (2 x 96 registers per SIMD) then fit on
 // the CU beside this one, which at one 339-register wave per SIMD they do not; DESIGN.md section 3 "round 4")
-template <int NCB, bool SHARED, int NW, class AR, bool LIST = false>
+template <int NCB, bool SHARED, int NW, class AR, bool LIST = false, bool PREFIX = false>
 __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 16 * kNbRb;
@@ -414,6 +507,18 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int e = blockIdx.y, row0 = blockIdx.x * BM;
   int rows = a.in.rows;
+  // tile row r -> row of the launch.  Plain: 16 kNbRb consecutive rows.  PREFIX (osrl_rows_t.share0, rows = n B + b): row
+  // block rb = sample s0 + rb of the 16 src0 rows b0 .. b0 + 15 -- tiles are dealt [sample group][src0 group], every tile whole
+  int sh_s0 = 0, sh_b0 = 0;
+  if constexpr (PREFIX) {
+    const int ogn = a.in.div0 >> 4, sg = blockIdx.x / ogn;
+    sh_s0 = sg * kNbRb;
+    sh_b0 = (blockIdx.x - sg * ogn) * 16;
+  }
+  auto grow = [&](int r) -> int {
+    if constexpr (PREFIX) return (sh_s0 + (r >> 4)) * a.in.div0 + sh_b0 + (r & 15);
+    else return row0 + r;
+  };
   const int lda = a.lda, L = a.net.n_layers;
   if constexpr (LIST) {  // a row set chosen on the device (osrl_rows_t.row_list): its size is a device word, the grid is sized
     const int nd = a.in.n_rows_dev[0];  // for the list's capacity -- workgroups past the count leave before any barrier
@@ -452,7 +557,7 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     float v[kPasses][kColChunks];
 #pragma unroll
     for (int p = 0; p < kPasses; ++p) {
-      const int gr = row0 + p * kRowsPass + rl;
+      const int gr = grow(p * kRowsPass + rl);
       const bool rok = gr < rows_v && (BM % kRowsPass == 0 || p * kRowsPass + rl < BM);
       unsigned grc = (unsigned)(rok ? gr : rows_v - 1);
       if constexpr (LIST) grc = (unsigned)a.in.row_list[grc];  // (one more dependent load in front of the tile's: this form only)
@@ -477,23 +582,27 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     __syncthreads();
   }
   PHASE_STAMP(1);
-  for (int l = 0; l + 1 < L; ++l) {  // wide layers
+  auto wide = [&](const int l, auto pre_tag) {  // one wide layer; pre_tag: layer 0 of a shared-src0-rows tile (nb_share_acc)
+    constexpr bool PRE = decltype(pre_tag)::value;
     const int K = a.net.dims[l], N = a.net.dims[l + 1];
     const int nblk = (N + 15) >> 4;
+    const int pre = PRE ? a.in.share_k16 : 0;  // phase A's k-steps (nb_share_acc)
     if constexpr (SHARED && NW == 8) {  // 8q + 1 blocks (25): q = 3 each, the last one shared by rows over waves 0..4
       const int q = nblk >> 3;
       if (wave < kNbRb)
-        nb_wide_layer_x<NCB - 1, 1, OSRL_NB8_ADB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q,
-                                                  8 * q, wave, lane, l);
+        nb_wide_layer_x<NCB - 1, 1, OSRL_NB8_ADB, PRE>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q,
+                                                       8 * q, wave, lane, l, pre);
       else
-        nb_wide_layer<NCB - 1, OSRL_NB8_ADB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, lane, l);
+        nb_wide_layer<NCB - 1, OSRL_NB8_ADB, PRE>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, lane, l,
+                                                  pre);
     } else if constexpr (SHARED) {  // 4q + 1 blocks (400-wide: 25): q each, the last one shared by rows
       const int q = nblk >> 2;
       if (wave == 0)
-        nb_wide_layer_x<NCB - 1, 2>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane, l);
+        nb_wide_layer_x<NCB - 1, 2, true, PRE>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], 0, 4 * q, 0, lane, l,
+                                               pre);
       else
-        nb_wide_layer_x<NCB - 1, 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, 4 * q,
-                                    wave + 1, lane, l);
+        nb_wide_layer_x<NCB - 1, 1, true, PRE>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], wave * q, 4 * q,
+                                               wave + 1, lane, l, pre);
     } else {
       int cb0, cnt;
       wave_blocks<NW>(nblk, wave, &cb0, &cnt);
@@ -501,19 +610,22 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
       const float* __restrict__ hw = headl ? a.net.Wf[e][L - 1] : nullptr;
       float* part = headl ? s_head + wave * BM : nullptr;
       if (cnt == NCB)
-        nb_wide_layer<NCB>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l, hw, part);
+        nb_wide_layer<NCB, true, PRE>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l, pre, hw, part);
       else
-        nb_wide_layer<NCB - 1>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l, hw, part);
+        nb_wide_layer<NCB - 1, true, PRE>(lds, lda, K, N, a.net.Wf[e][l], a.net.b[e][l], a.net.acts[l], cb0, lane, l, pre, hw,
+                                          part);
     }
-  }
+  };
+  if constexpr (PREFIX) wide(0, std::true_type{});
+  for (int l = PREFIX ? 1 : 0; l + 1 < L; ++l) wide(l, std::false_type{});
   if (!SHARED && a.fuse_head) {  // ---- one-output head: the waves' partial dot products, summed in wave order
     __syncthreads();
     const int l = L - 1;
-    if (tid < BM && row0 + tid < rows) {
+    if (tid < BM && grow(tid) < rows) {
       float sacc = s_head[tid];
 #pragma unroll
       for (int w = 1; w < NW; ++w) sacc += s_head[w * BM + tid];
-      a.y[e][row0 + tid] = act_fwd(a.net.acts[l], sacc + a.net.b[e][l][0]) * a.net.out_scale;
+      a.y[e][grow(tid)] = act_fwd(a.net.acts[l], sacc + a.net.b[e][l][0]) * a.net.out_scale;
     }
     PHASE_STAMP(5 + 4 * l);
     WG_LOG(1);
@@ -576,11 +688,11 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
     float* __restrict__ y = a.y[e];
     for (int idx = tid; idx < BM * N; idx += 64 * NW) {
       const int r = idx / N, c = idx - r * N;
-      if (row0 + r < rows) {
+      if (grow(r) < rows) {
         const float* p = lds + r * lda + c;
         float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
         if constexpr (NW == 8) sacc = (((sacc + p[4 * Np]) + p[5 * Np]) + p[6 * Np]) + p[7 * Np];
-        y[(size_t)(row0 + r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
+        y[(size_t)grow(r) * N + c] = act_fwd(act, sacc + bias[c]) * oscale;
       }
     }
     if (a.kl && e == 0) {
@@ -588,7 +700,7 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
       // one launch and one read of the head off the side chain's tail
       const int Lz = a.kl_L;
       for (int r = tid; r < BM; r += 64 * NW) {
-        if (row0 + r < rows) {
+        if (grow(r) < rows) {
           auto outv = [&](int c) {
             const float* p = lds + r * lda + c;
             float sacc = ((p[0] + p[Np]) + p[2 * Np]) + p[3 * Np];
@@ -601,7 +713,7 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
             const float sd = expf(fminf(fmaxf(outv(Lz + k), kNbLsMin), kNbLsMax));
             s_ += -0.5f * (1.0f + logf(sd * sd) - mean * mean - sd * sd);
           }
-          a.kl[row0 + r] = s_ / (float)Lz;
+          a.kl[grow(r)] = s_ / (float)Lz;
         }
       }
     }
@@ -613,14 +725,16 @@ __device__ __forceinline__ void mlp_fwd_nb_body(AR a) {
 // anyway -- with the one-output head fused in, the allocator took 205 VGPRs + 80 AGPRs where 512 are free, which left the
 // chain kernels of the other graph branch two 96-register waves per SIMD beside it instead of three: C2 2215-2221 vs
 // 2309-2322 steps/s with the cap (205 registers, accumulators in VGPRs), profiles/r6_nb_registers_ab.txt)
-template <int NCB, bool SHARED = false, bool LIST = false>
+// (PREFIX: tiles of shared src0 rows, osrl_rows_t.share0 / nb_share_acc above -- instantiations of their own, so that the plain
+// forms keep their register counts)
+template <int NCB, bool SHARED = false, bool LIST = false, bool PREFIX = false>
 __global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel(const NbArgs a) {
-  mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&, LIST>(a);
+  mlp_fwd_nb_body<NCB, SHARED, 4, const NbArgs&, LIST, PREFIX>(a);
 }
-template <int NCB, bool SHARED = false, bool LIST = false>
+template <int NCB, bool SHARED = false, bool LIST = false, bool PREFIX = false>
 __global__ __launch_bounds__(256, (kNbRb == 4 || NCB == 4) ? 2 : 1) void mlp_fwd_nb_kernel_p(const void* p) {
   OSRL_TRACE_BEGIN(8, p);
-  mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&, LIST>(*(const OSRL_CAS NbArgs*)p);
+  mlp_fwd_nb_body<NCB, SHARED, 4, const OSRL_CAS NbArgs&, LIST, PREFIX>(*(const OSRL_CAS NbArgs*)p);
 }
 // the 8-wave form (25-block layers): NCB - 1 = 3 column blocks per wave
 #ifndef OSRL_NB8_WPE
@@ -634,6 +748,13 @@ __global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_k
   OSRL_TRACE_BEGIN(9, p);
   mlp_fwd_nb_body<4, true, 8, const OSRL_CAS NbArgs&>(*(const OSRL_CAS NbArgs*)p);
 }
+__global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_pre_kernel(const NbArgs a) {
+  mlp_fwd_nb_body<4, true, 8, const NbArgs&, false, true>(a);
+}
+__global__ __launch_bounds__(512, OSRL_NB8_WPE) OSRL_NB8_ATTR void mlp_fwd_nb8_pre_kernel_p(const void* p) {
+  OSRL_TRACE_BEGIN(9, p);
+  mlp_fwd_nb_body<4, true, 8, const OSRL_CAS NbArgs&, false, true>(*(const OSRL_CAS NbArgs*)p);
+}
 
 // the 8-wave form of the 13..16-block (<= 256-wide) nets: 2 column blocks per wave, two waves per SIMD (the 4-wave form
 // runs ONE wave per SIMD -- its 84.5 KB activation tile allows one workgroup per CU -- so nothing covers a wave's
@@ -646,18 +767,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_nb8n_kernel_p(const void* p) {
 }
 
 // ---- host side of mlp_fwd_nb_kernel: eligibility + launch (tile_rows = 80) ------------------------------------
-template <int NCB, bool SHARED = false, bool LIST = false>
+template <int NCB, bool SHARED = false, bool LIST = false, bool PREFIX = false>
 static int launch_nb(const NbArgs& a, int tiles, int nets, size_t lds_bytes, hipStream_t stream) {
   const void* dev_args = osrl_argmem::slot(a);
-  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED, LIST>)
-                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED, LIST>),
+  hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb_kernel_p<NCB, SHARED, LIST, PREFIX>)
+                                              : reinterpret_cast<const void*>(mlp_fwd_nb_kernel<NCB, SHARED, LIST, PREFIX>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   (void)hipGetLastError();
   if (dev_args)
-    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED, LIST>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel_p<NCB, SHARED, LIST, PREFIX>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, dev_args);
   else
-    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED, LIST>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((mlp_fwd_nb_kernel<NCB, SHARED, LIST, PREFIX>), dim3(tiles, nets, 1), dim3(256), lds_bytes, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -689,6 +810,15 @@ __attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, 
   NbArgs a{};
   a.net = *net;
   a.in = *in;
+  bool share = false;
+  if (in->share0) {  // tiles of [kNbRb copies] x [16 src0 rows] (nb_share_acc): rows = n * div0 + b, every tile whole, phase A =
+    // the whole 16-column k-steps inside src0's columns with at least one k-step left for phase B.  A HINT: the launch
+    // computes the same function either way -- where the shape or the kernel form does not allow it, the plain tiles run
+    const int nk0 = (((net->dims[0] + 15) & ~15) >> 4), B0 = in->div0;
+    share = !in->row_list && in->map0 == OSRL_MAP_MOD && B0 >= 16 && !(B0 & 15) && in->rows % B0 == 0 &&
+            (in->rows / B0) % kNbRb == 0 && in->share_k16 >= 1 && in->share_k16 < nk0 && 16 * in->share_k16 <= in->d0;
+  }
+  a.in.share0 = 0;  // (set again where a shared-row form takes the launch: the plain kernels' descriptors stay as they were)
   for (int e = 0; e < OSRL_MAX_NETS; ++e) a.y[e] = e < nets ? out->h[e][L - 1] : nullptr;
   a.lda = lda;
   a.kl = kl;
@@ -715,13 +845,21 @@ __attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, 
   const char* nb_env = getenv("OSRL_NB_WAVES");  // (read per launch: a test flips it between calls)
   const bool nb8 = !(nb_env && atoi(nb_env) == 4);
   if (shared && nb8 && lda >= 8 * ((NL + 15) & ~15)) {
+    a.in.share0 = share ? 1 : 0;
     const void* dev_args = osrl_argmem::slot(a);
-    hipError_t e = hipFuncSetAttribute(dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb8_kernel_p)
-                                                : reinterpret_cast<const void*>(mlp_fwd_nb8_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const void* fn = share ? (dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb8_pre_kernel_p)
+                                         : reinterpret_cast<const void*>(mlp_fwd_nb8_pre_kernel))
+                             : (dev_args ? reinterpret_cast<const void*>(mlp_fwd_nb8_kernel_p)
+                                         : reinterpret_cast<const void*>(mlp_fwd_nb8_kernel));
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
     (void)hipGetLastError();
-    if (dev_args)
+    if (share) {
+      if (dev_args)
+        hipLaunchKernelGGL(mlp_fwd_nb8_pre_kernel_p, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, dev_args);
+      else
+        hipLaunchKernelGGL(mlp_fwd_nb8_pre_kernel, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
+    } else if (dev_args)
       hipLaunchKernelGGL(mlp_fwd_nb8_kernel_p, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, dev_args);
     else
       hipLaunchKernelGGL(mlp_fwd_nb8_kernel, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
@@ -756,6 +894,10 @@ __attribute__((visibility("hidden"))) int OSRL_NB_LAUNCH(const osrl_mlp_t* net, 
         hipLaunchKernelGGL(mlp_fwd_nb8n_kernel, dim3(tiles, nets, 1), dim3(512), lds_bytes, stream, a);
       return (int)hipGetLastError();
     }
+  }
+  if (share && ncb == 4 && !shared) {  // (the shared-row forms: 4-wave 13..16-block nets here, 8-wave 25-block nets above)
+    a.in.share0 = 1;
+    return launch_nb<4, false, false, true>(a, tiles, nets, lds_bytes, stream);
   }
   if (shared) return launch_nb<7, true>(a, tiles, nets, lds_bytes, stream);
   return ncb == 4 ? launch_nb<4>(a, tiles, nets, lds_bytes, stream) : launch_nb<7>(a, tiles, nets, lds_bytes, stream);

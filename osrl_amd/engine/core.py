@@ -418,14 +418,30 @@ class MlpRun:
                 "osrl_mlp_forward2")
         return self.y, other.y
 
+    def share_k16(self, d0: int, src0_rows: int, copies: int) -> int:
+        """How many whole 16-column k-steps of layer 0 a shared-src0-rows launch (osrl_rows_t.share0) can run once per src0
+        row: those inside src0's ``d0`` columns, at least one k-step left -- or 0 where the form does not exist (tile shape:
+        src0 rows a multiple of 16, copies a multiple of the 80-row tile's five row blocks)."""
+        dims = self.net.dims
+        k16 = d0 // 16
+        if k16 * 16 >= ((dims[0] + 15) // 16) * 16:
+            k16 -= 1
+        if k16 < 1 or src0_rows % 16 or copies % 5 or self.rows != src0_rows * copies:
+            return 0
+        return k16
+
     def forward(self, src0: torch.Tensor, src1: Optional[torch.Tensor] = None, map0=L.MAP_ID, div0=1,
                 map1=L.MAP_ID, div1=1, tail: Optional["L.TailT"] = None, row_list: Optional[torch.Tensor] = None,
-                n_rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                n_rows_dev: Optional[torch.Tensor] = None, share_k16: int = 0) -> torch.Tensor:
         """``tail``: an osrl_mlp_tail_t applied by the launch itself to net 0's output tile (osrl_mlp_forward_tail).
         ``row_list`` / ``n_rows_dev`` (int32 device tensors): the launch runs on the rows ``row_list[0 .. n_rows_dev[0])``
-        of the virtual input, outputs compacted in that order (osrl_rows_t.row_list; ``self.rows`` = the capacity)."""
+        of the virtual input, outputs compacted in that order (osrl_rows_t.row_list; ``self.rows`` = the capacity).
+        ``share_k16`` > 0 (rows = n * div0 + b, map0 = MAP_MOD): tiles of shared src0 rows, the first ``16 share_k16`` input
+        columns of layer 0 once per src0 row of a tile (osrl_rows_t.share0; ``self.share_k16()`` says how many)."""
         r = L.RowsT()
         r.rows = self.rows
+        if share_k16:
+            r.share0, r.share_k16 = 1, int(share_k16)
         if row_list is not None:
             assert row_list.dtype == torch.int32 and n_rows_dev.dtype == torch.int32 and row_list.numel() >= self.rows
             r.row_list, r.n_rows_dev = row_list.data_ptr(), n_rows_dev.data_ptr()

@@ -151,6 +151,12 @@ class CPQEngine:
         self.r_enc_ood = MlpRun(self.d_enc, N * B, False, dev,
                                 wg_cap=int(P.knob("OSRL_ENC_WG_CAP", "0", "workgroup cap of the N*B encoder launch")),
                                 tile_rows=int(P.knob("OSRL_ENC_TILE", str(ood_tile or 80), "row tile of the N*B encoder launch")))
+        # shared-observation tiles of the two N*B-row launches (plan.ood_share): their rows are the B observations N times over
+        # (cpq.py:164-176), so the observation part of layer 0 runs once per observation of a tile (osrl_rows_t.share0)
+        self.pre_cost = self.pre_enc = 0
+        if pl.ood_share and ood_tile == 80 and not self.ood_rows:
+            self.pre_cost = self.r_costold_ood.share_k16(od, B, N)
+            self.pre_enc = self.r_enc_ood.share_k16(od, B, N)
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)
@@ -376,7 +382,7 @@ class CPQEngine:
             qc_s = None
             if not self.ood_rows:  # (plan.ood_rows: this forward runs BEHIND the KL quantile, on the rows that pass it)
                 self._pr("costold_ood", 0)
-                qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B)
+                qc_s = self.r_costold_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, share_k16=self.pre_cost)
                 self._pr("costold_ood", 1)
             if nxt is not None and self.plan.pipe_prologue == "critic":
                 # the next step's prologue HERE: the main chain waits for this branch's critic Adam below (ev_critic), so
@@ -444,7 +450,8 @@ class CPQEngine:
                 self._update("vae", 0.0)  # (engine/plan.py vae_adam_side: off the main chain, in front of its only reader)
             self._pr("enc_ood", 0)  # bench.py: HIP events around the dominant launch as it runs inside the step
             # (the KL rows of cpq.py:178-182 by the encoder launch itself: OSRL_TAIL_VAE_KL)
-            self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl))
+            self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl),
+                                   share_k16=self.pre_enc)
             self._pr("enc_ood", 1)
             kl_on_side = dp is not None and par.enabled and DP_SIDE_COLL
             if kl_on_side:

@@ -70,6 +70,8 @@ class CPQPlan:
     vae_adam_side: bool       # single GPU: the VAE's optimizer step at the head of the side branch's second half
     steps_per_graph: int      # engine.steps_replay(): train steps per replayed hipGraph (engine/pipeline.py); 1 = one step
     ood_rows: bool = False    # single GPU: the target cost critics of the OOD penalty on the SELECTED rows only (cpq.py:183-184)
+    ood_share: bool = False   # the two N*B-row launches on tiles of shared observations: the observation part of layer 0 once
+    #                           per observation of a tile (osrl_rows_t.share0)
     pipe_no_join: bool = False   # pipelined graphs: no join between the steps of a graph (the dual step of step k at the head
     #                              of step k+1's side branch)
     pipe_prologue: str = "early"  # pipelined graphs: where step k+1's prologue sits on step k's side branch: in front of the
@@ -140,9 +142,17 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     # early part of the side branch to its tail, behind a 30-50 us single-workgroup select.  Off unless asked for.
     ood_rows = knob("OSRL_OOD_ROWS", "0", "target cost critics on the selected OOD rows only (single GPU): 1 / 0") == "1" \
         and ood_tile == 80 and ood_rows_ok(od, ad, B, N, c_hidden)
+    # the N*B rows of the two OOD launches are the B observations N times over (cpq.py:164-176): on tiles of [5 copies] x [16
+    # observations] the observation columns of layer 0 are multiplied once per observation (osrl_rows_t.share0, csrc/mlp_nb.hip
+    # nb_share_acc; second session of round 6).  Isolated launches at C2: cost critics 69.4 -> 60.9 us, encoder 72.1 -> 65.7;
+    # step, three alternating rounds: C2 2430-2448 against 2386-2395 (+2.3 %), C4 (one of two k-steps) 2419-2445 against 2411-2448
+    # (gpurun_out/r6share).  The outputs differ from the plain launch by fp32 rounding (another order of a row's sum); they
+    # feed qc_ood / the KL quantile only -- no gradient to any network (cpq.py:155-186) -- so parameters are the same bits.
+    ood_share = knob("OSRL_OOD_SHARE", "1", "N*B-row launches on tiles of shared observations (observation part of layer 0 once per observation): 1 / 0") == "1" \
+        and ood_tile == 80 and od >= 16 and B % 16 == 0 and N % 5 == 0
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=ood_tile, vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg,
-                   ood_rows=bool(ood_rows), pipe_no_join=bool(no_join), pipe_prologue=pro)
+                   ood_rows=bool(ood_rows), ood_share=bool(ood_share), pipe_no_join=bool(no_join), pipe_prologue=pro)
 
 
 def vae_ns_auto(rows: int, od: int, ad: int, vae_hidden: int = 400) -> bool:
@@ -193,10 +203,10 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True,
-                   steps_per_graph=20, ood_rows=False, pipe_no_join=True, pipe_prologue="head")),
+                   steps_per_graph=20, ood_rows=False, ood_share=True, pipe_no_join=True, pipe_prologue="head")),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
-                   steps_per_graph=8, ood_rows=False, pipe_no_join=True, pipe_prologue="critic")),
+                   steps_per_graph=8, ood_rows=False, ood_share=True, pipe_no_join=True, pipe_prologue="critic")),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
            BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6, steps_per_graph=10)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4, c_hidden=(32, 32)),

@@ -280,6 +280,94 @@ def test_mlp_fwd_big_rows(ci):
     assert np.abs(outs[0] - outs[1]).max() < 3e-5 * max(1.0, np.abs(outs[1]).max())
 
 
+SHARE_CASES = [
+    # E, dims, acts, out_scale, src0 rows B, copies N, d0, form
+    (2, [78, 256, 256, 1], ["relu", "relu", "id"], 1.0, 256, 10, 76, "80"),    # C2's target cost critics: 4 of 5 k-steps once per observation
+    (1, [78, 400, 400, 16], ["relu", "relu", "id"], 1.0, 256, 10, 76, "80"),   # C2's VAE encoder: the 8-wave 25-block form
+    (2, [23, 256, 256, 1], ["relu", "relu", "id"], 1.0, 304, 5, 17, "80"),     # C4: od = 17 -> one of two k-steps
+    (2, [41, 250, 230, 1], ["tanh", "tanh", "tanh"], 2.0, 160, 15, 33, "80"),  # ragged widths, tanh, scaled head, 3 sample groups
+    (3, [41, 256, 256, 4], ["relu", "relu", "id"], 1.0, 512, 8, 33, "64"),     # the 64-row form: 4 copies per tile
+    (1, [78, 400, 400, 16], ["relu", "relu", "id"], 1.0, 250, 10, 76, "80"),   # B % 16 != 0: the hint is not taken, plain tiles run
+]
+
+
+@pytest.mark.parametrize("ci", range(len(SHARE_CASES)))
+def test_mlp_fwd_big_rows_shared_src0_tiles(ci):
+    """osrl_rows_t.share0: the rows of CPQ's N*B-row inference launches are the B observations N times over (row = n B + b,
+    cpq.py:164-176), so a tile of [copies] x [16 observations] computes the part of layer 0 that lies inside the observation
+    columns once per observation (csrc/mlp_nb.hip nb_share_acc) and walks only the remaining k-steps per row.  Same products,
+    another order of a row's sum: within fp32 rounding of the plain launch (gate 2e-6 of the output scale; both forms within
+    the fp64 gate of test_mlp_fwd_big_rows), incl. the KL rows the encoder launch leaves as its tail.  The switch is a hint:
+    a shape that does not tile (case 5) runs the plain form -- bit-equal."""
+    from osrl_amd.engine import glue as G
+    from osrl_amd.engine.core import FlatGroup, LayerRef, MlpRun, NetDesc
+    E, dims, acts, oscale, B, N, d0, form = SHARE_CASES[ci]
+    dev = _dev()
+    rs = np.random.RandomState(300 + ci)
+    grp = FlatGroup("t", dev)
+    for e in range(E):
+        for l in range(len(dims) - 1):
+            grp.add(f"{e}.{l}.w", (dims[l + 1], dims[l]))
+            grp.mark_weight(f"{e}.{l}.w")
+            grp.add(f"{e}.{l}.b", (dims[l + 1],))
+    grp.finalize()
+    refs, Ws = [], []
+    for e in range(E):
+        rr, ww = [], []
+        for l in range(len(dims) - 1):
+            k = 1 / math.sqrt(dims[l])
+            W, b = grp.view(f"{e}.{l}.w"), grp.view(f"{e}.{l}.b")
+            W.copy_(torch.tensor(rs.uniform(-k, k, W.shape), dtype=torch.float32))
+            b.copy_(torch.tensor(rs.uniform(-k, k, b.shape), dtype=torch.float32))
+            rr.append(LayerRef(W, b, grp, f"{e}.{l}.w", f"{e}.{l}.b"))
+            ww.append((W.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)))
+        refs.append(rr)
+        Ws.append(ww)
+    grp.repack()
+    rows = N * B
+    src0 = torch.tensor(rs.randn(B, d0), dtype=torch.float32, device=dev)
+    src1 = torch.tensor(rs.randn(rows, dims[0] - d0), dtype=torch.float32, device=dev)
+    desc = NetDesc(refs, acts, oscale)
+    desc.c.tile_rows = 80
+    run = MlpRun(desc, rows, False, dev)
+    k16 = d0 // 16
+    kl_tail = dims[-1] == 16  # (the VAE encoder's launch: KL rows as its tail, osrl_mlp_forward_tail)
+    kl_a, kl_b = torch.zeros(rows, device=dev), torch.zeros(rows, device=dev)
+    os.environ["OSRL_NB64"] = "1" if form == "64" else "0"
+    try:
+        plain = torch.stack([t.clone() for t in run.forward(src0, src1, map0=1, div0=B,
+                                                            tail=G.vae_kl_tail(8, kl_a) if kl_tail else None)]).cpu().numpy()
+        assert (run.share_k16(d0, B, N) == k16) == (B % 16 == 0 and N % 5 == 0)
+        got = torch.stack([t.clone() for t in run.forward(src0, src1, map0=1, div0=B, share_k16=k16,
+                                                          tail=G.vae_kl_tail(8, kl_b) if kl_tail else None)]).cpu().numpy()
+    finally:
+        os.environ.pop("OSRL_NB64", None)
+    torch.cuda.synchronize()
+    idx0 = np.arange(rows) % B
+    X = np.concatenate([src0.cpu().numpy().astype(np.float64)[idx0], src1.cpu().numpy().astype(np.float64)], 1)
+    for e in range(E):
+        h = X
+        for l, a in enumerate(acts):
+            h = _act64(a, h @ Ws[e][l][0].T + Ws[e][l][1])
+        h = h * oscale
+        scale = max(1.0, np.abs(h).max())
+        assert np.abs(got[e].reshape(h.shape) - h).max() < 3e-5 * scale, f"case {ci} net {e}: shared-row form vs fp64"
+        d = np.abs(got[e] - plain[e]).max()
+        assert d < 2e-6 * scale, f"case {ci} net {e}: shared-row form vs plain launch {d:.3e}"
+    if B % 16:
+        assert np.array_equal(got, plain), "a shape that does not tile runs the plain form"
+    if kl_tail:
+        ka, kb = kl_a.cpu().numpy(), kl_b.cpu().numpy()
+        assert np.isfinite(kb).all() and np.abs(ka - kb).max() < 1e-5 * max(1.0, np.abs(ka).max())
+    # the tile kernels ignore the hint: same bits as their plain launch
+    desc16 = NetDesc(refs, acts, oscale)
+    desc16.c.tile_rows = 16
+    run16 = MlpRun(desc16, rows, False, dev)
+    y0 = torch.stack([t.clone() for t in run16.forward(src0, src1, map0=1, div0=B)])
+    y1 = torch.stack([t.clone() for t in run16.forward(src0, src1, map0=1, div0=B, share_k16=k16)])
+    assert torch.equal(y0, y1)
+
+
 def test_mlp_forward_pair_equals_two_launches():
     """osrl_mlp_forward2 (two independent problems, one launch) == two osrl_mlp_forward calls, incl. saved
     activations, different row counts / net counts / input widths, and the fallback for unequal tile shapes."""

@@ -27,7 +27,7 @@ def test_ctypes_struct_sizes_match_c():
     import ctypes as C
     from osrl_amd import _lib as L
     assert C.sizeof(L.MlpT) == 56 + 3 * 8 * 4 * 8 and C.sizeof(L.PackEntryT) == 32
-    assert C.sizeof(L.RowsT) == 64 and C.sizeof(L.ActsT) == 8 + 8 * 4 * 8
+    assert C.sizeof(L.RowsT) == 72 and C.sizeof(L.ActsT) == 8 + 8 * 4 * 8
     assert C.sizeof(L.GradsT) == 64 + 256 + 64 + 8 and C.sizeof(L.DwEntryT) == 48 and C.sizeof(L.StepStateT) == 24
 
 

@@ -71,8 +71,11 @@ def test_adam_requests_every_operand_up_front(listings):
 
 def test_nb_forward_kernel_shape(listings):
     """mlp_fwd_nb_kernel: no scratch, one wave's registers within the file, float4 epilogue stores."""
-    # (third template argument, round 6: the LIST instantiation that reads a device-chosen row set -- <4, false, true>)
-    for inst in ("ILi7ELb1ELb0E", "ILi4ELb0ELb0E", "ILi7ELb0ELb0E", "ILi4ELb0ELb1E"):
+    # (third template argument, round 6: the LIST instantiation that reads a device-chosen row set -- <4, false, true>;
+    # fourth, second session: tiles of shared src0 rows (osrl_rows_t.share0) -- an instantiation of its own so that the plain
+    # form keeps its registers: the chain kernels of the other graph branch fit beside <= 208 of them)
+    regs = {}
+    for inst in ("ILi7ELb1ELb0ELb0E", "ILi4ELb0ELb0ELb0E", "ILi7ELb0ELb0ELb0E", "ILi4ELb0ELb1ELb0E", "ILi4ELb0ELb0ELb1E"):
         shapes = []
         # by-value kernel and its device-resident-descriptor twin (csrc/argmem.h): the same body behind one extra
         # scalar load -- same registers, same stores
@@ -82,6 +85,11 @@ def test_nb_forward_kernel_shape(listings):
             assert r["b128_writes"] >= 60, (needles, r)  # the transposed-tile epilogue (ds_write_b32 per element before)
             shapes.append((r["vgprs"], r["b128_writes"]))
         assert shapes[0] == shapes[1], (inst, shapes)
+        regs[inst] = shapes[0][0]
+    assert regs["ILi4ELb0ELb0ELb0E"] <= 208 and regs["ILi4ELb0ELb0ELb1E"] <= 208, regs
+    for needle in ("mlp_fwd_nb8_kernelE", "mlp_fwd_nb8_kernel_pE", "mlp_fwd_nb8_pre_kernelE", "mlp_fwd_nb8_pre_kernel_pE"):
+        r = _one(listings["mlp_nb"], needle)  # the 8-wave 25-block form and its shared-row twin: two <= 160-register waves per
+        assert r["scratch"] == 0 and 0 < r["vgprs"] <= 160, (needle, r)  # SIMD leave room for two 96-register chain waves
 
 
 def test_descriptor_pointer_kernels_read_their_arguments_with_scalar_loads(listings):
