@@ -61,6 +61,7 @@ class CPQEngine:
         self.st = StepState(dev, STAT_KEYS)
         self._prologue_covered = False
         self._actor_pending = False
+        self._polyak_pending = False
         self._ev_prologue = None    # (pipelined graphs, plan.pipe_no_join: event behind the next step's prologue)
         self._dual_pending = False  # (this step's dual step is still to be issued by the next step of the graph)
         nq, nqc = m.num_q, m.num_qc
@@ -154,9 +155,11 @@ class CPQEngine:
         # shared-observation tiles of the two N*B-row launches (plan.ood_share): their rows are the B observations N times over
         # (cpq.py:164-176), so the observation part of layer 0 runs once per observation of a tile (osrl_rows_t.share0)
         self.pre_cost = self.pre_enc = 0
-        if pl.ood_share and ood_tile == 80 and not self.ood_rows:
-            self.pre_cost = self.r_costold_ood.share_k16(od, B, N)
-            self.pre_enc = self.r_enc_ood.share_k16(od, B, N)
+        if pl.ood_share and ood_tile == 80:
+            if not self.ood_rows:  # (a row SET has no tiles of shared observations)
+                self.pre_cost = self.r_costold_ood.share_k16(od, B, N)
+            if not self.ood_rows or P.knob("OSRL_OOD_ROWS_ENC_SHARE", "1", "plan.ood_rows: the N*B-row encoder launch keeps its shared-observation tiles: 1 / 0") == "1":
+                self.pre_enc = self.r_enc_ood.share_k16(od, B, N)
         self.kl = z(N * B)
         self.quant = z(4)
         self.ood_mean = z(4)
@@ -291,7 +294,7 @@ class CPQEngine:
         # its prologue only (issued on step k's side branch: ``_ev_prologue``), and step k's dual step runs at the head of
         # step k+1's side branch, right behind the fork -- the one place of the side branch that already has an edge from
         # the END of step k's main chain (so both halves of the logged cost loss are there) without a new mid-chain edge.
-        no_join = self.plan.pipe_no_join and par.enabled and dp is None and not self.ood_rows
+        no_join = self.plan.pipe_no_join and par.enabled and dp is None
         carried = prev if (no_join and prev is not None and prev._dual_pending) else None
         self._ev_prologue, self._prologue_covered = None, False
         if carried is not None and carried._ev_prologue is not None:
@@ -345,6 +348,13 @@ class CPQEngine:
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
+            if carried is not None and carried._polyak_pending:
+                # (plan.ood_rows in a no-join graph: the cost critics' target update of the previous step -- behind its last
+                # reader, the forward on the selected rows at that step's side-branch tail, and behind its main chain's
+                # optimizer step, which this branch's fork waited for; in front of this step's readers of the targets: the
+                # critic phase on this branch, the cost phase on the main chain through its wait for the action draws)
+                m.groups["cost_critic"].polyak_step(m.tau)
+                carried._polyak_pending = False
             if carried is not None and carried._actor_pending:
                 carried._optim("actor", carried.p_actor, m.tau)
                 carried._actor_pending = False
@@ -424,6 +434,12 @@ class CPQEngine:
         fuse_cost = dp is None and self.p_cost.can_fuse_adam() and not self.ood_rows
         if not fuse_cost:
             self.p_cost.launch()
+        if self.ood_rows and par.enabled and ev_vae is not None and self.plan.ood_rows_late:
+            # (plan.ood_rows_late: without the N*B-row cost-critic launch in its first half the side branch reaches the VAE's
+            # Adam + the N*B-row encoder launch ~70 us earlier -- beside THIS dW launch, whose 384 small workgroups then take
+            # 70 instead of 25 us, gpurun_out/r6oodrows3; the side branch waits for this point instead of the VAE's dW)
+            ev_vae = torch.cuda.Event()
+            ev_vae.record()
         par.wait(ev_critic)  # Adam + Polyak of this group rewrites cost_critic_old: after its readers on the side branch
         if fuse_cost:
             self.p_cost.launch_adam(m._lrs["cost_critic"], st.ptr, tau=m.tau)
@@ -533,6 +549,7 @@ class CPQEngine:
                 self._optim("actor", self.p_actor, m.tau)
             if carry:
                 self._dual_pending = True  # (the next step of this graph runs it: dual_step())
+                self._polyak_pending = bool(self.ood_rows)
                 return
             par.join(0)
         else:  # actor gradient, the per-rank partial statistics and the partial qc_ood mean in one collective

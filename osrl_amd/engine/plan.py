@@ -70,6 +70,7 @@ class CPQPlan:
     vae_adam_side: bool       # single GPU: the VAE's optimizer step at the head of the side branch's second half
     steps_per_graph: int      # engine.steps_replay(): train steps per replayed hipGraph (engine/pipeline.py); 1 = one step
     ood_rows: bool = False    # single GPU: the target cost critics of the OOD penalty on the SELECTED rows only (cpq.py:183-184)
+    ood_rows_late: bool = True   # ... and the side branch's second half then starts behind the cost critics' dW launch
     ood_share: bool = False   # the two N*B-row launches on tiles of shared observations: the observation part of layer 0 once
     #                           per observation of a tile (osrl_rows_t.share0)
     pipe_no_join: bool = False   # pipelined graphs: no join between the steps of a graph (the dual step of step k at the head
@@ -139,9 +140,22 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     # the selected quarter only -- 5.3 of C2's 29.6 issued GFLOP per step gone.  Built, parity-tested (same network
     # parameters bit for bit) and measured at the end of round 6: C2 +0.3 %, C4 +1.3 % (profiles/r6_ood_rows_ab.txt) -- 18 % of
     # the FLOPs buy one per cent because the step is not FLOP-bound; the forward moves from the idle
-    # early part of the side branch to its tail, behind a 30-50 us single-workgroup select.  Off unless asked for.
-    ood_rows = knob("OSRL_OOD_ROWS", "0", "target cost critics on the selected OOD rows only (single GPU): 1 / 0") == "1" \
+    # early part of the side branch to its tail, behind a 30-50 us single-workgroup select (that first form forced the joined graph).
+    # Third session of round 6, inside the no-join graphs (the cost critics' target update of step k carried to the head of
+    # step k+1's side branch, behind its last reader), three changes together make it the rule: (1) it no longer forces the
+    # joined graph; (2) ``ood_rows_late``: the second half of the side branch waits for the cost critics' dW launch instead of
+    # the VAE's -- without the N*B-row cost-critic launch in front of it the branch reaches the N*B-row encoder launch ~70 us
+    # earlier, beside that dW launch, whose 384 small workgroups then take 70 instead of 25 us; (3) the encoder launch keeps
+    # its shared-observation tiles (only the row SET has none).  Alternating rounds, un-profiled clocks:
+    #   C4 2498-2513 (1) / 2528-2541 (1 + 2) / 2527-2552 (1 + 2 + 3) against 2432-2443: +4.3 % (gpurun_out/r6oodrows2, 4, 5);
+    #   C2 2400-2433 (1) / 2441-2469 (1 + 2) / 2458-2475 (all three, five rounds at K = 300) against 2395-2420: +2.3 %; on the
+    #      driver's K = 20 command 2462-2499 (median 2490) against 2404-2459 (median 2433) (gpurun_out/r6oodrows6).
+    # Rule: on wherever the graphs are not joined and the row-set kernel exists.
+    rows_mode = knob("OSRL_OOD_ROWS", "auto", "target cost critics on the selected OOD rows only (single GPU): 1 / 0 / auto")
+    ood_rows = (rows_mode == "1" or (rows_mode == "auto" and bool(no_join))) \
         and ood_tile == 80 and ood_rows_ok(od, ad, B, N, c_hidden)
+    rows_late = knob("OSRL_OOD_ROWS_LATE", "1", "plan.ood_rows: the side branch's second half waits for the cost critics' dW "
+                     "launch instead of the VAE's: 1 / 0") == "1"
     # the N*B rows of the two OOD launches are the B observations N times over (cpq.py:164-176): on tiles of [5 copies] x [16
     # observations] the observation columns of layer 0 are multiplied once per observation (osrl_rows_t.share0, csrc/mlp_nb.hip
     # nb_share_acc; second session of round 6).  Isolated launches at C2: cost critics 69.4 -> 60.9 us, encoder 72.1 -> 65.7;
@@ -152,7 +166,7 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
         and ood_tile == 80 and od >= 16 and B % 16 == 0 and N % 5 == 0
     return CPQPlan(head_tails=bool(head_tails), vae_dw_tile=vt, vae_dw_splits=splits, small_dw=B >= 1024,
                    ood_tile=ood_tile, vae_ns=bool(vae_ns), vae_adam_side=bool(side), steps_per_graph=spg,
-                   ood_rows=bool(ood_rows), ood_share=bool(ood_share), pipe_no_join=bool(no_join), pipe_prologue=pro)
+                   ood_rows=bool(ood_rows), ood_rows_late=bool(rows_late), ood_share=bool(ood_share), pipe_no_join=bool(no_join), pipe_prologue=pro)
 
 
 def vae_ns_auto(rows: int, od: int, ad: int, vae_hidden: int = 400) -> bool:
@@ -203,10 +217,10 @@ def bcql_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = T
 PINNED = {
     "c2": (cpq_plan, dict(od=76, ad=2, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=True, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=True,
-                   steps_per_graph=20, ood_rows=False, ood_share=True, pipe_no_join=True, pipe_prologue="head")),
+                   steps_per_graph=20, ood_rows=True, ood_share=True, pipe_no_join=True, pipe_prologue="head")),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
-                   steps_per_graph=8, ood_rows=False, ood_share=True, pipe_no_join=True, pipe_prologue="critic")),
+                   steps_per_graph=8, ood_rows=True, ood_share=True, pipe_no_join=True, pipe_prologue="critic")),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
            BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6, steps_per_graph=10)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4, c_hidden=(32, 32)),

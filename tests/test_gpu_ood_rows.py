@@ -1,4 +1,5 @@
-"""CPQ's OOD penalty on the rows that count (engine/plan.py ``ood_rows``, opt-in: OSRL_LAB=1 OSRL_OOD_ROWS=1).
+"""CPQ's OOD penalty on the rows that count (engine/plan.py ``ood_rows``: the rule on one GPU wherever the pipelined graphs are
+not joined -- C2, C4; OSRL_LAB=1 OSRL_OOD_ROWS=0 / 1 forces it).
 
 ``qc_ood = ((KL_loss >= quantile) * qc_sampled).mean(0)`` (cpq.py:183-184, under no_grad) multiplies three quarters of the
 N*B target-cost-critic outputs by zero.  The plan runs the VAE encoder on the N*B rows first, takes the quantile and the
@@ -23,11 +24,8 @@ DEV = "cuda:0"
 
 def _wl(name, monkeypatch, on):
     import bench
-    if on:
-        monkeypatch.setenv("OSRL_LAB", "1")
-        monkeypatch.setenv("OSRL_OOD_ROWS", "1")
-    else:
-        monkeypatch.delenv("OSRL_OOD_ROWS", raising=False)
+    monkeypatch.setenv("OSRL_LAB", "1")  # (the rule turns the plan on where the side branch is the long one: C4)
+    monkeypatch.setenv("OSRL_OOD_ROWS", "1" if on else "0")
     wl = bench.Workload(name, torch.device(DEV), 0, 1, None, n_store=1 << 16, use_graph=True)
     assert bool(wl.eng.ood_rows) == on and bool(wl.eng.plan.ood_rows) == on
     return wl
