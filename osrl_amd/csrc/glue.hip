@@ -745,6 +745,7 @@ __global__ __launch_bounds__(kRed) void cpq_ood_select_kernel(const float* __res
   __shared__ uint32_t cnt[34];
   __shared__ uint32_t s_min[17];
   __shared__ uint32_t s_tot[kRed / 64 + 1];
+  OSRL_TRACE_BEGIN(14, list);
   const float quant = quantile_in ? quantile_in[0] : quantile_regs(kl, (int64_t)n, q, cnt, s_min);
   const int per = (n + kRed - 1) / kRed;  // <= 32 (host-checked)
   const int i0 = threadIdx.x * per;
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(kRed) void cpq_ood_sum_kernel(const float* __restri
                                                            const int32_t* __restrict__ count, float scale,
                                                            float* __restrict__ out) {
   __shared__ float sm[20];
+  OSRL_TRACE_BEGIN(15, out);
   int n = count[0];
   n = n < cap ? n : cap;
   float s = 0.f;

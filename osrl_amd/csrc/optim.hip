@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_counts_kernel(float* __restr
 // fp32 values).  For a plan whose LAST reader of the old targets runs after the group's optimizer step (CPQ's OOD rows).
 __global__ __launch_bounds__(256) void polyak_kernel(const float* __restrict__ p, float* __restrict__ tgt, int64_t n4,
                                                      float tau, const int32_t* __restrict__ map_f, float* __restrict__ tf) {
+  OSRL_TRACE_BEGIN(16, tgt);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i];
     const f32x4 tv0 = reinterpret_cast<const f32x4*>(tgt)[i];

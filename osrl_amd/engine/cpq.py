@@ -37,6 +37,12 @@ DP_SIDE_COLL = P.knob("OSRL_DP_SIDE_COLL", "0", "DP: VAE all-reduce / KL gather 
 # (pipelined graphs: where the next prologue sits and whether the steps of a graph are joined are plan fields --
 # engine/plan.py pipe_prologue / pipe_no_join; the lab switch OSRL_PIPE_DUAL=side keeps round 6's side-branch dual step)
 PIPE_DUAL_SIDE = P.knob("OSRL_PIPE_DUAL", "auto") == "side"
+# (no-join graphs with plan.vae_adam_side: the edge from the VAE's optimizer step on step k's side branch to the main chain,
+# whose next VAE phase reads what it wrote -- in front of the actor group's Adam, the last launch of step k's main chain
+# (actor) / at the head of step k+1's main chain (next) / none (0: lab only -- the second session's graphs, ordered by ~100 us
+# of timing slack and nothing else))
+VAE_ADAM_EDGE = P.knob("OSRL_VAE_ADAM_EDGE", "actor", "no-join graphs, VAE Adam on the side branch: its edge to the main chain "
+                       "in front of the actor group's Adam (actor) / at the head of the next step (next) / none (0, lab)")
 # (lab, no-join graphs: the actor group's dW + Adam of step k at the head of step k+1's side branch instead of the tail of
 # step k's main chain -- nothing on the main chain reads the actor before the next trunk launch, which is on that branch)
 PIPE_ACTOR_SIDE = P.knob("OSRL_PIPE_ACTOR", "main", "no-join pipelined steps: the actor group's dW + Adam on the main chain (main) / "
@@ -63,6 +69,7 @@ class CPQEngine:
         self._actor_pending = False
         self._polyak_pending = False
         self._ev_prologue = None    # (pipelined graphs, plan.pipe_no_join: event behind the next step's prologue)
+        self._ev_vae_adam = None    # (... and behind this step's VAE Adam where that runs on the side branch)
         self._dual_pending = False  # (this step's dual step is still to be issued by the next step of the graph)
         nq, nqc = m.num_q, m.num_qc
         c_hidden = [int(l.out_features) for l in m.cost_critic_old.q_nets[0] if isinstance(l, torch.nn.Linear)][:-1]
@@ -299,6 +306,9 @@ class CPQEngine:
         self._ev_prologue, self._prologue_covered = None, False
         if carried is not None and carried._ev_prologue is not None:
             par.wait(carried._ev_prologue)
+        if carried is not None and carried._ev_vae_adam is not None and VAE_ADAM_EDGE == "next":
+            par.wait(carried._ev_vae_adam)  # (this step's VAE phase reads what that optimizer step wrote)
+        self._ev_vae_adam = None
         par.fork(0)
         # ---- main: vae_loss  (cpq.py:125-135)
         sd = self.seeds
@@ -464,6 +474,10 @@ class CPQEngine:
                 par.side[0].wait_event(ev_vae)
             if dp is None and par.enabled and self.plan.vae_adam_side and not self.p_vae.can_fuse_adam():
                 self._update("vae", 0.0)  # (engine/plan.py vae_adam_side: off the main chain, in front of its only reader)
+                if no_join and nxt is not None and VAE_ADAM_EDGE != "0":
+                    # ... of THIS step: the next step's VAE phase, on the main chain, reads it too, and steps that are not
+                    # joined need an edge of their own for that
+                    self._ev_vae_adam = par.mark(0)
             self._pr("enc_ood", 0)  # bench.py: HIP events around the dominant launch as it runs inside the step
             # (the KL rows of cpq.py:178-182 by the encoder launch itself: OSRL_TAIL_VAE_KL)
             self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl),
@@ -543,6 +557,9 @@ class CPQEngine:
             self.r_actor_obs.backward_dz()
         if dp is None:
             carry = no_join and nxt is not None and (self._ev_prologue is not None or self._prologue_covered)
+            if self._ev_vae_adam is not None and (VAE_ADAM_EDGE == "actor" or not carry):
+                par.wait(self._ev_vae_adam)
+                self._ev_vae_adam = None
             if carry and PIPE_ACTOR_SIDE:
                 self._actor_pending = True  # (the next step issues it on its side branch, behind its fork)
             else:

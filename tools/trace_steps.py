@@ -25,7 +25,7 @@ from osrl_amd import _lib as L
 
 NAMES = {1: "step_begin", 2: "vae_ns_l0", 3: "vae_ns_fwd_enc", 40: "vae_ns_gen<0>", 41: "vae_ns_gen<1>", 42: "vae_ns_gen<2>",
          5: "mlp_fwd", 6: "mlp_fwd2", 7: "mlp_bwd_dz", 8: "mlp_fwd_nb", 9: "mlp_fwd_nb8", 11: "adam", 12: "cpq_ood_stat",
-         13: "cpq_alpha_step"}
+         13: "cpq_alpha_step", 14: "cpq_ood_select", 15: "cpq_ood_sum", 16: "polyak"}
 
 
 def main():
