@@ -41,6 +41,13 @@ PIPE_DUAL_SIDE = P.knob("OSRL_PIPE_DUAL", "auto") == "side"
 # whose next VAE phase reads what it wrote -- in front of the actor group's Adam, the last launch of step k's main chain
 # (actor) / at the head of step k+1's main chain (next) / none (0: lab only -- the second session's graphs, ordered by ~100 us
 # of timing slack and nothing else))
+# (no-join graphs with the VAE's optimizer step on the MAIN chain -- C4: step k's N*B-row encoder launch, late on its side branch,
+# reads the weights step k+1's optimizer step rewrites ~280 us later, and the main chain's first edge from that branch is the
+# wait for the action draws BEHIND that optimizer step.  1: an event behind the encoder launch, waited for in front of the
+# optimizer step; 0 (lab): unordered, as the second session's graphs were)
+VAE_WAR_EDGE = P.knob("OSRL_VAE_WAR_EDGE", "actor", "no-join graphs, VAE Adam on the main chain: ordered behind the previous step's "
+                      "N*B-row encoder launch by an edge to that step's actor Adam (actor) / to the VAE Adam itself (vae) / by "
+                      "timing slack (0, lab)")
 VAE_ADAM_EDGE = P.knob("OSRL_VAE_ADAM_EDGE", "actor", "no-join graphs, VAE Adam on the side branch: its edge to the main chain "
                        "in front of the actor group's Adam (actor) / at the head of the next step (next) / none (0, lab)")
 # (lab, no-join graphs: the actor group's dW + Adam of step k at the head of step k+1's side branch instead of the tail of
@@ -70,6 +77,7 @@ class CPQEngine:
         self._polyak_pending = False
         self._ev_prologue = None    # (pipelined graphs, plan.pipe_no_join: event behind the next step's prologue)
         self._ev_vae_adam = None    # (... and behind this step's VAE Adam where that runs on the side branch)
+        self._ev_enc_ood = None     # (... and behind this step's N*B-row encoder launch where the VAE Adam runs on the main chain)
         self._dual_pending = False  # (this step's dual step is still to be issued by the next step of the graph)
         nq, nqc = m.num_q, m.num_qc
         c_hidden = [int(l.out_features) for l in m.cost_critic_old.q_nets[0] if isinstance(l, torch.nn.Linear)][:-1]
@@ -350,6 +358,9 @@ class CPQEngine:
                 self.p_vae.launch()
                 self._pr("vae_dw", 1)
             else:
+                if carried is not None and carried._ev_enc_ood is not None:  # (OSRL_VAE_WAR_EDGE=vae)
+                    par.wait(carried._ev_enc_ood)  # (the previous step's last reader of the weights this step rewrites)
+                    carried._ev_enc_ood = None
                 self._optim("vae", self.p_vae, 0.0)
             ev_vae = torch.cuda.Event() if par.enabled else None
             if ev_vae is not None:
@@ -483,6 +494,8 @@ class CPQEngine:
             self.r_enc_ood.forward(self.obs, self.sampled, map0=L.MAP_MOD, div0=B, tail=G.vae_kl_tail(Lz, self.kl),
                                    share_k16=self.pre_enc)
             self._pr("enc_ood", 1)
+            if no_join and nxt is not None and VAE_WAR_EDGE != "0" and not (self.plan.vae_adam_side and not self.p_vae.can_fuse_adam()):
+                self._ev_enc_ood = par.mark(0)  # (the next step's VAE Adam, on the main chain, rewrites what this launch read)
             kl_on_side = dp is not None and par.enabled and DP_SIDE_COLL
             if kl_on_side:
                 # the batch-GLOBAL quantile (cpq.py:183 over all world * N * B values): gather, selection and masked mean
@@ -560,6 +573,9 @@ class CPQEngine:
             if self._ev_vae_adam is not None and (VAE_ADAM_EDGE == "actor" or not carry):
                 par.wait(self._ev_vae_adam)
                 self._ev_vae_adam = None
+            if self._ev_enc_ood is not None and (VAE_WAR_EDGE == "actor" or not carry):
+                par.wait(self._ev_enc_ood)
+                self._ev_enc_ood = None
             if carry and PIPE_ACTOR_SIDE:
                 self._actor_pending = True  # (the next step issues it on its side branch, behind its fork)
             else:
