@@ -76,6 +76,11 @@ class CPQEngine:
         self._actor_pending = False
         self._polyak_pending = False
         self._ev_prologue = None    # (pipelined graphs, plan.pipe_no_join: event behind the next step's prologue)
+        # (tests/test_gpu_pipeline.py test_unjoined_graphs_are_ordered_by_edges_not_by_timing: a spin kernel of this many
+        # cycles on the side branch in front of its second half -- VAE Adam / N*B-row encoder launch -- of every step)
+        self._stress_spin = int(P.knob("OSRL_STRESS_SPIN_CYCLES", "0", "tests: spin kernel (cycles) in front of the side branch's second half"))
+        self._stress_at = P.knob("OSRL_STRESS_SPIN_AT", "second", "tests: ... (second) / at the head of the side branch (head) / at the "
+                                 "head of the main chain (main)")
         self._ev_vae_adam = None    # (... and behind this step's VAE Adam where that runs on the side branch)
         self._ev_enc_ood = None     # (... and behind this step's N*B-row encoder launch where the VAE Adam runs on the main chain)
         self._dual_pending = False  # (this step's dual step is still to be issued by the next step of the graph)
@@ -310,6 +315,8 @@ class CPQEngine:
         # step k+1's side branch, right behind the fork -- the one place of the side branch that already has an edge from
         # the END of step k's main chain (so both halves of the logged cost loss are there) without a new mid-chain edge.
         no_join = self.plan.pipe_no_join and par.enabled and dp is None
+        # (read per capture, not per process: the ordering test builds graphs with and without these edges)
+        VAE_ADAM_EDGE, VAE_WAR_EDGE = P.knob("OSRL_VAE_ADAM_EDGE", "actor"), P.knob("OSRL_VAE_WAR_EDGE", "actor")
         carried = prev if (no_join and prev is not None and prev._dual_pending) else None
         self._ev_prologue, self._prologue_covered = None, False
         if carried is not None and carried._ev_prologue is not None:
@@ -318,6 +325,8 @@ class CPQEngine:
             par.wait(carried._ev_vae_adam)  # (this step's VAE phase reads what that optimizer step wrote)
         self._ev_vae_adam = None
         par.fork(0)
+        if self._stress_spin and par.enabled and self._stress_at == "main":
+            torch.cuda._sleep(self._stress_spin)  # (tests: the main chain arrives late)
         # ---- main: vae_loss  (cpq.py:125-135)
         sd = self.seeds
         if self.vae_ns is not None:  # five all-CU layer launches instead of the four fused ones (same buffers)
@@ -369,6 +378,8 @@ class CPQEngine:
         # ---- side branch: the actor forwards + heads, the target cost critics on the N*B rows (beside the VAE phase,
         # where the capped tile loop disturbs the chain least), then the critic phase
         with par.on(0):
+            if self._stress_spin and par.enabled and self._stress_at == "head":
+                torch.cuda._sleep(self._stress_spin)  # (tests: the side branch arrives late)
             if carried is not None and carried._polyak_pending:
                 # (plan.ood_rows in a no-join graph: the cost critics' target update of the previous step -- behind its last
                 # reader, the forward on the selected rows at that step's side-branch tail, and behind its main chain's
@@ -483,6 +494,8 @@ class CPQEngine:
         with par.on(0):
             if ev_vae is not None:
                 par.side[0].wait_event(ev_vae)
+            if self._stress_spin and par.enabled and self._stress_at == "second":
+                torch.cuda._sleep(self._stress_spin)  # (tests: this branch's second half arrives LATE; results must not move)
             if dp is None and par.enabled and self.plan.vae_adam_side and not self.p_vae.can_fuse_adam():
                 self._update("vae", 0.0)  # (engine/plan.py vae_adam_side: off the main chain, in front of its only reader)
                 if no_join and nxt is not None and VAE_ADAM_EDGE != "0":

@@ -146,6 +146,73 @@ def test_unjoined_pipelined_steps_equal_one_step_graph_replays(name, spg, total,
         assert many[s] == [ref_stats[s - 1][k] for k in e_b.st.keys], f"read_stats_many, step {s}"
 
 
+def _spin_cycles(us):
+    """Cycles of torch.cuda._sleep's spin kernel for ~``us`` microseconds on this device (calibrated here)."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    a.record()
+    torch.cuda._sleep(2_000_000)
+    b.record()
+    torch.cuda.synchronize()
+    return max(1000, int(2_000_000 * us / (a.elapsed_time(b) * 1e3)))
+
+
+@pytest.mark.parametrize("name,edge,at", [("c2", "OSRL_VAE_ADAM_EDGE", "second"), ("c4", "OSRL_VAE_WAR_EDGE", "second"),
+                                          ("c2", None, "head"), ("c4", None, "head"), ("c2", None, "main"), ("c4", None, "main")])
+def test_unjoined_graphs_are_ordered_by_edges_not_by_timing(name, edge, at, monkeypatch):
+    """The steps of a no-join graph overlap across their boundary, so every cross-queue dependency between step k's side
+    branch and step k+1's main chain needs a graph EDGE -- two of them had none until round 6's third session and were
+    ordered by ~100-280 us of timing slack: C2's VAE Adam on the side branch -> the next step's VAE phase (RAW on the VAE's
+    weights, WAR on its gradient slabs), and C4's N*B-row encoder launch at the tail of the side branch -> the next step's
+    VAE Adam on the main chain (WAR on the weights).  Here the side branch's second half of EVERY step is held back by a
+    ~600 us spin kernel (longer than a step): with the edges the pipelined graph still gives the one-step graph's bits --
+    parameters, moments, targets, ``log_alpha``, every step's statistics -- and, as the control that the delay reaches the
+    hazard, the same graph built WITHOUT the edge (lab switch) does not.  The same delay at the head of the side branch and
+    at the head of the main chain (no hazard known there, no control): same bits."""
+    m_a, e_a = _bench(name)
+    total, spg = 6, 3
+    for _ in range(total):
+        e_a.step_replay(True)
+    torch.cuda.synchronize()
+    ref = _state(m_a, e_a)
+    ref_stats = [e_a.st.read_stats(s) for s in range(1, total + 1)]
+    del m_a, e_a
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("OSRL_LAB", "1")
+    monkeypatch.setenv("OSRL_STRESS_SPIN_CYCLES", str(_spin_cycles(600.0)))
+    monkeypatch.setenv("OSRL_STRESS_SPIN_AT", at)
+
+    def run():
+        m_b, e_b = _bench(name)
+        assert e_b.plan.pipe_no_join and e_b._stress_spin > 0
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        e_b.steps_replay(total, steps_per_graph=spg)  # (capture + first replays)
+        torch.cuda.synchronize()
+        got, stats = _state(m_b, e_b), [e_b.st.read_stats(s) for s in range(1, total + 1)]
+        t0.record()
+        e_b.steps_replay(spg, steps_per_graph=spg)
+        t1.record()
+        torch.cuda.synchronize()
+        return got, stats, t0.elapsed_time(t1) * 1e3 / spg
+
+    got, stats, us = run()
+    assert us > 500.0, f"the spin kernel is not in the graph ({us:.0f} us per step)"
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), f"{name}: {k} moves when the side branch is late (max |d| = {(ref[k] - got[k]).abs().max().item():.3e})"
+    for s in range(total):
+        for k, v in ref_stats[s].items():
+            assert stats[s][k] == v, f"{name}: statistic {k} of step {s + 1} moves when the side branch is late: {stats[s][k]} vs {v}"
+    if edge is None:
+        return
+    # control: without the edge the same delay changes the result
+    monkeypatch.setenv(edge, "0")
+    got0, stats0, _ = run()
+    same = all(torch.equal(ref[k], got0[k]) for k in ref) and all(stats0[s][k] == v for s in range(total) for k, v in ref_stats[s].items())
+    assert not same, f"{name}: the un-edged graph gives the same bits under the delay -- the test does not reach the hazard"
+
+
 def test_steps_replay_follows_the_plan():
     """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 20 at C2's shape, 8 at C4's, neither
     joined inside a graph) and leaves the engine n steps further either way."""
