@@ -555,18 +555,18 @@ def roofline(eng, cfg_name="c2"):
            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
            "frac_is": ("in-run: the launch inside the REPLAYED one-step graph, bracketed by device-side 100 MHz stamps on its own "
                        "stream (in_graph_us; cross-check: the rocprofv3 --kernel-trace average of the same kernel over the one-step "
-                       "graph, profiles/r6b_bench_kernel_stats_c2_1step.csv; over the 20-step graph the timed region replays the "
-                       "profiler's average is ~7 % longer, r6b_bench_kernel_stats_c2.csv, while the un-profiled start stamps of "
-                       "that graph, r6b_trace_unprofiled_c2.txt, bound it by <= 96 us: rocprofv3 shifts how the two queues line "
-                       "up).  'Dominant' is PER LAUNCH: kernel = the single launch with the largest in-step duration; by TOTAL "
+                       "graph, 106.8 us in profiles/r6c_bench_kernel_stats_c2_1step.csv; over the 20-step graph the timed region replays "
+                       "the profiler's average is 99.9 us, r6c_bench_kernel_stats_c2.csv, and the un-profiled start stamps of that "
+                       "graph, r6c_trace_unprofiled_c2.txt, bound it by <= 92 us: how the two queues line up differs between the "
+                       "graphs and under rocprofv3).  'Dominant' is PER LAUNCH: kernel = the single launch with the largest in-step duration; by TOTAL "
                        "time per step the top symbol is another one (top_by_total)" if r.get("in_step_how") == "graph" else
                        "in-run (eagerly issued two-stream step body, HIP events)") if have_run else
                       "isolated (N > 1: no in-step probe)",
            # the symbol with the largest TOTAL time per step in the rocprofv3 --kernel-trace --stats summary of this command
-           # (profiles/r6b_bench_kernel_stats_c2.csv): three launches per step of the 16-row paired forward (actor trunks,
-           # critic-phase and cost-phase forwards), ~105 us per step between them at MFMA-busy 0.28 (profiles/r6_pmc_c2.json)
+           # (profiles/r6c_bench_kernel_stats_c2.csv): three launches per step of the 16-row paired forward (actor trunks,
+           # critic-phase and cost-phase forwards), ~127 us per step between them at MFMA-busy 0.28 (profiles/r6_pmc_c2.json)
            "top_by_total": {"symbol": "mlp_fwd2_kernel_p<1, 2, 8>", "launches_per_step": 3,
-                            "source": "static: profiles/r6b_bench_kernel_stats_c2.csv"} if cfg_name == "c2" else None,
+                            "source": "static: profiles/r6c_bench_kernel_stats_c2.csv"} if cfg_name == "c2" else None,
            "isolated_achieved": round(ach_iso, 3), "isolated_frac": round(ach_iso / PEAK_FP32_TFLOPS, 4),
            # what a loop of nothing but independent v_mfma_f32_16x16x4_f32 sustains on all 256 CUs (one / two waves per SIMD):
            # the nominal peak above assumes 32 cycles per instruction, the chip delivers 37-41.  Reported beside `peak`, never
