@@ -123,10 +123,12 @@ def cpq_plan(od: int, ad: int, B: int, vae_hidden: int, N: int, seeds: bool = Tr
     #      phase 2411-2417 at 4 steps per graph against 2330-2360 joined, 2361-2368 at one step per graph, 2358-2366 with "head": +2 %.
     # Steps per graph under the no-join plans (a replay boundary is the one full join left; gpurun_out/r6nj6, r6nj7): C2 at
     # K = 300 2358-2373 (5) / 2355-2378 (10) / 2390-2400 (20); on the driver's K = 20 command, six alternating runs, medians 2362
-    # (5) / 2383 (10) / 2390 (20: the 20 timed steps are ONE replay) -> 20.  C4 2399-2404 (2) / 2408-2436 (4) / 2423-2443 (8) -> 8.
+    # (5) / 2383 (10) / 2390 (20: the 20 timed steps are ONE replay) -> 20.  C4 2399-2404 (2) / 2408-2436 (4) / 2423-2443 (8) -> 8; under
+    # the third session's plan (ood_rows, the ordering edges; gpurun_out/r6spg2, three alternating rounds at K = 320): 2480-2488 (8) /
+    # 2497-2522 (12) / 2505-2540 (16) / 2526-2535 (20) -> 20 there too.
     side_long = not head_tails and B >= 1024
     spg = int(knob("OSRL_PIPE_STEPS", "0", "train steps per pipelined graph (0 = by rule)")) or \
-        (20 if (head_tails and B >= 1024) else 8 if side_long else 1)
+        (20 if B >= 1024 else 1)
     dual = knob("OSRL_PIPE_DUAL", "auto", "pipelined steps: the dual step behind the join (main) / on the side branch behind the "
                 "OOD statistic (side) / at the head of the NEXT step's side branch, no join between the steps of a graph (next)")
     pro = knob("OSRL_PIPE_PROLOGUE", "auto", "pipelined steps: the next step's prologue behind the OOD statistic (side) / in "
@@ -220,7 +222,7 @@ PINNED = {
                    steps_per_graph=20, ood_rows=True, ood_share=True, pipe_no_join=True, pipe_prologue="head")),
     "c4": (cpq_plan, dict(od=17, ad=6, B=2048, vae_hidden=400, N=10),
            CPQPlan(head_tails=False, vae_dw_tile=5, vae_dw_splits=3, small_dw=True, ood_tile=80, vae_ns=True, vae_adam_side=False,
-                   steps_per_graph=8, ood_rows=True, ood_share=True, pipe_no_join=True, pipe_prologue="critic")),
+                   steps_per_graph=20, ood_rows=True, ood_share=True, pipe_no_join=True, pipe_prologue="critic")),
     "c3": (bcql_plan, dict(od=33, ad=8, B=4096, vae_hidden=400, N=10),
            BCQLPlan(vae_dw_tile=5, target_tile=80, vae_ns=False, dw_splits=6, steps_per_graph=10)),
     "cpq_small": (cpq_plan, dict(od=5, ad=2, B=16, vae_hidden=48, N=4, c_hidden=(32, 32)),

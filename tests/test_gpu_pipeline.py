@@ -214,7 +214,7 @@ def test_unjoined_graphs_are_ordered_by_edges_not_by_timing(name, edge, at, monk
 
 
 def test_steps_replay_follows_the_plan():
-    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 20 at C2's shape, 8 at C4's, neither
+    """``engine.steps_replay(n)`` takes the plan's steps per graph (engine/plan.py: 20 at C2's and C4's shape, neither
     joined inside a graph) and leaves the engine n steps further either way."""
     m, e = _bench("c2")
     assert e.plan.steps_per_graph == 20 and e.plan.pipe_no_join and e.plan.pipe_prologue == "head"
@@ -222,10 +222,10 @@ def test_steps_replay_follows_the_plan():
     torch.cuda.synchronize()
     assert e._pipe is not None and e._pipe.n == 20 and e.st.device_step() == 45
     m4, e4 = _bench("c4")
-    assert e4.plan.steps_per_graph == 8 and e4.plan.pipe_no_join and e4.plan.pipe_prologue == "critic"
-    e4.steps_replay(19)
+    assert e4.plan.steps_per_graph == 20 and e4.plan.pipe_no_join and e4.plan.pipe_prologue == "critic"
+    e4.steps_replay(43)
     torch.cuda.synchronize()
-    assert e4._pipe is not None and e4._pipe.n == 8 and e4.st.device_step() == 19
+    assert e4._pipe is not None and e4._pipe.n == 20 and e4.st.device_step() == 43
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])
