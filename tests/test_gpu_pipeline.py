@@ -204,8 +204,8 @@ def test_unjoined_graphs_are_ordered_by_edges_not_by_timing(name, edge, at, monk
     for s in range(total):
         for k, v in ref_stats[s].items():
             assert stats[s][k] == v, f"{name}: statistic {k} of step {s + 1} moves when the side branch is late: {stats[s][k]} vs {v}"
-    if edge is None:
-        return
+    if edge is None or os.environ.get("OSRL_FUSE_DW_ADAM", "auto") != "auto":
+        return  # (with the fused dW + Adam launches forced, the VAE's Adam sits on the main chain: no hazard to reach at C2)
     # control: without the edge the same delay changes the result
     monkeypatch.setenv(edge, "0")
     got0, stats0, _ = run()
