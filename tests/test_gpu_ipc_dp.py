@@ -124,15 +124,18 @@ def _sharded_vs_concatenated(algo, W):
     t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
     # single device, concatenated batch
     batch = make_batch(c)
-    m1, tr1, lg1 = build_gpu(c)
-    for s in range(c.steps):
-        if algo == "bc":
-            tr1.train_one_step(*[t(batch[k]) for k in keys])
-        else:
-            tr1.train_one_step(*[t(batch[k]) for k in keys], noise={k: t(v) for k, v in make_noise(c, s).items()})
-    torch.cuda.synchronize()
-    want = {k: v.detach().cpu() for k, v in m1.state_dict().items()}
-    want_stats = dict(m1._engine.st.read_stats())
+
+    def reference():
+        m1, tr1, lg1 = build_gpu(c)
+        for s in range(c.steps):
+            if algo == "bc":
+                tr1.train_one_step(*[t(batch[k]) for k in keys])
+            else:
+                tr1.train_one_step(*[t(batch[k]) for k in keys], noise={k: t(v) for k, v in make_noise(c, s).items()})
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu() for k, v in m1.state_dict().items()}, dict(m1._engine.st.read_stats())
+
+    want, want_stats = reference()
     with tempfile.TemporaryDirectory() as d:
         import time
         ctx = mp.spawn(_worker, args=(W, _free_port(), algo, d), nprocs=W, join=False)
@@ -158,7 +161,13 @@ def _sharded_vs_concatenated(algo, W):
                 bad.append(f"{algo} rank {r} statistic {k}: {res[r]['stats'][k]} vs {v}")
     if bad:
         agree = all(torch.equal(v, res[r]["params"][k]) for r in range(1, W) for k, v in res[0]["params"].items())
-        return "\n".join(bad[:40]) + f"\n({len(bad)} gates missed; replicas bit-identical among themselves: {agree}; " \
+        # which side moved?  the single-device reference once more, in this process, against the one the gates used
+        want2, _ = reference()
+        ref_moved = [k for k, v in want.items() if not torch.equal(v, want2[k])]
+        ranks_vs_2 = max((res[0]["params"][k] - v).abs().max().item() for k, v in want2.items() if v.dtype != torch.bool)
+        bad.append(f"single-device reference recomputed: {len(ref_moved)} tensors differ from the first one {ref_moved[:6]}; "
+                   f"ranks against the recomputed reference: max {ranks_vs_2:.3e}")
+        return "\n".join(bad[:40] + bad[-1:]) + f"\n({len(bad) - 1} gates missed; replicas bit-identical among themselves: {agree}; " \
             f"exchanges done per rank: {[res[r]['exchanges'] for r in range(W)]})"
     # replicas bit-identical to each other (the sum runs in rank order on every rank)
     for r in range(1, W):
