@@ -839,8 +839,43 @@ def graph_capture(g: "torch.cuda.CUDAGraph"):
     group has such a thread: the group's watchdog polls the events of collectives still in flight (``hipEventQuery``), e.g.
     those of the warm-up pass a data-parallel engine runs right before it captures its step.  Seen once in four runs of the
     GPU suite: "operation not permitted when stream is capturing" thrown on the watchdog thread, which aborts the process.
-    Thread-local mode restricts the check to the capturing thread, which is the one that must not make such calls."""
-    return torch.cuda.graph(g, capture_error_mode="thread_local")
+    Thread-local mode restricts the check to the capturing thread, which is the one that must not make such calls.
+
+    ... and with Python's cyclic garbage collector OFF for the length of the capture (round 6, third session).  ``torch.cuda.graph``
+    collects once when it is entered; a step body then creates enough objects (events, ctypes descriptors) to start an AUTOMATIC
+    collection in the middle of the capture, and when that collection finds an engine of an earlier owner -- engines, their
+    pipelines and their CUDAGraphs hold each other in cycles -- it destroys a hipGraph / its streams on the capturing thread:
+    "operation not permitted when stream is capturing" inside a destructor, i.e. ``abort()``.  Deterministic for a given sequence
+    of allocations: one pytest command line aborted 5 times of 5 in its 25th test ("Fatal Python error: Aborted ...
+    Garbage-collecting" under ``prologue`` inside ``PipelinedSteps._capture_once``) while the same tests under ``-v`` and the
+    full suite never did (DESIGN_LOG)."""
+    return _GraphCapture(g)
+
+
+class _GraphCapture:
+    def __init__(self, g):
+        self.g, self.ctx, self.gc_was = g, None, False
+
+    def __enter__(self):
+        import gc
+        self.gc_was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            self.ctx = torch.cuda.graph(self.g, capture_error_mode="thread_local")
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.gc_was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.gc_was:
+                gc.enable()
 
 
 # A two-branch hipGraph runs its side branch on a stream the runtime creates when the graph is instantiated, and the
