@@ -224,7 +224,22 @@ def test_every_graph_capture_is_thread_local():
         for f in files:
             if f.endswith(".py"):
                 src = open(os.path.join(dp_, f)).read()
-                calls += [(f, m.group(0)) for m in re.finditer(r"(with|return) +torch\.cuda\.graph\([^\n]*", src)]
+                calls += [(f, m.group(0)) for m in re.finditer(r"(with|return|=) +torch\.cuda\.graph\([^\n]*", src)]
     assert len(calls) == 1 and calls[0][0] == "core.py" and 'capture_error_mode="thread_local"' in calls[0][1], calls
     from osrl_amd.engine import core
-    assert 'capture_error_mode="thread_local"' in inspect.getsource(core.graph_capture)
+    src = inspect.getsource(core._GraphCapture)
+    assert 'capture_error_mode="thread_local"' in src and "_GraphCapture(g)" in inspect.getsource(core.graph_capture)
+    # ... and with the cyclic garbage collector off until the capture has ended (round 6: an automatic collection inside a
+    # capture destroyed an earlier engine's hipGraph on the capturing thread -- abort()); the switch is put back either way
+    assert "gc.disable()" in src and src.count("gc.enable()") >= 2
+    import gc
+    was = gc.isenabled()
+
+    class _G:  # (no device here: entering the capture raises; the collector must be back on afterwards)
+        pass
+    try:
+        with core.graph_capture(_G()):
+            pass
+    except BaseException:
+        pass
+    assert gc.isenabled() == was
